@@ -1,0 +1,201 @@
+/*
+ * vidtok_amd.h -- C-ABI of libvidtok_amd.so: the MI355X (gfx950) kernels behind the VidTok
+ * causal tokenizer's encode / decode path.
+ *
+ * The reference (microsoft/VidTok) has no FFI of its own: every operator on the hot path is a
+ * torch.nn call.  Each entry point below replaces the ATen operator(s)
+ * the reference reaches from the cited file:line, so a maintainer binds them with ctypes
+ * (INTEGRATION.md shows the stub) from the Python modules that mirror the reference classes.
+ *
+ * Conventions
+ *   - plain C: pointers are DEVICE pointers unless said otherwise, sizes are element counts;
+ *   - every function returns 0 on success, a negative vt_status otherwise; vt_last_error()
+ *     returns a thread-local message; nothing throws across the boundary;
+ *   - the library never allocates or frees activation memory, never synchronises the stream
+ *     and is hipGraph-capture safe (all launches go to the stream argument);
+ *   - activation layout is NDHWC ([B][T][H][W][C], C innermost, C stored padded to `ld*`
+ *     elements); the public tensors of the reference API are NCTHW fp32 and are converted at
+ *     the two ends by vt_ncthw_to_ndhwc / the NCTHW epilogue of vt_conv;
+ *   - `dtype` selects the arithmetic: VT_F32 = fp32 storage + fp32-input MFMA
+ *     (v_mfma_f32_32x32x2_f32, bit-wise an fmaf chain), VT_BF16 = bf16 storage + bf16 MFMA
+ *     (v_mfma_f32_32x32x16_bf16) with fp32 accumulation.  Statistics, softmax, the regularizers
+ *     and all epilogue arithmetic are fp32 in both modes.
+ */
+#ifndef VIDTOK_AMD_H
+#define VIDTOK_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* vt_stream;          /* hipStream_t */
+
+typedef enum vt_status {
+  VT_OK = 0,
+  VT_ERR_ARG = -1,                /* bad / unsupported argument (message in vt_last_error) */
+  VT_ERR_HIP = -2,                /* a HIP runtime call failed */
+  VT_ERR_UNSUPPORTED = -3
+} vt_status;
+
+typedef enum vt_dtype { VT_F32 = 0, VT_BF16 = 1, VT_I32 = 2 } vt_dtype;
+
+/* time-axis treatment of taps that fall before the first frame of the input */
+typedef enum vt_tmode {
+  VT_TPAD_ZERO = 0,       /* v1.0 CausalConv{1,3}d, pad_mode "constant"  (model_3dcausal.py:156-159,193-197) */
+  VT_TPAD_REPLICATE = 1,  /* v1.1 first chunk: first frame repeated        (model_3dcausal_v1_1.py:160-163,217-220) */
+  VT_TPAD_CACHE = 2       /* v1.1 later chunks: last frames of the cache   (model_3dcausal_v1_1.py:164-171,221-228) */
+} vt_tmode;
+
+typedef enum vt_resmode {
+  VT_RES_NONE = 0,
+  VT_RES_ADD = 1,         /* y = conv + bias + res          (ResnetBlock x + h, model_3dcausal.py:337,424,499,118) */
+  VT_RES_MIX = 2          /* y = a*res + (1-a)*(conv+bias), a = sigmoid(*mix_factor)
+                             (TimeDown/UpsampleResCausal2x, model_3dcausal.py:248-252,268-273) */
+} vt_resmode;
+
+typedef enum vt_layout { VT_NDHWC = 0, VT_NCTHW = 1 } vt_layout;
+
+const char* vt_last_error(void);
+/* returns a version integer; also a cheap "is the library loadable" probe */
+int vt_version(void);
+/* number of bytes of dynamic LDS the biggest conv variant asks for (diagnostic) */
+int vt_conv_max_lds_bytes(void);
+
+/* ------------------------------------------------------------------------------------------
+ * vt_conv -- implicit-GEMM convolution on NDHWC, M = B*To*Ho*Wo pixels x N = Cout x K = taps*Cin.
+ * One entry point covers every convolution of the path:
+ *   nn.Conv2d 3x3 s1 p1      ResnetBlock.conv1/conv2            model_3dcausal.py:296,301
+ *   nn.Conv2d 3x3 s1 p1 after nearest x2   Upsample               model_3dcausal.py:208-212  (ups_s=1)
+ *   nn.Conv2d 3x3 s2 p0 after F.pad(0,1,0,1)  Downsample          model_3dcausal.py:223-227
+ *   nn.Conv2d 1x1            nin_shortcut                       model_3dcausal.py:306
+ *   nn.Conv1d k3 causal      CausalConv1d                       model_3dcausal.py:144-159
+ *   nn.Conv3d 3x3x3 causal   CausalConv3d (stride 1 or (2,1,1)) model_3dcausal.py:162-197
+ *   nn.Conv3d 1x1x1          AttnBlockWrapper q/k/v/proj_out    model_3dcausal.py:124-127
+ *   nearest x2 in T folded   TimeUpsampleResCausal2x            model_3dcausal.py:267-273  (ups_t=1)
+ * and, with KT=KH=KW=1 and nbatch>1, the batched GEMMs of the attention block
+ * (F.scaled_dot_product_attention, model_3dcausal.py:140).
+ *
+ * Tap (kt,kh,kw) of output (b,to,ho,wo) reads the *virtual* input position
+ *   tv = to*st + kt - pt,  hv = ho*sh + kh - ph,  wv = wo*sw + kw - pw
+ * in a virtual input of size (Ti<<ups_t, Hi<<ups_s, Wi<<ups_s); the stored element is
+ * (tv>>ups_t, hv>>ups_s, wv>>ups_s).  Spatial positions outside the virtual extent read 0;
+ * tv<0 follows `tmode` (cache: frame ncache+tv of `cache`, shape [B][ncache][Hi][Wi][Cin]);
+ * tv beyond the end reads 0.
+ * Weights are pre-packed row-major [Cout][ldw], k = ((kt*KH+kh)*KW+kw)*Cin + c (see
+ * vidtok_amd/packing.py), in the arithmetic dtype.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct vt_conv_desc {
+  const void* x;            /* input  [B][Ti][Hi][Wi][Cin]     (dtype)                        */
+  const void* w;            /* packed weights [Cout][ldw]       (dtype)                        */
+  const float* bias;        /* [Cout] fp32 or NULL                                             */
+  void* y;                  /* output, out_dtype; NDHWC [M][ldy] or NCTHW (see out_layout)     */
+  const void* res;          /* residual / mix operand, out_dtype, [B][Tr][Ho][Wo][ldr] or NULL */
+  const void* cache;        /* time cache [B][ncache][Hi][Wi][Cin] (dtype) or NULL             */
+  const float* mix_factor;  /* device scalar; alpha = sigmoid(*mix_factor) for VT_RES_MIX      */
+  int32_t B, Ti, Hi, Wi, Cin;
+  int32_t To, Ho, Wo, Cout;
+  int32_t ldw;              /* row stride of w in elements (>= KT*KH*KW*Cin, multiple of 16 B) */
+  int32_t ldy;              /* channel stride of y for NDHWC                                   */
+  int32_t KT, KH, KW;
+  int32_t st, sh, sw;
+  int32_t pt, ph, pw;
+  int32_t tmode, ncache;
+  int32_t ups_t, ups_s;
+  int32_t res_mode;         /* vt_resmode                                                      */
+  int32_t res_tshift;       /* res time index = to >> res_tshift                               */
+  int32_t Tr, ldr;
+  int32_t out_layout;       /* vt_layout; VT_NCTHW needs out_dtype == VT_F32                   */
+  int32_t t_trim;           /* NCTHW only: drop the first t_trim output frames                 */
+  int32_t dtype;            /* arithmetic / input / weight dtype                               */
+  int32_t out_dtype;        /* dtype or VT_F32                                                 */
+  int32_t nbatch;           /* >=1: independent problems along grid.z                          */
+  int64_t xs_z, ws_z, ys_z, rs_z;   /* element strides between problems                       */
+} vt_conv_desc;
+
+int vt_conv(const vt_conv_desc* d, vt_stream stream);
+
+/* ------------------------------------------------------------------------------------------
+ * vt_layernorm_act -- per-position LayerNorm over C (eps inside the sqrt, biased variance,
+ * affine) optionally followed by SiLU x*sigmoid(x).
+ * Replaces LayerNorm wrapper + nonlinearity: model_3dcausal.py:62-80, 26-27 (every norm site of
+ * ResnetBlock / ResnetCausalBlock / ResnetCausalBlock1D / AttnBlock / norm_out).
+ * x: [M][ldx] in `in_dtype`, y: [M][ldy] in `out_dtype`; gamma, beta fp32 [C].
+ * ---------------------------------------------------------------------------------------- */
+int vt_layernorm_act(const void* x, int in_dtype, int64_t ldx, void* y, int out_dtype, int64_t ldy,
+                     const float* gamma, const float* beta, int64_t M, int32_t C, float eps,
+                     int32_t silu, vt_stream stream);
+
+/* row softmax(scale * s) over the last dim; s fp32 [rows][cols] -> p (out_dtype) [rows][ldp].
+ * The softmax inside F.scaled_dot_product_attention (model_3dcausal.py:140), scale = C^-0.5. */
+int vt_softmax_rows(const float* s, void* p, int out_dtype, int64_t rows, int32_t cols,
+                    int64_t ldp, float scale, vt_stream stream);
+
+/* ------------------------------------------------------------------------------------------
+ * layout conversion at the two ends of the path
+ * vt_ncthw_to_ndhwc: x fp32 NCTHW [B][C][T][H][W] -> y (out_dtype) [B][tpad+T][H][W][ldy],
+ *   channels C..ldy-1 zero-filled, the first `tpad` frames replicate frame 0
+ *   (EncoderCausal3DPadding.forward pad_at_dim(..., "replicate"), model_3dcausal.py:685-689,
+ *   v1.1 model_3dcausal_v1_1.py:755-760).
+ * vt_ndhwc_to_ncthw: x (in_dtype) [B][T][H][W][ldx] -> y fp32 [B][C][T-ttrim][H][W]
+ *   (DecoderCausal3DPadding.forward trim, model_3dcausal.py:883-885).
+ * ---------------------------------------------------------------------------------------- */
+int vt_ncthw_to_ndhwc(const float* x, void* y, int out_dtype, int32_t B, int32_t C, int32_t T,
+                      int32_t H, int32_t W, int32_t ldy, int32_t tpad, vt_stream stream);
+int vt_ndhwc_to_ncthw(const void* x, int in_dtype, float* y, int32_t B, int32_t C, int32_t T,
+                      int32_t H, int32_t W, int32_t ldx, int32_t ttrim, vt_stream stream);
+
+/* ------------------------------------------------------------------------------------------
+ * time resamplers (the non-conv branches)
+ * vt_time_avgpool3s2: y[to] = (xp[2to]+xp[2to+1]+xp[2to+2])/3 over the front-padded sequence
+ *   xp = [pad, x]; pad frame = 0 (tmode ZERO, v1.0 model_3dcausal.py:249-250), x[0]
+ *   (REPLICATE, v1.1 first chunk) or `cache` (one frame [B][1][H][W][C], v1.1 later chunks,
+ *   model_3dcausal_v1_1.py:293-300).  x [B][Ti][HW][C] -> y [B][Ti/2][HW][C], same dtype.
+ * vt_time_lerp2x: F.interpolate(scale (2,1,1), "trilinear", align_corners=False) along T of a
+ *   sequence of Ti frames -> 2*Ti frames (model_3dcausal_v1_1.py:327-341); fp32 arithmetic.
+ * ---------------------------------------------------------------------------------------- */
+int vt_time_avgpool3s2(const void* x, const void* cache, void* y, int dtype, int32_t B, int32_t Ti,
+                       int64_t HW, int32_t C, int32_t tmode, vt_stream stream);
+int vt_time_lerp2x(const void* x, void* y, int dtype, int32_t B, int32_t Ti, int64_t HWC,
+                   vt_stream stream);
+
+/* ------------------------------------------------------------------------------------------
+ * regularizers; all tensors NCTHW fp32 as in the reference API
+ * vt_kl_sample: h [B][2*zc][S] (S = T*H*W); mean,logvar = chunk(h,2,dim=1); logvar clamped to
+ *   [-30,20]; z = mean + exp(0.5*logvar)*noise (noise [B][zc][S] or NULL -> mode());
+ *   *kl_out = 0.5*sum(mean^2 + var - 1 - logvar) / B     (distributions.py:8-28,
+ *   regularizers.py:82-92; the reference draws `noise` on the host with torch.randn).
+ * vt_fsq_quantize: h [B][D][S], levels[D]; bound -> round-half-even -> codes z [B][D][S]
+ *   (values q/(L//2)) and int32 indices [B][S] (regularizers.py:153-178, 225-230).
+ * vt_fsq_indices_to_codes: indices [B][S] -> z [B][D][S] (regularizers.py:180-198).
+ * vt_fsq_aux_stats: the two entropies and the commitment term of FSQRegularizer.forward
+ *   (regularizers.py:231-246) for h [B][D][S]: out[0] = per-sample entropy (mean), out[1] =
+ *   codebook entropy of the batch-mean distribution, out[2] = commit loss.  `work` is a device
+ *   scratch of vt_fsq_aux_work_floats(...) floats.
+ * ---------------------------------------------------------------------------------------- */
+/* host-only helper: writes half_l[D], offset[D], shift[D], basis[D] (as floats) exactly as the
+ * FSQ kernels use them (FSQRegularizer.bound constants, regularizers.py:153-158) -- no GPU needed. */
+int vt_fsq_consts(const int32_t* levels_host, int32_t D, float* out_host);
+int vt_kl_sample(const float* h, const float* noise, float* z, float* kl_out, int32_t B,
+                 int32_t zc, int64_t S, vt_stream stream);
+int vt_fsq_quantize(const float* h, float* z, int32_t* indices, const int32_t* levels_host,
+                    int32_t D, int32_t B, int64_t S, vt_stream stream);
+int vt_fsq_indices_to_codes(const int32_t* indices, float* z, const int32_t* levels_host,
+                            int32_t D, int32_t B, int64_t S, vt_stream stream);
+int64_t vt_fsq_aux_work_floats(const int32_t* levels_host, int32_t D, int32_t B, int64_t S);
+int vt_fsq_aux_stats(const float* h, const int32_t* levels_host, int32_t D, int32_t B, int64_t S,
+                     float inv_temperature, float* work, float* out3, vt_stream stream);
+
+/* copy `n` frames of `frame_elems` elements each: dst frame j <- src frame idx_host[j]
+ * (cache maintenance of the v1.1 chunked path, model_3dcausal_v1_1.py:172-176,230-234);
+ * src/dst are [B][Ts|Td][frame_elems] with the given batch strides, element size `esize`. */
+int vt_gather_frames(const void* src, void* dst, int32_t esize, int32_t B, int64_t frame_elems,
+                     int64_t src_bstride, int64_t dst_bstride, const int32_t* idx_host, int32_t n,
+                     vt_stream stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VIDTOK_AMD_H */

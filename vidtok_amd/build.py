@@ -1,0 +1,68 @@
+"""Build libvidtok_amd.so (gfx950) in-tree with hipcc -- no torch / cmake involved.
+
+`python -m vidtok_amd.build` or `vidtok_amd.build.build()`; hipcc cross-compiles without a GPU.
+The shared object lands next to this file (vidtok_amd/libvidtok_amd.so): git-ignored, but it
+travels with a gpurun snapshot.
+"""
+import hashlib
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libvidtok_amd.so")
+SOURCES = ["conv_igemm.hip", "pointwise.hip", "regularizers.hip", "error.cpp"]
+HEADERS = ["common.h", os.path.join("..", "..", "include", "vidtok_amd.h")]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+
+
+def _hipcc():
+    for c in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if c and os.path.exists(c):
+            return c
+    raise RuntimeError("hipcc not found (set HIPCC)")
+
+
+def _digest():
+    h = hashlib.sha256()
+    for f in SOURCES + HEADERS:
+        with open(os.path.join(CSRC, f), "rb") as fh:
+            h.update(fh.read())
+    h.update(" ".join(FLAGS).encode())
+    return h.hexdigest()
+
+
+def build(force: bool = False, verbose: bool = True) -> str:
+    stamp = LIB + ".stamp"
+    dig = _digest()
+    if not force and os.path.exists(LIB) and os.path.exists(stamp) and open(stamp).read() == dig:
+        return LIB
+    hipcc = _hipcc()
+    objdir = os.path.join(HERE, "build")
+    os.makedirs(objdir, exist_ok=True)
+    objs = []
+    procs = []
+    for src in SOURCES:
+        obj = os.path.join(objdir, os.path.splitext(src)[0] + ".o")
+        cmd = [hipcc, *FLAGS, "-x", "hip", "-c", os.path.join(CSRC, src), "-o", obj]
+        if verbose:
+            print("[vidtok_amd.build]", " ".join(cmd), flush=True)
+        procs.append((src, subprocess.Popen(cmd)))
+        objs.append(obj)
+    for src, p in procs:
+        if p.wait() != 0:
+            raise RuntimeError(f"hipcc failed on {src}")
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", LIB]
+    if verbose:
+        print("[vidtok_amd.build]", " ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    with open(stamp, "w") as f:
+        f.write(dig)
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)
+    print(LIB)

@@ -1,0 +1,467 @@
+// Implicit-GEMM convolution for NDHWC activations on gfx950 (MI355X) -- see include/vidtok_amd.h
+// (vt_conv) for the operator contract and the list of reference call sites it replaces.
+//
+// GEMM view:  Y[m][n] = sum_k  X_gather[m][k] * W[n][k],   m = output pixel (b,to,ho,wo),
+//             n = output channel, k = tap*Cin + c.
+//
+// Kernel structure (one workgroup = 256 threads = 4 wave64):
+//   * block tile BM pixels x BN channels, K step of 128 BYTES per row (BK = 64 bf16 / 32 fp32), so
+//     8 consecutive lanes fetch one full 128-B line of a pixel's channel vector (NDHWC keeps C
+//     innermost => coalesced) and of a weight row;
+//   * both operand tiles live in LDS as [row][BK] with a 16-B pad per row (row stride 144 B): the
+//     ds_write_b128 of the staging pass and the ds_read_b128 of the fragment pass are then
+//     bank-conflict free (9*row mod 16 is a bijection on every 16-lane service group);
+//   * global -> register -> LDS staging, LDS double-buffered, next K step's global loads are in
+//     flight while the MFMAs of the current step run (one barrier per K step);
+//   * MFMA 32x32 tiles with the operand roles SWAPPED: the weight fragment is the A operand
+//     (rows = n) and the pixel fragment the B operand (cols = m).  Every lane then owns one pixel
+//     and 4 *consecutive* output channels per accumulator quad, so the epilogue issues 16-B (fp32)
+//     / 8-B (bf16) vector stores into the NDHWC row instead of 16 scalar ones;
+//   * the K mapping inside a 16-B fragment is the same bijection for both operands, which is all
+//     an inner product needs: bf16 uses v_mfma_f32_32x32x16_bf16 (one 16-B read = one MFMA), fp32
+//     uses v_mfma_f32_32x32x2_f32 (one 16-B read feeds 4 MFMAs); fp32 results are bit-wise an
+//     fmaf chain (MI355X guide, "FP32-input MFMA");
+//   * padding, causal time padding (zero / replicate / cache), stride, and nearest-neighbour x2
+//     up-sampling in space or time are folded into the gather addresses: nothing is materialised;
+//   * epilogue: + bias, + residual or alpha-mix, dtype conversion, NDHWC vector store or
+//     NCTHW (fp32, with front time trim) store;
+//   * XCD-aware tile order: consecutive tiles of one XCD are neighbouring pixel tiles of the same
+//     channel tile, so halo rows and the weight slab are shared in that XCD's L2.
+#include "common.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kRowBytes = 128;     // bytes of K per tile row per step
+constexpr int kLdsRowBytes = 144;  // + 16 B pad
+
+struct ConvArgs {
+  const char* x;
+  const char* w;
+  const float* bias;
+  char* y;
+  const char* res;
+  const char* cache;
+  const float* mix_factor;
+  int B, Ti, Hi, Wi, Cin;
+  int To, Ho, Wo, Cout;
+  int ldw, ldy;
+  int KT, KH, KW;
+  int st, sh, sw;
+  int pt, ph, pw;
+  int tmode, ncache;
+  int ups_t, ups_s;
+  int res_mode, res_tshift, Tr, ldr;
+  int out_layout, t_trim;
+  int M, K, ntaps, nsteps;
+  int m_tiles, n_tiles;
+  long long xs_z, ws_z, ys_z, rs_z;
+};
+
+template <typename MT>
+__device__ __forceinline__ void mma_step(const u32x4& wfrag, const u32x4& xfrag, f32x16& acc);
+
+template <>
+__device__ __forceinline__ void mma_step<bf16_t>(const u32x4& wfrag, const u32x4& xfrag, f32x16& acc) {
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wfrag),
+                                                __builtin_bit_cast(bf16x8, xfrag), acc, 0, 0, 0);
+}
+template <>
+__device__ __forceinline__ void mma_step<float>(const u32x4& wfrag, const u32x4& xfrag, f32x16& acc) {
+#pragma unroll
+  for (int e = 0; e < 4; ++e)
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(wfrag[e]), __uint_as_float(xfrag[e]),
+                                               acc, 0, 0, 0);
+}
+
+// XCD-aware bijective remap of the linear block id (MI355X guide T1): block b runs on XCD b%8;
+// give every XCD a contiguous chunk of the tile sequence.
+__device__ __forceinline__ int xcd_remap(int bid, int nblk) {
+  const int xcd = bid & 7, loc = bid >> 3;
+  const int q = nblk >> 3, r = nblk & 7;
+  const int start = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return start + loc;
+}
+
+template <typename MT, typename TOut, int WAVES_M, int WAVES_N, int TM, int TN, bool FAST>
+__global__ __launch_bounds__(kThreads) void conv_igemm_kernel(const ConvArgs p) {
+  constexpr int VEC = 16 / (int)sizeof(MT);
+  constexpr int BK = kRowBytes / (int)sizeof(MT);
+  constexpr int BM = WAVES_M * TM * 32;
+  constexpr int BN = WAVES_N * TN * 32;
+  constexpr int A_VECS = BM * 8 / kThreads;
+  constexpr int B_VECS = BN * 8 / kThreads;
+  constexpr int A_BYTES = BM * kLdsRowBytes;
+  constexpr int STAGE_BYTES = (BM + BN) * kLdsRowBytes;
+  static_assert(WAVES_M * WAVES_N == 4, "4 waves per workgroup");
+  static_assert(A_VECS >= 1 && B_VECS >= 1, "tile too small");
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave % WAVES_M;
+  const int wn = wave / WAVES_M;
+
+  const int tile = xcd_remap(blockIdx.x, p.m_tiles * p.n_tiles);
+  const int nt = tile / p.m_tiles;
+  const int mt = tile - nt * p.m_tiles;
+  const int m_blk = mt * BM;
+  const int n_blk = nt * BN;
+
+  const long long z = blockIdx.z;
+  const MT* __restrict__ xg = reinterpret_cast<const MT*>(p.x) + z * p.xs_z;
+  const MT* __restrict__ wg = reinterpret_cast<const MT*>(p.w) + z * p.ws_z;
+  const MT* __restrict__ cg = reinterpret_cast<const MT*>(p.cache);
+
+  // ---- staging roles: this thread moves 16-B vector `kvec` of rows (tid>>3) + 32*i -----------
+  const int kvec = tid & 7;
+  const int srow = tid >> 3;
+
+  const int Hv = p.Hi << p.ups_s, Wv = p.Wi << p.ups_s;
+  const int Tv = p.Ti << p.ups_t;
+
+  int a_b[A_VECS], a_t0[A_VECS], a_h0[A_VECS], a_w0[A_VECS];
+#pragma unroll
+  for (int i = 0; i < A_VECS; ++i) {
+    const int m = m_blk + srow + 32 * i;
+    if (m < p.M) {
+      int wo = m % p.Wo;
+      int r = m / p.Wo;
+      int ho = r % p.Ho;
+      r /= p.Ho;
+      int to = r % p.To;
+      int b = r / p.To;
+      a_b[i] = b;
+      a_t0[i] = to * p.st - p.pt;
+      a_h0[i] = ho * p.sh - p.ph;
+      a_w0[i] = wo * p.sw - p.pw;
+    } else {
+      a_b[i] = -1;
+      a_t0[i] = a_h0[i] = a_w0[i] = 0;
+    }
+  }
+
+  u32x4 areg[A_VECS], breg[B_VECS];
+  const int cpb = FAST ? (p.Cin / BK) : 1;  // K steps per tap on the fast path
+  const int khw = p.KH * p.KW;
+
+  auto load_step = [&](int s) {
+    int tap, c;
+    if (FAST) {
+      tap = s / cpb;
+      c = (s - tap * cpb) * BK + kvec * VEC;
+    } else {
+      const int k = s * BK + kvec * VEC;
+      tap = k / p.Cin;
+      c = k - tap * p.Cin;
+    }
+    const bool kvalid = tap < p.ntaps;
+    const int kt = tap / khw;
+    const int r2 = tap - kt * khw;
+    const int kh = r2 / p.KW;
+    const int kw = r2 - kh * p.KW;
+#pragma unroll
+    for (int i = 0; i < A_VECS; ++i) {
+      u32x4 v = {0u, 0u, 0u, 0u};
+      int tv = a_t0[i] + kt;
+      const int hv = a_h0[i] + kh;
+      const int wv = a_w0[i] + kw;
+      bool ok = kvalid && (a_b[i] >= 0) && (hv >= 0) && (hv < Hv) && (wv >= 0) && (wv < Wv) && (tv < Tv);
+      const MT* base = xg;
+      int tstore = p.Ti, ti;
+      if (tv < 0) {
+        if (p.tmode == VT_TPAD_ZERO) {
+          ok = false;
+          ti = 0;
+        } else if (p.tmode == VT_TPAD_REPLICATE) {
+          ti = 0;
+        } else {
+          base = cg;
+          tstore = p.ncache;
+          ti = p.ncache + tv;
+          ok = ok && (ti >= 0);
+        }
+      } else {
+        ti = tv >> p.ups_t;
+      }
+      if (ok) {
+        const int hi = hv >> p.ups_s, wi = wv >> p.ups_s;
+        const long long pix = (((long long)a_b[i] * tstore + ti) * p.Hi + hi) * p.Wi + wi;
+        v = *reinterpret_cast<const u32x4*>(base + pix * p.Cin + c);
+      }
+      areg[i] = v;
+    }
+    const int kk = FAST ? (s * BK + kvec * VEC) : (tap * p.Cin + c);
+#pragma unroll
+    for (int j = 0; j < B_VECS; ++j) {
+      u32x4 v = {0u, 0u, 0u, 0u};
+      const int n = n_blk + srow + 32 * j;
+      if (kvalid && n < p.Cout) v = *reinterpret_cast<const u32x4*>(wg + (long long)n * p.ldw + kk);
+      breg[j] = v;
+    }
+  };
+
+  auto store_stage = [&](int buf) {
+    char* As = smem + buf * STAGE_BYTES;
+    char* Bs = As + A_BYTES;
+#pragma unroll
+    for (int i = 0; i < A_VECS; ++i)
+      *reinterpret_cast<u32x4*>(As + (srow + 32 * i) * kLdsRowBytes + kvec * 16) = areg[i];
+#pragma unroll
+    for (int j = 0; j < B_VECS; ++j)
+      *reinterpret_cast<u32x4*>(Bs + (srow + 32 * j) * kLdsRowBytes + kvec * 16) = breg[j];
+  };
+
+  f32x16 acc[TN][TM];
+#pragma unroll
+  for (int a = 0; a < TN; ++a)
+#pragma unroll
+    for (int b = 0; b < TM; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
+
+  const int frag_off = (lane & 31) * kLdsRowBytes + (lane >> 5) * 16;
+
+  auto compute_stage = [&](int buf) {
+    const char* As = smem + buf * STAGE_BYTES + (wm * TM * 32) * kLdsRowBytes + frag_off;
+    const char* Bs = smem + buf * STAGE_BYTES + A_BYTES + (wn * TN * 32) * kLdsRowBytes + frag_off;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      u32x4 wf[TN], xf[TM];
+#pragma unroll
+      for (int a = 0; a < TN; ++a)
+        wf[a] = *reinterpret_cast<const u32x4*>(Bs + a * 32 * kLdsRowBytes + ks * 32);
+#pragma unroll
+      for (int b = 0; b < TM; ++b)
+        xf[b] = *reinterpret_cast<const u32x4*>(As + b * 32 * kLdsRowBytes + ks * 32);
+#pragma unroll
+      for (int a = 0; a < TN; ++a)
+#pragma unroll
+        for (int b = 0; b < TM; ++b) mma_step<MT>(wf[a], xf[b], acc[a][b]);
+    }
+  };
+
+  // ---- main loop: LDS double buffer, register prefetch ----------------------------------------
+  load_step(0);
+  store_stage(0);
+  __syncthreads();
+  for (int s = 0; s < p.nsteps; ++s) {
+    const int cur = s & 1;
+    if (s + 1 < p.nsteps) load_step(s + 1);
+    compute_stage(cur);
+    if (s + 1 < p.nsteps) store_stage(cur ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue --------------------------------------------------------------------------------
+  float alpha = 0.0f;
+  if (p.res_mode == VT_RES_MIX) alpha = 1.0f / (1.0f + __expf(-p.mix_factor[0]));
+  TOut* __restrict__ yg = reinterpret_cast<TOut*>(p.y) + z * p.ys_z;
+  const TOut* __restrict__ rg = reinterpret_cast<const TOut*>(p.res) + z * p.rs_z;
+  const long long HWo = (long long)p.Ho * p.Wo;
+
+#pragma unroll
+  for (int b = 0; b < TM; ++b) {
+    const int m = m_blk + (wm * TM + b) * 32 + (lane & 31);
+    if (m >= p.M) continue;
+    long long mr = m;          // residual pixel index
+    long long ybase = 0;       // NCTHW: offset of (b, n=0, to-t_trim, ho, wo)
+    bool store_ok = true;
+    if (p.res_tshift != 0 || p.Tr != p.To || p.out_layout == VT_NCTHW) {
+      const long long hw = m % HWo;
+      const long long r = m / HWo;
+      const int to = (int)(r % p.To);
+      const int bb = (int)(r / p.To);
+      mr = ((long long)bb * p.Tr + (to >> p.res_tshift)) * HWo + hw;
+      if (p.out_layout == VT_NCTHW) {
+        const int Tout = p.To - p.t_trim;
+        store_ok = to >= p.t_trim;
+        ybase = ((long long)bb * p.Cout * Tout + (to - p.t_trim)) * HWo + hw;
+      }
+    }
+#pragma unroll
+    for (int a = 0; a < TN; ++a) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int n0 = n_blk + (wn * TN + a) * 32 + 8 * g + 4 * (lane >> 5);
+        if (n0 >= p.Cout) continue;
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = acc[a][b][4 * g + e];
+        const bool full = (n0 + 3 < p.Cout);
+        if (p.bias) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (full || n0 + e < p.Cout) v[e] += p.bias[n0 + e];
+        }
+        if (p.res_mode != VT_RES_NONE) {
+          float rv[4] = {0.f, 0.f, 0.f, 0.f};
+          const TOut* rp = rg + mr * p.ldr + n0;
+          if (full && (p.ldr & 3) == 0) {
+            if constexpr (sizeof(TOut) == 4) {
+              const f32x4 t = *reinterpret_cast<const f32x4*>(rp);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) rv[e] = t[e];
+            } else {
+              const u32x2 t = *reinterpret_cast<const u32x2*>(rp);
+              rv[0] = bf16_bits_to_f32(t[0] & 0xffffu);
+              rv[1] = bf16_bits_to_f32(t[0] >> 16);
+              rv[2] = bf16_bits_to_f32(t[1] & 0xffffu);
+              rv[3] = bf16_bits_to_f32(t[1] >> 16);
+            }
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              if (n0 + e < p.Cout) rv[e] = to_f32<TOut>(rp[e]);
+          }
+          if (p.res_mode == VT_RES_ADD) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = rv[e] + v[e];
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = alpha * rv[e] + (1.0f - alpha) * v[e];
+          }
+        }
+        if (p.out_layout == VT_NCTHW) {
+          if (store_ok) {
+            const int Tout = p.To - p.t_trim;
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              if (n0 + e < p.Cout) yg[ybase + (long long)(n0 + e) * Tout * HWo] = from_f32<TOut>(v[e]);
+          }
+        } else {
+          TOut* yp = yg + (long long)m * p.ldy + n0;
+          if (full && (p.ldy & 3) == 0) {
+            if constexpr (sizeof(TOut) == 4) {
+              f32x4 t;
+#pragma unroll
+              for (int e = 0; e < 4; ++e) t[e] = v[e];
+              *reinterpret_cast<f32x4*>(yp) = t;
+            } else {
+              u32x2 t;
+              t[0] = f32_to_bf16_bits(v[0]) | (f32_to_bf16_bits(v[1]) << 16);
+              t[1] = f32_to_bf16_bits(v[2]) | (f32_to_bf16_bits(v[3]) << 16);
+              *reinterpret_cast<u32x2*>(yp) = t;
+            }
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              if (n0 + e < p.Cout) yp[e] = from_f32<TOut>(v[e]);
+          }
+        }
+      }
+    }
+  }
+}
+
+template <typename MT, typename TOut, int WAVES_M, int WAVES_N, int TM, int TN, bool FAST>
+int launch_variant(const ConvArgs& a_in, int nbatch, hipStream_t stream) {
+  constexpr int BM = WAVES_M * TM * 32;
+  constexpr int BN = WAVES_N * TN * 32;
+  constexpr int BK = kRowBytes / (int)sizeof(MT);
+  constexpr int LDS = 2 * (BM + BN) * kLdsRowBytes;
+  ConvArgs a = a_in;
+  a.m_tiles = (a.M + BM - 1) / BM;
+  a.n_tiles = (a.Cout + BN - 1) / BN;
+  a.nsteps = FAST ? a.ntaps * (a.Cin / BK) : (a.K + BK - 1) / BK;
+  auto kern = conv_igemm_kernel<MT, TOut, WAVES_M, WAVES_N, TM, TN, FAST>;
+  static bool attr_done = false;  // per instantiation
+  if (!attr_done) {
+    VT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+    attr_done = true;
+  }
+  const long long nblk = (long long)a.m_tiles * a.n_tiles;
+  VT_CHECK_ARG(nblk < (1ll << 31), "vt_conv: too many tiles (%lld)", nblk);
+  dim3 grid((unsigned)nblk, 1, (unsigned)nbatch);
+  hipLaunchKernelGGL(kern, grid, dim3(kThreads), LDS, stream, a);
+  VT_CHECK_LAUNCH();
+  return VT_OK;
+}
+
+template <typename MT, typename TOut>
+int dispatch_tile(const ConvArgs& a, int nbatch, hipStream_t stream) {
+  constexpr int BK = kRowBytes / (int)sizeof(MT);
+  const bool fast = (a.Cin % BK) == 0;
+  if (a.Cout <= 32) {
+    // narrow-N: 256 pixels x 32 channels per workgroup
+    return fast ? launch_variant<MT, TOut, 4, 1, 2, 1, true>(a, nbatch, stream)
+                : launch_variant<MT, TOut, 4, 1, 2, 1, false>(a, nbatch, stream);
+  }
+  if (a.Cout <= 64) {
+    return fast ? launch_variant<MT, TOut, 4, 1, 2, 2, true>(a, nbatch, stream)
+                : launch_variant<MT, TOut, 4, 1, 2, 2, false>(a, nbatch, stream);
+  }
+  return fast ? launch_variant<MT, TOut, 2, 2, 2, 2, true>(a, nbatch, stream)
+              : launch_variant<MT, TOut, 2, 2, 2, 2, false>(a, nbatch, stream);
+}
+
+}  // namespace
+
+extern "C" int vt_conv_max_lds_bytes(void) { return 2 * (256 + 64) * kLdsRowBytes; }
+
+extern "C" int vt_conv(const vt_conv_desc* d, vt_stream stream_) {
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  VT_CHECK_ARG(d != nullptr, "vt_conv: null descriptor");
+  VT_CHECK_ARG(d->x && d->w && d->y, "vt_conv: null tensor pointer");
+  VT_CHECK_ARG(d->dtype == VT_F32 || d->dtype == VT_BF16, "vt_conv: dtype %d", d->dtype);
+  VT_CHECK_ARG(d->out_dtype == d->dtype || d->out_dtype == VT_F32, "vt_conv: out_dtype %d with dtype %d",
+               d->out_dtype, d->dtype);
+  const int vec = d->dtype == VT_F32 ? 4 : 8;
+  VT_CHECK_ARG(d->B > 0 && d->Ti > 0 && d->Hi > 0 && d->Wi > 0 && d->Cin > 0, "vt_conv: bad input dims");
+  VT_CHECK_ARG(d->To > 0 && d->Ho > 0 && d->Wo > 0 && d->Cout > 0, "vt_conv: bad output dims");
+  VT_CHECK_ARG(d->Cin % vec == 0, "vt_conv: Cin=%d must be a multiple of %d (pad the channel dim)", d->Cin, vec);
+  VT_CHECK_ARG(d->KT > 0 && d->KH > 0 && d->KW > 0 && d->KT * d->KH * d->KW <= 64, "vt_conv: bad taps");
+  VT_CHECK_ARG(d->st > 0 && d->sh > 0 && d->sw > 0, "vt_conv: bad strides");
+  VT_CHECK_ARG(d->ldw >= d->KT * d->KH * d->KW * d->Cin && d->ldw % vec == 0, "vt_conv: ldw=%d", d->ldw);
+  VT_CHECK_ARG((reinterpret_cast<uintptr_t>(d->x) & 15) == 0 && (reinterpret_cast<uintptr_t>(d->w) & 15) == 0,
+               "vt_conv: x / w must be 16-byte aligned");
+  VT_CHECK_ARG(d->ups_t == 0 || d->ups_t == 1, "vt_conv: ups_t");
+  VT_CHECK_ARG(d->ups_s == 0 || d->ups_s == 1, "vt_conv: ups_s");
+  VT_CHECK_ARG(d->tmode >= VT_TPAD_ZERO && d->tmode <= VT_TPAD_CACHE, "vt_conv: tmode %d", d->tmode);
+  if (d->tmode == VT_TPAD_CACHE && d->pt > 0) {
+    VT_CHECK_ARG(d->cache != nullptr && d->ncache >= d->pt, "vt_conv: cache mode needs cache with >= pt frames");
+    VT_CHECK_ARG(d->ups_t == 0, "vt_conv: cache mode with ups_t");
+    VT_CHECK_ARG((reinterpret_cast<uintptr_t>(d->cache) & 15) == 0, "vt_conv: cache must be 16-byte aligned");
+  }
+  VT_CHECK_ARG(d->res_mode >= VT_RES_NONE && d->res_mode <= VT_RES_MIX, "vt_conv: res_mode %d", d->res_mode);
+  if (d->res_mode != VT_RES_NONE) {
+    VT_CHECK_ARG(d->res != nullptr && d->Tr > 0 && d->ldr >= d->Cout, "vt_conv: residual operand");
+    VT_CHECK_ARG(((d->To - 1) >> d->res_tshift) < d->Tr, "vt_conv: residual time extent");
+  }
+  if (d->res_mode == VT_RES_MIX) VT_CHECK_ARG(d->mix_factor != nullptr, "vt_conv: mix_factor is null");
+  if (d->out_layout == VT_NCTHW) {
+    VT_CHECK_ARG(d->out_dtype == VT_F32, "vt_conv: NCTHW output is fp32 only");
+    VT_CHECK_ARG(d->t_trim >= 0 && d->t_trim < d->To, "vt_conv: t_trim");
+  } else {
+    VT_CHECK_ARG(d->out_layout == VT_NDHWC && d->ldy >= d->Cout, "vt_conv: ldy=%d < Cout=%d", d->ldy, d->Cout);
+  }
+  const long long M = (long long)d->B * d->To * d->Ho * d->Wo;
+  VT_CHECK_ARG(M < (1ll << 31), "vt_conv: M too large");
+  const int nbatch = d->nbatch > 0 ? d->nbatch : 1;
+
+  ConvArgs a;
+  memset(&a, 0, sizeof(a));
+  a.x = (const char*)d->x; a.w = (const char*)d->w; a.bias = d->bias; a.y = (char*)d->y;
+  a.res = (const char*)d->res; a.cache = (const char*)d->cache; a.mix_factor = d->mix_factor;
+  a.B = d->B; a.Ti = d->Ti; a.Hi = d->Hi; a.Wi = d->Wi; a.Cin = d->Cin;
+  a.To = d->To; a.Ho = d->Ho; a.Wo = d->Wo; a.Cout = d->Cout;
+  a.ldw = d->ldw; a.ldy = d->ldy;
+  a.KT = d->KT; a.KH = d->KH; a.KW = d->KW;
+  a.st = d->st; a.sh = d->sh; a.sw = d->sw;
+  a.pt = d->pt; a.ph = d->ph; a.pw = d->pw;
+  a.tmode = d->tmode; a.ncache = d->ncache;
+  a.ups_t = d->ups_t; a.ups_s = d->ups_s;
+  a.res_mode = d->res_mode; a.res_tshift = d->res_tshift;
+  a.Tr = d->res_mode != VT_RES_NONE ? d->Tr : d->To;
+  a.ldr = d->ldr;
+  a.out_layout = d->out_layout; a.t_trim = d->t_trim;
+  a.M = (int)M; a.ntaps = d->KT * d->KH * d->KW; a.K = a.ntaps * d->Cin;
+  a.xs_z = d->xs_z; a.ws_z = d->ws_z; a.ys_z = d->ys_z; a.rs_z = d->rs_z;
+
+  if (d->dtype == VT_F32) return dispatch_tile<float, float>(a, nbatch, stream);
+  if (d->out_dtype == VT_F32) return dispatch_tile<bf16_t, float>(a, nbatch, stream);
+  return dispatch_tile<bf16_t, bf16_t>(a, nbatch, stream);
+}

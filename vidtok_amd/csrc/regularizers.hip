@@ -1,0 +1,280 @@
+// KL (diagonal Gaussian) and FSQ regularizer kernels -- contracts in include/vidtok_amd.h.
+// All tensors here are the small NCTHW fp32 latents of the reference API ([B][C][S], S = T*H*W).
+#include <math.h>
+
+#include "common.h"
+
+namespace {
+
+constexpr int kBlock = 256;
+constexpr int kMaxD = 8;
+constexpr int kMaxL = 16;
+
+// ---- KL --------------------------------------------------------------------------------------
+// DiagonalGaussianDistribution (reference distributions.py:6-28) + DiagonalGaussianRegularizer
+// (regularizers.py:82-92).  One workgroup, fixed summation order => deterministic kl.
+__global__ __launch_bounds__(1024) void kl_sample_kernel(const float* __restrict__ h, const float* __restrict__ noise,
+                                                         float* __restrict__ z, float* __restrict__ kl_out, int B,
+                                                         int zc, long long S) {
+  __shared__ float red[16];
+  const long long per_b = (long long)zc * S;
+  const long long n = (long long)B * per_b;
+  float acc = 0.f;
+  for (long long i = threadIdx.x; i < n; i += 1024) {
+    const long long b = i / per_b;
+    const long long r = i - b * per_b;  // c*S + s
+    const float mean = h[b * 2 * per_b + r];
+    float logvar = h[b * 2 * per_b + per_b + r];
+    logvar = fminf(fmaxf(logvar, -30.0f), 20.0f);
+    const float stdv = expf(0.5f * logvar);
+    const float var = expf(logvar);
+    z[i] = noise ? mean + stdv * noise[i] : mean;
+    acc += mean * mean + var - 1.0f - logvar;
+  }
+  acc = wave_sum(acc, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    float v = threadIdx.x < 16 ? red[threadIdx.x] : 0.f;
+    v = wave_sum(v, 64);
+    if (threadIdx.x == 0) kl_out[0] = 0.5f * v / (float)B;
+  }
+}
+
+// ---- FSQ -------------------------------------------------------------------------------------
+struct FsqConsts {
+  int D;
+  int levels[kMaxD];
+  int basis[kMaxD];
+  float half_l[kMaxD];   // (L-1)*(1+eps)/2          regularizers.py:155
+  float offset[kMaxD];   // 0.5 for even L           regularizers.py:156
+  float shift[kMaxD];    // atanh(offset/half_l)     regularizers.py:157
+  float half_w[kMaxD];   // L//2                     regularizers.py:163
+};
+
+// tanh rounded from a double evaluation: within 0.5 ulp of the exact value, so it differs from
+// the host libm / Sleef result the reference uses by at most one fp32 ulp.
+__device__ __forceinline__ float tanh_cr(float x) { return (float)tanh((double)x); }
+
+// bound -> round half to even -> integer level (the value `quantized` of regularizers.py:160-164)
+__device__ __forceinline__ float fsq_round(float zv, float shift, float half_l, float offset) {
+  const float t = tanh_cr(__fadd_rn(zv, shift));
+  const float bounded = __fsub_rn(__fmul_rn(t, half_l), offset);  // separate roundings, like torch
+  return rintf(bounded);
+}
+
+__global__ __launch_bounds__(kBlock) void fsq_quantize_kernel(const float* __restrict__ h, float* __restrict__ z,
+                                                              int* __restrict__ indices, FsqConsts k, int B,
+                                                              long long S) {
+  const long long n = (long long)B * S;
+  for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < n; i += (long long)gridDim.x * kBlock) {
+    const long long b = i / S, s = i - b * S;
+    float idx = 0.f;
+    for (int d = 0; d < k.D; ++d) {
+      const float q = fsq_round(h[(b * k.D + d) * S + s], k.shift[d], k.half_l[d], k.offset[d]);
+      const float code = q / k.half_w[d];
+      z[(b * k.D + d) * S + s] = code;
+      // codes_to_indices: (code*half_w + half_w) * basis, summed in fp32 (exact: < 2^24)
+      idx += (code * k.half_w[d] + k.half_w[d]) * (float)k.basis[d];
+    }
+    indices[i] = (int)idx;
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void fsq_indices_to_codes_kernel(const int* __restrict__ indices,
+                                                                      float* __restrict__ z, FsqConsts k, int B,
+                                                                      long long S) {
+  const long long n = (long long)B * S;
+  for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < n; i += (long long)gridDim.x * kBlock) {
+    const long long b = i / S, s = i - b * S;
+    const int idx = indices[i];
+    for (int d = 0; d < k.D; ++d) {
+      const int lv = (idx / k.basis[d]) % k.levels[d];                  // regularizers.py:186
+      z[(b * k.D + d) * S + s] = ((float)lv - k.half_w[d]) / k.half_w[d];  // _scale_and_shift_inverse :170-172
+    }
+  }
+}
+
+// aux statistics, stage 1: per token the per-dimension softmax tables p[d][l] of
+// softmax_j(2*inv_temp * <z, c_j>) -- the implicit codebook is a product grid, so the softmax
+// over all prod(L) codes factorises exactly into per-dimension softmaxes -- and the commitment
+// partial sum.  work layout: [Ntok][D][kMaxL] tables, then 3 accumulators.
+__global__ __launch_bounds__(kBlock) void fsq_aux_tables_kernel(const float* __restrict__ h, FsqConsts k, int B,
+                                                                long long S, float inv_temp,
+                                                                float* __restrict__ tables, float* __restrict__ accum) {
+  const long long n = (long long)B * S;
+  float commit = 0.f;
+  for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < n; i += (long long)gridDim.x * kBlock) {
+    const long long b = i / S, s = i - b * S;
+    for (int d = 0; d < k.D; ++d) {
+      const float zv = h[(b * k.D + d) * S + s];
+      const float q = fsq_round(zv, k.shift[d], k.half_l[d], k.offset[d]);
+      const float code = q / k.half_w[d];
+      commit += (zv - code) * (zv - code);
+      float* t = tables + (i * k.D + d) * kMaxL;
+      const int L = k.levels[d];
+      float mx = -INFINITY;
+      for (int l = 0; l < L; ++l) {
+        const float c = ((float)l - k.half_w[d]) / k.half_w[d];
+        const float logit = 2.0f * inv_temp * zv * c;
+        t[l] = logit;
+        mx = fmaxf(mx, logit);
+      }
+      float sum = 0.f;
+      for (int l = 0; l < L; ++l) {
+        const float e = expf(t[l] - mx);
+        t[l] = e;
+        sum += e;
+      }
+      const float inv = 1.0f / sum;
+      for (int l = 0; l < L; ++l) t[l] *= inv;
+    }
+  }
+  commit = wave_sum(commit, 64);
+  if ((threadIdx.x & 63) == 0) atomicAdd(accum + 2, commit);
+}
+
+// stage 2: thread j owns code j; loops over all tokens accumulating the batch-mean probability
+// of its code and its share of the per-token entropies (with the reference's log clamp 1e-5,
+// regularizers.py:40-45).
+__global__ __launch_bounds__(kBlock) void fsq_aux_entropy_kernel(const float* __restrict__ tables, FsqConsts k,
+                                                                 long long ntok, int J, float* __restrict__ accum) {
+  const int j = blockIdx.x * kBlock + threadIdx.x;
+  float ent = 0.f, cbe = 0.f;
+  if (j < J) {
+    int off[kMaxD];
+    for (int d = 0; d < k.D; ++d) off[d] = d * kMaxL + (j / k.basis[d]) % k.levels[d];
+    float avg = 0.f;
+    for (long long t = 0; t < ntok; ++t) {
+      const float* tb = tables + t * k.D * kMaxL;
+      float p = 1.0f;
+      for (int d = 0; d < k.D; ++d) p *= tb[off[d]];
+      avg += p;
+      ent -= p * logf(fmaxf(p, 1e-5f));
+    }
+    avg /= (float)ntok;
+    cbe = -avg * logf(fmaxf(avg, 1e-5f));
+  }
+  ent = wave_sum(ent, 64);
+  cbe = wave_sum(cbe, 64);
+  if ((threadIdx.x & 63) == 0) {
+    atomicAdd(accum + 0, ent);
+    atomicAdd(accum + 1, cbe);
+  }
+}
+
+__global__ void fsq_aux_finish_kernel(const float* __restrict__ accum, long long ntok, long long nelem,
+                                      float* __restrict__ out3) {
+  out3[0] = accum[0] / (float)ntok;   // per-sample entropy, mean over tokens (num_codebooks = 1)
+  out3[1] = accum[1];                 // entropy of the batch-mean distribution
+  out3[2] = accum[2] / (float)nelem;  // F.mse_loss(..., "none").mean()
+}
+
+int make_consts(const int32_t* levels, int D, FsqConsts* k) {
+  VT_CHECK_ARG(levels != nullptr && D >= 1 && D <= kMaxD, "fsq: D=%d out of range [1,%d]", D, kMaxD);
+  k->D = D;
+  int basis = 1;
+  for (int d = 0; d < D; ++d) {
+    VT_CHECK_ARG(levels[d] >= 2 && levels[d] <= kMaxL, "fsq: level %d out of range [2,%d]", levels[d], kMaxL);
+    k->levels[d] = levels[d];
+    k->basis[d] = basis;
+    basis *= levels[d];
+    // fp32 operation order of FSQRegularizer.bound (regularizers.py:153-158)
+    const float half_l = (float)(levels[d] - 1) * (float)(1.0 + 1e-3) / 2.0f;
+    const float offset = (levels[d] % 2 == 0) ? 0.5f : 0.0f;
+    k->half_l[d] = half_l;
+    k->offset[d] = offset;
+    k->shift[d] = atanhf(offset / half_l);
+    k->half_w[d] = (float)(levels[d] / 2);
+  }
+  return VT_OK;
+}
+
+inline unsigned grid_for(long long n) {
+  long long b = (n + kBlock - 1) / kBlock;
+  if (b > 2048) b = 2048;
+  if (b < 1) b = 1;
+  return (unsigned)b;
+}
+
+}  // namespace
+
+extern "C" int vt_fsq_consts(const int32_t* levels_host, int32_t D, float* out_host) {
+  VT_CHECK_ARG(out_host != nullptr, "vt_fsq_consts: null output");
+  FsqConsts k;
+  int rc = make_consts(levels_host, D, &k);
+  if (rc != VT_OK) return rc;
+  for (int d = 0; d < D; ++d) {
+    out_host[d] = k.half_l[d];
+    out_host[D + d] = k.offset[d];
+    out_host[2 * D + d] = k.shift[d];
+    out_host[3 * D + d] = (float)k.basis[d];
+  }
+  return VT_OK;
+}
+
+extern "C" int vt_kl_sample(const float* h, const float* noise, float* z, float* kl_out, int32_t B, int32_t zc,
+                            int64_t S, vt_stream stream_) {
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  VT_CHECK_ARG(h && z && kl_out && B > 0 && zc > 0 && S > 0, "vt_kl_sample: bad arguments");
+  hipLaunchKernelGGL(kl_sample_kernel, dim3(1), dim3(1024), 0, stream, h, noise, z, kl_out, B, zc, (long long)S);
+  VT_CHECK_LAUNCH();
+  return VT_OK;
+}
+
+extern "C" int vt_fsq_quantize(const float* h, float* z, int32_t* indices, const int32_t* levels_host, int32_t D,
+                               int32_t B, int64_t S, vt_stream stream_) {
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  VT_CHECK_ARG(h && z && indices && B > 0 && S > 0, "vt_fsq_quantize: bad arguments");
+  FsqConsts k;
+  int rc = make_consts(levels_host, D, &k);
+  if (rc != VT_OK) return rc;
+  hipLaunchKernelGGL(fsq_quantize_kernel, dim3(grid_for((long long)B * S)), dim3(kBlock), 0, stream, h, z, indices, k,
+                     B, (long long)S);
+  VT_CHECK_LAUNCH();
+  return VT_OK;
+}
+
+extern "C" int vt_fsq_indices_to_codes(const int32_t* indices, float* z, const int32_t* levels_host, int32_t D,
+                                       int32_t B, int64_t S, vt_stream stream_) {
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  VT_CHECK_ARG(indices && z && B > 0 && S > 0, "vt_fsq_indices_to_codes: bad arguments");
+  FsqConsts k;
+  int rc = make_consts(levels_host, D, &k);
+  if (rc != VT_OK) return rc;
+  hipLaunchKernelGGL(fsq_indices_to_codes_kernel, dim3(grid_for((long long)B * S)), dim3(kBlock), 0, stream, indices,
+                     z, k, B, (long long)S);
+  VT_CHECK_LAUNCH();
+  return VT_OK;
+}
+
+extern "C" int64_t vt_fsq_aux_work_floats(const int32_t* levels_host, int32_t D, int32_t B, int64_t S) {
+  (void)levels_host;
+  return (int64_t)B * S * D * kMaxL + 4;
+}
+
+extern "C" int vt_fsq_aux_stats(const float* h, const int32_t* levels_host, int32_t D, int32_t B, int64_t S,
+                                float inv_temperature, float* work, float* out3, vt_stream stream_) {
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  VT_CHECK_ARG(h && work && out3 && B > 0 && S > 0, "vt_fsq_aux_stats: bad arguments");
+  FsqConsts k;
+  int rc = make_consts(levels_host, D, &k);
+  if (rc != VT_OK) return rc;
+  long long J = 1;
+  for (int d = 0; d < D; ++d) J *= levels_host[d];
+  VT_CHECK_ARG(J < (1ll << 30), "vt_fsq_aux_stats: codebook too large");
+  const long long ntok = (long long)B * S;
+  float* tables = work;
+  float* accum = work + ntok * D * kMaxL;
+  VT_CHECK_HIP(hipMemsetAsync(accum, 0, 4 * sizeof(float), stream));
+  hipLaunchKernelGGL(fsq_aux_tables_kernel, dim3(grid_for(ntok)), dim3(kBlock), 0, stream, h, k, B, (long long)S,
+                     inv_temperature, tables, accum);
+  VT_CHECK_LAUNCH();
+  hipLaunchKernelGGL(fsq_aux_entropy_kernel, dim3((unsigned)((J + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream,
+                     (const float*)tables, k, ntok, (int)J, accum);
+  VT_CHECK_LAUNCH();
+  hipLaunchKernelGGL(fsq_aux_finish_kernel, dim3(1), dim3(1), 0, stream, (const float*)accum, ntok,
+                     ntok * (long long)D, out3);
+  VT_CHECK_LAUNCH();
+  return VT_OK;
+}

@@ -1,0 +1,242 @@
+"""AutoencodingEngine -- the model API of the reference (vidtok/models/autoencoder.py:98-229 and
+autoencoder_v1_1.py:98-342) over the MI355X modules: forward / encode / decode /
+indices_to_latent / init_from_ckpt, plus the v1.1 temporal tiling with causal caches.
+
+`forward(x) -> (z, dec, reg_log)` is the reference's round-trip entry point; `encode_decode` is an
+alias (BASELINE.json names it that way).  Training (`training_step`, optimizers, EMA, losses) is out
+of scope: `loss_config` is accepted and ignored.
+"""
+import re
+from typing import Any, Dict, Tuple, Union
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from .config import instantiate_from_config
+
+
+def _print0(msg):
+    try:
+        import torch.distributed as dist
+
+        if dist.is_available() and dist.is_initialized() and dist.get_rank() != 0:
+            return
+    except Exception:
+        pass
+    print(msg)
+
+
+class AutoencodingEngine(nn.Module):
+    version = "v1_0"
+
+    def __init__(self, *args, encoder_config: Dict, decoder_config: Dict, loss_config: Dict = None,
+                 regularizer_config: Dict, optimizer_config: Union[Dict, None] = None, lr_g_factor: float = 1.0,
+                 compile_model: bool = False, **kwargs):
+        ckpt_path = kwargs.pop("ckpt_path", None)
+        ignore_keys = kwargs.pop("ignore_keys", ())
+        verbose = kwargs.pop("verbose", True)
+        self.use_tiling = kwargs.pop("use_tiling", False)
+        self.t_chunk_enc = kwargs.pop("t_chunk_enc", 16)
+        # AbstractAutoencoder keywords of the reference (autoencoder.py:26-33); training only
+        self.input_key = kwargs.pop("input_key", "jpg")
+        for k in ("ema_decay", "monitor", "mode", "base_learning_rate"):
+            kwargs.pop(k, None)
+        super().__init__()
+        self.global_step = 0
+        self.encoder = instantiate_from_config(encoder_config)
+        self.decoder = instantiate_from_config(decoder_config)
+        self.loss = nn.Identity()  # loss_config is training-only
+        self.regularization = instantiate_from_config(regularizer_config)
+        self.is_causal = self.encoder.is_causal
+        self.t_chunk_dec = self.t_chunk_enc // self.encoder.time_downsample_factor
+        self.use_overlap = False
+        if self.version == "v1_0" and self.use_tiling:
+            raise NotImplementedError("temporal tiling exists only in the v1.1 models of the reference")
+        if verbose:
+            _print0(f"[vidtok_amd.engine][AutoencodingEngine] Use ckpt_path: {ckpt_path}")
+        if ckpt_path is not None:
+            self.init_from_ckpt(ckpt_path, ignore_keys=ignore_keys, verbose=verbose)
+
+    # ---- numeric mode ---------------------------------------------------------------------------
+    def set_compute_dtype(self, dtype: torch.dtype):
+        """torch.float32: fp32 storage + fp32-input MFMA (parity mode); torch.bfloat16: bf16 storage +
+        bf16 MFMA with fp32 accumulation (throughput mode, the reference's autocast analogue)."""
+        assert dtype in (torch.float32, torch.bfloat16)
+        self.encoder.compute_dtype = dtype
+        self.decoder.compute_dtype = dtype
+        return self
+
+    # ---- checkpoints (autoencoder.py:146-176) ---------------------------------------------------
+    def init_from_ckpt(self, path: str, ignore_keys=tuple(), verbose: bool = True) -> None:
+        if path.endswith("ckpt"):
+            ckpt = torch.load(path, map_location="cpu")
+            weights = ckpt["state_dict"] if "state_dict" in ckpt else ckpt
+        elif path.endswith("safetensors"):
+            from safetensors.torch import load_file
+
+            weights = load_file(path)
+        else:
+            raise NotImplementedError(f"Unknown checkpoint: {path}")
+        for k in list(weights.keys()):
+            for ik in ignore_keys:
+                if re.match(ik, k):
+                    _print0(f"[vidtok_amd.engine] Deleting key {k} from state_dict.")
+                    del weights[k]
+                    break
+        missing, unexpected = self.load_state_dict(weights, strict=False)
+        _print0(f"[vidtok_amd.engine] Restored from {path} with {len(missing)} missing and "
+                f"{len(unexpected)} unexpected keys")
+        if verbose:
+            if missing:
+                _print0(f"[vidtok_amd.engine] Missing Keys: {missing}")
+            if unexpected:
+                _print0(f"[vidtok_amd.engine] Unexpected Keys: {unexpected}")
+
+    def get_last_layer(self):
+        return self.decoder.get_last_layer()
+
+    # ---- encode / decode ------------------------------------------------------------------------
+    @torch.no_grad()
+    def encode(self, x: Any, return_reg_log: bool = False) -> Any:
+        z = self.encoder(x)
+        z, reg_log = self.regularization(z, n_steps=self.global_step // 2)
+        if return_reg_log:
+            return z, reg_log
+        return z
+
+    @torch.no_grad()
+    def indices_to_latent(self, token_indices: torch.Tensor) -> torch.Tensor:
+        """int32 [B, T', H', W'] -> latent [B, D, T', H', W'] (autoencoder.py:205-213)."""
+        return self.regularization.indices_to_codes(token_indices)
+
+    @torch.no_grad()
+    def decode(self, z: Any, decode_from_indices: bool = False) -> torch.Tensor:
+        if decode_from_indices:
+            z = self.indices_to_latent(z)
+        return self.decoder(z)
+
+    @torch.no_grad()
+    def forward(self, x: Any) -> Tuple[torch.Tensor, torch.Tensor, dict]:
+        z, reg_log = self.encode(x, return_reg_log=True)
+        dec = self.decode(z)
+        return z, dec, reg_log
+
+    encode_decode = forward
+
+
+class AutoencodingEngineV11(AutoencodingEngine):
+    """v1.1: first-frame-replicate causal padding and sequential temporal tiling with per-module causal
+    caches and a one-latent-frame decoder look-ahead (autoencoder_v1_1.py:202-342)."""
+
+    version = "v1_1"
+
+    # -- cache / chunk protocol: walks the module tree exactly like the reference (:202-216) ------
+    def _empty_causal_cached(self, parent):
+        for _, module in parent.named_modules():
+            if hasattr(module, "causal_cache"):
+                module.causal_cache = None
+
+    def _set_first_chunk(self, is_first_chunk=True):
+        for module in self.modules():
+            if hasattr(module, "is_first_chunk"):
+                module.is_first_chunk = is_first_chunk
+
+    def _set_cache_offset(self, modules, cache_offset=0):
+        for module in modules:
+            for submodule in module.modules():
+                if hasattr(submodule, "cache_offset"):
+                    submodule.cache_offset = cache_offset
+
+    def build_chunk_start_end(self, t, decoder_mode=False):
+        """[[0,1],[1,1+c],[1+c,1+2c],...]: the first chunk is the single leading frame (:218-228)."""
+        step = self.t_chunk_dec if decoder_mode else self.t_chunk_enc
+        assert step > 0
+        start_end, start = [[0, 1]], 1
+        while start < t:
+            end = min(t, start + step)
+            start_end.append([start, end])
+            start = end
+        return start_end
+
+    @torch.no_grad()
+    def encode(self, x: Any, return_reg_log: bool = False) -> Any:
+        self._empty_causal_cached(self.encoder)
+        self._set_first_chunk(True)
+        if self.use_tiling:
+            z, reg_log = self.tile_encode(x)
+        else:
+            z = self.encoder(x)
+            z, reg_log = self.regularization(z, n_steps=self.global_step // 2)
+        if return_reg_log:
+            return z, reg_log
+        return z
+
+    def tile_encode(self, x: Any) -> Any:
+        result_z, result_log = [], []
+        for idx, (start, end) in enumerate(self.build_chunk_start_end(x.shape[2])):
+            self._set_first_chunk(idx == 0)
+            chunk_z = self.encoder(x[:, :, start:end, :, :])
+            chunk_z, chunk_log = self.regularization(chunk_z, n_steps=self.global_step // 2)
+            result_z.append(chunk_z)
+            result_log.append(chunk_log)
+        z = torch.cat(result_z, dim=2)
+        if "kl_loss" in result_log[0]:
+            return z, {"kl_loss": torch.mean(torch.stack([d["kl_loss"] for d in result_log]))}
+        return z, {"aux_loss": torch.mean(torch.stack([d["aux_loss"] for d in result_log])),
+                   "indices": torch.cat([d["indices"] for d in result_log], dim=1)}
+
+    def tile_indices_to_latent(self, token_indices: torch.Tensor) -> torch.Tensor:
+        chunks = self.build_chunk_start_end(token_indices.shape[1], decoder_mode=True)
+        return torch.cat([self.indices_to_latent(token_indices[:, s:e].contiguous()) for s, e in chunks], dim=2)
+
+    @torch.no_grad()
+    def decode(self, z: Any, decode_from_indices: bool = False) -> torch.Tensor:
+        if decode_from_indices:
+            z = self.tile_indices_to_latent(z) if self.use_tiling else self.indices_to_latent(z)
+        self._empty_causal_cached(self.decoder)
+        self._set_first_chunk(True)
+        if self.use_tiling:
+            return self.tile_decode(z)
+        return self.decoder(z)
+
+    def _overlap_offsets(self):
+        """cache_offset per decoder sub-tree when chunks carry one look-ahead latent frame: 1 at latent
+        rate, doubling after each temporal up-sampler (autoencoder_v1_1.py:307-320)."""
+        f, d = self.encoder.time_downsample_factor, self.decoder
+        assert f in [2, 4, 8], "Only support 2x, 4x or 8x temporal downsampling now."
+        self._set_cache_offset([d], 1)
+        if f == 4:
+            self._set_cache_offset([d.up_temporal[2].upsample, d.up_temporal[1]], 2)
+            self._set_cache_offset([d.up_temporal[1].upsample, d.up_temporal[0], d.conv_out], 4)
+        elif f == 2:
+            self._set_cache_offset([d.up_temporal[2].upsample, d.up_temporal[1], d.up_temporal[0], d.conv_out], 2)
+        else:
+            self._set_cache_offset([d.up_temporal[3].upsample, d.up_temporal[2]], 2)
+            self._set_cache_offset([d.up_temporal[2].upsample, d.up_temporal[1]], 4)
+            self._set_cache_offset([d.up_temporal[1].upsample, d.up_temporal[0], d.conv_out], 8)
+
+    def tile_decode(self, z: Any) -> torch.Tensor:
+        num_frames = z.shape[2]
+        f = self.encoder.time_downsample_factor
+        if self.use_overlap:
+            self._overlap_offsets()
+        result = []
+        for idx, (start, end) in enumerate(self.build_chunk_start_end(num_frames, decoder_mode=True)):
+            self._set_first_chunk(idx == 0)
+            look = self.use_overlap and end + 1 <= num_frames
+            chunk = self.decoder(z[:, :, start:end + 1] if look else z[:, :, start:end])
+            if look:
+                chunk = chunk[:, :, :-f]
+            result.append(chunk)
+        return torch.cat(result, dim=2)
+
+    @torch.no_grad()
+    def forward(self, x: Any) -> Tuple[torch.Tensor, torch.Tensor, dict]:
+        z, reg_log = self.encode(x, return_reg_log=True)
+        dec = self.decode(z)
+        if dec.shape[2] != x.shape[2]:
+            dec = dec[:, :, -x.shape[2]:, ...]
+        return z, dec, reg_log
+
+    encode_decode = forward

@@ -1,0 +1,93 @@
+"""ctypes binding of libvidtok_amd.so (C-ABI declared in include/vidtok_amd.h).
+
+The product path has no CPU fallback: if the shared object is missing or a symbol cannot be
+resolved, loading raises -- nothing silently degrades to torch ops.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libvidtok_amd.so")
+
+VT_F32, VT_BF16, VT_I32 = 0, 1, 2
+VT_TPAD_ZERO, VT_TPAD_REPLICATE, VT_TPAD_CACHE = 0, 1, 2
+VT_RES_NONE, VT_RES_ADD, VT_RES_MIX = 0, 1, 2
+VT_NDHWC, VT_NCTHW = 0, 1
+
+
+class VtError(RuntimeError):
+    pass
+
+
+class ConvDesc(C.Structure):
+    """Field-for-field mirror of `vt_conv_desc` (include/vidtok_amd.h)."""
+
+    _fields_ = (
+        [(n, C.c_void_p) for n in ("x", "w", "bias", "y", "res", "cache", "mix_factor")]
+        + [(n, C.c_int32) for n in (
+            "B", "Ti", "Hi", "Wi", "Cin",
+            "To", "Ho", "Wo", "Cout",
+            "ldw", "ldy",
+            "KT", "KH", "KW",
+            "st", "sh", "sw",
+            "pt", "ph", "pw",
+            "tmode", "ncache",
+            "ups_t", "ups_s",
+            "res_mode", "res_tshift", "Tr", "ldr",
+            "out_layout", "t_trim",
+            "dtype", "out_dtype",
+            "nbatch",
+        )]
+        + [(n, C.c_int64) for n in ("xs_z", "ws_z", "ys_z", "rs_z")]
+    )
+
+
+# name -> (restype, argtypes); every symbol include/vidtok_amd.h declares
+_P, _I32, _I64, _F = C.c_void_p, C.c_int32, C.c_int64, C.c_float
+SIGNATURES = {
+    "vt_last_error": (C.c_char_p, []),
+    "vt_version": (C.c_int, []),
+    "vt_conv_max_lds_bytes": (C.c_int, []),
+    "vt_conv": (C.c_int, [C.POINTER(ConvDesc), _P]),
+    "vt_layernorm_act": (C.c_int, [_P, C.c_int, _I64, _P, C.c_int, _I64, _P, _P, _I64, _I32, _F, _I32, _P]),
+    "vt_softmax_rows": (C.c_int, [_P, _P, C.c_int, _I64, _I32, _I64, _F, _P]),
+    "vt_ncthw_to_ndhwc": (C.c_int, [_P, _P, C.c_int, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _P]),
+    "vt_ndhwc_to_ncthw": (C.c_int, [_P, C.c_int, _P, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _P]),
+    "vt_time_avgpool3s2": (C.c_int, [_P, _P, _P, C.c_int, _I32, _I32, _I64, _I32, _I32, _P]),
+    "vt_time_lerp2x": (C.c_int, [_P, _P, C.c_int, _I32, _I32, _I64, _P]),
+    "vt_fsq_consts": (C.c_int, [C.POINTER(_I32), _I32, C.POINTER(_F)]),
+    "vt_kl_sample": (C.c_int, [_P, _P, _P, _P, _I32, _I32, _I64, _P]),
+    "vt_fsq_quantize": (C.c_int, [_P, _P, _P, C.POINTER(_I32), _I32, _I32, _I64, _P]),
+    "vt_fsq_indices_to_codes": (C.c_int, [_P, _P, C.POINTER(_I32), _I32, _I32, _I64, _P]),
+    "vt_fsq_aux_work_floats": (_I64, [C.POINTER(_I32), _I32, _I32, _I64]),
+    "vt_fsq_aux_stats": (C.c_int, [_P, C.POINTER(_I32), _I32, _I32, _I64, _F, _P, _P, _P]),
+    "vt_gather_frames": (C.c_int, [_P, _P, _I32, _I32, _I64, _I64, _I64, C.POINTER(_I32), _I32, _P]),
+}
+
+_lib = None
+
+
+def load(path: str = None):
+    """Load the shared object and bind every declared symbol; raises if anything is missing."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    path = path or os.environ.get("VIDTOK_AMD_LIB", LIB_PATH)
+    if not os.path.exists(path):
+        raise VtError(
+            f"{path} not found: build the HIP extension first (python -m vidtok_amd.build). "
+            "vidtok_amd has no CPU fallback."
+        )
+    lib = C.CDLL(path)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str = ""):
+    if rc != 0:
+        msg = load().vt_last_error()
+        raise VtError(f"{what} failed (status {rc}): {msg.decode() if msg else '?'}")

@@ -1,0 +1,569 @@
+"""Host-side mirror of the reference's causal encoder / decoder modules.
+
+Class names, constructor keywords, attributes read from outside and -- through the choice of
+parameter containers -- every `state_dict` key and shape are those of the reference
+(vidtok/modules/model_3dcausal.py and model_3dcausal_v1_1.py), so published
+checkpoints load unchanged.  The forward passes are NOT the reference's: activations stay in one
+NDHWC tensor end to end, the ~300 einops rearranges of the reference disappear, padding /
+up-sampling / residual adds / alpha mixes are folded into the HIP convolution kernel (ops.conv)
+and LayerNorm+SiLU is one HIP kernel.  torch.nn.Conv*/LayerNorm objects appear only as parameter
+containers (initialisation + key names); their forward() is never called.
+
+`version` selects the reference variant: "v1_0" = zero causal padding, nearest time up-sampling,
+decoder drops 3 frames; "v1_1" = first-frame-replicate / cached causal padding, trilinear time
+up-sampling, chunk-to-chunk caches (`causal_cache`, `is_first_chunk`, `cache_offset` attributes
+exactly as model_3dcausal_v1_1.py:155-157,212-214 so an engine can drive them).
+"""
+import torch
+import torch.nn as nn
+
+from . import lib as L
+from . import ops
+from .ops import ConvGeom
+from .packing import PackedCache
+
+
+def _check_norm(norm_type):
+    if norm_type != "layernorm":
+        raise NotImplementedError(
+            f"norm_type={norm_type!r}: only 'layernorm' (used by every shipped VidTok config) has a HIP kernel")
+
+
+class LayerNorm(nn.Module):
+    """Parameter holder for the channels-last LayerNorm wrapper (model_3dcausal.py:62-80)."""
+
+    def __init__(self, num_channels, eps=1e-6):
+        super().__init__()
+        self.norm = nn.LayerNorm(num_channels, eps=eps, elementwise_affine=True)
+        self._cache = None
+
+    def affine(self):
+        w, b = self.norm.weight, self.norm.bias
+        key = (w._version, b._version, w.device, w.data_ptr())
+        if self._cache is None or self._cache[0] != key:
+            self._cache = (key, w.detach().float().contiguous(), b.detach().float().contiguous())
+        return self._cache[1], self._cache[2]
+
+    def apply_ndhwc(self, x, silu, dt):
+        g, b = self.affine()
+        return ops.layernorm_act(x, g, b, silu=silu, eps=self.norm.eps, out_dtype=dt)
+
+
+def Normalize(in_channels, norm_type="layernorm"):
+    _check_norm(norm_type)
+    return LayerNorm(in_channels, eps=1e-6)
+
+
+class _CausalState:
+    """v1.1 chunk-to-chunk state shared by the causal convs (model_3dcausal_v1_1.py:155-178)."""
+
+    def _init_state(self):
+        self.is_first_chunk = True
+        self.causal_cache = None
+        self.cache_offset = 0
+
+    def _tmode_and_cache(self, version, time_pad):
+        if version == "v1_0" or time_pad == 0:
+            return L.VT_TPAD_ZERO, None
+        if self.is_first_chunk:
+            return L.VT_TPAD_REPLICATE, None
+        if self.causal_cache is None or self.causal_cache.shape[1] < time_pad:
+            raise RuntimeError("causal cache missing: run the first chunk with is_first_chunk=True")
+        return L.VT_TPAD_CACHE, self.causal_cache
+
+    def _update_cache(self, x, time_pad):
+        """Keep the last `time_pad` frames of padded[:len-cache_offset] where
+        padded = [pad frames (x[0] repeated | previous cache), x]  (model_3dcausal_v1_1.py:172-176)."""
+        if time_pad == 0:
+            return
+        T, off, P = x.shape[1], self.cache_offset, time_pad
+        src_x, src_c = [], []  # (dst slot, frame index)
+        for j in range(P):
+            q = T - off + j            # index into the padded sequence
+            if q >= P:
+                src_x.append((j, q - P))
+            elif q < 0:
+                raise RuntimeError("chunk shorter than cache_offset")
+            elif self.is_first_chunk:
+                src_x.append((j, 0))
+            else:
+                src_c.append((j, q))
+        if not src_c:
+            new = ops.gather_frames(x, [i for _, i in src_x])
+        else:
+            parts = {}
+            got_c = ops.gather_frames(self.causal_cache, [i for _, i in src_c])
+            for n, (j, _) in enumerate(src_c):
+                parts[j] = got_c[:, n:n + 1]
+            if src_x:
+                got_x = ops.gather_frames(x, [i for _, i in src_x])
+                for n, (j, _) in enumerate(src_x):
+                    parts[j] = got_x[:, n:n + 1]
+            new = torch.cat([parts[j] for j in range(P)], dim=1).contiguous()
+        self.causal_cache = new
+
+
+class CausalConv3d(nn.Module, _CausalState):
+    """model_3dcausal.py:162-197 / model_3dcausal_v1_1.py:181-236.  `conv` holds the parameters."""
+
+    def __init__(self, chan_in, chan_out, kernel_size, stride=1, version="v1_0"):
+        super().__init__()
+        ks = kernel_size if isinstance(kernel_size, tuple) else (kernel_size,) * 3
+        st = stride if isinstance(stride, tuple) else (stride,) * 3
+        assert ks[1] % 2 == 1 and ks[2] % 2 == 1
+        self.conv = nn.Conv3d(chan_in, chan_out, ks, stride=st)
+        self.ks, self.strides = ks, st
+        self.time_pad = (ks[0] - 1) + (1 - st[0])
+        self.chan_out = chan_out
+        self.version = version
+        self._pack = PackedCache()
+        self._init_state()
+
+    def geom(self, ups_t=0):
+        kt, kh, kw = self.ks
+        hp, wp = (kh - 1) + (1 - self.strides[1]), (kw - 1) + (1 - self.strides[2])
+        return ConvGeom(kt=kt, kh=kh, kw=kw, st=self.strides[0], sh=self.strides[1], sw=self.strides[2],
+                        pt=self.time_pad, ph=hp // 2, pw=wp // 2, ph_hi=hp - hp // 2, pw_hi=wp - wp // 2,
+                        ups_t=ups_t)
+
+    def run(self, x, dt, *, ups_t=0, **kw):
+        w, b = self._pack.get(self.conv.weight, self.conv.bias, dt, cin_stored=x.shape[-1])
+        tmode, cache = self._tmode_and_cache(self.version, self.time_pad)
+        y = ops.conv(x, w, b, self.geom(ups_t), cout=self.chan_out, tmode=tmode, cache=cache, **kw)
+        if self.version == "v1_1":
+            self._update_cache(x, self.time_pad)
+        return y
+
+
+class CausalConv1d(nn.Module, _CausalState):
+    """model_3dcausal.py:144-159 / model_3dcausal_v1_1.py:144-178 -- k taps along T only."""
+
+    def __init__(self, chan_in, chan_out, kernel_size, stride=1, version="v1_0"):
+        super().__init__()
+        self.conv = nn.Conv1d(chan_in, chan_out, kernel_size, stride=stride)
+        self.k, self.stride = kernel_size, stride
+        self.time_pad = (kernel_size - 1) + (1 - stride)
+        self.chan_out = chan_out
+        self.version = version
+        self._pack = PackedCache()
+        self._init_state()
+
+    def run(self, x, dt, **kw):
+        w, b = self._pack.get(self.conv.weight, self.conv.bias, dt, cin_stored=x.shape[-1])
+        tmode, cache = self._tmode_and_cache(self.version, self.time_pad)
+        g = ConvGeom(kt=self.k, st=self.stride, pt=self.time_pad)
+        y = ops.conv(x, w, b, g, cout=self.chan_out, tmode=tmode, cache=cache, **kw)
+        if self.version == "v1_1":
+            self._update_cache(x, self.time_pad)
+        return y
+
+
+class _Conv2dHolder:
+    """Runs an nn.Conv2d parameter set as a per-frame spatial conv on NDHWC."""
+
+    @staticmethod
+    def run(conv: nn.Conv2d, pack: PackedCache, x, dt, geom: ConvGeom, **kw):
+        w, b = pack.get(conv.weight, conv.bias, dt, cin_stored=x.shape[-1])
+        return ops.conv(x, w, b, geom, cout=conv.out_channels, **kw)
+
+
+_G3x3 = ConvGeom(kh=3, kw=3, ph=1, pw=1, ph_hi=1, pw_hi=1)
+_G1x1 = ConvGeom()
+
+
+class Upsample(nn.Module):
+    """nearest x2 + conv3x3 (model_3dcausal.py:200-212); the up-sampling is folded into the gather."""
+
+    def __init__(self, in_channels, with_conv):
+        super().__init__()
+        if not with_conv:
+            raise NotImplementedError("Upsample(with_conv=False) is not used by any VidTok config")
+        self.with_conv = with_conv
+        self.conv = nn.Conv2d(in_channels, in_channels, kernel_size=3, stride=1, padding=1)
+        self._pack = PackedCache()
+
+    def run(self, x, dt):
+        g = ConvGeom(kh=3, kw=3, ph=1, pw=1, ph_hi=1, pw_hi=1, ups_s=1)
+        return _Conv2dHolder.run(self.conv, self._pack, x, dt, g)
+
+
+class Downsample(nn.Module):
+    """F.pad(0,1,0,1) + conv3x3 stride 2 (model_3dcausal.py:215-230)."""
+
+    def __init__(self, in_channels, with_conv):
+        super().__init__()
+        if not with_conv:
+            raise NotImplementedError("Downsample(with_conv=False) is not used by any VidTok config")
+        self.with_conv = with_conv
+        self.conv = nn.Conv2d(in_channels, in_channels, kernel_size=3, stride=2, padding=0)
+        self._pack = PackedCache()
+
+    def run(self, x, dt):
+        g = ConvGeom(kh=3, kw=3, sh=2, sw=2, ph=0, pw=0, ph_hi=1, pw_hi=1)
+        return _Conv2dHolder.run(self.conv, self._pack, x, dt, g)
+
+
+class TimeDownsampleResCausal2x(nn.Module):
+    """alpha*avgpool3(stride 2) + (1-alpha)*causal conv3d stride (2,1,1)
+    (model_3dcausal.py:233-252, v1.1 model_3dcausal_v1_1.py:272-302)."""
+
+    def __init__(self, in_channels, out_channels, mix_factor: float = 2.0, version="v1_0"):
+        super().__init__()
+        self.conv = CausalConv3d(in_channels, out_channels, 3, stride=(2, 1, 1), version=version)
+        self.mix_factor = nn.Parameter(torch.Tensor([mix_factor]))
+        self.version = version
+        self.is_first_chunk = True
+        self.causal_cache = None
+
+    def run(self, x, dt):
+        if self.version == "v1_0":
+            x1 = ops.time_avgpool3s2(x, L.VT_TPAD_ZERO)
+        else:
+            if self.is_first_chunk:
+                x1 = ops.time_avgpool3s2(x, L.VT_TPAD_REPLICATE)
+            else:
+                x1 = ops.time_avgpool3s2(x, L.VT_TPAD_CACHE, cache=self.causal_cache)
+            self.causal_cache = ops.gather_frames(x, [x.shape[1] - 1])
+        return self.conv.run(x, dt, res=x1, res_mode=L.VT_RES_MIX, mix_factor=self.mix_factor.detach())
+
+
+class TimeUpsampleResCausal2x(nn.Module):
+    """alpha*up(x) + (1-alpha)*causal conv3d(up(x)); up = nearest (v1.0, folded into the conv's
+    gather and into the mix operand's time index) or trilinear with a frame cache (v1.1)
+    (model_3dcausal.py:255-273, model_3dcausal_v1_1.py:305-343)."""
+
+    def __init__(self, in_channels, out_channels, mix_factor: float = 2.0, interpolation_mode="nearest",
+                 num_temp_upsample=1, version="v1_0"):
+        super().__init__()
+        self.conv = CausalConv3d(in_channels, out_channels, 3, version=version)
+        self.mix_factor = nn.Parameter(torch.Tensor([mix_factor]))
+        self.interpolation_mode = interpolation_mode
+        self.num_temp_upsample = num_temp_upsample
+        self.enable_cached = interpolation_mode == "trilinear"
+        self.version = version
+        self.is_first_chunk = True
+        self.causal_cache = None
+
+    def _interp_v11(self, x):
+        n, T = self.num_temp_upsample, x.shape[1]
+        if not self.enable_cached:
+            return ops.gather_frames(x, [t // 2 for t in range(2 * T)])
+        if not self.is_first_chunk:
+            xc = torch.cat([self.causal_cache, x], dim=1).contiguous()
+            Tc = xc.shape[1]
+            self.causal_cache = ops.gather_frames(xc, list(range(max(0, Tc - 2 * n), Tc - n)))
+            up = ops.time_lerp2x(xc)
+            return ops.gather_frames(up, list(range(2 * n, 2 * Tc)))
+        self.causal_cache = ops.gather_frames(x, list(range(max(0, T - n), T)))
+        head = ops.time_lerp2x(ops.gather_frames(x, list(range(0, min(n, T)))))
+        if T > n:
+            tail = ops.time_lerp2x(ops.gather_frames(x, list(range(n, T))))
+            return torch.cat([head, tail], dim=1).contiguous()
+        return head
+
+    def run(self, x, dt):
+        mf = self.mix_factor.detach()
+        if self.version == "v1_0":
+            return self.conv.run(x, dt, ups_t=1, res=x, res_mode=L.VT_RES_MIX, res_tshift=1, mix_factor=mf)
+        xi = self._interp_v11(x)
+        return self.conv.run(xi, dt, res=xi, res_mode=L.VT_RES_MIX, mix_factor=mf)
+
+
+class ResnetBlock(nn.Module):
+    """Per-frame spatial block LN-SiLU-conv3x3-LN-SiLU-conv3x3 (+1x1 shortcut) + x
+    (model_3dcausal.py:276-337)."""
+
+    def __init__(self, *, in_channels, out_channels=None, conv_shortcut=False, dropout=0.0, temb_channels=0,
+                 use_checkpoint=False, norm_type="layernorm"):
+        super().__init__()
+        assert temb_channels == 0 and not conv_shortcut
+        out_channels = in_channels if out_channels is None else out_channels
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.norm1 = Normalize(in_channels, norm_type)
+        self.conv1 = nn.Conv2d(in_channels, out_channels, kernel_size=3, stride=1, padding=1)
+        self.norm2 = Normalize(out_channels, norm_type)
+        self.conv2 = nn.Conv2d(out_channels, out_channels, kernel_size=3, stride=1, padding=1)
+        if in_channels != out_channels:
+            self.nin_shortcut = nn.Conv2d(in_channels, out_channels, kernel_size=1, stride=1, padding=0)
+        self._p1, self._p2, self._p3 = PackedCache(), PackedCache(), PackedCache()
+
+    def run(self, x, dt):
+        h = self.norm1.apply_ndhwc(x, True, dt)
+        h = _Conv2dHolder.run(self.conv1, self._p1, h, dt, _G3x3)
+        h = self.norm2.apply_ndhwc(h, True, dt)
+        if self.in_channels != self.out_channels:
+            x = _Conv2dHolder.run(self.nin_shortcut, self._p3, x, dt, _G1x1)
+        return _Conv2dHolder.run(self.conv2, self._p2, h, dt, _G3x3, res=x, res_mode=L.VT_RES_ADD)
+
+
+class ResnetCausalBlock(nn.Module):
+    """3-D causal residual block of the mid section (model_3dcausal.py:340-424)."""
+
+    def __init__(self, *, in_channels, out_channels=None, conv_shortcut=False, dropout=0.0, temb_channels=0,
+                 use_checkpoint=False, norm_type="layernorm", version="v1_0"):
+        super().__init__()
+        assert temb_channels == 0 and not conv_shortcut
+        out_channels = in_channels if out_channels is None else out_channels
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.norm1 = Normalize(in_channels, norm_type)
+        self.conv1 = CausalConv3d(in_channels, out_channels, 3, version=version)
+        self.norm2 = Normalize(out_channels, norm_type)
+        self.conv2 = CausalConv3d(out_channels, out_channels, 3, version=version)
+        if in_channels != out_channels:
+            self.nin_shortcut = CausalConv3d(in_channels, out_channels, 1, version=version)
+
+    def run(self, x, dt):
+        h = self.norm1.apply_ndhwc(x, True, dt)
+        h = self.conv1.run(h, dt)
+        h = self.norm2.apply_ndhwc(h, True, dt)
+        if self.in_channels != self.out_channels:
+            x = self.nin_shortcut.run(x, dt)
+        return self.conv2.run(h, dt, res=x, res_mode=L.VT_RES_ADD)
+
+
+class ResnetCausalBlock1D(nn.Module):
+    """Temporal residual block: per-position LN-SiLU-causal conv1d x2 + x; conv2 is zero-initialised
+    (model_3dcausal.py:427-499).  On NDHWC the "(b h w) c t" view of the reference is just a conv
+    whose taps run along T."""
+
+    def __init__(self, *, in_channels, out_channels=None, conv_shortcut=False, dropout=0.0, temb_channels=0,
+                 zero_init=False, use_checkpoint=False, norm_type="layernorm", version="v1_0"):
+        super().__init__()
+        assert temb_channels == 0 and not conv_shortcut
+        out_channels = in_channels if out_channels is None else out_channels
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.norm1 = Normalize(in_channels, norm_type)
+        self.conv1 = CausalConv1d(in_channels, out_channels, 3, version=version)
+        self.norm2 = Normalize(out_channels, norm_type)
+        self.conv2 = CausalConv1d(out_channels, out_channels, 3, version=version)
+        if in_channels != out_channels:
+            self.nin_shortcut = CausalConv1d(in_channels, out_channels, 1, version=version)
+        if zero_init:
+            self.conv2.conv.weight.data.zero_()
+            self.conv2.conv.bias.data.zero_()
+
+    def run(self, x, dt):
+        h = self.norm1.apply_ndhwc(x, True, dt)
+        h = self.conv1.run(h, dt)
+        h = self.norm2.apply_ndhwc(h, True, dt)
+        if self.in_channels != self.out_channels:
+            x = self.nin_shortcut.run(x, dt)
+        return self.conv2.run(h, dt, res=x, res_mode=L.VT_RES_ADD)
+
+
+class AttnBlockWrapper(nn.Module):
+    """Per-frame spatial self-attention (model_3dcausal.py:83-141): LN, q/k/v 1x1x1, softmax(QK^T/sqrt(C))V
+    with "heads" = frames, proj_out, + x.  Q K^T and P V run on the MFMA GEMM kernel (ops.gemm_nt),
+    the softmax on a wave-shuffle kernel; V^T is produced directly by swapping the GEMM operands
+    (W_v as the row operand), and v's bias is added after P V (rows of P sum to 1)."""
+
+    def __init__(self, in_channels, use_checkpoint=False, norm_type="layernorm", version="v1_0"):
+        super().__init__()
+        self.in_channels = in_channels
+        self.norm = Normalize(in_channels, norm_type)
+        self.q = CausalConv3d(in_channels, in_channels, 1, version=version)
+        self.k = CausalConv3d(in_channels, in_channels, 1, version=version)
+        self.v = CausalConv3d(in_channels, in_channels, 1, version=version)
+        self.proj_out = CausalConv3d(in_channels, in_channels, 1, version=version)
+
+    def run(self, x, dt):
+        B, T, H, W, Cc = x.shape
+        S, Z = H * W, B * T
+        hn = self.norm.apply_ndhwc(x, False, dt)
+        q = self.q.run(hn, dt).view(Z, S, Cc)
+        k = self.k.run(hn, dt).view(Z, S, Cc)
+        wv, bv = self.v._pack.get(self.v.conv.weight, self.v.conv.bias, dt, cin_stored=Cc)
+        vT = ops.gemm_nt(wv.view(1, Cc, Cc), hn.view(Z, S, Cc))                               # [Z, C, S]
+        s = ops.gemm_nt(q, k, out_dtype=torch.float32)                                         # [Z, S, S]
+        p = ops.softmax_rows(s, float(Cc) ** -0.5, dt)
+        o = ops.gemm_nt(p, vT, bias=bv).view(B, T, H, W, Cc)
+        return self.proj_out.run(o, dt, res=x, res_mode=L.VT_RES_ADD)
+
+
+def _level_module():
+    m = nn.Module()
+    m.block = nn.ModuleList()
+    m.attn = nn.ModuleList()
+    return m
+
+
+class EncoderCausal3DPadding(nn.Module):
+    """EncoderCausal3D + EncoderCausal3DPadding of the reference (model_3dcausal.py:502-689,
+    v1.1 model_3dcausal_v1_1.py:745-760).  forward(x NCTHW fp32) -> h NCTHW fp32."""
+
+    version = "v1_0"
+
+    def __init__(self, *, ch, out_ch, ch_mult=(1, 2, 4, 8), spatial_ds=None, tempo_ds=None, num_res_blocks,
+                 dropout=0.0, resamp_with_conv=True, in_channels, z_channels, double_z=True,
+                 norm_type="layernorm", **ignore_kwargs):
+        super().__init__()
+        _check_norm(norm_type)
+        v = self.version
+        self.ch, self.temb_ch = ch, 0
+        self.num_resolutions = len(ch_mult)
+        self.num_res_blocks = num_res_blocks
+        self.in_channels = in_channels
+        self.norm_type = norm_type
+        self.fix_encoder = ignore_kwargs.get("fix_encoder", False)
+        self.is_causal = True
+        self.time_downsample_factor = ignore_kwargs.get("time_downsample_factor", 4)
+        self.init_pad_mode = ignore_kwargs.get("init_pad_mode", "replicate")
+        if self.init_pad_mode != "replicate":
+            raise NotImplementedError("init_pad_mode other than 'replicate' is not used by any VidTok config")
+        self.time_padding = self.time_downsample_factor - 1
+        self.out_channels = 2 * z_channels if double_z else z_channels
+        self.compute_dtype = torch.float32
+
+        self.conv_in = CausalConv3d(in_channels, ch, 3, version=v)
+        in_ch_mult = (1,) + tuple(ch_mult)
+        self.spatial_ds = list(range(0, self.num_resolutions - 1)) if spatial_ds is None else list(spatial_ds)
+        self.tempo_ds = ([self.num_resolutions - 2, self.num_resolutions - 3] if tempo_ds is None else list(tempo_ds))
+        self.down, self.down_temporal = nn.ModuleList(), nn.ModuleList()
+        block_in = ch
+        for i_level in range(self.num_resolutions):
+            block_in = ch * in_ch_mult[i_level]
+            block_out = ch * ch_mult[i_level]
+            down, down_t = _level_module(), _level_module()
+            for _ in range(num_res_blocks):
+                down.block.append(ResnetBlock(in_channels=block_in, out_channels=block_out, norm_type=norm_type))
+                down_t.block.append(ResnetCausalBlock1D(in_channels=block_out, out_channels=block_out,
+                                                        zero_init=True, norm_type=norm_type, version=v))
+                block_in = block_out
+            if i_level in self.spatial_ds:
+                down.downsample = Downsample(block_in, resamp_with_conv)
+                if i_level in self.tempo_ds:
+                    down_t.downsample = TimeDownsampleResCausal2x(block_in, block_in, version=v)
+            self.down.append(down)
+            self.down_temporal.append(down_t)
+        self.mid = nn.Module()
+        self.mid.block_1 = ResnetCausalBlock(in_channels=block_in, out_channels=block_in, norm_type=norm_type, version=v)
+        self.mid.attn_1 = AttnBlockWrapper(block_in, norm_type=norm_type, version=v)
+        self.mid.block_2 = ResnetCausalBlock(in_channels=block_in, out_channels=block_in, norm_type=norm_type, version=v)
+        self.norm_out = Normalize(block_in, norm_type)
+        self.conv_out = CausalConv3d(block_in, self.out_channels, 3, version=v)
+        if self.fix_encoder:
+            for p in self.parameters():
+                p.requires_grad = False
+
+    def _front_pad(self, T):
+        f = self.time_downsample_factor
+        if T % f == 0:
+            return 0
+        return self.time_padding if self.version == "v1_0" else f - T % f
+
+    @torch.no_grad()
+    def forward(self, x):
+        assert x.dim() == 5, "input should be 5D tensor, but got {}D tensor".format(x.dim())
+        dt = self.compute_dtype
+        h = ops.ncthw_to_ndhwc(x.contiguous().float(), dt, tpad=self._front_pad(x.shape[2]))
+        h = self.conv_in.run(h, dt)
+        for i_level in range(self.num_resolutions):
+            for i_block in range(self.num_res_blocks):
+                h = self.down[i_level].block[i_block].run(h, dt)
+                h = self.down_temporal[i_level].block[i_block].run(h, dt)
+            if i_level in self.spatial_ds:
+                h = self.down[i_level].downsample.run(h, dt)
+                if i_level in self.tempo_ds:
+                    h = self.down_temporal[i_level].downsample.run(h, dt)
+        h = self.mid.block_1.run(h, dt)
+        h = self.mid.attn_1.run(h, dt)
+        h = self.mid.block_2.run(h, dt)
+        h = self.norm_out.apply_ndhwc(h, True, dt)
+        return self.conv_out.run(h, dt, out_layout=L.VT_NCTHW)
+
+
+class DecoderCausal3DPadding(nn.Module):
+    """DecoderCausal3D + DecoderCausal3DPadding (model_3dcausal.py:692-885, v1.1
+    model_3dcausal_v1_1.py:767-959).  forward(z NCTHW fp32) -> x_hat NCTHW fp32."""
+
+    version = "v1_0"
+
+    def __init__(self, *, ch, out_ch, ch_mult=(1, 2, 4, 8), spatial_us=None, tempo_us=None, num_res_blocks,
+                 dropout=0.0, resamp_with_conv=True, in_channels, z_channels, give_pre_end=False, tanh_out=False,
+                 norm_type="layernorm", **ignorekwargs):
+        super().__init__()
+        _check_norm(norm_type)
+        if give_pre_end or tanh_out:
+            raise NotImplementedError("give_pre_end / tanh_out are never set by a VidTok config")
+        v = self.version
+        self.ch, self.temb_ch = ch, 0
+        self.num_resolutions = len(ch_mult)
+        self.num_res_blocks = num_res_blocks
+        self.in_channels = in_channels
+        self.out_ch = out_ch
+        self.norm_type = norm_type
+        self.fix_decoder = ignorekwargs.get("fix_decoder", False)
+        self.interpolation_mode = ignorekwargs.get("interpolation_mode", "nearest") if v == "v1_1" else "nearest"
+        assert self.interpolation_mode in ["nearest", "trilinear"]
+        self.time_downsample_factor = ignorekwargs.get("time_downsample_factor", 4)
+        self.time_padding = self.time_downsample_factor - 1
+        self.compute_dtype = torch.float32
+
+        block_in = ch * ch_mult[self.num_resolutions - 1]
+        self.conv_in = CausalConv3d(z_channels, block_in, 3, version=v)
+        self.mid = nn.Module()
+        self.mid.block_1 = ResnetCausalBlock(in_channels=block_in, out_channels=block_in, norm_type=norm_type, version=v)
+        self.mid.attn_1 = AttnBlockWrapper(block_in, norm_type=norm_type, version=v)
+        self.mid.block_2 = ResnetCausalBlock(in_channels=block_in, out_channels=block_in, norm_type=norm_type, version=v)
+
+        self.spatial_us = list(range(1, self.num_resolutions)) if spatial_us is None else list(spatial_us)
+        self.tempo_us = [1, 2] if tempo_us is None else list(tempo_us)
+        self.up = nn.ModuleList()
+        for i_level in reversed(range(self.num_resolutions)):
+            up = _level_module()
+            block_out = ch * ch_mult[i_level]
+            for _ in range(num_res_blocks + 1):
+                up.block.append(ResnetBlock(in_channels=block_in, out_channels=block_out, norm_type=norm_type))
+                block_in = block_out
+            if i_level in self.spatial_us:
+                up.upsample = Upsample(block_in, resamp_with_conv)
+            self.up.insert(0, up)
+        self.up_temporal = nn.ModuleList()
+        num_temp_upsample = 1
+        for i_level in reversed(range(self.num_resolutions)):
+            up_t = _level_module()
+            c = ch * ch_mult[i_level]
+            for _ in range(num_res_blocks + 1):
+                up_t.block.append(ResnetCausalBlock1D(in_channels=c, out_channels=c, zero_init=True,
+                                                      norm_type=norm_type, version=v))
+            if i_level in self.tempo_us:
+                up_t.upsample = TimeUpsampleResCausal2x(c, c, interpolation_mode=self.interpolation_mode,
+                                                        num_temp_upsample=num_temp_upsample, version=v)
+                num_temp_upsample *= 2
+            self.up_temporal.insert(0, up_t)
+        self.norm_out = Normalize(block_in, norm_type)
+        self.conv_out = CausalConv3d(block_in, out_ch, 3, version=v)
+        if self.fix_decoder:
+            for p in self.parameters():
+                p.requires_grad = False
+
+    def get_last_layer(self, **kwargs):
+        return self.conv_out.conv.weight
+
+    @torch.no_grad()
+    def forward(self, z):
+        dt = self.compute_dtype
+        h = ops.ncthw_to_ndhwc(z.contiguous().float(), dt)
+        h = self.conv_in.run(h, dt)
+        h = self.mid.block_1.run(h, dt)
+        h = self.mid.attn_1.run(h, dt)
+        h = self.mid.block_2.run(h, dt)
+        for i_level in reversed(range(self.num_resolutions)):
+            for i_block in range(self.num_res_blocks + 1):
+                h = self.up[i_level].block[i_block].run(h, dt)
+                h = self.up_temporal[i_level].block[i_block].run(h, dt)
+            if i_level in self.spatial_us:
+                h = self.up[i_level].upsample.run(h, dt)
+                if i_level in self.tempo_us:
+                    h = self.up_temporal[i_level].upsample.run(h, dt)
+        h = self.norm_out.apply_ndhwc(h, True, dt)
+        trim = self.time_padding if self.version == "v1_0" else 0
+        return self.conv_out.run(h, dt, out_layout=L.VT_NCTHW, t_trim=trim)
+
+
+class EncoderCausal3DPaddingV11(EncoderCausal3DPadding):
+    version = "v1_1"
+
+
+class DecoderCausal3DPaddingV11(DecoderCausal3DPadding):
+    version = "v1_1"

@@ -1,0 +1,302 @@
+"""Torch-tensor facing wrappers of the C-ABI operators (include/vidtok_amd.h).
+
+PyTorch is plumbing here: tensors provide device memory and the current HIP stream; every
+arithmetic operation of the path is one of the HIP kernels in vidtok_amd/csrc.  All wrappers
+raise if the tensors are not on a GPU -- there is no CPU implementation in the product.
+
+Activation tensors are NDHWC: shape [B, T, H, W, C], contiguous, float32 or bfloat16.
+"""
+import ctypes as C
+from dataclasses import dataclass
+from typing import Optional
+
+import torch
+
+from . import lib as L
+
+_DT = {torch.float32: L.VT_F32, torch.bfloat16: L.VT_BF16}
+CH_ALIGN = 8  # channel padding granule: 16 B of bf16 (and a multiple of the 4-float fp32 granule)
+
+
+def pad_channels(c: int) -> int:
+    return (c + CH_ALIGN - 1) // CH_ALIGN * CH_ALIGN
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _chk(t: torch.Tensor, name: str):
+    if not t.is_cuda:
+        raise L.VtError(f"{name}: tensor is on {t.device}; vidtok_amd runs on the GPU only (no CPU fallback)")
+    if not t.is_contiguous():
+        raise L.VtError(f"{name}: tensor must be contiguous")
+
+
+@dataclass(frozen=True)
+class ConvGeom:
+    """Static geometry of one convolution (see vt_conv in include/vidtok_amd.h)."""
+
+    kt: int = 1
+    kh: int = 1
+    kw: int = 1
+    st: int = 1
+    sh: int = 1
+    sw: int = 1
+    pt: int = 0        # causal front pad in time (taps that fall before frame 0)
+    ph: int = 0        # top / left pad
+    pw: int = 0
+    ph_hi: int = 0     # bottom / right pad (zeros)
+    pw_hi: int = 0
+    ups_t: int = 0     # nearest x2 folded into the gather
+    ups_s: int = 0
+
+    def out_dims(self, Ti, Hi, Wi):
+        Tv, Hv, Wv = Ti << self.ups_t, Hi << self.ups_s, Wi << self.ups_s
+        To = (Tv + self.pt - self.kt) // self.st + 1
+        Ho = (Hv + self.ph + self.ph_hi - self.kh) // self.sh + 1
+        Wo = (Wv + self.pw + self.pw_hi - self.kw) // self.sw + 1
+        return To, Ho, Wo
+
+
+def conv(x, w, bias, geom: ConvGeom, *, cout: int, out_dtype=None, tmode=L.VT_TPAD_ZERO, cache=None,
+         res=None, res_mode=L.VT_RES_NONE, res_tshift=0, mix_factor=None, out_layout=L.VT_NDHWC,
+         t_trim=0, ldy=None):
+    """y = conv(x) (+bias) (+res | alpha-mix); x [B,Ti,Hi,Wi,Cin], w packed [cout, ldw]."""
+    lib = L.load()
+    _chk(x, "conv.x"); _chk(w, "conv.w")
+    B, Ti, Hi, Wi, Cin = x.shape
+    assert w.dtype == x.dtype and x.dtype in _DT, (w.dtype, x.dtype)
+    out_dtype = out_dtype or x.dtype
+    To, Ho, Wo = geom.out_dims(Ti, Hi, Wi)
+    assert To > 0 and Ho > 0 and Wo > 0, (To, Ho, Wo)
+    if out_layout == L.VT_NCTHW:
+        y = torch.empty((B, cout, To - t_trim, Ho, Wo), dtype=torch.float32, device=x.device)
+        out_dtype = torch.float32
+        ldy = cout
+    else:
+        ldy = ldy or pad_channels(cout)
+        if ldy != cout:  # keep the pad lanes defined (they feed the next conv's zero weights)
+            y = torch.zeros((B, To, Ho, Wo, ldy), dtype=out_dtype, device=x.device)
+        else:
+            y = torch.empty((B, To, Ho, Wo, ldy), dtype=out_dtype, device=x.device)
+    d = L.ConvDesc()
+    d.x, d.w, d.bias, d.y = x.data_ptr(), w.data_ptr(), (bias.data_ptr() if bias is not None else None), y.data_ptr()
+    if bias is not None:
+        assert bias.dtype == torch.float32 and bias.numel() >= cout
+    d.B, d.Ti, d.Hi, d.Wi, d.Cin = B, Ti, Hi, Wi, Cin
+    d.To, d.Ho, d.Wo, d.Cout = To, Ho, Wo, cout
+    d.ldw, d.ldy = w.shape[1], ldy
+    d.KT, d.KH, d.KW = geom.kt, geom.kh, geom.kw
+    d.st, d.sh, d.sw = geom.st, geom.sh, geom.sw
+    d.pt, d.ph, d.pw = geom.pt, geom.ph, geom.pw
+    d.tmode = tmode
+    if cache is not None:
+        _chk(cache, "conv.cache")
+        assert cache.dtype == x.dtype and cache.shape[0] == B and tuple(cache.shape[2:]) == (Hi, Wi, Cin), cache.shape
+        d.cache, d.ncache = cache.data_ptr(), cache.shape[1]
+    d.ups_t, d.ups_s = geom.ups_t, geom.ups_s
+    d.res_mode = res_mode
+    if res_mode != L.VT_RES_NONE:
+        _chk(res, "conv.res")
+        assert res.dtype == out_dtype, (res.dtype, out_dtype)
+        assert res.shape[0] == B and tuple(res.shape[2:4]) == (Ho, Wo) and res.shape[4] >= cout, (res.shape, y.shape)
+        d.res, d.res_tshift, d.Tr, d.ldr = res.data_ptr(), res_tshift, res.shape[1], res.shape[4]
+        if res_mode == L.VT_RES_MIX:
+            assert mix_factor is not None and mix_factor.dtype == torch.float32 and mix_factor.is_cuda
+            d.mix_factor = mix_factor.data_ptr()
+    d.out_layout, d.t_trim = out_layout, t_trim
+    d.dtype, d.out_dtype = _DT[x.dtype], _DT[out_dtype]
+    d.nbatch = 1
+    L.check(lib.vt_conv(C.byref(d), _stream()), "vt_conv")
+    return y
+
+
+def gemm_nt(a, b, *, out_dtype=None, bias=None):
+    """Batched C[z] = A[z] @ B[z]^T : a [Z or 1, M, K], b [Z, N, K] -> [Z, M, N] (the two matmuls of
+    scaled_dot_product_attention, reference model_3dcausal.py:140) on the vt_conv kernel.
+    a with leading dim 1 is broadcast over Z (stride 0)."""
+    lib = L.load()
+    _chk(a, "gemm.a"); _chk(b, "gemm.b")
+    Za, M, K = a.shape
+    Z, N, Kb = b.shape
+    assert Za in (1, Z) and K == Kb and a.dtype == b.dtype
+    out_dtype = out_dtype or a.dtype
+    y = torch.empty((Z, M, N), dtype=out_dtype, device=a.device)
+    d = L.ConvDesc()
+    d.x, d.w, d.y = a.data_ptr(), b.data_ptr(), y.data_ptr()
+    d.bias = bias.data_ptr() if bias is not None else None
+    d.B, d.Ti, d.Hi, d.Wi, d.Cin = 1, 1, 1, M, K
+    d.To, d.Ho, d.Wo, d.Cout = 1, 1, M, N
+    d.ldw, d.ldy = K, N
+    d.KT = d.KH = d.KW = 1
+    d.st = d.sh = d.sw = 1
+    d.dtype, d.out_dtype = _DT[a.dtype], _DT[out_dtype]
+    d.nbatch = Z
+    d.xs_z, d.ws_z, d.ys_z = (M * K if Za == Z else 0), N * K, M * N
+    L.check(lib.vt_conv(C.byref(d), _stream()), "vt_conv(gemm)")
+    return y
+
+
+def layernorm_act(x, gamma, beta, *, silu: bool, eps: float = 1e-6, out_dtype=None, c: int = None):
+    """Per-position LayerNorm over the last dim (+SiLU)."""
+    lib = L.load()
+    _chk(x, "layernorm.x")
+    ld = x.shape[-1]
+    c = c or ld
+    M = x.numel() // ld
+    out_dtype = out_dtype or x.dtype
+    y = torch.empty(x.shape, dtype=out_dtype, device=x.device) if c == ld else torch.zeros(
+        x.shape, dtype=out_dtype, device=x.device)
+    assert gamma.dtype == torch.float32 and beta.dtype == torch.float32 and gamma.numel() == c
+    L.check(lib.vt_layernorm_act(_ptr(x), _DT[x.dtype], ld, _ptr(y), _DT[out_dtype], ld, _ptr(gamma), _ptr(beta),
+                                 M, c, float(eps), int(bool(silu)), _stream()), "vt_layernorm_act")
+    return y
+
+
+def softmax_rows(s, scale: float, out_dtype):
+    lib = L.load()
+    _chk(s, "softmax.s")
+    assert s.dtype == torch.float32
+    cols = s.shape[-1]
+    rows = s.numel() // cols
+    p = torch.empty(s.shape, dtype=out_dtype, device=s.device)
+    L.check(lib.vt_softmax_rows(_ptr(s), _ptr(p), _DT[out_dtype], rows, cols, cols, float(scale), _stream()),
+            "vt_softmax_rows")
+    return p
+
+
+def ncthw_to_ndhwc(x, dtype, tpad: int = 0, ld: int = None):
+    lib = L.load()
+    _chk(x, "ncthw_to_ndhwc.x")
+    assert x.dtype == torch.float32 and x.dim() == 5
+    B, Cc, T, H, W = x.shape
+    ld = ld or pad_channels(Cc)
+    y = torch.empty((B, T + tpad, H, W, ld), dtype=dtype, device=x.device)
+    L.check(lib.vt_ncthw_to_ndhwc(_ptr(x), _ptr(y), _DT[dtype], B, Cc, T, H, W, ld, tpad, _stream()),
+            "vt_ncthw_to_ndhwc")
+    return y
+
+
+def ndhwc_to_ncthw(x, c: int, ttrim: int = 0):
+    lib = L.load()
+    _chk(x, "ndhwc_to_ncthw.x")
+    B, T, H, W, ld = x.shape
+    y = torch.empty((B, c, T - ttrim, H, W), dtype=torch.float32, device=x.device)
+    L.check(lib.vt_ndhwc_to_ncthw(_ptr(x), _DT[x.dtype], _ptr(y), B, c, T, H, W, ld, ttrim, _stream()),
+            "vt_ndhwc_to_ncthw")
+    return y
+
+
+def time_avgpool3s2(x, tmode=L.VT_TPAD_ZERO, cache=None):
+    lib = L.load()
+    _chk(x, "avgpool.x")
+    B, Ti, H, W, Cc = x.shape
+    y = torch.empty((B, Ti // 2, H, W, Cc), dtype=x.dtype, device=x.device)
+    if cache is not None:
+        _chk(cache, "avgpool.cache")
+        assert cache.dtype == x.dtype and cache.numel() == B * H * W * Cc
+    L.check(lib.vt_time_avgpool3s2(_ptr(x), _ptr(cache), _ptr(y), _DT[x.dtype], B, Ti, H * W, Cc, tmode, _stream()),
+            "vt_time_avgpool3s2")
+    return y
+
+
+def time_lerp2x(x):
+    lib = L.load()
+    _chk(x, "lerp.x")
+    B, Ti, H, W, Cc = x.shape
+    y = torch.empty((B, 2 * Ti, H, W, Cc), dtype=x.dtype, device=x.device)
+    L.check(lib.vt_time_lerp2x(_ptr(x), _ptr(y), _DT[x.dtype], B, Ti, H * W * Cc, _stream()), "vt_time_lerp2x")
+    return y
+
+
+def gather_frames(src, idx):
+    """dst[:, j] = src[:, idx[j]] along dim 1 of an NDHWC tensor (v1.1 cache maintenance)."""
+    lib = L.load()
+    _chk(src, "gather.src")
+    B, Ts = src.shape[:2]
+    n = len(idx)
+    assert n >= 1 and all(0 <= i < Ts for i in idx), (idx, Ts)
+    frame = src[0, 0].numel()
+    dst = torch.empty((B, n) + tuple(src.shape[2:]), dtype=src.dtype, device=src.device)
+    arr = (C.c_int32 * n)(*idx)
+    L.check(lib.vt_gather_frames(_ptr(src), _ptr(dst), src.element_size(), B, frame, Ts * frame, n * frame, arr, n,
+                                 _stream()), "vt_gather_frames")
+    return dst
+
+
+def _levels_arr(levels):
+    return (C.c_int32 * len(levels))(*[int(v) for v in levels])
+
+
+def kl_sample(h, noise):
+    """h [B, 2*zc, T, H, W] fp32 NCTHW -> (z [B, zc, T, H, W], kl 0-dim)."""
+    lib = L.load()
+    _chk(h, "kl.h")
+    assert h.dtype == torch.float32
+    B, c2 = h.shape[:2]
+    zc = c2 // 2
+    S = h[0, 0].numel()
+    z = torch.empty((B, zc) + tuple(h.shape[2:]), dtype=torch.float32, device=h.device)
+    kl = torch.empty((), dtype=torch.float32, device=h.device)
+    if noise is not None:
+        _chk(noise, "kl.noise")
+        assert noise.shape == z.shape and noise.dtype == torch.float32
+    L.check(lib.vt_kl_sample(_ptr(h), _ptr(noise), _ptr(z), _ptr(kl), B, zc, S, _stream()), "vt_kl_sample")
+    return z, kl
+
+
+def fsq_quantize(h, levels):
+    lib = L.load()
+    _chk(h, "fsq.h")
+    assert h.dtype == torch.float32
+    B, D = h.shape[:2]
+    assert D == len(levels)
+    S = h[0, 0].numel()
+    z = torch.empty_like(h)
+    idx = torch.empty((B,) + tuple(h.shape[2:]), dtype=torch.int32, device=h.device)
+    L.check(lib.vt_fsq_quantize(_ptr(h), _ptr(z), _ptr(idx), _levels_arr(levels), D, B, S, _stream()),
+            "vt_fsq_quantize")
+    return z, idx
+
+
+def fsq_indices_to_codes(idx, levels):
+    lib = L.load()
+    _chk(idx, "fsq.indices")
+    assert idx.dtype == torch.int32
+    B = idx.shape[0]
+    D = len(levels)
+    S = idx[0].numel()
+    z = torch.empty((B, D) + tuple(idx.shape[1:]), dtype=torch.float32, device=idx.device)
+    L.check(lib.vt_fsq_indices_to_codes(_ptr(idx), _ptr(z), _levels_arr(levels), D, B, S, _stream()),
+            "vt_fsq_indices_to_codes")
+    return z
+
+
+def fsq_aux_stats(h, levels, inv_temperature: float = 100.0):
+    """-> fp32 tensor [3]: per-sample entropy, codebook entropy, commitment loss."""
+    lib = L.load()
+    _chk(h, "fsq.h")
+    B, D = h.shape[:2]
+    S = h[0, 0].numel()
+    arr = _levels_arr(levels)
+    nwork = lib.vt_fsq_aux_work_floats(arr, D, B, S)
+    work = torch.empty((nwork,), dtype=torch.float32, device=h.device)
+    out = torch.empty((3,), dtype=torch.float32, device=h.device)
+    L.check(lib.vt_fsq_aux_stats(_ptr(h), arr, D, B, S, float(inv_temperature), _ptr(work), _ptr(out), _stream()),
+            "vt_fsq_aux_stats")
+    return out
+
+
+def fsq_consts(levels):
+    """Host-only: (half_l, offset, shift, basis) lists as the kernels use them."""
+    lib = L.load()
+    D = len(levels)
+    out = (C.c_float * (4 * D))()
+    L.check(lib.vt_fsq_consts(_levels_arr(levels), D, out), "vt_fsq_consts")
+    v = list(out)
+    return v[:D], v[D:2 * D], v[2 * D:3 * D], v[3 * D:]

@@ -1,0 +1,117 @@
+"""KL and FSQ regularizers with the reference's module API (vidtok/modules/regularizers.py:74-268),
+computed by the HIP kernels vt_kl_sample / vt_fsq_* on the NCTHW fp32 latent."""
+from typing import Any, List, Optional, Tuple
+
+import torch
+import torch.nn as nn
+
+from . import ops
+
+
+class DiagonalGaussianRegularizer(nn.Module):
+    """regularizers.py:74-92 + distributions.py:5-28.
+
+    `noise_source="host"` (default) reproduces the reference bit-for-bit in its use of the RNG:
+    one `torch.randn(mean.shape)` on the CPU default generator per call, uploaded to the device
+    (distributions.py:16-18).  `noise_source="device"` draws the noise with the device generator
+    instead (no host round trip; hipGraph-capturable) -- same distribution, different stream.
+    """
+
+    def __init__(self, sample: bool = True, noise_source: str = "host"):
+        super().__init__()
+        self.sample = sample
+        assert noise_source in ("host", "device")
+        self.noise_source = noise_source
+
+    def get_trainable_parameters(self) -> Any:
+        yield from ()
+
+    @torch.no_grad()
+    def forward(self, z: torch.Tensor, n_steps=None) -> Tuple[torch.Tensor, dict]:
+        assert z.dim() >= 3 and z.shape[1] % 2 == 0
+        shape = (z.shape[0], z.shape[1] // 2) + tuple(z.shape[2:])
+        noise = None
+        if self.sample:
+            if self.noise_source == "host":
+                noise = torch.randn(shape).to(device=z.device)
+            else:
+                noise = torch.randn(shape, device=z.device, dtype=torch.float32)
+        zs, kl = ops.kl_sample(z.contiguous(), noise)
+        return zs, {"kl_loss": kl}
+
+
+class _Identity(nn.Identity):
+    pass
+
+
+class FSQRegularizer(nn.Module):
+    """Finite scalar quantisation (regularizers.py:95-268): tanh bound, round half to even, integer
+    codes packed in mixed radix; aux loss = entropy terms over the implicit codebook + commitment."""
+
+    def __init__(self, levels: List[int], dim: Optional[int] = None, num_codebooks=1,
+                 keep_num_codebooks_dim: Optional[bool] = None, scale: Optional[float] = None,
+                 entropy_loss_weight: float = 0.0, entropy_loss_annealing_steps: int = 0,
+                 entropy_loss_annealing_factor: float = 1.0, commitment_loss_weight: float = 0.0,
+                 diversity_gamma: float = 1.0, compute_aux_loss: bool = True):
+        super().__init__()
+        self.levels = [int(v) for v in levels]
+        if num_codebooks != 1:
+            raise NotImplementedError("num_codebooks > 1 is not used by any VidTok config")
+        self.num_codebooks = 1
+        self.codebook_dim = len(self.levels)
+        self.effective_codebook_dim = self.codebook_dim
+        self.keep_num_codebooks_dim = False if keep_num_codebooks_dim is None else keep_num_codebooks_dim
+        assert not self.keep_num_codebooks_dim
+        self.dim = self.codebook_dim if dim is None else dim
+        self.has_projections = self.dim != self.effective_codebook_dim
+        if self.has_projections:
+            raise NotImplementedError(
+                "FSQ with project_in/project_out (dim != len(levels)) is a SURVEY section 8(f) 'next' item")
+        self.project_in, self.project_out = _Identity(), _Identity()
+        self.scale = scale
+        self.entropy_loss_weight = entropy_loss_weight
+        self.entropy_loss_annealing_steps = entropy_loss_annealing_steps
+        self.entropy_loss_annealing_factor = entropy_loss_annealing_factor
+        self.commitment_loss_weight = commitment_loss_weight
+        self.diversity_gamma = diversity_gamma
+        self.compute_aux_loss = compute_aux_loss
+        cs = 1
+        for v in self.levels:
+            cs *= v
+        self.codebook_size = cs
+        self.register_buffer("_levels", torch.tensor(self.levels, dtype=torch.int32), persistent=False)
+        basis, b = [], 1
+        for v in self.levels:
+            basis.append(b)
+            b *= v
+        self.register_buffer("_basis", torch.tensor(basis, dtype=torch.int32), persistent=False)
+        self.register_buffer("zero", torch.tensor(0.0), persistent=False)
+
+    def get_trainable_parameters(self) -> Any:
+        return self.parameters()
+
+    def calculate_entropy_loss_weight(self, n_steps):
+        if n_steps >= self.entropy_loss_annealing_steps:
+            return self.entropy_loss_weight
+        start = self.entropy_loss_annealing_factor * self.entropy_loss_weight
+        return start - (n_steps / self.entropy_loss_annealing_steps) * (start - self.entropy_loss_weight)
+
+    @torch.no_grad()
+    def indices_to_codes(self, indices: torch.Tensor, project_out=True) -> torch.Tensor:
+        """indices int32 [B, ...] -> codes [B, D, ...] (regularizers.py:180-198, image/video form)."""
+        assert indices.dim() >= 3, "expects [B, T, H, W] (or [B, H, W]) index maps"
+        return ops.fsq_indices_to_codes(indices.to(torch.int32).contiguous(), self.levels)
+
+    @torch.no_grad()
+    def forward(self, z: torch.Tensor, inv_temperature: float = 100.0, n_steps: int = 0):
+        assert z.dim() >= 4, "expects [B, D, T, H, W]"
+        assert z.shape[1] == self.dim, f"expected dimension of {self.dim} but found dimension of {z.shape[1]}"
+        h = z.float().contiguous()
+        codes, indices = ops.fsq_quantize(h, self.levels)
+        if self.compute_aux_loss and (self.entropy_loss_weight > 0 or self.commitment_loss_weight > 0):
+            st = ops.fsq_aux_stats(h, self.levels, inv_temperature)
+            entropy_aux = st[0] - self.diversity_gamma * st[1]
+            aux = entropy_aux * self.calculate_entropy_loss_weight(n_steps) + st[2] * self.commitment_loss_weight
+        else:
+            aux = self.zero.to(z.device) * 1.0
+        return codes, dict(indices=indices, aux_loss=aux)
