@@ -116,6 +116,8 @@ typedef struct vt_conv_desc {
 } vt_conv_desc;
 
 int vt_conv(const vt_conv_desc* d, vt_stream stream);
+/* sizeof(vt_conv_desc) as compiled: lets a binding verify its struct mirror */
+int vt_conv_desc_size(void);
 
 /* ------------------------------------------------------------------------------------------
  * vt_layernorm_act -- per-position LayerNorm over C (eps inside the sqrt, biased variance,

@@ -1,0 +1,33 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "reference: needs /root/reference (build container only)")
+
+
+def pytest_collection_modifyitems(config, items):
+    from oracle.refload import reference_available
+
+    if reference_available():
+        return
+    skip = pytest.mark.skip(reason="/root/reference not present (GPU box): replayed from tests/golden instead")
+    for item in items:
+        if "reference" in item.keywords:
+            item.add_marker(skip)
+
+
+@pytest.fixture(scope="session")
+def built_lib():
+    """Build (or reuse) libvidtok_amd.so and load it."""
+    from vidtok_amd import build, lib
+
+    build.build(verbose=False)
+    return lib.load()

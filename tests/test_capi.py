@@ -1,0 +1,73 @@
+"""The C-ABI library builds for gfx950, loads, and exports every symbol include/vidtok_amd.h
+declares; argument validation works without a GPU (no compute calls here)."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+from util import ROOT
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "vidtok_amd.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(vt_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_symbols_are_exported_and_bound(built_lib):
+    from vidtok_amd import lib
+
+    declared = _declared_symbols()
+    assert len(declared) >= 15
+    for name in declared:
+        assert hasattr(built_lib, name), f"{name} declared in include/vidtok_amd.h but not exported"
+    assert set(lib.SIGNATURES) == set(declared), set(lib.SIGNATURES) ^ set(declared)
+    assert built_lib.vt_version() >= 100
+
+
+def test_conv_desc_layout_matches_header(built_lib):
+    from vidtok_amd import lib
+
+    assert built_lib.vt_conv_desc_size() == C.sizeof(lib.ConvDesc)
+    assert lib.ConvDesc.xs_z.offset % 8 == 0
+
+
+def test_argument_validation_without_gpu(built_lib):
+    from vidtok_amd import lib
+
+    assert built_lib.vt_conv(None, None) == -1
+    assert b"null descriptor" in built_lib.vt_last_error()
+    d = lib.ConvDesc()
+    d.x, d.w, d.y = 16, 16, 16          # never dereferenced: validation fails first
+    d.B = d.Ti = d.Hi = d.Wi = 1
+    d.Cin = 3                            # not a multiple of the 16-byte vector
+    d.To = d.Ho = d.Wo = d.Cout = 1
+    d.KT = d.KH = d.KW = d.st = d.sh = d.sw = 1
+    d.ldw = 3
+    assert built_lib.vt_conv(C.byref(d), None) == -1
+    assert b"Cin" in built_lib.vt_last_error()
+    assert built_lib.vt_layernorm_act(16, 0, 100, 16, 0, 100, 16, 16, 10, 100, 1e-6, 1, None) == -1
+    assert b"unsupported channel count" in built_lib.vt_last_error()
+
+
+def test_fsq_constants_match_reference_formula(built_lib):
+    import torch
+    from vidtok_amd import ops
+
+    for levels in ([8, 8, 8, 8, 8], [8, 5, 5, 5], [7, 5, 5, 5, 5], [8] * 6):
+        lv = torch.tensor(levels, dtype=torch.int32)
+        half_l = (lv - 1) * (1 + 1e-3) / 2                      # reference regularizers.py:155-157
+        offset = torch.where(lv % 2 == 0, 0.5, 0.0)
+        shift = (offset / half_l).atanh()
+        h, o, s, b = ops.fsq_consts(levels)
+        assert h == half_l.tolist() and o == offset.tolist() and s == shift.tolist()
+        assert b == [float(x) for x in torch.cumprod(torch.tensor([1] + levels[:-1]), 0)]
+
+
+def test_missing_library_fails_loudly(tmp_path, monkeypatch):
+    from vidtok_amd import lib
+
+    monkeypatch.setattr(lib, "_lib", None)
+    with pytest.raises(lib.VtError):
+        lib.load(str(tmp_path / "nope.so"))

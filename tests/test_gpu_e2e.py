@@ -1,0 +1,114 @@
+"""`-m gpu`: the whole encode/decode path on the MI355X through the C-ABI, against
+  (1) the committed outputs of the unmodified reference (tests/golden/),
+  (2) the CPU oracle on seeded inputs at sizes it finishes in seconds,
+  (3) size-independent properties at BASELINE.json's full 17x256x256 size.
+
+Tolerances: fp32 kernels vs fp32 reference: max|d|/max|ref| <= 1e-3 for z and the
+reconstruction (measured ~1e-5); FSQ integer codes: equality rate reported, >= 99.9 % required in
+fp32 mode (a code may flip only when the pre-quantisation value sits within fp32 round-off of a
+rounding boundary); bf16 kernels: error vs the fp32 oracle reported and bounded loosely (bf16 has
+3 significant digits; the reference's own fp32 vs bf16-autocast runs differ by ~2e-2)."""
+import os
+
+import pytest
+import torch
+from safetensors.torch import load_file
+
+from golden_cases import CASES, apply_tiling, make_input
+from util import GOLDEN_DIR, build_model, build_oracle, rel_err
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+@pytest.mark.parametrize("case", CASES, ids=[c["name"] for c in CASES])
+def test_fp32_matches_reference_golden(case):
+    gold = load_file(os.path.join(GOLDEN_DIR, case["name"] + ".safetensors"))
+    model, cfg, sd = build_model(case["config"], seed=case["weight_seed"], device=DEV, dtype=torch.float32)
+    apply_tiling(model, case)
+    torch.manual_seed(case["noise_seed"])          # host-side noise stream identical to the reference's
+    z, dec, log = model(make_input(case).to(DEV))
+    ez, ed = rel_err(z, gold["z"]), rel_err(dec, gold["dec"])
+    print(f"{case['name']}: z rel {ez:.2e} dec rel {ed:.2e}")
+    assert dec.shape == gold["dec"].shape and dec.dtype == torch.float32 and dec.is_cuda
+    assert ez < 1e-3 and ed < 1e-3
+    if "indices" in gold:
+        rate = (log["indices"].cpu() == gold["indices"]).float().mean().item()
+        print(f"{case['name']}: FSQ code match rate {rate:.6f}")
+        assert log["indices"].dtype == torch.int32 and rate >= 0.999
+        dec2 = model.decode(log["indices"], decode_from_indices=True)
+        assert torch.equal(dec2[:, :, -dec.shape[2]:], dec)       # decode(indices) == decode(z), bit for bit
+        assert abs(float(log["aux_loss"]) - float(gold["aux_loss"])) < 1e-3
+    else:
+        assert abs(float(log["kl_loss"]) - float(gold["kl_loss"])) < 1e-3 * abs(float(gold["kl_loss"]))
+
+
+@pytest.mark.parametrize("name,shape,dtype,tol", [
+    ("vidtok_kl_causal_488_4chn", (2, 3, 17, 64, 64), torch.float32, 1e-3),
+    ("vidtok_fsq_causal_488_32768", (1, 3, 17, 64, 64), torch.float32, 1e-3),
+    ("vidtok_kl_causal_488_4chn", (2, 3, 17, 64, 64), torch.bfloat16, 0.25),
+    ("vidtok_fsq_causal_488_32768", (1, 3, 17, 64, 64), torch.bfloat16, 0.25),
+    ("vidtok_kl_causal_488_16chn", (1, 3, 9, 40, 24), torch.bfloat16, 0.25),
+])
+def test_matches_cpu_oracle(name, shape, dtype, tol):
+    model, cfg, sd = build_model(name, seed=21, device=DEV, dtype=dtype)
+    ora = build_oracle(cfg, sd)
+    g = torch.Generator().manual_seed(9)
+    x = torch.rand(shape, generator=g) * 2 - 1
+    torch.manual_seed(4)
+    z, dec, log = model(x.to(DEV))
+    torch.manual_seed(4)
+    z2, dec2, log2 = ora(x)
+    ez, ed = rel_err(z, z2), rel_err(dec, dec2)
+    print(f"{name} {shape} {dtype}: z rel {ez:.3e} dec rel {ed:.3e}")
+    assert dec.shape == dec2.shape == tuple(shape) or dec.shape == dec2.shape
+    assert ez < tol and ed < tol
+    if "indices" in log2:
+        rate = (log["indices"].cpu() == log2["indices"]).float().mean().item()
+        print(f"{name} {dtype}: FSQ code match rate {rate:.5f} over {log2['indices'].numel()} tokens")
+        assert rate >= (0.999 if dtype == torch.float32 else 0.5)
+        # the quantiser itself is exact: feeding the oracle's own pre-quantisation h gives its codes
+        from oracle.vidtok_oracle import encoder_forward
+        h = encoder_forward(ora.sd, ora.enc_params, x, "v1_0")
+        _, qlog = model.regularization(h.to(DEV))
+        assert (qlog["indices"].cpu() != log2["indices"]).sum() <= 1
+
+
+def test_v11_long_video_tiled_matches_oracle():
+    name = "vidtok_v1_1/vidtok_kl_causal_488_16chn_v1_1"
+    model, cfg, sd = build_model(name, seed=22, device=DEV, dtype=torch.float32)
+    ora = build_oracle(cfg, sd)
+    for m in (model, ora):
+        m.use_tiling, m.t_chunk_enc, m.use_overlap = True, 16, True
+    model.t_chunk_dec = 4
+    x = torch.rand(1, 3, 49, 32, 32, generator=torch.Generator().manual_seed(3)) * 2 - 1
+    torch.manual_seed(5)
+    z, dec, log = model(x.to(DEV))
+    torch.manual_seed(5)
+    z2, dec2, log2 = ora(x)
+    print(f"v1.1 tiled T=49: z rel {rel_err(z, z2):.2e} dec rel {rel_err(dec, dec2):.2e}")
+    assert dec.shape == x.shape and rel_err(z, z2) < 1e-3 and rel_err(dec, dec2) < 1e-3
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+def test_full_size_properties(dtype):
+    """BASELINE.json size (17x256x256): properties that need no oracle."""
+    model, cfg, sd = build_model("vidtok_fsq_causal_488_32768", seed=23, device=DEV, dtype=dtype)
+    model.regularization.compute_aux_loss = False
+    g = torch.Generator().manual_seed(11)
+    x = (torch.rand((2, 3, 17, 256, 256), generator=g) * 2 - 1).to(DEV)
+    z, dec, log = model(x)
+    assert dec.shape == x.shape and z.shape == (2, 5, 5, 32, 32) and log["indices"].shape == (2, 5, 32, 32)
+    assert torch.isfinite(dec).all() and torch.isfinite(z).all()
+    assert int(log["indices"].min()) >= 0 and int(log["indices"].max()) < 32768
+    # determinism and batch independence: clips are independent units
+    z1, dec1, log1 = model(x[1:2].contiguous())
+    assert torch.equal(log1["indices"], log["indices"][1:2]) and torch.equal(dec1, dec[1:2])
+    # indices <-> latent <-> decode identities
+    assert torch.equal(model.indices_to_latent(log["indices"]), z)
+    assert torch.equal(model.decode(log["indices"], decode_from_indices=True), dec)
+    # causality: the first 5 output frames depend only on the first 5 input frames' latents
+    x2 = x.clone()
+    x2[:, :, 9:] = -x2[:, :, 9:]
+    _, decb, _ = model(x2)
+    assert torch.equal(decb[:, :, :1], dec[:, :, :1])

@@ -1,0 +1,235 @@
+"""`-m gpu`: every HIP operator of libvidtok_amd.so against the plain PyTorch fp32 statement of its
+contract (tests/torch_ops_ref.py) on the same seeded inputs.  fp32 arithmetic must agree to fp32
+round-off (fmaf-chain MFMA), bf16 to bf16 round-off of the output; integer results bit-exactly."""
+import math
+
+import pytest
+import torch
+
+import torch_ops_ref as R
+from util import rel_err
+from vidtok_amd import lib as L
+from vidtok_amd import ops
+from vidtok_amd.ops import ConvGeom
+from vidtok_amd.packing import pack_conv_weight
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+TOL = {torch.float32: 2e-5, torch.bfloat16: 1.2e-2}
+DTYPES = [torch.float32, torch.bfloat16]
+
+
+def _rand(shape, dtype, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(shape, generator=g) * scale).to(dtype).to(DEV)
+
+
+def _act(B, T, H, W, c_real, dtype, seed):
+    """NDHWC activation with channels padded to a multiple of 8 (pad lanes zero)."""
+    cp = ops.pad_channels(c_real)
+    x = torch.zeros((B, T, H, W, cp), dtype=dtype)
+    g = torch.Generator().manual_seed(seed)
+    x[..., :c_real] = torch.randn((B, T, H, W, c_real), generator=g).to(dtype)
+    return x.to(DEV)
+
+
+def _cpu(kw):
+    return {k: (v.cpu() if isinstance(v, torch.Tensor) else v) for k, v in kw.items()}
+
+
+G3 = dict(kh=3, kw=3, ph=1, pw=1, ph_hi=1, pw_hi=1)
+G333 = dict(kt=3, kh=3, kw=3, pt=2, ph=1, pw=1, ph_hi=1, pw_hi=1)
+
+# name, (B,T,H,W), Cin, Cout, weight kernel dims, geom, extras
+CONV_CASES = [
+    ("conv2d_3x3_128_128", (2, 3, 16, 16), 128, 128, (3, 3), ConvGeom(**G3), {}),
+    ("conv2d_3x3_256_128_res", (1, 2, 16, 24), 256, 128, (3, 3), ConvGeom(**G3), dict(res="add")),
+    ("conv2d_3x3_64_192_ragged", (1, 3, 5, 7), 64, 192, (3, 3), ConvGeom(**G3), dict(res="add")),
+    ("nin_1x1_128_256", (1, 2, 16, 16), 128, 256, (1, 1), ConvGeom(), {}),
+    ("downsample_s2", (1, 2, 16, 16), 128, 128, (3, 3), ConvGeom(kh=3, kw=3, sh=2, sw=2, ph_hi=1, pw_hi=1), {}),
+    ("upsample_fold", (1, 2, 8, 8), 128, 128, (3, 3), ConvGeom(ups_s=1, **G3), {}),
+    ("temporal_k3_res", (2, 6, 8, 8), 128, 128, (3,), ConvGeom(kt=3, pt=2), dict(res="add")),
+    ("temporal_k3_512", (1, 5, 4, 4), 512, 512, (3,), ConvGeom(kt=3, pt=2), {}),
+    ("conv3d_333_256", (1, 5, 8, 8), 256, 256, (3, 3, 3), ConvGeom(**G333), dict(res="add")),
+    ("timedown_s2_mix", (1, 6, 8, 8), 128, 128, (3, 3, 3),
+     ConvGeom(kt=3, kh=3, kw=3, st=2, pt=1, ph=1, pw=1, ph_hi=1, pw_hi=1), dict(res="mix")),
+    ("timeup_fold_mix", (1, 3, 8, 8), 128, 128, (3, 3, 3), ConvGeom(ups_t=1, **G333), dict(res="mix_up")),
+    ("conv_in_3_128", (1, 5, 16, 16), 3, 128, (3, 3, 3), ConvGeom(**G333), {}),
+    ("dec_conv_in_4_512", (2, 3, 4, 4), 4, 512, (3, 3, 3), ConvGeom(**G333), {}),
+    ("conv_out_128_3_ncthw_trim", (1, 8, 16, 16), 128, 3, (3, 3, 3), ConvGeom(**G333), dict(ncthw=3)),
+    ("enc_conv_out_512_8_ncthw", (2, 3, 4, 4), 512, 8, (3, 3, 3), ConvGeom(**G333), dict(ncthw=0)),
+    ("enc_conv_out_512_32_ncthw", (1, 3, 4, 4), 512, 32, (3, 3, 3), ConvGeom(**G333), dict(ncthw=0)),
+    ("narrow_ndhwc_128_5", (1, 2, 8, 8), 128, 5, (3, 3), ConvGeom(**G3), {}),
+    ("cout64_tile", (1, 2, 8, 8), 128, 64, (3, 3), ConvGeom(**G3), {}),
+    ("v11_replicate_3d", (1, 4, 8, 8), 128, 128, (3, 3, 3), ConvGeom(**G333), dict(tmode="replicate")),
+    ("v11_cache_3d", (2, 4, 8, 8), 128, 128, (3, 3, 3), ConvGeom(**G333), dict(tmode="cache")),
+    ("v11_cache_1d", (1, 4, 8, 8), 256, 256, (3,), ConvGeom(kt=3, pt=2), dict(tmode="cache", res="add")),
+    ("v11_cache_s2", (1, 4, 8, 8), 128, 128, (3, 3, 3),
+     ConvGeom(kt=3, kh=3, kw=3, st=2, pt=1, ph=1, pw=1, ph_hi=1, pw_hi=1), dict(tmode="cache")),
+]
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+@pytest.mark.parametrize("case", CONV_CASES, ids=[c[0] for c in CONV_CASES])
+def test_conv(case, dtype):
+    name, (B, T, H, W), cin, cout, kdims, geom, ex = case
+    x = _act(B, T, H, W, cin, dtype, 1)
+    g = torch.Generator().manual_seed(2)
+    fan = cin * math.prod(kdims)
+    wt = torch.randn((cout, cin) + tuple(kdims), generator=g) / math.sqrt(fan)
+    w = pack_conv_weight(wt, dtype, cin_stored=x.shape[-1]).to(DEV)
+    bias = _rand((cout,), torch.float32, 3, 0.1)
+    kw = {}
+    To, Ho, Wo = geom.out_dims(T, H, W)
+    out_dtype = dtype
+    if "ncthw" in ex:
+        kw.update(out_layout=L.VT_NCTHW, t_trim=ex["ncthw"])
+        out_dtype = torch.float32
+    if ex.get("res") == "add":
+        kw.update(res=_act(B, To, Ho, Wo, cout, out_dtype, 4), res_mode=L.VT_RES_ADD)
+    elif ex.get("res") == "mix":
+        kw.update(res=_act(B, To, Ho, Wo, cout, out_dtype, 4), res_mode=L.VT_RES_MIX,
+                  mix_factor=torch.tensor([0.37], device=DEV))
+    elif ex.get("res") == "mix_up":
+        kw.update(res=x, res_mode=L.VT_RES_MIX, res_tshift=1, mix_factor=torch.tensor([-0.6], device=DEV))
+    if ex.get("tmode") == "replicate":
+        kw.update(tmode=L.VT_TPAD_REPLICATE)
+    elif ex.get("tmode") == "cache":
+        kw.update(tmode=L.VT_TPAD_CACHE, cache=_act(B, geom.pt + 1, H, W, cin, dtype, 5))
+    y = ops.conv(x, w, bias, geom, cout=cout, **kw)
+    torch.cuda.synchronize()
+    yr = R.conv(x.cpu(), w.cpu(), bias.cpu(), geom, cout=cout, **_cpu(kw))   # reference on the host
+    assert y.shape == yr.shape and y.dtype == yr.dtype
+    assert torch.isfinite(y.float()).all()
+    e = rel_err(y, yr)
+    print(f"{name} {dtype}: rel_err={e:.3e}")
+    assert e < TOL[dtype], f"{name} {dtype}: rel_err={e}"
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+@pytest.mark.parametrize("Z,M,N,K,bcast,use_bias", [(3, 80, 48, 128, False, False), (2, 512, 64, 512, True, True),
+                                                      (5, 16, 16, 16, False, False), (2, 100, 512, 104, False, True),
+                                                      (2, 1024, 1024, 512, False, False)])
+def test_gemm_nt(Z, M, N, K, bcast, use_bias, dtype):
+    a = _rand((1 if bcast else Z, M, K), dtype, 1, 1.0 / math.sqrt(K))
+    b = _rand((Z, N, K), dtype, 2)
+    bias = _rand((N,), torch.float32, 3) if use_bias else None
+    for od in (dtype, torch.float32):
+        y = ops.gemm_nt(a, b, out_dtype=od, bias=bias)
+        yr = R.gemm_nt(a.cpu(), b.cpu(), out_dtype=od, bias=None if bias is None else bias.cpu())
+        e = rel_err(y, yr)
+        assert y.shape == (Z, M, N) and e < TOL[dtype], f"gemm {Z,M,N,K} {dtype}->{od}: {e}"
+
+
+@pytest.mark.parametrize("C", [32, 64, 128, 256, 512, 1024])
+@pytest.mark.parametrize("din,dout", [(torch.float32, torch.float32), (torch.bfloat16, torch.bfloat16),
+                                      (torch.float32, torch.bfloat16), (torch.bfloat16, torch.float32)])
+@pytest.mark.parametrize("silu", [True, False])
+def test_layernorm_act(C, din, dout, silu):
+    x = _rand((3, 7, 11, C), din, 1, 2.0) + 0.5
+    gm, bt = 1 + 0.1 * _rand((C,), torch.float32, 2), 0.1 * _rand((C,), torch.float32, 3)
+    y = ops.layernorm_act(x, gm, bt, silu=silu, out_dtype=dout)
+    yr = R.layernorm_act(x.cpu(), gm.cpu(), bt.cpu(), silu=silu, out_dtype=dout)
+    e = rel_err(y, yr)
+    assert e < (2e-5 if dout == torch.float32 else 1e-2), f"LN C={C} {din}->{dout} silu={silu}: {e}"
+
+
+@pytest.mark.parametrize("cols", [16, 100, 1024])
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+def test_softmax_rows(cols, dtype):
+    s = _rand((5, 33, cols), torch.float32, 1, 8.0)
+    p = ops.softmax_rows(s, 0.0442, dtype)
+    pr = R.softmax_rows(s.cpu(), 0.0442, dtype)
+    assert rel_err(p, pr) < (1e-5 if dtype == torch.float32 else 1e-2)
+    assert (p.float().sum(-1) - 1).abs().max() < (1e-5 if dtype == torch.float32 else 2e-2)
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+def test_layout_roundtrip(dtype):
+    x = _rand((2, 3, 5, 6, 7), torch.float32, 1)
+    y = ops.ncthw_to_ndhwc(x, dtype, tpad=3)
+    yr = R.ncthw_to_ndhwc(x.cpu(), dtype, tpad=3)
+    assert torch.equal(y.cpu(), yr) and y.shape == (2, 8, 6, 7, 8)
+    back = ops.ndhwc_to_ncthw(y, 3, ttrim=3)
+    assert torch.equal(back, x.to(dtype).float())
+    z = _rand((2, 16, 2, 4, 4), torch.float32, 2)
+    assert torch.equal(ops.ndhwc_to_ncthw(ops.ncthw_to_ndhwc(z, dtype), 16), z.to(dtype).float())
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+@pytest.mark.parametrize("tmode", [L.VT_TPAD_ZERO, L.VT_TPAD_REPLICATE, L.VT_TPAD_CACHE])
+def test_time_avgpool(dtype, tmode):
+    x = _act(2, 6, 4, 4, 128, dtype, 1)
+    cache = _act(2, 1, 4, 4, 128, dtype, 2) if tmode == L.VT_TPAD_CACHE else None
+    y = ops.time_avgpool3s2(x, tmode, cache)
+    yr = R.time_avgpool3s2(x.cpu(), tmode, None if cache is None else cache.cpu())
+    assert y.shape == (2, 3, 4, 4, 128) and rel_err(y, yr) < (1e-6 if dtype == torch.float32 else 8e-3)
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+@pytest.mark.parametrize("Ti", [1, 2, 5])
+def test_time_lerp2x(dtype, Ti):
+    x = _act(2, Ti, 4, 4, 128, dtype, 1)
+    y = ops.time_lerp2x(x)
+    yr = R.time_lerp2x(x.cpu())
+    assert y.shape == yr.shape and rel_err(y, yr) < (1e-6 if dtype == torch.float32 else 8e-3)
+
+
+def test_gather_frames():
+    x = _act(2, 5, 4, 4, 128, torch.bfloat16, 1)
+    idx = [4, 0, 0, 3, 2, 2]
+    assert torch.equal(ops.gather_frames(x, idx), x[:, idx])
+    xf = _act(1, 3, 2, 2, 8, torch.float32, 2)
+    assert torch.equal(ops.gather_frames(xf, [2]), xf[:, 2:3])
+
+
+@pytest.mark.parametrize("with_noise", [True, False])
+def test_kl_sample(with_noise):
+    h = _rand((3, 8, 2, 4, 4), torch.float32, 1, 3.0)
+    h[0, 4:, 0, 0, 0] = torch.tensor([50.0, -50.0, 0.0, 1.0], device=DEV)   # exercises the clamp
+    noise = _rand((3, 4, 2, 4, 4), torch.float32, 2) if with_noise else None
+    z, kl = ops.kl_sample(h, noise)
+    zr, klr = R.kl_sample(h.cpu(), None if noise is None else noise.cpu())
+    assert rel_err(z, zr) < 1e-6 and abs(float(kl) - float(klr)) < 1e-5 * abs(float(klr))
+
+
+@pytest.mark.parametrize("levels", [[8, 8, 8, 8, 8], [8, 5, 5, 5], [7, 5, 5, 5, 5], [8] * 6])
+def test_fsq_quantize_bit_exact(levels):
+    D = len(levels)
+    h = _rand((4, D, 5, 16, 16), torch.float32, 1, 1.5)
+    z, idx = ops.fsq_quantize(h, levels)
+    zr, idxr = R.fsq_quantize(h.cpu(), levels)          # CPU torch: the reference's own arithmetic
+    n_bad = int((idx.cpu() != idxr).sum())
+    print(f"fsq levels={levels}: {n_bad} / {idx.numel()} index mismatches vs CPU torch")
+    assert idx.dtype == torch.int32 and n_bad <= 1      # a 1-ulp tanh difference on a rounding boundary
+    if n_bad == 0:
+        assert torch.equal(z.cpu(), zr)
+    # round trip: indices -> codes == quantised z, bit for bit (SURVEY.md section 8c identity)
+    assert torch.equal(ops.fsq_indices_to_codes(idx, levels), z)
+
+
+def test_fsq_indices_to_codes_exhaustive():
+    levels = [8, 8, 8, 8, 8]
+    allidx = torch.arange(32768, dtype=torch.int32, device=DEV).reshape(1, 8, 64, 64)
+    codes = ops.fsq_indices_to_codes(allidx, levels)
+    ref = R.fsq_indices_to_codes(allidx.cpu(), levels)
+    assert torch.equal(codes.cpu(), ref)
+    # quantising the exact code points returns the same indices (codes sit mid-bin after the bound)
+    zin = torch.atanh(((codes * 4 + 0.5) / 3.5035).clamp(-0.9999, 0.9999)) - 0.14369
+    assert torch.equal(ops.fsq_quantize(zin.contiguous(), levels)[1], allidx)
+
+
+@pytest.mark.parametrize("levels,B", [([8, 8, 8, 8, 8], 2), ([8, 8, 8, 8], 1)])
+def test_fsq_aux_stats(levels, B):
+    h = _rand((B, len(levels), 2, 8, 8), torch.float32, 1, 0.7)
+    st = ops.fsq_aux_stats(h, levels, 100.0).cpu()
+    ref = R.fsq_aux_stats(h.cpu(), levels, 100.0)
+    print("fsq aux", st.tolist(), ref.tolist())
+    assert torch.allclose(st, ref, rtol=2e-4, atol=2e-5)
+
+
+def test_library_is_the_hip_extension():
+    lib = L.load()
+    assert lib.vt_version() >= 100 and L.LIB_PATH.endswith("libvidtok_amd.so")
+    with pytest.raises(L.VtError):
+        ops.layernorm_act(torch.zeros(4, 128), torch.ones(128), torch.zeros(128), silu=True)  # CPU tensor

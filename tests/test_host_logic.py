@@ -1,0 +1,129 @@
+"""CPU tests of the host side (vidtok_amd.modules / engine / config / packing): the HIP operators are
+replaced, for these tests only, by the torch statements of their contracts (tests/torch_ops_ref.py), so
+padding bookkeeping, weight packing, causal caches and tiling are checked end-to-end against the
+oracle and the reference goldens without a GPU."""
+import os
+
+import pytest
+import torch
+from safetensors.torch import load_file
+
+import torch_ops_ref
+from golden_cases import CASES, apply_tiling, make_input
+from util import GOLDEN_DIR, build_model, build_oracle, config_path, rel_err
+
+
+@pytest.fixture()
+def emulated_ops(monkeypatch):
+    torch_ops_ref.patch_ops(monkeypatch)
+
+
+@pytest.mark.parametrize("case", CASES, ids=[c["name"] for c in CASES])
+def test_host_graph_matches_reference_golden(case, emulated_ops):
+    gold = load_file(os.path.join(GOLDEN_DIR, case["name"] + ".safetensors"))
+    model, cfg, sd = build_model(case["config"], seed=case["weight_seed"])
+    apply_tiling(model, case)
+    torch.manual_seed(case["noise_seed"])
+    z, dec, log = model(make_input(case))
+    assert dec.shape == gold["dec"].shape
+    assert rel_err(z, gold["z"]) < 2e-5 and rel_err(dec, gold["dec"]) < 5e-5
+    if "indices" in gold:
+        assert torch.equal(log["indices"], gold["indices"])
+        assert abs(float(log["aux_loss"]) - float(gold["aux_loss"])) < 1e-4
+        dec2 = model.decode(log["indices"], decode_from_indices=True)
+        assert rel_err(dec2[:, :, -gold["dec"].shape[2]:], gold["dec"]) < 5e-5   # forward() keeps the last T frames
+    else:
+        assert abs(float(log["kl_loss"]) - float(gold["kl_loss"])) < 1e-4 * abs(float(gold["kl_loss"]))
+
+
+@pytest.mark.parametrize("name,shape", [
+    ("vidtok_kl_causal_288_8chn", (1, 3, 5, 32, 32)),
+    ("vidtok_kl_causal_444_4chn", (1, 3, 5, 16, 16)),
+    ("vidtok_kl_causal_41616_4chn", (1, 3, 5, 32, 32)),
+    ("vidtok_fsq_causal_488_4096", (1, 3, 4, 32, 32)),
+    ("vidtok_v1_1/vidtok_fsq_causal_888_32768_v1_1", (1, 3, 9, 32, 32)),
+])
+def test_other_causal_configs_match_oracle(name, shape, emulated_ops):
+    model, cfg, sd = build_model(name, seed=3)
+    ora = build_oracle(cfg, sd)
+    x = torch.rand(*shape) * 2 - 1
+    torch.manual_seed(1)
+    z, dec, log = model(x)
+    torch.manual_seed(1)
+    z2, dec2, log2 = ora(x)
+    assert dec.shape == dec2.shape
+    assert rel_err(z, z2) < 2e-5 and rel_err(dec, dec2) < 5e-5
+
+
+def test_api_surface_and_aliases(emulated_ops):
+    import vidtok_amd
+    from vidtok_amd.engine import AutoencodingEngine, AutoencodingEngineV11
+
+    m, cfg, _ = build_model("vidtok_kl_causal_488_4chn")
+    assert isinstance(m, AutoencodingEngine) and m.is_causal and m.encoder.time_downsample_factor == 4
+    assert m.encode_decode.__func__ is m.forward.__func__
+    x = torch.rand(1, 3, 5, 16, 16) * 2 - 1
+    m.regularization.sample = False
+    z = m.encode(x)
+    z2, log = m.encode(x, return_reg_log=True)
+    assert torch.equal(z, z2) and log["kl_loss"].dim() == 0
+    assert m.decode(z).shape == x.shape
+    m11, _, _ = build_model("vidtok_v1_1/vidtok_kl_causal_488_4chn_v1_1")
+    assert isinstance(m11, AutoencodingEngineV11)
+    assert m11.build_chunk_start_end(33) == [[0, 1], [1, 17], [17, 33]]
+    assert m11.build_chunk_start_end(9, decoder_mode=True) == [[0, 1], [1, 5], [5, 9]]
+    with pytest.raises(AssertionError):
+        m.encoder(torch.zeros(1, 3, 8, 8))
+    # reference target strings resolve to the MI355X classes (unmodified reference YAML surface)
+    assert vidtok_amd.config.get_obj_from_str("vidtok.models.autoencoder.AutoencodingEngine") is AutoencodingEngine
+
+
+def test_unsupported_variants_fail_loudly():
+    from vidtok_amd.modules import EncoderCausal3DPadding
+    from vidtok_amd.regularizers import FSQRegularizer
+
+    with pytest.raises(NotImplementedError):
+        EncoderCausal3DPadding(ch=32, out_ch=3, ch_mult=(1, 2), num_res_blocks=1, in_channels=3, z_channels=4,
+                               norm_type="groupnorm")
+    with pytest.raises(NotImplementedError):
+        FSQRegularizer(levels=[8, 8, 8], dim=6)
+
+
+def test_product_path_has_no_cpu_fallback():
+    """Without the monkeypatch the operators refuse CPU tensors instead of computing on the host."""
+    import vidtok_amd.lib as L
+
+    m, _, _ = build_model("vidtok_kl_causal_488_4chn")
+    with pytest.raises((L.VtError, OSError, AttributeError)):
+        m(torch.zeros(1, 3, 5, 16, 16))
+
+
+def test_weight_packing_layout():
+    from vidtok_amd.packing import pack_conv_weight
+
+    w = torch.arange(2 * 3 * 2 * 3 * 3, dtype=torch.float32).reshape(2, 3, 2, 3, 3)
+    p = pack_conv_weight(w, torch.float32)          # Cin 3 -> 8
+    assert p.shape == (2, 2 * 3 * 3 * 8)
+    p5 = p.reshape(2, 2, 3, 3, 8)
+    assert torch.equal(p5[..., :3], w.permute(0, 2, 3, 4, 1)) and p5[..., 3:].abs().sum() == 0
+    w1 = torch.randn(4, 16, 3)
+    assert torch.equal(pack_conv_weight(w1, torch.float32).reshape(4, 3, 16), w1.permute(0, 2, 1))
+
+
+def test_config_interpolation_and_checkpoint_roundtrip(tmp_path, emulated_ops):
+    import vidtok_amd
+    from safetensors.torch import save_file
+
+    cfg = vidtok_amd.load_config(config_path("vidtok_fsq_causal_488_32768"))
+    p = cfg["model"]["params"]
+    assert p["decoder_config"]["params"] == p["encoder_config"]["params"]
+    m, _, sd = build_model("vidtok_fsq_causal_488_32768", seed=5)
+    path = str(tmp_path / "w.safetensors")
+    extra = dict(sd)
+    extra["loss.logvar"] = torch.zeros(())          # checkpoints carry loss.* keys; must be ignored
+    save_file({k: v.contiguous() for k, v in extra.items()}, path)
+    m2 = vidtok_amd.load_model_from_config(cfg, ckpt=path, verbose=False)
+    for k, v in m2.state_dict().items():
+        assert torch.equal(v, sd[k]), k
+    m3 = vidtok_amd.load_model_from_config(cfg, ckpt=path, ignore_keys=[r"decoder\.conv_out\..*"], verbose=False)
+    assert not torch.equal(m3.state_dict()["decoder.conv_out.conv.weight"], sd["decoder.conv_out.conv.weight"])

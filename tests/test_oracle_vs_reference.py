@@ -1,0 +1,72 @@
+"""Pins oracle/vidtok_oracle.py against the UNMODIFIED reference (build container only: needs
+/root/reference; on the GPU box the same comparison is replayed from tests/golden/)."""
+import pytest
+import torch
+
+from oracle.refload import load_reference_model, randomize_weights
+from oracle.vidtok_oracle import OracleEngine
+from util import rel_err
+
+pytestmark = pytest.mark.reference
+
+CASES = [
+    ("vidtok_kl_causal_488_4chn", (1, 3, 9, 32, 32)),
+    ("vidtok_fsq_causal_488_32768", (2, 3, 5, 32, 32)),
+    ("vidtok_kl_causal_488_16chn", (1, 3, 8, 32, 32)),
+    ("vidtok_kl_causal_288_8chn", (1, 3, 5, 32, 32)),
+    ("vidtok_kl_causal_444_4chn", (1, 3, 5, 16, 16)),
+]
+
+
+@pytest.mark.parametrize("cfg,shape", CASES)
+def test_oracle_matches_reference_forward(cfg, shape):
+    ref, c = load_reference_model(cfg)
+    randomize_weights(ref)
+    ora = OracleEngine(c["model"]["params"], ref.state_dict())
+    x = torch.rand(*shape) * 2 - 1
+    with torch.no_grad():
+        torch.manual_seed(7)
+        z, dec, log = ref(x)
+        torch.manual_seed(7)
+        z2, dec2, log2 = ora(x)
+    assert dec.shape == dec2.shape and z.shape == z2.shape
+    assert rel_err(z2, z) < 2e-5 and rel_err(dec2, dec) < 5e-5
+    if "indices" in log:
+        assert torch.equal(log["indices"], log2["indices"])
+        assert abs(float(log["aux_loss"]) - float(log2["aux_loss"])) < 1e-4
+        # decode_from_indices identity (SURVEY.md section 8c free KAT)
+        assert rel_err(ora.decode(log2["indices"], decode_from_indices=True), dec) < 5e-5
+    else:
+        assert abs(float(log["kl_loss"]) - float(log2["kl_loss"])) < 1e-3 * abs(float(log["kl_loss"]))
+
+
+@pytest.mark.parametrize("overlap", [False, True])
+def test_oracle_matches_reference_v11_tiled(overlap):
+    cfg = "vidtok_v1_1/vidtok_kl_causal_488_16chn_v1_1"
+    ref, c = load_reference_model(cfg)
+    randomize_weights(ref)
+    ora = OracleEngine(c["model"]["params"], ref.state_dict())
+    x = torch.rand(1, 3, 41, 32, 32) * 2 - 1
+    for m in (ref, ora):
+        m.use_tiling, m.t_chunk_enc, m.use_overlap = True, 16, overlap
+    ref.t_chunk_dec = 4
+    with torch.no_grad():
+        torch.manual_seed(3)
+        z, dec, log = ref(x)
+        torch.manual_seed(3)
+        z2, dec2, log2 = ora(x)
+    assert dec.shape == dec2.shape == x.shape
+    assert rel_err(z2, z) < 2e-5 and rel_err(dec2, dec) < 5e-5
+
+
+def test_oracle_matches_reference_v11_fsq_untiled():
+    cfg = "vidtok_v1_1/vidtok_fsq_causal_488_32768_v1_1"
+    ref, c = load_reference_model(cfg)
+    randomize_weights(ref)
+    ora = OracleEngine(c["model"]["params"], ref.state_dict())
+    x = torch.rand(1, 3, 17, 32, 32) * 2 - 1
+    with torch.no_grad():
+        z, dec, log = ref(x)
+        z2, dec2, log2 = ora(x)
+    assert torch.equal(log["indices"], log2["indices"])
+    assert rel_err(dec2, dec) < 5e-5

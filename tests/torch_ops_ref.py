@@ -1,0 +1,184 @@
+"""TEST INFRASTRUCTURE ONLY -- plain PyTorch fp32 statements of the operator contracts of
+include/vidtok_amd.h, with the same Python signatures as vidtok_amd.ops.
+
+Two uses:
+  * `-m gpu` numerics tests: every HIP kernel is compared with its function here on the same inputs;
+  * `-m "not gpu"` host-logic tests: `patch_ops(monkeypatch)` swaps these in for vidtok_amd.ops so the
+    orchestration in vidtok_amd.modules / engine (padding bookkeeping, caches, tiling, state_dict
+    packing) is exercised end-to-end against the oracle on a machine without a GPU.
+The product never imports this file and has no switch to select it.
+"""
+import torch
+import torch.nn.functional as F
+
+from vidtok_amd import lib as L
+from vidtok_amd.ops import ConvGeom, pad_channels  # noqa: F401  (dataclass / helper only)
+
+
+def _round_like(t, dtype):
+    return t.to(dtype)
+
+
+def conv(x, w, bias, geom, *, cout, out_dtype=None, tmode=L.VT_TPAD_ZERO, cache=None, res=None,
+         res_mode=L.VT_RES_NONE, res_tshift=0, mix_factor=None, out_layout=L.VT_NDHWC, t_trim=0, ldy=None):
+    B, Ti, Hi, Wi, Cin = x.shape
+    out_dtype = out_dtype or x.dtype
+    xp = x.float().permute(0, 4, 1, 2, 3)  # NCTHW
+    if geom.ups_t:
+        xp = xp.repeat_interleave(2, dim=2)
+    if geom.ups_s:
+        xp = xp.repeat_interleave(2, dim=3).repeat_interleave(2, dim=4)
+    if geom.pt > 0:
+        if tmode == L.VT_TPAD_ZERO:
+            front = torch.zeros_like(xp[:, :, :1]).repeat(1, 1, geom.pt, 1, 1)
+        elif tmode == L.VT_TPAD_REPLICATE:
+            front = xp[:, :, :1].repeat(1, 1, geom.pt, 1, 1)
+        else:
+            assert not geom.ups_t and not geom.ups_s
+            front = cache.float().permute(0, 4, 1, 2, 3)[:, :, -geom.pt:]
+        xp = torch.cat([front, xp], dim=2)
+    xp = F.pad(xp, (geom.pw, geom.pw_hi, geom.ph, geom.ph_hi))
+    w5 = w.float().reshape(cout, geom.kt, geom.kh, geom.kw, Cin).permute(0, 4, 1, 2, 3)
+    y = F.conv3d(xp, w5, None if bias is None else bias.float()[:cout], stride=(geom.st, geom.sh, geom.sw))
+    To = y.shape[2]
+    if res_mode != L.VT_RES_NONE:
+        r = res.float().permute(0, 4, 1, 2, 3)[:, :cout]
+        tidx = torch.arange(To, device=y.device) >> res_tshift
+        r = r[:, :, tidx]
+        if res_mode == L.VT_RES_ADD:
+            y = r + y
+        else:
+            a = torch.sigmoid(mix_factor.float())
+            y = a * r + (1 - a) * y
+    if out_layout == L.VT_NCTHW:
+        return y[:, :, t_trim:].contiguous()
+    ldy = ldy or pad_channels(cout)
+    out = torch.zeros((B, To, y.shape[3], y.shape[4], ldy), dtype=out_dtype, device=x.device)
+    out[..., :cout] = y.permute(0, 2, 3, 4, 1).to(out_dtype)
+    return out
+
+
+def gemm_nt(a, b, *, out_dtype=None, bias=None):
+    out_dtype = out_dtype or a.dtype
+    y = torch.matmul(a.float(), b.float().transpose(-1, -2))
+    if bias is not None:
+        y = y + bias.float()[: y.shape[-1]]
+    return y.to(out_dtype)
+
+
+def layernorm_act(x, gamma, beta, *, silu, eps=1e-6, out_dtype=None, c=None):
+    out_dtype = out_dtype or x.dtype
+    c = c or x.shape[-1]
+    y = F.layer_norm(x.float()[..., :c], (c,), gamma.float(), beta.float(), eps)
+    if silu:
+        y = y * torch.sigmoid(y)
+    out = torch.zeros(x.shape, dtype=out_dtype, device=x.device)
+    out[..., :c] = y.to(out_dtype)
+    return out
+
+
+def softmax_rows(s, scale, out_dtype):
+    return torch.softmax(s.float() * scale, dim=-1).to(out_dtype)
+
+
+def ncthw_to_ndhwc(x, dtype, tpad=0, ld=None):
+    B, C, T, H, W = x.shape
+    ld = ld or pad_channels(C)
+    if tpad:
+        x = torch.cat([x[:, :, :1].repeat(1, 1, tpad, 1, 1), x], dim=2)
+    out = torch.zeros((B, T + tpad, H, W, ld), dtype=dtype, device=x.device)
+    out[..., :C] = x.permute(0, 2, 3, 4, 1).to(dtype)
+    return out
+
+
+def ndhwc_to_ncthw(x, c, ttrim=0):
+    return x[:, ttrim:, :, :, :c].float().permute(0, 4, 1, 2, 3).contiguous()
+
+
+def time_avgpool3s2(x, tmode=L.VT_TPAD_ZERO, cache=None):
+    xf = x.float()
+    if tmode == L.VT_TPAD_ZERO:
+        front = torch.zeros_like(xf[:, :1])
+    elif tmode == L.VT_TPAD_REPLICATE:
+        front = xf[:, :1]
+    else:
+        front = cache.float().reshape(xf[:, :1].shape)
+    xp = torch.cat([front, xf], dim=1)
+    To = x.shape[1] // 2
+    y = (xp[:, 0:2 * To:2] + xp[:, 1:2 * To + 1:2] + xp[:, 2:2 * To + 2:2]) / 3.0
+    return y.to(x.dtype)
+
+
+def time_lerp2x(x):
+    y = F.interpolate(x.float().permute(0, 4, 1, 2, 3), scale_factor=[2.0, 1.0, 1.0], mode="trilinear")
+    return y.permute(0, 2, 3, 4, 1).to(x.dtype).contiguous()
+
+
+def gather_frames(src, idx):
+    return src[:, list(idx)].contiguous()
+
+
+def kl_sample(h, noise):
+    mean, logvar = torch.chunk(h, 2, dim=1)
+    logvar = logvar.clamp(-30.0, 20.0)
+    z = mean if noise is None else mean + torch.exp(0.5 * logvar) * noise
+    kl = 0.5 * torch.sum(mean * mean + torch.exp(logvar) - 1.0 - logvar) / h.shape[0]
+    return z.contiguous(), kl
+
+
+def _fsq_consts(levels):
+    lv = torch.tensor(levels, dtype=torch.int32)
+    half_l = (lv - 1) * (1 + 1e-3) / 2
+    offset = torch.where(lv % 2 == 0, 0.5, 0.0)
+    shift = (offset / half_l).atanh()
+    basis = torch.cumprod(torch.tensor([1] + list(levels[:-1])), dim=0, dtype=torch.int32)
+    return lv, half_l, offset, shift, lv // 2, basis
+
+
+def fsq_quantize(h, levels):
+    lv, half_l, offset, shift, half_w, basis = (t.to(h.device) for t in _fsq_consts(levels))
+    zf = h.float().movedim(1, -1)
+    codes = ((zf + shift).tanh() * half_l - offset).round() / half_w
+    idx = ((codes * half_w + half_w) * basis).sum(-1).to(torch.int32)
+    return codes.movedim(-1, 1).contiguous(), idx
+
+
+def fsq_indices_to_codes(idx, levels):
+    lv, _, _, _, half_w, basis = (t.to(idx.device) for t in _fsq_consts(levels))
+    codes = ((idx[..., None] // basis) % lv - half_w) / half_w
+    return codes.movedim(-1, 1).contiguous().float()
+
+
+def fsq_aux_stats(h, levels, inv_temperature=100.0):
+    lv, _, _, _, half_w, basis = (t.to(h.device) for t in _fsq_consts(levels))
+    codes, _ = fsq_quantize(h, levels)
+    zf = h.float().movedim(1, -1).reshape(-1, len(levels))
+    J = int(torch.prod(lv))
+    cb = ((torch.arange(J, device=h.device)[:, None] // basis) % lv - half_w) / half_w
+    ent, avg = 0.0, torch.zeros(J, device=h.device)
+    for s in range(0, zf.shape[0], 1024):
+        p = ((2.0 * zf[s:s + 1024] @ cb.t()) * inv_temperature).softmax(-1)
+        ent = ent + (-p * p.clamp(min=1e-5).log()).sum()
+        avg = avg + p.sum(0)
+    avg = avg / zf.shape[0]
+    cbe = (-avg * avg.clamp(min=1e-5).log()).sum()
+    commit = ((h.float() - codes) ** 2).mean()
+    return torch.stack([ent / zf.shape[0], cbe, commit])
+
+
+def fsq_consts(levels):
+    _, half_l, offset, shift, _, basis = _fsq_consts(levels)
+    return half_l.tolist(), offset.tolist(), shift.tolist(), [float(b) for b in basis]
+
+
+ALL = ["conv", "gemm_nt", "layernorm_act", "softmax_rows", "ncthw_to_ndhwc", "ndhwc_to_ncthw", "time_avgpool3s2",
+       "time_lerp2x", "gather_frames", "kl_sample", "fsq_quantize", "fsq_indices_to_codes", "fsq_aux_stats"]
+
+
+def patch_ops(monkeypatch):
+    """Swap the reference statements in for the HIP operators (CPU host-logic tests only)."""
+    import vidtok_amd.ops as ops
+
+    g = globals()
+    for name in ALL:
+        monkeypatch.setattr(ops, name, g[name])

@@ -49,6 +49,7 @@ SIGNATURES = {
     "vt_version": (C.c_int, []),
     "vt_conv_max_lds_bytes": (C.c_int, []),
     "vt_conv": (C.c_int, [C.POINTER(ConvDesc), _P]),
+    "vt_conv_desc_size": (C.c_int, []),
     "vt_layernorm_act": (C.c_int, [_P, C.c_int, _I64, _P, C.c_int, _I64, _P, _P, _I64, _I32, _F, _I32, _P]),
     "vt_softmax_rows": (C.c_int, [_P, _P, C.c_int, _I64, _I32, _I64, _F, _P]),
     "vt_ncthw_to_ndhwc": (C.c_int, [_P, _P, C.c_int, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _P]),

@@ -18,6 +18,22 @@ _DT = {torch.float32: L.VT_F32, torch.bfloat16: L.VT_BF16}
 CH_ALIGN = 8  # channel padding granule: 16 B of bf16 (and a multiple of the 4-float fp32 granule)
 
 
+# Optional launch timeline for bench.py's roofline leg: when set to a list, every vt_conv launch
+# appends (start_event, end_event, label) recorded on the launch stream.  None in normal use.
+CONV_TIMELINE = None
+
+
+def _conv_launch(lib, d, what):
+    if CONV_TIMELINE is None:
+        L.check(lib.vt_conv(C.byref(d), _stream()), what)
+        return
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    L.check(lib.vt_conv(C.byref(d), _stream()), what)
+    e1.record()
+    CONV_TIMELINE.append((e0, e1, (d.B * d.To * d.Ho * d.Wo * max(1, d.nbatch), d.Cout, d.KT * d.KH * d.KW * d.Cin)))
+
+
 def pad_channels(c: int) -> int:
     return (c + CH_ALIGN - 1) // CH_ALIGN * CH_ALIGN
 
@@ -112,7 +128,7 @@ def conv(x, w, bias, geom: ConvGeom, *, cout: int, out_dtype=None, tmode=L.VT_TP
     d.out_layout, d.t_trim = out_layout, t_trim
     d.dtype, d.out_dtype = _DT[x.dtype], _DT[out_dtype]
     d.nbatch = 1
-    L.check(lib.vt_conv(C.byref(d), _stream()), "vt_conv")
+    _conv_launch(lib, d, "vt_conv")
     return y
 
 
@@ -138,7 +154,7 @@ def gemm_nt(a, b, *, out_dtype=None, bias=None):
     d.dtype, d.out_dtype = _DT[a.dtype], _DT[out_dtype]
     d.nbatch = Z
     d.xs_z, d.ws_z, d.ys_z = (M * K if Za == Z else 0), N * K, M * N
-    L.check(lib.vt_conv(C.byref(d), _stream()), "vt_conv(gemm)")
+    _conv_launch(lib, d, "vt_conv(gemm)")
     return y
 
 
