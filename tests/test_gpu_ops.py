@@ -201,7 +201,7 @@ def test_fsq_quantize_bit_exact(levels):
     zr, idxr = R.fsq_quantize(h.cpu(), levels)          # CPU torch: the reference's own arithmetic
     n_bad = int((idx.cpu() != idxr).sum())
     print(f"fsq levels={levels}: {n_bad} / {idx.numel()} index mismatches vs CPU torch")
-    assert idx.dtype == torch.int32 and n_bad <= 1      # a 1-ulp tanh difference on a rounding boundary
+    assert idx.dtype == torch.int32 and n_bad <= 1      # only a 1-ulp tanh difference on a rounding boundary
     if n_bad == 0:
         assert torch.equal(z.cpu(), zr)
     # round trip: indices -> codes == quantised z, bit for bit (SURVEY.md section 8c identity)

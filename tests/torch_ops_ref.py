@@ -58,12 +58,15 @@ def conv(x, w, bias, geom, *, cout, out_dtype=None, tmode=L.VT_TPAD_ZERO, cache=
     return out
 
 
-def gemm_nt(a, b, *, out_dtype=None, bias=None):
+def gemm_nt(a, b, *, out_dtype=None, bias=None, ld_out=None):
     out_dtype = out_dtype or a.dtype
     y = torch.matmul(a.float(), b.float().transpose(-1, -2))
     if bias is not None:
         y = y + bias.float()[: y.shape[-1]]
-    return y.to(out_dtype)
+    y = y.to(out_dtype)
+    if ld_out and ld_out > y.shape[-1]:
+        y = F.pad(y, (0, ld_out - y.shape[-1]))
+    return y.contiguous()
 
 
 def layernorm_act(x, gamma, beta, *, silu, eps=1e-6, out_dtype=None, c=None):
@@ -77,8 +80,11 @@ def layernorm_act(x, gamma, beta, *, silu, eps=1e-6, out_dtype=None, c=None):
     return out
 
 
-def softmax_rows(s, scale, out_dtype):
-    return torch.softmax(s.float() * scale, dim=-1).to(out_dtype)
+def softmax_rows(s, scale, out_dtype, ld_out=None):
+    p = torch.softmax(s.float() * scale, dim=-1).to(out_dtype)
+    if ld_out and ld_out > p.shape[-1]:
+        p = F.pad(p, (0, ld_out - p.shape[-1]))
+    return p.contiguous()
 
 
 def ncthw_to_ndhwc(x, dtype, tpad=0, ld=None):

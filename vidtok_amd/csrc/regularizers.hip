@@ -69,15 +69,16 @@ __global__ __launch_bounds__(kBlock) void fsq_quantize_kernel(const float* __res
   const long long n = (long long)B * S;
   for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < n; i += (long long)gridDim.x * kBlock) {
     const long long b = i / S, s = i - b * S;
-    float idx = 0.f;
+    int idx = 0;
     for (int d = 0; d < k.D; ++d) {
       const float q = fsq_round(h[(b * k.D + d) * S + s], k.shift[d], k.half_l[d], k.offset[d]);
-      const float code = q / k.half_w[d];
-      z[(b * k.D + d) * S + s] = code;
-      // codes_to_indices: (code*half_w + half_w) * basis, summed in fp32 (exact: < 2^24)
-      idx += (code * k.half_w[d] + k.half_w[d]) * (float)k.basis[d];
+      z[(b * k.D + d) * S + s] = q / k.half_w[d];
+      // codes_to_indices (regularizers.py:174-178): (code*half_w + half_w)*basis summed in fp32 and
+      // truncated.  Every term of that sum is an exact small integer (q/hw*hw rounds back to q), so
+      // integer arithmetic gives the reference's value without depending on FMA contraction.
+      idx += ((int)q + k.levels[d] / 2) * k.basis[d];
     }
-    indices[i] = (int)idx;
+    indices[i] = idx;
   }
 }
 

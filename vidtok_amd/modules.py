@@ -373,9 +373,10 @@ class AttnBlockWrapper(nn.Module):
         q = self.q.run(hn, dt).view(Z, S, Cc)
         k = self.k.run(hn, dt).view(Z, S, Cc)
         wv, bv = self.v._pack.get(self.v.conv.weight, self.v.conv.bias, dt, cin_stored=Cc)
-        vT = ops.gemm_nt(wv.view(1, Cc, Cc), hn.view(Z, S, Cc))                               # [Z, C, S]
+        Sp = ops.pad_channels(S)        # K-contiguous operands need 16-byte rows: pad S with zero columns
+        vT = ops.gemm_nt(wv.view(1, Cc, Cc), hn.view(Z, S, Cc), ld_out=Sp)                     # [Z, C, Sp]
         s = ops.gemm_nt(q, k, out_dtype=torch.float32)                                         # [Z, S, S]
-        p = ops.softmax_rows(s, float(Cc) ** -0.5, dt)
+        p = ops.softmax_rows(s, float(Cc) ** -0.5, dt, ld_out=Sp)                              # [Z, S, Sp]
         o = ops.gemm_nt(p, vT, bias=bv).view(B, T, H, W, Cc)
         return self.proj_out.run(o, dt, res=x, res_mode=L.VT_RES_ADD)
 

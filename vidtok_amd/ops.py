@@ -132,28 +132,31 @@ def conv(x, w, bias, geom: ConvGeom, *, cout: int, out_dtype=None, tmode=L.VT_TP
     return y
 
 
-def gemm_nt(a, b, *, out_dtype=None, bias=None):
+def gemm_nt(a, b, *, out_dtype=None, bias=None, ld_out=None):
     """Batched C[z] = A[z] @ B[z]^T : a [Z or 1, M, K], b [Z, N, K] -> [Z, M, N] (the two matmuls of
     scaled_dot_product_attention, reference model_3dcausal.py:140) on the vt_conv kernel.
-    a with leading dim 1 is broadcast over Z (stride 0)."""
+    a with leading dim 1 is broadcast over Z (stride 0).  ld_out > N returns [Z, M, ld_out] with the
+    columns N.. zero (so the result can be the K-contiguous operand of a following gemm_nt)."""
     lib = L.load()
     _chk(a, "gemm.a"); _chk(b, "gemm.b")
     Za, M, K = a.shape
     Z, N, Kb = b.shape
     assert Za in (1, Z) and K == Kb and a.dtype == b.dtype
     out_dtype = out_dtype or a.dtype
-    y = torch.empty((Z, M, N), dtype=out_dtype, device=a.device)
+    ldo = ld_out or N
+    assert ldo >= N
+    y = (torch.empty if ldo == N else torch.zeros)((Z, M, ldo), dtype=out_dtype, device=a.device)
     d = L.ConvDesc()
     d.x, d.w, d.y = a.data_ptr(), b.data_ptr(), y.data_ptr()
     d.bias = bias.data_ptr() if bias is not None else None
     d.B, d.Ti, d.Hi, d.Wi, d.Cin = 1, 1, 1, M, K
     d.To, d.Ho, d.Wo, d.Cout = 1, 1, M, N
-    d.ldw, d.ldy = K, N
+    d.ldw, d.ldy = K, ldo
     d.KT = d.KH = d.KW = 1
     d.st = d.sh = d.sw = 1
     d.dtype, d.out_dtype = _DT[a.dtype], _DT[out_dtype]
     d.nbatch = Z
-    d.xs_z, d.ws_z, d.ys_z = (M * K if Za == Z else 0), N * K, M * N
+    d.xs_z, d.ws_z, d.ys_z = (M * K if Za == Z else 0), N * K, M * ldo
     _conv_launch(lib, d, "vt_conv(gemm)")
     return y
 
@@ -174,14 +177,16 @@ def layernorm_act(x, gamma, beta, *, silu: bool, eps: float = 1e-6, out_dtype=No
     return y
 
 
-def softmax_rows(s, scale: float, out_dtype):
+def softmax_rows(s, scale: float, out_dtype, ld_out=None):
+    """softmax(scale*s) over the last dim; ld_out > cols pads the output rows with zeros."""
     lib = L.load()
     _chk(s, "softmax.s")
     assert s.dtype == torch.float32
     cols = s.shape[-1]
     rows = s.numel() // cols
-    p = torch.empty(s.shape, dtype=out_dtype, device=s.device)
-    L.check(lib.vt_softmax_rows(_ptr(s), _ptr(p), _DT[out_dtype], rows, cols, cols, float(scale), _stream()),
+    ldo = ld_out or cols
+    p = (torch.empty if ldo == cols else torch.zeros)(tuple(s.shape[:-1]) + (ldo,), dtype=out_dtype, device=s.device)
+    L.check(lib.vt_softmax_rows(_ptr(s), _ptr(p), _DT[out_dtype], rows, cols, ldo, float(scale), _stream()),
             "vt_softmax_rows")
     return p
 
