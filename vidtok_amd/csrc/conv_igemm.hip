@@ -27,6 +27,8 @@
 //     NCTHW (fp32, with front time trim) store;
 //   * XCD-aware tile order: consecutive tiles of one XCD are neighbouring pixel tiles of the same
 //     channel tile, so halo rows and the weight slab are shared in that XCD's L2.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -81,6 +83,111 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
   const int q = nblk >> 3, r = nblk & 7;
   const int start = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
   return start + loc;
+}
+
+// Epilogue shared by both staging variants: + bias, + residual / alpha-mix, dtype conversion, NDHWC
+// vector store (lane = one pixel, 4 consecutive channels per accumulator quad) or NCTHW fp32 store.
+template <typename TOut, int TM, int TN>
+__device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[TN][TM], int m_blk, int n_blk, int wm,
+                                              int wn, int lane, long long z) {
+  float alpha = 0.0f;
+  if (p.res_mode == VT_RES_MIX) alpha = 1.0f / (1.0f + __expf(-p.mix_factor[0]));
+  TOut* __restrict__ yg = reinterpret_cast<TOut*>(p.y) + z * p.ys_z;
+  const TOut* __restrict__ rg = reinterpret_cast<const TOut*>(p.res) + z * p.rs_z;
+  const long long HWo = (long long)p.Ho * p.Wo;
+
+#pragma unroll
+  for (int b = 0; b < TM; ++b) {
+    const int m = m_blk + (wm * TM + b) * 32 + (lane & 31);
+    if (m >= p.M) continue;
+    long long mr = m;          // residual pixel index
+    long long ybase = 0;       // NCTHW: offset of (b, n=0, to-t_trim, ho, wo)
+    bool store_ok = true;
+    if (p.res_tshift != 0 || p.Tr != p.To || p.out_layout == VT_NCTHW) {
+      const long long hw = m % HWo;
+      const long long r = m / HWo;
+      const int to = (int)(r % p.To);
+      const int bb = (int)(r / p.To);
+      mr = ((long long)bb * p.Tr + (to >> p.res_tshift)) * HWo + hw;
+      if (p.out_layout == VT_NCTHW) {
+        const int Tout = p.To - p.t_trim;
+        store_ok = to >= p.t_trim;
+        ybase = ((long long)bb * p.Cout * Tout + (to - p.t_trim)) * HWo + hw;
+      }
+    }
+#pragma unroll
+    for (int a = 0; a < TN; ++a) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int n0 = n_blk + (wn * TN + a) * 32 + 8 * g + 4 * (lane >> 5);
+        if (n0 >= p.Cout) continue;
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = acc[a][b][4 * g + e];
+        const bool full = (n0 + 3 < p.Cout);
+        if (p.bias) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (full || n0 + e < p.Cout) v[e] += p.bias[n0 + e];
+        }
+        if (p.res_mode != VT_RES_NONE) {
+          float rv[4] = {0.f, 0.f, 0.f, 0.f};
+          const TOut* rp = rg + mr * p.ldr + n0;
+          if (full && (p.ldr & 3) == 0) {
+            if constexpr (sizeof(TOut) == 4) {
+              const f32x4 t = *reinterpret_cast<const f32x4*>(rp);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) rv[e] = t[e];
+            } else {
+              const u32x2 t = *reinterpret_cast<const u32x2*>(rp);
+              rv[0] = bf16_bits_to_f32(t[0] & 0xffffu);
+              rv[1] = bf16_bits_to_f32(t[0] >> 16);
+              rv[2] = bf16_bits_to_f32(t[1] & 0xffffu);
+              rv[3] = bf16_bits_to_f32(t[1] >> 16);
+            }
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              if (n0 + e < p.Cout) rv[e] = to_f32<TOut>(rp[e]);
+          }
+          if (p.res_mode == VT_RES_ADD) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = rv[e] + v[e];
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = alpha * rv[e] + (1.0f - alpha) * v[e];
+          }
+        }
+        if (p.out_layout == VT_NCTHW) {
+          if (store_ok) {
+            const int Tout = p.To - p.t_trim;
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              if (n0 + e < p.Cout) yg[ybase + (long long)(n0 + e) * Tout * HWo] = from_f32<TOut>(v[e]);
+          }
+        } else {
+          TOut* yp = yg + (long long)m * p.ldy + n0;
+          if (full && (p.ldy & 3) == 0) {
+            if constexpr (sizeof(TOut) == 4) {
+              f32x4 t;
+#pragma unroll
+              for (int e = 0; e < 4; ++e) t[e] = v[e];
+              *reinterpret_cast<f32x4*>(yp) = t;
+            } else {
+              u32x2 t;
+              t[0] = f32_to_bf16_bits(v[0]) | (f32_to_bf16_bits(v[1]) << 16);
+              t[1] = f32_to_bf16_bits(v[2]) | (f32_to_bf16_bits(v[3]) << 16);
+              *reinterpret_cast<u32x2*>(yp) = t;
+            }
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              if (n0 + e < p.Cout) yp[e] = from_f32<TOut>(v[e]);
+          }
+        }
+      }
+    }
+  }
 }
 
 template <typename MT, typename TOut, int WAVES_M, int WAVES_N, int TM, int TN, bool FAST>
@@ -255,105 +362,228 @@ __global__ __launch_bounds__(kThreads) void conv_igemm_kernel(const ConvArgs p) 
     __syncthreads();
   }
 
-  // ---- epilogue --------------------------------------------------------------------------------
-  float alpha = 0.0f;
-  if (p.res_mode == VT_RES_MIX) alpha = 1.0f / (1.0f + __expf(-p.mix_factor[0]));
-  TOut* __restrict__ yg = reinterpret_cast<TOut*>(p.y) + z * p.ys_z;
-  const TOut* __restrict__ rg = reinterpret_cast<const TOut*>(p.res) + z * p.rs_z;
-  const long long HWo = (long long)p.Ho * p.Wo;
+  conv_epilogue<TOut, TM, TN>(p, acc, m_blk, n_blk, wm, wn, lane, z);
+}
 
+
+// ------------------------------------------------------------------------------------------------
+// LDS-DMA variant (default): the operand tiles go global -> LDS with global_load_lds_dwordx4
+// (no VGPR round trip, no ds_write pass -- on the register-staged variant the ds_write_b128 stream
+// alone costs ~415 LDS cycles per K step against 512 MFMA cycles).  The DMA writes each wave's 64
+// lanes x 16 B to a contiguous 1 KiB, so a tile row is exactly 128 B (no pad) and instruction i of
+// wave w fills rows 32*i + 8*w .. +8.  Bank conflicts are removed with an XOR swizzle applied on the
+// SOURCE side (guide rule 21): the lane that writes 16-B slot `pos` of row r fetches logical K chunk
+// pos ^ ((r>>1)&7); the fragment read of logical chunk c goes to slot c ^ ((r>>1)&7), which spreads
+// every 16-lane ds_read_b128 service group over all 16 slots of the 256-B bank row.  Taps that fall
+// in padding (and rows beyond M / Cout, K beyond taps*Cin) fetch from a zero page instead.
+// Pipeline: 2 LDS stages; per K step  wait own DMA (vmcnt 0) -> barrier -> issue DMA of step s+1 ->
+// MFMAs of step s, so a full step of MFMA work covers the DMA flight.  On the fast path (Cin a
+// multiple of the K step) the gather addresses are recomputed only when the tap changes.
+// ------------------------------------------------------------------------------------------------
+__device__ u32x4 g_zero_page[8];   // 128 B of zeros (static device memory, zero-initialised)
+
+template <typename MT, typename TOut, int WAVES_M, int WAVES_N, int TM, int TN, bool FAST, bool PRELOAD>
+__global__ __launch_bounds__(kThreads) void conv_igemm_glds_kernel(const ConvArgs p) {
+  constexpr int VEC = 16 / (int)sizeof(MT);
+  constexpr int BK = kRowBytes / (int)sizeof(MT);
+  constexpr int BM = WAVES_M * TM * 32;
+  constexpr int BN = WAVES_N * TN * 32;
+  constexpr int A_VECS = BM * 8 / kThreads;
+  constexpr int B_VECS = BN * 8 / kThreads;
+  constexpr int A_BYTES = BM * kRowBytes;
+  constexpr int STAGE_BYTES = (BM + BN) * kRowBytes;
+  static_assert(WAVES_M * WAVES_N == 4, "4 waves per workgroup");
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  typedef __attribute__((address_space(3))) void* lds_ptr_t;
+  typedef const __attribute__((address_space(1))) void* glb_ptr_t;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave % WAVES_M;
+  const int wn = wave / WAVES_M;
+
+  const int tile = xcd_remap(blockIdx.x, p.m_tiles * p.n_tiles);
+  const int nt = tile / p.m_tiles;
+  const int mt = tile - nt * p.m_tiles;
+  const int m_blk = mt * BM;
+  const int n_blk = nt * BN;
+
+  const long long z = blockIdx.z;
+  const MT* __restrict__ xg = reinterpret_cast<const MT*>(p.x) + z * p.xs_z;
+  const MT* __restrict__ wg = reinterpret_cast<const MT*>(p.w) + z * p.ws_z;
+  const MT* __restrict__ cg = reinterpret_cast<const MT*>(p.cache);
+  const MT* zero = reinterpret_cast<const MT*>(g_zero_page);
+
+  const int pos = tid & 7;                       // 16-B slot this lane writes in its rows
+  const int srow = tid >> 3;                     // rows srow + 32*i
+  const int chunk = pos ^ ((srow >> 1) & 7);     // logical K chunk this lane fetches (same for all i)
+  const int lds_row_off = (wave * 8) * kRowBytes;   // wave-uniform part of the DMA destination
+
+  const int Hv = p.Hi << p.ups_s, Wv = p.Wi << p.ups_s;
+  const int Tv = p.Ti << p.ups_t;
+
+  int a_b[A_VECS], a_t0[A_VECS], a_h0[A_VECS], a_w0[A_VECS];
 #pragma unroll
-  for (int b = 0; b < TM; ++b) {
-    const int m = m_blk + (wm * TM + b) * 32 + (lane & 31);
-    if (m >= p.M) continue;
-    long long mr = m;          // residual pixel index
-    long long ybase = 0;       // NCTHW: offset of (b, n=0, to-t_trim, ho, wo)
-    bool store_ok = true;
-    if (p.res_tshift != 0 || p.Tr != p.To || p.out_layout == VT_NCTHW) {
-      const long long hw = m % HWo;
-      const long long r = m / HWo;
-      const int to = (int)(r % p.To);
-      const int bb = (int)(r / p.To);
-      mr = ((long long)bb * p.Tr + (to >> p.res_tshift)) * HWo + hw;
-      if (p.out_layout == VT_NCTHW) {
-        const int Tout = p.To - p.t_trim;
-        store_ok = to >= p.t_trim;
-        ybase = ((long long)bb * p.Cout * Tout + (to - p.t_trim)) * HWo + hw;
-      }
-    }
-#pragma unroll
-    for (int a = 0; a < TN; ++a) {
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int n0 = n_blk + (wn * TN + a) * 32 + 8 * g + 4 * (lane >> 5);
-        if (n0 >= p.Cout) continue;
-        float v[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = acc[a][b][4 * g + e];
-        const bool full = (n0 + 3 < p.Cout);
-        if (p.bias) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e)
-            if (full || n0 + e < p.Cout) v[e] += p.bias[n0 + e];
-        }
-        if (p.res_mode != VT_RES_NONE) {
-          float rv[4] = {0.f, 0.f, 0.f, 0.f};
-          const TOut* rp = rg + mr * p.ldr + n0;
-          if (full && (p.ldr & 3) == 0) {
-            if constexpr (sizeof(TOut) == 4) {
-              const f32x4 t = *reinterpret_cast<const f32x4*>(rp);
-#pragma unroll
-              for (int e = 0; e < 4; ++e) rv[e] = t[e];
-            } else {
-              const u32x2 t = *reinterpret_cast<const u32x2*>(rp);
-              rv[0] = bf16_bits_to_f32(t[0] & 0xffffu);
-              rv[1] = bf16_bits_to_f32(t[0] >> 16);
-              rv[2] = bf16_bits_to_f32(t[1] & 0xffffu);
-              rv[3] = bf16_bits_to_f32(t[1] >> 16);
-            }
-          } else {
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-              if (n0 + e < p.Cout) rv[e] = to_f32<TOut>(rp[e]);
-          }
-          if (p.res_mode == VT_RES_ADD) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = rv[e] + v[e];
-          } else {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = alpha * rv[e] + (1.0f - alpha) * v[e];
-          }
-        }
-        if (p.out_layout == VT_NCTHW) {
-          if (store_ok) {
-            const int Tout = p.To - p.t_trim;
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-              if (n0 + e < p.Cout) yg[ybase + (long long)(n0 + e) * Tout * HWo] = from_f32<TOut>(v[e]);
-          }
-        } else {
-          TOut* yp = yg + (long long)m * p.ldy + n0;
-          if (full && (p.ldy & 3) == 0) {
-            if constexpr (sizeof(TOut) == 4) {
-              f32x4 t;
-#pragma unroll
-              for (int e = 0; e < 4; ++e) t[e] = v[e];
-              *reinterpret_cast<f32x4*>(yp) = t;
-            } else {
-              u32x2 t;
-              t[0] = f32_to_bf16_bits(v[0]) | (f32_to_bf16_bits(v[1]) << 16);
-              t[1] = f32_to_bf16_bits(v[2]) | (f32_to_bf16_bits(v[3]) << 16);
-              *reinterpret_cast<u32x2*>(yp) = t;
-            }
-          } else {
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-              if (n0 + e < p.Cout) yp[e] = from_f32<TOut>(v[e]);
-          }
-        }
-      }
+  for (int i = 0; i < A_VECS; ++i) {
+    const int m = m_blk + srow + 32 * i;
+    if (m < p.M) {
+      int wo = m % p.Wo;
+      int r = m / p.Wo;
+      int ho = r % p.Ho;
+      r /= p.Ho;
+      int to = r % p.To;
+      a_b[i] = r / p.To;
+      a_t0[i] = to * p.st - p.pt;
+      a_h0[i] = ho * p.sh - p.ph;
+      a_w0[i] = wo * p.sw - p.pw;
+    } else {
+      a_b[i] = -1;
+      a_t0[i] = a_h0[i] = a_w0[i] = 0;
     }
   }
+  const MT* b_row[B_VECS];
+#pragma unroll
+  for (int j = 0; j < B_VECS; ++j) {
+    const int n = n_blk + srow + 32 * j;
+    b_row[j] = (n < p.Cout) ? wg + (long long)n * p.ldw : nullptr;
+  }
+
+  // address of the first element of input row i for tap (kt,kh,kw), or nullptr when it reads padding
+  auto row_ptr = [&](int i, int kt, int kh, int kw) -> const MT* {
+    int tv = a_t0[i] + kt;
+    const int hv = a_h0[i] + kh;
+    const int wv = a_w0[i] + kw;
+    bool ok = (a_b[i] >= 0) && (hv >= 0) && (hv < Hv) && (wv >= 0) && (wv < Wv) && (tv < Tv);
+    const MT* base = xg;
+    int tstore = p.Ti, ti;
+    if (tv < 0) {
+      if (p.tmode == VT_TPAD_ZERO) {
+        ok = false;
+        ti = 0;
+      } else if (p.tmode == VT_TPAD_REPLICATE) {
+        ti = 0;
+      } else {
+        base = cg;
+        tstore = p.ncache;
+        ti = p.ncache + tv;
+        ok = ok && (ti >= 0);
+      }
+    } else {
+      ti = tv >> p.ups_t;
+    }
+    if (!ok) return nullptr;
+    const int hi = hv >> p.ups_s, wi = wv >> p.ups_s;
+    const long long pix = (((long long)a_b[i] * tstore + ti) * p.Hi + hi) * p.Wi + wi;
+    return base + pix * p.Cin;
+  };
+
+  const int khw = p.KH * p.KW;
+  const int cpb = FAST ? (p.Cin / BK) : 1;
+  const MT* a_ptr[A_VECS];       // FAST: cached per tap
+  int cur_tap = -1;
+
+  auto issue_step = [&](int s, int buf) {
+    char* As = smem + buf * STAGE_BYTES + lds_row_off;
+    char* Bs = As + A_BYTES;
+    int koff;          // element offset of this lane's chunk inside the weight row
+    int coff;          // element offset inside the pixel's channel vector
+    bool kvalid = true;
+    if (FAST) {
+      const int tap = s / cpb;
+      const int cc = s - tap * cpb;
+      if (tap != cur_tap) {          // uniform branch: new tap -> new gather addresses
+        cur_tap = tap;
+        const int kt = tap / khw;
+        const int r2 = tap - kt * khw;
+        const int kh = r2 / p.KW;
+        const int kw = r2 - kh * p.KW;
+#pragma unroll
+        for (int i = 0; i < A_VECS; ++i) a_ptr[i] = row_ptr(i, kt, kh, kw);
+      }
+      coff = cc * BK + chunk * VEC;
+      koff = s * BK + chunk * VEC;
+    } else {
+      const int k = s * BK + chunk * VEC;
+      const int tap = k / p.Cin;
+      coff = k - tap * p.Cin;
+      koff = k;
+      kvalid = tap < p.ntaps;
+      const int kt = tap / khw;
+      const int r2 = tap - kt * khw;
+      const int kh = r2 / p.KW;
+      const int kw = r2 - kh * p.KW;
+#pragma unroll
+      for (int i = 0; i < A_VECS; ++i) a_ptr[i] = kvalid ? row_ptr(i, kt, kh, kw) : nullptr;
+    }
+#pragma unroll
+    for (int i = 0; i < A_VECS; ++i) {
+      const MT* src = a_ptr[i] ? a_ptr[i] + coff : zero;
+      __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)(As + (32 * i) * kRowBytes), 16, 0, 0);
+    }
+#pragma unroll
+    for (int j = 0; j < B_VECS; ++j) {
+      const MT* src = (b_row[j] && kvalid) ? b_row[j] + koff : zero;
+      __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)(Bs + (32 * j) * kRowBytes), 16, 0, 0);
+    }
+  };
+
+  f32x16 acc[TN][TM];
+#pragma unroll
+  for (int a = 0; a < TN; ++a)
+#pragma unroll
+    for (int b = 0; b < TM; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
+
+  const int frag_row = (lane & 31) * kRowBytes;
+  const int swz = ((lane & 31) >> 1) & 7;
+  const int khalf = lane >> 5;
+
+  auto compute_stage = [&](int buf) {
+    const char* As = smem + buf * STAGE_BYTES + (wm * TM * 32) * kRowBytes + frag_row;
+    const char* Bs = smem + buf * STAGE_BYTES + A_BYTES + (wn * TN * 32) * kRowBytes + frag_row;
+    // all 4*(TM+TN) fragment reads of the stage are issued up front; the MFMAs then start as soon as
+    // their operands land (counted lgkmcnt), so LDS latency hides under the matrix pipe
+    u32x4 wf[4][TN], xf[4][TM];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const int slot = ((ks * 2 + khalf) ^ swz) * 16;
+#pragma unroll
+      for (int a = 0; a < TN; ++a) wf[ks][a] = *reinterpret_cast<const u32x4*>(Bs + a * 32 * kRowBytes + slot);
+#pragma unroll
+      for (int b = 0; b < TM; ++b) xf[ks][b] = *reinterpret_cast<const u32x4*>(As + b * 32 * kRowBytes + slot);
+    }
+    if (PRELOAD) __builtin_amdgcn_sched_barrier(0);   // keep the read burst ahead of the MFMA chain
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+      for (int a = 0; a < TN; ++a)
+#pragma unroll
+        for (int b = 0; b < TM; ++b) mma_step<MT>(wf[ks][a], xf[ks][b], acc[a][b]);
+  };
+
+  issue_step(0, 0);
+  for (int s = 0; s < p.nsteps; ++s) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // my DMA pieces of step s have landed
+    __syncthreads();                                    // everyone's have; stage (s+1)&1 is free again
+    if (s + 1 < p.nsteps) issue_step(s + 1, (s + 1) & 1);
+    compute_stage(s & 1);
+  }
+  conv_epilogue<TOut, TM, TN>(p, acc, m_blk, n_blk, wm, wn, lane, z);
+}
+
+// Staging variant: LDS-DMA (default); VT_CONV_IMPL=reg | glds | glds2 selects a variant for A/B runs.
+inline int conv_impl() {
+  static int mode = -1;
+  if (mode < 0) {
+    const char* e = getenv("VT_CONV_IMPL");
+    mode = 1;
+    if (e && strcmp(e, "reg") == 0) mode = 0;
+    if (e && strcmp(e, "glds2") == 0) mode = 2;
+  }
+  return mode;
 }
 
 template <typename MT, typename TOut, int WAVES_M, int WAVES_N, int TM, int TN, bool FAST>
@@ -361,17 +591,21 @@ int launch_variant(const ConvArgs& a_in, int nbatch, hipStream_t stream) {
   constexpr int BM = WAVES_M * TM * 32;
   constexpr int BN = WAVES_N * TN * 32;
   constexpr int BK = kRowBytes / (int)sizeof(MT);
-  constexpr int LDS = 2 * (BM + BN) * kLdsRowBytes;
+  const int impl = conv_impl();   // 0 register staging, 1 LDS-DMA, 2 LDS-DMA + pinned read burst
+  const bool glds = impl != 0;
+  const int LDS = 2 * (BM + BN) * (glds ? kRowBytes : kLdsRowBytes);
   ConvArgs a = a_in;
   a.m_tiles = (a.M + BM - 1) / BM;
   a.n_tiles = (a.Cout + BN - 1) / BN;
   a.nsteps = FAST ? a.ntaps * (a.Cin / BK) : (a.K + BK - 1) / BK;
-  auto kern = conv_igemm_kernel<MT, TOut, WAVES_M, WAVES_N, TM, TN, FAST>;
-  static bool attr_done = false;  // per instantiation
-  if (!attr_done) {
+  auto kern = impl == 2   ? conv_igemm_glds_kernel<MT, TOut, WAVES_M, WAVES_N, TM, TN, FAST, true>
+              : impl == 1 ? conv_igemm_glds_kernel<MT, TOut, WAVES_M, WAVES_N, TM, TN, FAST, false>
+                          : conv_igemm_kernel<MT, TOut, WAVES_M, WAVES_N, TM, TN, FAST>;
+  static bool attr_done[3] = {false, false, false};  // per instantiation and variant
+  if (!attr_done[impl]) {
     VT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
-    attr_done = true;
+    attr_done[impl] = true;
   }
   const long long nblk = (long long)a.m_tiles * a.n_tiles;
   VT_CHECK_ARG(nblk < (1ll << 31), "vt_conv: too many tiles (%lld)", nblk);

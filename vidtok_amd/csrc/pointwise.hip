@@ -45,9 +45,45 @@ __device__ __forceinline__ void store4<bf16_t>(bf16_t* p, const float (&v)[4]) {
 }
 
 // ---- LayerNorm over C (+SiLU) ---------------------------------------------------------------
-// LP lanes cooperate on one position; each lane owns R chunks of 4 channels (chunk r covers
-// channels (r*LP + l)*4 .. +3).  Two-pass statistics in registers (mean, then centred sum of
-// squares): same biased variance as torch.nn.LayerNorm, fp32 throughout.
+// LP lanes cooperate on one position; each lane owns R chunks of 8 channels (chunk r covers
+// channels (r*LP + l)*8 .. +7: one 16-B load in bf16, two in fp32).  Two-pass statistics in
+// registers (mean, then centred sum of squares): same biased variance as torch.nn.LayerNorm, fp32.
+template <typename T>
+__device__ __forceinline__ void load8(const T* p, float (&v)[8]);
+template <>
+__device__ __forceinline__ void load8<float>(const float* p, float (&v)[8]) {
+  const f32x4 a = *reinterpret_cast<const f32x4*>(p);
+  const f32x4 b = *reinterpret_cast<const f32x4*>(p + 4);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { v[e] = a[e]; v[4 + e] = b[e]; }
+}
+template <>
+__device__ __forceinline__ void load8<bf16_t>(const bf16_t* p, float (&v)[8]) {
+  const u32x4 t = *reinterpret_cast<const u32x4*>(p);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    v[2 * e] = bf16_bits_to_f32(t[e] & 0xffffu);
+    v[2 * e + 1] = bf16_bits_to_f32(t[e] >> 16);
+  }
+}
+template <typename T>
+__device__ __forceinline__ void store8(T* p, const float (&v)[8]);
+template <>
+__device__ __forceinline__ void store8<float>(float* p, const float (&v)[8]) {
+  f32x4 a, b;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { a[e] = v[e]; b[e] = v[4 + e]; }
+  *reinterpret_cast<f32x4*>(p) = a;
+  *reinterpret_cast<f32x4*>(p + 4) = b;
+}
+template <>
+__device__ __forceinline__ void store8<bf16_t>(bf16_t* p, const float (&v)[8]) {
+  u32x4 t;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) t[e] = f32_to_bf16_bits(v[2 * e]) | (f32_to_bf16_bits(v[2 * e + 1]) << 16);
+  *reinterpret_cast<u32x4*>(p) = t;
+}
+
 template <typename TI, typename TO, int LP, int R>
 __global__ __launch_bounds__(kBlock) void layernorm_act_kernel(const TI* __restrict__ x, long long ldx,
                                                                TO* __restrict__ y, long long ldy,
@@ -57,27 +93,28 @@ __global__ __launch_bounds__(kBlock) void layernorm_act_kernel(const TI* __restr
   constexpr int GROUPS = kBlock / LP;
   const int l = threadIdx.x % LP;
   const int g = threadIdx.x / LP;
-  float gm[R][4], bt[R][4];
+  float gm[R][8], bt[R][8];
 #pragma unroll
   for (int r = 0; r < R; ++r) {
-    load4<float>(gamma + (r * LP + l) * 4, gm[r]);
-    load4<float>(beta + (r * LP + l) * 4, bt[r]);
+    load8<float>(gamma + (r * LP + l) * 8, gm[r]);
+    load8<float>(beta + (r * LP + l) * 8, bt[r]);
   }
   const float invC = 1.0f / (float)C;
   for (long long m = (long long)blockIdx.x * GROUPS + g; m < M; m += (long long)gridDim.x * GROUPS) {
-    float v[R][4];
+    float v[R][8];
     float s = 0.f;
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-      load4<TI>(x + m * ldx + (r * LP + l) * 4, v[r]);
-      s += (v[r][0] + v[r][1]) + (v[r][2] + v[r][3]);
+      load8<TI>(x + m * ldx + (r * LP + l) * 8, v[r]);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s += v[r][e];
     }
     const float mean = wave_sum(s, LP) * invC;
     float q = 0.f;
 #pragma unroll
     for (int r = 0; r < R; ++r)
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
+      for (int e = 0; e < 8; ++e) {
         const float d = v[r][e] - mean;
         q += d * d;
       }
@@ -85,13 +122,13 @@ __global__ __launch_bounds__(kBlock) void layernorm_act_kernel(const TI* __restr
     const float rstd = 1.0f / sqrtf(var + eps);
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-      float o[4];
+      float o[8];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
+      for (int e = 0; e < 8; ++e) {
         float t = (v[r][e] - mean) * rstd * gm[r][e] + bt[r][e];
         o[e] = silu ? silu_f32(t) : t;
       }
-      store4<TO>(y + m * ldy + (r * LP + l) * 4, o);
+      store8<TO>(y + m * ldy + (r * LP + l) * 8, o);
     }
   }
 }
@@ -99,12 +136,12 @@ __global__ __launch_bounds__(kBlock) void layernorm_act_kernel(const TI* __restr
 template <typename TI, typename TO>
 int launch_layernorm(const void* x, long long ldx, void* y, long long ldy, const float* gamma,
                      const float* beta, long long M, int C, float eps, int silu, hipStream_t stream) {
-  // choose lanes-per-position LP (power of two <= 64) and chunks-per-lane R with C == 4*LP*R
+  // choose lanes-per-position LP (power of two <= 64) and chunks-per-lane R with C == 8*LP*R
   int LP = 0, R = 0;
-  for (int lp = 64; lp >= 8 && LP == 0; lp >>= 1)
-    for (int r = 1; r <= 8; r <<= 1)
-      if (C == 4 * lp * r) { LP = lp; R = r; break; }
-  VT_CHECK_ARG(LP != 0, "vt_layernorm_act: unsupported channel count C=%d (need C = 4*LP*R, LP in {8..64}, R in {1,2,4,8})", C);
+  for (int lp = 64; lp >= 4 && LP == 0; lp >>= 1)
+    for (int r = 1; r <= 4; r <<= 1)
+      if (C == 8 * lp * r) { LP = lp; R = r; break; }
+  VT_CHECK_ARG(LP != 0, "vt_layernorm_act: unsupported channel count C=%d (need C = 8*LP*R, LP in {4..64}, R in {1,2,4})", C);
   const int groups = kBlock / LP;
   long long blocks = (M + groups - 1) / groups;
   if (blocks > kMaxGrid) blocks = kMaxGrid;
@@ -116,8 +153,8 @@ int launch_layernorm(const void* x, long long ldx, void* y, long long ldy, const
     VT_CHECK_LAUNCH();                                                                               \
     return VT_OK;                                                                                    \
   }
-  VT_LN_CASE(64, 1) VT_LN_CASE(64, 2) VT_LN_CASE(64, 4) VT_LN_CASE(64, 8)
-  VT_LN_CASE(32, 1) VT_LN_CASE(16, 1) VT_LN_CASE(8, 1)
+  VT_LN_CASE(64, 1) VT_LN_CASE(64, 2) VT_LN_CASE(64, 4)
+  VT_LN_CASE(32, 1) VT_LN_CASE(16, 1) VT_LN_CASE(8, 1) VT_LN_CASE(4, 1)
 #undef VT_LN_CASE
   vt_set_error("vt_layernorm_act: no kernel for LP=%d R=%d", LP, R);
   return VT_ERR_UNSUPPORTED;
@@ -278,7 +315,7 @@ extern "C" int vt_layernorm_act(const void* x, int in_dtype, int64_t ldx, void* 
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
   VT_CHECK_ARG(x && y && gamma && beta, "vt_layernorm_act: null pointer");
   VT_CHECK_ARG(M >= 0 && C > 0 && ldx >= C && ldy >= C, "vt_layernorm_act: bad dims");
-  VT_CHECK_ARG(ldx % 4 == 0 && ldy % 4 == 0, "vt_layernorm_act: row strides must be multiples of 4");
+  VT_CHECK_ARG(ldx % 8 == 0 && ldy % 8 == 0, "vt_layernorm_act: row strides must be multiples of 8");
   if (M == 0) return VT_OK;
   if (in_dtype == VT_F32 && out_dtype == VT_F32)
     return launch_layernorm<float, float>(x, ldx, y, ldy, gamma, beta, M, C, eps, silu, stream);
