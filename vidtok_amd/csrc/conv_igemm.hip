@@ -382,17 +382,19 @@ __global__ __launch_bounds__(kThreads) void conv_igemm_kernel(const ConvArgs p) 
 // ------------------------------------------------------------------------------------------------
 __device__ u32x4 g_zero_page[8];   // 128 B of zeros (static device memory, zero-initialised)
 
-template <typename MT, typename TOut, int WAVES_M, int WAVES_N, int TM, int TN, bool FAST, bool PRELOAD>
-__global__ __launch_bounds__(kThreads) void conv_igemm_glds_kernel(const ConvArgs p) {
+template <typename MT, typename TOut, int WAVES_M, int WAVES_N, int TM, int TN, bool FAST>
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_igemm_glds_kernel(const ConvArgs p) {
+  constexpr int THREADS = 64 * WAVES_M * WAVES_N;   // 4 waves (128x128, 256x32/64 tiles) or 8 waves (256x128, 256x256)
+  constexpr int RSTEP = THREADS / 8;                // rows covered by one DMA instruction of the whole block
   constexpr int VEC = 16 / (int)sizeof(MT);
   constexpr int BK = kRowBytes / (int)sizeof(MT);
   constexpr int BM = WAVES_M * TM * 32;
   constexpr int BN = WAVES_N * TN * 32;
-  constexpr int A_VECS = BM * 8 / kThreads;
-  constexpr int B_VECS = BN * 8 / kThreads;
+  constexpr int A_VECS = BM * 8 / THREADS;
+  constexpr int B_VECS = BN * 8 / THREADS;
   constexpr int A_BYTES = BM * kRowBytes;
   constexpr int STAGE_BYTES = (BM + BN) * kRowBytes;
-  static_assert(WAVES_M * WAVES_N == 4, "4 waves per workgroup");
+  static_assert(A_VECS >= 1 && B_VECS >= 1 && BM % RSTEP == 0 && BN % RSTEP == 0, "tile / workgroup mismatch");
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   typedef __attribute__((address_space(3))) void* lds_ptr_t;
@@ -417,7 +419,7 @@ __global__ __launch_bounds__(kThreads) void conv_igemm_glds_kernel(const ConvArg
   const MT* zero = reinterpret_cast<const MT*>(g_zero_page);
 
   const int pos = tid & 7;                       // 16-B slot this lane writes in its rows
-  const int srow = tid >> 3;                     // rows srow + 32*i
+  const int srow = tid >> 3;                     // rows srow + RSTEP*i
   const int chunk = pos ^ ((srow >> 1) & 7);     // logical K chunk this lane fetches (same for all i)
   const int lds_row_off = (wave * 8) * kRowBytes;   // wave-uniform part of the DMA destination
 
@@ -427,7 +429,7 @@ __global__ __launch_bounds__(kThreads) void conv_igemm_glds_kernel(const ConvArg
   int a_b[A_VECS], a_t0[A_VECS], a_h0[A_VECS], a_w0[A_VECS];
 #pragma unroll
   for (int i = 0; i < A_VECS; ++i) {
-    const int m = m_blk + srow + 32 * i;
+    const int m = m_blk + srow + RSTEP * i;
     if (m < p.M) {
       int wo = m % p.Wo;
       int r = m / p.Wo;
@@ -446,7 +448,7 @@ __global__ __launch_bounds__(kThreads) void conv_igemm_glds_kernel(const ConvArg
   const MT* b_row[B_VECS];
 #pragma unroll
   for (int j = 0; j < B_VECS; ++j) {
-    const int n = n_blk + srow + 32 * j;
+    const int n = n_blk + srow + RSTEP * j;
     b_row[j] = (n < p.Cout) ? wg + (long long)n * p.ldw : nullptr;
   }
 
@@ -520,12 +522,12 @@ __global__ __launch_bounds__(kThreads) void conv_igemm_glds_kernel(const ConvArg
 #pragma unroll
     for (int i = 0; i < A_VECS; ++i) {
       const MT* src = a_ptr[i] ? a_ptr[i] + coff : zero;
-      __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)(As + (32 * i) * kRowBytes), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)(As + (RSTEP * i) * kRowBytes), 16, 0, 0);
     }
 #pragma unroll
     for (int j = 0; j < B_VECS; ++j) {
       const MT* src = (b_row[j] && kvalid) ? b_row[j] + koff : zero;
-      __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)(Bs + (32 * j) * kRowBytes), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)(Bs + (RSTEP * j) * kRowBytes), 16, 0, 0);
     }
   };
 
@@ -555,7 +557,6 @@ __global__ __launch_bounds__(kThreads) void conv_igemm_glds_kernel(const ConvArg
 #pragma unroll
       for (int b = 0; b < TM; ++b) xf[ks][b] = *reinterpret_cast<const u32x4*>(As + b * 32 * kRowBytes + slot);
     }
-    if (PRELOAD) __builtin_amdgcn_sched_barrier(0);   // keep the read burst ahead of the MFMA chain
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
@@ -574,67 +575,76 @@ __global__ __launch_bounds__(kThreads) void conv_igemm_glds_kernel(const ConvArg
   conv_epilogue<TOut, TM, TN>(p, acc, m_blk, n_blk, wm, wn, lane, z);
 }
 
-// Staging variant: LDS-DMA (default); VT_CONV_IMPL=reg | glds | glds2 selects a variant for A/B runs.
+// Staging variant: LDS-DMA (default); VT_CONV_IMPL=reg selects the register-staged kernel for A/B runs.
 inline int conv_impl() {
   static int mode = -1;
   if (mode < 0) {
     const char* e = getenv("VT_CONV_IMPL");
-    mode = 1;
-    if (e && strcmp(e, "reg") == 0) mode = 0;
-    if (e && strcmp(e, "glds2") == 0) mode = 2;
+    mode = (e && strcmp(e, "reg") == 0) ? 0 : 1;
   }
   return mode;
 }
 
-template <typename MT, typename TOut, int WAVES_M, int WAVES_N, int TM, int TN, bool FAST>
+template <typename MT, typename TOut, int WAVES_M, int WAVES_N, int TM, int TN, bool FAST, bool GLDS>
 int launch_variant(const ConvArgs& a_in, int nbatch, hipStream_t stream) {
   constexpr int BM = WAVES_M * TM * 32;
   constexpr int BN = WAVES_N * TN * 32;
   constexpr int BK = kRowBytes / (int)sizeof(MT);
-  const int impl = conv_impl();   // 0 register staging, 1 LDS-DMA, 2 LDS-DMA + pinned read burst
-  const bool glds = impl != 0;
-  const int LDS = 2 * (BM + BN) * (glds ? kRowBytes : kLdsRowBytes);
+  constexpr int THREADS = 64 * WAVES_M * WAVES_N;
+  constexpr int LDS = 2 * (BM + BN) * (GLDS ? kRowBytes : kLdsRowBytes);
   ConvArgs a = a_in;
   a.m_tiles = (a.M + BM - 1) / BM;
   a.n_tiles = (a.Cout + BN - 1) / BN;
   a.nsteps = FAST ? a.ntaps * (a.Cin / BK) : (a.K + BK - 1) / BK;
-  auto kern = impl == 2   ? conv_igemm_glds_kernel<MT, TOut, WAVES_M, WAVES_N, TM, TN, FAST, true>
-              : impl == 1 ? conv_igemm_glds_kernel<MT, TOut, WAVES_M, WAVES_N, TM, TN, FAST, false>
-                          : conv_igemm_kernel<MT, TOut, WAVES_M, WAVES_N, TM, TN, FAST>;
-  static bool attr_done[3] = {false, false, false};  // per instantiation and variant
-  if (!attr_done[impl]) {
-    VT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
-    attr_done[impl] = true;
+  const void* kern;
+  if constexpr (GLDS)
+    kern = reinterpret_cast<const void*>(&conv_igemm_glds_kernel<MT, TOut, WAVES_M, WAVES_N, TM, TN, FAST>);
+  else
+    kern = reinterpret_cast<const void*>(&conv_igemm_kernel<MT, TOut, WAVES_M, WAVES_N, TM, TN, FAST>);
+  static bool attr_done = false;  // per instantiation
+  if (!attr_done) {
+    VT_CHECK_HIP(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+    attr_done = true;
   }
   const long long nblk = (long long)a.m_tiles * a.n_tiles;
   VT_CHECK_ARG(nblk < (1ll << 31), "vt_conv: too many tiles (%lld)", nblk);
-  dim3 grid((unsigned)nblk, 1, (unsigned)nbatch);
-  hipLaunchKernelGGL(kern, grid, dim3(kThreads), LDS, stream, a);
-  VT_CHECK_LAUNCH();
+  void* kargs[] = {&a};
+  VT_CHECK_HIP(hipLaunchKernel(kern, dim3((unsigned)nblk, 1, (unsigned)nbatch), dim3(THREADS), kargs, LDS, stream));
   return VT_OK;
 }
 
+template <typename MT, typename TOut, int WAVES_M, int WAVES_N, int TM, int TN, bool GLDS>
+int launch_fast_or_general(const ConvArgs& a, int nbatch, hipStream_t stream) {
+  constexpr int BK = kRowBytes / (int)sizeof(MT);
+  return (a.Cin % BK) == 0 ? launch_variant<MT, TOut, WAVES_M, WAVES_N, TM, TN, true, GLDS>(a, nbatch, stream)
+                           : launch_variant<MT, TOut, WAVES_M, WAVES_N, TM, TN, false, GLDS>(a, nbatch, stream);
+}
+
+// Tile selection.  Bytes staged per FLOP fall with the tile area (128x128: 15.6 KB/MFLOP bf16,
+// 256x128: 11.7, 256x256: 7.8) and at 128x128 the L2->LDS stream is what limits the kernel, so take
+// the largest tile that still yields >= ~2 workgroups per CU-slot; small-M layers keep 128x128.
 template <typename MT, typename TOut>
 int dispatch_tile(const ConvArgs& a, int nbatch, hipStream_t stream) {
-  constexpr int BK = kRowBytes / (int)sizeof(MT);
-  const bool fast = (a.Cin % BK) == 0;
-  if (a.Cout <= 32) {
-    // narrow-N: 256 pixels x 32 channels per workgroup
-    return fast ? launch_variant<MT, TOut, 4, 1, 2, 1, true>(a, nbatch, stream)
-                : launch_variant<MT, TOut, 4, 1, 2, 1, false>(a, nbatch, stream);
+  auto blocks = [&](int bm, int bn) {
+    return (long long)((a.M + bm - 1) / bm) * ((a.Cout + bn - 1) / bn) * nbatch;
+  };
+  if (conv_impl() == 0) {
+    if (a.Cout <= 32) return launch_fast_or_general<MT, TOut, 4, 1, 2, 1, false>(a, nbatch, stream);
+    if (a.Cout <= 64) return launch_fast_or_general<MT, TOut, 4, 1, 2, 2, false>(a, nbatch, stream);
+    return launch_fast_or_general<MT, TOut, 2, 2, 2, 2, false>(a, nbatch, stream);
   }
-  if (a.Cout <= 64) {
-    return fast ? launch_variant<MT, TOut, 4, 1, 2, 2, true>(a, nbatch, stream)
-                : launch_variant<MT, TOut, 4, 1, 2, 2, false>(a, nbatch, stream);
-  }
-  return fast ? launch_variant<MT, TOut, 2, 2, 2, 2, true>(a, nbatch, stream)
-              : launch_variant<MT, TOut, 2, 2, 2, 2, false>(a, nbatch, stream);
+  if (a.Cout <= 32) return launch_fast_or_general<MT, TOut, 4, 1, 2, 1, true>(a, nbatch, stream);   // 256 x 32
+  if (a.Cout <= 64) return launch_fast_or_general<MT, TOut, 4, 1, 2, 2, true>(a, nbatch, stream);   // 256 x 64
+  if (a.Cout >= 256 && blocks(256, 256) >= 384)
+    return launch_fast_or_general<MT, TOut, 4, 2, 2, 4, true>(a, nbatch, stream);                   // 256 x 256, 8 waves
+  if (blocks(256, 128) >= 512)
+    return launch_fast_or_general<MT, TOut, 4, 2, 2, 2, true>(a, nbatch, stream);                   // 256 x 128, 8 waves
+  return launch_fast_or_general<MT, TOut, 2, 2, 2, 2, true>(a, nbatch, stream);                     // 128 x 128
 }
 
 }  // namespace
 
-extern "C" int vt_conv_max_lds_bytes(void) { return 2 * (256 + 64) * kLdsRowBytes; }
+extern "C" int vt_conv_max_lds_bytes(void) { return 2 * (256 + 256) * kRowBytes; }
 
 extern "C" int vt_conv(const vt_conv_desc* d, vt_stream stream_) {
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);

@@ -100,35 +100,48 @@ __global__ __launch_bounds__(kBlock) void layernorm_act_kernel(const TI* __restr
     load8<float>(beta + (r * LP + l) * 8, bt[r]);
   }
   const float invC = 1.0f / (float)C;
-  for (long long m = (long long)blockIdx.x * GROUPS + g; m < M; m += (long long)gridDim.x * GROUPS) {
-    float v[R][8];
-    float s = 0.f;
+  // U positions per lane group and iteration: their loads are issued back to back so every lane has
+  // U*R 16-B requests in flight (a single request per lane leaves the kernel latency-bound at ~3.7 TB/s)
+  constexpr int U = (R == 1) ? 4 : 2;
+  const long long stride = (long long)gridDim.x * GROUPS * U;
+  for (long long m0 = ((long long)blockIdx.x * GROUPS + g) * U; m0 < M; m0 += stride) {
+    float v[U][R][8];
 #pragma unroll
-    for (int r = 0; r < R; ++r) {
-      load8<TI>(x + m * ldx + (r * LP + l) * 8, v[r]);
+    for (int u = 0; u < U; ++u) {
+      const long long m = (m0 + u < M) ? m0 + u : M - 1;   // tail: re-read the last row, never stored
 #pragma unroll
-      for (int e = 0; e < 8; ++e) s += v[r][e];
+      for (int r = 0; r < R; ++r) load8<TI>(x + m * ldx + (r * LP + l) * 8, v[u][r]);
     }
-    const float mean = wave_sum(s, LP) * invC;
-    float q = 0.f;
 #pragma unroll
-    for (int r = 0; r < R; ++r)
+    for (int u = 0; u < U; ++u) {
+      float s = 0.f;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const float d = v[r][e] - mean;
-        q += d * d;
+      for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s += v[u][r][e];
+      const float mean = wave_sum(s, LP) * invC;
+      float q = 0.f;
+#pragma unroll
+      for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float d = v[u][r][e] - mean;
+          q += d * d;
+        }
+      const float var = wave_sum(q, LP) * invC;
+      const float rstd = 1.0f / sqrtf(var + eps);
+      if (m0 + u < M) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          float o[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            float t = (v[u][r][e] - mean) * rstd * gm[r][e] + bt[r][e];
+            o[e] = silu ? silu_f32(t) : t;
+          }
+          store8<TO>(y + (m0 + u) * ldy + (r * LP + l) * 8, o);
+        }
       }
-    const float var = wave_sum(q, LP) * invC;
-    const float rstd = 1.0f / sqrtf(var + eps);
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-      float o[8];
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        float t = (v[r][e] - mean) * rstd * gm[r][e] + bt[r][e];
-        o[e] = silu ? silu_f32(t) : t;
-      }
-      store8<TO>(y + m * ldy + (r * LP + l) * 8, o);
     }
   }
 }
@@ -142,7 +155,7 @@ int launch_layernorm(const void* x, long long ldx, void* y, long long ldy, const
     for (int r = 1; r <= 4; r <<= 1)
       if (C == 8 * lp * r) { LP = lp; R = r; break; }
   VT_CHECK_ARG(LP != 0, "vt_layernorm_act: unsupported channel count C=%d (need C = 8*LP*R, LP in {4..64}, R in {1,2,4})", C);
-  const int groups = kBlock / LP;
+  const int groups = (kBlock / LP) * ((R == 1) ? 4 : 2);   // positions per workgroup and iteration
   long long blocks = (M + groups - 1) / groups;
   if (blocks > kMaxGrid) blocks = kMaxGrid;
   if (blocks < 1) blocks = 1;
