@@ -47,12 +47,9 @@ void vt_set_error(const char* fmt, ...);
 __device__ __forceinline__ float bf16_bits_to_f32(uint32_t bits16) {
   return __uint_as_float(bits16 << 16);
 }
-// round-to-nearest-even fp32 -> bf16 bits (NaN kept quiet)
+// round-to-nearest-even fp32 -> bf16 bits: the native conversion (v_cvt_pk_bf16_f32 on gfx950)
 __device__ __forceinline__ uint32_t f32_to_bf16_bits(float f) {
-  uint32_t u = __float_as_uint(f);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return (u >> 16) | 0x40u;
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return u >> 16;
+  return (uint32_t)__builtin_bit_cast(uint16_t, (__bf16)f);
 }
 
 template <typename T>
@@ -74,6 +71,25 @@ __device__ __forceinline__ bf16_t from_f32<bf16_t>(float v) {
 
 // x * sigmoid(x), the reference `nonlinearity` (model_3dcausal.py:26-27), in fp32.
 __device__ __forceinline__ float silu_f32(float x) { return x / (1.0f + __expf(-x)); }
+
+// Sum over aligned groups of `WIDTH` lanes (WIDTH = 4..64, power of two); every lane gets the total.
+// The first four butterfly levels stay in the VALU (DPP quad_perm / row_half_mirror / row_mirror);
+// only the 16- and 32-lane levels go through ds_bpermute.
+template <int WIDTH>
+__device__ __forceinline__ float group_sum_dpp(float v) {
+#define VT_DPP_ADD(ctrl) v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), ctrl, 0xf, 0xf, false))
+  if (WIDTH >= 2) VT_DPP_ADD(0xB1);    // quad_perm [1,0,3,2]
+  if (WIDTH >= 4) VT_DPP_ADD(0x4E);    // quad_perm [2,3,0,1]
+  if (WIDTH >= 8) VT_DPP_ADD(0x141);   // row_half_mirror
+  if (WIDTH >= 16) VT_DPP_ADD(0x140);  // row_mirror
+#undef VT_DPP_ADD
+  if (WIDTH >= 32) v += __shfl_xor(v, 16, 64);
+  if (WIDTH >= 64) v += __shfl_xor(v, 32, 64);
+  return v;
+}
+
+// x * sigmoid(x) with the hardware reciprocal (1 ulp) instead of an IEEE division sequence
+__device__ __forceinline__ float silu_fast(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 
 __device__ __forceinline__ float wave_sum(float v, int width) {
   for (int o = width >> 1; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

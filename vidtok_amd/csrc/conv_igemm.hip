@@ -87,105 +87,161 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
 
 // Epilogue shared by both staging variants: + bias, + residual / alpha-mix, dtype conversion, NDHWC
 // vector store (lane = one pixel, 4 consecutive channels per accumulator quad) or NCTHW fp32 store.
-template <typename TOut, int TM, int TN>
-__device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[TN][TM], int m_blk, int n_blk, int wm,
-                                              int wn, int lane, long long z) {
-  float alpha = 0.0f;
-  if (p.res_mode == VT_RES_MIX) alpha = 1.0f / (1.0f + __expf(-p.mix_factor[0]));
+// Two straight-line paths chosen by ONE uniform branch: the fast path (full channel tile, NDHWC,
+// 4-aligned strides: every layer of the resolution pyramid) issues ALL bias / residual vector loads
+// back to back, then the arithmetic, then vector stores -- one memory latency per tile; the general
+// path (ragged channel tails, NCTHW, narrow outputs) does the same per 32-pixel row group with
+// clamped scalar loads.  (The first version branched and waited per element: ~26 us per tile.)
+template <typename TOut>
+struct Quad;   // 4 consecutive channels as stored
+template <>
+struct Quad<float> {
+  f32x4 v;
+  __device__ __forceinline__ float get(int e) const { return v[e]; }
+};
+template <>
+struct Quad<bf16_t> {
+  u32x2 v;
+  __device__ __forceinline__ float get(int e) const {
+    const uint32_t w = v[e >> 1];
+    return bf16_bits_to_f32((e & 1) ? (w >> 16) : (w & 0xffffu));
+  }
+};
+template <typename TOut>
+__device__ __forceinline__ void store_quad(TOut* p, const float (&v)[4]);
+template <>
+__device__ __forceinline__ void store_quad<float>(float* p, const float (&v)[4]) {
+  f32x4 t;
+  t[0] = v[0]; t[1] = v[1]; t[2] = v[2]; t[3] = v[3];
+  *reinterpret_cast<f32x4*>(p) = t;
+}
+template <>
+__device__ __forceinline__ void store_quad<bf16_t>(bf16_t* p, const float (&v)[4]) {
+  u32x2 t;
+  t[0] = f32_to_bf16_bits(v[0]) | (f32_to_bf16_bits(v[1]) << 16);
+  t[1] = f32_to_bf16_bits(v[2]) | (f32_to_bf16_bits(v[3]) << 16);
+  *reinterpret_cast<u32x2*>(p) = t;
+}
+
+template <typename TOut, int TM, int TN, bool GENERAL = true>
+__device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[TN][TM], int m_blk, int n_blk, int bn_tile,
+                                              int wm, int wn, int lane, long long z) {
   TOut* __restrict__ yg = reinterpret_cast<TOut*>(p.y) + z * p.ys_z;
   const TOut* __restrict__ rg = reinterpret_cast<const TOut*>(p.res) + z * p.rs_z;
   const long long HWo = (long long)p.Ho * p.Wo;
+  const bool has_res = p.res_mode != VT_RES_NONE;
+  const int nlast = p.Cout - 1;
+  const int nq = n_blk + wn * TN * 32 + 4 * (lane >> 5);   // + 32*a + 8*g : first channel of quad (a,g)
 
+  float alpha = 0.0f;
+  if (p.res_mode == VT_RES_MIX) alpha = 1.0f / (1.0f + __expf(-p.mix_factor[0]));
+
+  // per-pixel addresses (rows beyond M are clamped for loads; their stores are masked)
+  bool store_ok[TM];
+  long long mr[TM], ybase[TM];
+  int mrow[TM];
 #pragma unroll
   for (int b = 0; b < TM; ++b) {
-    const int m = m_blk + (wm * TM + b) * 32 + (lane & 31);
-    if (m >= p.M) continue;
-    long long mr = m;          // residual pixel index
-    long long ybase = 0;       // NCTHW: offset of (b, n=0, to-t_trim, ho, wo)
-    bool store_ok = true;
+    int m = m_blk + (wm * TM + b) * 32 + (lane & 31);
+    store_ok[b] = m < p.M;
+    if (m >= p.M) m = p.M - 1;
+    mrow[b] = m;
+    mr[b] = m;
+    ybase[b] = 0;
     if (p.res_tshift != 0 || p.Tr != p.To || p.out_layout == VT_NCTHW) {
       const long long hw = m % HWo;
       const long long r = m / HWo;
       const int to = (int)(r % p.To);
       const int bb = (int)(r / p.To);
-      mr = ((long long)bb * p.Tr + (to >> p.res_tshift)) * HWo + hw;
+      mr[b] = ((long long)bb * p.Tr + (to >> p.res_tshift)) * HWo + hw;
       if (p.out_layout == VT_NCTHW) {
         const int Tout = p.To - p.t_trim;
-        store_ok = to >= p.t_trim;
-        ybase = ((long long)bb * p.Cout * Tout + (to - p.t_trim)) * HWo + hw;
+        store_ok[b] = store_ok[b] && (to >= p.t_trim);
+        ybase[b] = ((long long)bb * p.Cout * Tout + (to - p.t_trim)) * HWo + hw;
       }
     }
+  }
+
+  // GENERAL == false: the launcher guarantees the fast-path conditions (256x256 tile), so the scalar
+  // path -- 128 address computations that would spill next to 128 accumulators -- is compiled out
+  const bool fast = !GENERAL || ((p.out_layout == VT_NDHWC) && (n_blk + bn_tile <= p.Cout) && ((p.ldy & 3) == 0) &&
+                                 (!has_res || (p.ldr & 3) == 0));
+  if (fast) {
+    // ---- fast path: straight-line vector code, GA channel sub-tiles (<= 64 channels) per batch ----
+    constexpr int GA = (TN >= 2 && TM * TN <= 4) ? 2 : 1;   // big tiles: one sub-tile per batch (register budget)
+#pragma unroll
+    for (int a0 = 0; a0 < TN; a0 += GA) {
+      Quad<TOut> rq[GA][TM][4];
+      f32x4 bq[GA][4];
+      if (has_res) {
+#pragma unroll
+        for (int b = 0; b < TM; ++b)
+#pragma unroll
+          for (int a = 0; a < GA; ++a)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+              rq[a][b][g].v = *reinterpret_cast<const decltype(rq[a][b][g].v)*>(rg + mr[b] * p.ldr + nq + 32 * (a0 + a) + 8 * g);
+      }
+      if (p.bias) {
+#pragma unroll
+        for (int a = 0; a < GA; ++a)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) bq[a][g] = *reinterpret_cast<const f32x4*>(p.bias + nq + 32 * (a0 + a) + 8 * g);
+      } else {
+#pragma unroll
+        for (int a = 0; a < GA; ++a)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) bq[a][g][0] = bq[a][g][1] = bq[a][g][2] = bq[a][g][3] = 0.0f;
+      }
+#pragma unroll
+      for (int b = 0; b < TM; ++b)
+#pragma unroll
+        for (int a = 0; a < GA; ++a)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              v[e] = acc[a0 + a][b][4 * g + e] + bq[a][g][e];
+              if (p.res_mode == VT_RES_ADD) v[e] = rq[a][b][g].get(e) + v[e];
+              if (p.res_mode == VT_RES_MIX) v[e] = alpha * rq[a][b][g].get(e) + (1.0f - alpha) * v[e];
+            }
+            if (store_ok[b]) store_quad<TOut>(yg + (long long)mrow[b] * p.ldy + nq + 32 * (a0 + a) + 8 * g, v);
+          }
+    }
+    return;
+  }
+  if (!GENERAL) return;
+
+  // ---- general path: scalar, clamped loads first, masked stores after; one 32x32 sub-tile at a time ----
+#pragma unroll
+  for (int b = 0; b < TM; ++b) {
 #pragma unroll
     for (int a = 0; a < TN; ++a) {
+      float bv[4][4], rv[4][4];
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int n0 = n_blk + (wn * TN + a) * 32 + 8 * g + 4 * (lane >> 5);
-        if (n0 >= p.Cout) continue;
-        float v[4];
+      for (int g = 0; g < 4; ++g)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = acc[a][b][4 * g + e];
-        const bool full = (n0 + 3 < p.Cout);
-        if (p.bias) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e)
-            if (full || n0 + e < p.Cout) v[e] += p.bias[n0 + e];
+        for (int e = 0; e < 4; ++e) {
+          const int n = min(nq + 32 * a + 8 * g + e, nlast);
+          bv[g][e] = p.bias ? p.bias[n] : 0.0f;
+          rv[g][e] = has_res ? to_f32<TOut>(rg[mr[b] * p.ldr + n]) : 0.0f;
         }
-        if (p.res_mode != VT_RES_NONE) {
-          float rv[4] = {0.f, 0.f, 0.f, 0.f};
-          const TOut* rp = rg + mr * p.ldr + n0;
-          if (full && (p.ldr & 3) == 0) {
-            if constexpr (sizeof(TOut) == 4) {
-              const f32x4 t = *reinterpret_cast<const f32x4*>(rp);
 #pragma unroll
-              for (int e = 0; e < 4; ++e) rv[e] = t[e];
-            } else {
-              const u32x2 t = *reinterpret_cast<const u32x2*>(rp);
-              rv[0] = bf16_bits_to_f32(t[0] & 0xffffu);
-              rv[1] = bf16_bits_to_f32(t[0] >> 16);
-              rv[2] = bf16_bits_to_f32(t[1] & 0xffffu);
-              rv[3] = bf16_bits_to_f32(t[1] >> 16);
-            }
-          } else {
+      for (int g = 0; g < 4; ++g)
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
-              if (n0 + e < p.Cout) rv[e] = to_f32<TOut>(rp[e]);
-          }
-          if (p.res_mode == VT_RES_ADD) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = rv[e] + v[e];
-          } else {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = alpha * rv[e] + (1.0f - alpha) * v[e];
+        for (int e = 0; e < 4; ++e) {
+          const int n = nq + 32 * a + 8 * g + e;
+          float v = acc[a][b][4 * g + e] + bv[g][e];
+          if (p.res_mode == VT_RES_ADD) v = rv[g][e] + v;
+          if (p.res_mode == VT_RES_MIX) v = alpha * rv[g][e] + (1.0f - alpha) * v;
+          if (store_ok[b] && n < p.Cout) {
+            if (p.out_layout == VT_NCTHW)
+              yg[ybase[b] + (long long)n * (p.To - p.t_trim) * HWo] = from_f32<TOut>(v);
+            else
+              yg[(long long)mrow[b] * p.ldy + n] = from_f32<TOut>(v);
           }
         }
-        if (p.out_layout == VT_NCTHW) {
-          if (store_ok) {
-            const int Tout = p.To - p.t_trim;
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-              if (n0 + e < p.Cout) yg[ybase + (long long)(n0 + e) * Tout * HWo] = from_f32<TOut>(v[e]);
-          }
-        } else {
-          TOut* yp = yg + (long long)m * p.ldy + n0;
-          if (full && (p.ldy & 3) == 0) {
-            if constexpr (sizeof(TOut) == 4) {
-              f32x4 t;
-#pragma unroll
-              for (int e = 0; e < 4; ++e) t[e] = v[e];
-              *reinterpret_cast<f32x4*>(yp) = t;
-            } else {
-              u32x2 t;
-              t[0] = f32_to_bf16_bits(v[0]) | (f32_to_bf16_bits(v[1]) << 16);
-              t[1] = f32_to_bf16_bits(v[2]) | (f32_to_bf16_bits(v[3]) << 16);
-              *reinterpret_cast<u32x2*>(yp) = t;
-            }
-          } else {
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-              if (n0 + e < p.Cout) yp[e] = from_f32<TOut>(v[e]);
-          }
-        }
-      }
     }
   }
 }
@@ -362,7 +418,7 @@ __global__ __launch_bounds__(kThreads) void conv_igemm_kernel(const ConvArgs p) 
     __syncthreads();
   }
 
-  conv_epilogue<TOut, TM, TN>(p, acc, m_blk, n_blk, wm, wn, lane, z);
+  conv_epilogue<TOut, TM, TN>(p, acc, m_blk, n_blk, BN, wm, wn, lane, z);
 }
 
 
@@ -572,7 +628,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_igemm_glds_kernel
     if (s + 1 < p.nsteps) issue_step(s + 1, (s + 1) & 1);
     compute_stage(s & 1);
   }
-  conv_epilogue<TOut, TM, TN>(p, acc, m_blk, n_blk, wm, wn, lane, z);
+  conv_epilogue<TOut, TM, TN, (TM * TN < 8)>(p, acc, m_blk, n_blk, BN, wm, wn, lane, z);
 }
 
 // Staging variant: LDS-DMA (default); VT_CONV_IMPL=reg selects the register-staged kernel for A/B runs.
@@ -621,8 +677,10 @@ int launch_fast_or_general(const ConvArgs& a, int nbatch, hipStream_t stream) {
 }
 
 // Tile selection.  Bytes staged per FLOP fall with the tile area (128x128: 15.6 KB/MFLOP bf16,
-// 256x128: 11.7, 256x256: 7.8) and at 128x128 the L2->LDS stream is what limits the kernel, so take
-// the largest tile that still yields >= ~2 workgroups per CU-slot; small-M layers keep 128x128.
+// 256x256: 7.8) and at 128x128 the L2->LDS stream limits the main loop, so Cout >= 256 layers with
+// enough pixels take the 8-wave 256x256 tile (measured 988 vs 814 TFLOP/s on the 27-tap 256->256
+// conv); everything else keeps 128x128 with two independent workgroups per CU (a 256x128 8-wave
+// tile measured slower: one barrier domain stalls all 8 waves on the same DMA).
 template <typename MT, typename TOut>
 int dispatch_tile(const ConvArgs& a, int nbatch, hipStream_t stream) {
   auto blocks = [&](int bm, int bn) {
@@ -635,10 +693,9 @@ int dispatch_tile(const ConvArgs& a, int nbatch, hipStream_t stream) {
   }
   if (a.Cout <= 32) return launch_fast_or_general<MT, TOut, 4, 1, 2, 1, true>(a, nbatch, stream);   // 256 x 32
   if (a.Cout <= 64) return launch_fast_or_general<MT, TOut, 4, 1, 2, 2, true>(a, nbatch, stream);   // 256 x 64
-  if (a.Cout >= 256 && blocks(256, 256) >= 384)
+  const bool vec_epi = a.out_layout == VT_NDHWC && (a.ldy & 3) == 0 && (a.res_mode == VT_RES_NONE || (a.ldr & 3) == 0);
+  if (a.Cout % 256 == 0 && vec_epi && blocks(256, 256) >= 384)
     return launch_fast_or_general<MT, TOut, 4, 2, 2, 4, true>(a, nbatch, stream);                   // 256 x 256, 8 waves
-  if (blocks(256, 128) >= 512)
-    return launch_fast_or_general<MT, TOut, 4, 2, 2, 2, true>(a, nbatch, stream);                   // 256 x 128, 8 waves
   return launch_fast_or_general<MT, TOut, 2, 2, 2, 2, true>(a, nbatch, stream);                     // 128 x 128
 }
 

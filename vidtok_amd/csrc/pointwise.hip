@@ -84,12 +84,12 @@ __device__ __forceinline__ void store8<bf16_t>(bf16_t* p, const float (&v)[8]) {
   *reinterpret_cast<u32x4*>(p) = t;
 }
 
-template <typename TI, typename TO, int LP, int R>
+template <typename TI, typename TO, int LP, int R, bool SILU>
 __global__ __launch_bounds__(kBlock) void layernorm_act_kernel(const TI* __restrict__ x, long long ldx,
                                                                TO* __restrict__ y, long long ldy,
                                                                const float* __restrict__ gamma,
                                                                const float* __restrict__ beta, long long M,
-                                                               int C, float eps, int silu) {
+                                                               int C, float eps) {
   constexpr int GROUPS = kBlock / LP;
   const int l = threadIdx.x % LP;
   const int g = threadIdx.x / LP;
@@ -119,7 +119,7 @@ __global__ __launch_bounds__(kBlock) void layernorm_act_kernel(const TI* __restr
       for (int r = 0; r < R; ++r)
 #pragma unroll
         for (int e = 0; e < 8; ++e) s += v[u][r][e];
-      const float mean = wave_sum(s, LP) * invC;
+      const float mean = group_sum_dpp<LP>(s) * invC;
       float q = 0.f;
 #pragma unroll
       for (int r = 0; r < R; ++r)
@@ -128,16 +128,16 @@ __global__ __launch_bounds__(kBlock) void layernorm_act_kernel(const TI* __restr
           const float d = v[u][r][e] - mean;
           q += d * d;
         }
-      const float var = wave_sum(q, LP) * invC;
-      const float rstd = 1.0f / sqrtf(var + eps);
+      const float var = group_sum_dpp<LP>(q) * invC;
+      const float rstd = __builtin_amdgcn_rsqf(var + eps);
       if (m0 + u < M) {
 #pragma unroll
         for (int r = 0; r < R; ++r) {
           float o[8];
 #pragma unroll
           for (int e = 0; e < 8; ++e) {
-            float t = (v[u][r][e] - mean) * rstd * gm[r][e] + bt[r][e];
-            o[e] = silu ? silu_f32(t) : t;
+            const float t = (v[u][r][e] - mean) * rstd * gm[r][e] + bt[r][e];
+            o[e] = SILU ? silu_fast(t) : t;
           }
           store8<TO>(y + (m0 + u) * ldy + (r * LP + l) * 8, o);
         }
@@ -161,8 +161,12 @@ int launch_layernorm(const void* x, long long ldx, void* y, long long ldy, const
   if (blocks < 1) blocks = 1;
 #define VT_LN_CASE(lp, r)                                                                            \
   if (LP == lp && R == r) {                                                                          \
-    hipLaunchKernelGGL((layernorm_act_kernel<TI, TO, lp, r>), dim3((unsigned)blocks), dim3(kBlock), 0, stream, \
-                       (const TI*)x, ldx, (TO*)y, ldy, gamma, beta, M, C, eps, silu);                 \
+    if (silu)                                                                                        \
+      hipLaunchKernelGGL((layernorm_act_kernel<TI, TO, lp, r, true>), dim3((unsigned)blocks), dim3(kBlock), 0,  \
+                         stream, (const TI*)x, ldx, (TO*)y, ldy, gamma, beta, M, C, eps);             \
+    else                                                                                             \
+      hipLaunchKernelGGL((layernorm_act_kernel<TI, TO, lp, r, false>), dim3((unsigned)blocks), dim3(kBlock), 0, \
+                         stream, (const TI*)x, ldx, (TO*)y, ldy, gamma, beta, M, C, eps);             \
     VT_CHECK_LAUNCH();                                                                               \
     return VT_OK;                                                                                    \
   }
