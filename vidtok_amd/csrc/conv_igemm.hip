@@ -438,19 +438,35 @@ __global__ __launch_bounds__(kThreads) void conv_igemm_kernel(const ConvArgs p) 
 // ------------------------------------------------------------------------------------------------
 __device__ u32x4 g_zero_page[8];   // 128 B of zeros (static device memory, zero-initialised)
 
-template <typename MT, typename TOut, int WAVES_M, int WAVES_N, int TM, int TN, bool FAST>
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// ROWB   bytes of K per tile row and pipeline step (128 or 64): BK = ROWB / sizeof(MT)
+// STAGES LDS ring depth; STAGES-1 steps of DMA are kept in flight (counted vmcnt + raw s_barrier:
+//        __syncthreads() would drain the DMA queue, guide section 5 "Pipelining across barriers")
+template <typename MT, typename TOut, int WAVES_M, int WAVES_N, int TM, int TN, bool FAST, int ROWB, int STAGES>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_igemm_glds_kernel(const ConvArgs p) {
-  constexpr int THREADS = 64 * WAVES_M * WAVES_N;   // 4 waves (128x128, 256x32/64 tiles) or 8 waves (256x128, 256x256)
-  constexpr int RSTEP = THREADS / 8;                // rows covered by one DMA instruction of the whole block
+  constexpr int THREADS = 64 * WAVES_M * WAVES_N;   // 4 waves (128x128, 256x32/64 tiles) or 8 waves (256x256)
+  constexpr int NS = ROWB / 16;                     // 16-B slots per tile row
+  constexpr int RSTEP = THREADS / NS;               // rows covered by one DMA instruction of the whole block
+  constexpr int ROWS_PER_WAVE = 64 / NS;
+  constexpr int SWZ_SHIFT = (ROWB == 128) ? 1 : 2;  // rows per 256-B bank window = 256 / ROWB
   constexpr int VEC = 16 / (int)sizeof(MT);
-  constexpr int BK = kRowBytes / (int)sizeof(MT);
+  constexpr int BK = ROWB / (int)sizeof(MT);
+  constexpr int KS = ROWB / 32;                     // 32-B (one MFMA K group) sub-steps per stage
   constexpr int BM = WAVES_M * TM * 32;
   constexpr int BN = WAVES_N * TN * 32;
-  constexpr int A_VECS = BM * 8 / THREADS;
-  constexpr int B_VECS = BN * 8 / THREADS;
-  constexpr int A_BYTES = BM * kRowBytes;
-  constexpr int STAGE_BYTES = (BM + BN) * kRowBytes;
+  constexpr int A_VECS = BM * NS / THREADS;
+  constexpr int B_VECS = BN * NS / THREADS;
+  constexpr int IPS = A_VECS + B_VECS;              // DMA instructions per thread and stage
+  constexpr int A_BYTES = BM * ROWB;
+  constexpr int STAGE_BYTES = (BM + BN) * ROWB;
+  constexpr int D = STAGES - 1;                     // prefetch distance
+  static_assert(ROWB == 128 || ROWB == 64, "row bytes");
   static_assert(A_VECS >= 1 && B_VECS >= 1 && BM % RSTEP == 0 && BN % RSTEP == 0, "tile / workgroup mismatch");
+  static_assert(D >= 1 && D <= 3 && (D - 1) * IPS <= 63, "pipeline depth");
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   typedef __attribute__((address_space(3))) void* lds_ptr_t;
@@ -474,10 +490,10 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_igemm_glds_kernel
   const MT* __restrict__ cg = reinterpret_cast<const MT*>(p.cache);
   const MT* zero = reinterpret_cast<const MT*>(g_zero_page);
 
-  const int pos = tid & 7;                       // 16-B slot this lane writes in its rows
-  const int srow = tid >> 3;                     // rows srow + RSTEP*i
-  const int chunk = pos ^ ((srow >> 1) & 7);     // logical K chunk this lane fetches (same for all i)
-  const int lds_row_off = (wave * 8) * kRowBytes;   // wave-uniform part of the DMA destination
+  const int pos = tid % NS;                                  // 16-B slot this lane writes in its rows
+  const int srow = tid / NS;                                 // rows srow + RSTEP*i
+  const int chunk = pos ^ ((srow >> SWZ_SHIFT) & (NS - 1));  // logical K chunk this lane fetches (same for all i)
+  const int lds_row_off = (wave * ROWS_PER_WAVE) * ROWB;     // wave-uniform part of the DMA destination
 
   const int Hv = p.Hi << p.ups_s, Wv = p.Wi << p.ups_s;
   const int Tv = p.Ti << p.ups_t;
@@ -542,8 +558,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_igemm_glds_kernel
   const MT* a_ptr[A_VECS];       // FAST: cached per tap
   int cur_tap = -1;
 
-  auto issue_step = [&](int s, int buf) {
-    char* As = smem + buf * STAGE_BYTES + lds_row_off;
+  auto issue_step = [&](int s, int stage) {
+    char* As = smem + stage * STAGE_BYTES + lds_row_off;
     char* Bs = As + A_BYTES;
     int koff;          // element offset of this lane's chunk inside the weight row
     int coff;          // element offset inside the pixel's channel vector
@@ -578,12 +594,12 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_igemm_glds_kernel
 #pragma unroll
     for (int i = 0; i < A_VECS; ++i) {
       const MT* src = a_ptr[i] ? a_ptr[i] + coff : zero;
-      __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)(As + (RSTEP * i) * kRowBytes), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)(As + (RSTEP * i) * ROWB), 16, 0, 0);
     }
 #pragma unroll
     for (int j = 0; j < B_VECS; ++j) {
       const MT* src = (b_row[j] && kvalid) ? b_row[j] + koff : zero;
-      __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)(Bs + (RSTEP * j) * kRowBytes), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)(Bs + (RSTEP * j) * ROWB), 16, 0, 0);
     }
   };
 
@@ -595,66 +611,80 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_igemm_glds_kernel
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
 
-  const int frag_row = (lane & 31) * kRowBytes;
-  const int swz = ((lane & 31) >> 1) & 7;
+  const int frag_row = (lane & 31) * ROWB;
+  const int swz = ((lane & 31) >> SWZ_SHIFT) & (NS - 1);
   const int khalf = lane >> 5;
 
-  auto compute_stage = [&](int buf) {
-    const char* As = smem + buf * STAGE_BYTES + (wm * TM * 32) * kRowBytes + frag_row;
-    const char* Bs = smem + buf * STAGE_BYTES + A_BYTES + (wn * TN * 32) * kRowBytes + frag_row;
-    // all 4*(TM+TN) fragment reads of the stage are issued up front; the MFMAs then start as soon as
+  auto compute_stage = [&](int stage) {
+    const char* As = smem + stage * STAGE_BYTES + (wm * TM * 32) * ROWB + frag_row;
+    const char* Bs = smem + stage * STAGE_BYTES + A_BYTES + (wn * TN * 32) * ROWB + frag_row;
+    // all KS*(TM+TN) fragment reads of the stage are issued up front; the MFMAs then start as soon as
     // their operands land (counted lgkmcnt), so LDS latency hides under the matrix pipe
-    u32x4 wf[4][TN], xf[4][TM];
+    u32x4 wf[KS][TN], xf[KS][TM];
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
+    for (int ks = 0; ks < KS; ++ks) {
       const int slot = ((ks * 2 + khalf) ^ swz) * 16;
 #pragma unroll
-      for (int a = 0; a < TN; ++a) wf[ks][a] = *reinterpret_cast<const u32x4*>(Bs + a * 32 * kRowBytes + slot);
+      for (int a = 0; a < TN; ++a) wf[ks][a] = *reinterpret_cast<const u32x4*>(Bs + a * 32 * ROWB + slot);
 #pragma unroll
-      for (int b = 0; b < TM; ++b) xf[ks][b] = *reinterpret_cast<const u32x4*>(As + b * 32 * kRowBytes + slot);
+      for (int b = 0; b < TM; ++b) xf[ks][b] = *reinterpret_cast<const u32x4*>(As + b * 32 * ROWB + slot);
     }
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks)
+    for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
       for (int a = 0; a < TN; ++a)
 #pragma unroll
         for (int b = 0; b < TM; ++b) mma_step<MT>(wf[ks][a], xf[ks][b], acc[a][b]);
   };
 
-  issue_step(0, 0);
+#pragma unroll
+  for (int d = 0; d < D; ++d)
+    if (d < p.nsteps) issue_step(d, d);
+  int stage = 0;
   for (int s = 0; s < p.nsteps; ++s) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // my DMA pieces of step s have landed
-    __syncthreads();                                    // everyone's have; stage (s+1)&1 is free again
-    if (s + 1 < p.nsteps) issue_step(s + 1, (s + 1) & 1);
-    compute_stage(s & 1);
+    // my DMA pieces of step s have landed once at most `newer` younger steps are still outstanding
+    const int newer = min(D - 1, p.nsteps - 1 - s);
+    if (D >= 3 && newer >= 2) wait_vmcnt<2 * IPS>();
+    else if (D >= 2 && newer >= 1) wait_vmcnt<IPS>();
+    else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();   // everyone's have; and everyone finished reading the stage refilled next
+    asm volatile("" ::: "memory");
+    if (s + D < p.nsteps) issue_step(s + D, (stage + D) % STAGES);
+    compute_stage(stage);
+    stage = (stage + 1 == STAGES) ? 0 : stage + 1;
   }
   conv_epilogue<TOut, TM, TN, (TM * TN < 8)>(p, acc, m_blk, n_blk, BN, wm, wn, lane, z);
 }
 
-// Staging variant: LDS-DMA (default); VT_CONV_IMPL=reg selects the register-staged kernel for A/B runs.
+// Staging variant: LDS-DMA (default); VT_CONV_IMPL=reg selects the register-staged kernel, VT_CONV_IMPL=glds2
+// the shallow (2-stage, 128-B rows) LDS-DMA pipeline -- kept for within-run A/B measurements.
 inline int conv_impl() {
   static int mode = -1;
   if (mode < 0) {
     const char* e = getenv("VT_CONV_IMPL");
-    mode = (e && strcmp(e, "reg") == 0) ? 0 : 1;
+    mode = 1;
+    if (e && strcmp(e, "reg") == 0) mode = 0;
+    if (e && strcmp(e, "glds2") == 0) mode = 2;
   }
   return mode;
 }
 
-template <typename MT, typename TOut, int WAVES_M, int WAVES_N, int TM, int TN, bool FAST, bool GLDS>
+// ROWB == 0 selects the register-staged kernel
+template <typename MT, typename TOut, int WAVES_M, int WAVES_N, int TM, int TN, bool FAST, int ROWB, int STAGES>
 int launch_variant(const ConvArgs& a_in, int nbatch, hipStream_t stream) {
+  constexpr bool GLDS = ROWB != 0;
   constexpr int BM = WAVES_M * TM * 32;
   constexpr int BN = WAVES_N * TN * 32;
-  constexpr int BK = kRowBytes / (int)sizeof(MT);
+  constexpr int BK = (GLDS ? ROWB : kRowBytes) / (int)sizeof(MT);
   constexpr int THREADS = 64 * WAVES_M * WAVES_N;
-  constexpr int LDS = 2 * (BM + BN) * (GLDS ? kRowBytes : kLdsRowBytes);
+  constexpr int LDS = GLDS ? STAGES * (BM + BN) * ROWB : 2 * (BM + BN) * kLdsRowBytes;
   ConvArgs a = a_in;
   a.m_tiles = (a.M + BM - 1) / BM;
   a.n_tiles = (a.Cout + BN - 1) / BN;
   a.nsteps = FAST ? a.ntaps * (a.Cin / BK) : (a.K + BK - 1) / BK;
   const void* kern;
   if constexpr (GLDS)
-    kern = reinterpret_cast<const void*>(&conv_igemm_glds_kernel<MT, TOut, WAVES_M, WAVES_N, TM, TN, FAST>);
+    kern = reinterpret_cast<const void*>(&conv_igemm_glds_kernel<MT, TOut, WAVES_M, WAVES_N, TM, TN, FAST, ROWB, STAGES>);
   else
     kern = reinterpret_cast<const void*>(&conv_igemm_kernel<MT, TOut, WAVES_M, WAVES_N, TM, TN, FAST>);
   static bool attr_done = false;  // per instantiation
@@ -669,34 +699,43 @@ int launch_variant(const ConvArgs& a_in, int nbatch, hipStream_t stream) {
   return VT_OK;
 }
 
-template <typename MT, typename TOut, int WAVES_M, int WAVES_N, int TM, int TN, bool GLDS>
+template <typename MT, typename TOut, int WAVES_M, int WAVES_N, int TM, int TN, int ROWB, int STAGES>
 int launch_fast_or_general(const ConvArgs& a, int nbatch, hipStream_t stream) {
-  constexpr int BK = kRowBytes / (int)sizeof(MT);
-  return (a.Cin % BK) == 0 ? launch_variant<MT, TOut, WAVES_M, WAVES_N, TM, TN, true, GLDS>(a, nbatch, stream)
-                           : launch_variant<MT, TOut, WAVES_M, WAVES_N, TM, TN, false, GLDS>(a, nbatch, stream);
+  constexpr int BK = (ROWB ? ROWB : kRowBytes) / (int)sizeof(MT);
+  return (a.Cin % BK) == 0 ? launch_variant<MT, TOut, WAVES_M, WAVES_N, TM, TN, true, ROWB, STAGES>(a, nbatch, stream)
+                           : launch_variant<MT, TOut, WAVES_M, WAVES_N, TM, TN, false, ROWB, STAGES>(a, nbatch, stream);
 }
 
-// Tile selection.  Bytes staged per FLOP fall with the tile area (128x128: 15.6 KB/MFLOP bf16,
-// 256x256: 7.8) and at 128x128 the L2->LDS stream limits the main loop, so Cout >= 256 layers with
-// enough pixels take the 8-wave 256x256 tile (measured 988 vs 814 TFLOP/s on the 27-tap 256->256
-// conv); everything else keeps 128x128 with two independent workgroups per CU (a 256x128 8-wave
-// tile measured slower: one barrier domain stalls all 8 waves on the same DMA).
+// Tile and pipeline selection.  Bytes staged per FLOP fall with the tile area (128x128: 15.6 KB/MFLOP
+// bf16, 256x256: 7.8) and the kernel is bound by the L2->LDS DMA round trip (~2 us under load), i.e. by
+// the bytes it keeps in flight per CU: so (a) Cout % 256 == 0 layers with enough pixels take the 8-wave
+// 256x256 tile, everything else 128x128 with two independent workgroups per CU (a 256x128 8-wave tile
+// measured slower: one barrier domain stalls all 8 waves on the same DMA); (b) the LDS ring is 4 stages
+// of 64-B rows with 3 steps of DMA in flight (96 of the CU's 160 KB) instead of 2 stages of 128-B rows.
 template <typename MT, typename TOut>
 int dispatch_tile(const ConvArgs& a, int nbatch, hipStream_t stream) {
   auto blocks = [&](int bm, int bn) {
     return (long long)((a.M + bm - 1) / bm) * ((a.Cout + bn - 1) / bn) * nbatch;
   };
-  if (conv_impl() == 0) {
-    if (a.Cout <= 32) return launch_fast_or_general<MT, TOut, 4, 1, 2, 1, false>(a, nbatch, stream);
-    if (a.Cout <= 64) return launch_fast_or_general<MT, TOut, 4, 1, 2, 2, false>(a, nbatch, stream);
-    return launch_fast_or_general<MT, TOut, 2, 2, 2, 2, false>(a, nbatch, stream);
-  }
-  if (a.Cout <= 32) return launch_fast_or_general<MT, TOut, 4, 1, 2, 1, true>(a, nbatch, stream);   // 256 x 32
-  if (a.Cout <= 64) return launch_fast_or_general<MT, TOut, 4, 1, 2, 2, true>(a, nbatch, stream);   // 256 x 64
+  const int impl = conv_impl();
   const bool vec_epi = a.out_layout == VT_NDHWC && (a.ldy & 3) == 0 && (a.res_mode == VT_RES_NONE || (a.ldr & 3) == 0);
-  if (a.Cout % 256 == 0 && vec_epi && blocks(256, 256) >= 384)
-    return launch_fast_or_general<MT, TOut, 4, 2, 2, 4, true>(a, nbatch, stream);                   // 256 x 256, 8 waves
-  return launch_fast_or_general<MT, TOut, 2, 2, 2, 2, true>(a, nbatch, stream);                     // 128 x 128
+  const bool big = a.Cout % 256 == 0 && vec_epi && blocks(256, 256) >= 384;
+#define VT_TILES(ROWB, STAGES)                                                                                  \
+  if (a.Cout <= 32) return launch_fast_or_general<MT, TOut, 4, 1, 2, 1, ROWB, STAGES>(a, nbatch, stream);       \
+  if (a.Cout <= 64) return launch_fast_or_general<MT, TOut, 4, 1, 2, 2, ROWB, STAGES>(a, nbatch, stream);
+  if (impl == 0) {
+    VT_TILES(0, 2)
+    return launch_fast_or_general<MT, TOut, 2, 2, 2, 2, 0, 2>(a, nbatch, stream);
+  }
+  if (impl == 2) {
+    VT_TILES(128, 2)
+    if (big) return launch_fast_or_general<MT, TOut, 4, 2, 2, 4, 128, 2>(a, nbatch, stream);
+    return launch_fast_or_general<MT, TOut, 2, 2, 2, 2, 128, 2>(a, nbatch, stream);
+  }
+  VT_TILES(128, 2)   // narrow-N tiles: a 64-B row ring would leave B_VECS < 1; they are A-stream bound anyway
+  if (big) return launch_fast_or_general<MT, TOut, 4, 2, 2, 4, 64, 4>(a, nbatch, stream);   // 256 x 256, 8 waves
+  return launch_fast_or_general<MT, TOut, 2, 2, 2, 2, 64, 4>(a, nbatch, stream);            // 128 x 128
+#undef VT_TILES
 }
 
 }  // namespace
