@@ -438,6 +438,9 @@ __global__ __launch_bounds__(kThreads) void conv_igemm_kernel(const ConvArgs p) 
 // ------------------------------------------------------------------------------------------------
 __device__ u32x4 g_zero_page[8];   // 128 B of zeros (static device memory, zero-initialised)
 
+struct TagTrue { static constexpr bool value = true; };
+struct TagFalse { static constexpr bool value = false; };
+
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
@@ -524,12 +527,24 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_igemm_glds_kernel
     b_row[j] = (n < p.Cout) ? wg + (long long)n * p.ldw : nullptr;
   }
 
+  // `plain`: no up-sampling folded and zero time padding (every v1.0 layer except the two time
+  // up-samplers): the stored pixel of tap (kt,kh,kw) is the tap-(0,0,0) pixel plus a uniform delta
+  const bool plain = (p.ups_t | p.ups_s) == 0 && p.tmode == VT_TPAD_ZERO;
+  long long a_pix0[A_VECS];
+#pragma unroll
+  for (int i = 0; i < A_VECS; ++i)
+    a_pix0[i] = (((long long)a_b[i] * p.Ti + a_t0[i]) * p.Hi + a_h0[i]) * p.Wi + a_w0[i];
+
   // address of the first element of input row i for tap (kt,kh,kw), or nullptr when it reads padding
   auto row_ptr = [&](int i, int kt, int kh, int kw) -> const MT* {
     int tv = a_t0[i] + kt;
     const int hv = a_h0[i] + kh;
     const int wv = a_w0[i] + kw;
     bool ok = (a_b[i] >= 0) && (hv >= 0) && (hv < Hv) && (wv >= 0) && (wv < Wv) && (tv < Tv);
+    if (plain) {
+      if (!ok || tv < 0) return nullptr;
+      return xg + (a_pix0[i] + ((long long)kt * p.Hi + kh) * p.Wi + kw) * p.Cin;
+    }
     const MT* base = xg;
     int tstore = p.Ti, ti;
     if (tv < 0) {
@@ -558,12 +573,11 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_igemm_glds_kernel
   const MT* a_ptr[A_VECS];       // FAST: cached per tap
   int cur_tap = -1;
 
-  auto issue_step = [&](int s, int stage) {
-    char* As = smem + stage * STAGE_BYTES + lds_row_off;
-    char* Bs = As + A_BYTES;
-    int koff;          // element offset of this lane's chunk inside the weight row
-    int coff;          // element offset inside the pixel's channel vector
-    bool kvalid = true;
+  int coff = 0, koff = 0;   // element offsets of this lane's chunk: in the pixel's channel vector / weight row
+  bool kvalid = true;
+  // addresses of pipeline step s (VALU only; the DMA pieces are fired separately so they can be
+  // interleaved with the MFMAs of the stage being computed)
+  auto prep_step = [&](int s) {
     if (FAST) {
       const int tap = s / cpb;
       const int cc = s - tap * cpb;
@@ -591,15 +605,17 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_igemm_glds_kernel
 #pragma unroll
       for (int i = 0; i < A_VECS; ++i) a_ptr[i] = kvalid ? row_ptr(i, kt, kh, kw) : nullptr;
     }
-#pragma unroll
-    for (int i = 0; i < A_VECS; ++i) {
-      const MT* src = a_ptr[i] ? a_ptr[i] + coff : zero;
-      __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)(As + (RSTEP * i) * ROWB), 16, 0, 0);
-    }
-#pragma unroll
-    for (int j = 0; j < B_VECS; ++j) {
+  };
+  // DMA piece q (0 .. IPS-1) of the prepared step into ring slot `stage`
+  auto fire_piece = [&](int q, int stage) {
+    char* As = smem + stage * STAGE_BYTES + lds_row_off;
+    if (q < A_VECS) {
+      const MT* src = a_ptr[q] ? a_ptr[q] + coff : zero;
+      __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)(As + (RSTEP * q) * ROWB), 16, 0, 0);
+    } else {
+      const int j = q - A_VECS;
       const MT* src = (b_row[j] && kvalid) ? b_row[j] + koff : zero;
-      __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)(Bs + (RSTEP * j) * ROWB), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)(As + A_BYTES + (RSTEP * j) * ROWB), 16, 0, 0);
     }
   };
 
@@ -614,57 +630,86 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_igemm_glds_kernel
   const int frag_row = (lane & 31) * ROWB;
   const int swz = ((lane & 31) >> SWZ_SHIFT) & (NS - 1);
   const int khalf = lane >> 5;
+  constexpr int NM = KS * TM * TN;                    // MFMA groups (one per 16-B fragment pair) per stage
+  constexpr int MPP = (NM + IPS - 1) / IPS;           // ... per DMA piece
 
-  auto compute_stage = [&](int stage) {
+  // stage `stage` -> MFMAs; if FIRE, the IPS DMA pieces of the prepared step go to ring slot `dst`,
+  // one after every MPP MFMA groups, so their issue cost hides under the matrix pipe.  Fragments are
+  // read KSB sub-steps at a time (all of the stage for the 4-wave tiles, half for the 8-wave tile whose
+  // 128 accumulators leave no room for 24 live fragments).
+  constexpr int KSB = (TM * TN >= 8 && KS > 2) ? 2 : KS;
+  auto compute_stage = [&](int stage, auto fire_tag, bool fire_rt, int dst) {
+    constexpr bool FIRE = decltype(fire_tag)::value;
     const char* As = smem + stage * STAGE_BYTES + (wm * TM * 32) * ROWB + frag_row;
     const char* Bs = smem + stage * STAGE_BYTES + A_BYTES + (wn * TN * 32) * ROWB + frag_row;
-    // all KS*(TM+TN) fragment reads of the stage are issued up front; the MFMAs then start as soon as
-    // their operands land (counted lgkmcnt), so LDS latency hides under the matrix pipe
-    u32x4 wf[KS][TN], xf[KS][TM];
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-      const int slot = ((ks * 2 + khalf) ^ swz) * 16;
+    for (int k0 = 0; k0 < KS; k0 += KSB) {
+      u32x4 wf[KSB][TN], xf[KSB][TM];
 #pragma unroll
-      for (int a = 0; a < TN; ++a) wf[ks][a] = *reinterpret_cast<const u32x4*>(Bs + a * 32 * ROWB + slot);
+      for (int kk = 0; kk < KSB; ++kk) {
+        const int slot = (((k0 + kk) * 2 + khalf) ^ swz) * 16;
 #pragma unroll
-      for (int b = 0; b < TM; ++b) xf[ks][b] = *reinterpret_cast<const u32x4*>(As + b * 32 * ROWB + slot);
+        for (int a = 0; a < TN; ++a) wf[kk][a] = *reinterpret_cast<const u32x4*>(Bs + a * 32 * ROWB + slot);
+#pragma unroll
+        for (int b = 0; b < TM; ++b) xf[kk][b] = *reinterpret_cast<const u32x4*>(As + b * 32 * ROWB + slot);
+      }
+#pragma unroll
+      for (int qq = 0; qq < KSB * TM * TN; ++qq) {
+        const int kk = qq / (TM * TN), a = (qq / TM) % TN, b = qq % TM;
+        const int q = k0 * TM * TN + qq;
+        mma_step<MT>(wf[kk][a], xf[kk][b], acc[a][b]);
+        if (FIRE && ((q + 1) % MPP == 0 || q == NM - 1)) {
+          const int piece = q / MPP;
+          if (piece < IPS && fire_rt) fire_piece(piece, dst);
+        }
+      }
     }
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks)
-#pragma unroll
-      for (int a = 0; a < TN; ++a)
-#pragma unroll
-        for (int b = 0; b < TM; ++b) mma_step<MT>(wf[ks][a], xf[ks][b], acc[a][b]);
   };
 
 #pragma unroll
   for (int d = 0; d < D; ++d)
-    if (d < p.nsteps) issue_step(d, d);
+    if (d < p.nsteps) {
+      prep_step(d);
+#pragma unroll
+      for (int q = 0; q < IPS; ++q) fire_piece(q, d);
+    }
   int stage = 0;
+  const int n_fire = p.nsteps - D;          // steps that still have a successor to prefetch
   for (int s = 0; s < p.nsteps; ++s) {
     // my DMA pieces of step s have landed once at most `newer` younger steps are still outstanding
     const int newer = min(D - 1, p.nsteps - 1 - s);
     if (D >= 3 && newer >= 2) wait_vmcnt<2 * IPS>();
     else if (D >= 2 && newer >= 1) wait_vmcnt<IPS>();
     else wait_vmcnt<0>();
-    __builtin_amdgcn_s_barrier();   // everyone's have; and everyone finished reading the stage refilled next
+    __builtin_amdgcn_s_barrier();   // everyone's have; and everyone finished reading the slot refilled next
     asm volatile("" ::: "memory");
-    if (s + D < p.nsteps) issue_step(s + D, (stage + D) % STAGES);
-    compute_stage(stage);
+    if (TM * TN >= 8) {
+      // 8-wave tile: one instantiation of the MFMA body (two would not fit the 256-register budget);
+      // the uniform `fire` test is a scalar branch around each DMA piece
+      const bool fire = s < n_fire;
+      if (fire) prep_step(s + D);
+      compute_stage(stage, TagTrue{}, fire, (stage + D) % STAGES);
+    } else if (s < n_fire) {
+      prep_step(s + D);
+      compute_stage(stage, TagTrue{}, true, (stage + D) % STAGES);
+    } else {
+      compute_stage(stage, TagFalse{}, false, 0);
+    }
     stage = (stage + 1 == STAGES) ? 0 : stage + 1;
   }
   conv_epilogue<TOut, TM, TN, (TM * TN < 8)>(p, acc, m_blk, n_blk, BN, wm, wn, lane, z);
 }
 
-// Staging variant: LDS-DMA (default); VT_CONV_IMPL=reg selects the register-staged kernel, VT_CONV_IMPL=glds2
-// the shallow (2-stage, 128-B rows) LDS-DMA pipeline -- kept for within-run A/B measurements.
+// Staging variant: LDS-DMA with a 2-stage ring of 128-B rows (default).  VT_CONV_IMPL=reg selects the
+// register-staged kernel, VT_CONV_IMPL=deep the 4-stage ring of 64-B rows (3 steps of DMA in flight;
+// measured no faster: the loop is not DMA-latency bound) -- both kept for within-run A/B measurements.
 inline int conv_impl() {
   static int mode = -1;
   if (mode < 0) {
     const char* e = getenv("VT_CONV_IMPL");
-    mode = 1;
+    mode = 2;
     if (e && strcmp(e, "reg") == 0) mode = 0;
-    if (e && strcmp(e, "glds2") == 0) mode = 2;
+    if (e && strcmp(e, "deep") == 0) mode = 1;
   }
   return mode;
 }
