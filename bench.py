@@ -104,6 +104,7 @@ def main():
     ap.add_argument("--batch", type=int, default=4, help="clips per GPU")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--breakdown", action="store_true", help="print the per-layer-shape conv timeline to stderr")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -188,6 +189,16 @@ def main():
         torch.cuda.synchronize()
         tl, ops.CONV_TIMELINE = ops.CONV_TIMELINE, None
         conv_ms = sum(e0.elapsed_time(e1) for e0, e1, _ in tl)
+        if args.breakdown:
+            agg = {}
+            for e0, e1, (M, N, K) in tl:
+                a = agg.setdefault((M, N, K), [0, 0.0])
+                a[0] += 1
+                a[1] += e0.elapsed_time(e1)
+            print("[bench] conv launches of one step by (pixels, Cout, K=taps*Cin):", file=sys.stderr)
+            for (M, N, K), (n, ms) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+                print(f"[bench]   M={M:8d} N={N:4d} K={K:6d}  x{n:3d}  {ms:8.3f} ms  {2.0 * M * N * K * n / ms / 1e9:8.1f} TFLOP/s"
+                      f"  {100 * ms / conv_ms:5.1f}%", file=sys.stderr)
         flops = FLOP_PER_PADDED_FRAME_256 * B * T_PADDED
         achieved = flops / (conv_ms * 1e-3) / 1e12
         peak = PEAK_TFLOPS[args.dtype]

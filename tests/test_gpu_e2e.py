@@ -113,3 +113,20 @@ def test_full_size_properties(dtype):
     x2[:, :, 9:] = -x2[:, :, 9:]
     _, decb, _ = model(x2)
     assert torch.equal(decb[:, :, :1], dec[:, :, :1])
+
+
+def test_v11_full_size_long_video_tiling_property():
+    """BASELINE.json configs[4] shape (129x256x256, t_chunk_enc=16, overlap) in fp32: the tiled path with
+    decoder look-ahead must reproduce the un-tiled forward (the reference's own tiled/un-tiled gap is
+    6e-4); z is chunk-invariant to fp32 round-off."""
+    name = "vidtok_v1_1/vidtok_kl_causal_488_16chn_v1_1"
+    model, cfg, sd = build_model(name, seed=31, device=DEV, dtype=torch.float32)
+    model.regularization.sample = False
+    x = (torch.rand((1, 3, 129, 256, 256), generator=torch.Generator().manual_seed(2)) * 2 - 1).to(DEV)
+    z0, dec0, _ = model(x)
+    model.use_tiling, model.t_chunk_enc, model.t_chunk_dec, model.use_overlap = True, 16, 4, True
+    z1, dec1, _ = model(x)
+    ez, ed = rel_err(z1, z0), rel_err(dec1, dec0)
+    print(f"v1.1 129x256x256 tiled vs un-tiled: z rel {ez:.2e} dec rel {ed:.2e}")
+    assert dec1.shape == x.shape == dec0.shape and z1.shape == (1, 16, 33, 32, 32)
+    assert ez < 1e-4 and ed < 5e-3
