@@ -301,7 +301,7 @@ __global__ __launch_bounds__(kBlock) void time_lerp2x_kernel(const T* __restrict
 }
 
 struct GatherIdx {
-  int idx[32];
+  int idx[128];
 };
 
 __global__ __launch_bounds__(kBlock) void gather_frames_kernel(const u32x4* __restrict__ src, u32x4* __restrict__ dst,
@@ -443,7 +443,7 @@ extern "C" int vt_gather_frames(const void* src, void* dst, int32_t esize, int32
                                 int64_t src_bstride, int64_t dst_bstride, const int32_t* idx_host, int32_t n,
                                 vt_stream stream_) {
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
-  VT_CHECK_ARG(src && dst && idx_host && B > 0 && n > 0 && n <= 32 && frame_elems > 0,
+  VT_CHECK_ARG(src && dst && idx_host && B > 0 && n > 0 && n <= 128 && frame_elems > 0,
                "vt_gather_frames: bad arguments (n=%d)", n);
   VT_CHECK_ARG(esize == 2 || esize == 4, "vt_gather_frames: esize %d", esize);
   VT_CHECK_ARG((frame_elems * esize) % 16 == 0 && (src_bstride * esize) % 16 == 0 && (dst_bstride * esize) % 16 == 0,

@@ -244,9 +244,12 @@ def gather_frames(src, idx):
     assert n >= 1 and all(0 <= i < Ts for i in idx), (idx, Ts)
     frame = src[0, 0].numel()
     dst = torch.empty((B, n) + tuple(src.shape[2:]), dtype=src.dtype, device=src.device)
-    arr = (C.c_int32 * n)(*idx)
-    L.check(lib.vt_gather_frames(_ptr(src), _ptr(dst), src.element_size(), B, frame, Ts * frame, n * frame, arr, n,
-                                 _stream()), "vt_gather_frames")
+    for j0 in range(0, n, 128):                       # the C-ABI takes up to 128 frame indices per call
+        part = list(idx[j0:j0 + 128])
+        arr = (C.c_int32 * len(part))(*part)
+        dptr = C.c_void_p(dst.data_ptr() + j0 * frame * dst.element_size())
+        L.check(lib.vt_gather_frames(_ptr(src), dptr, src.element_size(), B, frame, Ts * frame, n * frame, arr,
+                                     len(part), _stream()), "vt_gather_frames")
     return dst
 
 
