@@ -41,6 +41,7 @@ def main():
         if only and only not in name:
             continue
         cp = ops.pad_channels(cin)
+        torch.manual_seed(0)
         x = torch.randn((B, T, H, W, cp), device="cuda", dtype=dtype)
         w = (torch.randn((cout, taps * cp), device="cuda") / math.sqrt(taps * cin)).to(dtype)
         bias = torch.randn((cout,), device="cuda")
@@ -64,7 +65,8 @@ def main():
         fl = 2.0 * B * To * Ho * Wo * cout * taps * cin
         tot_ms += ms
         tot_fl += fl
-        print(f"  {name:46s} {ms:8.3f} ms  {fl / ms / 1e9:8.1f} TFLOP/s")
+        yf = y.float()
+        print(f"  {name:46s} {ms:8.3f} ms  {fl / ms / 1e9:8.1f} TFLOP/s   chk {yf.sum().item():+.6e} {yf.abs().sum().item():.6e}")
         del x, w, y, kw
     print(f"  total {tot_ms:.2f} ms, {tot_fl / tot_ms / 1e9:.1f} TFLOP/s aggregate")
     # LayerNorm+SiLU bandwidth on the two biggest activations

@@ -36,7 +36,6 @@ namespace {
 constexpr int kThreads = 256;
 constexpr int kRowBytes = 128;     // bytes of K per tile row per step
 constexpr int kLdsRowBytes = 144;  // + 16 B pad
-constexpr int kPersistGrid = 512;   // persistent kernel: 256 CUs x 2 resident workgroups
 
 struct ConvArgs {
   const char* x;
@@ -57,7 +56,7 @@ struct ConvArgs {
   int res_mode, res_tshift, Tr, ldr;
   int out_layout, t_trim;
   int M, K, ntaps, nsteps;
-  int m_tiles, n_tiles, nbatch;
+  int m_tiles, n_tiles;
   long long xs_z, ws_z, ys_z, rs_z;
 };
 
@@ -638,6 +637,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_igemm_glds_kernel
   // one after every MPP MFMA groups, so their issue cost hides under the matrix pipe.  Fragments are
   // read KSB sub-steps at a time (all of the stage for the 4-wave tiles, half for the 8-wave tile whose
   // 128 accumulators leave no room for 24 live fragments).
+  constexpr bool EIGHT_WAVES = (WAVES_M * WAVES_N == 8);
   constexpr int KSB = (TM * TN >= 8 && KS > 2) ? 2 : KS;
   auto compute_stage = [&](int stage, auto fire_tag, bool fire_rt, int dst) {
     constexpr bool FIRE = decltype(fire_tag)::value;
@@ -688,7 +688,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_igemm_glds_kernel
     else wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();   // everyone's have; and everyone finished reading the slot refilled next
     asm volatile("" ::: "memory");
-    if (TM * TN >= 8) {
+    if (EIGHT_WAVES) {
       // 8-wave tile: one instantiation of the MFMA body (two would not fit the 256-register budget);
       // the uniform `fire` test is a scalar branch around each DMA piece
       const bool fire = s < n_fire;
@@ -710,240 +710,6 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_igemm_glds_kernel
   conv_epilogue<TOut, TM, TN, (TM * TN < 8)>(p, acc, m_blk, n_blk, BN, wm, wn, lane, z);
 }
 
-// ------------------------------------------------------------------------------------------------
-// Persistent variant of the 4-wave LDS-DMA kernel (default for every tile except the 8-wave 256x256).
-// On the resolution-pyramid's widest level the GEMMs are short (K = 384 / 1152: 6 / 18 pipeline steps)
-// and a tile-per-workgroup launch spends ~11 us of every ~20-38 us tile outside the MFMA loop
-// (workgroup launch, index divisions, the first DMA round trip, the epilogue's load latency).  Here a
-// workgroup walks tiles b, b+G, b+2G, ... and the DMA pipeline never drains: while the last step of
-// tile i runs, step 0 of tile i+1 is already being fetched, and tile i's epilogue overlaps that flight.
-// The "issue side" (gather state of the tile whose steps are being requested) and the "compute side"
-// (tile whose accumulators are live) are separate register sets.
-// ------------------------------------------------------------------------------------------------
-template <typename MT, typename TOut, int WAVES_M, int WAVES_N, int TM, int TN, bool FAST>
-__global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_igemm_persist_kernel(const ConvArgs p) {
-  constexpr int ROWB = 128;
-  constexpr int THREADS = 64 * WAVES_M * WAVES_N;
-  constexpr int NS = ROWB / 16;
-  constexpr int RSTEP = THREADS / NS;
-  constexpr int VEC = 16 / (int)sizeof(MT);
-  constexpr int BK = ROWB / (int)sizeof(MT);
-  constexpr int KS = ROWB / 32;
-  constexpr int BM = WAVES_M * TM * 32;
-  constexpr int BN = WAVES_N * TN * 32;
-  constexpr int A_VECS = BM * NS / THREADS;
-  constexpr int B_VECS = BN * NS / THREADS;
-  constexpr int A_BYTES = BM * ROWB;
-  constexpr int STAGE_BYTES = (BM + BN) * ROWB;
-  static_assert(A_VECS >= 1 && B_VECS >= 1 && BM % RSTEP == 0 && BN % RSTEP == 0, "tile / workgroup mismatch");
-
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  typedef __attribute__((address_space(3))) void* lds_ptr_t;
-  typedef const __attribute__((address_space(1))) void* glb_ptr_t;
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = tid >> 6;
-  const int wm = wave % WAVES_M;
-  const int wn = wave / WAVES_M;
-  const int tiles_per_z = p.m_tiles * p.n_tiles;
-  const int ntiles = tiles_per_z * p.nbatch;
-  const int G = gridDim.x;
-  if ((int)blockIdx.x >= ntiles) return;
-
-  const MT* zero = reinterpret_cast<const MT*>(g_zero_page);
-  const MT* __restrict__ cg = reinterpret_cast<const MT*>(p.cache);
-  const int pos = tid % NS;
-  const int srow = tid / NS;
-  const int chunk = pos ^ ((srow >> 1) & (NS - 1));
-  const int lds_row_off = (wave * (64 / NS)) * ROWB;
-  const int Hv = p.Hi << p.ups_s, Wv = p.Wi << p.ups_s;
-  const int Tv = p.Ti << p.ups_t;
-  const bool plain = (p.ups_t | p.ups_s) == 0 && p.tmode == VT_TPAD_ZERO;
-  const int khw = p.KH * p.KW;
-  const int cpb = FAST ? (p.Cin / BK) : 1;
-
-  // tile id -> (z, m_blk, n_blk); ids are remapped per XCD inside one z slab
-  auto tile_coords = [&](int t, int& zz, int& mb, int& nb) {
-    zz = t / tiles_per_z;
-    const int tl = xcd_remap(t - zz * tiles_per_z, tiles_per_z);
-    const int nt = tl / p.m_tiles;
-    mb = (tl - nt * p.m_tiles) * BM;
-    nb = nt * BN;
-  };
-
-  // ---- issue side ---------------------------------------------------------------------------------
-  int i_tile = blockIdx.x, i_step = 0, cur_tap = -1;
-  const MT* i_xg = nullptr;
-  int a_b[A_VECS], a_t0[A_VECS], a_h0[A_VECS], a_w0[A_VECS];
-  long long a_pix0[A_VECS];
-  const MT* b_row[B_VECS];
-  const MT* a_ptr[A_VECS];
-  int coff = 0, koff = 0;
-  bool kvalid = true;
-
-  auto setup_issue_tile = [&](int t) {
-    int zz, mb, nb;
-    tile_coords(t, zz, mb, nb);
-    i_xg = reinterpret_cast<const MT*>(p.x) + (long long)zz * p.xs_z;
-    const MT* wgz = reinterpret_cast<const MT*>(p.w) + (long long)zz * p.ws_z;
-#pragma unroll
-    for (int i = 0; i < A_VECS; ++i) {
-      const int m = mb + srow + RSTEP * i;
-      if (m < p.M) {
-        int wo = m % p.Wo;
-        int r = m / p.Wo;
-        int ho = r % p.Ho;
-        r /= p.Ho;
-        int to = r % p.To;
-        a_b[i] = r / p.To;
-        a_t0[i] = to * p.st - p.pt;
-        a_h0[i] = ho * p.sh - p.ph;
-        a_w0[i] = wo * p.sw - p.pw;
-      } else {
-        a_b[i] = -1;
-        a_t0[i] = a_h0[i] = a_w0[i] = 0;
-      }
-      a_pix0[i] = (((long long)a_b[i] * p.Ti + a_t0[i]) * p.Hi + a_h0[i]) * p.Wi + a_w0[i];
-    }
-#pragma unroll
-    for (int j = 0; j < B_VECS; ++j) {
-      const int n = nb + srow + RSTEP * j;
-      b_row[j] = (n < p.Cout) ? wgz + (long long)n * p.ldw : nullptr;
-    }
-    cur_tap = -1;
-    i_step = 0;
-  };
-
-  auto row_ptr = [&](int i, int kt, int kh, int kw) -> const MT* {
-    int tv = a_t0[i] + kt;
-    const int hv = a_h0[i] + kh;
-    const int wv = a_w0[i] + kw;
-    bool ok = (a_b[i] >= 0) && (hv >= 0) && (hv < Hv) && (wv >= 0) && (wv < Wv) && (tv < Tv);
-    if (plain) {
-      if (!ok || tv < 0) return nullptr;
-      return i_xg + (a_pix0[i] + ((long long)kt * p.Hi + kh) * p.Wi + kw) * p.Cin;
-    }
-    const MT* base = i_xg;
-    int tstore = p.Ti, ti;
-    if (tv < 0) {
-      if (p.tmode == VT_TPAD_ZERO) {
-        ok = false;
-        ti = 0;
-      } else if (p.tmode == VT_TPAD_REPLICATE) {
-        ti = 0;
-      } else {
-        base = cg;
-        tstore = p.ncache;
-        ti = p.ncache + tv;
-        ok = ok && (ti >= 0);
-      }
-    } else {
-      ti = tv >> p.ups_t;
-    }
-    if (!ok) return nullptr;
-    const int hi = hv >> p.ups_s, wi = wv >> p.ups_s;
-    const long long pix = (((long long)a_b[i] * tstore + ti) * p.Hi + hi) * p.Wi + wi;
-    return base + pix * p.Cin;
-  };
-
-  // request pipeline step i_step of the issue tile into ring slot `stage`, then advance i_step
-  auto issue_next = [&](int stage) {
-    const int s = i_step;
-    if (FAST) {
-      const int tap = s / cpb;
-      const int cc = s - tap * cpb;
-      if (tap != cur_tap) {
-        cur_tap = tap;
-        const int kt = tap / khw;
-        const int r2 = tap - kt * khw;
-        const int kh = r2 / p.KW;
-        const int kw = r2 - kh * p.KW;
-#pragma unroll
-        for (int i = 0; i < A_VECS; ++i) a_ptr[i] = row_ptr(i, kt, kh, kw);
-      }
-      coff = cc * BK + chunk * VEC;
-      koff = s * BK + chunk * VEC;
-    } else {
-      const int k = s * BK + chunk * VEC;
-      const int tap = k / p.Cin;
-      coff = k - tap * p.Cin;
-      koff = k;
-      kvalid = tap < p.ntaps;
-      const int kt = tap / khw;
-      const int r2 = tap - kt * khw;
-      const int kh = r2 / p.KW;
-      const int kw = r2 - kh * p.KW;
-#pragma unroll
-      for (int i = 0; i < A_VECS; ++i) a_ptr[i] = kvalid ? row_ptr(i, kt, kh, kw) : nullptr;
-    }
-    char* As = smem + stage * STAGE_BYTES + lds_row_off;
-#pragma unroll
-    for (int i = 0; i < A_VECS; ++i) {
-      const MT* src = a_ptr[i] ? a_ptr[i] + coff : zero;
-      __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)(As + (RSTEP * i) * ROWB), 16, 0, 0);
-    }
-#pragma unroll
-    for (int j = 0; j < B_VECS; ++j) {
-      const MT* src = (b_row[j] && kvalid) ? b_row[j] + koff : zero;
-      __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)(As + A_BYTES + (RSTEP * j) * ROWB), 16, 0, 0);
-    }
-    i_step = s + 1;
-  };
-
-  // ---- compute side -------------------------------------------------------------------------------
-  f32x16 acc[TN][TM];
-  const int frag_row = (lane & 31) * ROWB;
-  const int swz = ((lane & 31) >> 1) & (NS - 1);
-  const int khalf = lane >> 5;
-  auto compute_stage = [&](int stage) {
-    const char* As = smem + stage * STAGE_BYTES + (wm * TM * 32) * ROWB + frag_row;
-    const char* Bs = smem + stage * STAGE_BYTES + A_BYTES + (wn * TN * 32) * ROWB + frag_row;
-    u32x4 wf[KS][TN], xf[KS][TM];
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-      const int slot = ((ks * 2 + khalf) ^ swz) * 16;
-#pragma unroll
-      for (int a = 0; a < TN; ++a) wf[ks][a] = *reinterpret_cast<const u32x4*>(Bs + a * 32 * ROWB + slot);
-#pragma unroll
-      for (int b = 0; b < TM; ++b) xf[ks][b] = *reinterpret_cast<const u32x4*>(As + b * 32 * ROWB + slot);
-    }
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks)
-#pragma unroll
-      for (int a = 0; a < TN; ++a)
-#pragma unroll
-        for (int b = 0; b < TM; ++b) mma_step<MT>(wf[ks][a], xf[ks][b], acc[a][b]);
-  };
-
-  setup_issue_tile(i_tile);
-  issue_next(0);
-  int stage = 0;
-  for (int tile = blockIdx.x; tile < ntiles; tile += G) {
-    int zz, m_blk, n_blk;
-    tile_coords(tile, zz, m_blk, n_blk);
-#pragma unroll
-    for (int a = 0; a < TN; ++a)
-#pragma unroll
-      for (int b = 0; b < TM; ++b)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
-    for (int s = 0; s < p.nsteps; ++s) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // my DMA pieces of this step (and older stores) are done
-      __builtin_amdgcn_s_barrier();                       // everyone's are; the other ring slot is free
-      asm volatile("" ::: "memory");
-      if (i_step == p.nsteps && i_tile + G < ntiles) {    // issue side moves on to the workgroup's next tile
-        i_tile += G;
-        setup_issue_tile(i_tile);
-      }
-      if (i_step < p.nsteps) issue_next(stage ^ 1);
-      compute_stage(stage);
-      stage ^= 1;
-    }
-    conv_epilogue<TOut, TM, TN>(p, acc, m_blk, n_blk, BN, wm, wn, lane, (long long)zz);
-  }
-}
-
 // Staging variant: LDS-DMA with a 2-stage ring of 128-B rows (default).  VT_CONV_IMPL=reg selects the
 // register-staged kernel, VT_CONV_IMPL=deep the 4-stage ring of 64-B rows (3 steps of DMA in flight;
 // measured no faster: the loop is not DMA-latency bound) -- both kept for within-run A/B measurements.
@@ -954,7 +720,7 @@ inline int conv_impl() {
     mode = 2;
     if (e && strcmp(e, "reg") == 0) mode = 0;
     if (e && strcmp(e, "deep") == 0) mode = 1;
-    if (e && strcmp(e, "glds") == 0) mode = 3;
+    if (e && strcmp(e, "tall") == 0) mode = 3;
   }
   return mode;
 }
@@ -989,40 +755,6 @@ int launch_variant(const ConvArgs& a_in, int nbatch, hipStream_t stream) {
   return VT_OK;
 }
 
-template <typename MT, typename TOut, int WAVES_M, int WAVES_N, int TM, int TN, bool FAST>
-int launch_persist(const ConvArgs& a_in, int nbatch, hipStream_t stream) {
-  constexpr int BM = WAVES_M * TM * 32;
-  constexpr int BN = WAVES_N * TN * 32;
-  constexpr int BK = kRowBytes / (int)sizeof(MT);
-  constexpr int THREADS = 64 * WAVES_M * WAVES_N;
-  constexpr int LDS = 2 * (BM + BN) * kRowBytes;
-  ConvArgs a = a_in;
-  a.m_tiles = (a.M + BM - 1) / BM;
-  a.n_tiles = (a.Cout + BN - 1) / BN;
-  a.nsteps = FAST ? a.ntaps * (a.Cin / BK) : (a.K + BK - 1) / BK;
-  a.nbatch = nbatch;
-  const void* kern = reinterpret_cast<const void*>(&conv_igemm_persist_kernel<MT, TOut, WAVES_M, WAVES_N, TM, TN, FAST>);
-  static bool attr_done = false;
-  if (!attr_done) {
-    VT_CHECK_HIP(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
-    attr_done = true;
-  }
-  const long long ntiles = (long long)a.m_tiles * a.n_tiles * nbatch;
-  VT_CHECK_ARG(ntiles < (1ll << 31), "vt_conv: too many tiles (%lld)", ntiles);
-  // two resident workgroups per CU (64-82 KB of LDS each); a multiple of 8 keeps a workgroup's tiles on one XCD chunk
-  const long long grid = ntiles < kPersistGrid ? ntiles : kPersistGrid;
-  void* kargs[] = {&a};
-  VT_CHECK_HIP(hipLaunchKernel(kern, dim3((unsigned)grid), dim3(THREADS), kargs, LDS, stream));
-  return VT_OK;
-}
-
-template <typename MT, typename TOut, int WAVES_M, int WAVES_N, int TM, int TN>
-int launch_persist_fast_or_general(const ConvArgs& a, int nbatch, hipStream_t stream) {
-  constexpr int BK = kRowBytes / (int)sizeof(MT);
-  return (a.Cin % BK) == 0 ? launch_persist<MT, TOut, WAVES_M, WAVES_N, TM, TN, true>(a, nbatch, stream)
-                           : launch_persist<MT, TOut, WAVES_M, WAVES_N, TM, TN, false>(a, nbatch, stream);
-}
-
 template <typename MT, typename TOut, int WAVES_M, int WAVES_N, int TM, int TN, int ROWB, int STAGES>
 int launch_fast_or_general(const ConvArgs& a, int nbatch, hipStream_t stream) {
   constexpr int BK = (ROWB ? ROWB : kRowBytes) / (int)sizeof(MT);
@@ -1051,15 +783,13 @@ int dispatch_tile(const ConvArgs& a, int nbatch, hipStream_t stream) {
     VT_TILES(0, 2)
     return launch_fast_or_general<MT, TOut, 2, 2, 2, 2, 0, 2>(a, nbatch, stream);
   }
-  if (impl == 2) {   // default: persistent 4-wave tiles + the 8-wave 256x256 tile
-    if (big) return launch_fast_or_general<MT, TOut, 4, 2, 2, 4, 128, 2>(a, nbatch, stream);
-    if (a.Cout <= 32) return launch_persist_fast_or_general<MT, TOut, 4, 1, 2, 1>(a, nbatch, stream);
-    if (a.Cout <= 64) return launch_persist_fast_or_general<MT, TOut, 4, 1, 2, 2>(a, nbatch, stream);
-    return launch_persist_fast_or_general<MT, TOut, 2, 2, 2, 2>(a, nbatch, stream);
-  }
-  if (impl == 3) {   // VT_CONV_IMPL=glds: one tile per workgroup (A/B reference for the persistent loop)
+  if (impl == 2 || impl == 3) {
     VT_TILES(128, 2)
     if (big) return launch_fast_or_general<MT, TOut, 4, 2, 2, 4, 128, 2>(a, nbatch, stream);
+    // impl 3 (VT_CONV_IMPL=tall): 256x128 4-wave tile with 64-B rows for the Cout % 128 == 0 layers whose
+    // tile count is large (the widest pyramid level): half the per-tile fixed cost and weight traffic per pixel
+    if (impl == 3 && a.Cout % 128 == 0 && vec_epi && blocks(256, 128) >= 1024)
+      return launch_fast_or_general<MT, TOut, 2, 2, 4, 2, 64, 2>(a, nbatch, stream);
     return launch_fast_or_general<MT, TOut, 2, 2, 2, 2, 128, 2>(a, nbatch, stream);
   }
   VT_TILES(128, 2)   // narrow-N tiles: a 64-B row ring would leave B_VECS < 1; they are A-stream bound anyway
