@@ -57,6 +57,7 @@ struct ConvArgs {
   int out_layout, t_trim;
   int M, K, ntaps, nsteps;
   int m_tiles, n_tiles;
+  unsigned x_bytes, w_bytes;   // BUF path: descriptor extents (0 = tensors too large, use pointers)
   long long xs_z, ws_z, ys_z, rs_z;
 };
 
@@ -449,7 +450,12 @@ __device__ __forceinline__ void wait_vmcnt() {
 // ROWB   bytes of K per tile row and pipeline step (128 or 64): BK = ROWB / sizeof(MT)
 // STAGES LDS ring depth; STAGES-1 steps of DMA are kept in flight (counted vmcnt + raw s_barrier:
 //        __syncthreads() would drain the DMA queue, guide section 5 "Pipelining across barriers")
-template <typename MT, typename TOut, int WAVES_M, int WAVES_N, int TM, int TN, bool FAST, int ROWB, int STAGES>
+// BUF    gather through buffer descriptors (buffer_load ... lds): the per-lane address is ONE 32-bit byte
+//        offset against an SGPR descriptor and out-of-range offsets read zeros in hardware, so padding
+//        taps / ragged rows need no zero-page select and no 64-bit pointer arithmetic (the K loop of the
+//        short-K layers is instruction-issue bound: ~13 VALU per MFMA with pointers).  Needs the tensors
+//        below 4 GiB and no cache-mode time padding; otherwise the pointer form is used.
+template <typename MT, typename TOut, int WAVES_M, int WAVES_N, int TM, int TN, bool FAST, int ROWB, int STAGES, bool BUF>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_igemm_glds_kernel(const ConvArgs p) {
   constexpr int THREADS = 64 * WAVES_M * WAVES_N;   // 4 waves (128x128, 256x32/64 tiles) or 8 waves (256x256)
   constexpr int NS = ROWB / 16;                     // 16-B slots per tile row
@@ -492,6 +498,12 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_igemm_glds_kernel
   const MT* __restrict__ wg = reinterpret_cast<const MT*>(p.w) + z * p.ws_z;
   const MT* __restrict__ cg = reinterpret_cast<const MT*>(p.cache);
   const MT* zero = reinterpret_cast<const MT*>(g_zero_page);
+  constexpr unsigned kOob = 0xFFFF0000u;   // BUF: offset beyond any descriptor's num_records -> hardware zero fill
+  __amdgpu_buffer_rsrc_t rsrc_x, rsrc_w;
+  if constexpr (BUF) {
+    rsrc_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<MT*>(xg), 0, p.x_bytes, 0x00020000);
+    rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<MT*>(wg), 0, p.w_bytes, 0x00020000);
+  }
 
   const int pos = tid % NS;                                  // 16-B slot this lane writes in its rows
   const int srow = tid / NS;                                 // rows srow + RSTEP*i
@@ -521,10 +533,12 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_igemm_glds_kernel
     }
   }
   const MT* b_row[B_VECS];
+  unsigned b_off[B_VECS];
 #pragma unroll
   for (int j = 0; j < B_VECS; ++j) {
     const int n = n_blk + srow + RSTEP * j;
     b_row[j] = (n < p.Cout) ? wg + (long long)n * p.ldw : nullptr;
+    b_off[j] = (n < p.Cout) ? (unsigned)n * (unsigned)p.ldw * (unsigned)sizeof(MT) : kOob;
   }
 
   // `plain`: no up-sampling folded and zero time padding (every v1.0 layer except the two time
@@ -568,9 +582,32 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_igemm_glds_kernel
     return base + pix * p.Cin;
   };
 
+  // BUF form of row_ptr: byte offset into x (tmode ZERO / REPLICATE only), kOob for padding
+  const unsigned pix_bytes = (unsigned)p.Cin * (unsigned)sizeof(MT);
+  auto row_off = [&](int i, int kt, int kh, int kw) -> unsigned {
+    const int tv = a_t0[i] + kt;
+    const int hv = a_h0[i] + kh;
+    const int wv = a_w0[i] + kw;
+    bool ok = (a_b[i] >= 0) && (hv >= 0) && (hv < Hv) && (wv >= 0) && (wv < Wv) && (tv < Tv);
+    if (plain) {
+      ok = ok && (tv >= 0);
+      const unsigned pix = (unsigned)((int)a_pix0[i] + (kt * p.Hi + kh) * p.Wi + kw);
+      return ok ? pix * pix_bytes : kOob;
+    }
+    int ti = tv >> p.ups_t;
+    if (tv < 0) {
+      ti = 0;
+      ok = ok && (p.tmode == VT_TPAD_REPLICATE);
+    }
+    const int hi = hv >> p.ups_s, wi = wv >> p.ups_s;
+    const unsigned pix = (unsigned)(((a_b[i] * p.Ti + ti) * p.Hi + hi) * p.Wi + wi);
+    return ok ? pix * pix_bytes : kOob;
+  };
+
   const int khw = p.KH * p.KW;
   const int cpb = FAST ? (p.Cin / BK) : 1;
   const MT* a_ptr[A_VECS];       // FAST: cached per tap
+  unsigned a_off[A_VECS];
   int cur_tap = -1;
 
   int coff = 0, koff = 0;   // element offsets of this lane's chunk: in the pixel's channel vector / weight row
@@ -588,7 +625,10 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_igemm_glds_kernel
         const int kh = r2 / p.KW;
         const int kw = r2 - kh * p.KW;
 #pragma unroll
-        for (int i = 0; i < A_VECS; ++i) a_ptr[i] = row_ptr(i, kt, kh, kw);
+        for (int i = 0; i < A_VECS; ++i) {
+          if constexpr (BUF) a_off[i] = row_off(i, kt, kh, kw);
+          else a_ptr[i] = row_ptr(i, kt, kh, kw);
+        }
       }
       coff = cc * BK + chunk * VEC;
       koff = s * BK + chunk * VEC;
@@ -603,19 +643,32 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_igemm_glds_kernel
       const int kh = r2 / p.KW;
       const int kw = r2 - kh * p.KW;
 #pragma unroll
-      for (int i = 0; i < A_VECS; ++i) a_ptr[i] = kvalid ? row_ptr(i, kt, kh, kw) : nullptr;
+      for (int i = 0; i < A_VECS; ++i) {
+        if constexpr (BUF) a_off[i] = kvalid ? row_off(i, kt, kh, kw) : kOob;
+        else a_ptr[i] = kvalid ? row_ptr(i, kt, kh, kw) : nullptr;
+      }
     }
   };
   // DMA piece q (0 .. IPS-1) of the prepared step into ring slot `stage`
   auto fire_piece = [&](int q, int stage) {
     char* As = smem + stage * STAGE_BYTES + lds_row_off;
     if (q < A_VECS) {
-      const MT* src = a_ptr[q] ? a_ptr[q] + coff : zero;
-      __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)(As + (RSTEP * q) * ROWB), 16, 0, 0);
+      if constexpr (BUF) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (lds_ptr_t)(As + (RSTEP * q) * ROWB), 16,
+                                                 a_off[q] + (unsigned)coff * (unsigned)sizeof(MT), 0, 0, 0);
+      } else {
+        const MT* src = a_ptr[q] ? a_ptr[q] + coff : zero;
+        __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)(As + (RSTEP * q) * ROWB), 16, 0, 0);
+      }
     } else {
       const int j = q - A_VECS;
-      const MT* src = (b_row[j] && kvalid) ? b_row[j] + koff : zero;
-      __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)(As + A_BYTES + (RSTEP * j) * ROWB), 16, 0, 0);
+      if constexpr (BUF) {
+        const unsigned off = kvalid ? b_off[j] + (unsigned)koff * (unsigned)sizeof(MT) : kOob;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (lds_ptr_t)(As + A_BYTES + (RSTEP * j) * ROWB), 16, off, 0, 0, 0);
+      } else {
+        const MT* src = (b_row[j] && kvalid) ? b_row[j] + koff : zero;
+        __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)(As + A_BYTES + (RSTEP * j) * ROWB), 16, 0, 0);
+      }
     }
   };
 
@@ -725,6 +778,16 @@ inline int conv_impl() {
   return mode;
 }
 
+// descriptor (buffer_load ... lds) gather; VT_CONV_BUF=0 falls back to 64-bit pointers (A/B runs)
+inline bool conv_buf() {
+  static int mode = -1;
+  if (mode < 0) {
+    const char* e = getenv("VT_CONV_BUF");
+    mode = (e && strcmp(e, "0") == 0) ? 0 : 1;
+  }
+  return mode == 1;
+}
+
 // ROWB == 0 selects the register-staged kernel
 template <typename MT, typename TOut, int WAVES_M, int WAVES_N, int TM, int TN, bool FAST, int ROWB, int STAGES>
 int launch_variant(const ConvArgs& a_in, int nbatch, hipStream_t stream) {
@@ -739,14 +802,27 @@ int launch_variant(const ConvArgs& a_in, int nbatch, hipStream_t stream) {
   a.n_tiles = (a.Cout + BN - 1) / BN;
   a.nsteps = FAST ? a.ntaps * (a.Cin / BK) : (a.K + BK - 1) / BK;
   const void* kern;
-  if constexpr (GLDS)
-    kern = reinterpret_cast<const void*>(&conv_igemm_glds_kernel<MT, TOut, WAVES_M, WAVES_N, TM, TN, FAST, ROWB, STAGES>);
-  else
+  int variant = 0;
+  if constexpr (GLDS) {
+    // descriptor gather needs both tensors under 4 GiB (minus the out-of-range marker) and no cache-mode padding
+    const unsigned long long xb = (unsigned long long)a.B * a.Ti * a.Hi * a.Wi * a.Cin * sizeof(MT);
+    const unsigned long long wb = (unsigned long long)a.Cout * a.ldw * sizeof(MT);
+    const bool buf = conv_buf() && xb < 0xFFFF0000ull && wb < 0xFFFF0000ull && a.tmode != VT_TPAD_CACHE;
+    if (buf) {
+      a.x_bytes = (unsigned)xb;
+      a.w_bytes = (unsigned)wb;
+      variant = 1;
+      kern = reinterpret_cast<const void*>(&conv_igemm_glds_kernel<MT, TOut, WAVES_M, WAVES_N, TM, TN, FAST, ROWB, STAGES, true>);
+    } else {
+      kern = reinterpret_cast<const void*>(&conv_igemm_glds_kernel<MT, TOut, WAVES_M, WAVES_N, TM, TN, FAST, ROWB, STAGES, false>);
+    }
+  } else {
     kern = reinterpret_cast<const void*>(&conv_igemm_kernel<MT, TOut, WAVES_M, WAVES_N, TM, TN, FAST>);
-  static bool attr_done = false;  // per instantiation
-  if (!attr_done) {
+  }
+  static bool attr_done[2] = {false, false};  // per instantiation and gather form
+  if (!attr_done[variant]) {
     VT_CHECK_HIP(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
-    attr_done = true;
+    attr_done[variant] = true;
   }
   const long long nblk = (long long)a.m_tiles * a.n_tiles;
   VT_CHECK_ARG(nblk < (1ll << 31), "vt_conv: too many tiles (%lld)", nblk);
