@@ -47,7 +47,7 @@ def test_argument_validation_without_gpu(built_lib):
     d.ldw = 3
     assert built_lib.vt_conv(C.byref(d), None) == -1
     assert b"Cin" in built_lib.vt_last_error()
-    assert built_lib.vt_layernorm_act(16, 0, 100, 16, 0, 100, 16, 16, 10, 100, 1e-6, 1, None) == -1
+    assert built_lib.vt_layernorm_act(16, 0, 104, 16, 0, 104, 16, 16, 10, 100, 1e-6, 1, None) == -1
     assert b"unsupported channel count" in built_lib.vt_last_error()
 
 

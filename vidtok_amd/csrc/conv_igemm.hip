@@ -437,10 +437,10 @@ __global__ __launch_bounds__(kThreads) void conv_igemm_kernel(const ConvArgs p) 
 // MFMAs of step s, so a full step of MFMA work covers the DMA flight.  On the fast path (Cin a
 // multiple of the K step) the gather addresses are recomputed only when the tap changes.
 // ------------------------------------------------------------------------------------------------
-__device__ u32x4 g_zero_page[8];   // 128 B of zeros (static device memory, zero-initialised)
+[[maybe_unused]] __device__ u32x4 g_zero_page[8];   // 128 B of zeros (static device memory, zero-initialised)
 
-struct TagTrue { static constexpr bool value = true; };
-struct TagFalse { static constexpr bool value = false; };
+struct TagTrue { [[maybe_unused]] static constexpr bool value = true; };
+struct TagFalse { [[maybe_unused]] static constexpr bool value = false; };
 
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
@@ -457,6 +457,7 @@ __device__ __forceinline__ void wait_vmcnt() {
 //        below 4 GiB and no cache-mode time padding; otherwise the pointer form is used.
 template <typename MT, typename TOut, int WAVES_M, int WAVES_N, int TM, int TN, bool FAST, int ROWB, int STAGES, bool BUF>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_igemm_glds_kernel(const ConvArgs p) {
+#if defined(__HIP_DEVICE_COMPILE__)   // device pass only: the host pass needs just the launch stub (buffer-descriptor types are device-only)
   constexpr int THREADS = 64 * WAVES_M * WAVES_N;   // 4 waves (128x128, 256x32/64 tiles) or 8 waves (256x256)
   constexpr int NS = ROWB / 16;                     // 16-B slots per tile row
   constexpr int RSTEP = THREADS / NS;               // rows covered by one DMA instruction of the whole block
@@ -761,6 +762,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_igemm_glds_kernel
     stage = (stage + 1 == STAGES) ? 0 : stage + 1;
   }
   conv_epilogue<TOut, TM, TN, (TM * TN < 8)>(p, acc, m_blk, n_blk, BN, wm, wn, lane, z);
+#endif
 }
 
 // Staging variant: LDS-DMA with a 2-stage ring of 128-B rows (default).  VT_CONV_IMPL=reg selects the
