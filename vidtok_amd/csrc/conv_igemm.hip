@@ -742,21 +742,22 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_igemm_glds_kernel
     else wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();   // everyone's have; and everyone finished reading the slot refilled next
     asm volatile("" ::: "memory");
+    // exactly ONE instantiation of the MFMA body per kernel: with two (a firing and a non-firing copy)
+    // the register allocator parked the accumulators in VGPRs across the loop edge and copied all of
+    // them to AGPRs and back every step (128 v_accvgpr moves per 16 MFMAs).
+    const bool fire = s < n_fire;
+    if (fire) prep_step(s + D);
     if (EIGHT_WAVES) {
-      // 8-wave tile: one instantiation of the MFMA body (two would not fit the 256-register budget);
-      // the uniform `fire` test is a scalar branch around each DMA piece
-      const bool fire = s < n_fire;
-      if (fire) prep_step(s + D);
+      // 8-wave tile: the DMA pieces are issued between MFMA groups (the uniform `fire` test is a scalar
+      // branch around each piece); measured 7 % faster than issuing them up front
       compute_stage(stage, TagTrue{}, fire, (stage + D) % STAGES);
-    } else if (s < n_fire) {
-      // 4-wave tiles: two workgroups share the CU and cover each other's DMA issue, and the prefetch is
-      // only one step deep, so the whole next stage is requested first (interleaving the pieces with
-      // the MFMAs measured 10-20 % slower here; on the 8-wave tile it is 7 % faster)
-      prep_step(s + D);
-#pragma unroll
-      for (int q = 0; q < IPS; ++q) fire_piece(q, (stage + D) % STAGES);
-      compute_stage(stage, TagFalse{}, false, 0);
     } else {
+      // 4-wave tiles: two workgroups share the CU and cover each other's DMA issue, and the prefetch is
+      // only one step deep, so the whole next stage is requested first (interleaving measured 10-20 % slower)
+      if (fire) {
+#pragma unroll
+        for (int q = 0; q < IPS; ++q) fire_piece(q, (stage + D) % STAGES);
+      }
       compute_stage(stage, TagFalse{}, false, 0);
     }
     stage = (stage + 1 == STAGES) ? 0 : stage + 1;
