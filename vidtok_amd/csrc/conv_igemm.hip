@@ -509,7 +509,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_igemm_glds_kernel
   const int pos = tid % NS;                                  // 16-B slot this lane writes in its rows
   const int srow = tid / NS;                                 // rows srow + RSTEP*i
   const int chunk = pos ^ ((srow >> SWZ_SHIFT) & (NS - 1));  // logical K chunk this lane fetches (same for all i)
-  const int lds_row_off = (wave * ROWS_PER_WAVE) * ROWB;     // wave-uniform part of the DMA destination
+  // wave-uniform part of the DMA destination, made provably uniform so the M0 set-up stays on the SALU
+  const int lds_row_off = __builtin_amdgcn_readfirstlane(wave * ROWS_PER_WAVE * ROWB);
 
   const int Hv = p.Hi << p.ups_s, Wv = p.Wi << p.ups_s;
   const int Tv = p.Ti << p.ups_t;
@@ -539,100 +540,86 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_igemm_glds_kernel
   for (int j = 0; j < B_VECS; ++j) {
     const int n = n_blk + srow + RSTEP * j;
     b_row[j] = (n < p.Cout) ? wg + (long long)n * p.ldw : nullptr;
-    b_off[j] = (n < p.Cout) ? (unsigned)n * (unsigned)p.ldw * (unsigned)sizeof(MT) : kOob;
+    b_off[j] = (n < p.Cout) ? (unsigned)n * (unsigned)p.ldw * (unsigned)sizeof(MT) + (FAST ? (unsigned)chunk * 16u : 0u) : kOob;
   }
 
-  // `plain`: no up-sampling folded and zero time padding (every v1.0 layer except the two time
-  // up-samplers): the stored pixel of tap (kt,kh,kw) is the tap-(0,0,0) pixel plus a uniform delta
-  const bool plain = (p.ups_t | p.ups_s) == 0 && p.tmode == VT_TPAD_ZERO;
-  long long a_pix0[A_VECS];
-#pragma unroll
-  for (int i = 0; i < A_VECS; ++i)
-    a_pix0[i] = (((long long)a_b[i] * p.Ti + a_t0[i]) * p.Hi + a_h0[i]) * p.Wi + a_w0[i];
-
-  // address of the first element of input row i for tap (kt,kh,kw), or nullptr when it reads padding
-  auto row_ptr = [&](int i, int kt, int kh, int kw) -> const MT* {
-    int tv = a_t0[i] + kt;
-    const int hv = a_h0[i] + kh;
-    const int wv = a_w0[i] + kw;
-    bool ok = (a_b[i] >= 0) && (hv >= 0) && (hv < Hv) && (wv >= 0) && (wv < Wv) && (tv < Tv);
-    if (plain) {
-      if (!ok || tv < 0) return nullptr;
-      return xg + (a_pix0[i] + ((long long)kt * p.Hi + kh) * p.Wi + kw) * p.Cin;
-    }
-    const MT* base = xg;
-    int tstore = p.Ti, ti;
-    if (tv < 0) {
-      if (p.tmode == VT_TPAD_ZERO) {
-        ok = false;
-        ti = 0;
-      } else if (p.tmode == VT_TPAD_REPLICATE) {
-        ti = 0;
-      } else {
-        base = cg;
-        tstore = p.ncache;
-        ti = p.ncache + tv;
-        ok = ok && (ti >= 0);
-      }
-    } else {
-      ti = tv >> p.ups_t;
-    }
-    if (!ok) return nullptr;
-    const int hi = hv >> p.ups_s, wi = wv >> p.ups_s;
-    const long long pix = (((long long)a_b[i] * tstore + ti) * p.Hi + hi) * p.Wi + wi;
-    return base + pix * p.Cin;
-  };
-
-  // BUF form of row_ptr: byte offset into x (tmode ZERO / REPLICATE only), kOob for padding
+  // Gather address of input row i for tap (kt,kh,kw).  Straight-line integer arithmetic (unsigned compares
+  // fold the >= 0 tests, bitwise & instead of && so no exec-mask branches are generated); the only
+  // branch left is the uniform cache-mode one of the pointer form (v1.1 later chunks).
+  const bool replicate = p.tmode == VT_TPAD_REPLICATE;
   const unsigned pix_bytes = (unsigned)p.Cin * (unsigned)sizeof(MT);
+  // descriptor form: byte offset into x, kOob for padding (tmode ZERO / REPLICATE only)
   auto row_off = [&](int i, int kt, int kh, int kw) -> unsigned {
     const int tv = a_t0[i] + kt;
     const int hv = a_h0[i] + kh;
     const int wv = a_w0[i] + kw;
-    bool ok = (a_b[i] >= 0) && (hv >= 0) && (hv < Hv) && (wv >= 0) && (wv < Wv) && (tv < Tv);
-    if (plain) {
-      ok = ok && (tv >= 0);
-      const unsigned pix = (unsigned)((int)a_pix0[i] + (kt * p.Hi + kh) * p.Wi + kw);
-      return ok ? pix * pix_bytes : kOob;
-    }
-    int ti = tv >> p.ups_t;
-    if (tv < 0) {
-      ti = 0;
-      ok = ok && (p.tmode == VT_TPAD_REPLICATE);
-    }
-    const int hi = hv >> p.ups_s, wi = wv >> p.ups_s;
-    const unsigned pix = (unsigned)(((a_b[i] * p.Ti + ti) * p.Hi + hi) * p.Wi + wi);
+    const bool ok = (a_b[i] >= 0) & ((unsigned)hv < (unsigned)Hv) & ((unsigned)wv < (unsigned)Wv) & (tv < Tv) &
+                    ((tv >= 0) | replicate);
+    const int ti = max(tv, 0) >> p.ups_t;
+    const unsigned pix = (unsigned)(((a_b[i] * p.Ti + ti) * p.Hi + (hv >> p.ups_s)) * p.Wi + (wv >> p.ups_s));
     return ok ? pix * pix_bytes : kOob;
+  };
+  // pointer form: first element of the row, or nullptr when it reads padding
+  auto row_ptr = [&](int i, int kt, int kh, int kw) -> const MT* {
+    const int tv = a_t0[i] + kt;
+    const int hv = a_h0[i] + kh;
+    const int wv = a_w0[i] + kw;
+    bool ok = (a_b[i] >= 0) & ((unsigned)hv < (unsigned)Hv) & ((unsigned)wv < (unsigned)Wv) & (tv < Tv);
+    const MT* base = xg;
+    int tstore = p.Ti;
+    int ti = max(tv, 0) >> p.ups_t;
+    if (p.tmode == VT_TPAD_CACHE) {            // uniform
+      if (tv < 0) {
+        base = cg;
+        tstore = p.ncache;
+        ti = p.ncache + tv;
+        ok = ok & (ti >= 0);
+      }
+    } else {
+      ok = ok & ((tv >= 0) | replicate);
+    }
+    const long long pix = (((long long)a_b[i] * tstore + ti) * p.Hi + (hv >> p.ups_s)) * p.Wi + (wv >> p.ups_s);
+    return ok ? base + pix * p.Cin : nullptr;
   };
 
   const int khw = p.KH * p.KW;
   const int cpb = FAST ? (p.Cin / BK) : 1;
   const MT* a_ptr[A_VECS];       // FAST: cached per tap
   unsigned a_off[A_VECS];
-  int cur_tap = -1;
 
   int coff = 0, koff = 0;   // element offsets of this lane's chunk: in the pixel's channel vector / weight row
   bool kvalid = true;
-  // addresses of pipeline step s (VALU only; the DMA pieces are fired separately so they can be
-  // interleaved with the MFMAs of the stage being computed)
+  // FAST path: pipeline steps are prepared strictly in order, so (tap, chunk-in-tap) advance as scalar
+  // counters instead of being recovered from the step index with three integer divisions per step
+  int q_step = 0, q_cc = 0, q_kt = 0, q_kh = 0, q_kw = 0;
+  unsigned s_a = 0, s_b = 0;   // BUF: wave-uniform byte offsets (soffset operand): chunk-in-tap for x, step for w
+  const unsigned chunk_bytes = (unsigned)chunk * 16u;
+  // addresses of the NEXT pipeline step (VALU/SALU only; the DMA pieces are fired separately so they can
+  // be interleaved with the MFMAs of the stage being computed)
   auto prep_step = [&](int s) {
     if (FAST) {
-      const int tap = s / cpb;
-      const int cc = s - tap * cpb;
-      if (tap != cur_tap) {          // uniform branch: new tap -> new gather addresses
-        cur_tap = tap;
-        const int kt = tap / khw;
-        const int r2 = tap - kt * khw;
-        const int kh = r2 / p.KW;
-        const int kw = r2 - kh * p.KW;
+      if (q_cc == 0) {               // uniform branch: new tap -> new gather addresses
 #pragma unroll
         for (int i = 0; i < A_VECS; ++i) {
-          if constexpr (BUF) a_off[i] = row_off(i, kt, kh, kw);
-          else a_ptr[i] = row_ptr(i, kt, kh, kw);
+          if constexpr (BUF) a_off[i] = row_off(i, q_kt, q_kh, q_kw) + chunk_bytes;   // kOob + chunk stays out of range
+          else a_ptr[i] = row_ptr(i, q_kt, q_kh, q_kw);
         }
       }
-      coff = cc * BK + chunk * VEC;
-      koff = s * BK + chunk * VEC;
+      coff = q_cc * BK + chunk * VEC;
+      koff = q_step * BK + chunk * VEC;
+      s_a = (unsigned)q_cc * (unsigned)ROWB;
+      s_b = (unsigned)q_step * (unsigned)ROWB;
+      ++q_step;
+      if (++q_cc == cpb) {
+        q_cc = 0;
+        if (++q_kw == p.KW) {
+          q_kw = 0;
+          if (++q_kh == p.KH) {
+            q_kh = 0;
+            ++q_kt;
+          }
+        }
+      }
     } else {
       const int k = s * BK + chunk * VEC;
       const int tap = k / p.Cin;
@@ -645,9 +632,11 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_igemm_glds_kernel
       const int kw = r2 - kh * p.KW;
 #pragma unroll
       for (int i = 0; i < A_VECS; ++i) {
-        if constexpr (BUF) a_off[i] = kvalid ? row_off(i, kt, kh, kw) : kOob;
+        if constexpr (BUF) a_off[i] = (kvalid ? row_off(i, kt, kh, kw) : kOob) + (unsigned)coff * (unsigned)sizeof(MT);
         else a_ptr[i] = kvalid ? row_ptr(i, kt, kh, kw) : nullptr;
       }
+      s_a = 0;
+      s_b = 0;
     }
   };
   // DMA piece q (0 .. IPS-1) of the prepared step into ring slot `stage`
@@ -655,8 +644,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_igemm_glds_kernel
     char* As = smem + stage * STAGE_BYTES + lds_row_off;
     if (q < A_VECS) {
       if constexpr (BUF) {
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (lds_ptr_t)(As + (RSTEP * q) * ROWB), 16,
-                                                 a_off[q] + (unsigned)coff * (unsigned)sizeof(MT), 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (lds_ptr_t)(As + (RSTEP * q) * ROWB), 16, a_off[q], s_a, 0, 0);
       } else {
         const MT* src = a_ptr[q] ? a_ptr[q] + coff : zero;
         __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)(As + (RSTEP * q) * ROWB), 16, 0, 0);
@@ -664,8 +652,10 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_igemm_glds_kernel
     } else {
       const int j = q - A_VECS;
       if constexpr (BUF) {
-        const unsigned off = kvalid ? b_off[j] + (unsigned)koff * (unsigned)sizeof(MT) : kOob;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (lds_ptr_t)(As + A_BYTES + (RSTEP * j) * ROWB), 16, off, 0, 0, 0);
+        // FAST: lane offset is fixed for the tile (row + chunk), the step advances through soffset;
+        // general: the lane's k offset is folded in here
+        const unsigned off = FAST ? b_off[j] : (kvalid ? b_off[j] + (unsigned)koff * (unsigned)sizeof(MT) : kOob);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (lds_ptr_t)(As + A_BYTES + (RSTEP * j) * ROWB), 16, off, s_b, 0, 0);
       } else {
         const MT* src = (b_row[j] && kvalid) ? b_row[j] + koff : zero;
         __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)(As + A_BYTES + (RSTEP * j) * ROWB), 16, 0, 0);
