@@ -589,15 +589,48 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_igemm_glds_kernel
 
   int coff = 0, koff = 0;   // element offsets of this lane's chunk: in the pixel's channel vector / weight row
   bool kvalid = true;
-  // FAST path: pipeline steps are prepared strictly in order, so (tap, chunk-in-tap) advance as scalar
-  // counters instead of being recovered from the step index with three integer divisions per step
+  // FAST path: pipeline steps are prepared strictly in order, so the position in the K walk advances as
+  // scalar counters instead of being recovered from the step index with three integer divisions per step.
+  // Descriptor form walks K as  (kt,kh) group -> channel chunk -> kw : the KW taps of one group read the same
+  // cache lines shifted by one pixel, so visiting them back to back turns two of every three operand
+  // fetches into L2 hits (tap-major order re-fetched them from the fabric: the reuse distance, one whole
+  // tap x channel sweep of every workgroup of the XCD, exceeds its 4 MiB L2), and the gather offsets of
+  // the whole group are computed once (A_VECS x KW registers).  Weights keep their tap-major rows; only
+  // the visiting order changes.  The pointer form keeps the plain tap-major walk.
+  constexpr int KWMAX = 3;
+  const bool kw_inner = BUF && p.KW <= KWMAX;
   int q_step = 0, q_cc = 0, q_kt = 0, q_kh = 0, q_kw = 0;
-  unsigned s_a = 0, s_b = 0;   // BUF: wave-uniform byte offsets (soffset operand): chunk-in-tap for x, step for w
+  unsigned a_offk[A_VECS][KWMAX];
+  unsigned s_a = 0, s_b = 0;   // BUF: wave-uniform byte offsets (soffset operand): chunk-in-tap for x, k offset for w
   const unsigned chunk_bytes = (unsigned)chunk * 16u;
   // addresses of the NEXT pipeline step (VALU/SALU only; the DMA pieces are fired separately so they can
   // be interleaved with the MFMAs of the stage being computed)
   auto prep_step = [&](int s) {
-    if (FAST) {
+    if (FAST && kw_inner) {
+      if constexpr (BUF) {
+        if (q_cc == 0 && q_kw == 0) {          // uniform branch: new (kt,kh) group -> offsets of its KW taps
+#pragma unroll
+          for (int i = 0; i < A_VECS; ++i)
+#pragma unroll
+            for (int w = 0; w < KWMAX; ++w) a_offk[i][w] = (w < p.KW) ? row_off(i, q_kt, q_kh, w) + chunk_bytes : kOob;
+        }
+#pragma unroll
+        for (int i = 0; i < A_VECS; ++i) a_off[i] = q_kw == 0 ? a_offk[i][0] : (q_kw == 1 ? a_offk[i][1] : a_offk[i][2]);
+        const int tap = (q_kt * p.KH + q_kh) * p.KW + q_kw;
+        s_a = (unsigned)q_cc * (unsigned)ROWB;
+        s_b = ((unsigned)tap * (unsigned)p.Cin + (unsigned)q_cc * (unsigned)BK) * (unsigned)sizeof(MT);
+        if (++q_kw == p.KW) {
+          q_kw = 0;
+          if (++q_cc == cpb) {
+            q_cc = 0;
+            if (++q_kh == p.KH) {
+              q_kh = 0;
+              ++q_kt;
+            }
+          }
+        }
+      }
+    } else if (FAST) {
       if (q_cc == 0) {               // uniform branch: new tap -> new gather addresses
 #pragma unroll
         for (int i = 0; i < A_VECS; ++i) {
