@@ -57,6 +57,7 @@ struct ConvArgs {
   int out_layout, t_trim;
   int M, K, ntaps, nsteps;
   int m_tiles, n_tiles;
+  int kwin;                    // K walk with kw innermost (descriptor form)
   unsigned x_bytes, w_bytes;   // BUF path: descriptor extents (0 = tensors too large, use pointers)
   long long xs_z, ws_z, ys_z, rs_z;
 };
@@ -598,7 +599,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_igemm_glds_kernel
   // the whole group are computed once (A_VECS x KW registers).  Weights keep their tap-major rows; only
   // the visiting order changes.  The pointer form keeps the plain tap-major walk.
   constexpr int KWMAX = 3;
-  const bool kw_inner = BUF && p.KW <= KWMAX;
+  const bool kw_inner = BUF && p.KW <= KWMAX && p.kwin != 0;
   int q_step = 0, q_cc = 0, q_kt = 0, q_kh = 0, q_kw = 0;
   unsigned a_offk[A_VECS][KWMAX];
   unsigned s_a = 0, s_b = 0;   // BUF: wave-uniform byte offsets (soffset operand): chunk-in-tap for x, k offset for w
@@ -608,14 +609,22 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_igemm_glds_kernel
   auto prep_step = [&](int s) {
     if (FAST && kw_inner) {
       if constexpr (BUF) {
-        if (q_cc == 0 && q_kw == 0) {          // uniform branch: new (kt,kh) group -> offsets of its KW taps
+        // the offsets of a tap are computed in the step that first needs it (chunk 0) and reused for the
+        // other chunks of the group: the address work stays spread over the steps (a burst for all KW taps
+        // delayed that step's DMA by a few hundred cycles, which the one-step-deep prefetch cannot hide)
+        if (q_cc == 0) {                       // uniform branches
 #pragma unroll
-          for (int i = 0; i < A_VECS; ++i)
+          for (int i = 0; i < A_VECS; ++i) {
+            const unsigned o = row_off(i, q_kt, q_kh, q_kw) + chunk_bytes;
+            a_off[i] = o;
+            if (q_kw == 0) a_offk[i][0] = o;
+            else if (q_kw == 1) a_offk[i][1] = o;
+            else a_offk[i][2] = o;
+          }
+        } else {
 #pragma unroll
-            for (int w = 0; w < KWMAX; ++w) a_offk[i][w] = (w < p.KW) ? row_off(i, q_kt, q_kh, w) + chunk_bytes : kOob;
+          for (int i = 0; i < A_VECS; ++i) a_off[i] = q_kw == 0 ? a_offk[i][0] : (q_kw == 1 ? a_offk[i][1] : a_offk[i][2]);
         }
-#pragma unroll
-        for (int i = 0; i < A_VECS; ++i) a_off[i] = q_kw == 0 ? a_offk[i][0] : (q_kw == 1 ? a_offk[i][1] : a_offk[i][2]);
         const int tap = (q_kt * p.KH + q_kh) * p.KW + q_kw;
         s_a = (unsigned)q_cc * (unsigned)ROWB;
         s_b = ((unsigned)tap * (unsigned)p.Cin + (unsigned)q_cc * (unsigned)BK) * (unsigned)sizeof(MT);
@@ -814,6 +823,16 @@ inline bool conv_buf() {
   return mode == 1;
 }
 
+// K walk order of the descriptor form; VT_CONV_KWIN=0 restores tap-major (A/B runs)
+inline bool conv_kwin() {
+  static int mode = -1;
+  if (mode < 0) {
+    const char* e = getenv("VT_CONV_KWIN");
+    mode = (e && strcmp(e, "0") == 0) ? 0 : 1;
+  }
+  return mode == 1;
+}
+
 // ROWB == 0 selects the register-staged kernel
 template <typename MT, typename TOut, int WAVES_M, int WAVES_N, int TM, int TN, bool FAST, int ROWB, int STAGES>
 int launch_variant(const ConvArgs& a_in, int nbatch, hipStream_t stream) {
@@ -834,6 +853,7 @@ int launch_variant(const ConvArgs& a_in, int nbatch, hipStream_t stream) {
     const unsigned long long xb = (unsigned long long)a.B * a.Ti * a.Hi * a.Wi * a.Cin * sizeof(MT);
     const unsigned long long wb = (unsigned long long)a.Cout * a.ldw * sizeof(MT);
     const bool buf = conv_buf() && xb < 0xFFFF0000ull && wb < 0xFFFF0000ull && a.tmode != VT_TPAD_CACHE;
+    a.kwin = conv_kwin() ? 1 : 0;
     if (buf) {
       a.x_bytes = (unsigned)xb;
       a.w_bytes = (unsigned)wb;
