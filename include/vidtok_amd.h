@@ -113,24 +113,11 @@ typedef struct vt_conv_desc {
   int32_t out_dtype;        /* dtype or VT_F32                                                 */
   int32_t nbatch;           /* >=1: independent problems along grid.z                          */
   int64_t xs_z, ws_z, ys_z, rs_z;   /* element strides between problems                       */
-  /* optional fused per-position LayerNorm(+SiLU) of the finished output row (the Normalize+nonlinearity
-   * that FOLLOWS this conv in the reference: ResnetBlock norm2 after conv1, the next block's norm1 after
-   * conv2, norm_out -- model_3dcausal.py:319-327,478-488,862-864).  Needs vt_conv_ln_fusable().        */
-  const float* ln_gamma;    /* [Cout] fp32 or NULL (no fusion)                                 */
-  const float* ln_beta;     /* [Cout] fp32                                                     */
-  void* ln_out;             /* normalised output, out_dtype, NDHWC [M][ldy]                    */
-  float ln_eps;
-  int32_t ln_silu;          /* apply x*sigmoid(x) after the affine                             */
-  int32_t ln_keep_raw;      /* also store the un-normalised result to y (else y may be NULL)   */
 } vt_conv_desc;
 
 int vt_conv(const vt_conv_desc* d, vt_stream stream);
 /* sizeof(vt_conv_desc) as compiled: lets a binding verify its struct mirror */
 int vt_conv_desc_size(void);
-/* 1 if a conv with M = B*To*Ho*Wo output pixels and Cout channels can fuse the LayerNorm of its output
- * (one workgroup tile must span all Cout channels: Cout == 128, or Cout == 256 with enough pixels
- * for the 256x256 tile), else 0. */
-int vt_conv_ln_fusable(int64_t M, int32_t Cout);
 
 /* ------------------------------------------------------------------------------------------
  * vt_layernorm_act -- per-position LayerNorm over C (eps inside the sqrt, biased variance,

@@ -233,48 +233,3 @@ def test_library_is_the_hip_extension():
     assert lib.vt_version() >= 100 and L.LIB_PATH.endswith("libvidtok_amd.so")
     with pytest.raises(L.VtError):
         ops.layernorm_act(torch.zeros(4, 128), torch.ones(128), torch.zeros(128), silu=True)  # CPU tensor
-
-
-LN_CASES = [
-    # name, (B,T,H,W), cin, cout, kernel dims, geom, residual, keep_raw, silu
-    ("ln_conv2_3x3_128_res_raw", (1, 2, 16, 24), 128, 128, (3, 3), ConvGeom(**G3), True, True, True),
-    ("ln_conv1_3x3_256_128_noraw", (1, 2, 16, 16), 256, 128, (3, 3), ConvGeom(**G3), False, False, True),
-    ("ln_temporal_128_ragged_m", (1, 5, 5, 7), 128, 128, (3,), ConvGeom(kt=3, pt=2), True, True, False),
-    ("ln_conv_in_3_128", (1, 4, 16, 16), 3, 128, (3, 3, 3), ConvGeom(**G333), False, True, True),
-    ("ln_bigtile_1x1_256", (1, 2, 256, 192), 256, 256, (1, 1), ConvGeom(), True, True, True),
-]
-
-
-@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
-@pytest.mark.parametrize("case", LN_CASES, ids=[c[0] for c in LN_CASES])
-def test_conv_fused_layernorm(case, dtype):
-    name, (B, T, H, W), cin, cout, kdims, geom, use_res, keep_raw, silu = case
-    x = _act(B, T, H, W, cin, dtype, 1)
-    g = torch.Generator().manual_seed(2)
-    wt = torch.randn((cout, cin) + tuple(kdims), generator=g) / math.sqrt(cin * math.prod(kdims))
-    w = pack_conv_weight(wt, dtype, cin_stored=x.shape[-1]).to(DEV)
-    bias = _rand((cout,), torch.float32, 3, 0.5)
-    gamma, beta = 1 + 0.2 * _rand((cout,), torch.float32, 6), 0.2 * _rand((cout,), torch.float32, 7)
-    To, Ho, Wo = geom.out_dims(T, H, W)
-    kw = {}
-    if use_res:
-        kw.update(res=_act(B, To, Ho, Wo, cout, dtype, 4), res_mode=L.VT_RES_ADD)
-    assert ops.conv_ln_fusable(x.shape, geom, cout)
-    y, yn = ops.conv(x, w, bias, geom, cout=cout, ln=(gamma, beta, 1e-6, silu), ln_keep_raw=keep_raw, **kw)
-    torch.cuda.synchronize()
-    yr, ynr = R.conv(x.cpu(), w.cpu(), bias.cpu(), geom, cout=cout, ln=(gamma.cpu(), beta.cpu(), 1e-6, silu),
-                     ln_keep_raw=keep_raw, **_cpu(kw))
-    assert (y is None) == (not keep_raw)
-    if keep_raw:
-        assert rel_err(y, yr) < TOL[dtype]
-    e = rel_err(yn, ynr)
-    print(f"{name} {dtype}: normalised rel_err={e:.3e}")
-    assert yn.shape == ynr.shape and torch.isfinite(yn.float()).all() and e < (5e-5 if dtype == torch.float32 else 2e-2)
-
-
-def test_conv_fused_layernorm_refused_when_not_fusable():
-    x = _act(1, 1, 8, 8, 128, torch.float32, 1)
-    w = pack_conv_weight(torch.randn(512, 128, 1, 1), torch.float32).to(DEV)
-    assert not ops.conv_ln_fusable(x.shape, ConvGeom(), 512)
-    with pytest.raises(L.VtError):
-        ops.conv(x, w, None, ConvGeom(), cout=512, ln=(torch.ones(512, device=DEV), torch.zeros(512, device=DEV), 1e-6, True))

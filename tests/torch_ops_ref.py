@@ -19,16 +19,8 @@ def _round_like(t, dtype):
     return t.to(dtype)
 
 
-def conv_ln_fusable(x_shape, geom, cout):
-    B, Ti, Hi, Wi, _ = x_shape
-    To, Ho, Wo = geom.out_dims(Ti, Hi, Wi)
-    M = B * To * Ho * Wo
-    return cout == 128 or (cout == 256 and (M + 255) // 256 >= 384)
-
-
 def conv(x, w, bias, geom, *, cout, out_dtype=None, tmode=L.VT_TPAD_ZERO, cache=None, res=None,
-         res_mode=L.VT_RES_NONE, res_tshift=0, mix_factor=None, out_layout=L.VT_NDHWC, t_trim=0, ldy=None,
-         ln=None, ln_keep_raw=True):
+         res_mode=L.VT_RES_NONE, res_tshift=0, mix_factor=None, out_layout=L.VT_NDHWC, t_trim=0, ldy=None):
     B, Ti, Hi, Wi, Cin = x.shape
     out_dtype = out_dtype or x.dtype
     xp = x.float().permute(0, 4, 1, 2, 3)  # NCTHW
@@ -63,13 +55,7 @@ def conv(x, w, bias, geom, *, cout, out_dtype=None, tmode=L.VT_TPAD_ZERO, cache=
     ldy = ldy or pad_channels(cout)
     out = torch.zeros((B, To, y.shape[3], y.shape[4], ldy), dtype=out_dtype, device=x.device)
     out[..., :cout] = y.permute(0, 2, 3, 4, 1).to(out_dtype)
-    if ln is None:
-        return out
-    gamma, beta, eps, silu = ln
-    yn = F.layer_norm(y.permute(0, 2, 3, 4, 1), (cout,), gamma.float(), beta.float(), eps)   # from the fp32 result
-    if silu:
-        yn = yn * torch.sigmoid(yn)
-    return (out if ln_keep_raw else None), yn.to(out_dtype).contiguous()
+    return out
 
 
 def gemm_nt(a, b, *, out_dtype=None, bias=None, ld_out=None):
@@ -191,7 +177,7 @@ def fsq_consts(levels):
     return half_l.tolist(), offset.tolist(), shift.tolist(), [float(b) for b in basis]
 
 
-ALL = ["conv", "conv_ln_fusable", "gemm_nt", "layernorm_act", "softmax_rows", "ncthw_to_ndhwc", "ndhwc_to_ncthw", "time_avgpool3s2",
+ALL = ["conv", "gemm_nt", "layernorm_act", "softmax_rows", "ncthw_to_ndhwc", "ndhwc_to_ncthw", "time_avgpool3s2",
        "time_lerp2x", "gather_frames", "kl_sample", "fsq_quantize", "fsq_indices_to_codes", "fsq_aux_stats"]
 
 

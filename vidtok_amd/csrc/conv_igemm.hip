@@ -45,11 +45,6 @@ struct ConvArgs {
   const char* res;
   const char* cache;
   const float* mix_factor;
-  const float* ln_gamma;   // fused LayerNorm(+SiLU) of the output row (needs the tile to span all Cout)
-  const float* ln_beta;
-  char* ln_out;            // normalised output, same layout / dtype as y
-  float ln_eps;
-  int ln_silu, ln_keep_raw;
   int B, Ti, Hi, Wi, Cin;
   int To, Ho, Wo, Cout;
   int ldw, ldy;
@@ -130,9 +125,9 @@ __device__ __forceinline__ void store_quad<bf16_t>(bf16_t* p, const float (&v)[4
   *reinterpret_cast<u32x2*>(p) = t;
 }
 
-template <typename TOut, int TM, int TN, bool GENERAL = true, int WAVES_N = 1>
+template <typename TOut, int TM, int TN, bool GENERAL = true>
 __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[TN][TM], int m_blk, int n_blk, int bn_tile,
-                                              int wm, int wn, int lane, long long z, float* lds_red = nullptr) {
+                                              int wm, int wn, int lane, long long z) {
   TOut* __restrict__ yg = reinterpret_cast<TOut*>(p.y) + z * p.ys_z;
   const TOut* __restrict__ rg = reinterpret_cast<const TOut*>(p.res) + z * p.rs_z;
   const long long HWo = (long long)p.Ho * p.Wo;
@@ -176,7 +171,6 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[T
   if (fast) {
     // ---- fast path: straight-line vector code, GA channel sub-tiles (<= 64 channels) per batch ----
     constexpr int GA = (TN >= 2 && TM * TN <= 4) ? 2 : 1;   // big tiles: one sub-tile per batch (register budget)
-    const bool fuse_ln = (p.ln_gamma != nullptr) && (lds_red != nullptr);
 #pragma unroll
     for (int a0 = 0; a0 < TN; a0 += GA) {
       Quad<TOut> rq[GA][TM][4];
@@ -213,78 +207,9 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[T
               v[e] = acc[a0 + a][b][4 * g + e] + bq[a][g][e];
               if (p.res_mode == VT_RES_ADD) v[e] = rq[a][b][g].get(e) + v[e];
               if (p.res_mode == VT_RES_MIX) v[e] = alpha * rq[a][b][g].get(e) + (1.0f - alpha) * v[e];
-              acc[a0 + a][b][4 * g + e] = v[e];   // kept for the fused LayerNorm below
             }
-            if (store_ok[b] && (!fuse_ln || p.ln_keep_raw))
-              store_quad<TOut>(yg + (long long)mrow[b] * p.ldy + nq + 32 * (a0 + a) + 8 * g, v);
+            if (store_ok[b]) store_quad<TOut>(yg + (long long)mrow[b] * p.ldy + nq + 32 * (a0 + a) + 8 * g, v);
           }
-    }
-    if (fuse_ln) {
-      // ---- fused per-position LayerNorm (+SiLU) of the finished row -------------------------------
-      // The tile spans all Cout channels (launcher guarantees n_tiles == 1): a pixel's row lives in
-      // WAVES_N waves x 2 half-waves x TN*16 registers.  Two-pass statistics exactly like
-      // layernorm_act_kernel (mean, then centred sum of squares), reduced in registers, across the
-      // half-waves with one lane-xor-32 exchange and across waves through 2 x WAVES_N x BM floats of LDS.
-      const float invC = 1.0f / (float)p.Cout;
-      const int BMT = TM * 32 * (int)(blockDim.x / 64 / WAVES_N);   // pixels per workgroup tile
-      float* red0 = lds_red;
-      float* red1 = lds_red + WAVES_N * BMT;
-      float mean[TM], rstd[TM];
-      __syncthreads();                         // every wave is done reading the operand ring
-#pragma unroll
-      for (int b = 0; b < TM; ++b) {
-        float sum = 0.f;
-#pragma unroll
-        for (int a = 0; a < TN; ++a)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) sum += acc[a][b][r];
-        sum += __shfl_xor(sum, 32, 64);
-        red0[wn * BMT + (wm * TM + b) * 32 + (lane & 31)] = sum;
-      }
-      __syncthreads();
-#pragma unroll
-      for (int b = 0; b < TM; ++b) {
-        float t = 0.f;
-#pragma unroll
-        for (int w = 0; w < WAVES_N; ++w) t += red0[w * BMT + (wm * TM + b) * 32 + (lane & 31)];
-        mean[b] = t * invC;
-        float q = 0.f;
-#pragma unroll
-        for (int a = 0; a < TN; ++a)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const float d = acc[a][b][r] - mean[b];
-            q += d * d;
-          }
-        q += __shfl_xor(q, 32, 64);
-        red1[wn * BMT + (wm * TM + b) * 32 + (lane & 31)] = q;
-      }
-      __syncthreads();
-#pragma unroll
-      for (int b = 0; b < TM; ++b) {
-        float t = 0.f;
-#pragma unroll
-        for (int w = 0; w < WAVES_N; ++w) t += red1[w * BMT + (wm * TM + b) * 32 + (lane & 31)];
-        rstd[b] = __builtin_amdgcn_rsqf(t * invC + p.ln_eps);
-      }
-      TOut* __restrict__ ng = reinterpret_cast<TOut*>(p.ln_out) + z * p.ys_z;
-#pragma unroll
-      for (int a = 0; a < TN; ++a)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const f32x4 gm = *reinterpret_cast<const f32x4*>(p.ln_gamma + nq + 32 * a + 8 * g);
-          const f32x4 bt = *reinterpret_cast<const f32x4*>(p.ln_beta + nq + 32 * a + 8 * g);
-#pragma unroll
-          for (int b = 0; b < TM; ++b) {
-            float v[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              const float t = (acc[a][b][4 * g + e] - mean[b]) * rstd[b] * gm[e] + bt[e];
-              v[e] = p.ln_silu ? silu_fast(t) : t;
-            }
-            if (store_ok[b]) store_quad<TOut>(ng + (long long)mrow[b] * p.ldy + nq + 32 * a + 8 * g, v);
-          }
-        }
     }
     return;
   }
@@ -869,7 +794,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_igemm_glds_kernel
     }
     stage = (stage + 1 == STAGES) ? 0 : stage + 1;
   }
-  conv_epilogue<TOut, TM, TN, (TM * TN < 8), WAVES_N>(p, acc, m_blk, n_blk, BN, wm, wn, lane, z, reinterpret_cast<float*>(smem));
+  conv_epilogue<TOut, TM, TN, (TM * TN < 8)>(p, acc, m_blk, n_blk, BN, wm, wn, lane, z);
 #endif
 }
 
@@ -899,7 +824,7 @@ inline bool conv_buf() {
 }
 
 // K walk order of the descriptor form.  Default tap-major; VT_CONV_KWIN=1 selects the kw-innermost walk:
-// measured on the 27-tap 256->256 conv it cuts the fabric fetch per launch from 28.3 to 12.3 M x 64 B
+// measured on the 27-tap 256->256 conv it cuts the fabric fetch per launch from 28.3 M to 12.3 M x 64 B
 // (L2 misses 477 M -> 224 M) but runs 4-9 % SLOWER (the shifted lines are requested while their fill is
 // still in flight), so it is not the default.
 inline bool conv_kwin() {
@@ -968,13 +893,6 @@ int launch_fast_or_general(const ConvArgs& a, int nbatch, hipStream_t stream) {
 // 256x256 tile, everything else 128x128 with two independent workgroups per CU (a 256x128 8-wave tile
 // measured slower: one barrier domain stalls all 8 waves on the same DMA); (b) the LDS ring is 4 stages
 // of 64-B rows with 3 steps of DMA in flight (96 of the CU's 160 KB) instead of 2 stages of 128-B rows.
-// one workgroup tile must span all Cout channels: 128 (128x128 tile) or 256 with enough pixels for the 256x256 tile
-inline bool ln_fusable(long long M, int Cout) {
-  if (Cout == 128) return true;
-  if (Cout == 256) return (M + 255) / 256 >= 384;
-  return false;
-}
-
 template <typename MT, typename TOut>
 int dispatch_tile(const ConvArgs& a, int nbatch, hipStream_t stream) {
   auto blocks = [&](int bm, int bn) {
@@ -983,13 +901,6 @@ int dispatch_tile(const ConvArgs& a, int nbatch, hipStream_t stream) {
   const int impl = conv_impl();
   const bool vec_epi = a.out_layout == VT_NDHWC && (a.ldy & 3) == 0 && (a.res_mode == VT_RES_NONE || (a.ldr & 3) == 0);
   const bool big = a.Cout % 256 == 0 && vec_epi && blocks(256, 256) >= 384;
-  if (a.ln_gamma != nullptr) {
-    // fused LayerNorm: the tile must span the whole channel row and take the vector epilogue
-    VT_CHECK_ARG(impl != 0 && vec_epi && nbatch == 1 && ln_fusable(a.M, a.Cout),
-                 "vt_conv: LayerNorm fusion not available for this conv (M=%d Cout=%d); see vt_conv_ln_fusable", a.M, a.Cout);
-    if (a.Cout == 256) return launch_fast_or_general<MT, TOut, 4, 2, 2, 4, 128, 2>(a, nbatch, stream);
-    return launch_fast_or_general<MT, TOut, 2, 2, 2, 2, 128, 2>(a, nbatch, stream);
-  }
 #define VT_TILES(ROWB, STAGES)                                                                                  \
   if (a.Cout <= 32) return launch_fast_or_general<MT, TOut, 4, 1, 2, 1, ROWB, STAGES>(a, nbatch, stream);       \
   if (a.Cout <= 64) return launch_fast_or_general<MT, TOut, 4, 1, 2, 2, ROWB, STAGES>(a, nbatch, stream);
@@ -1016,16 +927,10 @@ int dispatch_tile(const ConvArgs& a, int nbatch, hipStream_t stream) {
 
 extern "C" int vt_conv_max_lds_bytes(void) { return 2 * (256 + 256) * kRowBytes; }
 
-extern "C" int vt_conv_ln_fusable(int64_t M, int32_t Cout) { return ln_fusable(M, Cout) ? 1 : 0; }
-
 extern "C" int vt_conv(const vt_conv_desc* d, vt_stream stream_) {
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
   VT_CHECK_ARG(d != nullptr, "vt_conv: null descriptor");
-  VT_CHECK_ARG(d->x && d->w && (d->y || (d->ln_gamma && !d->ln_keep_raw)), "vt_conv: null tensor pointer");
-  if (d->ln_gamma) {
-    VT_CHECK_ARG(d->ln_beta && d->ln_out, "vt_conv: fused LayerNorm needs ln_beta and ln_out");
-    VT_CHECK_ARG(d->out_dtype == d->dtype && d->out_layout == VT_NDHWC, "vt_conv: fused LayerNorm writes dtype NDHWC");
-  }
+  VT_CHECK_ARG(d->x && d->w && d->y, "vt_conv: null tensor pointer");
   VT_CHECK_ARG(d->dtype == VT_F32 || d->dtype == VT_BF16, "vt_conv: dtype %d", d->dtype);
   VT_CHECK_ARG(d->out_dtype == d->dtype || d->out_dtype == VT_F32, "vt_conv: out_dtype %d with dtype %d",
                d->out_dtype, d->dtype);
@@ -1066,8 +971,6 @@ extern "C" int vt_conv(const vt_conv_desc* d, vt_stream stream_) {
   memset(&a, 0, sizeof(a));
   a.x = (const char*)d->x; a.w = (const char*)d->w; a.bias = d->bias; a.y = (char*)d->y;
   a.res = (const char*)d->res; a.cache = (const char*)d->cache; a.mix_factor = d->mix_factor;
-  a.ln_gamma = d->ln_gamma; a.ln_beta = d->ln_beta; a.ln_out = (char*)d->ln_out;
-  a.ln_eps = d->ln_eps; a.ln_silu = d->ln_silu; a.ln_keep_raw = d->ln_keep_raw;
   a.B = d->B; a.Ti = d->Ti; a.Hi = d->Hi; a.Wi = d->Wi; a.Cin = d->Cin;
   a.To = d->To; a.Ho = d->Ho; a.Wo = d->Wo; a.Cout = d->Cout;
   a.ldw = d->ldw; a.ldy = d->ldy;

@@ -39,8 +39,6 @@ class ConvDesc(C.Structure):
             "nbatch",
         )]
         + [(n, C.c_int64) for n in ("xs_z", "ws_z", "ys_z", "rs_z")]
-        + [(n, C.c_void_p) for n in ("ln_gamma", "ln_beta", "ln_out")]
-        + [("ln_eps", C.c_float), ("ln_silu", C.c_int32), ("ln_keep_raw", C.c_int32)]
     )
 
 
@@ -52,7 +50,6 @@ SIGNATURES = {
     "vt_conv_max_lds_bytes": (C.c_int, []),
     "vt_conv": (C.c_int, [C.POINTER(ConvDesc), _P]),
     "vt_conv_desc_size": (C.c_int, []),
-    "vt_conv_ln_fusable": (C.c_int, [_I64, _I32]),
     "vt_layernorm_act": (C.c_int, [_P, C.c_int, _I64, _P, C.c_int, _I64, _P, _P, _I64, _I32, _F, _I32, _P]),
     "vt_softmax_rows": (C.c_int, [_P, _P, C.c_int, _I64, _I32, _I64, _F, _P]),
     "vt_ncthw_to_ndhwc": (C.c_int, [_P, _P, C.c_int, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _P]),

@@ -49,22 +49,6 @@ class LayerNorm(nn.Module):
         return ops.layernorm_act(x, g, b, silu=silu, eps=self.norm.eps, out_dtype=dt)
 
 
-def _conv_then_norm(x, w, b, geom, cout, dt, ln_next, keep_raw, **kw):
-    """conv (+ the LayerNorm/SiLU that consumes its output).  ln_next = (LayerNorm module, silu) or None.
-    The norm is fused into the conv epilogue when one workgroup tile spans the channel row
-    (ops.conv_ln_fusable); otherwise it runs as the separate layernorm_act kernel.
-    Returns y when ln_next is None, else (y or None, y_norm)."""
-    if ln_next is None:
-        return ops.conv(x, w, b, geom, cout=cout, **kw)
-    norm, silu = ln_next
-    plain_out = kw.get("out_layout", L.VT_NDHWC) == L.VT_NDHWC and ops.pad_channels(cout) == cout
-    if plain_out and ops.conv_ln_fusable(x.shape, geom, cout):
-        g, bt = norm.affine()
-        return ops.conv(x, w, b, geom, cout=cout, ln=(g, bt, norm.norm.eps, silu), ln_keep_raw=keep_raw, **kw)
-    y = ops.conv(x, w, b, geom, cout=cout, **kw)
-    return y, norm.apply_ndhwc(y, silu, dt)
-
-
 def Normalize(in_channels, norm_type="layernorm"):
     _check_norm(norm_type)
     return LayerNorm(in_channels, eps=1e-6)
@@ -142,10 +126,10 @@ class CausalConv3d(nn.Module, _CausalState):
                         pt=self.time_pad, ph=hp // 2, pw=wp // 2, ph_hi=hp - hp // 2, pw_hi=wp - wp // 2,
                         ups_t=ups_t)
 
-    def run(self, x, dt, *, ups_t=0, ln_next=None, keep_raw=True, **kw):
+    def run(self, x, dt, *, ups_t=0, **kw):
         w, b = self._pack.get(self.conv.weight, self.conv.bias, dt, cin_stored=x.shape[-1])
         tmode, cache = self._tmode_and_cache(self.version, self.time_pad)
-        y = _conv_then_norm(x, w, b, self.geom(ups_t), self.chan_out, dt, ln_next, keep_raw, tmode=tmode, cache=cache, **kw)
+        y = ops.conv(x, w, b, self.geom(ups_t), cout=self.chan_out, tmode=tmode, cache=cache, **kw)
         if self.version == "v1_1":
             self._update_cache(x, self.time_pad)
         return y
@@ -164,11 +148,11 @@ class CausalConv1d(nn.Module, _CausalState):
         self._pack = PackedCache()
         self._init_state()
 
-    def run(self, x, dt, *, ln_next=None, keep_raw=True, **kw):
+    def run(self, x, dt, **kw):
         w, b = self._pack.get(self.conv.weight, self.conv.bias, dt, cin_stored=x.shape[-1])
         tmode, cache = self._tmode_and_cache(self.version, self.time_pad)
         g = ConvGeom(kt=self.k, st=self.stride, pt=self.time_pad)
-        y = _conv_then_norm(x, w, b, g, self.chan_out, dt, ln_next, keep_raw, tmode=tmode, cache=cache, **kw)
+        y = ops.conv(x, w, b, g, cout=self.chan_out, tmode=tmode, cache=cache, **kw)
         if self.version == "v1_1":
             self._update_cache(x, self.time_pad)
         return y
@@ -178,9 +162,9 @@ class _Conv2dHolder:
     """Runs an nn.Conv2d parameter set as a per-frame spatial conv on NDHWC."""
 
     @staticmethod
-    def run(conv: nn.Conv2d, pack: PackedCache, x, dt, geom: ConvGeom, ln_next=None, keep_raw=True, **kw):
+    def run(conv: nn.Conv2d, pack: PackedCache, x, dt, geom: ConvGeom, **kw):
         w, b = pack.get(conv.weight, conv.bias, dt, cin_stored=x.shape[-1])
-        return _conv_then_norm(x, w, b, geom, conv.out_channels, dt, ln_next, keep_raw, **kw)
+        return ops.conv(x, w, b, geom, cout=conv.out_channels, **kw)
 
 
 _G3x3 = ConvGeom(kh=3, kw=3, ph=1, pw=1, ph_hi=1, pw_hi=1)
@@ -198,9 +182,9 @@ class Upsample(nn.Module):
         self.conv = nn.Conv2d(in_channels, in_channels, kernel_size=3, stride=1, padding=1)
         self._pack = PackedCache()
 
-    def run(self, x, dt, ln_next=None):
+    def run(self, x, dt):
         g = ConvGeom(kh=3, kw=3, ph=1, pw=1, ph_hi=1, pw_hi=1, ups_s=1)
-        return _Conv2dHolder.run(self.conv, self._pack, x, dt, g, ln_next=ln_next)
+        return _Conv2dHolder.run(self.conv, self._pack, x, dt, g)
 
 
 class Downsample(nn.Module):
@@ -214,9 +198,9 @@ class Downsample(nn.Module):
         self.conv = nn.Conv2d(in_channels, in_channels, kernel_size=3, stride=2, padding=0)
         self._pack = PackedCache()
 
-    def run(self, x, dt, ln_next=None):
+    def run(self, x, dt):
         g = ConvGeom(kh=3, kw=3, sh=2, sw=2, ph=0, pw=0, ph_hi=1, pw_hi=1)
-        return _Conv2dHolder.run(self.conv, self._pack, x, dt, g, ln_next=ln_next)
+        return _Conv2dHolder.run(self.conv, self._pack, x, dt, g)
 
 
 class TimeDownsampleResCausal2x(nn.Module):
@@ -231,7 +215,7 @@ class TimeDownsampleResCausal2x(nn.Module):
         self.is_first_chunk = True
         self.causal_cache = None
 
-    def run(self, x, dt, ln_next=None):
+    def run(self, x, dt):
         if self.version == "v1_0":
             x1 = ops.time_avgpool3s2(x, L.VT_TPAD_ZERO)
         else:
@@ -240,7 +224,7 @@ class TimeDownsampleResCausal2x(nn.Module):
             else:
                 x1 = ops.time_avgpool3s2(x, L.VT_TPAD_CACHE, cache=self.causal_cache)
             self.causal_cache = ops.gather_frames(x, [x.shape[1] - 1])
-        return self.conv.run(x, dt, res=x1, res_mode=L.VT_RES_MIX, mix_factor=self.mix_factor.detach(), ln_next=ln_next)
+        return self.conv.run(x, dt, res=x1, res_mode=L.VT_RES_MIX, mix_factor=self.mix_factor.detach())
 
 
 class TimeUpsampleResCausal2x(nn.Module):
@@ -277,12 +261,12 @@ class TimeUpsampleResCausal2x(nn.Module):
             return torch.cat([head, tail], dim=1).contiguous()
         return head
 
-    def run(self, x, dt, ln_next=None):
+    def run(self, x, dt):
         mf = self.mix_factor.detach()
         if self.version == "v1_0":
-            return self.conv.run(x, dt, ups_t=1, res=x, res_mode=L.VT_RES_MIX, res_tshift=1, mix_factor=mf, ln_next=ln_next)
+            return self.conv.run(x, dt, ups_t=1, res=x, res_mode=L.VT_RES_MIX, res_tshift=1, mix_factor=mf)
         xi = self._interp_v11(x)
-        return self.conv.run(xi, dt, res=xi, res_mode=L.VT_RES_MIX, mix_factor=mf, ln_next=ln_next)
+        return self.conv.run(xi, dt, res=xi, res_mode=L.VT_RES_MIX, mix_factor=mf)
 
 
 class ResnetBlock(nn.Module):
@@ -303,15 +287,13 @@ class ResnetBlock(nn.Module):
             self.nin_shortcut = nn.Conv2d(in_channels, out_channels, kernel_size=1, stride=1, padding=0)
         self._p1, self._p2, self._p3 = PackedCache(), PackedCache(), PackedCache()
 
-    def run(self, x, dt, xn=None, ln_next=None):
-        """xn: SiLU(norm1(x)) if the producer of x already computed it in its epilogue.
-        Returns (y, y_norm): y_norm = the consumer's norm (ln_next) applied to y, or None."""
-        h = xn if xn is not None else self.norm1.apply_ndhwc(x, True, dt)
-        _, h = _Conv2dHolder.run(self.conv1, self._p1, h, dt, _G3x3, ln_next=(self.norm2, True), keep_raw=False)
+    def run(self, x, dt):
+        h = self.norm1.apply_ndhwc(x, True, dt)
+        h = _Conv2dHolder.run(self.conv1, self._p1, h, dt, _G3x3)
+        h = self.norm2.apply_ndhwc(h, True, dt)
         if self.in_channels != self.out_channels:
             x = _Conv2dHolder.run(self.nin_shortcut, self._p3, x, dt, _G1x1)
-        out = _Conv2dHolder.run(self.conv2, self._p2, h, dt, _G3x3, res=x, res_mode=L.VT_RES_ADD, ln_next=ln_next)
-        return out if ln_next is not None else (out, None)
+        return _Conv2dHolder.run(self.conv2, self._p2, h, dt, _G3x3, res=x, res_mode=L.VT_RES_ADD)
 
 
 class ResnetCausalBlock(nn.Module):
@@ -330,13 +312,13 @@ class ResnetCausalBlock(nn.Module):
         if in_channels != out_channels:
             self.nin_shortcut = CausalConv3d(in_channels, out_channels, 1, version=version)
 
-    def run(self, x, dt, xn=None, ln_next=None):
-        h = xn if xn is not None else self.norm1.apply_ndhwc(x, True, dt)
-        _, h = self.conv1.run(h, dt, ln_next=(self.norm2, True), keep_raw=False)
+    def run(self, x, dt):
+        h = self.norm1.apply_ndhwc(x, True, dt)
+        h = self.conv1.run(h, dt)
+        h = self.norm2.apply_ndhwc(h, True, dt)
         if self.in_channels != self.out_channels:
             x = self.nin_shortcut.run(x, dt)
-        out = self.conv2.run(h, dt, res=x, res_mode=L.VT_RES_ADD, ln_next=ln_next)
-        return out if ln_next is not None else (out, None)
+        return self.conv2.run(h, dt, res=x, res_mode=L.VT_RES_ADD)
 
 
 class ResnetCausalBlock1D(nn.Module):
@@ -360,13 +342,13 @@ class ResnetCausalBlock1D(nn.Module):
             self.conv2.conv.weight.data.zero_()
             self.conv2.conv.bias.data.zero_()
 
-    def run(self, x, dt, xn=None, ln_next=None):
-        h = xn if xn is not None else self.norm1.apply_ndhwc(x, True, dt)
-        _, h = self.conv1.run(h, dt, ln_next=(self.norm2, True), keep_raw=False)
+    def run(self, x, dt):
+        h = self.norm1.apply_ndhwc(x, True, dt)
+        h = self.conv1.run(h, dt)
+        h = self.norm2.apply_ndhwc(h, True, dt)
         if self.in_channels != self.out_channels:
             x = self.nin_shortcut.run(x, dt)
-        out = self.conv2.run(h, dt, res=x, res_mode=L.VT_RES_ADD, ln_next=ln_next)
-        return out if ln_next is not None else (out, None)
+        return self.conv2.run(h, dt, res=x, res_mode=L.VT_RES_ADD)
 
 
 class AttnBlockWrapper(nn.Module):
@@ -384,10 +366,10 @@ class AttnBlockWrapper(nn.Module):
         self.v = CausalConv3d(in_channels, in_channels, 1, version=version)
         self.proj_out = CausalConv3d(in_channels, in_channels, 1, version=version)
 
-    def run(self, x, dt, xn=None, ln_next=None):
+    def run(self, x, dt):
         B, T, H, W, Cc = x.shape
         S, Z = H * W, B * T
-        hn = xn if xn is not None else self.norm.apply_ndhwc(x, False, dt)
+        hn = self.norm.apply_ndhwc(x, False, dt)
         q = self.q.run(hn, dt).view(Z, S, Cc)
         k = self.k.run(hn, dt).view(Z, S, Cc)
         wv, bv = self.v._pack.get(self.v.conv.weight, self.v.conv.bias, dt, cin_stored=Cc)
@@ -396,25 +378,7 @@ class AttnBlockWrapper(nn.Module):
         s = ops.gemm_nt(q, k, out_dtype=torch.float32)                                         # [Z, S, S]
         p = ops.softmax_rows(s, float(Cc) ** -0.5, dt, ld_out=Sp)                              # [Z, S, Sp]
         o = ops.gemm_nt(p, vT, bias=bv).view(B, T, H, W, Cc)
-        out = self.proj_out.run(o, dt, res=x, res_mode=L.VT_RES_ADD, ln_next=ln_next)
-        return out if ln_next is not None else (out, None)
-
-
-def _consumer_norm(mod):
-    """(LayerNorm, silu) that `mod` applies to its input first, or None (resamplers consume the raw tensor)."""
-    if isinstance(mod, AttnBlockWrapper):
-        return (mod.norm, False)
-    if hasattr(mod, "norm1"):
-        return (mod.norm1, True)
-    return None
-
-
-def _run_stage(mod, h, hn, dt, nxt):
-    """Run one stage of the encoder / decoder chain; returns (output, output normalised for the next stage or None)."""
-    if hasattr(mod, "norm1") or isinstance(mod, AttnBlockWrapper):
-        return mod.run(h, dt, xn=hn, ln_next=nxt)
-    out = mod.run(h, dt, ln_next=nxt)          # resampler: raw input, may fuse the next stage's norm
-    return out if nxt is not None else (out, None)
+        return self.proj_out.run(o, dt, res=x, res_mode=L.VT_RES_ADD)
 
 
 def _level_module():
@@ -493,23 +457,19 @@ class EncoderCausal3DPadding(nn.Module):
         assert x.dim() == 5, "input should be 5D tensor, but got {}D tensor".format(x.dim())
         dt = self.compute_dtype
         h = ops.ncthw_to_ndhwc(x.contiguous().float(), dt, tpad=self._front_pad(x.shape[2]))
-        # every producer is told which LayerNorm consumes its output next, so the norm can ride in the
-        # producer's epilogue (`hn` = that norm already applied, or None when it could not be fused)
-        chain = []
+        h = self.conv_in.run(h, dt)
         for i_level in range(self.num_resolutions):
             for i_block in range(self.num_res_blocks):
-                chain.append(self.down[i_level].block[i_block])
-                chain.append(self.down_temporal[i_level].block[i_block])
+                h = self.down[i_level].block[i_block].run(h, dt)
+                h = self.down_temporal[i_level].block[i_block].run(h, dt)
             if i_level in self.spatial_ds:
-                chain.append(self.down[i_level].downsample)
+                h = self.down[i_level].downsample.run(h, dt)
                 if i_level in self.tempo_ds:
-                    chain.append(self.down_temporal[i_level].downsample)
-        chain += [self.mid.block_1, self.mid.attn_1, self.mid.block_2]
-        h, hn = self.conv_in.run(h, dt, ln_next=_consumer_norm(chain[0]))
-        for i, mod in enumerate(chain):
-            nxt = _consumer_norm(chain[i + 1]) if i + 1 < len(chain) else (self.norm_out, True)
-            h, hn = _run_stage(mod, h, hn, dt, nxt)
-        h = hn if hn is not None else self.norm_out.apply_ndhwc(h, True, dt)
+                    h = self.down_temporal[i_level].downsample.run(h, dt)
+        h = self.mid.block_1.run(h, dt)
+        h = self.mid.attn_1.run(h, dt)
+        h = self.mid.block_2.run(h, dt)
+        h = self.norm_out.apply_ndhwc(h, True, dt)
         return self.conv_out.run(h, dt, out_layout=L.VT_NCTHW)
 
 
@@ -585,20 +545,19 @@ class DecoderCausal3DPadding(nn.Module):
     def forward(self, z):
         dt = self.compute_dtype
         h = ops.ncthw_to_ndhwc(z.contiguous().float(), dt)
-        chain = [self.mid.block_1, self.mid.attn_1, self.mid.block_2]
+        h = self.conv_in.run(h, dt)
+        h = self.mid.block_1.run(h, dt)
+        h = self.mid.attn_1.run(h, dt)
+        h = self.mid.block_2.run(h, dt)
         for i_level in reversed(range(self.num_resolutions)):
             for i_block in range(self.num_res_blocks + 1):
-                chain.append(self.up[i_level].block[i_block])
-                chain.append(self.up_temporal[i_level].block[i_block])
+                h = self.up[i_level].block[i_block].run(h, dt)
+                h = self.up_temporal[i_level].block[i_block].run(h, dt)
             if i_level in self.spatial_us:
-                chain.append(self.up[i_level].upsample)
+                h = self.up[i_level].upsample.run(h, dt)
                 if i_level in self.tempo_us:
-                    chain.append(self.up_temporal[i_level].upsample)
-        h, hn = self.conv_in.run(h, dt, ln_next=_consumer_norm(chain[0]))
-        for i, mod in enumerate(chain):
-            nxt = _consumer_norm(chain[i + 1]) if i + 1 < len(chain) else (self.norm_out, True)
-            h, hn = _run_stage(mod, h, hn, dt, nxt)
-        h = hn if hn is not None else self.norm_out.apply_ndhwc(h, True, dt)
+                    h = self.up_temporal[i_level].upsample.run(h, dt)
+        h = self.norm_out.apply_ndhwc(h, True, dt)
         trim = self.time_padding if self.version == "v1_0" else 0
         return self.conv_out.run(h, dt, out_layout=L.VT_NCTHW, t_trim=trim)
 

@@ -79,20 +79,10 @@ class ConvGeom:
         return To, Ho, Wo
 
 
-def conv_ln_fusable(x_shape, geom: "ConvGeom", cout: int) -> bool:
-    """Can vt_conv fuse the LayerNorm of its output row for this problem (include/vidtok_amd.h)?"""
-    B, Ti, Hi, Wi, _ = x_shape
-    To, Ho, Wo = geom.out_dims(Ti, Hi, Wi)
-    return bool(L.load().vt_conv_ln_fusable(B * To * Ho * Wo, cout))
-
-
 def conv(x, w, bias, geom: ConvGeom, *, cout: int, out_dtype=None, tmode=L.VT_TPAD_ZERO, cache=None,
          res=None, res_mode=L.VT_RES_NONE, res_tshift=0, mix_factor=None, out_layout=L.VT_NDHWC,
-         t_trim=0, ldy=None, ln=None, ln_keep_raw=True):
-    """y = conv(x) (+bias) (+res | alpha-mix); x [B,Ti,Hi,Wi,Cin], w packed [cout, ldw].
-
-    ln = (gamma, beta, eps, silu): additionally fuse the per-position LayerNorm(+SiLU) of the output
-    row into the epilogue; returns (y, y_norm) -- y is None when ln_keep_raw is False."""
+         t_trim=0, ldy=None):
+    """y = conv(x) (+bias) (+res | alpha-mix); x [B,Ti,Hi,Wi,Cin], w packed [cout, ldw]."""
     lib = L.load()
     _chk(x, "conv.x"); _chk(w, "conv.w")
     B, Ti, Hi, Wi, Cin = x.shape
@@ -138,17 +128,8 @@ def conv(x, w, bias, geom: ConvGeom, *, cout: int, out_dtype=None, tmode=L.VT_TP
     d.out_layout, d.t_trim = out_layout, t_trim
     d.dtype, d.out_dtype = _DT[x.dtype], _DT[out_dtype]
     d.nbatch = 1
-    if ln is None:
-        _conv_launch(lib, d, "vt_conv")
-        return y
-    gamma, beta, eps, silu = ln
-    assert out_layout == L.VT_NDHWC and out_dtype == x.dtype and ldy == cout
-    assert gamma.dtype == torch.float32 and beta.dtype == torch.float32 and gamma.numel() == cout
-    yn = torch.empty_like(y)
-    d.ln_gamma, d.ln_beta, d.ln_out = gamma.data_ptr(), beta.data_ptr(), yn.data_ptr()
-    d.ln_eps, d.ln_silu, d.ln_keep_raw = float(eps), int(bool(silu)), int(bool(ln_keep_raw))
-    _conv_launch(lib, d, "vt_conv(+layernorm)")
-    return (y if ln_keep_raw else None), yn
+    _conv_launch(lib, d, "vt_conv")
+    return y
 
 
 def gemm_nt(a, b, *, out_dtype=None, bias=None, ld_out=None):
