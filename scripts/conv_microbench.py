@@ -1,5 +1,5 @@
 """GPU micro-benchmark of the vt_conv kernel on the layer shapes of vidtok_kl_causal_488_4chn at
-B=4, 17(20)x256x256.  `VT_CONV_IMPL=reg|glds|glds2 python scripts/conv_microbench.py`
+B=4, 17(20)x256x256.  `[VT_CONV_BUF=0|1] [VT_CONV_KWIN=0|1] python scripts/conv_microbench.py`
 prints one line per layer class: ms, TFLOP/s.  Used for within-run A/B of kernel variants."""
 import math
 import os
@@ -35,7 +35,7 @@ CASES = [  # name, (T,H,W), cin, cout, taps, geom, residual
 def main():
     dtype = torch.bfloat16 if os.environ.get("MB_DTYPE", "bf16") == "bf16" else torch.float32
     only = os.environ.get("MB_ONLY")
-    print(f"impl={os.environ.get('VT_CONV_IMPL', 'default')} dtype={dtype} B={B}")
+    print(f"buf={os.environ.get('VT_CONV_BUF', '1')} kwin={os.environ.get('VT_CONV_KWIN', '0')} dtype={dtype} B={B}")
     tot_ms = tot_fl = 0.0
     for name, (T, H, W), cin, cout, taps, geom, res in CASES:
         if only and only not in name:

@@ -4,38 +4,40 @@
 // GEMM view:  Y[m][n] = sum_k  X_gather[m][k] * W[n][k],   m = output pixel (b,to,ho,wo),
 //             n = output channel, k = tap*Cin + c.
 //
-// Kernel structure (one workgroup = 256 threads = 4 wave64):
-//   * block tile BM pixels x BN channels, K step of 128 BYTES per row (BK = 64 bf16 / 32 fp32), so
-//     8 consecutive lanes fetch one full 128-B line of a pixel's channel vector (NDHWC keeps C
-//     innermost => coalesced) and of a weight row;
-//   * both operand tiles live in LDS as [row][BK] with a 16-B pad per row (row stride 144 B): the
-//     ds_write_b128 of the staging pass and the ds_read_b128 of the fragment pass are then
-//     bank-conflict free (9*row mod 16 is a bijection on every 16-lane service group);
-//   * global -> register -> LDS staging, LDS double-buffered, next K step's global loads are in
-//     flight while the MFMAs of the current step run (one barrier per K step);
-//   * MFMA 32x32 tiles with the operand roles SWAPPED: the weight fragment is the A operand
-//     (rows = n) and the pixel fragment the B operand (cols = m).  Every lane then owns one pixel
-//     and 4 *consecutive* output channels per accumulator quad, so the epilogue issues 16-B (fp32)
-//     / 8-B (bf16) vector stores into the NDHWC row instead of 16 scalar ones;
-//   * the K mapping inside a 16-B fragment is the same bijection for both operands, which is all
-//     an inner product needs: bf16 uses v_mfma_f32_32x32x16_bf16 (one 16-B read = one MFMA), fp32
-//     uses v_mfma_f32_32x32x2_f32 (one 16-B read feeds 4 MFMAs); fp32 results are bit-wise an
-//     fmaf chain (MI355X guide, "FP32-input MFMA");
+// Kernel structure (conv_igemm_glds_kernel):
+//   * workgroup tile 128 pixels x 128 channels (4 wave64, two workgroups per CU), 256 x 256 (8 waves)
+//     for Cout % 256 == 0 layers with many pixels, 256 x 32/64 for narrow outputs; K step = 128 BYTES per
+//     tile row (64 bf16 / 32 fp32), so 8 consecutive lanes fetch one full 128-B line of a pixel's
+//     channel vector (NDHWC keeps C innermost) or of a weight row;
+//   * operands go global -> LDS by LDS-DMA (buffer_load ... lds / global_load_lds), no VGPR round trip;
+//     bank conflicts are removed by an XOR swizzle applied on the SOURCE side; 2-stage ring, the DMA of
+//     step s+1 flies during the MFMAs of step s (details at the kernel);
+//   * MFMA 32x32 tiles with the operand roles SWAPPED: the weight fragment is the A operand (rows = n)
+//     and the pixel fragment the B operand (cols = m).  Every lane then owns one pixel and 4
+//     *consecutive* output channels per accumulator quad, so the epilogue issues 16-B (fp32) / 8-B
+//     (bf16) vector loads/stores on the NDHWC rows;
+//   * the K mapping inside a 16-B fragment is the same bijection for both operands, which is all an
+//     inner product needs: bf16 uses v_mfma_f32_32x32x16_bf16 (one 16-B read = one MFMA), fp32 uses
+//     v_mfma_f32_32x32x2_f32 (one 16-B read feeds 4 MFMAs); fp32 results are bit-wise an fmaf chain;
 //   * padding, causal time padding (zero / replicate / cache), stride, and nearest-neighbour x2
 //     up-sampling in space or time are folded into the gather addresses: nothing is materialised;
-//   * epilogue: + bias, + residual or alpha-mix, dtype conversion, NDHWC vector store or
-//     NCTHW (fp32, with front time trim) store;
+//   * epilogue: + bias, + residual or alpha-mix, dtype conversion, NDHWC vector store or NCTHW (fp32,
+//     with front time trim) store;
 //   * XCD-aware tile order: consecutive tiles of one XCD are neighbouring pixel tiles of the same
 //     channel tile, so halo rows and the weight slab are shared in that XCD's L2.
+//
+// Measured dead ends (kept out of the code): register-staged operand tiles
+// (ds_write_b128 pass: 627 vs 440 TFLOP/s aggregate), a 4-stage ring of 64-B rows (no gain: the loop is
+// instruction-issue bound, not DMA-latency bound), 256x128 tiles with 8 or 4 waves (slower), a persistent
+// tile loop (40 % slower: the co-resident workgroups fall into lockstep), LayerNorm fused into the
+// epilogue (+1.6 ms per conv vs 0.5 ms for the separate kernel).
 #include <stdlib.h>
 
 #include "common.h"
 
 namespace {
 
-constexpr int kThreads = 256;
 constexpr int kRowBytes = 128;     // bytes of K per tile row per step
-constexpr int kLdsRowBytes = 144;  // + 16 B pad
 
 struct ConvArgs {
   const char* x;
@@ -248,186 +250,9 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[T
   }
 }
 
-template <typename MT, typename TOut, int WAVES_M, int WAVES_N, int TM, int TN, bool FAST>
-__global__ __launch_bounds__(kThreads) void conv_igemm_kernel(const ConvArgs p) {
-  constexpr int VEC = 16 / (int)sizeof(MT);
-  constexpr int BK = kRowBytes / (int)sizeof(MT);
-  constexpr int BM = WAVES_M * TM * 32;
-  constexpr int BN = WAVES_N * TN * 32;
-  constexpr int A_VECS = BM * 8 / kThreads;
-  constexpr int B_VECS = BN * 8 / kThreads;
-  constexpr int A_BYTES = BM * kLdsRowBytes;
-  constexpr int STAGE_BYTES = (BM + BN) * kLdsRowBytes;
-  static_assert(WAVES_M * WAVES_N == 4, "4 waves per workgroup");
-  static_assert(A_VECS >= 1 && B_VECS >= 1, "tile too small");
-
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = tid >> 6;
-  const int wm = wave % WAVES_M;
-  const int wn = wave / WAVES_M;
-
-  const int tile = xcd_remap(blockIdx.x, p.m_tiles * p.n_tiles);
-  const int nt = tile / p.m_tiles;
-  const int mt = tile - nt * p.m_tiles;
-  const int m_blk = mt * BM;
-  const int n_blk = nt * BN;
-
-  const long long z = blockIdx.z;
-  const MT* __restrict__ xg = reinterpret_cast<const MT*>(p.x) + z * p.xs_z;
-  const MT* __restrict__ wg = reinterpret_cast<const MT*>(p.w) + z * p.ws_z;
-  const MT* __restrict__ cg = reinterpret_cast<const MT*>(p.cache);
-
-  // ---- staging roles: this thread moves 16-B vector `kvec` of rows (tid>>3) + 32*i -----------
-  const int kvec = tid & 7;
-  const int srow = tid >> 3;
-
-  const int Hv = p.Hi << p.ups_s, Wv = p.Wi << p.ups_s;
-  const int Tv = p.Ti << p.ups_t;
-
-  int a_b[A_VECS], a_t0[A_VECS], a_h0[A_VECS], a_w0[A_VECS];
-#pragma unroll
-  for (int i = 0; i < A_VECS; ++i) {
-    const int m = m_blk + srow + 32 * i;
-    if (m < p.M) {
-      int wo = m % p.Wo;
-      int r = m / p.Wo;
-      int ho = r % p.Ho;
-      r /= p.Ho;
-      int to = r % p.To;
-      int b = r / p.To;
-      a_b[i] = b;
-      a_t0[i] = to * p.st - p.pt;
-      a_h0[i] = ho * p.sh - p.ph;
-      a_w0[i] = wo * p.sw - p.pw;
-    } else {
-      a_b[i] = -1;
-      a_t0[i] = a_h0[i] = a_w0[i] = 0;
-    }
-  }
-
-  u32x4 areg[A_VECS], breg[B_VECS];
-  const int cpb = FAST ? (p.Cin / BK) : 1;  // K steps per tap on the fast path
-  const int khw = p.KH * p.KW;
-
-  auto load_step = [&](int s) {
-    int tap, c;
-    if (FAST) {
-      tap = s / cpb;
-      c = (s - tap * cpb) * BK + kvec * VEC;
-    } else {
-      const int k = s * BK + kvec * VEC;
-      tap = k / p.Cin;
-      c = k - tap * p.Cin;
-    }
-    const bool kvalid = tap < p.ntaps;
-    const int kt = tap / khw;
-    const int r2 = tap - kt * khw;
-    const int kh = r2 / p.KW;
-    const int kw = r2 - kh * p.KW;
-#pragma unroll
-    for (int i = 0; i < A_VECS; ++i) {
-      u32x4 v = {0u, 0u, 0u, 0u};
-      int tv = a_t0[i] + kt;
-      const int hv = a_h0[i] + kh;
-      const int wv = a_w0[i] + kw;
-      bool ok = kvalid && (a_b[i] >= 0) && (hv >= 0) && (hv < Hv) && (wv >= 0) && (wv < Wv) && (tv < Tv);
-      const MT* base = xg;
-      int tstore = p.Ti, ti;
-      if (tv < 0) {
-        if (p.tmode == VT_TPAD_ZERO) {
-          ok = false;
-          ti = 0;
-        } else if (p.tmode == VT_TPAD_REPLICATE) {
-          ti = 0;
-        } else {
-          base = cg;
-          tstore = p.ncache;
-          ti = p.ncache + tv;
-          ok = ok && (ti >= 0);
-        }
-      } else {
-        ti = tv >> p.ups_t;
-      }
-      if (ok) {
-        const int hi = hv >> p.ups_s, wi = wv >> p.ups_s;
-        const long long pix = (((long long)a_b[i] * tstore + ti) * p.Hi + hi) * p.Wi + wi;
-        v = *reinterpret_cast<const u32x4*>(base + pix * p.Cin + c);
-      }
-      areg[i] = v;
-    }
-    const int kk = FAST ? (s * BK + kvec * VEC) : (tap * p.Cin + c);
-#pragma unroll
-    for (int j = 0; j < B_VECS; ++j) {
-      u32x4 v = {0u, 0u, 0u, 0u};
-      const int n = n_blk + srow + 32 * j;
-      if (kvalid && n < p.Cout) v = *reinterpret_cast<const u32x4*>(wg + (long long)n * p.ldw + kk);
-      breg[j] = v;
-    }
-  };
-
-  auto store_stage = [&](int buf) {
-    char* As = smem + buf * STAGE_BYTES;
-    char* Bs = As + A_BYTES;
-#pragma unroll
-    for (int i = 0; i < A_VECS; ++i)
-      *reinterpret_cast<u32x4*>(As + (srow + 32 * i) * kLdsRowBytes + kvec * 16) = areg[i];
-#pragma unroll
-    for (int j = 0; j < B_VECS; ++j)
-      *reinterpret_cast<u32x4*>(Bs + (srow + 32 * j) * kLdsRowBytes + kvec * 16) = breg[j];
-  };
-
-  f32x16 acc[TN][TM];
-#pragma unroll
-  for (int a = 0; a < TN; ++a)
-#pragma unroll
-    for (int b = 0; b < TM; ++b)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
-
-  const int frag_off = (lane & 31) * kLdsRowBytes + (lane >> 5) * 16;
-
-  auto compute_stage = [&](int buf) {
-    const char* As = smem + buf * STAGE_BYTES + (wm * TM * 32) * kLdsRowBytes + frag_off;
-    const char* Bs = smem + buf * STAGE_BYTES + A_BYTES + (wn * TN * 32) * kLdsRowBytes + frag_off;
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      u32x4 wf[TN], xf[TM];
-#pragma unroll
-      for (int a = 0; a < TN; ++a)
-        wf[a] = *reinterpret_cast<const u32x4*>(Bs + a * 32 * kLdsRowBytes + ks * 32);
-#pragma unroll
-      for (int b = 0; b < TM; ++b)
-        xf[b] = *reinterpret_cast<const u32x4*>(As + b * 32 * kLdsRowBytes + ks * 32);
-#pragma unroll
-      for (int a = 0; a < TN; ++a)
-#pragma unroll
-        for (int b = 0; b < TM; ++b) mma_step<MT>(wf[a], xf[b], acc[a][b]);
-    }
-  };
-
-  // ---- main loop: LDS double buffer, register prefetch ----------------------------------------
-  load_step(0);
-  store_stage(0);
-  __syncthreads();
-  for (int s = 0; s < p.nsteps; ++s) {
-    const int cur = s & 1;
-    if (s + 1 < p.nsteps) load_step(s + 1);
-    compute_stage(cur);
-    if (s + 1 < p.nsteps) store_stage(cur ^ 1);
-    __syncthreads();
-  }
-
-  conv_epilogue<TOut, TM, TN>(p, acc, m_blk, n_blk, BN, wm, wn, lane, z);
-}
-
-
 // ------------------------------------------------------------------------------------------------
-// LDS-DMA variant (default): the operand tiles go global -> LDS with global_load_lds_dwordx4
-// (no VGPR round trip, no ds_write pass -- on the register-staged variant the ds_write_b128 stream
-// alone costs ~415 LDS cycles per K step against 512 MFMA cycles).  The DMA writes each wave's 64
+// The operand tiles go global -> LDS with LDS-DMA (no VGPR round trip, no ds_write pass -- a
+// register-staged first version spent ~415 LDS cycles per K step on ds_write_b128 against 512 MFMA cycles).  The DMA writes each wave's 64
 // lanes x 16 B to a contiguous 1 KiB, so a tile row is exactly 128 B (no pad) and instruction i of
 // wave w fills rows 32*i + 8*w .. +8.  Bank conflicts are removed with an XOR swizzle applied on the
 // SOURCE side (guide rule 21): the lane that writes 16-B slot `pos` of row r fetches logical K chunk
@@ -798,21 +623,6 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_igemm_glds_kernel
 #endif
 }
 
-// Staging variant: LDS-DMA with a 2-stage ring of 128-B rows (default).  VT_CONV_IMPL=reg selects the
-// register-staged kernel, VT_CONV_IMPL=deep the 4-stage ring of 64-B rows (3 steps of DMA in flight;
-// measured no faster: the loop is not DMA-latency bound) -- both kept for within-run A/B measurements.
-inline int conv_impl() {
-  static int mode = -1;
-  if (mode < 0) {
-    const char* e = getenv("VT_CONV_IMPL");
-    mode = 2;
-    if (e && strcmp(e, "reg") == 0) mode = 0;
-    if (e && strcmp(e, "deep") == 0) mode = 1;
-    if (e && strcmp(e, "tall") == 0) mode = 3;
-  }
-  return mode;
-}
-
 // descriptor (buffer_load ... lds) gather; VT_CONV_BUF=0 falls back to 64-bit pointers (A/B runs)
 inline bool conv_buf() {
   static int mode = -1;
@@ -836,42 +646,35 @@ inline bool conv_kwin() {
   return mode == 1;
 }
 
-// ROWB == 0 selects the register-staged kernel
-template <typename MT, typename TOut, int WAVES_M, int WAVES_N, int TM, int TN, bool FAST, int ROWB, int STAGES>
+template <typename MT, typename TOut, int WAVES_M, int WAVES_N, int TM, int TN, bool FAST>
 int launch_variant(const ConvArgs& a_in, int nbatch, hipStream_t stream) {
-  constexpr bool GLDS = ROWB != 0;
+  constexpr int ROWB = kRowBytes, STAGES = 2;
   constexpr int BM = WAVES_M * TM * 32;
   constexpr int BN = WAVES_N * TN * 32;
-  constexpr int BK = (GLDS ? ROWB : kRowBytes) / (int)sizeof(MT);
+  constexpr int BK = ROWB / (int)sizeof(MT);
   constexpr int THREADS = 64 * WAVES_M * WAVES_N;
-  constexpr int LDS = GLDS ? STAGES * (BM + BN) * ROWB : 2 * (BM + BN) * kLdsRowBytes;
+  constexpr int LDS = STAGES * (BM + BN) * ROWB;
   ConvArgs a = a_in;
   a.m_tiles = (a.M + BM - 1) / BM;
   a.n_tiles = (a.Cout + BN - 1) / BN;
   a.nsteps = FAST ? a.ntaps * (a.Cin / BK) : (a.K + BK - 1) / BK;
+  a.kwin = conv_kwin() ? 1 : 0;
+  // descriptor gather needs both tensors under 4 GiB (minus the out-of-range marker) and no cache-mode padding
+  const unsigned long long xb = (unsigned long long)a.B * a.Ti * a.Hi * a.Wi * a.Cin * sizeof(MT);
+  const unsigned long long wb = (unsigned long long)a.Cout * a.ldw * sizeof(MT);
+  const bool buf = conv_buf() && xb < 0xFFFF0000ull && wb < 0xFFFF0000ull && a.tmode != VT_TPAD_CACHE;
   const void* kern;
-  int variant = 0;
-  if constexpr (GLDS) {
-    // descriptor gather needs both tensors under 4 GiB (minus the out-of-range marker) and no cache-mode padding
-    const unsigned long long xb = (unsigned long long)a.B * a.Ti * a.Hi * a.Wi * a.Cin * sizeof(MT);
-    const unsigned long long wb = (unsigned long long)a.Cout * a.ldw * sizeof(MT);
-    const bool buf = conv_buf() && xb < 0xFFFF0000ull && wb < 0xFFFF0000ull && a.tmode != VT_TPAD_CACHE;
-    a.kwin = conv_kwin() ? 1 : 0;
-    if (buf) {
-      a.x_bytes = (unsigned)xb;
-      a.w_bytes = (unsigned)wb;
-      variant = 1;
-      kern = reinterpret_cast<const void*>(&conv_igemm_glds_kernel<MT, TOut, WAVES_M, WAVES_N, TM, TN, FAST, ROWB, STAGES, true>);
-    } else {
-      kern = reinterpret_cast<const void*>(&conv_igemm_glds_kernel<MT, TOut, WAVES_M, WAVES_N, TM, TN, FAST, ROWB, STAGES, false>);
-    }
+  if (buf) {
+    a.x_bytes = (unsigned)xb;
+    a.w_bytes = (unsigned)wb;
+    kern = reinterpret_cast<const void*>(&conv_igemm_glds_kernel<MT, TOut, WAVES_M, WAVES_N, TM, TN, FAST, ROWB, STAGES, true>);
   } else {
-    kern = reinterpret_cast<const void*>(&conv_igemm_kernel<MT, TOut, WAVES_M, WAVES_N, TM, TN, FAST>);
+    kern = reinterpret_cast<const void*>(&conv_igemm_glds_kernel<MT, TOut, WAVES_M, WAVES_N, TM, TN, FAST, ROWB, STAGES, false>);
   }
   static bool attr_done[2] = {false, false};  // per instantiation and gather form
-  if (!attr_done[variant]) {
+  if (!attr_done[buf]) {
     VT_CHECK_HIP(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
-    attr_done[variant] = true;
+    attr_done[buf] = true;
   }
   const long long nblk = (long long)a.m_tiles * a.n_tiles;
   VT_CHECK_ARG(nblk < (1ll << 31), "vt_conv: too many tiles (%lld)", nblk);
@@ -880,47 +683,28 @@ int launch_variant(const ConvArgs& a_in, int nbatch, hipStream_t stream) {
   return VT_OK;
 }
 
-template <typename MT, typename TOut, int WAVES_M, int WAVES_N, int TM, int TN, int ROWB, int STAGES>
+template <typename MT, typename TOut, int WAVES_M, int WAVES_N, int TM, int TN>
 int launch_fast_or_general(const ConvArgs& a, int nbatch, hipStream_t stream) {
-  constexpr int BK = (ROWB ? ROWB : kRowBytes) / (int)sizeof(MT);
-  return (a.Cin % BK) == 0 ? launch_variant<MT, TOut, WAVES_M, WAVES_N, TM, TN, true, ROWB, STAGES>(a, nbatch, stream)
-                           : launch_variant<MT, TOut, WAVES_M, WAVES_N, TM, TN, false, ROWB, STAGES>(a, nbatch, stream);
+  constexpr int BK = kRowBytes / (int)sizeof(MT);
+  return (a.Cin % BK) == 0 ? launch_variant<MT, TOut, WAVES_M, WAVES_N, TM, TN, true>(a, nbatch, stream)
+                           : launch_variant<MT, TOut, WAVES_M, WAVES_N, TM, TN, false>(a, nbatch, stream);
 }
 
-// Tile and pipeline selection.  Bytes staged per FLOP fall with the tile area (128x128: 15.6 KB/MFLOP
-// bf16, 256x256: 7.8) and the kernel is bound by the L2->LDS DMA round trip (~2 us under load), i.e. by
-// the bytes it keeps in flight per CU: so (a) Cout % 256 == 0 layers with enough pixels take the 8-wave
-// 256x256 tile, everything else 128x128 with two independent workgroups per CU (a 256x128 8-wave tile
-// measured slower: one barrier domain stalls all 8 waves on the same DMA); (b) the LDS ring is 4 stages
-// of 64-B rows with 3 steps of DMA in flight (96 of the CU's 160 KB) instead of 2 stages of 128-B rows.
+// Tile selection.  Bytes staged per FLOP fall with the tile area (128x128: 15.6 KB/MFLOP bf16, 256x256: 7.8),
+// so Cout % 256 == 0 layers with enough pixels take the 8-wave 256x256 tile (measured 988 vs 814 TFLOP/s on
+// the 27-tap 256->256 conv when introduced); everything else keeps 128x128 with two independent workgroups
+// per CU, which cover each other's prologue / epilogue / DMA stalls (256x128 tiles measured slower).
 template <typename MT, typename TOut>
 int dispatch_tile(const ConvArgs& a, int nbatch, hipStream_t stream) {
   auto blocks = [&](int bm, int bn) {
     return (long long)((a.M + bm - 1) / bm) * ((a.Cout + bn - 1) / bn) * nbatch;
   };
-  const int impl = conv_impl();
   const bool vec_epi = a.out_layout == VT_NDHWC && (a.ldy & 3) == 0 && (a.res_mode == VT_RES_NONE || (a.ldr & 3) == 0);
-  const bool big = a.Cout % 256 == 0 && vec_epi && blocks(256, 256) >= 384;
-#define VT_TILES(ROWB, STAGES)                                                                                  \
-  if (a.Cout <= 32) return launch_fast_or_general<MT, TOut, 4, 1, 2, 1, ROWB, STAGES>(a, nbatch, stream);       \
-  if (a.Cout <= 64) return launch_fast_or_general<MT, TOut, 4, 1, 2, 2, ROWB, STAGES>(a, nbatch, stream);
-  if (impl == 0) {
-    VT_TILES(0, 2)
-    return launch_fast_or_general<MT, TOut, 2, 2, 2, 2, 0, 2>(a, nbatch, stream);
-  }
-  if (impl == 2 || impl == 3) {
-    VT_TILES(128, 2)
-    if (big) return launch_fast_or_general<MT, TOut, 4, 2, 2, 4, 128, 2>(a, nbatch, stream);
-    // impl 3 (VT_CONV_IMPL=tall): 256x128 4-wave tile with 64-B rows for the Cout % 128 == 0 layers whose
-    // tile count is large (the widest pyramid level): half the per-tile fixed cost and weight traffic per pixel
-    if (impl == 3 && a.Cout % 128 == 0 && vec_epi && blocks(256, 128) >= 1024)
-      return launch_fast_or_general<MT, TOut, 2, 2, 4, 2, 64, 2>(a, nbatch, stream);
-    return launch_fast_or_general<MT, TOut, 2, 2, 2, 2, 128, 2>(a, nbatch, stream);
-  }
-  VT_TILES(128, 2)   // narrow-N tiles: a 64-B row ring would leave B_VECS < 1; they are A-stream bound anyway
-  if (big) return launch_fast_or_general<MT, TOut, 4, 2, 2, 4, 64, 4>(a, nbatch, stream);   // 256 x 256, 8 waves
-  return launch_fast_or_general<MT, TOut, 2, 2, 2, 2, 64, 4>(a, nbatch, stream);            // 128 x 128
-#undef VT_TILES
+  if (a.Cout <= 32) return launch_fast_or_general<MT, TOut, 4, 1, 2, 1>(a, nbatch, stream);   // 256 x 32
+  if (a.Cout <= 64) return launch_fast_or_general<MT, TOut, 4, 1, 2, 2>(a, nbatch, stream);   // 256 x 64
+  if (a.Cout % 256 == 0 && vec_epi && blocks(256, 256) >= 384)
+    return launch_fast_or_general<MT, TOut, 4, 2, 2, 4>(a, nbatch, stream);                   // 256 x 256, 8 waves
+  return launch_fast_or_general<MT, TOut, 2, 2, 2, 2>(a, nbatch, stream);                     // 128 x 128
 }
 
 }  // namespace
