@@ -11,10 +11,11 @@ Workload at every N: BASELINE.json configs[1] -- vidtok_kl_causal_488_4chn, bf16
 section 8e; only the timing/metrics reduction crosses ranks).  Prints ONE JSON line on rank 0.
 
   value       real frames/s over the whole job = N*B*17*K / max-over-ranks(time of K steps)
-  roofline    conv_igemm kernel (all convolutions + the attention GEMMs = every MFMA FLOP of the
+  roofline    conv_igemm_glds_kernel (all convolutions + the attention GEMMs = every MFMA FLOP of the
               path): algorithmic FLOPs of one step (1.0345 TFLOP per padded 256x256 frame, SURVEY.md
               section 8d) / sum of that kernel's launch durations in one step, measured live with HIP
-              events on the launch stream; peak = dense MFMA peak of the dtype
+              events on the launch stream; peak = dense MFMA peak of the dtype; traffic = HBM-side
+              bytes per launch from the committed rocprofv3 PMC pass (profiles/)
   cpu_baseline  the CPU oracle (port of the reference, oracle/vidtok_oracle.py) timed on this host's
               cores on a bounded sample of the same workload; a baseline, not a target
 """
@@ -202,8 +203,15 @@ def main():
         flops = FLOP_PER_PADDED_FRAME_256 * B * T_PADDED
         achieved = flops / (conv_ms * 1e-3) / 1e12
         peak = PEAK_TFLOPS[args.dtype]
-        roof = {"bound": "mfma", "kernel": "conv_igemm_kernel", "achieved": round(achieved, 2), "peak": peak,
-                "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": None,
+        # HBM-side bytes per launch come from rocprofv3 PMC passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE,
+        # scripts/pmc_bench.sh + scripts/pmc_traffic.py); counters cannot be read inside a normal run, so the
+        # figure of the committed pass for this dtype is quoted (null when there is none)
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", f"r01_conv_traffic_pmc{'' if args.dtype == 'bf16' else '_' + args.dtype}.json")
+        if os.path.exists(tpath) and B == 4:
+            traffic = round(json.load(open(tpath))["traffic_bytes_per_launch"])
+        roof = {"bound": "mfma", "kernel": "conv_igemm_glds_kernel", "achieved": round(achieved, 2), "peak": peak,
+                "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic,
                 "launches_per_step": len(tl), "kernel_ms_per_step": round(conv_ms, 3),
                 "avg_launch_ms": round(conv_ms / max(1, len(tl)), 4), "algorithmic_tflop_per_step": round(flops / 1e12, 3)}
 

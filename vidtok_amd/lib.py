@@ -6,6 +6,12 @@ resolved, loading raises -- nothing silently degrades to torch ops.
 import ctypes as C
 import os
 
+# PyTorch-ROCm bundles its own libamdhip64.so.7 / libhsa-runtime64; libvidtok_amd.so needs the same SONAME.
+# Import torch FIRST so that the process has exactly one HIP runtime (torch's): if this library were loaded
+# before torch, the dynamic linker would bind it to /opt/rocm's copy and the two runtimes would not share a
+# device context (observed: hipErrorNoDevice on the first launch).
+import torch  # noqa: F401  (load order matters)
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libvidtok_amd.so")
 
