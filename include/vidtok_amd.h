@@ -197,6 +197,20 @@ int vt_gather_frames(const void* src, void* dst, int32_t esize, int32_t B, int64
                      int64_t src_bstride, int64_t dst_bstride, const int32_t* idx_host, int32_t n,
                      vt_stream stream);
 
+/* ------------------------------------------------------------------------------------------
+ * evaluation metrics of the reference's eval loop: per frame
+ *   out = clamp(y,-1,1); x,out -> (.+1)/2                          scripts/inference_evaluate.py:175-176
+ *   psnr = -10 log10(mean_{c,h,w}(x-out)^2 + 1e-8)                  vidtok/modules/util.py:146-154
+ *   ssim = mean_c mean_{h,w} SSIM map, 11x11 Gaussian sigma 1.5      vidtok/modules/util.py:157-222
+ * x, y NCTHW fp32 [B][C][T][H][W]; psnr, ssim [B][T]; work: vt_eval_work_floats() floats of scratch.
+ * raw = 1: x, y are the model's input / output in [-1,1], the post-processing above is applied inside;
+ * raw = 0: x, y are already [0,1] images (the argument convention of compute_psnr / compute_ssim).
+ * (The reference averages these per-frame values over 16-frame splits: a mean of means of equal size.)
+ * ---------------------------------------------------------------------------------------- */
+int64_t vt_eval_work_floats(int32_t B, int32_t T);
+int vt_eval_psnr_ssim(const float* x, const float* y, float* psnr, float* ssim, float* work, int32_t B, int32_t C,
+                      int32_t T, int32_t H, int32_t W, int32_t raw, vt_stream stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -177,8 +177,19 @@ def fsq_consts(levels):
     return half_l.tolist(), offset.tolist(), shift.tolist(), [float(b) for b in basis]
 
 
+def eval_psnr_ssim(x, y, raw=True):
+    """contract of vt_eval_psnr_ssim: per-frame PSNR / SSIM, [B,T] each (oracle/metrics_oracle.py is the restatement of
+    the reference; this is the operator contract the host mirror is tested against on CPU)"""
+    from oracle import metrics_oracle as M
+
+    if raw:
+        x, y = M.postprocess(x, y)
+    return M.psnr_frames(x, y), M.ssim_frames(x, y)
+
+
 ALL = ["conv", "gemm_nt", "layernorm_act", "softmax_rows", "ncthw_to_ndhwc", "ndhwc_to_ncthw", "time_avgpool3s2",
-       "time_lerp2x", "gather_frames", "kl_sample", "fsq_quantize", "fsq_indices_to_codes", "fsq_aux_stats"]
+       "time_lerp2x", "gather_frames", "kl_sample", "fsq_quantize", "fsq_indices_to_codes", "fsq_aux_stats",
+       "eval_psnr_ssim"]
 
 
 def patch_ops(monkeypatch):

@@ -59,7 +59,6 @@ struct ConvArgs {
   int out_layout, t_trim;
   int M, K, ntaps, nsteps;
   int m_tiles, n_tiles;
-  int kwin;                    // K walk with kw innermost (descriptor form)
   unsigned x_bytes, w_bytes;   // BUF path: descriptor extents (0 = tensors too large, use pointers)
   long long xs_z, ws_z, ys_z, rs_z;
 };
@@ -326,11 +325,10 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_igemm_glds_kernel
   const MT* __restrict__ cg = reinterpret_cast<const MT*>(p.cache);
   const MT* zero = reinterpret_cast<const MT*>(g_zero_page);
   constexpr unsigned kOob = 0xFFFF0000u;   // BUF: offset beyond any descriptor's num_records -> hardware zero fill
-  __amdgpu_buffer_rsrc_t rsrc_x, rsrc_w;
-  if constexpr (BUF) {
-    rsrc_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<MT*>(xg), 0, p.x_bytes, 0x00020000);
-    rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<MT*>(wg), 0, p.w_bytes, 0x00020000);
-  }
+  // BUF: the extents are loop state -- the steps after the last real prefetch still issue their DMA pieces,
+  // against extent 0 (every lane out of range: zeros into a slot nobody reads again, no memory traffic), so
+  // the K loop has no branch around any piece and ONE straight-line body
+  unsigned ext_x = BUF ? p.x_bytes : 0u, ext_w = BUF ? p.w_bytes : 0u;
 
   const int pos = tid % NS;                                  // 16-B slot this lane writes in its rows
   const int srow = tid / NS;                                 // rows srow + RSTEP*i
@@ -410,66 +408,80 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_igemm_glds_kernel
 
   const int khw = p.KH * p.KW;
   const int cpb = FAST ? (p.Cin / BK) : 1;
-  const MT* a_ptr[A_VECS];       // FAST: cached per tap
-  unsigned a_off[A_VECS];
+  const MT* a_ptr[A_VECS];       // FAST pointer form: cached per tap
+  unsigned a_off[A_VECS];        // descriptor form: byte offset of this lane's 16 B in x, or kOob
+
+  // FAST descriptor form: the gather offset of a tap is  time part (changes with kt only) + a wave-uniform
+  // (kh,kw) displacement, and whether the tap reads padding is ONE bit test against a per-row mask built once
+  // per tile -- 4 VALU per row and tap instead of the ~25 (three of them quarter-rate multiplies) of the
+  // general formula: on the short-K layers (Cin = 128: a new tap every other K step) the address work was
+  // more than half of the instructions of the K loop, which is instruction-issue bound.
+  //   a_mask: bit kh = row (h0+kh) inside the image, bit 8+kw likewise for columns, bit 16 = time tap valid
+  //           (set per kt), bits 17/18 = parity of h0 / w0 (x2 nearest up-sampling folded into the gather:
+  //           (h0+kh)>>1 = (h0>>1) + ((h0&1)+kh)>>1, i.e. base + uniform part + parity * uniform part)
+  unsigned a_mask[A_VECS], a_tb[A_VECS];
+  int a_bt[A_VECS], a_hw[A_VECS];
+  if constexpr (FAST && BUF) {
+#pragma unroll
+    for (int i = 0; i < A_VECS; ++i) {
+      unsigned mk = 0;
+      if (a_b[i] >= 0) {
+        for (int kh = 0; kh < p.KH; ++kh) mk |= ((unsigned)(a_h0[i] + kh) < (unsigned)Hv) ? (1u << kh) : 0u;
+        for (int kw = 0; kw < p.KW; ++kw) mk |= ((unsigned)(a_w0[i] + kw) < (unsigned)Wv) ? (1u << (8 + kw)) : 0u;
+        mk |= (unsigned)(a_h0[i] & 1) << 17;
+        mk |= (unsigned)(a_w0[i] & 1) << 18;
+      }
+      a_mask[i] = mk;
+      a_bt[i] = a_b[i] * p.Ti;
+      a_hw[i] = (a_h0[i] >> p.ups_s) * p.Wi + (a_w0[i] >> p.ups_s);   // arithmetic shifts: floor also for the -1 halo
+      a_tb[i] = 0;
+    }
+  }
 
   int coff = 0, koff = 0;   // element offsets of this lane's chunk: in the pixel's channel vector / weight row
   bool kvalid = true;
-  // FAST path: pipeline steps are prepared strictly in order, so the position in the K walk advances as
-  // scalar counters instead of being recovered from the step index with three integer divisions per step.
-  // Descriptor form walks K as  (kt,kh) group -> channel chunk -> kw : the KW taps of one group read the same
-  // cache lines shifted by one pixel, so visiting them back to back turns two of every three operand
-  // fetches into L2 hits (tap-major order re-fetched them from the fabric: the reuse distance, one whole
-  // tap x channel sweep of every workgroup of the XCD, exceeds its 4 MiB L2), and the gather offsets of
-  // the whole group are computed once (A_VECS x KW registers).  Weights keep their tap-major rows; only
-  // the visiting order changes.  The pointer form keeps the plain tap-major walk.
-  constexpr int KWMAX = 3;
-  const bool kw_inner = BUF && p.KW <= KWMAX && p.kwin != 0;
+  // FAST path: pipeline steps are prepared strictly in order, so the position in the K walk (tap-major, channel
+  // chunks innermost) advances as scalar counters instead of being recovered from the step index with three
+  // integer divisions per step.
   int q_step = 0, q_cc = 0, q_kt = 0, q_kh = 0, q_kw = 0;
-  unsigned a_offk[A_VECS][KWMAX];
   unsigned s_a = 0, s_b = 0;   // BUF: wave-uniform byte offsets (soffset operand): chunk-in-tap for x, k offset for w
   const unsigned chunk_bytes = (unsigned)chunk * 16u;
+  const unsigned HiWi = (unsigned)p.Hi * (unsigned)p.Wi;
   // addresses of the NEXT pipeline step (VALU/SALU only; the DMA pieces are fired separately so they can
   // be interleaved with the MFMAs of the stage being computed)
   auto prep_step = [&](int s) {
-    if (FAST && kw_inner) {
-      if constexpr (BUF) {
-        // the offsets of a tap are computed in the step that first needs it (chunk 0) and reused for the
-        // other chunks of the group: the address work stays spread over the steps (a burst for all KW taps
-        // delayed that step's DMA by a few hundred cycles, which the one-step-deep prefetch cannot hide)
-        if (q_cc == 0) {                       // uniform branches
+    if (FAST) {
+      if (q_cc == 0) {               // uniform branch: new tap -> new gather addresses
+        if constexpr (BUF) {
+          if ((q_kh | q_kw) == 0) {  // new kt (rare): time part of the offsets, time-padding bit
 #pragma unroll
-          for (int i = 0; i < A_VECS; ++i) {
-            const unsigned o = row_off(i, q_kt, q_kh, q_kw) + chunk_bytes;
-            a_off[i] = o;
-            if (q_kw == 0) a_offk[i][0] = o;
-            else if (q_kw == 1) a_offk[i][1] = o;
-            else a_offk[i][2] = o;
+            for (int i = 0; i < A_VECS; ++i) {
+              const int tv = a_t0[i] + q_kt;
+              const bool ok = (tv < Tv) & ((tv >= 0) | replicate);
+              const unsigned ti = (unsigned)(max(tv, 0) >> p.ups_t);
+              a_tb[i] = (((unsigned)a_bt[i] + ti) * HiWi + (unsigned)a_hw[i]) * pix_bytes + chunk_bytes;
+              a_mask[i] = (a_mask[i] & ~(1u << 16)) | (ok ? (1u << 16) : 0u);
+            }
+          }
+          const unsigned tm = (1u << q_kh) | (1u << (8 + q_kw)) | (1u << 16);
+          if (p.ups_s == 0) {
+            const unsigned delta = (unsigned)(q_kh * p.Wi + q_kw) * pix_bytes;
+#pragma unroll
+            for (int i = 0; i < A_VECS; ++i) a_off[i] = ((a_mask[i] & tm) == tm) ? a_tb[i] + delta : kOob;
+          } else {
+            const unsigned delta = (unsigned)((q_kh >> 1) * p.Wi + (q_kw >> 1)) * pix_bytes;
+            const unsigned dh = (q_kh & 1) ? (unsigned)p.Wi * pix_bytes : 0u;
+            const unsigned dw = (q_kw & 1) ? pix_bytes : 0u;
+#pragma unroll
+            for (int i = 0; i < A_VECS; ++i) {
+              const unsigned ph = (unsigned)(((int)(a_mask[i] << 14)) >> 31) & dh;   // parity bit 17 -> all-ones mask
+              const unsigned pw = (unsigned)(((int)(a_mask[i] << 13)) >> 31) & dw;   // parity bit 18
+              a_off[i] = ((a_mask[i] & tm) == tm) ? a_tb[i] + delta + ph + pw : kOob;
+            }
           }
         } else {
 #pragma unroll
-          for (int i = 0; i < A_VECS; ++i) a_off[i] = q_kw == 0 ? a_offk[i][0] : (q_kw == 1 ? a_offk[i][1] : a_offk[i][2]);
-        }
-        const int tap = (q_kt * p.KH + q_kh) * p.KW + q_kw;
-        s_a = (unsigned)q_cc * (unsigned)ROWB;
-        s_b = ((unsigned)tap * (unsigned)p.Cin + (unsigned)q_cc * (unsigned)BK) * (unsigned)sizeof(MT);
-        if (++q_kw == p.KW) {
-          q_kw = 0;
-          if (++q_cc == cpb) {
-            q_cc = 0;
-            if (++q_kh == p.KH) {
-              q_kh = 0;
-              ++q_kt;
-            }
-          }
-        }
-      }
-    } else if (FAST) {
-      if (q_cc == 0) {               // uniform branch: new tap -> new gather addresses
-#pragma unroll
-        for (int i = 0; i < A_VECS; ++i) {
-          if constexpr (BUF) a_off[i] = row_off(i, q_kt, q_kh, q_kw) + chunk_bytes;   // kOob + chunk stays out of range
-          else a_ptr[i] = row_ptr(i, q_kt, q_kh, q_kw);
+          for (int i = 0; i < A_VECS; ++i) a_ptr[i] = row_ptr(i, q_kt, q_kh, q_kw);
         }
       }
       coff = q_cc * BK + chunk * VEC;
@@ -511,6 +523,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_igemm_glds_kernel
     char* As = smem + stage * STAGE_BYTES + lds_row_off;
     if (q < A_VECS) {
       if constexpr (BUF) {
+        const __amdgpu_buffer_rsrc_t rsrc_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<MT*>(xg), 0, ext_x, 0x00020000);
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (lds_ptr_t)(As + (RSTEP * q) * ROWB), 16, a_off[q], s_a, 0, 0);
       } else {
         const MT* src = a_ptr[q] ? a_ptr[q] + coff : zero;
@@ -522,6 +535,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_igemm_glds_kernel
         // FAST: lane offset is fixed for the tile (row + chunk), the step advances through soffset;
         // general: the lane's k offset is folded in here
         const unsigned off = FAST ? b_off[j] : (kvalid ? b_off[j] + (unsigned)koff * (unsigned)sizeof(MT) : kOob);
+        const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<MT*>(wg), 0, ext_w, 0x00020000);
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (lds_ptr_t)(As + A_BYTES + (RSTEP * j) * ROWB), 16, off, s_b, 0, 0);
       } else {
         const MT* src = (b_row[j] && kvalid) ? b_row[j] + koff : zero;
@@ -604,14 +618,15 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_igemm_glds_kernel
     // them to AGPRs and back every step (128 v_accvgpr moves per 16 MFMAs).
     const bool fire = s < n_fire;
     if (fire) prep_step(s + D);
+    else if (BUF) ext_x = ext_w = 0u;        // past the last prefetch: the pieces below turn into zero fills
+    const bool fire_rt = BUF || fire;        // pointer form keeps the uniform branch around its pieces
     if (EIGHT_WAVES) {
-      // 8-wave tile: the DMA pieces are issued between MFMA groups (the uniform `fire` test is a scalar
-      // branch around each piece); measured 7 % faster than issuing them up front
-      compute_stage(stage, TagTrue{}, fire, (stage + D) % STAGES);
+      // 8-wave tile: the DMA pieces are issued between MFMA groups; measured 7 % faster than issuing them up front
+      compute_stage(stage, TagTrue{}, fire_rt, (stage + D) % STAGES);
     } else {
       // 4-wave tiles: two workgroups share the CU and cover each other's DMA issue, and the prefetch is
       // only one step deep, so the whole next stage is requested first (interleaving measured 10-20 % slower)
-      if (fire) {
+      if (fire_rt) {
 #pragma unroll
         for (int q = 0; q < IPS; ++q) fire_piece(q, (stage + D) % STAGES);
       }
@@ -619,6 +634,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_igemm_glds_kernel
     }
     stage = (stage + 1 == STAGES) ? 0 : stage + 1;
   }
+  if constexpr (BUF) wait_vmcnt<0>();   // the trailing zero-fill pieces must land before the LDS allocation is released
   conv_epilogue<TOut, TM, TN, (TM * TN < 8)>(p, acc, m_blk, n_blk, BN, wm, wn, lane, z);
 #endif
 }
@@ -629,19 +645,6 @@ inline bool conv_buf() {
   if (mode < 0) {
     const char* e = getenv("VT_CONV_BUF");
     mode = (e && strcmp(e, "0") == 0) ? 0 : 1;
-  }
-  return mode == 1;
-}
-
-// K walk order of the descriptor form.  Default tap-major; VT_CONV_KWIN=1 selects the kw-innermost walk:
-// measured on the 27-tap 256->256 conv it cuts the fabric fetch per launch from 28.3 M to 12.3 M x 64 B
-// (L2 misses 477 M -> 224 M) but runs 4-9 % SLOWER (the shifted lines are requested while their fill is
-// still in flight), so it is not the default.
-inline bool conv_kwin() {
-  static int mode = -1;
-  if (mode < 0) {
-    const char* e = getenv("VT_CONV_KWIN");
-    mode = (e && strcmp(e, "1") == 0) ? 1 : 0;
   }
   return mode == 1;
 }
@@ -658,11 +661,11 @@ int launch_variant(const ConvArgs& a_in, int nbatch, hipStream_t stream) {
   a.m_tiles = (a.M + BM - 1) / BM;
   a.n_tiles = (a.Cout + BN - 1) / BN;
   a.nsteps = FAST ? a.ntaps * (a.Cin / BK) : (a.K + BK - 1) / BK;
-  a.kwin = conv_kwin() ? 1 : 0;
   // descriptor gather needs both tensors under 4 GiB (minus the out-of-range marker) and no cache-mode padding
   const unsigned long long xb = (unsigned long long)a.B * a.Ti * a.Hi * a.Wi * a.Cin * sizeof(MT);
   const unsigned long long wb = (unsigned long long)a.Cout * a.ldw * sizeof(MT);
-  const bool buf = conv_buf() && xb < 0xFFFF0000ull && wb < 0xFFFF0000ull && a.tmode != VT_TPAD_CACHE;
+  const bool buf = conv_buf() && xb < 0xFFFF0000ull && wb < 0xFFFF0000ull && a.tmode != VT_TPAD_CACHE &&
+                   a.KH <= 8 && a.KW <= 8;   // the per-row padding mask of the FAST form holds 8 bits per axis
   const void* kern;
   if (buf) {
     a.x_bytes = (unsigned)xb;

@@ -68,6 +68,8 @@ SIGNATURES = {
     "vt_fsq_indices_to_codes": (C.c_int, [_P, _P, C.POINTER(_I32), _I32, _I32, _I64, _P]),
     "vt_fsq_aux_work_floats": (_I64, [C.POINTER(_I32), _I32, _I32, _I64]),
     "vt_fsq_aux_stats": (C.c_int, [_P, C.POINTER(_I32), _I32, _I32, _I64, _F, _P, _P, _P]),
+    "vt_eval_work_floats": (_I64, [_I32, _I32]),
+    "vt_eval_psnr_ssim": (C.c_int, [_P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _P]),
     "vt_gather_frames": (C.c_int, [_P, _P, _I32, _I32, _I64, _I64, _I64, C.POINTER(_I32), _I32, _P]),
 }
 

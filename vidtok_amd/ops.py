@@ -324,3 +324,18 @@ def fsq_consts(levels):
     L.check(lib.vt_fsq_consts(_levels_arr(levels), D, out), "vt_fsq_consts")
     v = list(out)
     return v[:D], v[D:2 * D], v[2 * D:3 * D], v[3 * D:]
+
+
+def eval_psnr_ssim(x, y, raw=True):
+    """Per-frame PSNR / SSIM of a reconstruction y against the input x (both NCTHW fp32 in [-1,1]); with raw=True the
+    clamp and (.+1)/2 post-processing of the reference's eval loop are fused in, with raw=False x, y are [0,1] images.  Returns (psnr [B,T], ssim [B,T])."""
+    lib = L.load()
+    _chk(x, "eval.x"); _chk(y, "eval.y")
+    assert x.dtype == torch.float32 and y.dtype == torch.float32 and x.shape == y.shape and x.dim() == 5
+    B, Cc, T, H, W = x.shape
+    psnr = torch.empty((B, T), dtype=torch.float32, device=x.device)
+    ssim = torch.empty((B, T), dtype=torch.float32, device=x.device)
+    work = torch.empty((lib.vt_eval_work_floats(B, T),), dtype=torch.float32, device=x.device)
+    L.check(lib.vt_eval_psnr_ssim(_ptr(x), _ptr(y), _ptr(psnr), _ptr(ssim), _ptr(work), B, Cc, T, H, W, int(bool(raw)),
+                                  _stream()), "vt_eval_psnr_ssim")
+    return psnr, ssim
