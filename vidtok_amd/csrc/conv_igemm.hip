@@ -59,6 +59,7 @@ struct ConvArgs {
   int out_layout, t_trim;
   int M, K, ntaps, nsteps;
   int m_tiles, n_tiles;
+  int hw_tiles;                // > 0: pixel tiles per frame, tile order (b, hw tile, t) -- see launch_variant
   unsigned x_bytes, w_bytes;   // BUF path: descriptor extents (0 = tensors too large, use pointers)
   long long xs_z, ws_z, ys_z, rs_z;
 };
@@ -315,7 +316,14 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_igemm_glds_kernel
 
   const int tile = xcd_remap(blockIdx.x, p.m_tiles * p.n_tiles);
   const int nt = tile / p.m_tiles;
-  const int mt = tile - nt * p.m_tiles;
+  int mt = tile - nt * p.m_tiles;
+  if (p.hw_tiles > 0) {   // frames innermost: the kt taps of a tile were fetched by its predecessors on this XCD
+    const int per_b = p.hw_tiles * p.To;
+    const int b = mt / per_b;
+    const int r = mt - b * per_b;
+    const int hwt = r / p.To;
+    mt = (b * p.To + (r - hwt * p.To)) * p.hw_tiles + hwt;
+  }
   const int m_blk = mt * BM;
   const int n_blk = nt * BN;
 
@@ -649,6 +657,16 @@ inline bool conv_buf() {
   return mode == 1;
 }
 
+// VT_CONV_TINNER=0 keeps the plain pixel order for temporal convs (A/B runs)
+inline bool conv_tinner() {
+  static int mode = -1;
+  if (mode < 0) {
+    const char* e = getenv("VT_CONV_TINNER");
+    mode = (e && strcmp(e, "0") == 0) ? 0 : 1;
+  }
+  return mode == 1;
+}
+
 template <typename MT, typename TOut, int WAVES_M, int WAVES_N, int TM, int TN, bool FAST>
 int launch_variant(const ConvArgs& a_in, int nbatch, hipStream_t stream) {
   constexpr int ROWB = kRowBytes, STAGES = 2;
@@ -661,6 +679,13 @@ int launch_variant(const ConvArgs& a_in, int nbatch, hipStream_t stream) {
   a.m_tiles = (a.M + BM - 1) / BM;
   a.n_tiles = (a.Cout + BN - 1) / BN;
   a.nsteps = FAST ? a.ntaps * (a.Cin / BK) : (a.K + BK - 1) / BK;
+  // Temporal taps: in pixel order (b,t,h,w) the frames t-1, t-2 a tile reads were last touched one whole frame of
+  // tiles earlier -- far beyond the 4 MiB L2 of its XCD -- so every kt tap came from the fabric again (the k3
+  // temporal conv of the widest level moved 3x its input).  Walking the tiles as (b, hw tile, t) puts the
+  // producers of those lines right before their consumer on the same XCD (xcd_remap keeps the sequence
+  // contiguous): 298 -> 340 TFLOP/s on that layer, +3 % on the 27-tap up-sampler conv (same-run A/B).
+  a.hw_tiles = 0;
+  if (conv_tinner() && a.KT > 1 && a.To > 1 && ((long long)a.Ho * a.Wo) % BM == 0) a.hw_tiles = (int)(((long long)a.Ho * a.Wo) / BM);
   // descriptor gather needs both tensors under 4 GiB (minus the out-of-range marker) and no cache-mode padding
   const unsigned long long xb = (unsigned long long)a.B * a.Ti * a.Hi * a.Wi * a.Cin * sizeof(MT);
   const unsigned long long wb = (unsigned long long)a.Cout * a.ldw * sizeof(MT);
