@@ -1,0 +1,107 @@
+// Pieces shared by the convolution kernels (conv_igemm.hip, conv_stream.hip).
+#pragma once
+#include <stdlib.h>
+
+#include "common.h"
+
+namespace {
+
+constexpr int kRowBytes = 128;     // bytes of K per tile row per step
+
+struct ConvArgs {
+  const char* x;
+  const char* w;
+  const float* bias;
+  char* y;
+  const char* res;
+  const char* cache;
+  const float* mix_factor;
+  int B, Ti, Hi, Wi, Cin;
+  int To, Ho, Wo, Cout;
+  int ldw, ldy;
+  int KT, KH, KW;
+  int st, sh, sw;
+  int pt, ph, pw;
+  int tmode, ncache;
+  int ups_t, ups_s;
+  int res_mode, res_tshift, Tr, ldr;
+  int out_layout, t_trim;
+  int M, K, ntaps, nsteps;
+  int m_tiles, n_tiles;
+  int hw_tiles;                // > 0: pixel tiles per frame, tile order (b, hw tile, t) -- see launch_variant
+  unsigned x_bytes, w_bytes;   // BUF path: descriptor extents (0 = tensors too large, use pointers)
+  unsigned y_bytes, r_bytes;   // conv_stream: extents of the output / residual descriptors
+  long long xs_z, ws_z, ys_z, rs_z;
+};
+
+template <typename MT>
+__device__ __forceinline__ void mma_step(const u32x4& wfrag, const u32x4& xfrag, f32x16& acc);
+
+template <>
+__device__ __forceinline__ void mma_step<bf16_t>(const u32x4& wfrag, const u32x4& xfrag, f32x16& acc) {
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wfrag),
+                                                __builtin_bit_cast(bf16x8, xfrag), acc, 0, 0, 0);
+}
+template <>
+__device__ __forceinline__ void mma_step<float>(const u32x4& wfrag, const u32x4& xfrag, f32x16& acc) {
+#pragma unroll
+  for (int e = 0; e < 4; ++e)
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(wfrag[e]), __uint_as_float(xfrag[e]),
+                                               acc, 0, 0, 0);
+}
+
+// XCD-aware bijective remap of the linear block id (MI355X guide T1): block b runs on XCD b%8;
+// give every XCD a contiguous chunk of the tile sequence.
+__device__ __forceinline__ int xcd_remap(int bid, int nblk) {
+  const int xcd = bid & 7, loc = bid >> 3;
+  const int q = nblk >> 3, r = nblk & 7;
+  const int start = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return start + loc;
+}
+
+template <typename TOut>
+struct Quad;   // 4 consecutive channels as stored
+template <>
+struct Quad<float> {
+  f32x4 v;
+  __device__ __forceinline__ float get(int e) const { return v[e]; }
+};
+template <>
+struct Quad<bf16_t> {
+  u32x2 v;
+  __device__ __forceinline__ float get(int e) const {
+    const uint32_t w = v[e >> 1];
+    return bf16_bits_to_f32((e & 1) ? (w >> 16) : (w & 0xffffu));
+  }
+};
+template <typename TOut>
+__device__ __forceinline__ void store_quad(TOut* p, const float (&v)[4]);
+template <>
+__device__ __forceinline__ void store_quad<float>(float* p, const float (&v)[4]) {
+  f32x4 t;
+  t[0] = v[0]; t[1] = v[1]; t[2] = v[2]; t[3] = v[3];
+  *reinterpret_cast<f32x4*>(p) = t;
+}
+template <>
+__device__ __forceinline__ void store_quad<bf16_t>(bf16_t* p, const float (&v)[4]) {
+  u32x2 t;
+  t[0] = f32_to_bf16_bits(v[0]) | (f32_to_bf16_bits(v[1]) << 16);
+  t[1] = f32_to_bf16_bits(v[2]) | (f32_to_bf16_bits(v[3]) << 16);
+  *reinterpret_cast<u32x2*>(p) = t;
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+struct TagTrue { [[maybe_unused]] static constexpr bool value = true; };
+struct TagFalse { [[maybe_unused]] static constexpr bool value = false; };
+
+// environment switch helper for same-run A/B measurements: value of `name` or `dflt`
+inline int env_int(const char* name, int dflt) {
+  const char* e = getenv(name);
+  return e ? atoi(e) : dflt;
+}
+
+}  // namespace

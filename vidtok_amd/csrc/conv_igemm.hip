@@ -31,63 +31,13 @@
 // instruction-issue bound, not DMA-latency bound), 256x128 tiles with 8 or 4 waves (slower), a persistent
 // tile loop (40 % slower: the co-resident workgroups fall into lockstep), LayerNorm fused into the
 // epilogue (+1.6 ms per conv vs 0.5 ms for the separate kernel).
-#include <stdlib.h>
+#include <type_traits>
 
-#include "common.h"
+#include "conv_common.h"
+
+int vt_conv_stream_launch(const void* args, int dtype_code, hipStream_t stream);   // conv_stream.hip
 
 namespace {
-
-constexpr int kRowBytes = 128;     // bytes of K per tile row per step
-
-struct ConvArgs {
-  const char* x;
-  const char* w;
-  const float* bias;
-  char* y;
-  const char* res;
-  const char* cache;
-  const float* mix_factor;
-  int B, Ti, Hi, Wi, Cin;
-  int To, Ho, Wo, Cout;
-  int ldw, ldy;
-  int KT, KH, KW;
-  int st, sh, sw;
-  int pt, ph, pw;
-  int tmode, ncache;
-  int ups_t, ups_s;
-  int res_mode, res_tshift, Tr, ldr;
-  int out_layout, t_trim;
-  int M, K, ntaps, nsteps;
-  int m_tiles, n_tiles;
-  int hw_tiles;                // > 0: pixel tiles per frame, tile order (b, hw tile, t) -- see launch_variant
-  unsigned x_bytes, w_bytes;   // BUF path: descriptor extents (0 = tensors too large, use pointers)
-  long long xs_z, ws_z, ys_z, rs_z;
-};
-
-template <typename MT>
-__device__ __forceinline__ void mma_step(const u32x4& wfrag, const u32x4& xfrag, f32x16& acc);
-
-template <>
-__device__ __forceinline__ void mma_step<bf16_t>(const u32x4& wfrag, const u32x4& xfrag, f32x16& acc) {
-  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wfrag),
-                                                __builtin_bit_cast(bf16x8, xfrag), acc, 0, 0, 0);
-}
-template <>
-__device__ __forceinline__ void mma_step<float>(const u32x4& wfrag, const u32x4& xfrag, f32x16& acc) {
-#pragma unroll
-  for (int e = 0; e < 4; ++e)
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(wfrag[e]), __uint_as_float(xfrag[e]),
-                                               acc, 0, 0, 0);
-}
-
-// XCD-aware bijective remap of the linear block id (MI355X guide T1): block b runs on XCD b%8;
-// give every XCD a contiguous chunk of the tile sequence.
-__device__ __forceinline__ int xcd_remap(int bid, int nblk) {
-  const int xcd = bid & 7, loc = bid >> 3;
-  const int q = nblk >> 3, r = nblk & 7;
-  const int start = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
-  return start + loc;
-}
 
 // Epilogue shared by both staging variants: + bias, + residual / alpha-mix, dtype conversion, NDHWC
 // vector store (lane = one pixel, 4 consecutive channels per accumulator quad) or NCTHW fp32 store.
@@ -96,37 +46,6 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
 // back to back, then the arithmetic, then vector stores -- one memory latency per tile; the general
 // path (ragged channel tails, NCTHW, narrow outputs) does the same per 32-pixel row group with
 // clamped scalar loads.  (The first version branched and waited per element: ~26 us per tile.)
-template <typename TOut>
-struct Quad;   // 4 consecutive channels as stored
-template <>
-struct Quad<float> {
-  f32x4 v;
-  __device__ __forceinline__ float get(int e) const { return v[e]; }
-};
-template <>
-struct Quad<bf16_t> {
-  u32x2 v;
-  __device__ __forceinline__ float get(int e) const {
-    const uint32_t w = v[e >> 1];
-    return bf16_bits_to_f32((e & 1) ? (w >> 16) : (w & 0xffffu));
-  }
-};
-template <typename TOut>
-__device__ __forceinline__ void store_quad(TOut* p, const float (&v)[4]);
-template <>
-__device__ __forceinline__ void store_quad<float>(float* p, const float (&v)[4]) {
-  f32x4 t;
-  t[0] = v[0]; t[1] = v[1]; t[2] = v[2]; t[3] = v[3];
-  *reinterpret_cast<f32x4*>(p) = t;
-}
-template <>
-__device__ __forceinline__ void store_quad<bf16_t>(bf16_t* p, const float (&v)[4]) {
-  u32x2 t;
-  t[0] = f32_to_bf16_bits(v[0]) | (f32_to_bf16_bits(v[1]) << 16);
-  t[1] = f32_to_bf16_bits(v[2]) | (f32_to_bf16_bits(v[3]) << 16);
-  *reinterpret_cast<u32x2*>(p) = t;
-}
-
 template <typename TOut, int TM, int TN, bool GENERAL = true>
 __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[TN][TM], int m_blk, int n_blk, int bn_tile,
                                               int wm, int wn, int lane, long long z) {
@@ -265,13 +184,6 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[T
 // ------------------------------------------------------------------------------------------------
 [[maybe_unused]] __device__ u32x4 g_zero_page[8];   // 128 B of zeros (static device memory, zero-initialised)
 
-struct TagTrue { [[maybe_unused]] static constexpr bool value = true; };
-struct TagFalse { [[maybe_unused]] static constexpr bool value = false; };
-
-template <int N>
-__device__ __forceinline__ void wait_vmcnt() {
-  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
-}
 
 // ROWB   bytes of K per tile row and pipeline step (128 or 64): BK = ROWB / sizeof(MT)
 // STAGES LDS ring depth; STAGES-1 steps of DMA are kept in flight (counted vmcnt + raw s_barrier:
@@ -692,6 +604,22 @@ int launch_variant(const ConvArgs& a_in, int nbatch, hipStream_t stream) {
   const bool buf = conv_buf() && xb < 0xFFFF0000ull && wb < 0xFFFF0000ull && a.tmode != VT_TPAD_CACHE &&
                    a.KH <= 8 && a.KW <= 8;   // the per-row padding mask of the FAST form holds 8 bits per axis
   const void* kern;
+  if constexpr (WAVES_M == 2 && WAVES_N == 2 && TM == 2 && TN == 2 && FAST) {
+    // short tiles with many of them: the persistent kernel with the deferred epilogue (conv_stream.hip)
+    const bool plain_res = a.res_mode == VT_RES_NONE ||
+                           (a.res_mode == VT_RES_ADD && (a.ldr & 3) == 0 && a.res_tshift == 0 && a.Tr == a.To);
+    if (buf && env_int("VT_CONV_STREAM", 0) != 0 && nbatch == 1 && a.Cout % BN == 0 && a.M % BM == 0 &&
+        a.out_layout == VT_NDHWC && (a.ldy & 3) == 0 && plain_res && a.nsteps >= 4 && a.Cout <= 1024 &&
+        (long long)a.m_tiles * a.n_tiles >= 1024 && (unsigned long long)a.M * a.ldy * sizeof(TOut) < 0xFFFF0000ull &&
+        (unsigned long long)a.M * a.ldr * sizeof(TOut) < 0xFFFF0000ull) {
+      a.x_bytes = (unsigned)xb;
+      a.w_bytes = (unsigned)wb;
+      a.y_bytes = (unsigned)((unsigned long long)a.M * a.ldy * sizeof(TOut));
+      a.r_bytes = (unsigned)((unsigned long long)a.M * a.ldr * sizeof(TOut));
+      const int code = std::is_same<MT, float>::value ? 0 : (std::is_same<TOut, float>::value ? 1 : 2);
+      return vt_conv_stream_launch(&a, code, stream);
+    }
+  }
   if (buf) {
     a.x_bytes = (unsigned)xb;
     a.w_bytes = (unsigned)wb;
