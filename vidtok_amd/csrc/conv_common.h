@@ -28,6 +28,7 @@ struct ConvArgs {
   int out_layout, t_trim;
   int M, K, ntaps, nsteps;
   int m_tiles, n_tiles;
+  int lds_epi;                 // 128 x 128 tile: epilogue transposed through the LDS (coalesced rows)
   int hw_tiles;                // > 0: pixel tiles per frame, tile order (b, hw tile, t) -- see launch_variant
   unsigned x_bytes, w_bytes;   // BUF path: descriptor extents (0 = tensors too large, use pointers)
   unsigned y_bytes, r_bytes;   // conv_stream: extents of the output / residual descriptors

@@ -169,6 +169,88 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[T
   }
 }
 
+// Coalesced epilogue of the 128 x 128 tile (4 waves).  In the MFMA layout a lane owns one pixel and 4 consecutive
+// channels per quad, so a wave-level store touches 32 pixel rows with 8 B (bf16) each -- 64 separate 8-B L2
+// transactions per instruction, and the residual read likewise.  Measured on the widest level (same-run, stores /
+// residual switched off one by one): the 2.7 GB of epilogue traffic of a 128->128 conv cost 0.5-0.6 ms of a 2.5 ms
+// launch and did not overlap with the co-resident workgroup's K loop: the L2 path is transaction-bound, not
+// byte-bound.  Here the tile (+ bias) is transposed through the LDS the K loop no longer needs (128 x 128 fp32 =
+// the 64 KiB of the two stages): every lane then handles 4 consecutive channels of a pixel row with 32 lanes per
+// 128 channels, so a wave instruction covers whole 128-B lines (2 rows x 256 B bf16, 1 row x 512 B fp32).
+//   LDS layout: T[pixel][32 chunks of 4 floats], chunk index XOR (pixel & 31): the 8 lanes a ds_write_b128 services
+//   together hold 8 different pixels of one chunk -> 8 different columns; a ds_read_b128 group reads 16 different
+//   chunks of one row -> 16 different bank quads.
+template <typename TOut>
+__device__ __forceinline__ void conv_epilogue_lds128(const ConvArgs& p, f32x16 (&acc)[2][2], int m_blk, int n_blk, int wm,
+                                                     int wn, int lane, int tid, char* smem, long long z) {
+  TOut* __restrict__ yg = reinterpret_cast<TOut*>(p.y) + z * p.ys_z;
+  const TOut* __restrict__ rg = reinterpret_cast<const TOut*>(p.res) + z * p.rs_z;
+  float* T = reinterpret_cast<float*>(smem);
+  const bool has_res = p.res_mode != VT_RES_NONE;
+  float alpha = 0.0f;
+  if (p.res_mode == VT_RES_MIX) alpha = 1.0f / (1.0f + __expf(-p.mix_factor[0]));
+  constexpr int NT = 16;                      // (row, chunk) tasks per lane: 128 rows x 32 chunks / 256 lanes
+  const int chunk_j = tid & 31;               // this lane's chunk: channels 4j .. 4j+3 of the tile
+  const int row0 = tid >> 5;                  // rows row0 + 8*it
+  // residual quads first: their latency rides under the transposition
+  Quad<TOut> rq[NT];
+  long long mres[NT];
+  if (has_res) {
+    const bool remap = p.res_tshift != 0 || p.Tr != p.To;   // uniform
+    const long long HWo = (long long)p.Ho * p.Wo;
+#pragma unroll
+    for (int it = 0; it < NT; ++it) {
+      long long m = m_blk + row0 + 8 * it;
+      if (remap) {
+        const long long hw = m % HWo;
+        const long long r = m / HWo;
+        const int to = (int)(r % p.To);
+        const int bb = (int)(r / p.To);
+        m = ((long long)bb * p.Tr + (to >> p.res_tshift)) * HWo + hw;
+      }
+      mres[it] = m;
+    }
+#pragma unroll
+    for (int it = 0; it < NT; ++it)
+      rq[it].v = *reinterpret_cast<const decltype(rq[it].v)*>(rg + mres[it] * p.ldr + n_blk + 4 * chunk_j);
+  }
+  __syncthreads();                            // every wave has finished reading the last stage
+  {
+    const int h = lane >> 5;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int c = wn * 64 + 32 * a + 8 * g + 4 * h;        // first channel of the quad inside the tile
+        f32x4 bq;
+        if (p.bias) bq = *reinterpret_cast<const f32x4*>(p.bias + n_blk + c);
+        else bq[0] = bq[1] = bq[2] = bq[3] = 0.0f;
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+          const int prow = (wm * 2 + b) * 32 + (lane & 31);
+          f32x4 v;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = acc[a][b][4 * g + e] + bq[e];
+          *reinterpret_cast<f32x4*>(T + prow * 128 + (((c >> 2) ^ (prow & 31)) << 2)) = v;
+        }
+      }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int it = 0; it < NT; ++it) {
+    const int row = row0 + 8 * it;
+    const f32x4 t = *reinterpret_cast<const f32x4*>(T + row * 128 + ((chunk_j ^ (row & 31)) << 2));
+    float v[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      v[e] = t[e];
+      if (p.res_mode == VT_RES_ADD) v[e] = rq[it].get(e) + v[e];
+      if (p.res_mode == VT_RES_MIX) v[e] = alpha * rq[it].get(e) + (1.0f - alpha) * v[e];
+    }
+    store_quad<TOut>(yg + (long long)(m_blk + row) * p.ldy + n_blk + 4 * chunk_j, v);
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // The operand tiles go global -> LDS with LDS-DMA (no VGPR round trip, no ds_write pass -- a
 // register-staged first version spent ~415 LDS cycles per K step on ds_write_b128 against 512 MFMA cycles).  The DMA writes each wave's 64
@@ -194,7 +276,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[T
 //        short-K layers is instruction-issue bound: ~13 VALU per MFMA with pointers).  Needs the tensors
 //        below 4 GiB and no cache-mode time padding; otherwise the pointer form is used.
 template <typename MT, typename TOut, int WAVES_M, int WAVES_N, int TM, int TN, bool FAST, int ROWB, int STAGES, bool BUF>
-__global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_igemm_glds_kernel(const ConvArgs p) {
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_igemm_glds_kernel(const ConvArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)   // device pass only: the host pass needs just the launch stub (buffer-descriptor types are device-only)
   constexpr int THREADS = 64 * WAVES_M * WAVES_N;   // 4 waves (128x128, 256x32/64 tiles) or 8 waves (256x256)
   constexpr int NS = ROWB / 16;                     // 16-B slots per tile row
@@ -555,6 +637,14 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_igemm_glds_kernel
     stage = (stage + 1 == STAGES) ? 0 : stage + 1;
   }
   if constexpr (BUF) wait_vmcnt<0>();   // the trailing zero-fill pieces must land before the LDS allocation is released
+  if constexpr (WAVES_M == 2 && WAVES_N == 2 && TM == 2 && TN == 2 && STAGES * STAGE_BYTES >= 128 * 128 * 4) {
+    // full tile, NDHWC, 4-aligned strides (uniform): the coalesced epilogue through the LDS
+    if (p.lds_epi && m_blk + BM <= p.M && n_blk + BN <= p.Cout) {
+      if constexpr (!BUF) wait_vmcnt<0>();
+      conv_epilogue_lds128<TOut>(p, acc, m_blk, n_blk, wm, wn, lane, tid, smem, z);
+      return;
+    }
+  }
   conv_epilogue<TOut, TM, TN, (TM * TN < 8)>(p, acc, m_blk, n_blk, BN, wm, wn, lane, z);
 #endif
 }
@@ -596,6 +686,8 @@ int launch_variant(const ConvArgs& a_in, int nbatch, hipStream_t stream) {
   // temporal conv of the widest level moved 3x its input).  Walking the tiles as (b, hw tile, t) puts the
   // producers of those lines right before their consumer on the same XCD (xcd_remap keeps the sequence
   // contiguous): 298 -> 340 TFLOP/s on that layer, +3 % on the 27-tap up-sampler conv (same-run A/B).
+  a.lds_epi = (env_int("VT_CONV_LDSEPI", 1) != 0 && a.out_layout == VT_NDHWC && (a.ldy & 3) == 0 &&
+               (a.res_mode == VT_RES_NONE || (a.ldr & 3) == 0)) ? 1 : 0;
   a.hw_tiles = 0;
   if (conv_tinner() && a.KT > 1 && a.To > 1 && ((long long)a.Ho * a.Wo) % BM == 0) a.hw_tiles = (int)(((long long)a.Ho * a.Wo) / BM);
   // descriptor gather needs both tensors under 4 GiB (minus the out-of-range marker) and no cache-mode padding
