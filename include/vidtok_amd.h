@@ -86,6 +86,12 @@ int vt_conv_max_lds_bytes(void);
  * tv beyond the end reads 0.
  * Weights are pre-packed row-major [Cout][ldw], k = ((kt*KH+kh)*KW+kw)*Cin + c (see
  * vidtok_amd/packing.py), in the arithmetic dtype.
+ * ln_mode != 0 additionally emits ln_out = [SiLU](LayerNorm_Cout(result) * gamma + beta), the norm that follows the
+ * convolution inside the residual blocks (norm2 + nonlinearity after conv1, model_3dcausal.py:321-323,405-407,
+ * 482-484).  When the tile spans the channel row (Cout = 128) the statistics are taken from the fp32 result inside
+ * the epilogue and, with ln_keep_y = 0, y is never written: one activation write instead of write + read + write.
+ * Otherwise the library runs the convolution into y and vt_layernorm_act on it -- same contract, y must always be
+ * a full-size buffer.  NDHWC output, nbatch = 1 only.
  * ---------------------------------------------------------------------------------------- */
 typedef struct vt_conv_desc {
   const void* x;            /* input  [B][Ti][Hi][Wi][Cin]     (dtype)                        */
@@ -95,6 +101,9 @@ typedef struct vt_conv_desc {
   const void* res;          /* residual / mix operand, out_dtype, [B][Tr][Ho][Wo][ldr] or NULL */
   const void* cache;        /* time cache [B][ncache][Hi][Wi][Cin] (dtype) or NULL             */
   const float* mix_factor;  /* device scalar; alpha = sigmoid(*mix_factor) for VT_RES_MIX      */
+  const float* ln_gamma;    /* fused LayerNorm of the result (ln_mode != 0): affine, fp32 [Cout]  */
+  const float* ln_beta;
+  void* ln_out;             /* normalised (+SiLU) result, out_dtype, NDHWC [M][ldn]            */
   int32_t B, Ti, Hi, Wi, Cin;
   int32_t To, Ho, Wo, Cout;
   int32_t ldw;              /* row stride of w in elements (>= KT*KH*KW*Cin, multiple of 16 B) */
@@ -112,6 +121,10 @@ typedef struct vt_conv_desc {
   int32_t dtype;            /* arithmetic / input / weight dtype                               */
   int32_t out_dtype;        /* dtype or VT_F32                                                 */
   int32_t nbatch;           /* >=1: independent problems along grid.z                          */
+  int32_t ln_mode;          /* 0 none, 1 LayerNorm over Cout, 2 LayerNorm + SiLU -> ln_out     */
+  int32_t ln_keep_y;        /* 0: only ln_out is needed; y is then scratch (may stay unwritten) */
+  int32_t ldn;              /* channel stride of ln_out                                        */
+  float ln_eps;
   int64_t xs_z, ws_z, ys_z, rs_z;   /* element strides between problems                       */
 } vt_conv_desc;
 

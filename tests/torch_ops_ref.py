@@ -20,7 +20,8 @@ def _round_like(t, dtype):
 
 
 def conv(x, w, bias, geom, *, cout, out_dtype=None, tmode=L.VT_TPAD_ZERO, cache=None, res=None,
-         res_mode=L.VT_RES_NONE, res_tshift=0, mix_factor=None, out_layout=L.VT_NDHWC, t_trim=0, ldy=None):
+         res_mode=L.VT_RES_NONE, res_tshift=0, mix_factor=None, out_layout=L.VT_NDHWC, t_trim=0, ldy=None,
+         ln=None, ln_keep_y=True):
     B, Ti, Hi, Wi, Cin = x.shape
     out_dtype = out_dtype or x.dtype
     xp = x.float().permute(0, 4, 1, 2, 3)  # NCTHW
@@ -55,7 +56,15 @@ def conv(x, w, bias, geom, *, cout, out_dtype=None, tmode=L.VT_TPAD_ZERO, cache=
     ldy = ldy or pad_channels(cout)
     out = torch.zeros((B, To, y.shape[3], y.shape[4], ldy), dtype=out_dtype, device=x.device)
     out[..., :cout] = y.permute(0, 2, 3, 4, 1).to(out_dtype)
-    return out
+    if ln is None:
+        return out
+    gamma, beta, eps, silu = ln          # statistics of the fp32 result (the fused kernel normalises before rounding)
+    nrm = F.layer_norm(y.permute(0, 2, 3, 4, 1), (cout,), gamma.float()[:cout], beta.float()[:cout], eps)
+    if silu:
+        nrm = nrm * torch.sigmoid(nrm)
+    n = torch.zeros_like(out)
+    n[..., :cout] = nrm.to(out_dtype)
+    return (out, n) if ln_keep_y else n
 
 
 def gemm_nt(a, b, *, out_dtype=None, bias=None, ld_out=None):

@@ -16,6 +16,9 @@ struct ConvArgs {
   const char* res;
   const char* cache;
   const float* mix_factor;
+  const float* ln_gamma;
+  const float* ln_beta;
+  char* ln_out;
   int B, Ti, Hi, Wi, Cin;
   int To, Ho, Wo, Cout;
   int ldw, ldy;
@@ -28,6 +31,8 @@ struct ConvArgs {
   int out_layout, t_trim;
   int M, K, ntaps, nsteps;
   int m_tiles, n_tiles;
+  int ln_mode, ln_keep_y, ldn;  // fused LayerNorm of the result (only set when the lds128 epilogue will run)
+  float ln_eps;
   int lds_epi;                 // 128 x 128 tile: epilogue transposed through the LDS (coalesced rows)
   int hw_tiles;                // > 0: pixel tiles per frame, tile order (b, hw tile, t) -- see launch_variant
   unsigned x_bytes, w_bytes;   // BUF path: descriptor extents (0 = tensors too large, use pointers)

@@ -236,6 +236,13 @@ __device__ __forceinline__ void conv_epilogue_lds128(const ConvArgs& p, f32x16 (
       }
   }
   __syncthreads();
+  // fused LayerNorm (+SiLU) of the finished rows: the 32 lanes of a row hold its 128 channels (launcher: Cout = 128)
+  f32x4 lg, lb;
+  TOut* __restrict__ ng = reinterpret_cast<TOut*>(p.ln_out);
+  if (p.ln_mode) {
+    lg = *reinterpret_cast<const f32x4*>(p.ln_gamma + 4 * chunk_j);
+    lb = *reinterpret_cast<const f32x4*>(p.ln_beta + 4 * chunk_j);
+  }
 #pragma unroll
   for (int it = 0; it < NT; ++it) {
     const int row = row0 + 8 * it;
@@ -247,7 +254,24 @@ __device__ __forceinline__ void conv_epilogue_lds128(const ConvArgs& p, f32x16 (
       if (p.res_mode == VT_RES_ADD) v[e] = rq[it].get(e) + v[e];
       if (p.res_mode == VT_RES_MIX) v[e] = alpha * rq[it].get(e) + (1.0f - alpha) * v[e];
     }
-    store_quad<TOut>(yg + (long long)(m_blk + row) * p.ldy + n_blk + 4 * chunk_j, v);
+    if (!p.ln_mode || p.ln_keep_y) store_quad<TOut>(yg + (long long)(m_blk + row) * p.ldy + n_blk + 4 * chunk_j, v);
+    if (p.ln_mode) {   // uniform; same two-pass statistics as layernorm_act_kernel, taken before the rounding to TOut
+      const float mean = group_sum_dpp<32>((v[0] + v[1]) + (v[2] + v[3])) * (1.0f / 128.0f);
+      float d[4], q = 0.f;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        d[e] = v[e] - mean;
+        q += d[e] * d[e];
+      }
+      const float rstd = __builtin_amdgcn_rsqf(group_sum_dpp<32>(q) * (1.0f / 128.0f) + p.ln_eps);
+      float o[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float u = d[e] * rstd * lg[e] + lb[e];
+        o[e] = (p.ln_mode == 2) ? silu_fast(u) : u;
+      }
+      store_quad<TOut>(ng + (long long)(m_blk + row) * p.ldn + 4 * chunk_j, o);
+    }
   }
 }
 
@@ -700,7 +724,7 @@ int launch_variant(const ConvArgs& a_in, int nbatch, hipStream_t stream) {
     // short tiles with many of them: the persistent kernel with the deferred epilogue (conv_stream.hip)
     const bool plain_res = a.res_mode == VT_RES_NONE ||
                            (a.res_mode == VT_RES_ADD && (a.ldr & 3) == 0 && a.res_tshift == 0 && a.Tr == a.To);
-    if (buf && env_int("VT_CONV_STREAM", 0) != 0 && nbatch == 1 && a.Cout % BN == 0 && a.M % BM == 0 &&
+    if (buf && env_int("VT_CONV_STREAM", 0) != 0 && nbatch == 1 && a.ln_mode == 0 && a.Cout % BN == 0 && a.M % BM == 0 &&
         a.out_layout == VT_NDHWC && (a.ldy & 3) == 0 && plain_res && a.nsteps >= 4 && a.Cout <= 1024 &&
         (long long)a.m_tiles * a.n_tiles >= 1024 && (unsigned long long)a.M * a.ldy * sizeof(TOut) < 0xFFFF0000ull &&
         (unsigned long long)a.M * a.ldr * sizeof(TOut) < 0xFFFF0000ull) {
@@ -798,6 +822,11 @@ extern "C" int vt_conv(const vt_conv_desc* d, vt_stream stream_) {
   const long long M = (long long)d->B * d->To * d->Ho * d->Wo;
   VT_CHECK_ARG(M < (1ll << 31), "vt_conv: M too large");
   const int nbatch = d->nbatch > 0 ? d->nbatch : 1;
+  if (d->ln_mode != 0) {
+    VT_CHECK_ARG(d->ln_mode == 1 || d->ln_mode == 2, "vt_conv: ln_mode %d", d->ln_mode);
+    VT_CHECK_ARG(d->ln_gamma && d->ln_beta && d->ln_out, "vt_conv: fused LayerNorm needs gamma, beta and ln_out");
+    VT_CHECK_ARG(d->out_layout == VT_NDHWC && nbatch == 1 && d->ldn >= d->Cout, "vt_conv: fused LayerNorm: NDHWC, nbatch 1, ldn >= Cout");
+  }
 
   ConvArgs a;
   memset(&a, 0, sizeof(a));
@@ -818,7 +847,20 @@ extern "C" int vt_conv(const vt_conv_desc* d, vt_stream stream_) {
   a.M = (int)M; a.ntaps = d->KT * d->KH * d->KW; a.K = a.ntaps * d->Cin;
   a.xs_z = d->xs_z; a.ws_z = d->ws_z; a.ys_z = d->ys_z; a.rs_z = d->rs_z;
 
-  if (d->dtype == VT_F32) return dispatch_tile<float, float>(a, nbatch, stream);
-  if (d->out_dtype == VT_F32) return dispatch_tile<bf16_t, float>(a, nbatch, stream);
-  return dispatch_tile<bf16_t, bf16_t>(a, nbatch, stream);
+  // LayerNorm inside the epilogue: the 128 x 128 tile with the LDS epilogue on full tiles spanning the channel row
+  const bool ln_fused = d->ln_mode != 0 && d->Cout == 128 && M % 128 == 0 && (d->ldy & 3) == 0 && (d->ldn & 3) == 0 &&
+                        (d->res_mode == VT_RES_NONE || (d->ldr & 3) == 0) && env_int("VT_CONV_LDSEPI", 1) != 0 &&
+                        env_int("VT_CONV_FUSE_LN", 1) != 0;
+  if (ln_fused) {
+    a.ln_gamma = d->ln_gamma; a.ln_beta = d->ln_beta; a.ln_out = (char*)d->ln_out;
+    a.ln_mode = d->ln_mode; a.ln_keep_y = d->ln_keep_y; a.ldn = d->ldn; a.ln_eps = d->ln_eps;
+  }
+  int rc;
+  if (d->dtype == VT_F32) rc = dispatch_tile<float, float>(a, nbatch, stream);
+  else if (d->out_dtype == VT_F32) rc = dispatch_tile<bf16_t, float>(a, nbatch, stream);
+  else rc = dispatch_tile<bf16_t, bf16_t>(a, nbatch, stream);
+  if (rc != VT_OK || d->ln_mode == 0 || ln_fused) return rc;
+  // not fusable here: the same contract in two launches
+  return vt_layernorm_act(d->y, d->out_dtype, d->ldy, d->ln_out, d->out_dtype, d->ldn, d->ln_gamma, d->ln_beta, M, d->Cout,
+                          d->ln_eps, d->ln_mode == 2 ? 1 : 0, stream_);
 }

@@ -29,7 +29,7 @@ class ConvDesc(C.Structure):
     """Field-for-field mirror of `vt_conv_desc` (include/vidtok_amd.h)."""
 
     _fields_ = (
-        [(n, C.c_void_p) for n in ("x", "w", "bias", "y", "res", "cache", "mix_factor")]
+        [(n, C.c_void_p) for n in ("x", "w", "bias", "y", "res", "cache", "mix_factor", "ln_gamma", "ln_beta", "ln_out")]
         + [(n, C.c_int32) for n in (
             "B", "Ti", "Hi", "Wi", "Cin",
             "To", "Ho", "Wo", "Cout",
@@ -43,7 +43,9 @@ class ConvDesc(C.Structure):
             "out_layout", "t_trim",
             "dtype", "out_dtype",
             "nbatch",
+            "ln_mode", "ln_keep_y", "ldn",
         )]
+        + [("ln_eps", C.c_float)]
         + [(n, C.c_int64) for n in ("xs_z", "ws_z", "ys_z", "rs_z")]
     )
 

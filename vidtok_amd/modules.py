@@ -48,6 +48,11 @@ class LayerNorm(nn.Module):
         g, b = self.affine()
         return ops.layernorm_act(x, g, b, silu=silu, eps=self.norm.eps, out_dtype=dt)
 
+    def fused(self, silu):
+        """(gamma, beta, eps, silu) for the `ln=` argument of ops.conv: this norm applied by the producing conv."""
+        g, b = self.affine()
+        return (g, b, self.norm.eps, silu)
+
 
 def Normalize(in_channels, norm_type="layernorm"):
     _check_norm(norm_type)
@@ -289,8 +294,8 @@ class ResnetBlock(nn.Module):
 
     def run(self, x, dt):
         h = self.norm1.apply_ndhwc(x, True, dt)
-        h = _Conv2dHolder.run(self.conv1, self._p1, h, dt, _G3x3)
-        h = self.norm2.apply_ndhwc(h, True, dt)
+        # conv1's result is only ever seen through norm2 + SiLU: the conv emits that directly
+        h = _Conv2dHolder.run(self.conv1, self._p1, h, dt, _G3x3, ln=self.norm2.fused(True), ln_keep_y=False)
         if self.in_channels != self.out_channels:
             x = _Conv2dHolder.run(self.nin_shortcut, self._p3, x, dt, _G1x1)
         return _Conv2dHolder.run(self.conv2, self._p2, h, dt, _G3x3, res=x, res_mode=L.VT_RES_ADD)
@@ -314,8 +319,7 @@ class ResnetCausalBlock(nn.Module):
 
     def run(self, x, dt):
         h = self.norm1.apply_ndhwc(x, True, dt)
-        h = self.conv1.run(h, dt)
-        h = self.norm2.apply_ndhwc(h, True, dt)
+        h = self.conv1.run(h, dt, ln=self.norm2.fused(True), ln_keep_y=False)
         if self.in_channels != self.out_channels:
             x = self.nin_shortcut.run(x, dt)
         return self.conv2.run(h, dt, res=x, res_mode=L.VT_RES_ADD)
@@ -344,8 +348,7 @@ class ResnetCausalBlock1D(nn.Module):
 
     def run(self, x, dt):
         h = self.norm1.apply_ndhwc(x, True, dt)
-        h = self.conv1.run(h, dt)
-        h = self.norm2.apply_ndhwc(h, True, dt)
+        h = self.conv1.run(h, dt, ln=self.norm2.fused(True), ln_keep_y=False)
         if self.in_channels != self.out_channels:
             x = self.nin_shortcut.run(x, dt)
         return self.conv2.run(h, dt, res=x, res_mode=L.VT_RES_ADD)

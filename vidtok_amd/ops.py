@@ -81,8 +81,10 @@ class ConvGeom:
 
 def conv(x, w, bias, geom: ConvGeom, *, cout: int, out_dtype=None, tmode=L.VT_TPAD_ZERO, cache=None,
          res=None, res_mode=L.VT_RES_NONE, res_tshift=0, mix_factor=None, out_layout=L.VT_NDHWC,
-         t_trim=0, ldy=None):
-    """y = conv(x) (+bias) (+res | alpha-mix); x [B,Ti,Hi,Wi,Cin], w packed [cout, ldw]."""
+         t_trim=0, ldy=None, ln=None, ln_keep_y=True):
+    """y = conv(x) (+bias) (+res | alpha-mix); x [B,Ti,Hi,Wi,Cin], w packed [cout, ldw].
+    ln = (gamma, beta, eps, silu) additionally returns n = [SiLU](LayerNorm(y)): (y, n), or just n with
+    ln_keep_y=False (y is then scratch: the fused kernel never writes it)."""
     lib = L.load()
     _chk(x, "conv.x"); _chk(w, "conv.w")
     B, Ti, Hi, Wi, Cin = x.shape
@@ -128,8 +130,18 @@ def conv(x, w, bias, geom: ConvGeom, *, cout: int, out_dtype=None, tmode=L.VT_TP
     d.out_layout, d.t_trim = out_layout, t_trim
     d.dtype, d.out_dtype = _DT[x.dtype], _DT[out_dtype]
     d.nbatch = 1
+    n = None
+    if ln is not None:
+        gamma, beta, eps, silu = ln
+        assert out_layout == L.VT_NDHWC and gamma.dtype == torch.float32 and beta.dtype == torch.float32
+        assert gamma.numel() >= cout and beta.numel() >= cout and gamma.is_cuda and beta.is_cuda
+        n = (torch.zeros if ldy != cout else torch.empty)(y.shape, dtype=out_dtype, device=x.device)
+        d.ln_gamma, d.ln_beta, d.ln_out = gamma.data_ptr(), beta.data_ptr(), n.data_ptr()
+        d.ln_mode, d.ln_keep_y, d.ldn, d.ln_eps = (2 if silu else 1), int(bool(ln_keep_y)), ldy, float(eps)
     _conv_launch(lib, d, "vt_conv")
-    return y
+    if ln is None:
+        return y
+    return (y, n) if ln_keep_y else n
 
 
 def gemm_nt(a, b, *, out_dtype=None, bias=None, ld_out=None):
