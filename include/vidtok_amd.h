@@ -46,7 +46,8 @@ typedef enum vt_dtype { VT_F32 = 0, VT_BF16 = 1, VT_I32 = 2 } vt_dtype;
 typedef enum vt_tmode {
   VT_TPAD_ZERO = 0,       /* v1.0 CausalConv{1,3}d, pad_mode "constant"  (model_3dcausal.py:156-159,193-197) */
   VT_TPAD_REPLICATE = 1,  /* v1.1 first chunk: first frame repeated        (model_3dcausal_v1_1.py:160-163,217-220) */
-  VT_TPAD_CACHE = 2       /* v1.1 later chunks: last frames of the cache   (model_3dcausal_v1_1.py:164-171,221-228) */
+  VT_TPAD_CACHE = 2,      /* v1.1 later chunks: last frames of the cache   (model_3dcausal_v1_1.py:164-171,221-228) */
+  VT_TPAD_ZERO_BACK = 3   /* vt_time_avgpool3s2 only: one zero frame AFTER the sequence, non-causal TimeDownsampleRes2x (model_3dnoncausal.py:86-89) */
 } vt_tmode;
 
 typedef enum vt_resmode {
@@ -167,7 +168,8 @@ int vt_ndhwc_to_ncthw(const void* x, int in_dtype, float* y, int32_t B, int32_t 
  * vt_time_avgpool3s2: y[to] = (xp[2to]+xp[2to+1]+xp[2to+2])/3 over the front-padded sequence
  *   xp = [pad, x]; pad frame = 0 (tmode ZERO, v1.0 model_3dcausal.py:249-250), x[0]
  *   (REPLICATE, v1.1 first chunk) or `cache` (one frame [B][1][H][W][C], v1.1 later chunks,
- *   model_3dcausal_v1_1.py:293-300).  x [B][Ti][HW][C] -> y [B][Ti/2][HW][C], same dtype.
+ *   model_3dcausal_v1_1.py:293-300); VT_TPAD_ZERO_BACK: xp = [x, 0] instead (non-causal family,
+ *   model_3dnoncausal.py:86-89).  x [B][Ti][HW][C] -> y [B][Ti/2][HW][C], same dtype.
  * vt_time_lerp2x: F.interpolate(scale (2,1,1), "trilinear", align_corners=False) along T of a
  *   sequence of Ti frames -> 2*Ti frames (model_3dcausal_v1_1.py:327-341); fp32 arithmetic.
  * ---------------------------------------------------------------------------------------- */

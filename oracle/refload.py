@@ -93,9 +93,9 @@ def randomize_weights(model, seed: int = 1):
     g = torch.Generator().manual_seed(seed)
     with torch.no_grad():
         for name, p in model.named_parameters():
-            if name.endswith("conv2.conv.weight") and p.dim() == 3:
+            if (name.endswith("conv2.conv.weight") or name.endswith("conv2.weight")) and p.dim() == 3:   # zero-init temporal conv2
                 p.copy_(torch.randn(p.shape, generator=g) * (1.0 / (p.shape[1] * p.shape[2]) ** 0.5))
-            elif name.endswith("conv2.conv.bias") and "temporal" in name:
+            elif (name.endswith("conv2.conv.bias") or name.endswith("conv2.bias")) and "temporal" in name:
                 p.copy_(torch.randn(p.shape, generator=g) * 0.02)
             elif ".norm" in name and name.endswith("weight") and p.dim() == 1:
                 p.copy_(1.0 + 0.1 * torch.randn(p.shape, generator=g))

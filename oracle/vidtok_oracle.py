@@ -256,6 +256,99 @@ def decoder_forward(sd, params, z, version="v1_0", state: Optional[ChunkState] =
 
 
 # --------------------------------------------------------------------------------------------------
+# non-causal family (R/modules/model_3dnoncausal.py): centred temporal windows, zeros outside the clip
+# --------------------------------------------------------------------------------------------------
+def conv_centered(sd, name, x, stride=(1, 1, 1), pad=None):
+    """nn.Conv3d / nn.Conv1d / nn.Conv2d of the non-causal modules as ONE F.conv3d on the 5-D tensor.  A Conv1d
+    weight [Co,Ci,k] acts along T ("(b h w) c t" view, model_3dcausal.py:14-23), a Conv2d weight on every frame;
+    `pad` = (t_front, t_back, h, w) zeros, default k//2 on every axis the kernel extends over."""
+    w = sd[name + ".weight"]
+    if w.dim() == 3:
+        w = w[:, :, :, None, None]
+    elif w.dim() == 4:
+        w = w[:, :, None]
+    kt, kh, kw = w.shape[2:]
+    tf, tb, ph, pw = pad if pad is not None else (kt // 2, kt // 2, kh // 2, kw // 2)
+    x = F.pad(x, (pw, pw, ph, ph, tf, tb))
+    return F.conv3d(x, w, sd.get(name + ".bias"), stride=stride)
+
+
+def resnet_block_centered(sd, p, x):
+    """ResnetBlock1D._forward / ResnetNoncausalBlock._forward, R/modules/model_3dnoncausal.py:228-248, 291-311
+    (the channel-changing shortcut is never instantiated: in_channels == out_channels at every call site)."""
+    h = silu(layernorm_c(x, sd[p + ".norm1.norm.weight"], sd[p + ".norm1.norm.bias"]))
+    h = conv_centered(sd, p + ".conv1", h)
+    h = silu(layernorm_c(h, sd[p + ".norm2.norm.weight"], sd[p + ".norm2.norm.bias"]))
+    return x + conv_centered(sd, p + ".conv2", h)
+
+
+def attn_block_nc(sd, p, x):
+    """AttnBlockWrapper of the non-causal file (1x1x1 Conv3d projections), R/modules/model_3dnoncausal.py:17-34."""
+    B, C, T, H, W = x.shape
+    hn = layernorm_c(x, sd[p + ".norm.norm.weight"], sd[p + ".norm.norm.bias"])
+    q, k, v = (conv_centered(sd, f"{p}.{n}", hn).permute(0, 2, 3, 4, 1).reshape(B, T, H * W, C) for n in "qkv")
+    att = torch.softmax(q @ k.transpose(-1, -2) * (C ** -0.5), dim=-1)
+    o = (att @ v).reshape(B, T, H, W, C).permute(0, 4, 1, 2, 3)
+    return x + conv_centered(sd, p + ".proj_out", o)
+
+
+def time_downsample_nc(sd, p, x):
+    """TimeDownsampleRes2x.forward, R/modules/model_3dnoncausal.py:84-90: one zero frame AFTER the clip."""
+    alpha = torch.sigmoid(sd[p + ".mix_factor"])
+    xp = F.pad(x, (0, 0, 0, 0, 0, 1))
+    x1 = F.avg_pool3d(xp, (3, 1, 1), stride=(2, 1, 1))
+    x2 = conv_centered(sd, p + ".conv", x, stride=(2, 1, 1), pad=(0, 1, 1, 1))
+    return alpha * x1 + (1 - alpha) * x2
+
+
+def time_upsample_nc(sd, p, x):
+    """TimeUpsampleRes2x.forward, R/modules/model_3dnoncausal.py:105-115: every frame twice, then a centred conv."""
+    alpha = torch.sigmoid(sd[p + ".mix_factor"])
+    x = x.repeat_interleave(2, dim=2)
+    return alpha * x + (1 - alpha) * conv_centered(sd, p + ".conv", x)
+
+
+def encoder3d_forward(sd, params, x, prefix="encoder"):
+    """Encoder3D.forward, R/modules/model_3dnoncausal.py:446-482."""
+    nres = len(params["ch_mult"])
+    tempo_ds = [nres - 2, nres - 3]
+    h = conv_centered(sd, f"{prefix}.conv_in", x)
+    for lvl in range(nres):
+        for blk in range(params["num_res_blocks"]):
+            h = resnet_block_2d(sd, f"{prefix}.down.{lvl}.block.{blk}", h)
+            h = resnet_block_centered(sd, f"{prefix}.down_temporal.{lvl}.block.{blk}", h)
+        if lvl != nres - 1:
+            h = conv2d_frames(sd, f"{prefix}.down.{lvl}.downsample.conv", h, stride=2, pad=(0, 1, 0, 1))
+            if lvl in tempo_ds:
+                h = time_downsample_nc(sd, f"{prefix}.down_temporal.{lvl}.downsample", h)
+    h = resnet_block_centered(sd, f"{prefix}.mid.block_1", h)
+    h = attn_block_nc(sd, f"{prefix}.mid.attn_1", h)
+    h = resnet_block_centered(sd, f"{prefix}.mid.block_2", h)
+    h = silu(layernorm_c(h, sd[f"{prefix}.norm_out.norm.weight"], sd[f"{prefix}.norm_out.norm.bias"]))
+    return conv_centered(sd, f"{prefix}.conv_out", h)
+
+
+def decoder3d_forward(sd, params, z, prefix="decoder"):
+    """Decoder3D.forward, R/modules/model_3dnoncausal.py:618-651 (tempo_us = [1, 2], every frame returned)."""
+    nres = len(params["ch_mult"])
+    h = conv_centered(sd, f"{prefix}.conv_in", z)
+    h = resnet_block_centered(sd, f"{prefix}.mid.block_1", h)
+    h = attn_block_nc(sd, f"{prefix}.mid.attn_1", h)
+    h = resnet_block_centered(sd, f"{prefix}.mid.block_2", h)
+    for lvl in reversed(range(nres)):
+        for blk in range(params["num_res_blocks"] + 1):
+            h = resnet_block_2d(sd, f"{prefix}.up.{lvl}.block.{blk}", h)
+            h = resnet_block_centered(sd, f"{prefix}.up_temporal.{lvl}.block.{blk}", h)
+        if lvl != 0:
+            h = F.interpolate(h, scale_factor=[1.0, 2.0, 2.0], mode="nearest")
+            h = conv2d_frames(sd, f"{prefix}.up.{lvl}.upsample.conv", h)
+            if lvl in (1, 2):
+                h = time_upsample_nc(sd, f"{prefix}.up_temporal.{lvl}.upsample", h)
+    h = silu(layernorm_c(h, sd[f"{prefix}.norm_out.norm.weight"], sd[f"{prefix}.norm_out.norm.bias"]))
+    return conv_centered(sd, f"{prefix}.conv_out", h)
+
+
+# --------------------------------------------------------------------------------------------------
 # regularizers
 # --------------------------------------------------------------------------------------------------
 def kl_regularize(h, sample=True, noise=None):
@@ -341,6 +434,7 @@ class OracleEngine:
         dec = model_params["decoder_config"]["params"]
         self.dec_params = dict(self.enc_params if isinstance(dec, str) else dec)
         enc_target = model_params["encoder_config"]["target"]
+        self.noncausal = "noncausal" in enc_target.lower() or enc_target.endswith("Encoder3D")
         self.version = version or ("v1_1" if ("v1_1" in enc_target or "V11" in enc_target) else "v1_0")
         reg = model_params["regularizer_config"]
         self.reg_kind = "fsq" if "FSQ" in reg["target"] else "kl"
@@ -378,7 +472,16 @@ class OracleEngine:
         return out
 
     @torch.no_grad()
+    def pre_quant(self, x):
+        """encoder output before the regulariser (un-tiled)"""
+        if self.noncausal:
+            return encoder3d_forward(self.sd, self.enc_params, x)
+        return encoder_forward(self.sd, self.enc_params, x, self.version)
+
+    @torch.no_grad()
     def encode(self, x):
+        if self.noncausal:
+            return self.regularize(encoder3d_forward(self.sd, self.enc_params, x))
         if self.version == "v1_0":
             return self.regularize(encoder_forward(self.sd, self.enc_params, x, "v1_0"))
         st = self._enc_state
@@ -421,6 +524,8 @@ class OracleEngine:
     def decode(self, z, decode_from_indices=False):
         if decode_from_indices:
             z = self.indices_to_latent(z)
+        if self.noncausal:
+            return decoder3d_forward(self.sd, self.dec_params, z)
         if self.version == "v1_0":
             return decoder_forward(self.sd, self.dec_params, z, "v1_0")
         st = self._dec_state

@@ -1,7 +1,7 @@
 """Build-container helper: derive configs/*.yaml (model section only, vidtok_amd targets) from the
-hyper-parameters of the reference's causal configs under /root/reference/configs.  The emitted files
-are plain data (channel counts, levels, flags); the non-causal models, the `data:` and `lightning:`
-sections and the training loss are out of scope and are not carried over."""
+hyper-parameters of the reference's causal and non-causal configs under /root/reference/configs.  The emitted
+files are plain data (channel counts, levels, flags); the `data:` and `lightning:` sections and the training loss
+are out of scope and are not carried over."""
 import glob
 import os
 import sys
@@ -16,7 +16,7 @@ OUT = os.path.join(os.path.dirname(__file__), "..", "configs")
 
 
 def main():
-    paths = sorted(glob.glob(f"{REF}/vidtok_*_causal_*.yaml") + glob.glob(f"{REF}/vidtok_v1_1/*.yaml"))
+    paths = sorted(glob.glob(f"{REF}/vidtok_*causal_*.yaml") + glob.glob(f"{REF}/vidtok_v1_1/*.yaml"))
     for p in paths:
         src = yaml.safe_load(open(p))["model"]
         prm = src["params"]

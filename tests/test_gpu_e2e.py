@@ -49,6 +49,9 @@ def test_fp32_matches_reference_golden(case):
     ("vidtok_kl_causal_488_4chn", (2, 3, 17, 64, 64), torch.bfloat16, 0.25),
     ("vidtok_fsq_causal_488_32768", (1, 3, 17, 64, 64), torch.bfloat16, 0.25),
     ("vidtok_kl_causal_488_16chn", (1, 3, 9, 40, 24), torch.bfloat16, 0.25),
+    ("vidtok_kl_noncausal_488_4chn", (2, 3, 16, 64, 64), torch.float32, 1e-3),
+    ("vidtok_kl_noncausal_488_4chn", (1, 3, 16, 64, 64), torch.bfloat16, 0.25),
+    ("vidtok_fsq_noncausal_41616_262144", (1, 3, 8, 64, 64), torch.float32, 1e-3),
 ])
 def test_matches_cpu_oracle(name, shape, dtype, tol):
     model, cfg, sd = build_model(name, seed=21, device=DEV, dtype=dtype)
@@ -69,8 +72,7 @@ def test_matches_cpu_oracle(name, shape, dtype, tol):
         print(f"{name} {dtype}: FSQ code match rate {rate:.5f} over {log2['indices'].numel()} tokens")
         assert rate >= (0.999 if dtype == torch.float32 else 0.5)
         # the quantiser itself is exact: feeding the oracle's own pre-quantisation h gives its codes
-        from oracle.vidtok_oracle import encoder_forward
-        h = encoder_forward(ora.sd, ora.enc_params, x, "v1_0")
+        h = ora.pre_quant(x)
         _, qlog = model.regularization(h.to(DEV))
         assert (qlog["indices"].cpu() != log2["indices"]).sum() <= 1
 

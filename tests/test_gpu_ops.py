@@ -66,6 +66,14 @@ CONV_CASES = [
     ("v11_cache_1d", (1, 4, 8, 8), 256, 256, (3,), ConvGeom(kt=3, pt=2), dict(tmode="cache", res="add")),
     ("v11_cache_s2", (1, 4, 8, 8), 128, 128, (3, 3, 3),
      ConvGeom(kt=3, kh=3, kw=3, st=2, pt=1, ph=1, pw=1, ph_hi=1, pw_hi=1), dict(tmode="cache")),
+    # non-causal family: centred temporal windows (zeros after the clip as well), back-padded stride-2 conv
+    ("nc_conv3d_sym", (1, 4, 8, 8), 128, 128, (3, 3, 3),
+     ConvGeom(kt=3, kh=3, kw=3, pt=1, pt_hi=1, ph=1, pw=1, ph_hi=1, pw_hi=1), dict(res="add")),
+    ("nc_conv1d_sym_512", (1, 5, 4, 4), 512, 512, (3,), ConvGeom(kt=3, pt=1, pt_hi=1), {}),
+    ("nc_timedown_back_mix", (1, 6, 8, 8), 128, 128, (3, 3, 3),
+     ConvGeom(kt=3, kh=3, kw=3, st=2, pt=0, pt_hi=1, ph=1, pw=1, ph_hi=1, pw_hi=1), dict(res="mix")),
+    ("nc_timeup_sym_mix", (1, 3, 8, 8), 128, 128, (3, 3, 3),
+     ConvGeom(kt=3, kh=3, kw=3, pt=1, pt_hi=1, ph=1, pw=1, ph_hi=1, pw_hi=1, ups_t=1), dict(res="mix_up")),
     # frames-innermost tile order (Ho*Wo a multiple of the pixel tile) and the LDS epilogue on several full tiles
     ("temporal_k3_tinner", (2, 5, 16, 16), 128, 128, (3,), ConvGeom(kt=3, pt=2), dict(res="add")),
     ("conv3d_333_tinner_256", (1, 4, 16, 16), 256, 256, (3, 3, 3), ConvGeom(**G333), {}),
@@ -182,7 +190,7 @@ def test_layout_roundtrip(dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
-@pytest.mark.parametrize("tmode", [L.VT_TPAD_ZERO, L.VT_TPAD_REPLICATE, L.VT_TPAD_CACHE])
+@pytest.mark.parametrize("tmode", [L.VT_TPAD_ZERO, L.VT_TPAD_REPLICATE, L.VT_TPAD_CACHE, L.VT_TPAD_ZERO_BACK])
 def test_time_avgpool(dtype, tmode):
     x = _act(2, 6, 4, 4, 128, dtype, 1)
     cache = _act(2, 1, 4, 4, 128, dtype, 2) if tmode == L.VT_TPAD_CACHE else None

@@ -42,6 +42,9 @@ def test_host_graph_matches_reference_golden(case, emulated_ops):
     ("vidtok_kl_causal_41616_4chn", (1, 3, 5, 32, 32)),
     ("vidtok_fsq_causal_488_4096", (1, 3, 4, 32, 32)),
     ("vidtok_v1_1/vidtok_fsq_causal_888_32768_v1_1", (1, 3, 9, 32, 32)),
+    ("vidtok_kl_noncausal_41616_4chn", (1, 3, 8, 32, 32)),
+    ("vidtok_kl_noncausal_488_16chn", (2, 3, 4, 32, 32)),
+    ("vidtok_fsq_noncausal_41616_262144", (1, 3, 8, 32, 32)),
 ])
 def test_other_causal_configs_match_oracle(name, shape, emulated_ops):
     model, cfg, sd = build_model(name, seed=3)

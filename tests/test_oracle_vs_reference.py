@@ -15,6 +15,10 @@ CASES = [
     ("vidtok_kl_causal_488_16chn", (1, 3, 8, 32, 32)),
     ("vidtok_kl_causal_288_8chn", (1, 3, 5, 32, 32)),
     ("vidtok_kl_causal_444_4chn", (1, 3, 5, 16, 16)),
+    # non-causal family: T a multiple of the temporal factor
+    ("vidtok_kl_noncausal_488_4chn", (1, 3, 8, 32, 32)),
+    ("vidtok_fsq_noncausal_488_262144", (2, 3, 4, 32, 32)),
+    ("vidtok_kl_noncausal_41616_16chn", (1, 3, 8, 32, 32)),
 ]
 
 

@@ -38,7 +38,7 @@ def conv(x, w, bias, geom, *, cout, out_dtype=None, tmode=L.VT_TPAD_ZERO, cache=
             assert not geom.ups_t and not geom.ups_s
             front = cache.float().permute(0, 4, 1, 2, 3)[:, :, -geom.pt:]
         xp = torch.cat([front, xp], dim=2)
-    xp = F.pad(xp, (geom.pw, geom.pw_hi, geom.ph, geom.ph_hi))
+    xp = F.pad(xp, (geom.pw, geom.pw_hi, geom.ph, geom.ph_hi, 0, geom.pt_hi))
     w5 = w.float().reshape(cout, geom.kt, geom.kh, geom.kw, Cin).permute(0, 4, 1, 2, 3)
     y = F.conv3d(xp, w5, None if bias is None else bias.float()[:cout], stride=(geom.st, geom.sh, geom.sw))
     To = y.shape[2]
@@ -112,6 +112,10 @@ def ndhwc_to_ncthw(x, c, ttrim=0):
 
 def time_avgpool3s2(x, tmode=L.VT_TPAD_ZERO, cache=None):
     xf = x.float()
+    if tmode == L.VT_TPAD_ZERO_BACK:
+        xp = torch.cat([xf, torch.zeros_like(xf[:, :1])], dim=1)
+        To = x.shape[1] // 2
+        return ((xp[:, 0:2 * To:2] + xp[:, 1:2 * To + 1:2] + xp[:, 2:2 * To + 2:2]) / 3.0).to(x.dtype)
     if tmode == L.VT_TPAD_ZERO:
         front = torch.zeros_like(xf[:, :1])
     elif tmode == L.VT_TPAD_REPLICATE:

@@ -22,6 +22,8 @@ TARGET_ALIASES = {
     "vidtok.modules.model_3dcausal.DecoderCausal3DPadding": "vidtok_amd.modules.DecoderCausal3DPadding",
     "vidtok.modules.model_3dcausal_v1_1.EncoderCausal3DPadding": "vidtok_amd.modules.EncoderCausal3DPaddingV11",
     "vidtok.modules.model_3dcausal_v1_1.DecoderCausal3DPadding": "vidtok_amd.modules.DecoderCausal3DPaddingV11",
+    "vidtok.modules.model_3dnoncausal.Encoder3D": "vidtok_amd.modules_noncausal.Encoder3D",
+    "vidtok.modules.model_3dnoncausal.Decoder3D": "vidtok_amd.modules_noncausal.Decoder3D",
     "vidtok.modules.regularizers.DiagonalGaussianRegularizer": "vidtok_amd.regularizers.DiagonalGaussianRegularizer",
     "vidtok.modules.regularizers.FSQRegularizer": "vidtok_amd.regularizers.FSQRegularizer",
     "vidtok.modules.losses.GeneralLPIPSWithDiscriminator": "torch.nn.Identity",

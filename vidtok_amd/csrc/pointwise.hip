@@ -255,7 +255,7 @@ __global__ __launch_bounds__(kBlock) void time_avgpool3s2_kernel(const T* __rest
     const int b = (int)(r / To);
     float a[4], c[4], d[4], o[4];
     const T* xb = x + ((long long)b * Ti) * F4 * 4 + f * 4;
-    const int t0 = 2 * to - 1;  // x index of the first tap (may be -1 = pad frame)
+    const int t0 = (tmode == VT_TPAD_ZERO_BACK) ? 2 * to : 2 * to - 1;  // x index of the first tap (-1 = front pad frame)
     if (t0 >= 0) {
       load4<T>(xb + (long long)t0 * F4 * 4, a);
     } else if (tmode == VT_TPAD_REPLICATE) {
@@ -266,7 +266,8 @@ __global__ __launch_bounds__(kBlock) void time_avgpool3s2_kernel(const T* __rest
       a[0] = a[1] = a[2] = a[3] = 0.f;
     }
     load4<T>(xb + (long long)(t0 + 1) * F4 * 4, c);
-    load4<T>(xb + (long long)(t0 + 2) * F4 * 4, d);
+    if (t0 + 2 < Ti) load4<T>(xb + (long long)(t0 + 2) * F4 * 4, d);
+    else d[0] = d[1] = d[2] = d[3] = 0.f;    // back pad frame (VT_TPAD_ZERO_BACK only)
 #pragma unroll
     for (int e = 0; e < 4; ++e) o[e] = ((a[e] + c[e]) + d[e]) / 3.0f;
     store4<T>(y + i * 4, o);
@@ -406,6 +407,7 @@ extern "C" int vt_time_avgpool3s2(const void* x, const void* cache, void* y, int
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
   VT_CHECK_ARG(x && y && B > 0 && Ti >= 2 && (Ti % 2) == 0 && HW > 0 && C > 0, "vt_time_avgpool3s2: bad dims (Ti=%d)", Ti);
   VT_CHECK_ARG((HW * C) % 4 == 0, "vt_time_avgpool3s2: frame size must be a multiple of 4 elements");
+  VT_CHECK_ARG(tmode >= VT_TPAD_ZERO && tmode <= VT_TPAD_ZERO_BACK, "vt_time_avgpool3s2: tmode %d", tmode);
   VT_CHECK_ARG(tmode != VT_TPAD_CACHE || cache != nullptr, "vt_time_avgpool3s2: cache mode without cache");
   const long long F4 = HW * C / 4;
   const long long n = (long long)B * (Ti / 2) * F4;

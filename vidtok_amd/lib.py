@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libvidtok_amd.so")
 
 VT_F32, VT_BF16, VT_I32 = 0, 1, 2
-VT_TPAD_ZERO, VT_TPAD_REPLICATE, VT_TPAD_CACHE = 0, 1, 2
+VT_TPAD_ZERO, VT_TPAD_REPLICATE, VT_TPAD_CACHE, VT_TPAD_ZERO_BACK = 0, 1, 2, 3
 VT_RES_NONE, VT_RES_ADD, VT_RES_MIX = 0, 1, 2
 VT_NDHWC, VT_NCTHW = 0, 1
 

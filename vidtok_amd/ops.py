@@ -68,12 +68,13 @@ class ConvGeom:
     pw: int = 0
     ph_hi: int = 0     # bottom / right pad (zeros)
     pw_hi: int = 0
+    pt_hi: int = 0     # zero frames after the last one (non-causal convs; the kernel reads 0 beyond the end)
     ups_t: int = 0     # nearest x2 folded into the gather
     ups_s: int = 0
 
     def out_dims(self, Ti, Hi, Wi):
         Tv, Hv, Wv = Ti << self.ups_t, Hi << self.ups_s, Wi << self.ups_s
-        To = (Tv + self.pt - self.kt) // self.st + 1
+        To = (Tv + self.pt + self.pt_hi - self.kt) // self.st + 1
         Ho = (Hv + self.ph + self.ph_hi - self.kh) // self.sh + 1
         Wo = (Wv + self.pw + self.pw_hi - self.kw) // self.sw + 1
         return To, Ho, Wo
