@@ -175,11 +175,46 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[T
 // residual switched off one by one): the 2.7 GB of epilogue traffic of a 128->128 conv cost 0.5-0.6 ms of a 2.5 ms
 // launch and did not overlap with the co-resident workgroup's K loop: the L2 path is transaction-bound, not
 // byte-bound.  Here the tile (+ bias) is transposed through the LDS the K loop no longer needs (128 x 128 fp32 =
-// the 64 KiB of the two stages): every lane then handles 4 consecutive channels of a pixel row with 32 lanes per
-// 128 channels, so a wave instruction covers whole 128-B lines (2 rows x 256 B bf16, 1 row x 512 B fp32).
+// the 64 KiB of the two stages): every lane then handles 8 consecutive channels of a pixel row with 16 lanes per
+// 128 channels, so a wave instruction covers whole 128-B lines (4 rows x 256 B bf16, 4 rows x 512 B fp32).
 //   LDS layout: T[pixel][32 chunks of 4 floats], chunk index XOR (pixel & 31): the 8 lanes a ds_write_b128 services
 //   together hold 8 different pixels of one chunk -> 8 different columns; a ds_read_b128 group reads 16 different
 //   chunks of one row -> 16 different bank quads.
+// 8 consecutive channels of one pixel row as stored (16 B bf16 / 32 B fp32)
+template <typename TOut>
+struct Oct;
+template <>
+struct Oct<float> {
+  f32x4 lo, hi;
+  __device__ __forceinline__ void load(const float* p) {
+    lo = *reinterpret_cast<const f32x4*>(p);
+    hi = *reinterpret_cast<const f32x4*>(p + 4);
+  }
+  __device__ __forceinline__ float get(int e) const { return e < 4 ? lo[e] : hi[e - 4]; }
+  static __device__ __forceinline__ void store(float* p, const float (&v)[8]) {
+    f32x4 a, b;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { a[e] = v[e]; b[e] = v[4 + e]; }
+    *reinterpret_cast<f32x4*>(p) = a;
+    *reinterpret_cast<f32x4*>(p + 4) = b;
+  }
+};
+template <>
+struct Oct<bf16_t> {
+  u32x4 w;
+  __device__ __forceinline__ void load(const bf16_t* p) { w = *reinterpret_cast<const u32x4*>(p); }
+  __device__ __forceinline__ float get(int e) const {
+    const uint32_t t = w[e >> 1];
+    return bf16_bits_to_f32((e & 1) ? (t >> 16) : (t & 0xffffu));
+  }
+  static __device__ __forceinline__ void store(bf16_t* p, const float (&v)[8]) {
+    u32x4 t;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) t[e] = f32_to_bf16_bits(v[2 * e]) | (f32_to_bf16_bits(v[2 * e + 1]) << 16);
+    *reinterpret_cast<u32x4*>(p) = t;
+  }
+};
+
 template <typename TOut>
 __device__ __forceinline__ void conv_epilogue_lds128(const ConvArgs& p, f32x16 (&acc)[2][2], int m_blk, int n_blk, int wm,
                                                      int wn, int lane, int tid, char* smem, long long z) {
@@ -189,18 +224,21 @@ __device__ __forceinline__ void conv_epilogue_lds128(const ConvArgs& p, f32x16 (
   const bool has_res = p.res_mode != VT_RES_NONE;
   float alpha = 0.0f;
   if (p.res_mode == VT_RES_MIX) alpha = 1.0f / (1.0f + __expf(-p.mix_factor[0]));
-  constexpr int NT = 16;                      // (row, chunk) tasks per lane: 128 rows x 32 chunks / 256 lanes
-  const int chunk_j = tid & 31;               // this lane's chunk: channels 4j .. 4j+3 of the tile
-  const int row0 = tid >> 5;                  // rows row0 + 8*it
-  // residual quads first: their latency rides under the transposition
-  Quad<TOut> rq[NT];
-  long long mres[NT];
+  // read-back mapping: 16 lanes per pixel row, 8 consecutive channels each (two adjacent 16-B chunks of the row:
+  // the XOR swizzle keeps a pair adjacent), rows row0 + 16*it.  A wave instruction covers 4 rows x 256 B (bf16);
+  // the LayerNorm statistics of a row reduce over 16 lanes with DPP only.
+  constexpr int NT = 8;
+  const int oct_j = tid & 15;
+  const int row0 = tid >> 4;
+  // residual first: its latency rides under the transposition
+  Oct<TOut> rq[NT];
   if (has_res) {
     const bool remap = p.res_tshift != 0 || p.Tr != p.To;   // uniform
     const long long HWo = (long long)p.Ho * p.Wo;
+    long long mres[NT];
 #pragma unroll
     for (int it = 0; it < NT; ++it) {
-      long long m = m_blk + row0 + 8 * it;
+      long long m = m_blk + row0 + 16 * it;
       if (remap) {
         const long long hw = m % HWo;
         const long long r = m / HWo;
@@ -211,8 +249,7 @@ __device__ __forceinline__ void conv_epilogue_lds128(const ConvArgs& p, f32x16 (
       mres[it] = m;
     }
 #pragma unroll
-    for (int it = 0; it < NT; ++it)
-      rq[it].v = *reinterpret_cast<const decltype(rq[it].v)*>(rg + mres[it] * p.ldr + n_blk + 4 * chunk_j);
+    for (int it = 0; it < NT; ++it) rq[it].load(rg + mres[it] * p.ldr + n_blk + 8 * oct_j);
   }
   __syncthreads();                            // every wave has finished reading the last stage
   {
@@ -236,41 +273,49 @@ __device__ __forceinline__ void conv_epilogue_lds128(const ConvArgs& p, f32x16 (
       }
   }
   __syncthreads();
-  // fused LayerNorm (+SiLU) of the finished rows: the 32 lanes of a row hold its 128 channels (launcher: Cout = 128)
-  f32x4 lg, lb;
+  // fused LayerNorm (+SiLU) of the finished rows (launcher: Cout = 128, so the 16 lanes of a row hold all of it)
+  float lg[8], lb[8];
   TOut* __restrict__ ng = reinterpret_cast<TOut*>(p.ln_out);
   if (p.ln_mode) {
-    lg = *reinterpret_cast<const f32x4*>(p.ln_gamma + 4 * chunk_j);
-    lb = *reinterpret_cast<const f32x4*>(p.ln_beta + 4 * chunk_j);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      lg[e] = p.ln_gamma[8 * oct_j + e];
+      lb[e] = p.ln_beta[8 * oct_j + e];
+    }
   }
 #pragma unroll
   for (int it = 0; it < NT; ++it) {
-    const int row = row0 + 8 * it;
-    const f32x4 t = *reinterpret_cast<const f32x4*>(T + row * 128 + ((chunk_j ^ (row & 31)) << 2));
-    float v[4];
+    const int row = row0 + 16 * it;
+    const int sw = row & 31;
+    const f32x4 t0 = *reinterpret_cast<const f32x4*>(T + row * 128 + (((2 * oct_j) ^ sw) << 2));
+    const f32x4 t1 = *reinterpret_cast<const f32x4*>(T + row * 128 + (((2 * oct_j + 1) ^ sw) << 2));
+    float v[8];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      v[e] = t[e];
+    for (int e = 0; e < 8; ++e) {
+      v[e] = e < 4 ? t0[e] : t1[e - 4];
       if (p.res_mode == VT_RES_ADD) v[e] = rq[it].get(e) + v[e];
       if (p.res_mode == VT_RES_MIX) v[e] = alpha * rq[it].get(e) + (1.0f - alpha) * v[e];
     }
-    if (!p.ln_mode || p.ln_keep_y) store_quad<TOut>(yg + (long long)(m_blk + row) * p.ldy + n_blk + 4 * chunk_j, v);
+    if (!p.ln_mode || p.ln_keep_y) Oct<TOut>::store(yg + (long long)(m_blk + row) * p.ldy + n_blk + 8 * oct_j, v);
     if (p.ln_mode) {   // uniform; same two-pass statistics as layernorm_act_kernel, taken before the rounding to TOut
-      const float mean = group_sum_dpp<32>((v[0] + v[1]) + (v[2] + v[3])) * (1.0f / 128.0f);
-      float d[4], q = 0.f;
+      float s = 0.f;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        d[e] = v[e] - mean;
-        q += d[e] * d[e];
+      for (int e = 0; e < 8; ++e) s += v[e];
+      const float mean = group_sum_dpp<16>(s) * (1.0f / 128.0f);
+      float q = 0.f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        v[e] -= mean;
+        q += v[e] * v[e];
       }
-      const float rstd = __builtin_amdgcn_rsqf(group_sum_dpp<32>(q) * (1.0f / 128.0f) + p.ln_eps);
-      float o[4];
+      const float rstd = __builtin_amdgcn_rsqf(group_sum_dpp<16>(q) * (1.0f / 128.0f) + p.ln_eps);
+      float o[8];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const float u = d[e] * rstd * lg[e] + lb[e];
+      for (int e = 0; e < 8; ++e) {
+        const float u = v[e] * rstd * lg[e] + lb[e];
         o[e] = (p.ln_mode == 2) ? silu_fast(u) : u;
       }
-      store_quad<TOut>(ng + (long long)(m_blk + row) * p.ldn + 4 * chunk_j, o);
+      Oct<TOut>::store(ng + (long long)(m_blk + row) * p.ldn + 8 * oct_j, o);
     }
   }
 }
@@ -710,8 +755,9 @@ int launch_variant(const ConvArgs& a_in, int nbatch, hipStream_t stream) {
   // temporal conv of the widest level moved 3x its input).  Walking the tiles as (b, hw tile, t) puts the
   // producers of those lines right before their consumer on the same XCD (xcd_remap keeps the sequence
   // contiguous): 298 -> 340 TFLOP/s on that layer, +3 % on the 27-tap up-sampler conv (same-run A/B).
-  a.lds_epi = (env_int("VT_CONV_LDSEPI", 1) != 0 && a.out_layout == VT_NDHWC && (a.ldy & 3) == 0 &&
-               (a.res_mode == VT_RES_NONE || (a.ldr & 3) == 0)) ? 1 : 0;
+  constexpr int kOctAlign = 16 / (int)sizeof(TOut) > 4 ? 8 : 4;   // elements per 16 bytes, at least a quad
+  a.lds_epi = (env_int("VT_CONV_LDSEPI", 1) != 0 && a.out_layout == VT_NDHWC && a.ldy % kOctAlign == 0 &&
+               (a.res_mode == VT_RES_NONE || a.ldr % kOctAlign == 0) && (a.ln_mode == 0 || a.ldn % kOctAlign == 0)) ? 1 : 0;
   a.hw_tiles = 0;
   if (conv_tinner() && a.KT > 1 && a.To > 1 && ((long long)a.Ho * a.Wo) % BM == 0) a.hw_tiles = (int)(((long long)a.Ho * a.Wo) / BM);
   // descriptor gather needs both tensors under 4 GiB (minus the out-of-range marker) and no cache-mode padding
@@ -848,8 +894,8 @@ extern "C" int vt_conv(const vt_conv_desc* d, vt_stream stream_) {
   a.xs_z = d->xs_z; a.ws_z = d->ws_z; a.ys_z = d->ys_z; a.rs_z = d->rs_z;
 
   // LayerNorm inside the epilogue: the 128 x 128 tile with the LDS epilogue on full tiles spanning the channel row
-  const bool ln_fused = d->ln_mode != 0 && d->Cout == 128 && M % 128 == 0 && (d->ldy & 3) == 0 && (d->ldn & 3) == 0 &&
-                        (d->res_mode == VT_RES_NONE || (d->ldr & 3) == 0) && env_int("VT_CONV_LDSEPI", 1) != 0 &&
+  const bool ln_fused = d->ln_mode != 0 && d->Cout == 128 && M % 128 == 0 && (d->ldy & 7) == 0 && (d->ldn & 7) == 0 &&
+                        (d->res_mode == VT_RES_NONE || (d->ldr & 7) == 0) && env_int("VT_CONV_LDSEPI", 1) != 0 &&
                         env_int("VT_CONV_FUSE_LN", 1) != 0;
   if (ln_fused) {
     a.ln_gamma = d->ln_gamma; a.ln_beta = d->ln_beta; a.ln_out = (char*)d->ln_out;
