@@ -22,15 +22,18 @@
 //   * padding, causal time padding (zero / replicate / cache), stride, and nearest-neighbour x2
 //     up-sampling in space or time are folded into the gather addresses: nothing is materialised;
 //   * epilogue: + bias, + residual or alpha-mix, dtype conversion, NDHWC vector store or NCTHW (fp32,
-//     with front time trim) store;
+//     with front time trim) store; the 128 x 128 tile transposes through the LDS first so rows are
+//     written with whole-line 16-B accesses, and can emit LayerNorm(+SiLU) of the result from there
+//     (conv_epilogue_lds128);
 //   * XCD-aware tile order: consecutive tiles of one XCD are neighbouring pixel tiles of the same
-//     channel tile, so halo rows and the weight slab are shared in that XCD's L2.
+//     channel tile, so halo rows and the weight slab are shared in that XCD's L2; temporal convs walk
+//     the frames innermost (launch_variant).
 //
 // Measured dead ends (kept out of the code): register-staged operand tiles
-// (ds_write_b128 pass: 627 vs 440 TFLOP/s aggregate), a 4-stage ring of 64-B rows (no gain: the loop is
-// instruction-issue bound, not DMA-latency bound), 256x128 tiles with 8 or 4 waves (slower), a persistent
-// tile loop (40 % slower: the co-resident workgroups fall into lockstep), LayerNorm fused into the
-// epilogue (+1.6 ms per conv vs 0.5 ms for the separate kernel).
+// (ds_write_b128 pass: 627 vs 440 TFLOP/s aggregate), a 4-stage ring of 64-B rows (no gain), 256x128 tiles
+// with 8 or 4 waves (slower), 3-4 waves/SIMD with 64-B rows (slower), LayerNorm in the MFMA-layout epilogue
+// (+1.6 ms per conv), a kw-innermost K walk (less fabric traffic, more time).  The persistent variant with a
+// deferred epilogue lives in conv_stream.hip (opt-in).
 #include <type_traits>
 
 #include "conv_common.h"

@@ -10,13 +10,16 @@
 // Here a workgroup is persistent (2 per CU) and walks a sequence of tiles:
 //   * the DMA pipeline runs across tile boundaries: during the LAST K step of tile i the coordinates of
 //     tile i+1 are set up and its first stage is requested, so the memory latency hides under MFMAs;
-//   * the epilogue is DEFERRED: the accumulators of tile i are parked in a second register set and drained
-//     in slices (one accumulator quad = 4 channels of one pixel per lane: residual load at the top of a K
-//     step, bias/residual arithmetic and the store after that step's MFMAs) during the K steps of tile i+1,
-//     so residual latency, the VALU work and the write traffic are spread under the matrix pipe;
-//   * vmcnt bookkeeping: within a step the program order is  residual loads -> DMA pieces -> (MFMAs) ->
-//     stores, and VM operations retire in order, so "my DMA pieces have landed" is vmcnt(#stores of the step)
-//     -- the stores of the drain stay in flight across the barrier.
+//   * the epilogue is DEFERRED: the accumulators of tile i (started at the bias) are parked in a second
+//     register set and drained in slices of SPS accumulator quads (a quad = 4 channels of one pixel per lane)
+//     during the first K steps of tile i+1: add the residual, convert, store;
+//   * vmcnt bookkeeping: within a step the program order is  DMA pieces -> (MFMAs) -> stores of this step's
+//     slice -> residual loads of the NEXT step's slice, and VM operations retire in order, so "my DMA pieces
+//     have landed" is vmcnt(#younger operations) -- stores and residual loads stay in flight across the barrier.
+// STATUS: experimental, off by default (VT_CONV_STREAM=1).  Results are identical to conv_igemm's (same op tests),
+// the bare persistent K loop is 1.3-1.7x faster on the widest level, but the drain's stores delay the next DMA
+// wait (in-order retirement, one step of slack with a 2-stage ring) and the set-up is serial: net +3 %
+// (DESIGN.md section 6).
 // Restrictions (the launcher falls back to conv_igemm otherwise): descriptor gather, Cin a multiple of the
 // K step, Cout a multiple of 128, NDHWC vector epilogue, plain residual (no time shift), one problem per launch.
 #include <type_traits>
