@@ -14,6 +14,8 @@ decoder drops 3 frames; "v1_1" = first-frame-replicate / cached causal padding, 
 up-sampling, chunk-to-chunk caches (`causal_cache`, `is_first_chunk`, `cache_offset` attributes
 exactly as model_3dcausal_v1_1.py:155-157,212-214 so an engine can drive them).
 """
+import os
+
 import torch
 import torch.nn as nn
 
@@ -27,6 +29,36 @@ def _check_norm(norm_type):
     if norm_type != "layernorm":
         raise NotImplementedError(
             f"norm_type={norm_type!r}: only 'layernorm' (used by every shipped VidTok config) has a HIP kernel")
+
+
+class Normed:
+    """An activation together with the LayerNorm(+SiLU) its consumer applies first, already produced by the conv
+    that wrote the activation (`ln=` of ops.conv: one pass over the tensor instead of write + read + write)."""
+
+    __slots__ = ("y", "n", "norm", "silu")
+
+    def __init__(self, y, n, norm, silu):
+        self.y, self.n, self.norm, self.silu = y, n, norm, silu
+
+
+def plain(x):
+    return x.y if isinstance(x, Normed) else x
+
+
+_EMIT_NEXT_NORM = os.environ.get("VIDTOK_AMD_EMIT_NEXT_NORM", "1") != "0"   # A/B switch (0: consumers run their own norm)
+
+
+def _emit(next_norm):
+    """kwargs for the last conv of a block: also emit the consumer's norm; `next_norm` = (LayerNorm, silu) or None"""
+    if next_norm is None or not _EMIT_NEXT_NORM:
+        return {}
+    return dict(ln=next_norm[0].fused(next_norm[1]), ln_keep_y=True)
+
+
+def _wrap(out, next_norm):
+    if next_norm is None or not _EMIT_NEXT_NORM:
+        return out
+    return Normed(out[0], out[1], next_norm[0], next_norm[1])
 
 
 class LayerNorm(nn.Module):
@@ -45,6 +77,10 @@ class LayerNorm(nn.Module):
         return self._cache[1], self._cache[2]
 
     def apply_ndhwc(self, x, silu, dt):
+        if isinstance(x, Normed):
+            if x.norm is self and x.silu == silu:
+                return x.n            # the producing conv already applied this norm
+            x = x.y
         g, b = self.affine()
         return ops.layernorm_act(x, g, b, silu=silu, eps=self.norm.eps, out_dtype=dt)
 
@@ -187,9 +223,9 @@ class Upsample(nn.Module):
         self.conv = nn.Conv2d(in_channels, in_channels, kernel_size=3, stride=1, padding=1)
         self._pack = PackedCache()
 
-    def run(self, x, dt):
+    def run(self, x, dt, next_norm=None):
         g = ConvGeom(kh=3, kw=3, ph=1, pw=1, ph_hi=1, pw_hi=1, ups_s=1)
-        return _Conv2dHolder.run(self.conv, self._pack, x, dt, g)
+        return _wrap(_Conv2dHolder.run(self.conv, self._pack, plain(x), dt, g, **_emit(next_norm)), next_norm)
 
 
 class Downsample(nn.Module):
@@ -203,9 +239,9 @@ class Downsample(nn.Module):
         self.conv = nn.Conv2d(in_channels, in_channels, kernel_size=3, stride=2, padding=0)
         self._pack = PackedCache()
 
-    def run(self, x, dt):
+    def run(self, x, dt, next_norm=None):
         g = ConvGeom(kh=3, kw=3, sh=2, sw=2, ph=0, pw=0, ph_hi=1, pw_hi=1)
-        return _Conv2dHolder.run(self.conv, self._pack, x, dt, g)
+        return _wrap(_Conv2dHolder.run(self.conv, self._pack, plain(x), dt, g, **_emit(next_norm)), next_norm)
 
 
 class TimeDownsampleResCausal2x(nn.Module):
@@ -220,7 +256,8 @@ class TimeDownsampleResCausal2x(nn.Module):
         self.is_first_chunk = True
         self.causal_cache = None
 
-    def run(self, x, dt):
+    def run(self, x, dt, next_norm=None):
+        x = plain(x)
         if self.version == "v1_0":
             x1 = ops.time_avgpool3s2(x, L.VT_TPAD_ZERO)
         else:
@@ -229,7 +266,8 @@ class TimeDownsampleResCausal2x(nn.Module):
             else:
                 x1 = ops.time_avgpool3s2(x, L.VT_TPAD_CACHE, cache=self.causal_cache)
             self.causal_cache = ops.gather_frames(x, [x.shape[1] - 1])
-        return self.conv.run(x, dt, res=x1, res_mode=L.VT_RES_MIX, mix_factor=self.mix_factor.detach())
+        return _wrap(self.conv.run(x, dt, res=x1, res_mode=L.VT_RES_MIX, mix_factor=self.mix_factor.detach(),
+                                   **_emit(next_norm)), next_norm)
 
 
 class TimeUpsampleResCausal2x(nn.Module):
@@ -266,12 +304,14 @@ class TimeUpsampleResCausal2x(nn.Module):
             return torch.cat([head, tail], dim=1).contiguous()
         return head
 
-    def run(self, x, dt):
+    def run(self, x, dt, next_norm=None):
+        x = plain(x)
         mf = self.mix_factor.detach()
         if self.version == "v1_0":
-            return self.conv.run(x, dt, ups_t=1, res=x, res_mode=L.VT_RES_MIX, res_tshift=1, mix_factor=mf)
+            return _wrap(self.conv.run(x, dt, ups_t=1, res=x, res_mode=L.VT_RES_MIX, res_tshift=1, mix_factor=mf,
+                                       **_emit(next_norm)), next_norm)
         xi = self._interp_v11(x)
-        return self.conv.run(xi, dt, res=xi, res_mode=L.VT_RES_MIX, mix_factor=mf)
+        return _wrap(self.conv.run(xi, dt, res=xi, res_mode=L.VT_RES_MIX, mix_factor=mf, **_emit(next_norm)), next_norm)
 
 
 class ResnetBlock(nn.Module):
@@ -292,13 +332,18 @@ class ResnetBlock(nn.Module):
             self.nin_shortcut = nn.Conv2d(in_channels, out_channels, kernel_size=1, stride=1, padding=0)
         self._p1, self._p2, self._p3 = PackedCache(), PackedCache(), PackedCache()
 
-    def run(self, x, dt):
+    def first_norm(self):
+        return (self.norm1, True)
+
+    def run(self, x, dt, next_norm=None):
         h = self.norm1.apply_ndhwc(x, True, dt)
+        x = plain(x)
         # conv1's result is only ever seen through norm2 + SiLU: the conv emits that directly
         h = _Conv2dHolder.run(self.conv1, self._p1, h, dt, _G3x3, ln=self.norm2.fused(True), ln_keep_y=False)
         if self.in_channels != self.out_channels:
             x = _Conv2dHolder.run(self.nin_shortcut, self._p3, x, dt, _G1x1)
-        return _Conv2dHolder.run(self.conv2, self._p2, h, dt, _G3x3, res=x, res_mode=L.VT_RES_ADD)
+        return _wrap(_Conv2dHolder.run(self.conv2, self._p2, h, dt, _G3x3, res=x, res_mode=L.VT_RES_ADD,
+                                       **_emit(next_norm)), next_norm)
 
 
 class ResnetCausalBlock(nn.Module):
@@ -317,12 +362,16 @@ class ResnetCausalBlock(nn.Module):
         if in_channels != out_channels:
             self.nin_shortcut = CausalConv3d(in_channels, out_channels, 1, version=version)
 
-    def run(self, x, dt):
+    def first_norm(self):
+        return (self.norm1, True)
+
+    def run(self, x, dt, next_norm=None):
         h = self.norm1.apply_ndhwc(x, True, dt)
+        x = plain(x)
         h = self.conv1.run(h, dt, ln=self.norm2.fused(True), ln_keep_y=False)
         if self.in_channels != self.out_channels:
             x = self.nin_shortcut.run(x, dt)
-        return self.conv2.run(h, dt, res=x, res_mode=L.VT_RES_ADD)
+        return _wrap(self.conv2.run(h, dt, res=x, res_mode=L.VT_RES_ADD, **_emit(next_norm)), next_norm)
 
 
 class ResnetCausalBlock1D(nn.Module):
@@ -346,12 +395,16 @@ class ResnetCausalBlock1D(nn.Module):
             self.conv2.conv.weight.data.zero_()
             self.conv2.conv.bias.data.zero_()
 
-    def run(self, x, dt):
+    def first_norm(self):
+        return (self.norm1, True)
+
+    def run(self, x, dt, next_norm=None):
         h = self.norm1.apply_ndhwc(x, True, dt)
+        x = plain(x)
         h = self.conv1.run(h, dt, ln=self.norm2.fused(True), ln_keep_y=False)
         if self.in_channels != self.out_channels:
             x = self.nin_shortcut.run(x, dt)
-        return self.conv2.run(h, dt, res=x, res_mode=L.VT_RES_ADD)
+        return _wrap(self.conv2.run(h, dt, res=x, res_mode=L.VT_RES_ADD, **_emit(next_norm)), next_norm)
 
 
 class AttnBlockWrapper(nn.Module):
@@ -369,10 +422,14 @@ class AttnBlockWrapper(nn.Module):
         self.v = CausalConv3d(in_channels, in_channels, 1, version=version)
         self.proj_out = CausalConv3d(in_channels, in_channels, 1, version=version)
 
-    def run(self, x, dt):
+    def first_norm(self):
+        return (self.norm, False)
+
+    def run(self, x, dt, next_norm=None):
+        hn = self.norm.apply_ndhwc(x, False, dt)
+        x = plain(x)
         B, T, H, W, Cc = x.shape
         S, Z = H * W, B * T
-        hn = self.norm.apply_ndhwc(x, False, dt)
         q = self.q.run(hn, dt).view(Z, S, Cc)
         k = self.k.run(hn, dt).view(Z, S, Cc)
         wv, bv = self.v._pack.get(self.v.conv.weight, self.v.conv.bias, dt, cin_stored=Cc)
@@ -381,7 +438,23 @@ class AttnBlockWrapper(nn.Module):
         s = ops.gemm_nt(q, k, out_dtype=torch.float32)                                         # [Z, S, S]
         p = ops.softmax_rows(s, float(Cc) ** -0.5, dt, ld_out=Sp)                              # [Z, S, Sp]
         o = ops.gemm_nt(p, vT, bias=bv).view(B, T, H, W, Cc)
-        return self.proj_out.run(o, dt, res=x, res_mode=L.VT_RES_ADD)
+        return _wrap(self.proj_out.run(o, dt, res=x, res_mode=L.VT_RES_ADD, **_emit(next_norm)), next_norm)
+
+
+def first_norm_of(stage):
+    """(LayerNorm, silu) a stage applies to its input first, or None (resamplers)"""
+    return stage.first_norm() if hasattr(stage, "first_norm") else None
+
+
+def run_stages(stages, h, dt, last_norm=None, first=None):
+    """Run the blocks in order; every block is told which norm its consumer starts with, so the conv that writes the
+    activation can emit that norm as well (ops.conv `ln=`).  `h` may already come with stages[0]'s norm (`first`)."""
+    if first is not None and not isinstance(h, Normed):
+        h = _wrap(h, first)
+    for i, stage in enumerate(stages):
+        nxt = first_norm_of(stages[i + 1]) if i + 1 < len(stages) else last_norm
+        h = stage.run(h, dt, next_norm=nxt)
+    return h
 
 
 def _level_module():
@@ -460,18 +533,17 @@ class EncoderCausal3DPadding(nn.Module):
         assert x.dim() == 5, "input should be 5D tensor, but got {}D tensor".format(x.dim())
         dt = self.compute_dtype
         h = ops.ncthw_to_ndhwc(x.contiguous().float(), dt, tpad=self._front_pad(x.shape[2]))
-        h = self.conv_in.run(h, dt)
+        stages = []
         for i_level in range(self.num_resolutions):
             for i_block in range(self.num_res_blocks):
-                h = self.down[i_level].block[i_block].run(h, dt)
-                h = self.down_temporal[i_level].block[i_block].run(h, dt)
+                stages += [self.down[i_level].block[i_block], self.down_temporal[i_level].block[i_block]]
             if i_level in self.spatial_ds:
-                h = self.down[i_level].downsample.run(h, dt)
+                stages.append(self.down[i_level].downsample)
                 if i_level in self.tempo_ds:
-                    h = self.down_temporal[i_level].downsample.run(h, dt)
-        h = self.mid.block_1.run(h, dt)
-        h = self.mid.attn_1.run(h, dt)
-        h = self.mid.block_2.run(h, dt)
+                    stages.append(self.down_temporal[i_level].downsample)
+        stages += [self.mid.block_1, self.mid.attn_1, self.mid.block_2]
+        h = run_stages(stages, self.conv_in.run(h, dt, **_emit(first_norm_of(stages[0]))), dt,
+                       last_norm=(self.norm_out, True), first=first_norm_of(stages[0]))
         h = self.norm_out.apply_ndhwc(h, True, dt)
         return self.conv_out.run(h, dt, out_layout=L.VT_NCTHW)
 
@@ -548,18 +620,16 @@ class DecoderCausal3DPadding(nn.Module):
     def forward(self, z):
         dt = self.compute_dtype
         h = ops.ncthw_to_ndhwc(z.contiguous().float(), dt)
-        h = self.conv_in.run(h, dt)
-        h = self.mid.block_1.run(h, dt)
-        h = self.mid.attn_1.run(h, dt)
-        h = self.mid.block_2.run(h, dt)
+        stages = [self.mid.block_1, self.mid.attn_1, self.mid.block_2]
         for i_level in reversed(range(self.num_resolutions)):
             for i_block in range(self.num_res_blocks + 1):
-                h = self.up[i_level].block[i_block].run(h, dt)
-                h = self.up_temporal[i_level].block[i_block].run(h, dt)
+                stages += [self.up[i_level].block[i_block], self.up_temporal[i_level].block[i_block]]
             if i_level in self.spatial_us:
-                h = self.up[i_level].upsample.run(h, dt)
+                stages.append(self.up[i_level].upsample)
                 if i_level in self.tempo_us:
-                    h = self.up_temporal[i_level].upsample.run(h, dt)
+                    stages.append(self.up_temporal[i_level].upsample)
+        h = run_stages(stages, self.conv_in.run(h, dt, **_emit(first_norm_of(stages[0]))), dt,
+                       last_norm=(self.norm_out, True), first=first_norm_of(stages[0]))
         h = self.norm_out.apply_ndhwc(h, True, dt)
         trim = self.time_padding if self.version == "v1_0" else 0
         return self.conv_out.run(h, dt, out_layout=L.VT_NCTHW, t_trim=trim)

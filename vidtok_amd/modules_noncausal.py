@@ -15,7 +15,8 @@ import torch.nn as nn
 
 from . import lib as L
 from . import ops
-from .modules import Downsample, Normalize, ResnetBlock, Upsample, _check_norm, _level_module
+from .modules import (Downsample, Normalize, ResnetBlock, Upsample, _check_norm, _emit, _level_module, _wrap,
+                      first_norm_of, plain, run_stages)
 from .ops import ConvGeom
 from .packing import PackedCache
 
@@ -50,11 +51,12 @@ class TimeDownsampleRes2x(nn.Module):
         self.mix_factor = nn.Parameter(torch.Tensor([mix_factor]))
         self._pack = PackedCache()
 
-    def run(self, x, dt):
+    def run(self, x, dt, next_norm=None):
+        x = plain(x)
         x1 = ops.time_avgpool3s2(x, L.VT_TPAD_ZERO_BACK)
         g = ConvGeom(kt=3, kh=3, kw=3, st=2, pt=0, pt_hi=1, ph=1, pw=1, ph_hi=1, pw_hi=1)
-        return _Conv3dSym.run(self.conv, self._pack, x, dt, g, res=x1, res_mode=L.VT_RES_MIX,
-                              mix_factor=self.mix_factor.detach())
+        return _wrap(_Conv3dSym.run(self.conv, self._pack, x, dt, g, res=x1, res_mode=L.VT_RES_MIX,
+                                    mix_factor=self.mix_factor.detach(), **_emit(next_norm)), next_norm)
 
 
 class TimeUpsampleRes2x(nn.Module):
@@ -67,9 +69,11 @@ class TimeUpsampleRes2x(nn.Module):
         self.mix_factor = nn.Parameter(torch.Tensor([mix_factor]))
         self._pack = PackedCache()
 
-    def run(self, x, dt):
-        return _Conv3dSym.run(self.conv, self._pack, x, dt, _Conv3dSym.geom(self.conv, ups_t=1), res=x,
-                              res_mode=L.VT_RES_MIX, res_tshift=1, mix_factor=self.mix_factor.detach())
+    def run(self, x, dt, next_norm=None):
+        x = plain(x)
+        return _wrap(_Conv3dSym.run(self.conv, self._pack, x, dt, _Conv3dSym.geom(self.conv, ups_t=1), res=x,
+                                    res_mode=L.VT_RES_MIX, res_tshift=1, mix_factor=self.mix_factor.detach(),
+                                    **_emit(next_norm)), next_norm)
 
 
 class _ResnetSym(nn.Module):
@@ -94,10 +98,15 @@ class _ResnetSym(nn.Module):
             self.conv2.bias.data.zero_()
         self._p1, self._p2 = PackedCache(), PackedCache()
 
-    def run(self, x, dt):
+    def first_norm(self):
+        return (self.norm1, True)
+
+    def run(self, x, dt, next_norm=None):
         h = self.norm1.apply_ndhwc(x, True, dt)
+        x = plain(x)
         h = _Conv3dSym.run(self.conv1, self._p1, h, dt, ln=self.norm2.fused(True), ln_keep_y=False)
-        return _Conv3dSym.run(self.conv2, self._p2, h, dt, res=x, res_mode=L.VT_RES_ADD)
+        return _wrap(_Conv3dSym.run(self.conv2, self._p2, h, dt, res=x, res_mode=L.VT_RES_ADD, **_emit(next_norm)),
+                     next_norm)
 
 
 class ResnetBlock1D(_ResnetSym):
@@ -130,10 +139,14 @@ class AttnBlockWrapper(nn.Module):
         self.proj_out = nn.Conv3d(in_channels, in_channels, kernel_size=1, stride=1, padding=0)
         self._pq, self._pk, self._pv, self._po = PackedCache(), PackedCache(), PackedCache(), PackedCache()
 
-    def run(self, x, dt):
+    def first_norm(self):
+        return (self.norm, False)
+
+    def run(self, x, dt, next_norm=None):
+        hn = self.norm.apply_ndhwc(x, False, dt)
+        x = plain(x)
         B, T, H, W, Cc = x.shape
         S, Z = H * W, B * T
-        hn = self.norm.apply_ndhwc(x, False, dt)
         q = _Conv3dSym.run(self.q, self._pq, hn, dt).view(Z, S, Cc)
         k = _Conv3dSym.run(self.k, self._pk, hn, dt).view(Z, S, Cc)
         wv, bv = self._pv.get(self.v.weight, self.v.bias, dt, cin_stored=Cc)
@@ -142,7 +155,8 @@ class AttnBlockWrapper(nn.Module):
         s = ops.gemm_nt(q, k, out_dtype=torch.float32)
         p = ops.softmax_rows(s, float(Cc) ** -0.5, dt, ld_out=Sp)
         o = ops.gemm_nt(p, vT, bias=bv).view(B, T, H, W, Cc)
-        return _Conv3dSym.run(self.proj_out, self._po, o, dt, res=x, res_mode=L.VT_RES_ADD)
+        return _wrap(_Conv3dSym.run(self.proj_out, self._po, o, dt, res=x, res_mode=L.VT_RES_ADD, **_emit(next_norm)),
+                     next_norm)
 
 
 class Encoder3D(nn.Module):
@@ -201,18 +215,18 @@ class Encoder3D(nn.Module):
             raise ValueError("Mismatched number of input channels")
         dt = self.compute_dtype
         h = ops.ncthw_to_ndhwc(x.contiguous().float(), dt)
-        h = _Conv3dSym.run(self.conv_in, self._pin, h, dt)
+        stages = []
         for i_level in range(self.num_resolutions):
             for i_block in range(self.num_res_blocks):
-                h = self.down[i_level].block[i_block].run(h, dt)
-                h = self.down_temporal[i_level].block[i_block].run(h, dt)
+                stages += [self.down[i_level].block[i_block], self.down_temporal[i_level].block[i_block]]
             if i_level != self.num_resolutions - 1:
-                h = self.down[i_level].downsample.run(h, dt)
+                stages.append(self.down[i_level].downsample)
                 if i_level in self.tempo_ds:
-                    h = self.down_temporal[i_level].downsample.run(h, dt)
-        h = self.mid.block_1.run(h, dt)
-        h = self.mid.attn_1.run(h, dt)
-        h = self.mid.block_2.run(h, dt)
+                    stages.append(self.down_temporal[i_level].downsample)
+        stages += [self.mid.block_1, self.mid.attn_1, self.mid.block_2]
+        first = first_norm_of(stages[0])
+        h = run_stages(stages, _Conv3dSym.run(self.conv_in, self._pin, h, dt, **_emit(first)), dt,
+                       last_norm=(self.norm_out, True), first=first)
         h = self.norm_out.apply_ndhwc(h, True, dt)
         return _Conv3dSym.run(self.conv_out, self._pout, h, dt, out_layout=L.VT_NCTHW)
 
@@ -275,17 +289,16 @@ class Decoder3D(nn.Module):
     def forward(self, z):
         dt = self.compute_dtype
         h = ops.ncthw_to_ndhwc(z.contiguous().float(), dt)
-        h = _Conv3dSym.run(self.conv_in, self._pin, h, dt)
-        h = self.mid.block_1.run(h, dt)
-        h = self.mid.attn_1.run(h, dt)
-        h = self.mid.block_2.run(h, dt)
+        stages = [self.mid.block_1, self.mid.attn_1, self.mid.block_2]
         for i_level in reversed(range(self.num_resolutions)):
             for i_block in range(self.num_res_blocks + 1):
-                h = self.up[i_level].block[i_block].run(h, dt)
-                h = self.up_temporal[i_level].block[i_block].run(h, dt)
+                stages += [self.up[i_level].block[i_block], self.up_temporal[i_level].block[i_block]]
             if i_level != 0:
-                h = self.up[i_level].upsample.run(h, dt)
+                stages.append(self.up[i_level].upsample)
                 if i_level in self.tempo_us:
-                    h = self.up_temporal[i_level].upsample.run(h, dt)
+                    stages.append(self.up_temporal[i_level].upsample)
+        first = first_norm_of(stages[0])
+        h = run_stages(stages, _Conv3dSym.run(self.conv_in, self._pin, h, dt, **_emit(first)), dt,
+                       last_norm=(self.norm_out, True), first=first)
         h = self.norm_out.apply_ndhwc(h, True, dt)
         return _Conv3dSym.run(self.conv_out, self._pout, h, dt, out_layout=L.VT_NCTHW)
