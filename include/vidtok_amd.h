@@ -144,6 +144,21 @@ int vt_layernorm_act(const void* x, int in_dtype, int64_t ldx, void* y, int out_
                      const float* gamma, const float* beta, int64_t M, int32_t C, float eps,
                      int32_t silu, vt_stream stream);
 
+/* ------------------------------------------------------------------------------------------
+ * vt_groupnorm_act -- torch.nn.GroupNorm(32, C, eps, affine) optionally followed by SiLU: the `norm_type: groupnorm`
+ * branch of Normalize() (model_3dcausal.py:30-34; no shipped config selects it).  GroupNorm normalises over
+ * (C/groups, *spatial) of the view its call site passes, so the reduction domain is a parameter:
+ *   VT_GN_FRAME  spatial ResnetBlock on "(b t) c h w"  (model_3dcausal.py:14-19, 317-337)  per (b,t,g) over (C/G,H,W)
+ *   VT_GN_PIXEL  temporal blocks on "(b h w) c t"       (model_3dcausal.py:20-23, 473-499)  per (b,h,w,g) over (C/G,T)
+ *   VT_GN_CLIP   3-D blocks, attention norm, norm_out on "b c t h w"                          per (b,g) over (C/G,T,H,W)
+ * x [B][T][HW][ldx], y [B][T][HW][ldy]; gamma, beta fp32 [C]; work: vt_groupnorm_work_bytes() bytes (fp64 sums).
+ * ---------------------------------------------------------------------------------------- */
+typedef enum { VT_GN_FRAME = 0, VT_GN_PIXEL = 1, VT_GN_CLIP = 2 } vt_gn_scope;
+int64_t vt_groupnorm_work_bytes(int32_t B, int32_t T, int32_t groups, int32_t scope);
+int vt_groupnorm_act(const void* x, int in_dtype, int64_t ldx, void* y, int out_dtype, int64_t ldy,
+                     const float* gamma, const float* beta, int32_t B, int32_t T, int64_t HW, int32_t C,
+                     int32_t groups, int32_t scope, float eps, int32_t silu, void* work, vt_stream stream);
+
 /* row softmax(scale * s) over the last dim; s fp32 [rows][cols] -> p (out_dtype) [rows][ldp].
  * The softmax inside F.scaled_dot_product_attention (model_3dcausal.py:140), scale = C^-0.5. */
 int vt_softmax_rows(const float* s, void* p, int out_dtype, int64_t rows, int32_t cols,
@@ -211,6 +226,12 @@ int vt_fsq_aux_stats(const float* h, const int32_t* levels_host, int32_t D, int3
 int vt_gather_frames(const void* src, void* dst, int32_t esize, int32_t B, int64_t frame_elems,
                      int64_t src_bstride, int64_t dst_bstride, const int32_t* idx_host, int32_t n,
                      vt_stream stream);
+
+/* nn.Linear along the channel axis of an NCTHW fp32 tensor viewed as [B][Cin][S] -> [B][Cout][S]:
+ * FSQRegularizer.project_in / project_out when dim != len(levels) (vidtok/modules/regularizers.py:137-139,225,255).
+ * w [Cout][Cin] row-major, bias [Cout] or NULL. */
+int vt_channel_linear(const float* x, const float* w, const float* bias, float* y, int32_t B, int32_t Cin,
+                      int32_t Cout, int64_t S, vt_stream stream);
 
 /* ------------------------------------------------------------------------------------------
  * evaluation metrics of the reference's eval loop: per frame

@@ -72,8 +72,9 @@ def load_reference_config(cfg_rel: str) -> dict:
     return cfg
 
 
-def load_reference_model(cfg_rel: str, seed: int = 0, overrides: dict = None):
-    """Instantiate the reference AutoencodingEngine (random init under `seed`), eval mode."""
+def load_reference_model(cfg_rel: str, seed: int = 0, overrides: dict = None, reg_overrides: dict = None):
+    """Instantiate the reference AutoencodingEngine (random init under `seed`), eval mode.  `overrides` update the
+    encoder/decoder params, `reg_overrides` the regularizer params (variants no shipped YAML exercises)."""
     _install_stubs()
     from vidtok.modules.util import instantiate_from_config  # reference vidtok/modules/util.py:69
 
@@ -81,6 +82,8 @@ def load_reference_model(cfg_rel: str, seed: int = 0, overrides: dict = None):
     if overrides:
         for k in ("encoder_config", "decoder_config"):
             cfg["model"]["params"][k]["params"].update(overrides)
+    if reg_overrides:
+        cfg["model"]["params"]["regularizer_config"].setdefault("params", {}).update(reg_overrides)
     torch.manual_seed(seed)
     model = instantiate_from_config(cfg["model"]).eval()
     return model, cfg

@@ -37,6 +37,30 @@ def layernorm_c(x, w, b, eps=1e-6):
     return y.movedim(-1, 1)
 
 
+def norm_c(sd, prefix, x, site="clip"):
+    """Normalize() of the reference at one call site, R/modules/model_3dcausal.py:30-34: the LayerNorm wrapper (keys
+    `<prefix>.norm.weight`) or, with `norm_type: groupnorm`, torch.nn.GroupNorm(32, C, eps=1e-6) (keys
+    `<prefix>.weight`).  GroupNorm normalises over the spatial axes of the VIEW the call site passes, `site`:
+    "frame" = "(b t) c h w" (spatial ResnetBlock :14-19; in the causal family also the 3-D blocks :402-413, the attention
+    norm :129-133 and norm_out :664-666), "pos" = "(b t) c s" with s = 1 (causal temporal blocks, :476-487),
+    "pixel" = "(b h w) c t" (non-causal temporal blocks, model_3dnoncausal.py:228-236), "clip" = the 5-D tensor
+    (non-causal 3-D blocks, attention norm, norm_out)."""
+    if (prefix + ".norm.weight") in sd:
+        return layernorm_c(x, sd[prefix + ".norm.weight"], sd[prefix + ".norm.bias"])
+    w, b = sd[prefix + ".weight"], sd[prefix + ".bias"]
+    B, C, T, H, W = x.shape
+    if site == "frame":
+        v = F.group_norm(x.permute(0, 2, 1, 3, 4).reshape(B * T, C, H, W), 32, w, b, 1e-6)
+        return v.reshape(B, T, C, H, W).permute(0, 2, 1, 3, 4)
+    if site == "pixel":
+        v = F.group_norm(x.permute(0, 3, 4, 1, 2).reshape(B * H * W, C, T), 32, w, b, 1e-6)
+        return v.reshape(B, H, W, C, T).permute(0, 3, 4, 1, 2)
+    if site == "pos":
+        v = F.group_norm(x.permute(0, 2, 3, 4, 1).reshape(-1, C, 1), 32, w, b, 1e-6)
+        return v.reshape(B, T, H, W, C).permute(0, 4, 1, 2, 3)
+    return F.group_norm(x, 32, w, b, 1e-6)
+
+
 class ChunkState:
     """Chunk-to-chunk state of the v1.1 models (R/modules/model_3dcausal_v1_1.py:155-157, 212-214,
     286-287, 323-324 and R/models/autoencoder_v1_1.py:202-216)."""
@@ -109,9 +133,9 @@ def conv2d_frames(sd, name, x, stride=1, pad=(1, 1, 1, 1)):
 # --------------------------------------------------------------------------------------------------
 def resnet_block_2d(sd, p, x):
     """ResnetBlock._forward, R/modules/model_3dcausal.py:317-337."""
-    h = silu(layernorm_c(x, sd[p + ".norm1.norm.weight"], sd[p + ".norm1.norm.bias"]))
+    h = silu(norm_c(sd, p + ".norm1", x, "frame"))
     h = conv2d_frames(sd, p + ".conv1", h)
-    h = silu(layernorm_c(h, sd[p + ".norm2.norm.weight"], sd[p + ".norm2.norm.bias"]))
+    h = silu(norm_c(sd, p + ".norm2", h, "frame"))
     h = conv2d_frames(sd, p + ".conv2", h)
     if (p + ".nin_shortcut.weight") in sd:
         x = conv2d_frames(sd, p + ".nin_shortcut", x, pad=(0, 0, 0, 0))
@@ -122,9 +146,10 @@ def resnet_block_causal(sd, p, x, version, state):
     """ResnetCausalBlock (3-D convs) and ResnetCausalBlock1D (temporal convs): same dataflow,
     R/modules/model_3dcausal.py:400-424 and 473-499.  The 1-D block's LayerNorm sees
     '(b t) c s' with s = 1, i.e. again per-position over C."""
-    h = silu(layernorm_c(x, sd[p + ".norm1.norm.weight"], sd[p + ".norm1.norm.bias"]))
+    site = "pos" if sd[p + ".conv1.conv.weight"].dim() == 3 else "frame"   # temporal block: single positions; 3-D: frames
+    h = silu(norm_c(sd, p + ".norm1", x, site))
     h = causal_conv(sd, p + ".conv1.conv", h, version, state)
-    h = silu(layernorm_c(h, sd[p + ".norm2.norm.weight"], sd[p + ".norm2.norm.bias"]))
+    h = silu(norm_c(sd, p + ".norm2", h, site))
     h = causal_conv(sd, p + ".conv2.conv", h, version, state)
     if (p + ".nin_shortcut.conv.weight") in sd:
         x = causal_conv(sd, p + ".nin_shortcut.conv", x, version, state)
@@ -135,7 +160,7 @@ def attn_block(sd, p, x, version, state):
     """AttnBlockWrapper.attention + AttnBlock._forward, R/modules/model_3dcausal.py:114-118, 129-141:
     batch b, 'heads' = frames t, sequence h*w, head_dim c, scale c^-0.5, no mask."""
     B, C, T, H, W = x.shape
-    hn = layernorm_c(x, sd[p + ".norm.norm.weight"], sd[p + ".norm.norm.bias"])
+    hn = norm_c(sd, p + ".norm", x, "frame")
     q = causal_conv(sd, p + ".q.conv", hn, version, state)
     k = causal_conv(sd, p + ".k.conv", hn, version, state)
     v = causal_conv(sd, p + ".v.conv", hn, version, state)
@@ -217,7 +242,7 @@ def encoder_forward(sd, params, x, version="v1_0", state: Optional[ChunkState] =
     h = resnet_block_causal(sd, f"{prefix}.mid.block_1", h, version, state)
     h = attn_block(sd, f"{prefix}.mid.attn_1", h, version, state)
     h = resnet_block_causal(sd, f"{prefix}.mid.block_2", h, version, state)
-    h = silu(layernorm_c(h, sd[f"{prefix}.norm_out.norm.weight"], sd[f"{prefix}.norm_out.norm.bias"]))
+    h = silu(norm_c(sd, f"{prefix}.norm_out", h, "frame"))
     return causal_conv(sd, f"{prefix}.conv_out.conv", h, version, state)
 
 
@@ -250,7 +275,7 @@ def decoder_forward(sd, params, z, version="v1_0", state: Optional[ChunkState] =
             h = conv2d_frames(sd, f"{prefix}.up.{lvl}.upsample.conv", h)
             if lvl in tempo_us:
                 h = time_upsample(sd, f"{prefix}.up_temporal.{lvl}.upsample", h, version, state, mode, n_of[lvl])
-    h = silu(layernorm_c(h, sd[f"{prefix}.norm_out.norm.weight"], sd[f"{prefix}.norm_out.norm.bias"]))
+    h = silu(norm_c(sd, f"{prefix}.norm_out", h, "frame"))
     h = causal_conv(sd, f"{prefix}.conv_out.conv", h, version, state)
     return h[:, :, f - 1:] if version == "v1_0" else h
 
@@ -276,16 +301,17 @@ def conv_centered(sd, name, x, stride=(1, 1, 1), pad=None):
 def resnet_block_centered(sd, p, x):
     """ResnetBlock1D._forward / ResnetNoncausalBlock._forward, R/modules/model_3dnoncausal.py:228-248, 291-311
     (the channel-changing shortcut is never instantiated: in_channels == out_channels at every call site)."""
-    h = silu(layernorm_c(x, sd[p + ".norm1.norm.weight"], sd[p + ".norm1.norm.bias"]))
+    site = "pixel" if sd[p + ".conv1.weight"].dim() == 3 else "clip"
+    h = silu(norm_c(sd, p + ".norm1", x, site))
     h = conv_centered(sd, p + ".conv1", h)
-    h = silu(layernorm_c(h, sd[p + ".norm2.norm.weight"], sd[p + ".norm2.norm.bias"]))
+    h = silu(norm_c(sd, p + ".norm2", h, site))
     return x + conv_centered(sd, p + ".conv2", h)
 
 
 def attn_block_nc(sd, p, x):
     """AttnBlockWrapper of the non-causal file (1x1x1 Conv3d projections), R/modules/model_3dnoncausal.py:17-34."""
     B, C, T, H, W = x.shape
-    hn = layernorm_c(x, sd[p + ".norm.norm.weight"], sd[p + ".norm.norm.bias"])
+    hn = norm_c(sd, p + ".norm", x, "clip")
     q, k, v = (conv_centered(sd, f"{p}.{n}", hn).permute(0, 2, 3, 4, 1).reshape(B, T, H * W, C) for n in "qkv")
     att = torch.softmax(q @ k.transpose(-1, -2) * (C ** -0.5), dim=-1)
     o = (att @ v).reshape(B, T, H, W, C).permute(0, 4, 1, 2, 3)
@@ -324,7 +350,7 @@ def encoder3d_forward(sd, params, x, prefix="encoder"):
     h = resnet_block_centered(sd, f"{prefix}.mid.block_1", h)
     h = attn_block_nc(sd, f"{prefix}.mid.attn_1", h)
     h = resnet_block_centered(sd, f"{prefix}.mid.block_2", h)
-    h = silu(layernorm_c(h, sd[f"{prefix}.norm_out.norm.weight"], sd[f"{prefix}.norm_out.norm.bias"]))
+    h = silu(norm_c(sd, f"{prefix}.norm_out", h, "clip"))
     return conv_centered(sd, f"{prefix}.conv_out", h)
 
 
@@ -344,7 +370,7 @@ def decoder3d_forward(sd, params, z, prefix="decoder"):
             h = conv2d_frames(sd, f"{prefix}.up.{lvl}.upsample.conv", h)
             if lvl in (1, 2):
                 h = time_upsample_nc(sd, f"{prefix}.up_temporal.{lvl}.upsample", h)
-    h = silu(layernorm_c(h, sd[f"{prefix}.norm_out.norm.weight"], sd[f"{prefix}.norm_out.norm.bias"]))
+    h = silu(norm_c(sd, f"{prefix}.norm_out", h, "clip"))
     return conv_centered(sd, f"{prefix}.conv_out", h)
 
 
@@ -454,12 +480,21 @@ class OracleEngine:
         return self.t_chunk_enc // self.f
 
     # -- regularizer --------------------------------------------------------------------------------
+    def _project(self, name, x):
+        """nn.Linear along the channel axis (FSQ project_in / project_out, R/modules/regularizers.py:137-139,225,255)"""
+        w, b = self.sd[f"regularization.{name}.weight"], self.sd[f"regularization.{name}.bias"]
+        return (torch.einsum("oc,bc...->bo...", w, x) + b.reshape((1, -1) + (1,) * (x.dim() - 2))).contiguous()
+
     def regularize(self, h):
         if self.reg_kind == "kl":
             return kl_regularize(h, sample=self.sample)
-        return fsq_regularize(h, self.reg_params["levels"],
-                              **{k: v for k, v in self.reg_params.items() if k not in ("levels",)},
-                              with_aux=self.with_aux)
+        proj = "regularization.project_in.weight" in self.sd      # dim != len(levels)
+        if proj:
+            h = self._project("project_in", h)
+        z, log = fsq_regularize(h, self.reg_params["levels"],
+                                **{k: v for k, v in self.reg_params.items() if k not in ("levels", "dim")},
+                                with_aux=self.with_aux)
+        return (self._project("project_out", z) if proj else z), log
 
     # -- chunks (R/models/autoencoder_v1_1.py:218-228) ---------------------------------------------
     def chunks(self, t, decoder_mode=False):
@@ -502,7 +537,8 @@ class OracleEngine:
                    "indices": torch.cat([d["indices"] for d in logs], dim=1)}
 
     def indices_to_latent(self, idx):
-        return fsq_indices_to_codes(idx, self.reg_params["levels"])
+        z = fsq_indices_to_codes(idx, self.reg_params["levels"])
+        return self._project("project_out", z) if "regularization.project_out.weight" in self.sd else z
 
     def _overlap_rules(self):
         """R/models/autoencoder_v1_1.py:307-320: sub-trees named by module path; later rules override."""

@@ -77,6 +77,30 @@ def test_matches_cpu_oracle(name, shape, dtype, tol):
         assert (qlog["indices"].cpu() != log2["indices"]).sum() <= 1
 
 
+@pytest.mark.parametrize("name,shape", [("vidtok_kl_causal_488_4chn", (1, 3, 9, 32, 32)),
+                                        ("vidtok_kl_noncausal_488_4chn", (1, 3, 8, 32, 32))])
+def test_groupnorm_variant_matches_oracle(name, shape):
+    model, cfg, sd = build_model(name, seed=6, device=DEV, overrides=dict(norm_type="groupnorm"))
+    ora = build_oracle(cfg, sd)
+    x = torch.rand(shape, generator=torch.Generator().manual_seed(3)) * 2 - 1
+    torch.manual_seed(4)
+    z, dec, log = model(x.to(DEV))
+    torch.manual_seed(4)
+    z2, dec2, log2 = ora(x)
+    assert rel_err(z, z2) < 1e-3 and rel_err(dec, dec2) < 1e-3
+
+
+def test_fsq_with_projections_matches_oracle():
+    model, cfg, sd = build_model("vidtok_fsq_causal_488_32768", seed=5, device=DEV, overrides=dict(z_channels=8),
+                                 reg_overrides=dict(dim=8, levels=[8, 8, 8, 5, 5, 5]))
+    ora = build_oracle(cfg, sd)
+    x = torch.rand((1, 3, 5, 32, 32), generator=torch.Generator().manual_seed(2)) * 2 - 1
+    z, dec, log = model(x.to(DEV))
+    z2, dec2, log2 = ora(x)
+    assert z.shape == (1, 8, 2, 4, 4) and rel_err(z, z2) < 1e-3 and rel_err(dec, dec2) < 1e-3
+    assert torch.equal(log["indices"].cpu(), log2["indices"])
+
+
 def test_v11_long_video_tiled_matches_oracle():
     name = "vidtok_v1_1/vidtok_kl_causal_488_16chn_v1_1"
     model, cfg, sd = build_model(name, seed=22, device=DEV, dtype=torch.float32)

@@ -286,6 +286,31 @@ def test_fsq_aux_stats(levels, B):
     assert torch.allclose(st, ref, rtol=2e-4, atol=2e-5)
 
 
+@pytest.mark.parametrize("din,dout", [(torch.float32, torch.float32), (torch.bfloat16, torch.bfloat16)],
+                         ids=["f32", "bf16"])
+@pytest.mark.parametrize("scope", [L.VT_GN_FRAME, L.VT_GN_PIXEL, L.VT_GN_CLIP, ops.GN_POS], ids=["frame", "pixel", "clip", "pos"])
+@pytest.mark.parametrize("C", [128, 512])
+def test_groupnorm_act(C, scope, din, dout):
+    x = _act(2, 5, 12, 10, C, din, 1) * 1.5 + 0.3
+    gam, bet = _rand((C,), torch.float32, 2, 0.3) + 1.0, _rand((C,), torch.float32, 3, 0.2)
+    y = ops.groupnorm_act(x, gam, bet, scope=scope, silu=True, out_dtype=dout)
+    yr = R.groupnorm_act(x.cpu(), gam.cpu(), bet.cpu(), scope=scope, silu=True, out_dtype=dout)
+    assert y.shape == yr.shape and y.dtype == yr.dtype
+    assert rel_err(y, yr) < (2e-5 if dout == torch.float32 else 1.2e-2)
+    y2 = ops.groupnorm_act(x, gam, bet, scope=scope, silu=False, out_dtype=dout)
+    assert rel_err(y2, R.groupnorm_act(x.cpu(), gam.cpu(), bet.cpu(), scope=scope, silu=False, out_dtype=dout)) < (
+        2e-5 if dout == torch.float32 else 1.2e-2)
+
+
+def test_channel_linear():
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn((2, 8, 3, 5, 7), generator=g).to(DEV)
+    w, b = torch.randn((6, 8), generator=g).to(DEV), torch.randn((6,), generator=g).to(DEV)
+    y = ops.channel_linear(x, w, b)
+    assert y.shape == (2, 6, 3, 5, 7) and rel_err(y, R.channel_linear(x.cpu(), w.cpu(), b.cpu())) < 1e-6
+    assert rel_err(ops.channel_linear(x, w, None), R.channel_linear(x.cpu(), w.cpu(), None)) < 1e-6
+
+
 def test_library_is_the_hip_extension():
     lib = L.load()
     assert lib.vt_version() >= 100 and L.LIB_PATH.endswith("libvidtok_amd.so")

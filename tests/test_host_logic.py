@@ -58,6 +58,38 @@ def test_other_causal_configs_match_oracle(name, shape, emulated_ops):
     assert rel_err(z, z2) < 2e-5 and rel_err(dec, dec2) < 5e-5
 
 
+@pytest.mark.parametrize("name,shape", [
+    ("vidtok_kl_causal_488_4chn", (1, 3, 5, 32, 32)),
+    ("vidtok_v1_1/vidtok_kl_causal_488_16chn_v1_1", (1, 3, 9, 32, 32)),
+    ("vidtok_kl_noncausal_488_4chn", (1, 3, 8, 32, 32)),
+])
+def test_groupnorm_variants_match_oracle(name, shape, emulated_ops):
+    """norm_type: groupnorm -- reference key names (no `.norm` level), site-dependent statistics, no epilogue fusion"""
+    model, cfg, sd = build_model(name, seed=6, overrides=dict(norm_type="groupnorm"))
+    assert "encoder.down.0.block.0.norm1.weight" in sd and "encoder.down.0.block.0.norm1.norm.weight" not in sd
+    ora = build_oracle(cfg, sd)
+    x = torch.rand(*shape) * 2 - 1
+    torch.manual_seed(1)
+    z, dec, log = model(x)
+    torch.manual_seed(1)
+    z2, dec2, log2 = ora(x)
+    assert dec.shape == dec2.shape and rel_err(z, z2) < 2e-5 and rel_err(dec, dec2) < 1e-4
+
+
+def test_fsq_with_projections_matches_oracle(emulated_ops):
+    """dim != len(levels): nn.Linear project_in / project_out (reference parameter names) around the quantiser"""
+    model, cfg, sd = build_model("vidtok_fsq_causal_488_32768", seed=5, overrides=dict(z_channels=8),
+                                 reg_overrides=dict(dim=8, levels=[8, 8, 8, 5, 5, 5]))
+    assert "regularization.project_in.weight" in sd and sd["regularization.project_out.weight"].shape == (8, 6)
+    ora = build_oracle(cfg, sd)
+    x = torch.rand(1, 3, 5, 32, 32) * 2 - 1
+    z, dec, log = model(x)
+    z2, dec2, log2 = ora(x)
+    assert z.shape == (1, 8, 2, 4, 4) and rel_err(z, z2) < 2e-5 and rel_err(dec, dec2) < 5e-5
+    assert torch.equal(log["indices"], log2["indices"])
+    assert rel_err(model.decode(log["indices"], decode_from_indices=True), dec) < 1e-6
+
+
 def test_api_surface_and_aliases(emulated_ops):
     import vidtok_amd
     from vidtok_amd.engine import AutoencodingEngine, AutoencodingEngineV11
@@ -87,9 +119,9 @@ def test_unsupported_variants_fail_loudly():
 
     with pytest.raises(NotImplementedError):
         EncoderCausal3DPadding(ch=32, out_ch=3, ch_mult=(1, 2), num_res_blocks=1, in_channels=3, z_channels=4,
-                               norm_type="groupnorm")
+                               norm_type="batchnorm")
     with pytest.raises(NotImplementedError):
-        FSQRegularizer(levels=[8, 8, 8], dim=6)
+        FSQRegularizer(levels=[8, 8, 8], num_codebooks=2)
 
 
 def test_product_path_has_no_cpu_fallback():

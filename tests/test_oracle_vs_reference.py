@@ -74,3 +74,57 @@ def test_oracle_matches_reference_v11_fsq_untiled():
         z2, dec2, log2 = ora(x)
     assert torch.equal(log["indices"], log2["indices"])
     assert rel_err(dec2, dec) < 5e-5
+
+
+FSQ_PROJ = dict(overrides=dict(z_channels=8), reg_overrides=dict(dim=8, levels=[8, 8, 8, 5, 5, 5]))
+
+
+def test_oracle_matches_reference_fsq_with_projections():
+    """dim != len(levels): project_in / project_out around the quantiser (no shipped YAML sets it)"""
+    ref, c = load_reference_model("vidtok_fsq_causal_488_32768", **FSQ_PROJ)
+    randomize_weights(ref)
+    assert ref.regularization.has_projections
+    ora = OracleEngine(c["model"]["params"], ref.state_dict())
+    x = torch.rand(1, 3, 5, 32, 32) * 2 - 1
+    with torch.no_grad():
+        z, dec, log = ref(x)
+        z2, dec2, log2 = ora(x)
+    assert z.shape == z2.shape == (1, 8, 2, 4, 4)
+    assert rel_err(z2, z) < 2e-5 and rel_err(dec2, dec) < 5e-5
+    assert torch.equal(log["indices"], log2["indices"])
+    assert rel_err(ora.decode(log2["indices"], decode_from_indices=True), dec) < 5e-5
+
+
+def _perturb_norm_affines(model, seed=3):
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            if "norm" in n and p.dim() == 1:
+                p.copy_((1.0 if n.endswith("weight") else 0.0) + 0.1 * torch.randn(p.shape, generator=g))
+
+
+@pytest.mark.parametrize("cfg,shape,tiled", [
+    ("vidtok_kl_causal_488_4chn", (1, 3, 5, 32, 32), False),
+    ("vidtok_fsq_causal_488_32768", (1, 3, 5, 32, 32), False),
+    ("vidtok_v1_1/vidtok_kl_causal_488_4chn_v1_1", (1, 3, 25, 32, 32), True),
+    ("vidtok_kl_noncausal_488_4chn", (1, 3, 8, 32, 32), False),
+])
+def test_oracle_matches_reference_groupnorm(cfg, shape, tiled):
+    """`norm_type: groupnorm` (no shipped YAML): torch.nn.GroupNorm(32) whose statistics follow the view of each call
+    site -- frames, single positions, pixels over time or whole clips (oracle norm_c)."""
+    ref, c = load_reference_model(cfg, overrides=dict(norm_type="groupnorm"))
+    randomize_weights(ref)
+    _perturb_norm_affines(ref)
+    assert "encoder.down.0.block.0.norm1.weight" in ref.state_dict()
+    ora = OracleEngine(c["model"]["params"], ref.state_dict())
+    if tiled:
+        for m in (ref, ora):
+            m.use_tiling, m.t_chunk_enc, m.use_overlap = True, 8, True
+        ref.t_chunk_dec = 2
+    x = torch.rand(*shape) * 2 - 1
+    with torch.no_grad():
+        torch.manual_seed(7)
+        z, dec, log = ref(x)
+        torch.manual_seed(7)
+        z2, dec2, log2 = ora(x)
+    assert rel_err(z2, z) < 2e-5 and rel_err(dec2, dec) < 1e-4

@@ -89,6 +89,30 @@ def layernorm_act(x, gamma, beta, *, silu, eps=1e-6, out_dtype=None, c=None):
     return out
 
 
+def groupnorm_act(x, gamma, beta, *, scope, silu, eps=1e-6, out_dtype=None, c=None, groups=32):
+    out_dtype = out_dtype or x.dtype
+    if scope == 3:                   # GN_POS: "(b t) c s" with s = 1
+        shp = x.shape
+        return groupnorm_act(x.reshape(1, 1, -1, 1, shp[-1]), gamma, beta, scope=L.VT_GN_PIXEL, silu=silu, eps=eps,
+                             out_dtype=out_dtype, c=c, groups=groups).reshape(shp)
+    B, T, H, W, ld = x.shape
+    c = c or ld
+    xc = x.float()[..., :c]
+    if scope == L.VT_GN_FRAME:       # "(b t) c h w"
+        v = F.group_norm(xc.reshape(B * T, H, W, c).permute(0, 3, 1, 2), groups, gamma.float()[:c], beta.float()[:c], eps)
+        v = v.permute(0, 2, 3, 1).reshape(B, T, H, W, c)
+    elif scope == L.VT_GN_PIXEL:     # "(b h w) c t"
+        v = F.group_norm(xc.permute(0, 2, 3, 4, 1).reshape(B * H * W, c, T), groups, gamma.float()[:c], beta.float()[:c], eps)
+        v = v.reshape(B, H, W, c, T).permute(0, 4, 1, 2, 3)
+    else:                            # "b c t h w"
+        v = F.group_norm(xc.permute(0, 4, 1, 2, 3), groups, gamma.float()[:c], beta.float()[:c], eps).permute(0, 2, 3, 4, 1)
+    if silu:
+        v = v * torch.sigmoid(v)
+    out = torch.zeros(x.shape, dtype=out_dtype, device=x.device)
+    out[..., :c] = v.to(out_dtype)
+    return out
+
+
 def softmax_rows(s, scale, out_dtype, ld_out=None):
     p = torch.softmax(s.float() * scale, dim=-1).to(out_dtype)
     if ld_out and ld_out > p.shape[-1]:
@@ -190,6 +214,13 @@ def fsq_consts(levels):
     return half_l.tolist(), offset.tolist(), shift.tolist(), [float(b) for b in basis]
 
 
+def channel_linear(x, w, bias):
+    y = torch.einsum("oc,bc...->bo...", w.float(), x.float())
+    if bias is not None:
+        y = y + bias.float().reshape((1, -1) + (1,) * (x.dim() - 2))
+    return y.contiguous()
+
+
 def eval_psnr_ssim(x, y, raw=True):
     """contract of vt_eval_psnr_ssim: per-frame PSNR / SSIM, [B,T] each (oracle/metrics_oracle.py is the restatement of
     the reference; this is the operator contract the host mirror is tested against on CPU)"""
@@ -202,7 +233,7 @@ def eval_psnr_ssim(x, y, raw=True):
 
 ALL = ["conv", "gemm_nt", "layernorm_act", "softmax_rows", "ncthw_to_ndhwc", "ndhwc_to_ncthw", "time_avgpool3s2",
        "time_lerp2x", "gather_frames", "kl_sample", "fsq_quantize", "fsq_indices_to_codes", "fsq_aux_stats",
-       "eval_psnr_ssim"]
+       "eval_psnr_ssim", "channel_linear", "groupnorm_act"]
 
 
 def patch_ops(monkeypatch):

@@ -41,11 +41,19 @@ def rel_err(a: torch.Tensor, b: torch.Tensor) -> float:
     return ((a - b).abs().max() / b.abs().max().clamp_min(1e-30)).item()
 
 
-def build_model(name: str, seed: int = 1234, device="cpu", dtype=torch.float32):
-    """vidtok_amd engine from configs/<name>.yaml with seeded weights; returns (model, cfg, state_dict)."""
+def build_model(name: str, seed: int = 1234, device="cpu", dtype=torch.float32, overrides=None, reg_overrides=None):
+    """vidtok_amd engine from configs/<name>.yaml with seeded weights; returns (model, cfg, state_dict).
+    `overrides` / `reg_overrides` update the encoder+decoder / regularizer params (variants without a YAML)."""
     import vidtok_amd
 
     cfg = vidtok_amd.load_config(config_path(name))
+    prm = cfg["model"]["params"]
+    if overrides:
+        prm["encoder_config"]["params"].update(overrides)
+        if isinstance(prm["decoder_config"]["params"], dict):
+            prm["decoder_config"]["params"].update(overrides)
+    if reg_overrides:
+        prm["regularizer_config"].setdefault("params", {}).update(reg_overrides)
     model = vidtok_amd.load_model_from_config(cfg, verbose=False)
     sd = seeded_state_dict({k: v.shape for k, v in model.state_dict().items()}, seed)
     missing, unexpected = model.load_state_dict(sd, strict=True)

@@ -236,6 +236,36 @@ extern "C" int vt_fsq_quantize(const float* h, float* z, int32_t* indices, const
   return VT_OK;
 }
 
+// y[b][o][s] = bias[o] + sum_i w[o][i] * x[b][i][s]  on NCTHW-flattened [B][C][S] fp32 tensors: nn.Linear along the
+// channel axis -- FSQ's project_in / project_out when dim != len(levels) (regularizers.py:137-139, 225, 255).
+// A few thousand positions x <= 64 channels: one thread per position, weights through the scalar cache.
+__global__ __launch_bounds__(kBlock) void channel_linear_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                               const float* __restrict__ bias, float* __restrict__ y,
+                                                               int B, int Cin, int Cout, long long S) {
+  const long long n = (long long)B * S;
+  for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < n; i += (long long)gridDim.x * kBlock) {
+    const long long b = i / S, sp = i - b * S;
+    const float* xb = x + b * Cin * S + sp;
+    float* yb = y + b * Cout * S + sp;
+    for (int o = 0; o < Cout; ++o) {
+      float acc = bias ? bias[o] : 0.0f;
+      for (int c = 0; c < Cin; ++c) acc = fmaf(w[o * Cin + c], xb[(long long)c * S], acc);
+      yb[(long long)o * S] = acc;
+    }
+  }
+}
+
+extern "C" int vt_channel_linear(const float* x, const float* w, const float* bias, float* y, int32_t B, int32_t Cin,
+                                 int32_t Cout, int64_t S, vt_stream stream_) {
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  VT_CHECK_ARG(x && w && y && B > 0 && Cin > 0 && Cout > 0 && S > 0 && Cin <= 1024 && Cout <= 1024,
+               "vt_channel_linear: bad arguments");
+  hipLaunchKernelGGL(channel_linear_kernel, dim3(grid_for((long long)B * S)), dim3(kBlock), 0, stream, x, w, bias, y, B,
+                     Cin, Cout, (long long)S);
+  VT_CHECK_LAUNCH();
+  return VT_OK;
+}
+
 extern "C" int vt_fsq_indices_to_codes(const int32_t* indices, float* z, const int32_t* levels_host, int32_t D,
                                        int32_t B, int64_t S, vt_stream stream_) {
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);

@@ -17,6 +17,7 @@ LIB_PATH = os.path.join(_HERE, "libvidtok_amd.so")
 
 VT_F32, VT_BF16, VT_I32 = 0, 1, 2
 VT_TPAD_ZERO, VT_TPAD_REPLICATE, VT_TPAD_CACHE, VT_TPAD_ZERO_BACK = 0, 1, 2, 3
+VT_GN_FRAME, VT_GN_PIXEL, VT_GN_CLIP = 0, 1, 2
 VT_RES_NONE, VT_RES_ADD, VT_RES_MIX = 0, 1, 2
 VT_NDHWC, VT_NCTHW = 0, 1
 
@@ -70,6 +71,10 @@ SIGNATURES = {
     "vt_fsq_indices_to_codes": (C.c_int, [_P, _P, C.POINTER(_I32), _I32, _I32, _I64, _P]),
     "vt_fsq_aux_work_floats": (_I64, [C.POINTER(_I32), _I32, _I32, _I64]),
     "vt_fsq_aux_stats": (C.c_int, [_P, C.POINTER(_I32), _I32, _I32, _I64, _F, _P, _P, _P]),
+    "vt_groupnorm_work_bytes": (_I64, [_I32, _I32, _I32, _I32]),
+    "vt_groupnorm_act": (C.c_int, [_P, C.c_int, _I64, _P, C.c_int, _I64, _P, _P, _I32, _I32, _I64, _I32, _I32, _I32,
+                                   C.c_float, _I32, _P, _P]),
+    "vt_channel_linear": (C.c_int, [_P, _P, _P, _P, _I32, _I32, _I32, _I64, _P]),
     "vt_eval_work_floats": (_I64, [_I32, _I32]),
     "vt_eval_psnr_ssim": (C.c_int, [_P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _P]),
     "vt_gather_frames": (C.c_int, [_P, _P, _I32, _I32, _I64, _I64, _I64, C.POINTER(_I32), _I32, _P]),

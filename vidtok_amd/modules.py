@@ -26,9 +26,16 @@ from .packing import PackedCache
 
 
 def _check_norm(norm_type):
-    if norm_type != "layernorm":
-        raise NotImplementedError(
-            f"norm_type={norm_type!r}: only 'layernorm' (used by every shipped VidTok config) has a HIP kernel")
+    if norm_type not in ("layernorm", "groupnorm"):
+        raise NotImplementedError(f"norm_type={norm_type!r}: the reference knows 'layernorm' and 'groupnorm'")
+
+
+# which view of the activation a norm's call site hands to it in the reference (matters for GroupNorm only, whose
+# statistics run over that view's spatial axes): "(b t) c h w", "(b h w) c t", "b c t h w", or "(b t) c s" with s = 1.
+# The causal family normalises per frame everywhere (model_3dcausal.py:402-413, 129-133, 664-666) except in its
+# temporal blocks, which see single positions (:476-487); the non-causal family uses the pixel and clip views
+# (model_3dnoncausal.py:228-236, 26, 477).
+SITE_FRAME, SITE_PIXEL, SITE_CLIP, SITE_POS = L.VT_GN_FRAME, L.VT_GN_PIXEL, L.VT_GN_CLIP, ops.GN_POS
 
 
 class Normed:
@@ -50,13 +57,13 @@ _EMIT_NEXT_NORM = os.environ.get("VIDTOK_AMD_EMIT_NEXT_NORM", "1") != "0"   # A/
 
 def _emit(next_norm):
     """kwargs for the last conv of a block: also emit the consumer's norm; `next_norm` = (LayerNorm, silu) or None"""
-    if next_norm is None or not _EMIT_NEXT_NORM:
+    if next_norm is None or not _EMIT_NEXT_NORM or not next_norm[0].fusable:
         return {}
     return dict(ln=next_norm[0].fused(next_norm[1]), ln_keep_y=True)
 
 
 def _wrap(out, next_norm):
-    if next_norm is None or not _EMIT_NEXT_NORM:
+    if next_norm is None or not _EMIT_NEXT_NORM or not next_norm[0].fusable:
         return out
     return Normed(out[0], out[1], next_norm[0], next_norm[1])
 
@@ -76,7 +83,9 @@ class LayerNorm(nn.Module):
             self._cache = (key, w.detach().float().contiguous(), b.detach().float().contiguous())
         return self._cache[1], self._cache[2]
 
-    def apply_ndhwc(self, x, silu, dt):
+    fusable = True     # per-position statistics: the producing conv can emit this norm from its epilogue
+
+    def apply_ndhwc(self, x, silu, dt, site=None):
         if isinstance(x, Normed):
             if x.norm is self and x.silu == silu:
                 return x.n            # the producing conv already applied this norm
@@ -89,10 +98,33 @@ class LayerNorm(nn.Module):
         g, b = self.affine()
         return (g, b, self.norm.eps, silu)
 
+    def after(self, conv, silu, dt, site=None):
+        """norm(conv(...)) where only the normalised tensor is needed: `conv(**kw)` runs the convolution"""
+        return conv(ln=self.fused(silu), ln_keep_y=False)
+
+
+class GroupNorm32(nn.GroupNorm):
+    """torch.nn.GroupNorm(32, C, eps=1e-6, affine=True) parameter holder -- `norm_type: groupnorm` of Normalize()
+    (model_3dcausal.py:30-32; state_dict keys `...norm1.weight / .bias`, no `.norm` level).  Its statistics span the
+    spatial axes of the call site's view, so it is never fused into a conv epilogue (vt_groupnorm_act)."""
+
+    fusable = False
+
+    def __init__(self, num_channels):
+        super().__init__(num_groups=32, num_channels=num_channels, eps=1e-6, affine=True)
+
+    def apply_ndhwc(self, x, silu, dt, site=SITE_FRAME):
+        x = plain(x)
+        return ops.groupnorm_act(x, self.weight.detach().float().contiguous(), self.bias.detach().float().contiguous(),
+                                 scope=site, silu=silu, eps=self.eps, out_dtype=dt, c=self.num_channels)
+
+    def after(self, conv, silu, dt, site=SITE_FRAME):
+        return self.apply_ndhwc(conv(), silu, dt, site)
+
 
 def Normalize(in_channels, norm_type="layernorm"):
     _check_norm(norm_type)
-    return LayerNorm(in_channels, eps=1e-6)
+    return GroupNorm32(in_channels) if norm_type == "groupnorm" else LayerNorm(in_channels, eps=1e-6)
 
 
 class _CausalState:
@@ -336,10 +368,10 @@ class ResnetBlock(nn.Module):
         return (self.norm1, True)
 
     def run(self, x, dt, next_norm=None):
-        h = self.norm1.apply_ndhwc(x, True, dt)
+        h = self.norm1.apply_ndhwc(x, True, dt, SITE_FRAME)
         x = plain(x)
-        # conv1's result is only ever seen through norm2 + SiLU: the conv emits that directly
-        h = _Conv2dHolder.run(self.conv1, self._p1, h, dt, _G3x3, ln=self.norm2.fused(True), ln_keep_y=False)
+        # conv1's result is only ever seen through norm2 + SiLU: with LayerNorm the conv emits that directly
+        h = self.norm2.after(lambda **kw: _Conv2dHolder.run(self.conv1, self._p1, h, dt, _G3x3, **kw), True, dt, SITE_FRAME)
         if self.in_channels != self.out_channels:
             x = _Conv2dHolder.run(self.nin_shortcut, self._p3, x, dt, _G1x1)
         return _wrap(_Conv2dHolder.run(self.conv2, self._p2, h, dt, _G3x3, res=x, res_mode=L.VT_RES_ADD,
@@ -366,9 +398,9 @@ class ResnetCausalBlock(nn.Module):
         return (self.norm1, True)
 
     def run(self, x, dt, next_norm=None):
-        h = self.norm1.apply_ndhwc(x, True, dt)
+        h = self.norm1.apply_ndhwc(x, True, dt, SITE_FRAME)
         x = plain(x)
-        h = self.conv1.run(h, dt, ln=self.norm2.fused(True), ln_keep_y=False)
+        h = self.norm2.after(lambda **kw: self.conv1.run(h, dt, **kw), True, dt, SITE_FRAME)
         if self.in_channels != self.out_channels:
             x = self.nin_shortcut.run(x, dt)
         return _wrap(self.conv2.run(h, dt, res=x, res_mode=L.VT_RES_ADD, **_emit(next_norm)), next_norm)
@@ -399,9 +431,9 @@ class ResnetCausalBlock1D(nn.Module):
         return (self.norm1, True)
 
     def run(self, x, dt, next_norm=None):
-        h = self.norm1.apply_ndhwc(x, True, dt)
+        h = self.norm1.apply_ndhwc(x, True, dt, SITE_POS)
         x = plain(x)
-        h = self.conv1.run(h, dt, ln=self.norm2.fused(True), ln_keep_y=False)
+        h = self.norm2.after(lambda **kw: self.conv1.run(h, dt, **kw), True, dt, SITE_POS)
         if self.in_channels != self.out_channels:
             x = self.nin_shortcut.run(x, dt)
         return _wrap(self.conv2.run(h, dt, res=x, res_mode=L.VT_RES_ADD, **_emit(next_norm)), next_norm)
@@ -426,7 +458,7 @@ class AttnBlockWrapper(nn.Module):
         return (self.norm, False)
 
     def run(self, x, dt, next_norm=None):
-        hn = self.norm.apply_ndhwc(x, False, dt)
+        hn = self.norm.apply_ndhwc(x, False, dt, SITE_FRAME)
         x = plain(x)
         B, T, H, W, Cc = x.shape
         S, Z = H * W, B * T
@@ -544,7 +576,7 @@ class EncoderCausal3DPadding(nn.Module):
         stages += [self.mid.block_1, self.mid.attn_1, self.mid.block_2]
         h = run_stages(stages, self.conv_in.run(h, dt, **_emit(first_norm_of(stages[0]))), dt,
                        last_norm=(self.norm_out, True), first=first_norm_of(stages[0]))
-        h = self.norm_out.apply_ndhwc(h, True, dt)
+        h = self.norm_out.apply_ndhwc(h, True, dt, SITE_FRAME)
         return self.conv_out.run(h, dt, out_layout=L.VT_NCTHW)
 
 
@@ -630,7 +662,7 @@ class DecoderCausal3DPadding(nn.Module):
                     stages.append(self.up_temporal[i_level].upsample)
         h = run_stages(stages, self.conv_in.run(h, dt, **_emit(first_norm_of(stages[0]))), dt,
                        last_norm=(self.norm_out, True), first=first_norm_of(stages[0]))
-        h = self.norm_out.apply_ndhwc(h, True, dt)
+        h = self.norm_out.apply_ndhwc(h, True, dt, SITE_FRAME)
         trim = self.time_padding if self.version == "v1_0" else 0
         return self.conv_out.run(h, dt, out_layout=L.VT_NCTHW, t_trim=trim)
 

@@ -15,8 +15,8 @@ import torch.nn as nn
 
 from . import lib as L
 from . import ops
-from .modules import (Downsample, Normalize, ResnetBlock, Upsample, _check_norm, _emit, _level_module, _wrap,
-                      first_norm_of, plain, run_stages)
+from .modules import (SITE_CLIP, SITE_PIXEL, Downsample, Normalize, ResnetBlock, Upsample, _check_norm, _emit,
+                      _level_module, _wrap, first_norm_of, plain, run_stages)
 from .ops import ConvGeom
 from .packing import PackedCache
 
@@ -79,6 +79,8 @@ class TimeUpsampleRes2x(nn.Module):
 class _ResnetSym(nn.Module):
     """LN-SiLU-conv-LN-SiLU-conv + x with centred convs; `make_conv(cin, cout, k)` builds the conv type."""
 
+    site = SITE_CLIP   # view the reference hands to this block's norms (GroupNorm statistics)
+
     def __init__(self, make_conv, *, in_channels, out_channels=None, conv_shortcut=False, dropout=0.0, temb_channels=0,
                  zero_init=False, use_checkpoint=False, norm_type="layernorm"):
         super().__init__()
@@ -102,9 +104,9 @@ class _ResnetSym(nn.Module):
         return (self.norm1, True)
 
     def run(self, x, dt, next_norm=None):
-        h = self.norm1.apply_ndhwc(x, True, dt)
+        h = self.norm1.apply_ndhwc(x, True, dt, self.site)
         x = plain(x)
-        h = _Conv3dSym.run(self.conv1, self._p1, h, dt, ln=self.norm2.fused(True), ln_keep_y=False)
+        h = self.norm2.after(lambda **kw: _Conv3dSym.run(self.conv1, self._p1, h, dt, **kw), True, dt, self.site)
         return _wrap(_Conv3dSym.run(self.conv2, self._p2, h, dt, res=x, res_mode=L.VT_RES_ADD, **_emit(next_norm)),
                      next_norm)
 
@@ -112,6 +114,8 @@ class _ResnetSym(nn.Module):
 class ResnetBlock1D(_ResnetSym):
     """Temporal block on the "(b h w) c t" view of the reference = taps along T on NDHWC; conv2 zero-initialised
     (model_3dnoncausal.py:182-248)."""
+
+    site = SITE_PIXEL
 
     def __init__(self, **kw):
         super().__init__(lambda ci, co: nn.Conv1d(ci, co, kernel_size=3, stride=1, padding=1), **kw)
@@ -143,7 +147,7 @@ class AttnBlockWrapper(nn.Module):
         return (self.norm, False)
 
     def run(self, x, dt, next_norm=None):
-        hn = self.norm.apply_ndhwc(x, False, dt)
+        hn = self.norm.apply_ndhwc(x, False, dt, SITE_CLIP)
         x = plain(x)
         B, T, H, W, Cc = x.shape
         S, Z = H * W, B * T
@@ -227,7 +231,7 @@ class Encoder3D(nn.Module):
         first = first_norm_of(stages[0])
         h = run_stages(stages, _Conv3dSym.run(self.conv_in, self._pin, h, dt, **_emit(first)), dt,
                        last_norm=(self.norm_out, True), first=first)
-        h = self.norm_out.apply_ndhwc(h, True, dt)
+        h = self.norm_out.apply_ndhwc(h, True, dt, SITE_CLIP)
         return _Conv3dSym.run(self.conv_out, self._pout, h, dt, out_layout=L.VT_NCTHW)
 
 
@@ -300,5 +304,5 @@ class Decoder3D(nn.Module):
         first = first_norm_of(stages[0])
         h = run_stages(stages, _Conv3dSym.run(self.conv_in, self._pin, h, dt, **_emit(first)), dt,
                        last_norm=(self.norm_out, True), first=first)
-        h = self.norm_out.apply_ndhwc(h, True, dt)
+        h = self.norm_out.apply_ndhwc(h, True, dt, SITE_CLIP)
         return _Conv3dSym.run(self.conv_out, self._pout, h, dt, out_layout=L.VT_NCTHW)

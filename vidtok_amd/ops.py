@@ -190,6 +190,30 @@ def layernorm_act(x, gamma, beta, *, silu: bool, eps: float = 1e-6, out_dtype=No
     return y
 
 
+GN_POS = 3   # host-level scope: statistics per position over the C/groups channels of a group (see groupnorm_act)
+
+
+def groupnorm_act(x, gamma, beta, *, scope, silu, eps=1e-6, out_dtype=None, c=None, groups=32):
+    """torch.nn.GroupNorm(groups, C)(+SiLU) on NDHWC x [B,T,H,W,ld]; `scope` = L.VT_GN_FRAME / PIXEL / CLIP says which
+    view of the tensor the reference's call site normalises (see include/vidtok_amd.h); GN_POS = the causal temporal
+    blocks, whose "(b t) c s" view has s = 1 (model_3dcausal.py:476-487)."""
+    lib = L.load()
+    _chk(x, "groupnorm.x")
+    if scope == GN_POS:     # per position over C/groups only: the PIXEL domain of a one-frame view
+        shp = x.shape
+        return groupnorm_act(x.reshape(1, 1, -1, 1, shp[-1]), gamma, beta, scope=L.VT_GN_PIXEL, silu=silu, eps=eps,
+                             out_dtype=out_dtype, c=c, groups=groups).reshape(shp)
+    B, T, H, W, ld = x.shape
+    c = c or ld
+    out_dtype = out_dtype or x.dtype
+    y = (torch.zeros if c != ld else torch.empty)(x.shape, dtype=out_dtype, device=x.device)
+    nbytes = lib.vt_groupnorm_work_bytes(B, T, groups, scope)
+    work = torch.empty((max(nbytes, 8) // 8,), dtype=torch.float64, device=x.device)
+    L.check(lib.vt_groupnorm_act(_ptr(x), _DT[x.dtype], ld, _ptr(y), _DT[out_dtype], ld, _ptr(gamma), _ptr(beta), B, T, H * W,
+                                 c, groups, scope, float(eps), int(bool(silu)), _ptr(work), _stream()), "vt_groupnorm_act")
+    return y
+
+
 def softmax_rows(s, scale: float, out_dtype, ld_out=None):
     """softmax(scale*s) over the last dim; ld_out > cols pads the output rows with zeros."""
     lib = L.load()
@@ -312,6 +336,19 @@ def fsq_indices_to_codes(idx, levels):
     L.check(lib.vt_fsq_indices_to_codes(_ptr(idx), _ptr(z), _levels_arr(levels), D, B, S, _stream()),
             "vt_fsq_indices_to_codes")
     return z
+
+
+def channel_linear(x, w, bias):
+    """nn.Linear along dim 1 of an fp32 [B, Cin, ...] tensor -> [B, Cout, ...] (FSQ project_in / project_out)."""
+    lib = L.load()
+    _chk(x, "linear.x"); _chk(w, "linear.w")
+    assert x.dtype == torch.float32 and w.dtype == torch.float32 and w.shape[1] == x.shape[1]
+    B, Cin = x.shape[0], x.shape[1]
+    S = x[0, 0].numel()
+    y = torch.empty((B, w.shape[0]) + tuple(x.shape[2:]), dtype=torch.float32, device=x.device)
+    L.check(lib.vt_channel_linear(_ptr(x), _ptr(w), _ptr(bias), _ptr(y), B, Cin, w.shape[0], S, _stream()),
+            "vt_channel_linear")
+    return y
 
 
 def fsq_aux_stats(h, levels, inv_temperature: float = 100.0):

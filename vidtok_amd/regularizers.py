@@ -64,10 +64,9 @@ class FSQRegularizer(nn.Module):
         assert not self.keep_num_codebooks_dim
         self.dim = self.codebook_dim if dim is None else dim
         self.has_projections = self.dim != self.effective_codebook_dim
-        if self.has_projections:
-            raise NotImplementedError(
-                "FSQ with project_in/project_out (dim != len(levels)) is a SURVEY section 8(f) 'next' item")
-        self.project_in, self.project_out = _Identity(), _Identity()
+        # same parameter names as the reference (regularizers.py:137-139): checkpoints load unchanged
+        self.project_in = nn.Linear(self.dim, self.effective_codebook_dim) if self.has_projections else _Identity()
+        self.project_out = nn.Linear(self.effective_codebook_dim, self.dim) if self.has_projections else _Identity()
         self.scale = scale
         self.entropy_loss_weight = entropy_loss_weight
         self.entropy_loss_annealing_steps = entropy_loss_annealing_steps
@@ -100,13 +99,23 @@ class FSQRegularizer(nn.Module):
     def indices_to_codes(self, indices: torch.Tensor, project_out=True) -> torch.Tensor:
         """indices int32 [B, ...] -> codes [B, D, ...] (regularizers.py:180-198, image/video form)."""
         assert indices.dim() >= 3, "expects [B, T, H, W] (or [B, H, W]) index maps"
-        return ops.fsq_indices_to_codes(indices.to(torch.int32).contiguous(), self.levels)
+        codes = ops.fsq_indices_to_codes(indices.to(torch.int32).contiguous(), self.levels)
+        if project_out and self.has_projections:
+            codes = self._linear(self.project_out, codes)
+        return codes
+
+    @staticmethod
+    def _linear(lin: nn.Linear, x):
+        return ops.channel_linear(x, lin.weight.detach().float().contiguous(),
+                                  None if lin.bias is None else lin.bias.detach().float().contiguous())
 
     @torch.no_grad()
     def forward(self, z: torch.Tensor, inv_temperature: float = 100.0, n_steps: int = 0):
         assert z.dim() >= 4, "expects [B, D, T, H, W]"
         assert z.shape[1] == self.dim, f"expected dimension of {self.dim} but found dimension of {z.shape[1]}"
         h = z.float().contiguous()
+        if self.has_projections:
+            h = self._linear(self.project_in, h)
         codes, indices = ops.fsq_quantize(h, self.levels)
         if self.compute_aux_loss and (self.entropy_loss_weight > 0 or self.commitment_loss_weight > 0):
             st = ops.fsq_aux_stats(h, self.levels, inv_temperature)
@@ -114,4 +123,6 @@ class FSQRegularizer(nn.Module):
             aux = entropy_aux * self.calculate_entropy_loss_weight(n_steps) + st[2] * self.commitment_loss_weight
         else:
             aux = self.zero.to(z.device) * 1.0
+        if self.has_projections:
+            codes = self._linear(self.project_out, codes)
         return codes, dict(indices=indices, aux_loss=aux)
