@@ -185,7 +185,17 @@ def main():
     # ---- roofline leg: per-launch HIP-event timeline of the conv kernel over one eager step --------
     roof = None
     if rank == 0:
+        # The eager step is enqueued behind a ~0.3 s device-side spin, so the host runs ahead and the conv kernels
+        # execute back to back: an event pair then brackets kernel time only, not the Python launch gaps of an
+        # un-graphed step (they inflated the short launches by 5-10 %).
+        c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        c0.record()
+        torch.cuda._sleep(10_000_000)
+        c1.record()
+        torch.cuda.synchronize()
+        cycles_per_ms = 10_000_000 / max(c0.elapsed_time(c1), 1e-3)
         ops.CONV_TIMELINE = []
+        torch.cuda._sleep(int(300 * cycles_per_ms))
         step()
         torch.cuda.synchronize()
         tl, ops.CONV_TIMELINE = ops.CONV_TIMELINE, None
