@@ -1,4 +1,4 @@
-// Pieces shared by the convolution kernels (conv_igemm.hip, conv_stream.hip).
+// Types and helpers of the convolution kernel (conv_igemm.hip).
 #pragma once
 #include <stdlib.h>
 
@@ -7,6 +7,28 @@
 namespace {
 
 constexpr int kRowBytes = 128;     // bytes of K per tile row per step
+
+// Division of a 32-bit unsigned by a launch-invariant divisor (Granlund-Montgomery round-up form): the host computes
+// (mul, shift), the device needs one mul_hi and three cheap ops instead of the ~25-instruction reciprocal sequence
+// the compiler emits for `/` by a runtime value.  12 of them per lane decode the pixel coordinates of a tile.
+struct FastDiv {
+  unsigned mul, shift, d;
+};
+inline FastDiv make_fastdiv(unsigned d) {
+  FastDiv f;
+  f.d = d;
+  if (d <= 1) { f.mul = 0; f.shift = 0; return f; }
+  unsigned l = 0;
+  while ((1ull << l) < d) ++l;
+  f.mul = (unsigned)((((1ull << 32) * ((1ull << l) - d)) / d) + 1);
+  f.shift = l - 1;
+  return f;
+}
+__device__ __forceinline__ unsigned fast_div(unsigned n, const FastDiv& f) {
+  if (f.d <= 1) return n;                       // uniform
+  const unsigned t = __umulhi(n, f.mul);
+  return (t + ((n - t) >> 1)) >> f.shift;
+}
 
 struct ConvArgs {
   const char* x;
@@ -33,10 +55,10 @@ struct ConvArgs {
   int m_tiles, n_tiles;
   int ln_mode, ln_keep_y, ldn;  // fused LayerNorm of the result (only set when the lds128 epilogue will run)
   float ln_eps;
+  FastDiv fd_wo, fd_ho, fd_to;   // pixel index -> (b, to, ho, wo)
   int lds_epi;                 // 128 x 128 tile: epilogue transposed through the LDS (coalesced rows)
   int hw_tiles;                // > 0: pixel tiles per frame, tile order (b, hw tile, t) -- see launch_variant
   unsigned x_bytes, w_bytes;   // BUF path: descriptor extents (0 = tensors too large, use pointers)
-  unsigned y_bytes, r_bytes;   // conv_stream: extents of the output / residual descriptors
   long long xs_z, ws_z, ys_z, rs_z;
 };
 

@@ -32,13 +32,12 @@
 // Measured dead ends (kept out of the code): register-staged operand tiles
 // (ds_write_b128 pass: 627 vs 440 TFLOP/s aggregate), a 4-stage ring of 64-B rows (no gain), 256x128 tiles
 // with 8 or 4 waves (slower), 3-4 waves/SIMD with 64-B rows (slower), LayerNorm in the MFMA-layout epilogue
-// (+1.6 ms per conv), a kw-innermost K walk (less fabric traffic, more time).  The persistent variant with a
-// deferred epilogue lives in conv_stream.hip (opt-in).
+// (+1.6 ms per conv), a kw-innermost K walk (less fabric traffic, more time), a persistent variant with a deferred
+// epilogue (conv_stream.hip in the git history: +3 % only, and its counted-vmcnt drain was not race-free in fp32).
 #include <type_traits>
 
 #include "conv_common.h"
 
-int vt_conv_stream_launch(const void* args, int dtype_code, hipStream_t stream);   // conv_stream.hip
 
 namespace {
 
@@ -418,12 +417,13 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_igemm_glds_ker
   for (int i = 0; i < A_VECS; ++i) {
     const int m = m_blk + srow + RSTEP * i;
     if (m < p.M) {
-      int wo = m % p.Wo;
-      int r = m / p.Wo;
-      int ho = r % p.Ho;
-      r /= p.Ho;
-      int to = r % p.To;
-      a_b[i] = r / p.To;
+      const unsigned r1 = fast_div((unsigned)m, p.fd_wo);
+      const int wo = m - (int)r1 * p.Wo;
+      const unsigned r2 = fast_div(r1, p.fd_ho);
+      const int ho = (int)r1 - (int)r2 * p.Ho;
+      const unsigned r3 = fast_div(r2, p.fd_to);
+      const int to = (int)r2 - (int)r3 * p.To;
+      a_b[i] = (int)r3;
       a_t0[i] = to * p.st - p.pt;
       a_h0[i] = ho * p.sh - p.ph;
       a_w0[i] = wo * p.sw - p.pw;
@@ -769,22 +769,6 @@ int launch_variant(const ConvArgs& a_in, int nbatch, hipStream_t stream) {
   const bool buf = conv_buf() && xb < 0xFFFF0000ull && wb < 0xFFFF0000ull && a.tmode != VT_TPAD_CACHE &&
                    a.KH <= 8 && a.KW <= 8;   // the per-row padding mask of the FAST form holds 8 bits per axis
   const void* kern;
-  if constexpr (WAVES_M == 2 && WAVES_N == 2 && TM == 2 && TN == 2 && FAST) {
-    // short tiles with many of them: the persistent kernel with the deferred epilogue (conv_stream.hip)
-    const bool plain_res = a.res_mode == VT_RES_NONE ||
-                           (a.res_mode == VT_RES_ADD && (a.ldr & 3) == 0 && a.res_tshift == 0 && a.Tr == a.To);
-    if (buf && env_int("VT_CONV_STREAM", 0) != 0 && nbatch == 1 && a.ln_mode == 0 && a.Cout % BN == 0 && a.M % BM == 0 &&
-        a.out_layout == VT_NDHWC && (a.ldy & 3) == 0 && plain_res && a.nsteps >= 4 && a.Cout <= 1024 &&
-        (long long)a.m_tiles * a.n_tiles >= 1024 && (unsigned long long)a.M * a.ldy * sizeof(TOut) < 0xFFFF0000ull &&
-        (unsigned long long)a.M * a.ldr * sizeof(TOut) < 0xFFFF0000ull) {
-      a.x_bytes = (unsigned)xb;
-      a.w_bytes = (unsigned)wb;
-      a.y_bytes = (unsigned)((unsigned long long)a.M * a.ldy * sizeof(TOut));
-      a.r_bytes = (unsigned)((unsigned long long)a.M * a.ldr * sizeof(TOut));
-      const int code = std::is_same<MT, float>::value ? 0 : (std::is_same<TOut, float>::value ? 1 : 2);
-      return vt_conv_stream_launch(&a, code, stream);
-    }
-  }
   if (buf) {
     a.x_bytes = (unsigned)xb;
     a.w_bytes = (unsigned)wb;
@@ -894,6 +878,7 @@ extern "C" int vt_conv(const vt_conv_desc* d, vt_stream stream_) {
   a.ldr = d->ldr;
   a.out_layout = d->out_layout; a.t_trim = d->t_trim;
   a.M = (int)M; a.ntaps = d->KT * d->KH * d->KW; a.K = a.ntaps * d->Cin;
+  a.fd_wo = make_fastdiv((unsigned)d->Wo); a.fd_ho = make_fastdiv((unsigned)d->Ho); a.fd_to = make_fastdiv((unsigned)d->To);
   a.xs_z = d->xs_z; a.ws_z = d->ws_z; a.ys_z = d->ys_z; a.rs_z = d->rs_z;
 
   // LayerNorm inside the epilogue: the 128 x 128 tile with the LDS epilogue on full tiles spanning the channel row
