@@ -87,6 +87,10 @@ int vt_conv_max_lds_bytes(void);
  * tv beyond the end reads 0.
  * Weights are pre-packed row-major [Cout][ldw], k = ((kt*KH+kh)*KW+kw)*Cin + c (see
  * vidtok_amd/packing.py), in the arithmetic dtype.
+ * yt_mul = 2 serves the convolutions over a nearest-x2 frame-repeated input (TimeUpsampleRes*2x): with u[t] = x[t>>1]
+ * the three temporal taps of an output frame hit only two input frames, so even and odd output frames are two 2-tap
+ * convolutions over x with pre-summed weights -- 2/3 of the MACs of the folded ups_t form, no up-sampled tensor
+ * either way (vidtok_amd/packing.py::time_upsample_parity_weights).
  * ln_mode != 0 additionally emits ln_out = [SiLU](LayerNorm_Cout(result) * gamma + beta), the norm that follows the
  * convolution inside the residual blocks (norm2 + nonlinearity after conv1, model_3dcausal.py:321-323,405-407,
  * 482-484).  When the tile spans the channel row (Cout = 128) the statistics are taken from the fp32 result inside
@@ -125,6 +129,8 @@ typedef struct vt_conv_desc {
   int32_t ln_mode;          /* 0 none, 1 LayerNorm over Cout, 2 LayerNorm + SiLU -> ln_out     */
   int32_t ln_keep_y;        /* 0: only ln_out is needed; y is then scratch (may stay unwritten) */
   int32_t ldn;              /* channel stride of ln_out                                        */
+  int32_t yt_mul, yt_off;   /* output frame interleave: computed frame f (b*To + to) is stored as frame
+                               f*yt_mul + yt_off of a y (and ln_out) holding To*yt_mul frames; 0/1 = off  */
   float ln_eps;
   int64_t xs_z, ws_z, ys_z, rs_z;   /* element strides between problems                       */
 } vt_conv_desc;

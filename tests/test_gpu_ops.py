@@ -140,6 +140,30 @@ def test_conv(case, dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+@pytest.mark.parametrize("cout,hw", [(128, (16, 16)), (256, (8, 8)), (512, (5, 7))])
+def test_conv_output_frame_interleave(cout, hw, dtype):
+    """yt_mul / yt_off: two k=2 launches fill the even / odd frames of one output (the parity convs of a time
+    up-sampler), through every epilogue: LDS-transposed (Cout 128, full tiles), vector, scalar (ragged)."""
+    B, T, (H, W), cin = 2, 3, hw, 128
+    x = _act(B, T, H, W, cin, dtype, 1)
+    g = torch.Generator().manual_seed(2)
+    geom = ConvGeom(kt=2, kh=3, kw=3, pt=1, ph=1, pw=1, ph_hi=1, pw_hi=1)
+    bias = _rand((cout,), torch.float32, 3, 0.1)
+    res = _act(B, T, H, W, cout, dtype, 4)
+    mf = torch.tensor([0.2], device=DEV)
+    y = torch.full((B, 2 * T, H, W, cout), float("nan"), dtype=dtype, device=DEV)
+    yr = torch.zeros((B, 2 * T, H, W, cout), dtype=dtype)
+    for par in (0, 1):
+        wt = torch.randn((cout, cin, 2, 3, 3), generator=g) / math.sqrt(cin * 18)
+        w = pack_conv_weight(wt, dtype, cin_stored=x.shape[-1]).to(DEV)
+        kw = dict(res=res, res_mode=L.VT_RES_MIX, mix_factor=mf)
+        ops.conv(x, w, bias, geom, cout=cout, out=y, out_t=(2, par), **kw)
+        R.conv(x.cpu(), w.cpu(), bias.cpu(), geom, cout=cout, out=yr, out_t=(2, par), **_cpu(kw))
+    torch.cuda.synchronize()
+    assert torch.isfinite(y.float()).all() and rel_err(y, yr) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
 @pytest.mark.parametrize("Z,M,N,K,bcast,use_bias", [(3, 80, 48, 128, False, False), (2, 512, 64, 512, True, True),
                                                       (5, 16, 16, 16, False, False), (2, 100, 512, 104, False, True),
                                                       (2, 1024, 1024, 512, False, False)])

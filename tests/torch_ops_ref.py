@@ -21,7 +21,17 @@ def _round_like(t, dtype):
 
 def conv(x, w, bias, geom, *, cout, out_dtype=None, tmode=L.VT_TPAD_ZERO, cache=None, res=None,
          res_mode=L.VT_RES_NONE, res_tshift=0, mix_factor=None, out_layout=L.VT_NDHWC, t_trim=0, ldy=None,
-         ln=None, ln_keep_y=True):
+         ln=None, ln_keep_y=True, out=None, ln_out=None, out_t=None):
+    if out_t is not None:          # this launch fills frames to*mul + off of preallocated tensors
+        mul, off = out_t
+        res_ = conv(x, w, bias, geom, cout=cout, out_dtype=out_dtype, tmode=tmode, cache=cache, res=res, res_mode=res_mode,
+                    res_tshift=res_tshift, mix_factor=mix_factor, ldy=out.shape[4], ln=ln, ln_keep_y=True if ln else ln_keep_y)
+        yv, nv = res_ if ln is not None else (res_, None)
+        out[:, off::mul] = yv
+        if ln is None:
+            return out
+        ln_out[:, off::mul] = nv
+        return (out, ln_out) if ln_keep_y else ln_out
     B, Ti, Hi, Wi, Cin = x.shape
     out_dtype = out_dtype or x.dtype
     xp = x.float().permute(0, 4, 1, 2, 3)  # NCTHW

@@ -30,6 +30,9 @@ __device__ __forceinline__ unsigned fast_div(unsigned n, const FastDiv& f) {
   return (t + ((n - t) >> 1)) >> f.shift;
 }
 
+struct ConvArgs;
+__device__ __forceinline__ long long out_row(const ConvArgs& p, int m);
+
 struct ConvArgs {
   const char* x;
   const char* w;
@@ -56,6 +59,9 @@ struct ConvArgs {
   int ln_mode, ln_keep_y, ldn;  // fused LayerNorm of the result (only set when the lds128 epilogue will run)
   float ln_eps;
   FastDiv fd_wo, fd_ho, fd_to;   // pixel index -> (b, to, ho, wo)
+  FastDiv fd_hw;                 // pixel index -> frame index (output frame interleave)
+  int yt_mul;                    // output frame of computed frame f is f * yt_mul + yt_off (1, 0 = plain)
+  long long yt_step, yt_base;    // (yt_mul - 1) * Ho*Wo and yt_off * Ho*Wo rows
   int lds_epi;                 // 128 x 128 tile: epilogue transposed through the LDS (coalesced rows)
   int hw_tiles;                // > 0: pixel tiles per frame, tile order (b, hw tile, t) -- see launch_variant
   unsigned x_bytes, w_bytes;   // BUF path: descriptor extents (0 = tensors too large, use pointers)
@@ -125,6 +131,13 @@ __device__ __forceinline__ void wait_vmcnt() {
 
 struct TagTrue { [[maybe_unused]] static constexpr bool value = true; };
 struct TagFalse { [[maybe_unused]] static constexpr bool value = false; };
+
+// Output pixel row of computed pixel m.  With yt_mul > 1 the launch computes every yt_mul-th frame of the output
+// tensor (the parity classes of a convolution over a x2 frame-repeated input, see vt_conv_desc.yt_mul).
+__device__ __forceinline__ long long out_row(const ConvArgs& p, int m) {
+  if (p.yt_mul == 1) return m;                                    // uniform
+  return (long long)m + (long long)fast_div((unsigned)m, p.fd_hw) * p.yt_step + p.yt_base;
+}
 
 // environment switch helper for same-run A/B measurements: value of `name` or `dflt`
 inline int env_int(const char* name, int dflt) {

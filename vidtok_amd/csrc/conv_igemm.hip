@@ -64,13 +64,13 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[T
   // per-pixel addresses (rows beyond M are clamped for loads; their stores are masked)
   bool store_ok[TM];
   long long mr[TM], ybase[TM];
-  int mrow[TM];
+  long long mrow[TM];
 #pragma unroll
   for (int b = 0; b < TM; ++b) {
     int m = m_blk + (wm * TM + b) * 32 + (lane & 31);
     store_ok[b] = m < p.M;
     if (m >= p.M) m = p.M - 1;
-    mrow[b] = m;
+    mrow[b] = out_row(p, m);
     mr[b] = m;
     ybase[b] = 0;
     if (p.res_tshift != 0 || p.Tr != p.To || p.out_layout == VT_NCTHW) {
@@ -131,7 +131,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[T
               if (p.res_mode == VT_RES_ADD) v[e] = rq[a][b][g].get(e) + v[e];
               if (p.res_mode == VT_RES_MIX) v[e] = alpha * rq[a][b][g].get(e) + (1.0f - alpha) * v[e];
             }
-            if (store_ok[b]) store_quad<TOut>(yg + (long long)mrow[b] * p.ldy + nq + 32 * (a0 + a) + 8 * g, v);
+            if (store_ok[b]) store_quad<TOut>(yg + mrow[b] * p.ldy + nq + 32 * (a0 + a) + 8 * g, v);
           }
     }
     return;
@@ -164,7 +164,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[T
             if (p.out_layout == VT_NCTHW)
               yg[ybase[b] + (long long)n * (p.To - p.t_trim) * HWo] = from_f32<TOut>(v);
             else
-              yg[(long long)mrow[b] * p.ldy + n] = from_f32<TOut>(v);
+              yg[mrow[b] * p.ldy + n] = from_f32<TOut>(v);
           }
         }
     }
@@ -298,7 +298,8 @@ __device__ __forceinline__ void conv_epilogue_lds128(const ConvArgs& p, f32x16 (
       if (p.res_mode == VT_RES_ADD) v[e] = rq[it].get(e) + v[e];
       if (p.res_mode == VT_RES_MIX) v[e] = alpha * rq[it].get(e) + (1.0f - alpha) * v[e];
     }
-    if (!p.ln_mode || p.ln_keep_y) Oct<TOut>::store(yg + (long long)(m_blk + row) * p.ldy + n_blk + 8 * oct_j, v);
+    const long long orow = out_row(p, m_blk + row);
+    if (!p.ln_mode || p.ln_keep_y) Oct<TOut>::store(yg + orow * p.ldy + n_blk + 8 * oct_j, v);
     if (p.ln_mode) {   // uniform; same two-pass statistics as layernorm_act_kernel, taken before the rounding to TOut
       float s = 0.f;
 #pragma unroll
@@ -317,7 +318,7 @@ __device__ __forceinline__ void conv_epilogue_lds128(const ConvArgs& p, f32x16 (
         const float u = v[e] * rstd * lg[e] + lb[e];
         o[e] = (p.ln_mode == 2) ? silu_fast(u) : u;
       }
-      Oct<TOut>::store(ng + (long long)(m_blk + row) * p.ldn + 8 * oct_j, o);
+      Oct<TOut>::store(ng + orow * p.ldn + 8 * oct_j, o);
     }
   }
 }
@@ -855,6 +856,10 @@ extern "C" int vt_conv(const vt_conv_desc* d, vt_stream stream_) {
   const long long M = (long long)d->B * d->To * d->Ho * d->Wo;
   VT_CHECK_ARG(M < (1ll << 31), "vt_conv: M too large");
   const int nbatch = d->nbatch > 0 ? d->nbatch : 1;
+  const int yt_mul = d->yt_mul > 0 ? d->yt_mul : 1;
+  if (yt_mul != 1)
+    VT_CHECK_ARG(d->out_layout == VT_NDHWC && nbatch == 1 && d->yt_off >= 0 && d->yt_off < yt_mul,
+                 "vt_conv: output frame interleave needs NDHWC, nbatch 1 and 0 <= yt_off < yt_mul");
   if (d->ln_mode != 0) {
     VT_CHECK_ARG(d->ln_mode == 1 || d->ln_mode == 2, "vt_conv: ln_mode %d", d->ln_mode);
     VT_CHECK_ARG(d->ln_gamma && d->ln_beta && d->ln_out, "vt_conv: fused LayerNorm needs gamma, beta and ln_out");
@@ -878,6 +883,10 @@ extern "C" int vt_conv(const vt_conv_desc* d, vt_stream stream_) {
   a.ldr = d->ldr;
   a.out_layout = d->out_layout; a.t_trim = d->t_trim;
   a.M = (int)M; a.ntaps = d->KT * d->KH * d->KW; a.K = a.ntaps * d->Cin;
+  a.yt_mul = yt_mul;
+  a.yt_step = (long long)(yt_mul - 1) * d->Ho * d->Wo;
+  a.yt_base = (long long)(yt_mul != 1 ? d->yt_off : 0) * d->Ho * d->Wo;
+  a.fd_hw = make_fastdiv((unsigned)(d->Ho * d->Wo));
   a.fd_wo = make_fastdiv((unsigned)d->Wo); a.fd_ho = make_fastdiv((unsigned)d->Ho); a.fd_to = make_fastdiv((unsigned)d->To);
   a.xs_z = d->xs_z; a.ws_z = d->ws_z; a.ys_z = d->ys_z; a.rs_z = d->rs_z;
 
@@ -894,6 +903,7 @@ extern "C" int vt_conv(const vt_conv_desc* d, vt_stream stream_) {
   else if (d->out_dtype == VT_F32) rc = dispatch_tile<bf16_t, float>(a, nbatch, stream);
   else rc = dispatch_tile<bf16_t, bf16_t>(a, nbatch, stream);
   if (rc != VT_OK || d->ln_mode == 0 || ln_fused) return rc;
+  VT_CHECK_ARG(yt_mul == 1, "vt_conv: LayerNorm of an interleaved output is only available fused (Cout = 128, full tiles)");
   // not fusable here: the same contract in two launches
   return vt_layernorm_act(d->y, d->out_dtype, d->ldy, d->ln_out, d->out_dtype, d->ldn, d->ln_gamma, d->ln_beta, M, d->Cout,
                           d->ln_eps, d->ln_mode == 2 ? 1 : 0, stream_);

@@ -45,6 +45,7 @@ class ConvDesc(C.Structure):
             "dtype", "out_dtype",
             "nbatch",
             "ln_mode", "ln_keep_y", "ldn",
+            "yt_mul", "yt_off",
         )]
         + [("ln_eps", C.c_float)]
         + [(n, C.c_int64) for n in ("xs_z", "ws_z", "ys_z", "rs_z")]

@@ -22,7 +22,7 @@ import torch.nn as nn
 from . import lib as L
 from . import ops
 from .ops import ConvGeom
-from .packing import PackedCache
+from .packing import PackedCache, time_upsample_parity_weights
 
 
 def _check_norm(norm_type):
@@ -318,6 +318,8 @@ class TimeUpsampleResCausal2x(nn.Module):
         self.version = version
         self.is_first_chunk = True
         self.causal_cache = None
+        self._parity_packs = (PackedCache(lambda w: time_upsample_parity_weights(w, early=True)),
+                              PackedCache(lambda w: time_upsample_parity_weights(w, early=False)))
 
     def _interp_v11(self, x):
         n, T = self.num_temp_upsample, x.shape[1]
@@ -340,8 +342,19 @@ class TimeUpsampleResCausal2x(nn.Module):
         x = plain(x)
         mf = self.mix_factor.detach()
         if self.version == "v1_0":
-            return _wrap(self.conv.run(x, dt, ups_t=1, res=x, res_mode=L.VT_RES_MIX, res_tshift=1, mix_factor=mf,
-                                       **_emit(next_norm)), next_norm)
+            # up(x)[t] = x[t >> 1]: the 3 temporal taps of an output frame hit 2 input frames, so even / odd output
+            # frames are two k=2 causal convs over x with pre-summed weights (2/3 of the MACs of the 27-tap form):
+            #   o[2j] = (W0+W1) x[j-1] + W2 x[j]      o[2j+1] = W0 x[j-1] + (W1+W2) x[j]
+            # each launch writes its frames of the interleaved output; the mix operand up(x)[2j+p] is x[j].
+            B, T, H, W, C = x.shape
+            ld = ops.pad_channels(self.conv.chan_out)
+            y = (torch.empty if ld == self.conv.chan_out else torch.zeros)((B, 2 * T, H, W, ld), dtype=dt, device=x.device)
+            g = ConvGeom(kt=2, kh=3, kw=3, pt=1, ph=1, pw=1, ph_hi=1, pw_hi=1)
+            for par, pack in enumerate(self._parity_packs):
+                w, b = pack.get(self.conv.conv.weight, self.conv.conv.bias, dt, cin_stored=C)
+                ops.conv(x, w, b, g, cout=self.conv.chan_out, tmode=L.VT_TPAD_ZERO, res=x, res_mode=L.VT_RES_MIX,
+                         mix_factor=mf, out=y, out_t=(2, par))
+            return y
         xi = self._interp_v11(x)
         return _wrap(self.conv.run(xi, dt, res=xi, res_mode=L.VT_RES_MIX, mix_factor=mf, **_emit(next_norm)), next_norm)
 

@@ -18,7 +18,7 @@ from . import ops
 from .modules import (SITE_CLIP, SITE_PIXEL, Downsample, Normalize, ResnetBlock, Upsample, _check_norm, _emit,
                       _level_module, _wrap, first_norm_of, plain, run_stages)
 from .ops import ConvGeom
-from .packing import PackedCache
+from .packing import PackedCache, time_upsample_parity_weights
 
 
 class _Conv3dSym:
@@ -67,13 +67,23 @@ class TimeUpsampleRes2x(nn.Module):
         super().__init__()
         self.conv = nn.Conv3d(in_channels, out_channels, 3, padding=1)
         self.mix_factor = nn.Parameter(torch.Tensor([mix_factor]))
-        self._pack = PackedCache()
+        # centred window over up(x)[t] = x[t >> 1]:  o[2j] = W0 x[j-1] + (W1+W2) x[j],  o[2j+1] = (W0+W1) x[j] + W2 x[j+1]
+        self._parity = ((PackedCache(lambda w: time_upsample_parity_weights(w, early=False)),
+                         ConvGeom(kt=2, kh=3, kw=3, pt=1, pt_hi=0, ph=1, pw=1, ph_hi=1, pw_hi=1)),
+                        (PackedCache(lambda w: time_upsample_parity_weights(w, early=True)),
+                         ConvGeom(kt=2, kh=3, kw=3, pt=0, pt_hi=1, ph=1, pw=1, ph_hi=1, pw_hi=1)))
 
     def run(self, x, dt, next_norm=None):
         x = plain(x)
-        return _wrap(_Conv3dSym.run(self.conv, self._pack, x, dt, _Conv3dSym.geom(self.conv, ups_t=1), res=x,
-                                    res_mode=L.VT_RES_MIX, res_tshift=1, mix_factor=self.mix_factor.detach(),
-                                    **_emit(next_norm)), next_norm)
+        B, T, H, W, C = x.shape
+        cout = self.conv.out_channels
+        ld = ops.pad_channels(cout)
+        y = (torch.empty if ld == cout else torch.zeros)((B, 2 * T, H, W, ld), dtype=dt, device=x.device)
+        for par, (pack, g) in enumerate(self._parity):      # two k=2 convs with pre-summed taps: 2/3 of the MACs
+            w, b = pack.get(self.conv.weight, self.conv.bias, dt, cin_stored=C)
+            ops.conv(x, w, b, g, cout=cout, res=x, res_mode=L.VT_RES_MIX, mix_factor=self.mix_factor.detach(),
+                     out=y, out_t=(2, par))
+        return y
 
 
 class _ResnetSym(nn.Module):

@@ -82,10 +82,12 @@ class ConvGeom:
 
 def conv(x, w, bias, geom: ConvGeom, *, cout: int, out_dtype=None, tmode=L.VT_TPAD_ZERO, cache=None,
          res=None, res_mode=L.VT_RES_NONE, res_tshift=0, mix_factor=None, out_layout=L.VT_NDHWC,
-         t_trim=0, ldy=None, ln=None, ln_keep_y=True):
+         t_trim=0, ldy=None, ln=None, ln_keep_y=True, out=None, ln_out=None, out_t=None):
     """y = conv(x) (+bias) (+res | alpha-mix); x [B,Ti,Hi,Wi,Cin], w packed [cout, ldw].
     ln = (gamma, beta, eps, silu) additionally returns n = [SiLU](LayerNorm(y)): (y, n), or just n with
-    ln_keep_y=False (y is then scratch: the fused kernel never writes it)."""
+    ln_keep_y=False (y is then scratch: the fused kernel never writes it).
+    out_t = (mul, off) with out (and ln_out) preallocated [B, To*mul, Ho, Wo, ld]: this launch fills the frames
+    to*mul + off (the parity classes of a time up-sampler)."""
     lib = L.load()
     _chk(x, "conv.x"); _chk(w, "conv.w")
     B, Ti, Hi, Wi, Cin = x.shape
@@ -93,11 +95,17 @@ def conv(x, w, bias, geom: ConvGeom, *, cout: int, out_dtype=None, tmode=L.VT_TP
     out_dtype = out_dtype or x.dtype
     To, Ho, Wo = geom.out_dims(Ti, Hi, Wi)
     assert To > 0 and Ho > 0 and Wo > 0, (To, Ho, Wo)
-    if out_layout == L.VT_NCTHW:
+    mul, off = out_t or (1, 0)
+    if out is not None:
+        assert out_layout == L.VT_NDHWC and out.is_contiguous() and out.dtype == out_dtype
+        assert tuple(out.shape[:4]) == (B, To * mul, Ho, Wo), (out.shape, (B, To * mul, Ho, Wo))
+        y, ldy = out, out.shape[4]
+    elif out_layout == L.VT_NCTHW:
         y = torch.empty((B, cout, To - t_trim, Ho, Wo), dtype=torch.float32, device=x.device)
         out_dtype = torch.float32
         ldy = cout
     else:
+        assert mul == 1
         ldy = ldy or pad_channels(cout)
         if ldy != cout:  # keep the pad lanes defined (they feed the next conv's zero weights)
             y = torch.zeros((B, To, Ho, Wo, ldy), dtype=out_dtype, device=x.device)
@@ -131,12 +139,17 @@ def conv(x, w, bias, geom: ConvGeom, *, cout: int, out_dtype=None, tmode=L.VT_TP
     d.out_layout, d.t_trim = out_layout, t_trim
     d.dtype, d.out_dtype = _DT[x.dtype], _DT[out_dtype]
     d.nbatch = 1
+    d.yt_mul, d.yt_off = mul, off
     n = None
     if ln is not None:
         gamma, beta, eps, silu = ln
         assert out_layout == L.VT_NDHWC and gamma.dtype == torch.float32 and beta.dtype == torch.float32
         assert gamma.numel() >= cout and beta.numel() >= cout and gamma.is_cuda and beta.is_cuda
-        n = (torch.zeros if ldy != cout else torch.empty)(y.shape, dtype=out_dtype, device=x.device)
+        if ln_out is not None:
+            assert ln_out.shape == y.shape and ln_out.dtype == out_dtype and ln_out.is_contiguous()
+            n = ln_out
+        else:
+            n = (torch.zeros if ldy != cout else torch.empty)(y.shape, dtype=out_dtype, device=x.device)
         d.ln_gamma, d.ln_beta, d.ln_out = gamma.data_ptr(), beta.data_ptr(), n.data_ptr()
         d.ln_mode, d.ln_keep_y, d.ldn, d.ln_eps = (2 if silu else 1), int(bool(ln_keep_y)), ldy, float(eps)
     _conv_launch(lib, d, "vt_conv")

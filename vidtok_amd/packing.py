@@ -25,18 +25,33 @@ def pack_conv_weight(weight: torch.Tensor, dtype: torch.dtype, cin_stored: int =
     return w.reshape(cout, -1).to(dtype).contiguous()
 
 
-class PackedCache:
-    """Caches the packed weight / fp32 bias of one conv-like parameter holder."""
+def time_upsample_parity_weights(weight: torch.Tensor, early: bool):
+    """A k=3 temporal conv over a nearest-x2 frame-repeated input u[t] = x[t >> 1] touches only two input frames per
+    output frame, so it equals a k=2 conv over x with pre-summed taps (fp32 sums, rounded once when packed):
+      window (j-1, j)  when the three taps cover u[2j-2 .. 2j]   : [W0 + W1, W2]   `early=True`
+                       or                 u[2j-1 .. 2j+1] causal : [W0, W1 + W2]   `early=False`
+    (the caller pairs each output parity with its window, see TimeUpsampleRes*2x).  weight [Co, Ci, 3, kh, kw]."""
+    w = weight.detach().to(torch.float32)
+    assert w.dim() == 5 and w.shape[2] == 3
+    if early:
+        return torch.stack([w[:, :, 0] + w[:, :, 1], w[:, :, 2]], dim=2)
+    return torch.stack([w[:, :, 0], w[:, :, 1] + w[:, :, 2]], dim=2)
 
-    def __init__(self):
+
+class PackedCache:
+    """Caches the packed weight / fp32 bias of one conv-like parameter holder.  `transform` (optional) maps the
+    parameter tensor to the tensor that is packed (e.g. the parity weights of a time up-sampler)."""
+
+    def __init__(self, transform=None):
         self._key = None
         self._val = None
+        self._transform = transform
 
     def get(self, weight: torch.nn.Parameter, bias, dtype, cin_stored=None):
         key = (dtype, weight.device, weight._version, None if bias is None else bias._version, cin_stored,
                weight.data_ptr())
         if key != self._key:
-            w = pack_conv_weight(weight, dtype, cin_stored)
+            w = pack_conv_weight(weight if self._transform is None else self._transform(weight), dtype, cin_stored)
             b = None if bias is None else bias.detach().to(torch.float32).contiguous()
             self._key, self._val = key, (w, b)
         return self._val
