@@ -91,6 +91,9 @@ int vt_conv_max_lds_bytes(void);
  * the three temporal taps of an output frame hit only two input frames, so even and odd output frames are two 2-tap
  * convolutions over x with pre-summed weights -- 2/3 of the MACs of the folded ups_t form, no up-sampled tensor
  * either way (vidtok_amd/packing.py::time_upsample_parity_weights).
+ * ys_mul = 2 is the same identity in space (Upsample: nearest x2 then 3x3): each of the four output parities (py, px)
+ * is a 2x2 convolution over the stored frame with pre-summed taps, 4/9 of the MACs
+ * (vidtok_amd/packing.py::space_upsample_parity_weights).
  * ln_mode != 0 additionally emits ln_out = [SiLU](LayerNorm_Cout(result) * gamma + beta), the norm that follows the
  * convolution inside the residual blocks (norm2 + nonlinearity after conv1, model_3dcausal.py:321-323,405-407,
  * 482-484).  When the tile spans the channel row (Cout = 128) the statistics are taken from the fp32 result inside
@@ -131,6 +134,8 @@ typedef struct vt_conv_desc {
   int32_t ldn;              /* channel stride of ln_out                                        */
   int32_t yt_mul, yt_off;   /* output frame interleave: computed frame f (b*To + to) is stored as frame
                                f*yt_mul + yt_off of a y (and ln_out) holding To*yt_mul frames; 0/1 = off  */
+  int32_t ys_mul, ys_oh, ys_ow; /* ys_mul = 2: computed pixel (ho, wo) is stored as pixel (2ho+ys_oh, 2wo+ys_ow) of
+                               a y whose frames are 2Ho x 2Wo (spatial parity classes, see below); 0/1 = off     */
   float ln_eps;
   int64_t xs_z, ws_z, ys_z, rs_z;   /* element strides between problems                       */
 } vt_conv_desc;

@@ -164,6 +164,30 @@ def test_conv_output_frame_interleave(cout, hw, dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+@pytest.mark.parametrize("cout,hw", [(128, (8, 16)), (256, (8, 8)), (512, (5, 7))])
+def test_conv_output_pixel_interleave(cout, hw, dtype):
+    """ys_mul = 2: four 2x2 launches fill the parity classes of a 2H x 2W output (spatial up-sampler)"""
+    from vidtok_amd.packing import space_upsample_parity_weights
+
+    B, T, (H, W), cin = 1, 2, hw, 128
+    x = _act(B, T, H, W, cin, dtype, 1)
+    g = torch.Generator().manual_seed(2)
+    w3 = torch.randn((cout, cin, 3, 3), generator=g) / math.sqrt(cin * 9)
+    bias = _rand((cout,), torch.float32, 3, 0.1)
+    y = torch.full((B, T, 2 * H, 2 * W, cout), float("nan"), dtype=dtype, device=DEV)
+    for py in (0, 1):
+        for px in (0, 1):
+            w = pack_conv_weight(space_upsample_parity_weights(w3, py, px), dtype, cin_stored=x.shape[-1]).to(DEV)
+            geom = ConvGeom(kh=2, kw=2, ph=1 - py, pw=1 - px, ph_hi=py, pw_hi=px)
+            ops.conv(x, w, bias, geom, cout=cout, out=y, out_s=(py, px))
+    torch.cuda.synchronize()
+    # against the plain statement: 3x3 conv over the nearest-x2 up-sampled frame
+    w9 = pack_conv_weight(w3, dtype, cin_stored=x.shape[-1])
+    yr = R.conv(x.cpu(), w9, bias.cpu(), ConvGeom(ups_s=1, **G3), cout=cout)
+    assert torch.isfinite(y.float()).all() and rel_err(y, yr) < 1.5 * TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
 @pytest.mark.parametrize("Z,M,N,K,bcast,use_bias", [(3, 80, 48, 128, False, False), (2, 512, 64, 512, True, True),
                                                       (5, 16, 16, 16, False, False), (2, 100, 512, 104, False, True),
                                                       (2, 1024, 1024, 512, False, False)])

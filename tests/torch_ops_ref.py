@@ -21,7 +21,12 @@ def _round_like(t, dtype):
 
 def conv(x, w, bias, geom, *, cout, out_dtype=None, tmode=L.VT_TPAD_ZERO, cache=None, res=None,
          res_mode=L.VT_RES_NONE, res_tshift=0, mix_factor=None, out_layout=L.VT_NDHWC, t_trim=0, ldy=None,
-         ln=None, ln_keep_y=True, out=None, ln_out=None, out_t=None):
+         ln=None, ln_keep_y=True, out=None, ln_out=None, out_t=None, out_s=None):
+    if out_s is not None:          # this launch fills pixels (2ho+py, 2wo+px) of a preallocated tensor
+        yv = conv(x, w, bias, geom, cout=cout, out_dtype=out_dtype, tmode=tmode, cache=cache, res=res, res_mode=res_mode,
+                  res_tshift=res_tshift, mix_factor=mix_factor, ldy=out.shape[4])
+        out[:, :, out_s[0]::2, out_s[1]::2] = yv
+        return out
     if out_t is not None:          # this launch fills frames to*mul + off of preallocated tensors
         mul, off = out_t
         res_ = conv(x, w, bias, geom, cout=cout, out_dtype=out_dtype, tmode=tmode, cache=cache, res=res, res_mode=res_mode,

@@ -62,6 +62,7 @@ struct ConvArgs {
   FastDiv fd_hw;                 // pixel index -> frame index (output frame interleave)
   int yt_mul;                    // output frame of computed frame f is f * yt_mul + yt_off (1, 0 = plain)
   long long yt_step, yt_base;    // (yt_mul - 1) * Ho*Wo and yt_off * Ho*Wo rows
+  int ys_mul, ys_oh, ys_ow;      // 2: computed pixel (ho, wo) is output pixel (2 ho + ys_oh, 2 wo + ys_ow) of a 2Ho x 2Wo frame
   int lds_epi;                 // 128 x 128 tile: epilogue transposed through the LDS (coalesced rows)
   int hw_tiles;                // > 0: pixel tiles per frame, tile order (b, hw tile, t) -- see launch_variant
   unsigned x_bytes, w_bytes;   // BUF path: descriptor extents (0 = tensors too large, use pointers)
@@ -135,6 +136,13 @@ struct TagFalse { [[maybe_unused]] static constexpr bool value = false; };
 // Output pixel row of computed pixel m.  With yt_mul > 1 the launch computes every yt_mul-th frame of the output
 // tensor (the parity classes of a convolution over a x2 frame-repeated input, see vt_conv_desc.yt_mul).
 __device__ __forceinline__ long long out_row(const ConvArgs& p, int m) {
+  if (p.ys_mul == 2) {                                            // uniform: spatial parity class (see vt_conv_desc.ys_mul)
+    const unsigned f = fast_div((unsigned)m, p.fd_hw);
+    const unsigned hw = (unsigned)m - f * (unsigned)(p.Ho * p.Wo);
+    const unsigned ho = fast_div(hw, p.fd_wo);
+    const unsigned wo = hw - ho * (unsigned)p.Wo;
+    return ((long long)f * (2 * p.Ho) + (2 * ho + p.ys_oh)) * (2 * p.Wo) + (2 * wo + p.ys_ow);
+  }
   if (p.yt_mul == 1) return m;                                    // uniform
   return (long long)m + (long long)fast_div((unsigned)m, p.fd_hw) * p.yt_step + p.yt_base;
 }

@@ -860,6 +860,11 @@ extern "C" int vt_conv(const vt_conv_desc* d, vt_stream stream_) {
   if (yt_mul != 1)
     VT_CHECK_ARG(d->out_layout == VT_NDHWC && nbatch == 1 && d->yt_off >= 0 && d->yt_off < yt_mul,
                  "vt_conv: output frame interleave needs NDHWC, nbatch 1 and 0 <= yt_off < yt_mul");
+  const int ys_mul = d->ys_mul == 2 ? 2 : 1;
+  VT_CHECK_ARG(d->ys_mul == 0 || d->ys_mul == 1 || d->ys_mul == 2, "vt_conv: ys_mul %d", d->ys_mul);
+  if (ys_mul == 2)
+    VT_CHECK_ARG(d->out_layout == VT_NDHWC && nbatch == 1 && yt_mul == 1 && (d->ys_oh | d->ys_ow | 1) == 1,
+                 "vt_conv: output pixel interleave needs NDHWC, nbatch 1, no frame interleave, offsets in {0,1}");
   if (d->ln_mode != 0) {
     VT_CHECK_ARG(d->ln_mode == 1 || d->ln_mode == 2, "vt_conv: ln_mode %d", d->ln_mode);
     VT_CHECK_ARG(d->ln_gamma && d->ln_beta && d->ln_out, "vt_conv: fused LayerNorm needs gamma, beta and ln_out");
@@ -883,6 +888,7 @@ extern "C" int vt_conv(const vt_conv_desc* d, vt_stream stream_) {
   a.ldr = d->ldr;
   a.out_layout = d->out_layout; a.t_trim = d->t_trim;
   a.M = (int)M; a.ntaps = d->KT * d->KH * d->KW; a.K = a.ntaps * d->Cin;
+  a.ys_mul = ys_mul; a.ys_oh = d->ys_oh; a.ys_ow = d->ys_ow;
   a.yt_mul = yt_mul;
   a.yt_step = (long long)(yt_mul - 1) * d->Ho * d->Wo;
   a.yt_base = (long long)(yt_mul != 1 ? d->yt_off : 0) * d->Ho * d->Wo;
@@ -903,7 +909,8 @@ extern "C" int vt_conv(const vt_conv_desc* d, vt_stream stream_) {
   else if (d->out_dtype == VT_F32) rc = dispatch_tile<bf16_t, float>(a, nbatch, stream);
   else rc = dispatch_tile<bf16_t, bf16_t>(a, nbatch, stream);
   if (rc != VT_OK || d->ln_mode == 0 || ln_fused) return rc;
-  VT_CHECK_ARG(yt_mul == 1, "vt_conv: LayerNorm of an interleaved output is only available fused (Cout = 128, full tiles)");
+  VT_CHECK_ARG(yt_mul == 1 && ys_mul == 1,
+               "vt_conv: LayerNorm of an interleaved output is only available fused (Cout = 128, full tiles)");
   // not fusable here: the same contract in two launches
   return vt_layernorm_act(d->y, d->out_dtype, d->ldy, d->ln_out, d->out_dtype, d->ldn, d->ln_gamma, d->ln_beta, M, d->Cout,
                           d->ln_eps, d->ln_mode == 2 ? 1 : 0, stream_);

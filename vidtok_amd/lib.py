@@ -46,6 +46,7 @@ class ConvDesc(C.Structure):
             "nbatch",
             "ln_mode", "ln_keep_y", "ldn",
             "yt_mul", "yt_off",
+            "ys_mul", "ys_oh", "ys_ow",
         )]
         + [("ln_eps", C.c_float)]
         + [(n, C.c_int64) for n in ("xs_z", "ws_z", "ys_z", "rs_z")]

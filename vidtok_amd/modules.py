@@ -22,7 +22,7 @@ import torch.nn as nn
 from . import lib as L
 from . import ops
 from .ops import ConvGeom
-from .packing import PackedCache, time_upsample_parity_weights
+from .packing import PackedCache, space_upsample_parity_weights, time_upsample_parity_weights
 
 
 def _check_norm(norm_type):
@@ -253,11 +253,23 @@ class Upsample(nn.Module):
             raise NotImplementedError("Upsample(with_conv=False) is not used by any VidTok config")
         self.with_conv = with_conv
         self.conv = nn.Conv2d(in_channels, in_channels, kernel_size=3, stride=1, padding=1)
-        self._pack = PackedCache()
+        # up(x)[Y][X] = x[Y>>1][X>>1]: an output pixel of parity (py, px) sees a 2x2 window of x, so the 3x3 conv over
+        # the up-sampled frame is four 2x2 convs over x with pre-summed taps (4/9 of the MACs), each writing its
+        # parity class of the output: rows (a-1, a) for py = 0, (a, a+1) for py = 1, likewise for columns
+        self._parity = [(py, px, PackedCache(lambda w, py=py, px=px: space_upsample_parity_weights(w, py, px)),
+                         ConvGeom(kh=2, kw=2, ph=1 - py, pw=1 - px, ph_hi=py, pw_hi=px))
+                        for py in (0, 1) for px in (0, 1)]
 
     def run(self, x, dt, next_norm=None):
-        g = ConvGeom(kh=3, kw=3, ph=1, pw=1, ph_hi=1, pw_hi=1, ups_s=1)
-        return _wrap(_Conv2dHolder.run(self.conv, self._pack, plain(x), dt, g, **_emit(next_norm)), next_norm)
+        x = plain(x)
+        B, T, H, W, C = x.shape
+        cout = self.conv.out_channels
+        ld = ops.pad_channels(cout)
+        y = (torch.empty if ld == cout else torch.zeros)((B, T, 2 * H, 2 * W, ld), dtype=dt, device=x.device)
+        for py, px, pack, g in self._parity:
+            w, b = pack.get(self.conv.weight, self.conv.bias, dt, cin_stored=C)
+            ops.conv(x, w, b, g, cout=cout, out=y, out_s=(py, px))
+        return y
 
 
 class Downsample(nn.Module):

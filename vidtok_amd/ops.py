@@ -82,12 +82,13 @@ class ConvGeom:
 
 def conv(x, w, bias, geom: ConvGeom, *, cout: int, out_dtype=None, tmode=L.VT_TPAD_ZERO, cache=None,
          res=None, res_mode=L.VT_RES_NONE, res_tshift=0, mix_factor=None, out_layout=L.VT_NDHWC,
-         t_trim=0, ldy=None, ln=None, ln_keep_y=True, out=None, ln_out=None, out_t=None):
+         t_trim=0, ldy=None, ln=None, ln_keep_y=True, out=None, ln_out=None, out_t=None, out_s=None):
     """y = conv(x) (+bias) (+res | alpha-mix); x [B,Ti,Hi,Wi,Cin], w packed [cout, ldw].
     ln = (gamma, beta, eps, silu) additionally returns n = [SiLU](LayerNorm(y)): (y, n), or just n with
     ln_keep_y=False (y is then scratch: the fused kernel never writes it).
     out_t = (mul, off) with out (and ln_out) preallocated [B, To*mul, Ho, Wo, ld]: this launch fills the frames
-    to*mul + off (the parity classes of a time up-sampler)."""
+    to*mul + off (the parity classes of a time up-sampler).  out_s = (py, px) with out [B, To, 2Ho, 2Wo, ld]: this
+    launch fills the pixels (2ho+py, 2wo+px) (the parity classes of a spatial up-sampler)."""
     lib = L.load()
     _chk(x, "conv.x"); _chk(w, "conv.w")
     B, Ti, Hi, Wi, Cin = x.shape
@@ -98,7 +99,8 @@ def conv(x, w, bias, geom: ConvGeom, *, cout: int, out_dtype=None, tmode=L.VT_TP
     mul, off = out_t or (1, 0)
     if out is not None:
         assert out_layout == L.VT_NDHWC and out.is_contiguous() and out.dtype == out_dtype
-        assert tuple(out.shape[:4]) == (B, To * mul, Ho, Wo), (out.shape, (B, To * mul, Ho, Wo))
+        smul = 2 if out_s is not None else 1
+        assert tuple(out.shape[:4]) == (B, To * mul, Ho * smul, Wo * smul), (out.shape, (B, To * mul, Ho, Wo))
         y, ldy = out, out.shape[4]
     elif out_layout == L.VT_NCTHW:
         y = torch.empty((B, cout, To - t_trim, Ho, Wo), dtype=torch.float32, device=x.device)
@@ -140,6 +142,9 @@ def conv(x, w, bias, geom: ConvGeom, *, cout: int, out_dtype=None, tmode=L.VT_TP
     d.dtype, d.out_dtype = _DT[x.dtype], _DT[out_dtype]
     d.nbatch = 1
     d.yt_mul, d.yt_off = mul, off
+    if out_s is not None:
+        assert out is not None and mul == 1
+        d.ys_mul, d.ys_oh, d.ys_ow = 2, int(out_s[0]), int(out_s[1])
     n = None
     if ln is not None:
         gamma, beta, eps, silu = ln

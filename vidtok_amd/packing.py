@@ -38,6 +38,18 @@ def time_upsample_parity_weights(weight: torch.Tensor, early: bool):
     return torch.stack([w[:, :, 0], w[:, :, 1] + w[:, :, 2]], dim=2)
 
 
+def space_upsample_parity_weights(weight: torch.Tensor, py: int, px: int):
+    """A 3x3 conv (pad 1) over a nearest-x2 up-sampled frame v[Y][X] = x[Y>>1][X>>1] reads, for an output pixel of
+    parity (py, px), only a 2x2 window of x: rows (a-1, a) with taps [W0, W1+W2] for py = 0, rows (a, a+1) with
+    [W0+W1, W2] for py = 1, likewise for columns.  weight [Co, Ci, 3, 3] -> [Co, Ci, 2, 2] (fp32 sums)."""
+    w = weight.detach().to(torch.float32)
+    assert w.dim() == 4 and tuple(w.shape[2:]) == (3, 3)
+    rows = torch.stack([w[:, :, 0], w[:, :, 1] + w[:, :, 2]], dim=2) if py == 0 else \
+        torch.stack([w[:, :, 0] + w[:, :, 1], w[:, :, 2]], dim=2)                     # [Co, Ci, 2, 3]
+    return torch.stack([rows[..., 0], rows[..., 1] + rows[..., 2]], dim=3) if px == 0 else \
+        torch.stack([rows[..., 0] + rows[..., 1], rows[..., 2]], dim=3)               # [Co, Ci, 2, 2]
+
+
 class PackedCache:
     """Caches the packed weight / fp32 bias of one conv-like parameter holder.  `transform` (optional) maps the
     parameter tensor to the tensor that is packed (e.g. the parity weights of a time up-sampler)."""
