@@ -33,6 +33,26 @@ def test_conv_desc_layout_matches_header(built_lib):
     assert lib.ConvDesc.xs_z.offset % 8 == 0
 
 
+def test_conv_desc_field_order_matches_header_and_integration_doc():
+    """The ctypes mirror, the header struct and the binding stub shown in INTEGRATION.md list the same fields in the
+    same order (a silent drift would shift every field after the edit)."""
+    from vidtok_amd import lib
+
+    names = [f[0] for f in lib.ConvDesc._fields_]
+    hdr = open(os.path.join(ROOT, "include", "vidtok_amd.h")).read()
+    body = hdr[hdr.index("typedef struct vt_conv_desc {") + len("typedef struct vt_conv_desc {"):hdr.index("} vt_conv_desc;")]
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    decl = []
+    for stmt in body.split(";"):
+        m = re.match(r"\s*(?:const\s+)?(?:void|float|int32_t|int64_t)\s*\*?\s*(.+)$", stmt.strip(), flags=re.S)
+        if m:
+            decl += [n.strip() for n in m.group(1).split(",")]
+    assert decl == names, [(a, b) for a, b in zip(decl, names) if a != b]
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    blk = doc[doc.index("class vt_conv_desc"):doc.index("assert lib.vt_conv_desc_size()")]
+    assert re.findall(r'"(\w+)"', blk) == names
+
+
 def test_argument_validation_without_gpu(built_lib):
     from vidtok_amd import lib
 
