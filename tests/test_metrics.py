@@ -106,3 +106,18 @@ def test_hip_metrics_bad_size_fails_loudly():
 
     with pytest.raises(RuntimeError, match="Kernel size"):
         ops.eval_psnr_ssim(torch.zeros(1, 3, 1, 10, 32).cuda(), torch.zeros(1, 3, 1, 10, 32).cuda())
+
+
+@pytest.mark.gpu
+def test_evaluate_clip_matches_oracle_metrics():
+    """model(x) + fused post-processing + per-frame metrics: the per-batch body of the reference's eval loop"""
+    from util import build_model
+    from vidtok_amd import metrics
+
+    model, _, _ = build_model("vidtok_kl_causal_488_4chn", seed=3, device="cuda")
+    x = torch.rand((1, 3, 5, 64, 64), generator=torch.Generator().manual_seed(4)) * 2 - 1
+    torch.manual_seed(0)
+    xrec, psnr, ssim = metrics.evaluate_clip(model, x.cuda())
+    assert xrec.shape == x.shape and psnr.shape == ssim.shape == (1, 5)
+    ops_, oss = M.eval_psnr_ssim(x, xrec.cpu())
+    assert (psnr.cpu() - ops_).abs().max() < PSNR_TOL and (ssim.cpu() - oss).abs().max() < SSIM_TOL
