@@ -6,16 +6,26 @@
 One "step" = one pass of the hot path, `model(x)` = encode -> KL regularizer -> decode
 (reference AutoencodingEngine.forward, vidtok/models/autoencoder.py:221-229), over one batch of
 synthetic clips x = rand(B,3,17,256,256)*2-1 that is resident in HBM before the timed region.
-Workload at every N: BASELINE.json configs[1] -- vidtok_kl_causal_488_4chn, bf16, B=4 clips per GPU
-(weak scaling: every rank runs its own B clips; the path has no data-path collective, SURVEY.md
-section 8e; only the timing/metrics reduction crosses ranks).  Prints ONE JSON line on rank 0.
+Workload: N=1 -> BASELINE.json configs[1], vidtok_kl_causal_488_4chn, bf16, B=4 clips; N>1 -> configs[3],
+vidtok_kl_causal_488_16chn, global batch 4*N clips batch-sharded over the N GPUs (B=32 at N=8), 4 clips per
+GPU (weak scaling: the path has no data-path collective; only the timing / metrics
+reduction crosses ranks, one tiny RCCL all_reduce).  The two configs differ in two layers (encoder.conv_out /
+decoder.conv_in width), < 0.01 % of the FLOPs.  Prints ONE JSON line on rank 0.
+
+Launch: `python bench.py --gpus N` spawns its N ranks itself (re-executes under torch.distributed.run on
+127.0.0.1) when it is not already running under a launcher; under `python -m torch.distributed.run ... bench.py
+--gpus N` it reads RANK / LOCAL_RANK / WORLD_SIZE from the environment.
 
   value       real frames/s over the whole job = N*B*17*K / max-over-ranks(time of K steps)
   roofline    conv_igemm_glds_kernel (all convolutions + the attention GEMMs = every MFMA FLOP of the
               path): algorithmic FLOPs of one step (1.0345 TFLOP per padded 256x256 frame, SURVEY.md
-              section 8d) / sum of that kernel's launch durations in one step, measured live with HIP
-              events on the launch stream; peak = dense MFMA peak of the dtype; traffic = HBM-side
-              bytes per launch from the committed rocprofv3 PMC pass (profiles/)
+              section 8d) / that kernel's time in one step.  The kernel time is measured live: the conv
+              launches of one step (same descriptors, same tensors) are replayed back to back from a
+              hipGraph that contains nothing else, bracketed by HIP events on the launch stream -- no
+              per-launch event overhead, so it is <= ms_per_step by construction; the rocprofv3
+              --kernel-trace average of the same command is committed under profiles/.  peak = dense MFMA
+              peak of the dtype; traffic = HBM-side bytes per launch from the committed rocprofv3 PMC
+              pass of this command (profiles/; counters cannot be read inside an un-profiled run)
   cpu_baseline  the CPU oracle (port of the reference, oracle/vidtok_oracle.py) timed on this host's
               cores on a bounded sample of the same workload; a baseline, not a target
 """
@@ -34,7 +44,9 @@ sys.path.insert(0, ROOT)
 FLOP_PER_PADDED_FRAME_256 = 1.0345e12     # SURVEY.md section 8(d), conv + attention MACs x 2
 PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}   # MI355X_MICROARCH.md: dense MFMA peaks
 T_REAL, T_PADDED, RES = 17, 20, 256
-CONFIG = "vidtok_kl_causal_488_4chn"
+CONFIG_1GPU = "vidtok_kl_causal_488_4chn"       # BASELINE.json configs[1]
+CONFIG_NGPU = "vidtok_kl_causal_488_16chn"      # BASELINE.json configs[3]
+CONFIG = CONFIG_1GPU
 
 
 def randomize_weights(model, seed=0):
@@ -53,17 +65,17 @@ def randomize_weights(model, seed=0):
                 p.copy_(torch.randn(p.shape, generator=g) / math.sqrt(p[0].numel()))
 
 
-def cpu_baseline(budget_s=25.0):
-    """Time the CPU oracle on a bounded sample: one 17-frame clip at the largest square resolution in
-    {64,128,256} whose forward is expected to fit the budget; throughput is scaled to 256x256 frames
-    by the pixel ratio (every op of the path is linear in H*W).  The thread count is the better of
-    16 / 64 (capped by the host) on a small probe: torch's CPU convolutions collapse when given all
-    256 hardware threads of the GPU box (measured: 17x64x64 took 122 s on 256 threads)."""
+def cpu_baseline():
+    """Time the CPU oracle (a port: the reference is Python and cannot travel to the GPU box) on ONE unscaled
+    17x256x256 clip of the bench workload -- about 30 s of CPU work.  The thread count is the best of 16 / 32 / 64
+    (capped by the host) on a 17x64x64 probe: torch's CPU convolutions collapse when given all 256 hardware threads
+    of the GPU box (measured: 17x64x64 took 122 s on 256 threads).  In the build container the unmodified reference
+    runs this same clip 1.0-1.1x slower than the oracle, so the port is a fair stand-in."""
     import vidtok_amd
     from oracle.vidtok_oracle import OracleEngine
 
     cores = os.cpu_count() or 1
-    cfg = vidtok_amd.load_config(os.path.join(ROOT, "configs", CONFIG + ".yaml"))
+    cfg = vidtok_amd.load_config(os.path.join(ROOT, "configs", CONFIG_1GPU + ".yaml"))
     model = vidtok_amd.load_model_from_config(cfg, verbose=False)
     randomize_weights(model, 0)
     ora = OracleEngine(cfg["model"]["params"], model.state_dict())
@@ -76,7 +88,7 @@ def cpu_baseline(budget_s=25.0):
         return time.perf_counter() - t0
 
     best_t, threads = None, 1
-    for nt in sorted({min(cores, 16), min(cores, 64)}):
+    for nt in sorted({min(cores, 16), min(cores, 32), min(cores, 64)}):
         torch.set_num_threads(nt)
         run(32)                   # warm-up (thread pool, allocator)
         t = run(64)
@@ -85,15 +97,27 @@ def cpu_baseline(budget_s=25.0):
         if t > 10.0:
             break
     torch.set_num_threads(threads)
-    t64, res = best_t, 64
-    for cand in (128, 256):
-        if t64 * (cand / 64) ** 2 * 1.15 <= budget_s:
-            res = cand
-    t = run(res) if res != 64 else t64
-    fps256 = T_REAL / (t * (RES / res) ** 2)
-    return {"value": round(fps256, 4), "unit": "frames/s", "cores": threads, "kind": "port",
-            "sample": f"oracle/vidtok_oracle.py forward, fp32, 1 clip 17x{res}x{res} in {t:.2f}s on {threads} of "
-                      f"{cores} host threads, scaled x{(res / RES) ** 2:.4g} to 256x256 frames"}
+    t = run(RES)
+    return {"value": round(T_REAL / t, 4), "unit": "frames/s", "cores": threads, "kind": "port",
+            "sample": f"oracle/vidtok_oracle.py forward, fp32, 1 unscaled clip 17x{RES}x{RES} in {t:.2f}s on {threads} of "
+                      f"{cores} host threads ({CONFIG_1GPU})"}
+
+
+def spawn_ranks(n):
+    """`python bench.py --gpus N` outside a launcher: re-execute under torch.distributed.run, one rank per GPU."""
+    import socket
+    import subprocess
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: RCCL needs it on this driver
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print(f"[bench] spawning {n} ranks: {' '.join(cmd)}", file=sys.stderr)
+    return subprocess.call(cmd, env=env)
 
 
 def main():
@@ -106,18 +130,43 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--breakdown", action="store_true", help="print the per-layer-shape conv timeline to stderr")
+    ap.add_argument("--selftest-spawn", action="store_true",
+                    help="CPU/gloo check of the N-rank launch path only (no GPU work): prints the world size reached")
+    ap.add_argument("--config", default=None, help="override the workload's YAML (default: BASELINE configs[1] / [3])")
     args = ap.parse_args()
 
+    if not torch.cuda.is_available() and not args.selftest_spawn:
+        raise SystemExit("bench.py needs a GPU: the vidtok_amd path has no CPU fallback")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        if not args.selftest_spawn and torch.cuda.device_count() < args.gpus:
+            raise SystemExit(f"bench.py --gpus {args.gpus}: only {torch.cuda.device_count()} GPU(s) visible")
+        raise SystemExit(spawn_ranks(args.gpus))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and rank == 0:
-        print(f"[bench] note: WORLD_SIZE={world} but --gpus {args.gpus}; using WORLD_SIZE", file=sys.stderr)
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: the vidtok_amd path has no CPU fallback")
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
+    import torch.distributed as dist
+
+    if args.selftest_spawn:
+        # launch plumbing only (CPU, gloo): every rank joins, the metrics reduction runs, rank 0 reports the world
+        from vidtok_amd.sharding import reduce_metrics, shard_range
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        if world > 1:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        a, b = shard_range(4 * world, world, rank)
+        red = reduce_metrics(1.0 + rank, {"clips": float(b - a)})
+        if rank == 0:
+            print(json.dumps({"selftest": "spawn", "n_gpus": red["world"], "clips": red["clips"], "elapsed_s": red["elapsed_s"]}),
+                  flush=True)
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    import torch.distributed as dist
 
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -128,7 +177,8 @@ def main():
     from vidtok_amd import ops
 
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
-    model = vidtok_amd.load_model_from_config(os.path.join(ROOT, "configs", CONFIG + ".yaml"), verbose=False)
+    config = args.config or (CONFIG_1GPU if world == 1 else CONFIG_NGPU)
+    model = vidtok_amd.load_model_from_config(os.path.join(ROOT, "configs", config + ".yaml"), verbose=False)
     randomize_weights(model, 0)
     model = model.to(dev).eval().set_compute_dtype(dtype)
     model.regularization.noise_source = "device"   # reparameterisation noise drawn on the GPU (capturable)
@@ -182,48 +232,57 @@ def main():
     z, dec, log = out
     ok = bool(torch.isfinite(dec).all()) and dec.shape == x.shape
 
-    # ---- roofline leg: per-launch HIP-event timeline of the conv kernel over one eager step --------
+    # ---- roofline leg: the conv launches of one step, replayed alone from a hipGraph, timed with HIP events -----
     roof = None
     if rank == 0:
-        # The eager step is enqueued behind a ~0.3 s device-side spin, so the host runs ahead and the conv kernels
-        # execute back to back: an event pair then brackets kernel time only, not the Python launch gaps of an
-        # un-graphed step (they inflated the short launches by 5-10 %).
-        c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        c0.record()
-        torch.cuda._sleep(10_000_000)
-        c1.record()
+        ops.CONV_RECORD = []
+        step()                                          # eager: records descriptors + keeps their tensors alive
         torch.cuda.synchronize()
-        cycles_per_ms = 10_000_000 / max(c0.elapsed_time(c1), 1e-3)
-        ops.CONV_TIMELINE = []
-        torch.cuda._sleep(int(300 * cycles_per_ms))
-        step()
-        torch.cuda.synchronize()
-        tl, ops.CONV_TIMELINE = ops.CONV_TIMELINE, None
-        conv_ms = sum(e0.elapsed_time(e1) for e0, e1, _ in tl)
+        rec, ops.CONV_RECORD = ops.CONV_RECORD, None
+        tl = [lab for _, _, lab in rec]
+
+        def time_replay(records, reps=3):
+            """ms per replay of `records` (conv kernel only) from a hipGraph, HIP events on the launch stream"""
+            g2 = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g2):
+                ops.replay_convs(records)
+            g2.replay()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                g2.replay()
+            e1.record()
+            torch.cuda.synchronize()
+            return e0.elapsed_time(e1) / reps
+
+        conv_ms = time_replay(rec, reps=max(3, min(args.steps, 10)))
         if args.breakdown:
-            agg = {}
-            for e0, e1, (M, N, K) in tl:
-                a = agg.setdefault((M, N, K), [0, 0.0])
-                a[0] += 1
-                a[1] += e0.elapsed_time(e1)
-            print("[bench] conv launches of one step by (pixels, Cout, K=taps*Cin):", file=sys.stderr)
-            for (M, N, K), (n, ms) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+            groups = {}
+            for r in rec:
+                groups.setdefault(r[2], []).append(r)
+            rows = [(lab, len(rs), time_replay(rs)) for lab, rs in groups.items()]
+            print("[bench] conv launches of one step by (pixels, Cout, K=taps*Cin), each group replayed alone:", file=sys.stderr)
+            tot = sum(ms for _, _, ms in rows)
+            for (M, N, K), n, ms in sorted(rows, key=lambda r: -r[2]):
                 print(f"[bench]   M={M:8d} N={N:4d} K={K:6d}  x{n:3d}  {ms:8.3f} ms  {2.0 * M * N * K * n / ms / 1e9:8.1f} TFLOP/s"
-                      f"  {100 * ms / conv_ms:5.1f}%", file=sys.stderr)
+                      f"  {100 * ms / tot:5.1f}%", file=sys.stderr)
         flops = FLOP_PER_PADDED_FRAME_256 * B * T_PADDED
         achieved = flops / (conv_ms * 1e-3) / 1e12
         # MACs the launches really execute: the up-sampler convs run as parity classes with pre-summed taps (2/3 resp.
         # 4/9 of the reference's MACs for the same result), so `achieved` -- algorithmic FLOPs of the reference per
         # unit (SURVEY 8d) over kernel time -- is an effective rate; the executed rate is reported next to it
-        executed = sum(2.0 * M * N * K for _, _, (M, N, K) in tl)
+        executed = sum(2.0 * M * N * K for (M, N, K) in tl)
         peak = PEAK_TFLOPS[args.dtype]
         # HBM-side bytes per launch come from rocprofv3 PMC passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE,
         # scripts/pmc_bench.sh + scripts/pmc_traffic.py); counters cannot be read inside a normal run, so the
         # figure of the committed pass for this dtype is quoted (null when there is none)
         traffic = None
-        tpath = os.path.join(ROOT, "profiles", f"r01_conv_traffic_pmc{'' if args.dtype == 'bf16' else '_' + args.dtype}.json")
-        if os.path.exists(tpath) and B == 4:
-            traffic = round(json.load(open(tpath))["traffic_bytes_per_launch"])
+        for rnd in ("r02", "r01"):
+            tpath = os.path.join(ROOT, "profiles", f"{rnd}_conv_traffic_pmc{'' if args.dtype == 'bf16' else '_' + args.dtype}.json")
+            if os.path.exists(tpath) and B == 4 and world == 1:
+                traffic = round(json.load(open(tpath))["traffic_bytes_per_launch"])
+                break
         roof = {"bound": "mfma", "kernel": "conv_igemm_glds_kernel", "achieved": round(achieved, 2), "peak": peak,
                 "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic,
                 "launches_per_step": len(tl), "kernel_ms_per_step": round(conv_ms, 3),
@@ -240,11 +299,11 @@ def main():
         ms = elapsed / args.steps * 1e3
         value = total_frames / elapsed
         line = {
-            "metric": "encode+decode frames/sec, vidtok_kl_causal_488_4chn 17x256x256", "value": round(value, 2),
+            "metric": f"encode+decode frames/sec, {config} 17x256x256", "value": round(value, 2),
             "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic uniform[-1,1] clips, random-init weights (temporal convs un-zeroed)",
-            "config": {"workload": f"{CONFIG} forward (encode+KL+decode), {args.dtype}, B={B} clips/GPU, 17x256x256",
+            "config": {"workload": f"{config} forward (encode+KL+decode), {args.dtype}, B={B} clips/GPU, 17x256x256",
                        "global_batch": world * B, "parallelism": f"dp{world} (batch-sharded, no data-path collective)",
                        "launch": "hipGraph replay" if graph is not None else "eager"},
             "output_finite": ok, "roofline": roof, "cpu_baseline": cpu,

@@ -141,6 +141,10 @@ typedef struct vt_conv_desc {
 } vt_conv_desc;
 
 int vt_conv(const vt_conv_desc* d, vt_stream stream);
+/* What vt_conv(d) would do, without launching (no GPU needed): out6 = {pixel tile, channel tile, waves per
+ * workgroup, workgroups, 1 if LayerNorm comes from the conv epilogue, kernel launches of the call}.  Validates
+ * `d` exactly like vt_conv.  Test / measurement aid: which instantiation does a parity case exercise. */
+int vt_conv_plan(const vt_conv_desc* d, int32_t* out6);
 /* sizeof(vt_conv_desc) as compiled: lets a binding verify its struct mirror */
 int vt_conv_desc_size(void);
 
@@ -217,6 +221,10 @@ int vt_time_lerp2x(const void* x, void* y, int dtype, int32_t B, int32_t Ti, int
  *   (regularizers.py:231-246) for h [B][D][S]: out[0] = per-sample entropy (mean), out[1] =
  *   codebook entropy of the batch-mean distribution, out[2] = commit loss.  `work` is a device
  *   scratch of vt_fsq_aux_work_floats(...) floats.
+ * vt_fsq_aux_stats_avg: the same, and (avg_out != NULL) the batch-mean code distribution avg_prob[prod(levels)] the
+ *   codebook entropy is taken of -- the tensor the reference averages across ranks when torch.distributed runs
+ *   with world > 1 (maybe_distributed_mean, regularizers.py:49-59,240); vt_entropy(avg, J, out) then recomputes
+ *   out[0] = sum_j -avg_j * log(max(avg_j, 1e-5)) (regularizers.py:40-45) of the all-reduced distribution.
  * ---------------------------------------------------------------------------------------- */
 /* host-only helper: writes half_l[D], offset[D], shift[D], basis[D] (as floats) exactly as the
  * FSQ kernels use them (FSQRegularizer.bound constants, regularizers.py:153-158) -- no GPU needed. */
@@ -230,6 +238,9 @@ int vt_fsq_indices_to_codes(const int32_t* indices, float* z, const int32_t* lev
 int64_t vt_fsq_aux_work_floats(const int32_t* levels_host, int32_t D, int32_t B, int64_t S);
 int vt_fsq_aux_stats(const float* h, const int32_t* levels_host, int32_t D, int32_t B, int64_t S,
                      float inv_temperature, float* work, float* out3, vt_stream stream);
+int vt_fsq_aux_stats_avg(const float* h, const int32_t* levels_host, int32_t D, int32_t B, int64_t S,
+                         float inv_temperature, float* work, float* out3, float* avg_out, vt_stream stream);
+int vt_entropy(const float* avg, int64_t J, float* out, vt_stream stream);
 
 /* copy `n` frames of `frame_elems` elements each: dst frame j <- src frame idx_host[j]
  * (cache maintenance of the v1.1 chunked path, model_3dcausal_v1_1.py:172-176,230-234);

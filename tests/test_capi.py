@@ -91,3 +91,45 @@ def test_missing_library_fails_loudly(tmp_path, monkeypatch):
     monkeypatch.setattr(lib, "_lib", None)
     with pytest.raises(lib.VtError):
         lib.load(str(tmp_path / "nope.so"))
+
+
+def test_conv_plan_tile_selection(built_lib, monkeypatch):
+    """vt_conv_plan (no GPU): the 8-wave 256x256 tile is what BASELINE-sized Cout % 256 == 0 layers get, VT_CONV_TILE
+    forces / forbids it for small parity cases, LayerNorm is fused only for Cout = 128 on full tiles."""
+    from vidtok_amd import lib as L
+    from vidtok_amd import ops
+
+    def desc(M_hw, cin, cout, **kw):
+        d = L.ConvDesc()
+        d.x = d.w = d.y = 4096
+        d.B, d.Ti, d.Hi, d.Wi, d.Cin = 1, 1, M_hw[0], M_hw[1], cin
+        d.To, d.Ho, d.Wo, d.Cout = 1, M_hw[0], M_hw[1], cout
+        d.ldw, d.ldy = 9 * cin, cout
+        d.KT, d.KH, d.KW = 1, 3, 3
+        d.st = d.sh = d.sw = 1
+        d.ph = d.pw = 1
+        d.dtype = d.out_dtype = L.VT_BF16
+        for k, v in kw.items():
+            setattr(d, k, v)
+        return d
+
+    monkeypatch.delenv("VT_CONV_TILE", raising=False)
+    big = ops.conv_plan(desc((1280, 1024), 256, 256))            # the 256-channel level of the benchmark (B=4: 20 frames)
+    assert big["tile"] == (256, 256) and big["waves"] == 8 and big["workgroups"] == 5120
+    assert ops.conv_plan(desc((64, 64), 256, 256))["tile"] == (128, 128)
+    assert ops.conv_plan(desc((64, 64), 128, 8))["tile"] == (256, 32)
+    assert ops.conv_plan(desc((64, 64), 128, 64))["tile"] == (256, 64)
+    monkeypatch.setenv("VT_CONV_TILE", "256")
+    assert ops.conv_plan(desc((64, 64), 256, 256))["tile"] == (256, 256)
+    assert ops.conv_plan(desc((64, 64), 256, 128))["tile"] == (128, 128)     # not legal there
+    monkeypatch.setenv("VT_CONV_TILE", "128")
+    assert ops.conv_plan(desc((1280, 1024), 256, 256))["tile"] == (128, 128)
+    monkeypatch.delenv("VT_CONV_TILE")
+    ln = dict(ln_mode=2, ln_gamma=4096, ln_beta=4096, ln_out=4096, ldn=128, ln_eps=1e-6)
+    p = ops.conv_plan(desc((64, 64), 128, 128, **ln))
+    assert p["ln_fused"] and p["launches"] == 1
+    ln["ldn"] = 256
+    p = ops.conv_plan(desc((64, 64), 128, 256, **ln))
+    assert not p["ln_fused"] and p["launches"] == 2
+    with pytest.raises(L.VtError):
+        ops.conv_plan(desc((64, 64), 100, 128))                  # same validation as vt_conv

@@ -19,6 +19,11 @@ from util import GOLDEN_DIR, build_model, build_oracle, rel_err
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
+# bf16 gates: a small multiple of what the bf16 kernels measure against the fp32 oracle (recon 1.5e-2..2.2e-2, z 6e-3,
+# FSQ codes 93-94 % -- the reference's own fp32 vs bf16-autocast agreement, SURVEY.md finding 5): a 2-3x loss of
+# accuracy in a kernel turns these red.  test_bf16_vs_autocast_oracle additionally pins the bf16 path to the
+# oracle run under torch.autocast(bfloat16) on the same GPU (the reference's own bf16 mode).
+BF16_RECON, BF16_Z, BF16_CODE_RATE = 5e-2, 2e-2, 0.9
 
 
 @pytest.mark.parametrize("case", CASES, ids=[c["name"] for c in CASES])
@@ -46,12 +51,34 @@ def test_fp32_matches_reference_golden(case):
 @pytest.mark.parametrize("name,shape,dtype,tol", [
     ("vidtok_kl_causal_488_4chn", (2, 3, 17, 64, 64), torch.float32, 1e-3),
     ("vidtok_fsq_causal_488_32768", (1, 3, 17, 64, 64), torch.float32, 1e-3),
-    ("vidtok_kl_causal_488_4chn", (2, 3, 17, 64, 64), torch.bfloat16, 0.25),
-    ("vidtok_fsq_causal_488_32768", (1, 3, 17, 64, 64), torch.bfloat16, 0.25),
-    ("vidtok_kl_causal_488_16chn", (1, 3, 9, 40, 24), torch.bfloat16, 0.25),
+    ("vidtok_kl_causal_488_4chn", (2, 3, 17, 64, 64), torch.bfloat16, BF16_RECON),
+    ("vidtok_fsq_causal_488_32768", (1, 3, 17, 64, 64), torch.bfloat16, BF16_RECON),
+    ("vidtok_kl_causal_488_16chn", (1, 3, 9, 40, 24), torch.bfloat16, BF16_RECON),
     ("vidtok_kl_noncausal_488_4chn", (2, 3, 16, 64, 64), torch.float32, 1e-3),
-    ("vidtok_kl_noncausal_488_4chn", (1, 3, 16, 64, 64), torch.bfloat16, 0.25),
+    ("vidtok_kl_noncausal_488_4chn", (1, 3, 16, 64, 64), torch.bfloat16, BF16_RECON),
     ("vidtok_fsq_noncausal_41616_262144", (1, 3, 8, 64, 64), torch.float32, 1e-3),
+    # the other compression schedules of the reference's config set on the GPU --
+    # 4x16x16 (ch_mult [1,2,4,4,4]), 2x8x8 (tempo_ds [1]), 4x4x4 (spatial_ds [1,2]), 8x8x8 v1.1 (tempo_ds [0,1,2]),
+    # the other FSQ codebooks, the v1.1 variants un-tiled (reference configs/*.yaml:19-23)
+    ("vidtok_kl_causal_41616_4chn", (1, 3, 9, 64, 64), torch.float32, 1e-3),
+    ("vidtok_kl_causal_41616_4chn", (1, 3, 9, 64, 64), torch.bfloat16, BF16_RECON),
+    ("vidtok_kl_causal_288_8chn", (2, 3, 9, 64, 48), torch.float32, 1e-3),
+    ("vidtok_kl_causal_288_8chn", (1, 3, 9, 64, 48), torch.bfloat16, BF16_RECON),
+    ("vidtok_kl_causal_444_4chn", (1, 3, 9, 32, 48), torch.float32, 1e-3),
+    ("vidtok_kl_causal_444_4chn", (1, 3, 9, 32, 48), torch.bfloat16, BF16_RECON),
+    ("vidtok_kl_causal_488_8chn", (1, 3, 5, 64, 64), torch.float32, 1e-3),
+    ("vidtok_fsq_causal_488_4096", (1, 3, 9, 64, 64), torch.float32, 1e-3),
+    ("vidtok_fsq_causal_488_262144", (1, 3, 9, 64, 64), torch.float32, 1e-3),
+    ("vidtok_fsq_causal_41616_262144", (1, 3, 9, 64, 64), torch.float32, 1e-3),
+    ("vidtok_v1_1/vidtok_fsq_causal_888_32768_v1_1", (1, 3, 17, 64, 64), torch.float32, 1e-3),
+    ("vidtok_v1_1/vidtok_fsq_causal_888_32768_v1_1", (1, 3, 17, 64, 64), torch.bfloat16, BF16_RECON),
+    ("vidtok_v1_1/vidtok_kl_causal_288_8chn_v1_1", (1, 3, 9, 64, 64), torch.float32, 1e-3),
+    ("vidtok_v1_1/vidtok_kl_causal_41616_16chn_v1_1", (1, 3, 9, 64, 64), torch.float32, 1e-3),
+    ("vidtok_v1_1/vidtok_fsq_causal_41616_262144_v1_1", (1, 3, 9, 64, 64), torch.float32, 1e-3),
+    ("vidtok_v1_1/vidtok_kl_causal_488_4chn_v1_1", (1, 3, 9, 64, 64), torch.float32, 1e-3),
+    ("vidtok_kl_noncausal_41616_4chn", (1, 3, 8, 64, 64), torch.float32, 1e-3),
+    ("vidtok_kl_noncausal_488_16chn", (1, 3, 8, 64, 64), torch.float32, 1e-3),
+    ("vidtok_fsq_noncausal_488_262144", (1, 3, 8, 64, 64), torch.float32, 1e-3),
 ])
 def test_matches_cpu_oracle(name, shape, dtype, tol):
     model, cfg, sd = build_model(name, seed=21, device=DEV, dtype=dtype)
@@ -66,11 +93,12 @@ def test_matches_cpu_oracle(name, shape, dtype, tol):
     print(f"{name} {shape} {dtype}: z rel {ez:.3e} dec rel {ed:.3e}")
     assert dec.shape == dec2.shape and ed < tol
     if "indices" not in log2 or dtype == torch.float32:
-        assert ez < tol           # (bf16 FSQ latents are code values: compared through the match rate below)
+        # (bf16 FSQ latents are code values: compared through the match rate below)
+        assert ez < (tol if dtype == torch.float32 else BF16_Z)
     if "indices" in log2:
         rate = (log["indices"].cpu() == log2["indices"]).float().mean().item()
         print(f"{name} {dtype}: FSQ code match rate {rate:.5f} over {log2['indices'].numel()} tokens")
-        assert rate >= (0.999 if dtype == torch.float32 else 0.5)
+        assert rate >= (0.999 if dtype == torch.float32 else BF16_CODE_RATE)
         # the quantiser itself is exact: feeding the oracle's own pre-quantisation h gives its codes
         h = ora.pre_quant(x)
         _, qlog = model.regularization(h.to(DEV))
@@ -156,3 +184,105 @@ def test_v11_full_size_long_video_tiling_property():
     print(f"v1.1 129x256x256 tiled vs un-tiled: z rel {ez:.2e} dec rel {ed:.2e}")
     assert dec1.shape == x.shape == dec0.shape and z1.shape == (1, 16, 33, 32, 32)
     assert ez < 1e-4 and ed < 5e-3
+
+
+# --------------------------------------------------------------------------------------------------
+# BASELINE.json sizes against the oracle: the layers of the benchmarked problem -- the 8-wave
+# 256x256 conv tile (picked for Cout % 256 == 0 with >= 384 tiles, i.e. only at this size), the frames-innermost
+# tile order over 20 frames, cache-mode gathers on 256x256 frames -- are compared with the CPU oracle itself.
+# The oracle needs ~30 s per 17x256x256 clip, so each (config, shape) result is computed once per session.
+# --------------------------------------------------------------------------------------------------
+_ORACLE_RUNS = {}
+
+
+def _oracle_full(name, shape, seed, tiling=None):
+    key = (name, shape, seed, tiling)
+    if key not in _ORACLE_RUNS:
+        model, cfg, sd = build_model(name, seed=seed, device="cpu")
+        ora = build_oracle(cfg, sd)
+        if tiling:
+            ora.use_tiling, ora.t_chunk_enc, ora.use_overlap = True, tiling[0], tiling[1]
+        x = torch.rand(shape, generator=torch.Generator().manual_seed(41)) * 2 - 1
+        torch.manual_seed(8)
+        _ORACLE_RUNS[key] = (cfg, sd, x, ora(x))
+    return _ORACLE_RUNS[key]
+
+
+FULL = [("vidtok_kl_causal_488_4chn", (2, 3, 17, 256, 256)), ("vidtok_fsq_causal_488_32768", (1, 3, 17, 256, 256))]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+@pytest.mark.parametrize("name,shape", FULL, ids=["kl_4chn_B2", "fsq_B1"])
+def test_full_size_matches_cpu_oracle(name, shape, dtype):
+    cfg, sd, x, (z2, dec2, log2) = _oracle_full(name, shape, 33)
+    model, _, _ = build_model(name, seed=33, device=DEV, dtype=dtype)
+    torch.manual_seed(8)
+    z, dec, log = model(x.to(DEV))
+    ez, ed = rel_err(z, z2), rel_err(dec, dec2)
+    print(f"FULL {name} {shape} {dtype}: z rel {ez:.3e} dec rel {ed:.3e}")
+    assert dec.shape == dec2.shape
+    if dtype == torch.float32:
+        assert ez < 1e-3 and ed < 1e-3
+    else:
+        assert ed < BF16_RECON and ("indices" in log2 or ez < BF16_Z)
+    if "indices" in log2:
+        n_bad = int((log["indices"].cpu() != log2["indices"]).sum())
+        print(f"FULL {name} {dtype}: {n_bad} of {log2['indices'].numel()} FSQ codes differ")
+        if dtype == torch.float32:
+            assert n_bad == 0                      # bit-exact at the benchmarked size
+        else:
+            assert n_bad <= (1 - BF16_CODE_RATE) * log2["indices"].numel()
+
+
+def test_full_size_v11_tiled_matches_cpu_oracle():
+    """BASELINE.json configs[4] geometry (256x256 frames, t_chunk_enc=16, decoder look-ahead) on a 33-frame clip:
+    cache-mode (pointer form) gathers, chunk caches and the trilinear up-sampler at full frame size vs the oracle."""
+    name = "vidtok_v1_1/vidtok_kl_causal_488_16chn_v1_1"
+    cfg, sd, x, (z2, dec2, log2) = _oracle_full(name, (1, 3, 33, 256, 256), 34, tiling=(16, True))
+    model, _, _ = build_model(name, seed=34, device=DEV, dtype=torch.float32)
+    model.use_tiling, model.t_chunk_enc, model.t_chunk_dec, model.use_overlap = True, 16, 4, True
+    torch.manual_seed(8)
+    z, dec, log = model(x.to(DEV))
+    ez, ed = rel_err(z, z2), rel_err(dec, dec2)
+    print(f"FULL v1.1 tiled T=33 256x256: z rel {ez:.3e} dec rel {ed:.3e}")
+    assert dec.shape == x.shape and ez < 1e-3 and ed < 1e-3
+
+
+@pytest.mark.parametrize("name,shape", [("vidtok_kl_causal_488_4chn", (1, 3, 17, 256, 256)),
+                                        ("vidtok_fsq_causal_488_32768", (1, 3, 17, 128, 128))], ids=["kl_256", "fsq_128"])
+def test_bf16_vs_autocast_oracle(name, shape):
+    """bf16 kernels vs the reference's own bf16 mode -- the oracle's functional torch graph run
+    on this GPU under torch.autocast(bfloat16) (ATen/MIOpen kernels; test infrastructure), regulariser in fp32 like the
+    reference's autocast(enabled=False) block.  Both are compared with the fp32 CPU oracle: the HIP bf16 path must
+    not be further from fp32 than 2x the autocast run is, and the two bf16 runs must agree to the bf16 gates."""
+    from oracle.vidtok_oracle import OracleEngine
+
+    model, cfg, sd = build_model(name, seed=35, device=DEV, dtype=torch.bfloat16)
+    ora = build_oracle(cfg, sd)
+    ora.sample = False
+    if hasattr(model.regularization, "sample"):
+        model.regularization.sample = False
+    x = torch.rand(shape, generator=torch.Generator().manual_seed(42)) * 2 - 1
+    z0, dec0, log0 = ora(x)                                        # fp32 CPU oracle
+    ora_gpu = OracleEngine(cfg["model"]["params"], {k: v.to(DEV) for k, v in sd.items()})
+    try:
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            h = ora_gpu.pre_quant(x.to(DEV))
+        za, loga = ora.regularize(h.float().cpu())
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            deca = ora_gpu.decode(za.to(DEV)).float()
+    except RuntimeError as e:                                      # an ATen/MIOpen bf16 conv3d gap is not our bug
+        pytest.skip(f"torch autocast oracle unavailable on this stack: {e}")
+    z, dec, log = model(x.to(DEV))
+    e_ours, e_auto, e_cross = rel_err(dec, dec0), rel_err(deca, dec0), rel_err(dec, deca)
+    print(f"bf16 {name}: recon vs fp32 oracle: HIP {e_ours:.3e}, autocast oracle {e_auto:.3e}; HIP vs autocast {e_cross:.3e}")
+    assert e_ours < BF16_RECON and e_ours < 2.0 * e_auto + 5e-3 and e_cross < 1.5 * BF16_RECON
+    if "indices" in log0:
+        r_ours = (log["indices"].cpu() == log0["indices"]).float().mean().item()
+        r_auto = (loga["indices"] == log0["indices"]).float().mean().item()
+        print(f"bf16 {name}: FSQ code match vs fp32 oracle: HIP {r_ours:.4f}, autocast oracle {r_auto:.4f}")
+        assert r_ours >= BF16_CODE_RATE and r_ours >= r_auto - 0.03
+    else:
+        ez_ours, ez_auto = rel_err(z, z0), rel_err(za, z0)
+        print(f"bf16 {name}: z vs fp32 oracle: HIP {ez_ours:.3e}, autocast oracle {ez_auto:.3e}")
+        assert ez_ours < BF16_Z and ez_ours < 2.0 * ez_auto + 2e-3

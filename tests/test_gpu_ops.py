@@ -91,6 +91,63 @@ CONV_CASES = [
 @pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
 @pytest.mark.parametrize("case", CONV_CASES, ids=[c[0] for c in CONV_CASES])
 def test_conv(case, dtype):
+    _check_conv(case, dtype)
+
+
+# The 8-wave 256x256 instantiation is chosen only for Cout % 256 == 0 with >= 384 tiles (M >= ~98 K pixels): every
+# Cout % 256 == 0 case above is replayed with VT_CONV_TILE=256 (forces that tile however few tiles there are: ragged
+# pixel tiles, every padding / cache / residual mode), and the cases below reach it -- and the frames-innermost
+# order, the parity interleave, cache mode -- at sizes where the dispatcher picks it by itself (BASELINE-sized layers).
+BIG256 = [c for c in CONV_CASES if c[3] % 256 == 0]
+CONV_CASES_LARGE = [
+    ("L_conv3d_333_256_m98k", (1, 6, 128, 128), 256, 256, (3, 3, 3), ConvGeom(**G333), dict(res="add")),
+    ("L_conv2d_3x3_256_256", (2, 3, 128, 128), 256, 256, (3, 3), ConvGeom(**G3), dict(res="add")),
+    ("L_temporal_k3_512", (2, 12, 64, 64), 512, 512, (3,), ConvGeom(kt=3, pt=2), dict(res="add")),
+    ("L_timeup_parity_kt2_256", (1, 6, 128, 128), 256, 256, (2, 3, 3),
+     ConvGeom(kt=2, kh=3, kw=3, pt=1, ph=1, pw=1, ph_hi=1, pw_hi=1), dict(res="mix")),
+    ("L_v11_cache_3d_256", (1, 6, 128, 128), 256, 256, (3, 3, 3), ConvGeom(**G333), dict(tmode="cache")),
+    ("L_v11_cache_1d_128", (1, 8, 128, 128), 128, 128, (3,), ConvGeom(kt=3, pt=2), dict(tmode="cache", res="add")),
+    ("L_conv2d_128_128_ln", (1, 4, 256, 256), 128, 128, (3, 3), ConvGeom(**G3), dict(res="add", ln="keep")),
+]
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+@pytest.mark.parametrize("case", BIG256, ids=[c[0] for c in BIG256])
+def test_conv_forced_256_tile(case, dtype, monkeypatch):
+    monkeypatch.setenv("VT_CONV_TILE", "256")
+    assert _check_conv(case, dtype)["tile"] == (256, 256)
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+@pytest.mark.parametrize("case", CONV_CASES_LARGE, ids=[c[0] for c in CONV_CASES_LARGE])
+def test_conv_large(case, dtype):
+    plan = _check_conv(case, dtype)
+    assert plan["tile"] == ((256, 256) if case[3] % 256 == 0 else (128, 128)) and plan["workgroups"] >= 384
+    if "ln" in case[6]:
+        assert plan["ln_fused"]
+
+
+POINTER_CASES = [c for c in CONV_CASES if c[0] in ("conv2d_3x3_256_128_res", "conv2d_3x3_64_192_ragged", "upsample_fold",
+                                                   "temporal_k3_512", "conv3d_333_256", "timeup_fold_mix", "conv_in_3_128",
+                                                   "conv_out_128_3_ncthw_trim", "v11_replicate_3d", "nc_conv3d_sym",
+                                                   "conv3d_333_tinner_256", "conv2d_ln_fused")] + CONV_CASES_LARGE[:3]
+
+
+@pytest.mark.parametrize("tile", ["", "256"])
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+@pytest.mark.parametrize("case", POINTER_CASES, ids=[c[0] for c in POINTER_CASES])
+def test_conv_pointer_gather(case, dtype, tile, monkeypatch):
+    """VT_CONV_BUF=0: the 64-bit pointer form of the gather (what tensors >= 4 GiB and v1.1 cache mode use)"""
+    if tile and case[3] % 256 != 0:
+        pytest.skip("256 tile needs Cout % 256 == 0")
+    monkeypatch.setenv("VT_CONV_BUF", "0")
+    if tile:
+        monkeypatch.setenv("VT_CONV_TILE", tile)
+    plan = _check_conv(case, dtype)
+    assert not tile or plan["tile"] == (256, 256)
+
+
+def _check_conv(case, dtype):
     name, (B, T, H, W), cin, cout, kdims, geom, ex = case
     x = _act(B, T, H, W, cin, dtype, 1)
     g = torch.Generator().manual_seed(2)
@@ -118,7 +175,9 @@ def test_conv(case, dtype):
     if "ln" in ex:
         gam, bet = _rand((cout,), torch.float32, 6, 0.5) + 1.0, _rand((cout,), torch.float32, 7, 0.2)
         keep = ex["ln"] == "keep"
+        ops.CONV_RECORD = []
         out = ops.conv(x, w, bias, geom, cout=cout, ln=(gam, bet, 1e-6, True), ln_keep_y=keep, **kw)
+        rec, ops.CONV_RECORD = ops.CONV_RECORD, None
         torch.cuda.synchronize()
         ref = R.conv(x.cpu(), w.cpu(), bias.cpu(), geom, cout=cout, ln=(gam.cpu(), bet.cpu(), 1e-6, True),
                      ln_keep_y=keep, **_cpu(kw))
@@ -128,8 +187,10 @@ def test_conv(case, dtype):
             e = rel_err(o, r)
             # the normalised output amplifies the bf16 rounding of y when the library normalises the stored y
             assert e < 2 * TOL[dtype], f"{name} {dtype}: rel_err={e}"
-        return
+        return ops.conv_plan(rec[0][0])
+    ops.CONV_RECORD = []
     y = ops.conv(x, w, bias, geom, cout=cout, **kw)
+    rec, ops.CONV_RECORD = ops.CONV_RECORD, None
     torch.cuda.synchronize()
     yr = R.conv(x.cpu(), w.cpu(), bias.cpu(), geom, cout=cout, **_cpu(kw))   # reference on the host
     assert y.shape == yr.shape and y.dtype == yr.dtype
@@ -137,6 +198,7 @@ def test_conv(case, dtype):
     e = rel_err(y, yr)
     print(f"{name} {dtype}: rel_err={e:.3e}")
     assert e < TOL[dtype], f"{name} {dtype}: rel_err={e}"
+    return ops.conv_plan(rec[0][0])
 
 
 @pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
@@ -307,6 +369,18 @@ def test_fsq_aux_stats(levels, B):
     ref = R.fsq_aux_stats(h.cpu(), levels, 100.0)
     print("fsq aux", st.tolist(), ref.tolist())
     assert torch.allclose(st, ref, rtol=2e-4, atol=2e-5)
+
+
+def test_fsq_aux_avg_and_entropy():
+    """the batch-mean code distribution (what the reference all-reduces across ranks) and its entropy"""
+    levels = [8, 8, 8, 5, 5]
+    h = _rand((2, 5, 2, 8, 8), torch.float32, 1, 0.7)
+    st, avg = ops.fsq_aux_stats(h, levels, 100.0, return_avg=True)
+    str_, avgr = R.fsq_aux_stats(h.cpu(), levels, 100.0, return_avg=True)
+    assert avg.shape == (8 * 8 * 8 * 5 * 5,) and torch.allclose(avg.cpu(), avgr, rtol=2e-4, atol=1e-7)
+    assert abs(float(avg.sum()) - 1.0) < 1e-4
+    assert torch.allclose(ops.entropy(avg).cpu(), st[1].cpu(), rtol=1e-5)
+    assert torch.allclose(ops.entropy(avg).cpu(), R.entropy(avgr), rtol=2e-4)
 
 
 @pytest.mark.parametrize("din,dout", [(torch.float32, torch.float32), (torch.bfloat16, torch.bfloat16)],

@@ -207,7 +207,11 @@ def fsq_indices_to_codes(idx, levels):
     return codes.movedim(-1, 1).contiguous().float()
 
 
-def fsq_aux_stats(h, levels, inv_temperature=100.0):
+def entropy(avg):
+    return (-avg * avg.clamp(min=1e-5).log()).sum()
+
+
+def fsq_aux_stats(h, levels, inv_temperature=100.0, return_avg=False):
     lv, _, _, _, half_w, basis = (t.to(h.device) for t in _fsq_consts(levels))
     codes, _ = fsq_quantize(h, levels)
     zf = h.float().movedim(1, -1).reshape(-1, len(levels))
@@ -221,7 +225,8 @@ def fsq_aux_stats(h, levels, inv_temperature=100.0):
     avg = avg / zf.shape[0]
     cbe = (-avg * avg.clamp(min=1e-5).log()).sum()
     commit = ((h.float() - codes) ** 2).mean()
-    return torch.stack([ent / zf.shape[0], cbe, commit])
+    st = torch.stack([ent / zf.shape[0], cbe, commit])
+    return (st, avg) if return_avg else st
 
 
 def fsq_consts(levels):
@@ -247,7 +252,7 @@ def eval_psnr_ssim(x, y, raw=True):
 
 
 ALL = ["conv", "gemm_nt", "layernorm_act", "softmax_rows", "ncthw_to_ndhwc", "ndhwc_to_ncthw", "time_avgpool3s2",
-       "time_lerp2x", "gather_frames", "kl_sample", "fsq_quantize", "fsq_indices_to_codes", "fsq_aux_stats",
+       "time_lerp2x", "gather_frames", "kl_sample", "fsq_quantize", "fsq_indices_to_codes", "fsq_aux_stats", "entropy",
        "eval_psnr_ssim", "channel_linear", "groupnorm_act"]
 
 

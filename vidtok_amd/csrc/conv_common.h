@@ -7,6 +7,7 @@
 namespace {
 
 constexpr int kRowBytes = 128;     // bytes of K per tile row per step
+constexpr int kMaxDevices = 64;    // per-device launch state (function attributes)
 
 // Division of a 32-bit unsigned by a launch-invariant divisor (Granlund-Montgomery round-up form): the host computes
 // (mul, shift), the device needs one mul_hi and three cheap ops instead of the ~25-instruction reciprocal sequence

@@ -34,6 +34,7 @@
 // with 8 or 4 waves (slower), 3-4 waves/SIMD with 64-B rows (slower), LayerNorm in the MFMA-layout epilogue
 // (+1.6 ms per conv), a kw-innermost K walk (less fabric traffic, more time), a persistent variant with a deferred
 // epilogue (conv_stream.hip in the git history: +3 % only, and its counted-vmcnt drain was not race-free in fp32).
+#include <atomic>
 #include <type_traits>
 
 #include "conv_common.h"
@@ -722,25 +723,14 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_igemm_glds_ker
 #endif
 }
 
-// descriptor (buffer_load ... lds) gather; VT_CONV_BUF=0 falls back to 64-bit pointers (A/B runs)
-inline bool conv_buf() {
-  static int mode = -1;
-  if (mode < 0) {
-    const char* e = getenv("VT_CONV_BUF");
-    mode = (e && strcmp(e, "0") == 0) ? 0 : 1;
-  }
-  return mode == 1;
-}
-
-// VT_CONV_TINNER=0 keeps the plain pixel order for temporal convs (A/B runs)
-inline bool conv_tinner() {
-  static int mode = -1;
-  if (mode < 0) {
-    const char* e = getenv("VT_CONV_TINNER");
-    mode = (e && strcmp(e, "0") == 0) ? 0 : 1;
-  }
-  return mode == 1;
-}
+// Test / A-B switches, read from the environment at every call (a getenv per launch is noise next to the launch
+// itself, and nothing is cached in unsynchronised statics):
+//   VT_CONV_BUF=0     gather through 64-bit pointers (global_load_lds) instead of buffer descriptors
+//   VT_CONV_TINNER=0  plain pixel order for temporal convs
+//   VT_CONV_TILE=256  force the 8-wave 256x256 tile wherever it is legal (Cout % 256 == 0, vector epilogue), however
+//                     few tiles that gives; =128 forbids it -- lets small parity cases reach either instantiation
+inline bool conv_buf() { return env_int("VT_CONV_BUF", 1) != 0; }
+inline bool conv_tinner() { return env_int("VT_CONV_TINNER", 1) != 0; }
 
 template <typename MT, typename TOut, int WAVES_M, int WAVES_N, int TM, int TN, bool FAST>
 int launch_variant(const ConvArgs& a_in, int nbatch, hipStream_t stream) {
@@ -777,10 +767,13 @@ int launch_variant(const ConvArgs& a_in, int nbatch, hipStream_t stream) {
   } else {
     kern = reinterpret_cast<const void*>(&conv_igemm_glds_kernel<MT, TOut, WAVES_M, WAVES_N, TM, TN, FAST, ROWB, STAGES, false>);
   }
-  static bool attr_done[2] = {false, false};  // per instantiation and gather form
-  if (!attr_done[buf]) {
+  // the attribute is per device: one flag per (instantiation, gather form, device), set race-free
+  static std::atomic<bool> attr_done[2][kMaxDevices];
+  int dev = 0;
+  VT_CHECK_HIP(hipGetDevice(&dev));
+  if (dev < 0 || dev >= kMaxDevices || !attr_done[buf][dev].load(std::memory_order_acquire)) {
     VT_CHECK_HIP(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
-    attr_done[buf] = true;
+    if (dev >= 0 && dev < kMaxDevices) attr_done[buf][dev].store(true, std::memory_order_release);
   }
   const long long nblk = (long long)a.m_tiles * a.n_tiles;
   VT_CHECK_ARG(nblk < (1ll << 31), "vt_conv: too many tiles (%lld)", nblk);
@@ -800,25 +793,37 @@ int launch_fast_or_general(const ConvArgs& a, int nbatch, hipStream_t stream) {
 // so Cout % 256 == 0 layers with enough pixels take the 8-wave 256x256 tile (measured 988 vs 814 TFLOP/s on
 // the 27-tap 256->256 conv when introduced); everything else keeps 128x128 with two independent workgroups
 // per CU, which cover each other's prologue / epilogue / DMA stalls (256x128 tiles measured slower).
-template <typename MT, typename TOut>
-int dispatch_tile(const ConvArgs& a, int nbatch, hipStream_t stream) {
+enum TileKind { TILE_256x32 = 0, TILE_256x64, TILE_256x256, TILE_128x128 };
+
+inline TileKind select_tile(const ConvArgs& a, int nbatch) {
   auto blocks = [&](int bm, int bn) {
     return (long long)((a.M + bm - 1) / bm) * ((a.Cout + bn - 1) / bn) * nbatch;
   };
   const bool vec_epi = a.out_layout == VT_NDHWC && (a.ldy & 3) == 0 && (a.res_mode == VT_RES_NONE || (a.ldr & 3) == 0);
-  if (a.Cout <= 32) return launch_fast_or_general<MT, TOut, 4, 1, 2, 1>(a, nbatch, stream);   // 256 x 32
-  if (a.Cout <= 64) return launch_fast_or_general<MT, TOut, 4, 1, 2, 2>(a, nbatch, stream);   // 256 x 64
-  if (a.Cout % 256 == 0 && vec_epi && blocks(256, 256) >= 384)
-    return launch_fast_or_general<MT, TOut, 4, 2, 2, 4>(a, nbatch, stream);                   // 256 x 256, 8 waves
-  return launch_fast_or_general<MT, TOut, 2, 2, 2, 2>(a, nbatch, stream);                     // 128 x 128
+  if (a.Cout <= 32) return TILE_256x32;
+  if (a.Cout <= 64) return TILE_256x64;
+  const int force = env_int("VT_CONV_TILE", 0);
+  if (a.Cout % 256 == 0 && vec_epi && force != 128 && (blocks(256, 256) >= 384 || force == 256)) return TILE_256x256;
+  return TILE_128x128;
+}
+
+template <typename MT, typename TOut>
+int dispatch_tile(const ConvArgs& a, int nbatch, hipStream_t stream) {
+  switch (select_tile(a, nbatch)) {
+    case TILE_256x32: return launch_fast_or_general<MT, TOut, 4, 1, 2, 1>(a, nbatch, stream);
+    case TILE_256x64: return launch_fast_or_general<MT, TOut, 4, 1, 2, 2>(a, nbatch, stream);
+    case TILE_256x256: return launch_fast_or_general<MT, TOut, 4, 2, 2, 4>(a, nbatch, stream);   // 8 waves
+    default: return launch_fast_or_general<MT, TOut, 2, 2, 2, 2>(a, nbatch, stream);
+  }
 }
 
 }  // namespace
 
 extern "C" int vt_conv_max_lds_bytes(void) { return 2 * (256 + 256) * kRowBytes; }
 
-extern "C" int vt_conv(const vt_conv_desc* d, vt_stream stream_) {
-  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+namespace {
+// argument validation + the kernel's view of the descriptor; shared by vt_conv and vt_conv_plan
+int conv_prepare(const vt_conv_desc* d, ConvArgs& a, bool& ln_fused, int& nbatch_out) {
   VT_CHECK_ARG(d != nullptr, "vt_conv: null descriptor");
   VT_CHECK_ARG(d->x && d->w && d->y, "vt_conv: null tensor pointer");
   VT_CHECK_ARG(d->dtype == VT_F32 || d->dtype == VT_BF16, "vt_conv: dtype %d", d->dtype);
@@ -871,7 +876,6 @@ extern "C" int vt_conv(const vt_conv_desc* d, vt_stream stream_) {
     VT_CHECK_ARG(d->out_layout == VT_NDHWC && nbatch == 1 && d->ldn >= d->Cout, "vt_conv: fused LayerNorm: NDHWC, nbatch 1, ldn >= Cout");
   }
 
-  ConvArgs a;
   memset(&a, 0, sizeof(a));
   a.x = (const char*)d->x; a.w = (const char*)d->w; a.bias = d->bias; a.y = (char*)d->y;
   a.res = (const char*)d->res; a.cache = (const char*)d->cache; a.mix_factor = d->mix_factor;
@@ -897,20 +901,53 @@ extern "C" int vt_conv(const vt_conv_desc* d, vt_stream stream_) {
   a.xs_z = d->xs_z; a.ws_z = d->ws_z; a.ys_z = d->ys_z; a.rs_z = d->rs_z;
 
   // LayerNorm inside the epilogue: the 128 x 128 tile with the LDS epilogue on full tiles spanning the channel row
-  const bool ln_fused = d->ln_mode != 0 && d->Cout == 128 && M % 128 == 0 && (d->ldy & 7) == 0 && (d->ldn & 7) == 0 &&
+  ln_fused = d->ln_mode != 0 && d->Cout == 128 && M % 128 == 0 && (d->ldy & 7) == 0 && (d->ldn & 7) == 0 &&
                         (d->res_mode == VT_RES_NONE || (d->ldr & 7) == 0) && env_int("VT_CONV_LDSEPI", 1) != 0 &&
                         env_int("VT_CONV_FUSE_LN", 1) != 0;
   if (ln_fused) {
     a.ln_gamma = d->ln_gamma; a.ln_beta = d->ln_beta; a.ln_out = (char*)d->ln_out;
     a.ln_mode = d->ln_mode; a.ln_keep_y = d->ln_keep_y; a.ldn = d->ldn; a.ln_eps = d->ln_eps;
   }
-  int rc;
+  if (d->ln_mode != 0 && !ln_fused)
+    VT_CHECK_ARG(yt_mul == 1 && ys_mul == 1,
+                 "vt_conv: LayerNorm of an interleaved output is only available fused (Cout = 128, full tiles)");
+  nbatch_out = nbatch;
+  return VT_OK;
+}
+}  // namespace
+
+// What vt_conv(d) will do, without launching: out[0..1] = pixel x channel tile, out[2] = waves per workgroup,
+// out[3] = workgroups, out[4] = 1 when LayerNorm is produced by the conv kernel's epilogue (0: second launch of
+// vt_layernorm_act, or no LayerNorm requested), out[5] = kernel launches the call performs.  Lets tests assert which
+// instantiation a parity case exercises and lets bench.py separate conv kernel time from LayerNorm passes.
+extern "C" int vt_conv_plan(const vt_conv_desc* d, int32_t* out6) {
+  VT_CHECK_ARG(out6 != nullptr, "vt_conv_plan: null output");
+  ConvArgs a;
+  bool ln_fused = false;
+  int nbatch = 1;
+  const int rc = conv_prepare(d, a, ln_fused, nbatch);
+  if (rc != VT_OK) return rc;
+  static const int dims[4][3] = {{256, 32, 4}, {256, 64, 4}, {256, 256, 8}, {128, 128, 4}};
+  const int k = (int)select_tile(a, nbatch);
+  out6[0] = dims[k][0]; out6[1] = dims[k][1]; out6[2] = dims[k][2];
+  out6[3] = (int32_t)((long long)((a.M + dims[k][0] - 1) / dims[k][0]) * ((a.Cout + dims[k][1] - 1) / dims[k][1]) * nbatch);
+  out6[4] = ln_fused ? 1 : 0;
+  out6[5] = (d->ln_mode != 0 && !ln_fused) ? 2 : 1;
+  return VT_OK;
+}
+
+extern "C" int vt_conv(const vt_conv_desc* d, vt_stream stream_) {
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  ConvArgs a;
+  bool ln_fused = false;
+  int nbatch = 1;
+  int rc = conv_prepare(d, a, ln_fused, nbatch);
+  if (rc != VT_OK) return rc;
+  const long long M = a.M;
   if (d->dtype == VT_F32) rc = dispatch_tile<float, float>(a, nbatch, stream);
   else if (d->out_dtype == VT_F32) rc = dispatch_tile<bf16_t, float>(a, nbatch, stream);
   else rc = dispatch_tile<bf16_t, bf16_t>(a, nbatch, stream);
   if (rc != VT_OK || d->ln_mode == 0 || ln_fused) return rc;
-  VT_CHECK_ARG(yt_mul == 1 && ys_mul == 1,
-               "vt_conv: LayerNorm of an interleaved output is only available fused (Cout = 128, full tiles)");
   // not fusable here: the same contract in two launches
   return vt_layernorm_act(d->y, d->out_dtype, d->ldy, d->ln_out, d->out_dtype, d->ldn, d->ln_gamma, d->ln_beta, M, d->Cout,
                           d->ln_eps, d->ln_mode == 2 ? 1 : 0, stream_);

@@ -139,7 +139,8 @@ __global__ __launch_bounds__(kBlock) void fsq_aux_tables_kernel(const float* __r
 // of its code and its share of the per-token entropies (with the reference's log clamp 1e-5,
 // regularizers.py:40-45).
 __global__ __launch_bounds__(kBlock) void fsq_aux_entropy_kernel(const float* __restrict__ tables, FsqConsts k,
-                                                                 long long ntok, int J, float* __restrict__ accum) {
+                                                                 long long ntok, int J, float* __restrict__ accum,
+                                                                 float* __restrict__ avg_out) {
   const int j = blockIdx.x * kBlock + threadIdx.x;
   float ent = 0.f, cbe = 0.f;
   if (j < J) {
@@ -154,6 +155,7 @@ __global__ __launch_bounds__(kBlock) void fsq_aux_entropy_kernel(const float* __
       ent -= p * logf(fmaxf(p, 1e-5f));
     }
     avg /= (float)ntok;
+    if (avg_out) avg_out[j] = avg;   // batch-mean code distribution: what the reference all-reduces across ranks
     cbe = -avg * logf(fmaxf(avg, 1e-5f));
   }
   ent = wave_sum(ent, 64);
@@ -161,6 +163,25 @@ __global__ __launch_bounds__(kBlock) void fsq_aux_entropy_kernel(const float* __
   if ((threadIdx.x & 63) == 0) {
     atomicAdd(accum + 0, ent);
     atomicAdd(accum + 1, cbe);
+  }
+}
+
+// entropy(avg) with the reference's log clamp (regularizers.py:40-45) of a J-entry distribution: the codebook entropy
+// recomputed after the cross-rank mean of avg_prob (maybe_distributed_mean, regularizers.py:49-59,240)
+__global__ __launch_bounds__(kBlock) void entropy_kernel(const float* __restrict__ avg, long long J, float* __restrict__ out) {
+  __shared__ float part[kBlock / 64];
+  float e = 0.f;
+  for (long long j = threadIdx.x; j < J; j += kBlock) {
+    const float a = avg[j];
+    e -= a * logf(fmaxf(a, 1e-5f));
+  }
+  e = wave_sum(e, 64);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = e;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float t = 0.f;
+    for (int w = 0; w < kBlock / 64; ++w) t += part[w];
+    out[0] = t;
   }
 }
 
@@ -286,6 +307,19 @@ extern "C" int64_t vt_fsq_aux_work_floats(const int32_t* levels_host, int32_t D,
 
 extern "C" int vt_fsq_aux_stats(const float* h, const int32_t* levels_host, int32_t D, int32_t B, int64_t S,
                                 float inv_temperature, float* work, float* out3, vt_stream stream_) {
+  return vt_fsq_aux_stats_avg(h, levels_host, D, B, S, inv_temperature, work, out3, nullptr, stream_);
+}
+
+extern "C" int vt_entropy(const float* avg, int64_t J, float* out, vt_stream stream_) {
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  VT_CHECK_ARG(avg && out && J > 0, "vt_entropy: bad arguments");
+  hipLaunchKernelGGL(entropy_kernel, dim3(1), dim3(kBlock), 0, stream, avg, (long long)J, out);
+  VT_CHECK_LAUNCH();
+  return VT_OK;
+}
+
+extern "C" int vt_fsq_aux_stats_avg(const float* h, const int32_t* levels_host, int32_t D, int32_t B, int64_t S,
+                                    float inv_temperature, float* work, float* out3, float* avg_out, vt_stream stream_) {
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
   VT_CHECK_ARG(h && work && out3 && B > 0 && S > 0, "vt_fsq_aux_stats: bad arguments");
   FsqConsts k;
@@ -302,7 +336,7 @@ extern "C" int vt_fsq_aux_stats(const float* h, const int32_t* levels_host, int3
                      inv_temperature, tables, accum);
   VT_CHECK_LAUNCH();
   hipLaunchKernelGGL(fsq_aux_entropy_kernel, dim3((unsigned)((J + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream,
-                     (const float*)tables, k, ntok, (int)J, accum);
+                     (const float*)tables, k, ntok, (int)J, accum, avg_out);
   VT_CHECK_LAUNCH();
   hipLaunchKernelGGL(fsq_aux_finish_kernel, dim3(1), dim3(1), 0, stream, (const float*)accum, ntok,
                      ntok * (long long)D, out3);

@@ -61,6 +61,7 @@ SIGNATURES = {
     "vt_conv_max_lds_bytes": (C.c_int, []),
     "vt_conv": (C.c_int, [C.POINTER(ConvDesc), _P]),
     "vt_conv_desc_size": (C.c_int, []),
+    "vt_conv_plan": (C.c_int, [C.POINTER(ConvDesc), C.POINTER(_I32)]),
     "vt_layernorm_act": (C.c_int, [_P, C.c_int, _I64, _P, C.c_int, _I64, _P, _P, _I64, _I32, _F, _I32, _P]),
     "vt_softmax_rows": (C.c_int, [_P, _P, C.c_int, _I64, _I32, _I64, _F, _P]),
     "vt_ncthw_to_ndhwc": (C.c_int, [_P, _P, C.c_int, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _P]),
@@ -73,6 +74,8 @@ SIGNATURES = {
     "vt_fsq_indices_to_codes": (C.c_int, [_P, _P, C.POINTER(_I32), _I32, _I32, _I64, _P]),
     "vt_fsq_aux_work_floats": (_I64, [C.POINTER(_I32), _I32, _I32, _I64]),
     "vt_fsq_aux_stats": (C.c_int, [_P, C.POINTER(_I32), _I32, _I32, _I64, _F, _P, _P, _P]),
+    "vt_fsq_aux_stats_avg": (C.c_int, [_P, C.POINTER(_I32), _I32, _I32, _I64, _F, _P, _P, _P, _P]),
+    "vt_entropy": (C.c_int, [_P, _I64, _P, _P]),
     "vt_groupnorm_work_bytes": (_I64, [_I32, _I32, _I32, _I32]),
     "vt_groupnorm_act": (C.c_int, [_P, C.c_int, _I64, _P, C.c_int, _I64, _P, _P, _I32, _I32, _I64, _I32, _I32, _I32,
                                    C.c_float, _I32, _P, _P]),

@@ -18,20 +18,37 @@ _DT = {torch.float32: L.VT_F32, torch.bfloat16: L.VT_BF16}
 CH_ALIGN = 8  # channel padding granule: 16 B of bf16 (and a multiple of the 4-float fp32 granule)
 
 
-# Optional launch timeline for bench.py's roofline leg: when set to a list, every vt_conv launch
-# appends (start_event, end_event, label) recorded on the launch stream.  None in normal use.
-CONV_TIMELINE = None
+# Optional launch record for bench.py's roofline leg: when set to a list, every vt_conv launch appends
+# (descriptor, tensors it points into -- kept alive --, (pixels, Cout, K)), so the conv launches of a step can be
+# replayed on their own (replay_convs).  None in normal use.
+CONV_RECORD = None
 
 
-def _conv_launch(lib, d, what):
-    if CONV_TIMELINE is None:
-        L.check(lib.vt_conv(C.byref(d), _stream()), what)
-        return
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
+def _conv_launch(lib, d, what, keep=()):
     L.check(lib.vt_conv(C.byref(d), _stream()), what)
-    e1.record()
-    CONV_TIMELINE.append((e0, e1, (d.B * d.To * d.Ho * d.Wo * max(1, d.nbatch), d.Cout, d.KT * d.KH * d.KW * d.Cin)))
+    if CONV_RECORD is not None:
+        CONV_RECORD.append((d, keep, (d.B * d.To * d.Ho * d.Wo * max(1, d.nbatch), d.Cout, d.KT * d.KH * d.KW * d.Cin)))
+
+
+def conv_plan(d):
+    """vt_conv_plan(d) -> dict(tile=(BM, BN), waves, workgroups, ln_fused, launches)"""
+    out = (C.c_int32 * 6)()
+    L.check(L.load().vt_conv_plan(C.byref(d), out), "vt_conv_plan")
+    return dict(tile=(out[0], out[1]), waves=out[2], workgroups=out[3], ln_fused=bool(out[4]), launches=out[5])
+
+
+def replay_convs(record, conv_kernel_only=True):
+    """Re-issue recorded vt_conv launches on the current stream (same descriptors, same tensors).  With
+    conv_kernel_only a descriptor whose LayerNorm is not produced by the conv epilogue is replayed without it (that
+    LayerNorm is a separate vt_layernorm_act launch, not conv kernel time)."""
+    lib = L.load()
+    for d, _keep, _label in record:
+        if conv_kernel_only and d.ln_mode != 0 and not conv_plan(d)["ln_fused"]:
+            d2 = L.ConvDesc()
+            C.memmove(C.byref(d2), C.byref(d), C.sizeof(d))
+            d2.ln_mode = 0
+            d = d2
+        L.check(lib.vt_conv(C.byref(d), _stream()), "vt_conv(replay)")
 
 
 def pad_channels(c: int) -> int:
@@ -157,7 +174,7 @@ def conv(x, w, bias, geom: ConvGeom, *, cout: int, out_dtype=None, tmode=L.VT_TP
             n = (torch.zeros if ldy != cout else torch.empty)(y.shape, dtype=out_dtype, device=x.device)
         d.ln_gamma, d.ln_beta, d.ln_out = gamma.data_ptr(), beta.data_ptr(), n.data_ptr()
         d.ln_mode, d.ln_keep_y, d.ldn, d.ln_eps = (2 if silu else 1), int(bool(ln_keep_y)), ldy, float(eps)
-    _conv_launch(lib, d, "vt_conv")
+    _conv_launch(lib, d, "vt_conv", (x, w, bias, y, res, cache, mix_factor, n, ln))
     if ln is None:
         return y
     return (y, n) if ln_keep_y else n
@@ -188,7 +205,7 @@ def gemm_nt(a, b, *, out_dtype=None, bias=None, ld_out=None):
     d.dtype, d.out_dtype = _DT[a.dtype], _DT[out_dtype]
     d.nbatch = Z
     d.xs_z, d.ws_z, d.ys_z = (M * K if Za == Z else 0), N * K, M * ldo
-    _conv_launch(lib, d, "vt_conv(gemm)")
+    _conv_launch(lib, d, "vt_conv(gemm)", (a, b, bias, y))
     return y
 
 
@@ -369,8 +386,9 @@ def channel_linear(x, w, bias):
     return y
 
 
-def fsq_aux_stats(h, levels, inv_temperature: float = 100.0):
-    """-> fp32 tensor [3]: per-sample entropy, codebook entropy, commitment loss."""
+def fsq_aux_stats(h, levels, inv_temperature: float = 100.0, return_avg: bool = False):
+    """-> fp32 tensor [3]: per-sample entropy, codebook entropy, commitment loss; with return_avg also the batch-mean
+    code distribution avg_prob [prod(levels)] the codebook entropy was taken of."""
     lib = L.load()
     _chk(h, "fsq.h")
     B, D = h.shape[:2]
@@ -379,9 +397,25 @@ def fsq_aux_stats(h, levels, inv_temperature: float = 100.0):
     nwork = lib.vt_fsq_aux_work_floats(arr, D, B, S)
     work = torch.empty((nwork,), dtype=torch.float32, device=h.device)
     out = torch.empty((3,), dtype=torch.float32, device=h.device)
-    L.check(lib.vt_fsq_aux_stats(_ptr(h), arr, D, B, S, float(inv_temperature), _ptr(work), _ptr(out), _stream()),
-            "vt_fsq_aux_stats")
-    return out
+    avg = None
+    if return_avg:
+        J = 1
+        for v in levels:
+            J *= int(v)
+        avg = torch.empty((J,), dtype=torch.float32, device=h.device)
+    L.check(lib.vt_fsq_aux_stats_avg(_ptr(h), arr, D, B, S, float(inv_temperature), _ptr(work), _ptr(out), _ptr(avg),
+                                     _stream()), "vt_fsq_aux_stats_avg")
+    return (out, avg) if return_avg else out
+
+
+def entropy(avg):
+    """sum_j -avg_j log(max(avg_j, 1e-5)) of a distribution on the device (0-dim fp32)."""
+    lib = L.load()
+    _chk(avg, "entropy.avg")
+    assert avg.dtype == torch.float32
+    out = torch.empty((1,), dtype=torch.float32, device=avg.device)
+    L.check(lib.vt_entropy(_ptr(avg), avg.numel(), _ptr(out), _stream()), "vt_entropy")
+    return out[0]
 
 
 def fsq_consts(levels):

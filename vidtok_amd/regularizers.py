@@ -109,6 +109,20 @@ class FSQRegularizer(nn.Module):
         return ops.channel_linear(x, lin.weight.detach().float().contiguous(),
                                   None if lin.bias is None else lin.bias.detach().float().contiguous())
 
+    def _aux_stats(self, h, inv_temperature):
+        """(stats [3], codebook entropy).  Like the reference, the batch-mean code distribution is averaged over the
+        ranks whenever torch.distributed runs with world > 1 -- in eval too (maybe_distributed_mean,
+        regularizers.py:49-59,240): one all_reduce (RCCL on GPUs) of prod(levels) floats, then its entropy."""
+        import torch.distributed as dist
+
+        if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+            st = ops.fsq_aux_stats(h, self.levels, inv_temperature)
+            return st, st[1]
+        st, avg = ops.fsq_aux_stats(h, self.levels, inv_temperature, return_avg=True)
+        dist.all_reduce(avg)
+        avg = avg / dist.get_world_size()
+        return st, ops.entropy(avg)
+
     @torch.no_grad()
     def forward(self, z: torch.Tensor, inv_temperature: float = 100.0, n_steps: int = 0):
         assert z.dim() >= 4, "expects [B, D, T, H, W]"
@@ -118,8 +132,8 @@ class FSQRegularizer(nn.Module):
             h = self._linear(self.project_in, h)
         codes, indices = ops.fsq_quantize(h, self.levels)
         if self.compute_aux_loss and (self.entropy_loss_weight > 0 or self.commitment_loss_weight > 0):
-            st = ops.fsq_aux_stats(h, self.levels, inv_temperature)
-            entropy_aux = st[0] - self.diversity_gamma * st[1]
+            st, codebook_entropy = self._aux_stats(h, inv_temperature)
+            entropy_aux = st[0] - self.diversity_gamma * codebook_entropy
             aux = entropy_aux * self.calculate_entropy_loss_weight(n_steps) + st[2] * self.commitment_loss_weight
         else:
             aux = self.zero.to(z.device) * 1.0
