@@ -141,12 +141,49 @@ typedef struct vt_conv_desc {
 } vt_conv_desc;
 
 int vt_conv(const vt_conv_desc* d, vt_stream stream);
-/* What vt_conv(d) would do, without launching (no GPU needed): out6 = {pixel tile, channel tile, waves per
- * workgroup, workgroups, 1 if LayerNorm comes from the conv epilogue, kernel launches of the call}.  Validates
- * `d` exactly like vt_conv.  Test / measurement aid: which instantiation does a parity case exercise. */
-int vt_conv_plan(const vt_conv_desc* d, int32_t* out6);
+/* What vt_conv(d) would do, without launching (no GPU needed): out8 = {pixel tile, channel tile, waves per
+ * workgroup, workgroups (tiles for the persistent kernel), 1 if LayerNorm comes from the conv epilogue, kernel
+ * launches of the call, kernel (0 = tile-per-workgroup implicit GEMM, 1 = weight-stationary persistent 3x3 for
+ * Cin = Cout = 128 bf16), 0}.  Validates `d` exactly like vt_conv.  Test / measurement aid: which kernel and
+ * instantiation does a parity case exercise. */
+int vt_conv_plan(const vt_conv_desc* d, int32_t* out8);
 /* sizeof(vt_conv_desc) as compiled: lets a binding verify its struct mirror */
 int vt_conv_desc_size(void);
+
+/* ------------------------------------------------------------------------------------------
+ * vt_temporal_block -- one fused launch for the temporal residual block of the reference,
+ * ResnetCausalBlock1D._forward (vidtok/modules/model_3dcausal.py:473-499 with CausalConv1d :144-159 and, for the
+ * first-frame-replicate padding of v1.1, model_3dcausal_v1_1.py:159-178):
+ *     y = x + conv2( SiLU(LN2( conv1( SiLU(LN1(x)) ) )) )       conv = causal Conv1d over T, k = 3, C -> C
+ * on an NDHWC activation x [B][T][HW][ld]; optionally also n_out = [SiLU](LayerNorm_next(y)), the norm the consumer
+ * of y starts with (same contract as vt_conv's ln_mode / ln_keep_y).  LayerNorms are per position over C, eps as
+ * given, statistics in fp32.  w1 / w2 are packed like vt_conv weights: [C][3*C], k = kt*C + c.
+ * tmode: VT_TPAD_ZERO (frames before the clip are zeros) or VT_TPAD_REPLICATE (first frame repeated); the
+ * chunk-to-chunk cache mode of v1.1 tiling is not covered -- callers keep such blocks on vt_layernorm_act + vt_conv.
+ * Covered shapes: bf16, C = ld = 128, HW % 64 == 0 (the widest level of every 488 / 41616 / 288 config);
+ * vt_temporal_block_supported(d) says so without launching (1 / 0); anything else returns VT_ERR_ARG.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct vt_tblock_desc {
+  const void* x;                 /* [B][T][HW][ld]                                            */
+  void* y;                       /* same shape; may be NULL when keep_y == 0                   */
+  void* n_out;                   /* same shape; LayerNorm_next(y) (+SiLU), or NULL             */
+  const void* w1; const float* b1;   /* conv1: [C][3C] packed, bias [C] fp32 or NULL           */
+  const void* w2; const float* b2;   /* conv2                                                   */
+  const float* norm1_gamma; const float* norm1_beta;   /* [C] fp32                              */
+  const float* norm2_gamma; const float* norm2_beta;
+  const float* next_gamma; const float* next_beta;     /* used when ln_next_mode != 0           */
+  int32_t dtype;                 /* VT_BF16                                                    */
+  int32_t C, ld;
+  int32_t B, T;
+  int64_t HW;
+  int32_t tmode;                 /* VT_TPAD_ZERO | VT_TPAD_REPLICATE                           */
+  int32_t keep_y;                /* 0: only n_out is needed (y is never written)               */
+  int32_t ln_next_mode;          /* 0 none, 1 LayerNorm, 2 LayerNorm + SiLU                    */
+  float eps;
+} vt_tblock_desc;
+
+int vt_temporal_block_supported(const vt_tblock_desc* d);
+int vt_temporal_block(const vt_tblock_desc* d, vt_stream stream);
 
 /* ------------------------------------------------------------------------------------------
  * vt_layernorm_act -- per-position LayerNorm over C (eps inside the sqrt, biased variance,

@@ -51,6 +51,8 @@ def main():
             kw = dict(res=torch.randn((B, To, Ho, Wo, cout), device="cuda", dtype=dtype), res_mode=L.VT_RES_ADD)
         if "NCTHW" in name:
             kw = dict(out_layout=L.VT_NCTHW, t_trim=3)
+        if os.environ.get("MB_LN", "0") == "1" and cout == 128 and "NCTHW" not in name:
+            kw.update(ln=(torch.ones(cout, device="cuda"), torch.zeros(cout, device="cuda"), 1e-6, True), ln_keep_y=True)
         for _ in range(2):
             y = ops.conv(x, w, bias, geom, cout=cout, **kw)
         torch.cuda.synchronize()
@@ -65,10 +67,34 @@ def main():
         fl = 2.0 * B * To * Ho * Wo * cout * taps * cin
         tot_ms += ms
         tot_fl += fl
-        yf = y.float()
+        yf = (y[0] if isinstance(y, tuple) else y).float()
         print(f"  {name:46s} {ms:8.3f} ms  {fl / ms / 1e9:8.1f} TFLOP/s   chk {yf.sum().item():+.6e} {yf.abs().sum().item():.6e}")
         del x, w, y, kw
     print(f"  total {tot_ms:.2f} ms, {tot_fl / tot_ms / 1e9:.1f} TFLOP/s aggregate")
+    # fused temporal residual block of the widest level (vt_temporal_block) vs its two K=384 convolutions above
+    if dtype == torch.bfloat16 and (not only or "tblock" in only or "L0" in only):
+        T, H, W, Cc = 20, 256, 256, 128
+        x = torch.randn((B, T, H, W, Cc), device="cuda", dtype=dtype)
+        ws = [(torch.randn((Cc, 3 * Cc), device="cuda") / math.sqrt(3 * Cc)).to(dtype) for _ in range(2)]
+        bs = [torch.randn((Cc,), device="cuda") for _ in range(2)]
+        nm = (torch.ones(Cc, device="cuda"), torch.zeros(Cc, device="cuda"))
+        for nxt in (None, (nm[0], nm[1], True)):
+            if not ops.temporal_block_supported(x, L.VT_TPAD_ZERO):
+                break
+            for _ in range(2):
+                ops.temporal_block(x, ws[0], bs[0], ws[1], bs[1], nm, nm, next_ln=nxt)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(5):
+                out = ops.temporal_block(x, ws[0], bs[0], ws[1], bs[1], nm, nm, next_ln=nxt)
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / 5
+            fl = 2 * 2.0 * B * T * H * W * Cc * 3 * Cc
+            nb = (2 if nxt is None else 3) * x.numel() * 2
+            print(f"  tblock fused 128 @256^2 (next norm: {nxt is not None})        {ms:8.3f} ms  {fl / ms / 1e9:8.1f} TFLOP/s  {nb / ms / 1e6:7.0f} GB/s")
+        del x
     # LayerNorm+SiLU bandwidth on the two biggest activations
     for (T, H, W, C) in ((20, 256, 256, 128), (20, 128, 128, 256)):
         x = torch.randn((B, T, H, W, C), device="cuda", dtype=dtype)

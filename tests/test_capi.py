@@ -131,5 +131,14 @@ def test_conv_plan_tile_selection(built_lib, monkeypatch):
     ln["ldn"] = 256
     p = ops.conv_plan(desc((64, 64), 128, 256, **ln))
     assert not p["ln_fused"] and p["launches"] == 2
+    # the weight-stationary persistent kernel: bf16, 3x3, Cin = Cout = 128, frames tiling by 8 x 16
+    p = ops.conv_plan(desc((256, 256), 128, 128))
+    assert p["kernel"] == "ws128" and p["workgroups"] == 32 * 16
+    assert ops.conv_plan(desc((256, 256), 128, 128, **dict(ln, ldn=128)))["ln_fused"]
+    assert ops.conv_plan(desc((256, 250), 128, 128))["kernel"] == "igemm"
+    assert ops.conv_plan(desc((256, 256), 128, 128, dtype=L.VT_F32, out_dtype=L.VT_F32))["kernel"] == "igemm"
+    monkeypatch.setenv("VT_CONV_WS", "0")
+    assert ops.conv_plan(desc((256, 256), 128, 128))["kernel"] == "igemm"
+    monkeypatch.delenv("VT_CONV_WS")
     with pytest.raises(L.VtError):
         ops.conv_plan(desc((64, 64), 100, 128))                  # same validation as vt_conv

@@ -127,6 +127,79 @@ def test_conv_large(case, dtype):
         assert plan["ln_fused"]
 
 
+# The weight-stationary persistent kernel (conv_ws128.hip) takes bf16 3x3 / Cin = Cout = 128 / frames tiling by 8 x 16:
+# single-tile frames (every halo side out of range at once), tile rows / columns with one border, many tiles per
+# workgroup (double-buffered patch pipeline), + residual, LayerNorm fused with and without keeping y.  Each case also
+# runs with VT_CONV_WS=0 so the tile-per-workgroup kernel keeps its coverage of the same shapes.
+WS_CASES = [
+    ("ws_single_tile", (1, 1, 8, 16), 128, 128, (3, 3), ConvGeom(**G3), {}),
+    ("ws_one_tile_column", (1, 2, 24, 16), 128, 128, (3, 3), ConvGeom(**G3), dict(res="add")),
+    ("ws_one_tile_row", (1, 2, 8, 48), 128, 128, (3, 3), ConvGeom(**G3), dict(res="add", ln="keep")),
+    ("ws_3x3_tiles_frames", (2, 3, 24, 48), 128, 128, (3, 3), ConvGeom(**G3), dict(ln="only")),
+    ("ws_many_tiles_res_ln", (1, 5, 128, 128), 128, 128, (3, 3), ConvGeom(**G3), dict(res="add", ln="keep")),
+    ("ws_many_tiles_plain", (1, 3, 256, 256), 128, 128, (3, 3), ConvGeom(**G3), {}),
+    ("ws_no_bias_path", (1, 2, 16, 32), 128, 128, (3, 3), ConvGeom(**G3), dict(res="add", nobias=True)),
+]
+
+
+@pytest.mark.parametrize("ws", ["1", "0"], ids=["ws128", "igemm"])
+@pytest.mark.parametrize("case", WS_CASES, ids=[c[0] for c in WS_CASES])
+def test_conv_weight_stationary(case, ws, monkeypatch):
+    monkeypatch.setenv("VT_CONV_WS", ws)
+    plan = _check_conv(case, torch.bfloat16)
+    assert plan["kernel"] == ("ws128" if ws == "1" else "igemm")
+    if "ln" in case[6]:
+        assert plan["ln_fused"]
+
+
+TBLOCK_CASES = [  # (B, T, H, W), tmode, next norm (None | silu flag), keep_y
+    ((1, 5, 8, 8), L.VT_TPAD_ZERO, None, True),
+    ((2, 7, 16, 16), L.VT_TPAD_ZERO, True, True),
+    ((1, 1, 8, 16), L.VT_TPAD_ZERO, False, True),            # single frame: both missing taps skipped
+    ((1, 2, 8, 8), L.VT_TPAD_REPLICATE, True, False),        # only the next norm is written
+    ((2, 6, 16, 8), L.VT_TPAD_REPLICATE, None, True),
+    ((1, 20, 128, 128), L.VT_TPAD_ZERO, True, True),         # 256 columns: every CU walks a full 20-frame column
+    ((3, 9, 64, 48), L.VT_TPAD_ZERO, True, True),            # 144 columns: uneven split over the workgroups
+]
+
+
+@pytest.mark.parametrize("shape,tmode,nxt,keep", TBLOCK_CASES, ids=[f"{c[0]}-{c[1]}-{c[2]}-{c[3]}" for c in TBLOCK_CASES])
+def test_temporal_block_fused(shape, tmode, nxt, keep):
+    """vt_temporal_block (one launch) vs the unfused operator sequence it replaces, stated in torch on the host"""
+    B, T, H, W = shape
+    dt, C_ = torch.bfloat16, 128
+    x = _act(B, T, H, W, C_, dt, 1)
+    g = torch.Generator().manual_seed(2)
+    ws = [pack_conv_weight(torch.randn((C_, C_, 3), generator=g) / math.sqrt(3 * C_), dt, cin_stored=C_).to(DEV) for _ in range(2)]
+    bs = [_rand((C_,), torch.float32, 3 + i, 0.1) for i in range(2)]
+    norms = [(_rand((C_,), torch.float32, 10 + i, 0.3) + 1.0, _rand((C_,), torch.float32, 20 + i, 0.2)) for i in range(3)]
+    next_ln = None if nxt is None else (norms[2][0], norms[2][1], nxt)
+    assert ops.temporal_block_supported(x, tmode)
+    out = ops.temporal_block(x, ws[0], bs[0], ws[1], bs[1], norms[0], norms[1], tmode=tmode, next_ln=next_ln, keep_y=keep)
+    torch.cuda.synchronize()
+    c = lambda t: None if t is None else (tuple(u.cpu() if isinstance(u, torch.Tensor) else u for u in t) if isinstance(t, tuple) else t.cpu())
+    ref = R.temporal_block(x.cpu(), ws[0].cpu(), bs[0].cpu(), ws[1].cpu(), bs[1].cpu(), c(norms[0]), c(norms[1]), tmode=tmode,
+                           next_ln=c(next_ln), keep_y=keep)
+    outs = out if isinstance(out, tuple) else (out,)
+    refs = ref if isinstance(ref, tuple) else (ref,)
+    assert len(outs) == len(refs)
+    for o, r in zip(outs, refs):
+        assert o.shape == r.shape and o.dtype == r.dtype and torch.isfinite(o.float()).all()
+        e = rel_err(o, r)
+        print(f"tblock {shape} tmode={tmode}: rel_err={e:.3e}")
+        assert e < 2 * TOL[dt]
+    # not covered: fp32, other channel counts, ragged pixel counts -> the host falls back to the unfused launches
+    assert not ops.temporal_block_supported(_act(1, 2, 8, 8, 128, torch.float32, 1), tmode)
+    assert not ops.temporal_block_supported(_act(1, 2, 8, 8, 256, dt, 1), tmode)
+    assert not ops.temporal_block_supported(_act(1, 2, 5, 7, 128, dt, 1), tmode)
+    assert not ops.temporal_block_supported(x, L.VT_TPAD_CACHE)
+
+
+def test_conv_weight_stationary_not_for_fp32_or_other_shapes():
+    assert _check_conv(WS_CASES[0], torch.float32)["kernel"] == "igemm"
+    assert _check_conv(("ws_ragged_w", (1, 1, 8, 24), 128, 128, (3, 3), ConvGeom(**G3), {}), torch.bfloat16)["kernel"] == "igemm"
+
+
 POINTER_CASES = [c for c in CONV_CASES if c[0] in ("conv2d_3x3_256_128_res", "conv2d_3x3_64_192_ragged", "upsample_fold",
                                                    "temporal_k3_512", "conv3d_333_256", "timeup_fold_mix", "conv_in_3_128",
                                                    "conv_out_128_3_ncthw_trim", "v11_replicate_3d", "nc_conv3d_sym",
@@ -154,7 +227,7 @@ def _check_conv(case, dtype):
     fan = cin * math.prod(kdims)
     wt = torch.randn((cout, cin) + tuple(kdims), generator=g) / math.sqrt(fan)
     w = pack_conv_weight(wt, dtype, cin_stored=x.shape[-1]).to(DEV)
-    bias = _rand((cout,), torch.float32, 3, 0.1)
+    bias = None if ex.get("nobias") else _rand((cout,), torch.float32, 3, 0.1)
     kw = {}
     To, Ho, Wo = geom.out_dims(T, H, W)
     out_dtype = dtype
@@ -179,7 +252,7 @@ def _check_conv(case, dtype):
         out = ops.conv(x, w, bias, geom, cout=cout, ln=(gam, bet, 1e-6, True), ln_keep_y=keep, **kw)
         rec, ops.CONV_RECORD = ops.CONV_RECORD, None
         torch.cuda.synchronize()
-        ref = R.conv(x.cpu(), w.cpu(), bias.cpu(), geom, cout=cout, ln=(gam.cpu(), bet.cpu(), 1e-6, True),
+        ref = R.conv(x.cpu(), w.cpu(), None if bias is None else bias.cpu(), geom, cout=cout, ln=(gam.cpu(), bet.cpu(), 1e-6, True),
                      ln_keep_y=keep, **_cpu(kw))
         outs, refs = (out if keep else (out,)), (ref if keep else (ref,))
         for o, r in zip(outs, refs):
@@ -192,7 +265,7 @@ def _check_conv(case, dtype):
     y = ops.conv(x, w, bias, geom, cout=cout, **kw)
     rec, ops.CONV_RECORD = ops.CONV_RECORD, None
     torch.cuda.synchronize()
-    yr = R.conv(x.cpu(), w.cpu(), bias.cpu(), geom, cout=cout, **_cpu(kw))   # reference on the host
+    yr = R.conv(x.cpu(), w.cpu(), None if bias is None else bias.cpu(), geom, cout=cout, **_cpu(kw))   # reference on the host
     assert y.shape == yr.shape and y.dtype == yr.dtype
     assert torch.isfinite(y.float()).all()
     e = rel_err(y, yr)

@@ -207,6 +207,21 @@ def fsq_indices_to_codes(idx, levels):
     return codes.movedim(-1, 1).contiguous().float()
 
 
+def temporal_block_supported(x, tmode):
+    return False        # the CPU host-logic tests run the blocks unfused (the fused launch is a GPU kernel)
+
+
+def temporal_block(x, w1, b1, w2, b2, norm1, norm2, *, tmode=L.VT_TPAD_ZERO, eps=1e-6, next_ln=None, keep_y=True):
+    """contract of vt_temporal_block: the unfused sequence on the same operators (intermediates rounded to the
+    storage dtype exactly where the unfused HIP path stores them)"""
+    c = x.shape[-1]
+    g = ConvGeom(kt=3, pt=2)
+    h = layernorm_act(x, norm1[0], norm1[1], silu=True, eps=eps)
+    h = conv(h, w1, b1, g, cout=c, tmode=tmode, ln=(norm2[0], norm2[1], eps, True), ln_keep_y=False)
+    kw = {} if next_ln is None else dict(ln=(next_ln[0], next_ln[1], eps, next_ln[2]), ln_keep_y=keep_y)
+    return conv(h, w2, b2, g, cout=c, tmode=tmode, res=x, res_mode=L.VT_RES_ADD, **kw)
+
+
 def entropy(avg):
     return (-avg * avg.clamp(min=1e-5).log()).sum()
 
@@ -252,7 +267,7 @@ def eval_psnr_ssim(x, y, raw=True):
 
 
 ALL = ["conv", "gemm_nt", "layernorm_act", "softmax_rows", "ncthw_to_ndhwc", "ndhwc_to_ncthw", "time_avgpool3s2",
-       "time_lerp2x", "gather_frames", "kl_sample", "fsq_quantize", "fsq_indices_to_codes", "fsq_aux_stats", "entropy",
+       "time_lerp2x", "gather_frames", "kl_sample", "fsq_quantize", "fsq_indices_to_codes", "fsq_aux_stats", "entropy", "temporal_block", "temporal_block_supported",
        "eval_psnr_ssim", "channel_linear", "groupnorm_act"]
 
 

@@ -126,6 +126,41 @@ __device__ __forceinline__ void store_quad<bf16_t>(bf16_t* p, const float (&v)[4
   *reinterpret_cast<u32x2*>(p) = t;
 }
 
+// 8 consecutive channels of one pixel row as stored (16 B bf16 / 32 B fp32)
+template <typename TOut>
+struct Oct;
+template <>
+struct Oct<float> {
+  f32x4 lo, hi;
+  __device__ __forceinline__ void load(const float* p) {
+    lo = *reinterpret_cast<const f32x4*>(p);
+    hi = *reinterpret_cast<const f32x4*>(p + 4);
+  }
+  __device__ __forceinline__ float get(int e) const { return e < 4 ? lo[e] : hi[e - 4]; }
+  static __device__ __forceinline__ void store(float* p, const float (&v)[8]) {
+    f32x4 a, b;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { a[e] = v[e]; b[e] = v[4 + e]; }
+    *reinterpret_cast<f32x4*>(p) = a;
+    *reinterpret_cast<f32x4*>(p + 4) = b;
+  }
+};
+template <>
+struct Oct<bf16_t> {
+  u32x4 w;
+  __device__ __forceinline__ void load(const bf16_t* p) { w = *reinterpret_cast<const u32x4*>(p); }
+  __device__ __forceinline__ float get(int e) const {
+    const uint32_t t = w[e >> 1];
+    return bf16_bits_to_f32((e & 1) ? (t >> 16) : (t & 0xffffu));
+  }
+  static __device__ __forceinline__ void store(bf16_t* p, const float (&v)[8]) {
+    u32x4 t;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) t[e] = f32_to_bf16_bits(v[2 * e]) | (f32_to_bf16_bits(v[2 * e + 1]) << 16);
+    *reinterpret_cast<u32x4*>(p) = t;
+  }
+};
+
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");

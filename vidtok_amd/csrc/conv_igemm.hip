@@ -183,41 +183,6 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[T
 //   LDS layout: T[pixel][32 chunks of 4 floats], chunk index XOR (pixel & 31): the 8 lanes a ds_write_b128 services
 //   together hold 8 different pixels of one chunk -> 8 different columns; a ds_read_b128 group reads 16 different
 //   chunks of one row -> 16 different bank quads.
-// 8 consecutive channels of one pixel row as stored (16 B bf16 / 32 B fp32)
-template <typename TOut>
-struct Oct;
-template <>
-struct Oct<float> {
-  f32x4 lo, hi;
-  __device__ __forceinline__ void load(const float* p) {
-    lo = *reinterpret_cast<const f32x4*>(p);
-    hi = *reinterpret_cast<const f32x4*>(p + 4);
-  }
-  __device__ __forceinline__ float get(int e) const { return e < 4 ? lo[e] : hi[e - 4]; }
-  static __device__ __forceinline__ void store(float* p, const float (&v)[8]) {
-    f32x4 a, b;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) { a[e] = v[e]; b[e] = v[4 + e]; }
-    *reinterpret_cast<f32x4*>(p) = a;
-    *reinterpret_cast<f32x4*>(p + 4) = b;
-  }
-};
-template <>
-struct Oct<bf16_t> {
-  u32x4 w;
-  __device__ __forceinline__ void load(const bf16_t* p) { w = *reinterpret_cast<const u32x4*>(p); }
-  __device__ __forceinline__ float get(int e) const {
-    const uint32_t t = w[e >> 1];
-    return bf16_bits_to_f32((e & 1) ? (t >> 16) : (t & 0xffffu));
-  }
-  static __device__ __forceinline__ void store(bf16_t* p, const float (&v)[8]) {
-    u32x4 t;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) t[e] = f32_to_bf16_bits(v[2 * e]) | (f32_to_bf16_bits(v[2 * e + 1]) << 16);
-    *reinterpret_cast<u32x4*>(p) = t;
-  }
-};
-
 template <typename TOut>
 __device__ __forceinline__ void conv_epilogue_lds128(const ConvArgs& p, f32x16 (&acc)[2][2], int m_blk, int n_blk, int wm,
                                                      int wn, int lane, int tid, char* smem, long long z) {
@@ -795,6 +760,22 @@ int launch_fast_or_general(const ConvArgs& a, int nbatch, hipStream_t stream) {
 // per CU, which cover each other's prologue / epilogue / DMA stalls (256x128 tiles measured slower).
 enum TileKind { TILE_256x32 = 0, TILE_256x64, TILE_256x256, TILE_128x128 };
 
+// Weight-stationary persistent kernel (conv_ws128.hip): bf16 3x3 stride-1 pad-1 convolutions with Cin = Cout = 128 on
+// frames that tile by 8 x 16 pixels -- the nine ResnetBlock convolutions of the widest level.  VT_CONV_WS=0 keeps them
+// on the tile-per-workgroup kernel (A/B runs, and the parity tests run both).
+inline bool ws128_eligible(const ConvArgs& a, int nbatch, bool bf16_io) {
+  if (!bf16_io || env_int("VT_CONV_WS", 1) == 0) return false;
+  if (a.Cin != 128 || a.Cout != 128 || a.ldw != 1152 || a.ldy != 128) return false;
+  if (a.KT != 1 || a.KH != 3 || a.KW != 3 || a.st != 1 || a.sh != 1 || a.sw != 1 || a.ph != 1 || a.pw != 1) return false;
+  if (a.ups_t || a.ups_s || a.Ho != a.Hi || a.Wo != a.Wi || a.To != a.Ti) return false;
+  if (a.Ho % 8 != 0 || a.Wo % 16 != 0 || (long long)a.Ho * a.Wo * 256 > (1ll << 30)) return false;
+  if (a.out_layout != VT_NDHWC || a.yt_mul != 1 || a.ys_mul == 2 || nbatch != 1) return false;
+  if (a.res_mode == VT_RES_MIX) return false;
+  if (a.res_mode == VT_RES_ADD && (a.ldr != 128 || a.Tr != a.To || a.res_tshift != 0 || (reinterpret_cast<uintptr_t>(a.res) & 15))) return false;
+  if ((reinterpret_cast<uintptr_t>(a.y) & 15) || (a.bias && (reinterpret_cast<uintptr_t>(a.bias) & 15))) return false;
+  return true;
+}
+
 inline TileKind select_tile(const ConvArgs& a, int nbatch) {
   auto blocks = [&](int bm, int bn) {
     return (long long)((a.M + bm - 1) / bm) * ((a.Cout + bn - 1) / bn) * nbatch;
@@ -819,11 +800,13 @@ int dispatch_tile(const ConvArgs& a, int nbatch, hipStream_t stream) {
 
 }  // namespace
 
+extern "C" int vt_ws128_launch(const void* conv_args, void* stream);   // conv_ws128.hip
+
 extern "C" int vt_conv_max_lds_bytes(void) { return 2 * (256 + 256) * kRowBytes; }
 
 namespace {
 // argument validation + the kernel's view of the descriptor; shared by vt_conv and vt_conv_plan
-int conv_prepare(const vt_conv_desc* d, ConvArgs& a, bool& ln_fused, int& nbatch_out) {
+int conv_prepare(const vt_conv_desc* d, ConvArgs& a, bool& ln_fused, int& nbatch_out, bool& use_ws) {
   VT_CHECK_ARG(d != nullptr, "vt_conv: null descriptor");
   VT_CHECK_ARG(d->x && d->w && d->y, "vt_conv: null tensor pointer");
   VT_CHECK_ARG(d->dtype == VT_F32 || d->dtype == VT_BF16, "vt_conv: dtype %d", d->dtype);
@@ -901,9 +884,12 @@ int conv_prepare(const vt_conv_desc* d, ConvArgs& a, bool& ln_fused, int& nbatch
   a.xs_z = d->xs_z; a.ws_z = d->ws_z; a.ys_z = d->ys_z; a.rs_z = d->rs_z;
 
   // LayerNorm inside the epilogue: the 128 x 128 tile with the LDS epilogue on full tiles spanning the channel row
-  ln_fused = d->ln_mode != 0 && d->Cout == 128 && M % 128 == 0 && (d->ldy & 7) == 0 && (d->ldn & 7) == 0 &&
+  const bool bf16_io = d->dtype == VT_BF16 && d->out_dtype == VT_BF16;
+  const bool ws_ln_ok = d->ln_mode == 0 || (d->ldn == 128 && (reinterpret_cast<uintptr_t>(d->ln_out) & 15) == 0);
+  use_ws = ws_ln_ok && ws128_eligible(a, nbatch, bf16_io);
+  ln_fused = d->ln_mode != 0 && (use_ws || (d->Cout == 128 && M % 128 == 0 && (d->ldy & 7) == 0 && (d->ldn & 7) == 0 &&
                         (d->res_mode == VT_RES_NONE || (d->ldr & 7) == 0) && env_int("VT_CONV_LDSEPI", 1) != 0 &&
-                        env_int("VT_CONV_FUSE_LN", 1) != 0;
+                        env_int("VT_CONV_FUSE_LN", 1) != 0));
   if (ln_fused) {
     a.ln_gamma = d->ln_gamma; a.ln_beta = d->ln_beta; a.ln_out = (char*)d->ln_out;
     a.ln_mode = d->ln_mode; a.ln_keep_y = d->ln_keep_y; a.ldn = d->ldn; a.ln_eps = d->ln_eps;
@@ -917,32 +903,43 @@ int conv_prepare(const vt_conv_desc* d, ConvArgs& a, bool& ln_fused, int& nbatch
 }  // namespace
 
 // What vt_conv(d) will do, without launching: out[0..1] = pixel x channel tile, out[2] = waves per workgroup,
-// out[3] = workgroups, out[4] = 1 when LayerNorm is produced by the conv kernel's epilogue (0: second launch of
-// vt_layernorm_act, or no LayerNorm requested), out[5] = kernel launches the call performs.  Lets tests assert which
+// out[3] = workgroups (tiles for the persistent kernel), out[4] = 1 when LayerNorm is produced by the conv kernel's
+// epilogue (0: second launch of vt_layernorm_act, or no LayerNorm requested), out[5] = kernel launches the call
+// performs, out[6] = kernel: 0 = conv_igemm_glds_kernel, 1 = conv3x3_ws128_kernel (weight-stationary), out[7] = 0.  Lets tests assert which
 // instantiation a parity case exercises and lets bench.py separate conv kernel time from LayerNorm passes.
-extern "C" int vt_conv_plan(const vt_conv_desc* d, int32_t* out6) {
-  VT_CHECK_ARG(out6 != nullptr, "vt_conv_plan: null output");
+extern "C" int vt_conv_plan(const vt_conv_desc* d, int32_t* out8) {
+  VT_CHECK_ARG(out8 != nullptr, "vt_conv_plan: null output");
   ConvArgs a;
-  bool ln_fused = false;
+  bool ln_fused = false, use_ws = false;
   int nbatch = 1;
-  const int rc = conv_prepare(d, a, ln_fused, nbatch);
+  const int rc = conv_prepare(d, a, ln_fused, nbatch, use_ws);
   if (rc != VT_OK) return rc;
+  out8[6] = use_ws ? 1 : 0;
+  out8[7] = 0;
+  if (use_ws) {   // persistent: 8 x 16-pixel tiles x all 128 channels, at most one workgroup per CU
+    out8[0] = 128; out8[1] = 128; out8[2] = 4;
+    out8[3] = (a.Wo / 16) * (a.Ho / 8) * a.B * a.To;
+    out8[4] = d->ln_mode != 0 ? 1 : 0;
+    out8[5] = 1;
+    return VT_OK;
+  }
   static const int dims[4][3] = {{256, 32, 4}, {256, 64, 4}, {256, 256, 8}, {128, 128, 4}};
   const int k = (int)select_tile(a, nbatch);
-  out6[0] = dims[k][0]; out6[1] = dims[k][1]; out6[2] = dims[k][2];
-  out6[3] = (int32_t)((long long)((a.M + dims[k][0] - 1) / dims[k][0]) * ((a.Cout + dims[k][1] - 1) / dims[k][1]) * nbatch);
-  out6[4] = ln_fused ? 1 : 0;
-  out6[5] = (d->ln_mode != 0 && !ln_fused) ? 2 : 1;
+  out8[0] = dims[k][0]; out8[1] = dims[k][1]; out8[2] = dims[k][2];
+  out8[3] = (int32_t)((long long)((a.M + dims[k][0] - 1) / dims[k][0]) * ((a.Cout + dims[k][1] - 1) / dims[k][1]) * nbatch);
+  out8[4] = ln_fused ? 1 : 0;
+  out8[5] = (d->ln_mode != 0 && !ln_fused) ? 2 : 1;
   return VT_OK;
 }
 
 extern "C" int vt_conv(const vt_conv_desc* d, vt_stream stream_) {
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
   ConvArgs a;
-  bool ln_fused = false;
+  bool ln_fused = false, use_ws = false;
   int nbatch = 1;
-  int rc = conv_prepare(d, a, ln_fused, nbatch);
+  int rc = conv_prepare(d, a, ln_fused, nbatch, use_ws);
   if (rc != VT_OK) return rc;
+  if (use_ws) return vt_ws128_launch(&a, stream_);
   const long long M = a.M;
   if (d->dtype == VT_F32) rc = dispatch_tile<float, float>(a, nbatch, stream);
   else if (d->out_dtype == VT_F32) rc = dispatch_tile<bf16_t, float>(a, nbatch, stream);

@@ -1,0 +1,334 @@
+// Fused temporal residual block of the widest level (C = 128, bf16):
+//     y = x + conv2( SiLU(LN2( conv1( SiLU(LN1(x)) ) )) ),   conv = causal Conv1d over T, k = 3
+// = ResnetCausalBlock1D._forward of the reference (model_3dcausal.py:473-499 with CausalConv1d :144-159), optionally
+// followed by the LayerNorm(+SiLU) the NEXT block starts with (emitted like vt_conv's `ln_mode`).
+//
+// Unfused, the two K = 384 convolutions of such a block are HBM-shaped (95 FLOP/B): per pixel they move the normalised
+// input, the intermediate twice, the residual, the result and the next norm -- ~2 KiB -- in two launches of 1.45 ms.
+// Here a block reads x once and writes y (+ the next norm) once: 512-768 B per pixel, one launch.
+//
+// Structure (weight-stationary like conv_ws128.hip): one workgroup per CU, 4 waves = one per SIMD with the whole
+// register file; wave w keeps output channels [32w, 32w+32) of BOTH convolutions (2 x 24 MFMA A-fragments = 192
+// registers, all in the accumulator half) for the lifetime of the kernel.  A workgroup owns pixel columns -- 64
+// consecutive pixels of one clip -- and walks each column through time:
+//   step t:  x[t] rows (prefetched into registers one step ahead) -> LN1+SiLU -> ring1[t % 3]          (LDS, bf16)
+//            GEMM1: taps = ring1 slots of frames t-2, t-1, t                 -> T (fp32, transposed)   (LDS)
+//            rows of T + b1 -> LN2+SiLU -> ring2[t % 3]
+//            GEMM2: taps = ring2 slots                                        -> T
+//            rows of T + b2 + x[t] (still in registers) -> y[t], LayerNorm_next -> n[t]                (HBM)
+// Causal padding: frames before the clip are zeros (v1.0: their taps are skipped) or the first frame repeated (v1.1
+// first chunk / un-tiled).  Chunk-to-chunk caches (v1.1 tiling) are not handled here: the host keeps those blocks on
+// the unfused path.  Four barriers per step; nothing depends on load / store ordering.
+#include <atomic>
+#include <type_traits>
+
+#include "conv_common.h"
+
+namespace {
+
+[[maybe_unused]] constexpr int TB_PIX = 64;                      // pixels per column step
+[[maybe_unused]] constexpr int TB_ROWP = 272;                    // ring row: 256 B of channels + 16 B pad (bank spread)
+[[maybe_unused]] constexpr int TB_SLOT = TB_PIX * TB_ROWP;       // 17 408
+[[maybe_unused]] constexpr int TB_RING = 3 * TB_SLOT;            // 52 224
+[[maybe_unused]] constexpr int TB_T = TB_PIX * 128 * 4;          // 32 768
+[[maybe_unused]] constexpr int TB_LDS = 2 * TB_RING + TB_T;      // 137 216: [ring1][ring2][T]
+
+struct TBlockArgs {
+  const bf16_t* x;
+  bf16_t* y;
+  bf16_t* n_out;
+  const bf16_t* w1;
+  const bf16_t* w2;
+  const float* b1;
+  const float* b2;
+  const float* g1; const float* be1;
+  const float* g2; const float* be2;
+  const float* gn; const float* ben;
+  int B, T, HW;
+  int replicate;      // 0: zero frames before the clip, 1: first frame repeated
+  int keep_y;         // write y (0 only with ln_next != 0: the consumer needs just the normalised tensor)
+  int ln_next;        // 0 none, 1 LayerNorm, 2 LayerNorm + SiLU
+  float eps;
+};
+
+template <int I, int N, typename F>
+__device__ __forceinline__ void tb_static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    tb_static_for<I + 1, N>(f);
+  }
+}
+
+// accumulators in the architectural half, stationary weights in the accumulator half (see conv_ws128.hip)
+__device__ __forceinline__ void tb_mfma(const u32x4& w, const u32x4& x, f32x16& acc) {
+  asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "a"(w), "v"(x));
+}
+
+// LayerNorm (+SiLU) of one pixel row held by 16 lanes x 8 channels; two-pass statistics like layernorm_act_kernel
+template <bool SILU>
+__device__ __forceinline__ void tb_row_norm(float (&v)[8], const float (&g)[8], const float (&b)[8], float eps, float (&o)[8]) {
+  float s = 0.f;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) s += v[e];
+  const float mean = group_sum_dpp<16>(s) * (1.0f / 128.0f);
+  float q = 0.f;
+  float d[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    d[e] = v[e] - mean;
+    q += d[e] * d[e];
+  }
+  const float rstd = __builtin_amdgcn_rsqf(group_sum_dpp<16>(q) * (1.0f / 128.0f) + eps);
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const float u = d[e] * rstd * g[e] + b[e];
+    o[e] = SILU ? silu_fast(u) : u;
+  }
+}
+
+__global__ __launch_bounds__(256, 1) void tblock_ws128_kernel(const TBlockArgs p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ptiles = p.HW / TB_PIX;
+  const int ncols = p.B * ptiles;
+  const int G = gridDim.x;
+  const int slot_id = xcd_remap(blockIdx.x, G);
+  const int cq = ncols / G, cr = ncols - cq * G;
+  const int c_begin = slot_id * cq + min(slot_id, cr);
+  const int c_end = c_begin + cq + (slot_id < cr ? 1 : 0);
+  if (c_begin >= c_end) return;
+
+  char* ring1 = smem;
+  char* ring2 = smem + TB_RING;
+  float* T = reinterpret_cast<float*>(smem + 2 * TB_RING);
+
+  // ---- stationary weights: fragments [0,24) = conv1, [24,48) = conv2; g = kt*8 + c (k = kt*128 + 16c + 8*(lane/32) ..+8)
+  u32x4 wreg[48];
+  {
+    const long long roff = (long long)(wave * 32 + (lane & 31)) * 384 + (lane >> 5) * 8;
+#pragma unroll
+    for (int g = 0; g < 24; ++g) wreg[g] = *reinterpret_cast<const u32x4*>(p.w1 + roff + g * 16);
+#pragma unroll
+    for (int g = 0; g < 24; ++g) wreg[24 + g] = *reinterpret_cast<const u32x4*>(p.w2 + roff + g * 16);
+  }
+  // ---- per-lane row geometry: rows row0 + 16*it (it < 4), channels [8 oct_j, +8) -------------------------------------
+  const int oct_j = tid & 15, row0 = tid >> 4;
+  float lg1[8], lb1[8], lg2[8], lb2[8], lgn[8], lbn[8], bo1[8], bo2[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    lg1[e] = p.g1[8 * oct_j + e]; lb1[e] = p.be1[8 * oct_j + e];
+    lg2[e] = p.g2[8 * oct_j + e]; lb2[e] = p.be2[8 * oct_j + e];
+    lgn[e] = p.ln_next ? p.gn[8 * oct_j + e] : 1.0f;
+    lbn[e] = p.ln_next ? p.ben[8 * oct_j + e] : 0.0f;
+    bo1[e] = p.b1 ? p.b1[8 * oct_j + e] : 0.0f;
+    bo2[e] = p.b2 ? p.b2[8 * oct_j + e] : 0.0f;
+  }
+  const int frag_off = (lane & 31) * TB_ROWP + (lane >> 5) * 16;     // B-fragment of pixel lane%32, k half lane/32
+  const int row_lds = oct_j * 16;                                    // + row * TB_ROWP : this lane's 16 B of a ring row
+  auto col_base = [&](int col) -> long long {                        // element offset of (b, frame 0, first pixel of the tile)
+    const int b = col / ptiles;
+    const int pt = col - b * ptiles;
+    return ((long long)b * p.T * p.HW + (long long)pt * TB_PIX) * 128;
+  };
+  const long long frame_stride = (long long)p.HW * 128;
+
+  // GEMM over the valid taps [KT0, 3) of a ring: acc[j] (j = 0, 1: pixel sub-tiles of 32) += W[kt] . ring[frame t-2+kt].
+  // Software pipeline: the two B-fragments of group g+2 are requested before the MFMAs of group g.
+  auto gemm = [&](auto kt0_c, auto wbase_c, const char* ring, int t, f32x16 (&acc)[2]) {
+    constexpr int KT0 = decltype(kt0_c)::value, WB = decltype(wbase_c)::value;
+    constexpr int G0 = KT0 * 8;
+    const char* sp[3];
+#pragma unroll
+    for (int kt = 0; kt < 3; ++kt) {
+      const int fr = max(t - 2 + kt, 0);                             // replicate: frames before the clip = frame 0
+      sp[kt] = ring + (fr % 3) * TB_SLOT + frag_off;
+    }
+    auto faddr = [&](int g, int j) -> const u32x4* {
+      return reinterpret_cast<const u32x4*>(sp[g >> 3] + j * (32 * TB_ROWP) + (g & 7) * 32);
+    };
+    u32x4 xf[3][2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) xf[G0 % 3][j] = *faddr(G0, j);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) xf[(G0 + 1) % 3][j] = *faddr(G0 + 1, j);
+    tb_static_for<G0, 24>([&](auto gc) {
+      constexpr int g = decltype(gc)::value;
+      if constexpr (g + 2 < 24) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) xf[(g + 2) % 3][j] = *faddr(g + 2, j);
+      }
+#pragma unroll
+      for (int j = 0; j < 2; ++j) tb_mfma(wreg[WB + g], xf[g % 3][j], acc[j]);
+      __builtin_amdgcn_sched_barrier(0);
+    });
+    asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");               // last MFMA -> first VALU reader of its accumulator
+  };
+  auto gemm_taps = [&](auto wbase_c, const char* ring, int t, f32x16 (&acc)[2]) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[j][r] = 0.0f;
+    const int first = p.replicate ? 0 : max(0, 2 - t);                // uniform
+    if (first == 0) gemm(std::integral_constant<int, 0>{}, wbase_c, ring, t, acc);
+    else if (first == 1) gemm(std::integral_constant<int, 1>{}, wbase_c, ring, t, acc);
+    else gemm(std::integral_constant<int, 2>{}, wbase_c, ring, t, acc);
+  };
+  // accumulators (MFMA layout: lane = pixel 32j + lane%32, channels 32 wave + 8g + 4 (lane/32) + e) -> T, transposed
+  auto acc_to_T = [&](f32x16 (&acc)[2]) {
+    const int h = lane >> 5;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int prow = 32 * j + (lane & 31);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int c = wave * 32 + 8 * g + 4 * h;
+        f32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = acc[j][4 * g + e];
+        *reinterpret_cast<f32x4*>(T + prow * 128 + (((c >> 2) ^ (prow & 31)) << 2)) = v;
+      }
+    }
+  };
+  auto T_row = [&](int row, float (&v)[8]) {
+    const int sw = row & 31;
+    const f32x4 t0 = *reinterpret_cast<const f32x4*>(T + row * 128 + (((2 * oct_j) ^ sw) << 2));
+    const f32x4 t1 = *reinterpret_cast<const f32x4*>(T + row * 128 + (((2 * oct_j + 1) ^ sw) << 2));
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = e < 4 ? t0[e] : t1[e - 4];
+  };
+  auto ring_store = [&](char* ring, int t, int row, const float (&o)[8]) {
+    u32x4 w;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) w[e] = f32_to_bf16_bits(o[2 * e]) | (f32_to_bf16_bits(o[2 * e + 1]) << 16);
+    *reinterpret_cast<u32x4*>(ring + (t % 3) * TB_SLOT + row * TB_ROWP + row_lds) = w;
+  };
+
+  Oct<bf16_t> xr[4], xn[4];
+  {
+    const bf16_t* src = p.x + col_base(c_begin) + 8 * oct_j;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) xr[it].load(src + (long long)(row0 + 16 * it) * 128);
+  }
+  for (int col = c_begin; col < c_end; ++col) {
+    const long long cb = col_base(col);
+    for (int t = 0; t < p.T; ++t) {
+      // ---- P0: LN1 + SiLU of x[t] -> ring1[t % 3] ----
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        float v[8], o[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = xr[it].get(e);
+        tb_row_norm<true>(v, lg1, lb1, p.eps, o);
+        ring_store(ring1, t, row0 + 16 * it, o);
+      }
+      // prefetch the rows of the next step (next frame of this column, or frame 0 of the next column)
+      {
+        const bool last_t = t + 1 == p.T;
+        const bool more = !last_t || col + 1 < c_end;                 // uniform
+        if (more) {
+          const bf16_t* src = p.x + (last_t ? col_base(col + 1) : cb + (long long)(t + 1) * frame_stride) + 8 * oct_j;
+#pragma unroll
+          for (int it = 0; it < 4; ++it) xn[it].load(src + (long long)(row0 + 16 * it) * 128);
+        }
+      }
+      __syncthreads();                                                // (1) ring1[t] visible; T free
+      f32x16 acc[2];
+      gemm_taps(std::integral_constant<int, 0>{}, ring1, t, acc);
+      acc_to_T(acc);
+      __syncthreads();                                                // (2)
+      // ---- rows of conv1 + b1 -> LN2 + SiLU -> ring2[t % 3] ----
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        float v[8], o[8];
+        T_row(row0 + 16 * it, v);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += bo1[e];
+        tb_row_norm<true>(v, lg2, lb2, p.eps, o);
+        ring_store(ring2, t, row0 + 16 * it, o);
+      }
+      __syncthreads();                                                // (3) ring2[t] visible; T free
+      gemm_taps(std::integral_constant<int, 24>{}, ring2, t, acc);
+      acc_to_T(acc);
+      __syncthreads();                                                // (4)
+      // ---- rows of conv2 + b2 + x[t] -> y[t]; LayerNorm_next -> n[t] ----
+      const long long ob = cb + (long long)t * frame_stride + 8 * oct_j;
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int row = row0 + 16 * it;
+        float v[8];
+        T_row(row, v);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = xr[it].get(e) + (v[e] + bo2[e]);
+        if (p.keep_y) Oct<bf16_t>::store(p.y + ob + (long long)row * 128, v);
+        if (p.ln_next) {                                              // uniform
+          float o[8];
+          if (p.ln_next == 2) tb_row_norm<true>(v, lgn, lbn, p.eps, o);
+          else tb_row_norm<false>(v, lgn, lbn, p.eps, o);
+          Oct<bf16_t>::store(p.n_out + ob + (long long)row * 128, o);
+        }
+      }
+#pragma unroll
+      for (int it = 0; it < 4; ++it) xr[it] = xn[it];
+    }
+  }
+#endif
+}
+
+}  // namespace
+
+// Fused temporal residual block, see include/vidtok_amd.h (vt_temporal_block).  Returns VT_ERR_ARG with a message when
+// the shape is not one this kernel covers; vt_temporal_block_supported lets the host ask first.
+extern "C" int vt_temporal_block_supported(const vt_tblock_desc* d) {
+  if (!d) return 0;
+  if (d->dtype != VT_BF16 || d->C != 128 || d->ld != 128) return 0;
+  if (d->B <= 0 || d->T <= 0 || d->HW <= 0 || d->HW % TB_PIX != 0) return 0;
+  if (d->tmode != VT_TPAD_ZERO && d->tmode != VT_TPAD_REPLICATE) return 0;
+  if (d->ln_next_mode < 0 || d->ln_next_mode > 2) return 0;
+  if (env_int("VT_TBLOCK_FUSED", 1) == 0) return 0;
+  return 1;
+}
+
+extern "C" int vt_temporal_block(const vt_tblock_desc* d, vt_stream stream_) {
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  VT_CHECK_ARG(d != nullptr, "vt_temporal_block: null descriptor");
+  VT_CHECK_ARG(vt_temporal_block_supported(d),
+               "vt_temporal_block: only bf16, C = ld = 128, HW %% 64 == 0, zero / replicate time padding (got dtype %d C %d ld %d "
+               "HW %lld tmode %d)", d->dtype, d->C, d->ld, (long long)d->HW, d->tmode);
+  VT_CHECK_ARG(d->x && d->w1 && d->w2 && d->norm1_gamma && d->norm1_beta && d->norm2_gamma && d->norm2_beta,
+               "vt_temporal_block: null tensor pointer");
+  VT_CHECK_ARG(d->keep_y || d->ln_next_mode != 0, "vt_temporal_block: nothing to write (keep_y = 0 and no next norm)");
+  VT_CHECK_ARG(!d->keep_y || d->y, "vt_temporal_block: y is null");
+  VT_CHECK_ARG(d->ln_next_mode == 0 || (d->next_gamma && d->next_beta && d->n_out), "vt_temporal_block: next norm needs gamma, beta, n_out");
+  const uintptr_t al = reinterpret_cast<uintptr_t>(d->x) | reinterpret_cast<uintptr_t>(d->y) | reinterpret_cast<uintptr_t>(d->n_out) |
+                       reinterpret_cast<uintptr_t>(d->w1) | reinterpret_cast<uintptr_t>(d->w2);
+  VT_CHECK_ARG((al & 15) == 0, "vt_temporal_block: tensors must be 16-byte aligned");
+  TBlockArgs a;
+  a.x = (const bf16_t*)d->x; a.y = (bf16_t*)d->y; a.n_out = (bf16_t*)d->n_out;
+  a.w1 = (const bf16_t*)d->w1; a.w2 = (const bf16_t*)d->w2; a.b1 = d->b1; a.b2 = d->b2;
+  a.g1 = d->norm1_gamma; a.be1 = d->norm1_beta; a.g2 = d->norm2_gamma; a.be2 = d->norm2_beta;
+  a.gn = d->next_gamma; a.ben = d->next_beta;
+  a.B = d->B; a.T = d->T; a.HW = (int)d->HW;
+  a.replicate = d->tmode == VT_TPAD_REPLICATE ? 1 : 0;
+  a.keep_y = d->keep_y ? 1 : 0;
+  a.ln_next = d->ln_next_mode;
+  a.eps = d->eps;
+  const void* kern = reinterpret_cast<const void*>(&tblock_ws128_kernel);
+  static std::atomic<int> cus[kMaxDevices];
+  int dev = 0;
+  VT_CHECK_HIP(hipGetDevice(&dev));
+  int ncu = (dev >= 0 && dev < kMaxDevices) ? cus[dev].load(std::memory_order_acquire) : 0;
+  if (ncu == 0) {
+    VT_CHECK_HIP(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, TB_LDS));
+    VT_CHECK_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
+    if (ncu <= 0) ncu = 256;
+    if (dev >= 0 && dev < kMaxDevices) cus[dev].store(ncu, std::memory_order_release);
+  }
+  const long long ncols = (long long)d->B * (d->HW / TB_PIX);
+  const int grid = ncols < ncu ? (int)ncols : ncu;
+  void* kargs[] = {&a};
+  VT_CHECK_HIP(hipLaunchKernel(kern, dim3((unsigned)grid), dim3(256), kargs, TB_LDS, stream));
+  return VT_OK;
+}

@@ -142,6 +142,13 @@ class AutoencodingEngineV11(AutoencodingEngine):
             if hasattr(module, "is_first_chunk"):
                 module.is_first_chunk = is_first_chunk
 
+    def _set_fused_temporal(self):
+        """Un-tiled passes never read the chunk caches, so blocks that can run as one fused launch (which keeps their
+        convolutions' inputs on chip and therefore cannot leave caches behind) may do so; tiled passes may not."""
+        for module in self.modules():
+            if hasattr(module, "allow_fused"):
+                module.allow_fused = not self.use_tiling
+
     def _set_cache_offset(self, modules, cache_offset=0):
         for module in modules:
             for submodule in module.modules():
@@ -163,6 +170,7 @@ class AutoencodingEngineV11(AutoencodingEngine):
     def encode(self, x: Any, return_reg_log: bool = False) -> Any:
         self._empty_causal_cached(self.encoder)
         self._set_first_chunk(True)
+        self._set_fused_temporal()
         if self.use_tiling:
             z, reg_log = self.tile_encode(x)
         else:
@@ -196,6 +204,7 @@ class AutoencodingEngineV11(AutoencodingEngine):
             z = self.tile_indices_to_latent(z) if self.use_tiling else self.indices_to_latent(z)
         self._empty_causal_cached(self.decoder)
         self._set_first_chunk(True)
+        self._set_fused_temporal()
         if self.use_tiling:
             return self.tile_decode(z)
         return self.decoder(z)

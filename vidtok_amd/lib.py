@@ -53,6 +53,19 @@ class ConvDesc(C.Structure):
     )
 
 
+class TBlockDesc(C.Structure):
+    """Field-for-field mirror of `vt_tblock_desc` (include/vidtok_amd.h)."""
+
+    _fields_ = (
+        [(n, C.c_void_p) for n in ("x", "y", "n_out", "w1", "b1", "w2", "b2", "norm1_gamma", "norm1_beta", "norm2_gamma",
+                                   "norm2_beta", "next_gamma", "next_beta")]
+        + [(n, C.c_int32) for n in ("dtype", "C", "ld", "B", "T")]
+        + [("HW", C.c_int64)]
+        + [(n, C.c_int32) for n in ("tmode", "keep_y", "ln_next_mode")]
+        + [("eps", C.c_float)]
+    )
+
+
 # name -> (restype, argtypes); every symbol include/vidtok_amd.h declares
 _P, _I32, _I64, _F = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 SIGNATURES = {
@@ -62,6 +75,8 @@ SIGNATURES = {
     "vt_conv": (C.c_int, [C.POINTER(ConvDesc), _P]),
     "vt_conv_desc_size": (C.c_int, []),
     "vt_conv_plan": (C.c_int, [C.POINTER(ConvDesc), C.POINTER(_I32)]),
+    "vt_temporal_block_supported": (C.c_int, [C.POINTER(TBlockDesc)]),
+    "vt_temporal_block": (C.c_int, [C.POINTER(TBlockDesc), _P]),
     "vt_layernorm_act": (C.c_int, [_P, C.c_int, _I64, _P, C.c_int, _I64, _P, _P, _I64, _I32, _F, _I32, _P]),
     "vt_softmax_rows": (C.c_int, [_P, _P, C.c_int, _I64, _I32, _I64, _F, _P]),
     "vt_ncthw_to_ndhwc": (C.c_int, [_P, _P, C.c_int, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _P]),

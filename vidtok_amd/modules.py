@@ -53,6 +53,7 @@ def plain(x):
 
 
 _EMIT_NEXT_NORM = os.environ.get("VIDTOK_AMD_EMIT_NEXT_NORM", "1") != "0"   # A/B switch (0: consumers run their own norm)
+_FUSE_TBLOCK = os.environ.get("VIDTOK_AMD_FUSE_TBLOCK", "1") != "0"         # A/B switch (0: temporal blocks as two convs)
 
 
 def _emit(next_norm):
@@ -452,12 +453,40 @@ class ResnetCausalBlock1D(nn.Module):
             self.conv2.conv.weight.data.zero_()
             self.conv2.conv.bias.data.zero_()
 
-    def first_norm(self):
+    # v1.1 blocks keep chunk-to-chunk caches of their convolutions' inputs, which the fused launch never materialises:
+    # an engine that is NOT tiling sets this (AutoencodingEngineV11._set_fused_temporal); v1.0 has no caches
+    allow_fused = False
+
+    def _fusable(self, dt):
+        """may run as ONE launch (ops.temporal_block): LayerNorm variant, C -> C, bf16, no live v1.1 chunk state"""
+        if not _FUSE_TBLOCK or dt != torch.bfloat16 or self.in_channels != self.out_channels:
+            return False
+        if not (self.norm1.fusable and self.norm2.fusable):
+            return False
+        return self.conv1.version == "v1_0" or (self.allow_fused and self.conv1.is_first_chunk)
+
+    def first_norm(self, dt=None):
+        # a fused block normalises x itself: its producer must not spend a write on LayerNorm1(x)
+        if dt is not None and self._fusable(dt) and self.in_channels == 128:
+            return None
         return (self.norm1, True)
 
     def run(self, x, dt, next_norm=None):
+        xp = plain(x)
+        tmode = L.VT_TPAD_ZERO if self.conv1.version == "v1_0" else L.VT_TPAD_REPLICATE
+        if self._fusable(dt) and ops.temporal_block_supported(xp, tmode):
+            c = xp.shape[-1]
+            w1, b1 = self.conv1._pack.get(self.conv1.conv.weight, self.conv1.conv.bias, dt, cin_stored=c)
+            w2, b2 = self.conv2._pack.get(self.conv2.conv.weight, self.conv2.conv.bias, dt, cin_stored=c)
+            nxt = None
+            if next_norm is not None and _EMIT_NEXT_NORM and next_norm[0].fusable:
+                g, b = next_norm[0].affine()
+                nxt = (g, b, next_norm[1])
+            out = ops.temporal_block(xp, w1, b1, w2, b2, self.norm1.affine(), self.norm2.affine(), tmode=tmode,
+                                     eps=self.norm1.norm.eps, next_ln=nxt, keep_y=True)
+            return out if nxt is None else Normed(out[0], out[1], next_norm[0], next_norm[1])
         h = self.norm1.apply_ndhwc(x, True, dt, SITE_POS)
-        x = plain(x)
+        x = xp
         h = self.norm2.after(lambda **kw: self.conv1.run(h, dt, **kw), True, dt, SITE_POS)
         if self.in_channels != self.out_channels:
             x = self.nin_shortcut.run(x, dt)
@@ -498,9 +527,13 @@ class AttnBlockWrapper(nn.Module):
         return _wrap(self.proj_out.run(o, dt, res=x, res_mode=L.VT_RES_ADD, **_emit(next_norm)), next_norm)
 
 
-def first_norm_of(stage):
-    """(LayerNorm, silu) a stage applies to its input first, or None (resamplers)"""
-    return stage.first_norm() if hasattr(stage, "first_norm") else None
+def first_norm_of(stage, dt=None):
+    """(LayerNorm, silu) a stage wants applied to its input by its producer, or None (resamplers, fused temporal blocks)"""
+    if not hasattr(stage, "first_norm"):
+        return None
+    if isinstance(stage, ResnetCausalBlock1D):
+        return stage.first_norm(dt)
+    return stage.first_norm()
 
 
 def run_stages(stages, h, dt, last_norm=None, first=None):
@@ -509,7 +542,7 @@ def run_stages(stages, h, dt, last_norm=None, first=None):
     if first is not None and not isinstance(h, Normed):
         h = _wrap(h, first)
     for i, stage in enumerate(stages):
-        nxt = first_norm_of(stages[i + 1]) if i + 1 < len(stages) else last_norm
+        nxt = first_norm_of(stages[i + 1], dt) if i + 1 < len(stages) else last_norm
         h = stage.run(h, dt, next_norm=nxt)
     return h
 
@@ -599,8 +632,8 @@ class EncoderCausal3DPadding(nn.Module):
                 if i_level in self.tempo_ds:
                     stages.append(self.down_temporal[i_level].downsample)
         stages += [self.mid.block_1, self.mid.attn_1, self.mid.block_2]
-        h = run_stages(stages, self.conv_in.run(h, dt, **_emit(first_norm_of(stages[0]))), dt,
-                       last_norm=(self.norm_out, True), first=first_norm_of(stages[0]))
+        h = run_stages(stages, self.conv_in.run(h, dt, **_emit(first_norm_of(stages[0], dt))), dt,
+                       last_norm=(self.norm_out, True), first=first_norm_of(stages[0], dt))
         h = self.norm_out.apply_ndhwc(h, True, dt, SITE_FRAME)
         return self.conv_out.run(h, dt, out_layout=L.VT_NCTHW)
 
@@ -685,8 +718,8 @@ class DecoderCausal3DPadding(nn.Module):
                 stages.append(self.up[i_level].upsample)
                 if i_level in self.tempo_us:
                     stages.append(self.up_temporal[i_level].upsample)
-        h = run_stages(stages, self.conv_in.run(h, dt, **_emit(first_norm_of(stages[0]))), dt,
-                       last_norm=(self.norm_out, True), first=first_norm_of(stages[0]))
+        h = run_stages(stages, self.conv_in.run(h, dt, **_emit(first_norm_of(stages[0], dt))), dt,
+                       last_norm=(self.norm_out, True), first=first_norm_of(stages[0], dt))
         h = self.norm_out.apply_ndhwc(h, True, dt, SITE_FRAME)
         trim = self.time_padding if self.version == "v1_0" else 0
         return self.conv_out.run(h, dt, out_layout=L.VT_NCTHW, t_trim=trim)

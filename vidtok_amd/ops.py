@@ -31,10 +31,11 @@ def _conv_launch(lib, d, what, keep=()):
 
 
 def conv_plan(d):
-    """vt_conv_plan(d) -> dict(tile=(BM, BN), waves, workgroups, ln_fused, launches)"""
-    out = (C.c_int32 * 6)()
+    """vt_conv_plan(d) -> dict(tile=(BM, BN), waves, workgroups, ln_fused, launches, kernel="igemm" | "ws128")"""
+    out = (C.c_int32 * 8)()
     L.check(L.load().vt_conv_plan(C.byref(d), out), "vt_conv_plan")
-    return dict(tile=(out[0], out[1]), waves=out[2], workgroups=out[3], ln_fused=bool(out[4]), launches=out[5])
+    return dict(tile=(out[0], out[1]), waves=out[2], workgroups=out[3], ln_fused=bool(out[4]), launches=out[5],
+                kernel="ws128" if out[6] == 1 else "igemm")
 
 
 def replay_convs(record, conv_kernel_only=True):
@@ -178,6 +179,47 @@ def conv(x, w, bias, geom: ConvGeom, *, cout: int, out_dtype=None, tmode=L.VT_TP
     if ln is None:
         return y
     return (y, n) if ln_keep_y else n
+
+
+def _tblock_desc(x, tmode):
+    d = L.TBlockDesc()
+    B, T, H, W, ld = x.shape
+    d.dtype, d.C, d.ld, d.B, d.T, d.HW, d.tmode = _DT.get(x.dtype, -1), ld, ld, B, T, H * W, tmode
+    return d
+
+
+def temporal_block_supported(x, tmode) -> bool:
+    """True if vt_temporal_block covers a block on this activation (bf16, C = ld = 128, HW % 64 == 0, zero / replicate
+    time padding): the fused launch for ResnetCausalBlock1D (reference model_3dcausal.py:473-499)."""
+    if not x.is_cuda or x.dtype not in _DT:
+        return False
+    return bool(L.load().vt_temporal_block_supported(C.byref(_tblock_desc(x, tmode))))
+
+
+def temporal_block(x, w1, b1, w2, b2, norm1, norm2, *, tmode=L.VT_TPAD_ZERO, eps=1e-6, next_ln=None, keep_y=True):
+    """y = x + conv2(SiLU(LN2(conv1(SiLU(LN1(x)))))) with causal k=3 temporal convs, one launch (vt_temporal_block).
+    norm1 / norm2 = (gamma, beta) fp32; w packed [C, 3C].  next_ln = (gamma, beta, silu) additionally returns
+    n = [SiLU](LayerNorm(y)): (y, n), or just n with keep_y=False."""
+    lib = L.load()
+    _chk(x, "tblock.x"); _chk(w1, "tblock.w1"); _chk(w2, "tblock.w2")
+    d = _tblock_desc(x, tmode)
+    y = torch.empty_like(x) if keep_y else None
+    n = torch.empty_like(x) if next_ln is not None else None
+    d.x, d.y, d.n_out = x.data_ptr(), (y.data_ptr() if keep_y else None), (n.data_ptr() if n is not None else None)
+    d.w1, d.w2 = w1.data_ptr(), w2.data_ptr()
+    d.b1 = b1.data_ptr() if b1 is not None else None
+    d.b2 = b2.data_ptr() if b2 is not None else None
+    for t in (norm1[0], norm1[1], norm2[0], norm2[1]):
+        assert t.dtype == torch.float32 and t.is_cuda and t.numel() >= x.shape[-1]
+    d.norm1_gamma, d.norm1_beta, d.norm2_gamma, d.norm2_beta = (t.data_ptr() for t in (norm1[0], norm1[1], norm2[0], norm2[1]))
+    if next_ln is not None:
+        assert next_ln[0].dtype == torch.float32 and next_ln[1].dtype == torch.float32
+        d.next_gamma, d.next_beta, d.ln_next_mode = next_ln[0].data_ptr(), next_ln[1].data_ptr(), (2 if next_ln[2] else 1)
+    d.keep_y, d.eps = int(bool(keep_y)), float(eps)
+    L.check(lib.vt_temporal_block(C.byref(d), _stream()), "vt_temporal_block")
+    if next_ln is None:
+        return y
+    return (y, n) if keep_y else n
 
 
 def gemm_nt(a, b, *, out_dtype=None, bias=None, ld_out=None):
