@@ -17,8 +17,8 @@ Launch: `python bench.py --gpus N` spawns its N ranks itself (re-executes under 
 --gpus N` it reads RANK / LOCAL_RANK / WORLD_SIZE from the environment.
 
   value       real frames/s over the whole job = N*B*17*K / max-over-ranks(time of K steps)
-  roofline    conv_igemm_glds_kernel (all convolutions + the attention GEMMs = every MFMA FLOP of the
-              path): algorithmic FLOPs of one step (1.0345 TFLOP per padded 256x256 frame, SURVEY.md
+  roofline    the MFMA kernels (conv_igemm_glds_kernel, conv3x3_ws128_kernel, tblock_ws128_kernel: all
+              convolutions + the attention GEMMs = every MFMA FLOP of the path): algorithmic FLOPs of one step (1.0345 TFLOP per padded 256x256 frame, SURVEY.md
               section 8d) / that kernel's time in one step.  The kernel time is measured live: the conv
               launches of one step (same descriptors, same tensors) are replayed back to back from a
               hipGraph that contains nothing else, bracketed by HIP events on the launch stream -- no
@@ -189,37 +189,21 @@ def main():
     def step():
         return model(x)
 
-    for _ in range(max(1, args.warmup)):
+    # launch mode: the engine's own per-shape hipGraph cache (vidtok_amd/graphs.py: encoder and decoder launch
+    # sequences captured on their second call, replayed afterwards); --no-graph launches every kernel eagerly
+    model.enable_graphs(not args.no_graph)
+    for _ in range(max(3, args.warmup)):
         out = step()
     torch.cuda.synchronize()
-
-    graph = None
-    if not args.no_graph:
-        try:
-            s = torch.cuda.Stream()
-            s.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(s):
-                step()
-            torch.cuda.current_stream().wait_stream(s)
-            torch.cuda.synchronize()
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                out = step()
-            graph.replay()
-            torch.cuda.synchronize()
-        except Exception as e:  # stay on the HIP path, just launch eagerly
-            print(f"[bench] hipGraph capture failed ({type(e).__name__}: {e}); launching eagerly", file=sys.stderr)
-            graph = None
-            torch.cuda.synchronize()
-
-    run = graph.replay if graph is not None else step
+    graph = None if args.no_graph else True
+    run = step
 
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        run()
+        out = run()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -235,6 +219,7 @@ def main():
     # ---- roofline leg: the conv launches of one step, replayed alone from a hipGraph, timed with HIP events -----
     roof = None
     if rank == 0:
+        model.enable_graphs(False)
         ops.CONV_RECORD = []
         step()                                          # eager: records descriptors + keeps their tensors alive
         torch.cuda.synchronize()
@@ -283,7 +268,7 @@ def main():
             if os.path.exists(tpath) and B == 4 and world == 1:
                 traffic = round(json.load(open(tpath))["traffic_bytes_per_launch"])
                 break
-        roof = {"bound": "mfma", "kernel": "conv_igemm_glds_kernel", "achieved": round(achieved, 2), "peak": peak,
+        roof = {"bound": "mfma", "kernel": "conv_igemm_glds_kernel + conv3x3_ws128_kernel + tblock_ws128_kernel", "achieved": round(achieved, 2), "peak": peak,
                 "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic,
                 "launches_per_step": len(tl), "kernel_ms_per_step": round(conv_ms, 3),
                 "avg_launch_ms": round(conv_ms / max(1, len(tl)), 4), "algorithmic_tflop_per_step": round(flops / 1e12, 3),
@@ -305,7 +290,7 @@ def main():
             "dtype": args.dtype, "data": "synthetic uniform[-1,1] clips, random-init weights (temporal convs un-zeroed)",
             "config": {"workload": f"{config} forward (encode+KL+decode), {args.dtype}, B={B} clips/GPU, 17x256x256",
                        "global_batch": world * B, "parallelism": f"dp{world} (batch-sharded, no data-path collective)",
-                       "launch": "hipGraph replay" if graph is not None else "eager"},
+                       "launch": "hipGraph replay (engine graph cache)" if graph is not None else "eager"},
             "output_finite": ok, "roofline": roof, "cpu_baseline": cpu,
         }
         print(json.dumps(line), flush=True)

@@ -303,3 +303,33 @@ def test_bf16_vs_autocast_oracle(name, shape):
     e_ours, e_auto, e_cross = rel_err(dec, dec0), rel_err(deca, dec0), rel_err(dec, deca)
     print(f"bf16 {name}: recon vs fp32 oracle: HIP {e_ours:.3e}, autocast oracle {e_auto:.3e}; HIP vs autocast {e_cross:.3e}")
     assert e_ours < BF16_RECON and e_ours < 2.0 * e_auto + 5e-3 and e_cross < 2.0 * BF16_RECON
+
+
+@pytest.mark.parametrize("name,shape,dtype", [("vidtok_fsq_causal_488_32768", (2, 3, 9, 64, 64), torch.bfloat16),
+                                              ("vidtok_v1_1/vidtok_kl_causal_488_16chn_v1_1", (1, 3, 9, 64, 64), torch.float32)])
+def test_engine_graph_cache_replays_bit_exact(name, shape, dtype):
+    """enable_graphs(): encoder / decoder launch sequences captured per shape (vidtok_amd/graphs.py) must reproduce the
+    eager launches bit for bit, on fresh inputs, across shapes, and after a weight reload."""
+    model, cfg, sd = build_model(name, seed=12, device=DEV, dtype=dtype)
+    if hasattr(model.regularization, "sample"):
+        model.regularization.sample = False
+    xs = [(torch.rand(shape, generator=torch.Generator().manual_seed(100 + i)) * 2 - 1).to(DEV) for i in range(4)]
+    eager = [model(x) for x in xs]
+    model.enable_graphs()
+    for rnd in range(2):                                   # call 1 eager, call 2 captures, later calls replay
+        for x, (z0, d0, l0) in zip(xs, eager):
+            z, d, l = model(x)
+            assert torch.equal(z, z0) and torch.equal(d, d0)
+            if "indices" in l0:
+                assert torch.equal(l["indices"], l0["indices"])
+    assert len(model._genc.entries) == 1 and isinstance(next(iter(model._genc.entries.values())), tuple)
+    x2 = xs[0][:, :, :5].contiguous()                      # another shape: its own entry
+    z2e, d2e, _ = model.enable_graphs(False)(x2)
+    model.enable_graphs()
+    for _ in range(3):
+        z2, d2, _ = model(x2)
+        assert torch.equal(d2, d2e)
+    sd2 = {k: v * 1.01 for k, v in sd.items()}
+    model.load_state_dict(sd2)                             # invalidates: the next calls must use the new weights
+    outs = [model(xs[0])[1] for _ in range(3)]
+    assert not torch.equal(outs[0], eager[0][1]) and torch.equal(outs[0], outs[1]) and torch.equal(outs[1], outs[2])

@@ -14,6 +14,7 @@ import torch.nn as nn
 
 from . import ops
 from .config import instantiate_from_config
+from .graphs import GraphedCall
 
 
 def _print0(msg):
@@ -53,6 +54,9 @@ class AutoencodingEngine(nn.Module):
         self.use_overlap = False
         if self.version == "v1_0" and self.use_tiling:
             raise NotImplementedError("temporal tiling exists only in the v1.1 models of the reference")
+        self.use_graphs = False
+        self._genc = GraphedCall(lambda t: self.encoder(t))
+        self._gdec = GraphedCall(lambda t: self.decoder(t))
         if verbose:
             _print0(f"[vidtok_amd.engine][AutoencodingEngine] Use ckpt_path: {ckpt_path}")
         if ckpt_path is not None:
@@ -65,7 +69,33 @@ class AutoencodingEngine(nn.Module):
         assert dtype in (torch.float32, torch.bfloat16)
         self.encoder.compute_dtype = dtype
         self.decoder.compute_dtype = dtype
+        self.invalidate_graphs()
         return self
+
+    # ---- launch mode: per-shape hipGraphs of the encoder / decoder launch sequences (vidtok_amd/graphs.py) ----
+    def enable_graphs(self, on: bool = True):
+        self.use_graphs = bool(on)
+        self.invalidate_graphs()
+        return self
+
+    def invalidate_graphs(self):
+        """forget captured graphs (call after editing parameters in place)"""
+        self._genc.clear()
+        self._gdec.clear()
+
+    def _apply(self, fn, *a, **kw):           # .to() / .cuda() / .float(): parameters move, captured graphs are stale
+        self.invalidate_graphs()
+        return super()._apply(fn, *a, **kw)
+
+    def load_state_dict(self, *a, **kw):
+        self.invalidate_graphs()
+        return super().load_state_dict(*a, **kw)
+
+    def _run_encoder(self, x):
+        return self._genc(x, (self.encoder.compute_dtype,)) if self.use_graphs else self.encoder(x)
+
+    def _run_decoder(self, z):
+        return self._gdec(z, (self.decoder.compute_dtype,)) if self.use_graphs else self.decoder(z)
 
     # ---- checkpoints (autoencoder.py:146-176) ---------------------------------------------------
     def init_from_ckpt(self, path: str, ignore_keys=tuple(), verbose: bool = True) -> None:
@@ -99,7 +129,7 @@ class AutoencodingEngine(nn.Module):
     # ---- encode / decode ------------------------------------------------------------------------
     @torch.no_grad()
     def encode(self, x: Any, return_reg_log: bool = False) -> Any:
-        z = self.encoder(x)
+        z = self._run_encoder(x)
         z, reg_log = self.regularization(z, n_steps=self.global_step // 2)
         if return_reg_log:
             return z, reg_log
@@ -114,7 +144,7 @@ class AutoencodingEngine(nn.Module):
     def decode(self, z: Any, decode_from_indices: bool = False) -> torch.Tensor:
         if decode_from_indices:
             z = self.indices_to_latent(z)
-        return self.decoder(z)
+        return self._run_decoder(z)
 
     @torch.no_grad()
     def forward(self, x: Any) -> Tuple[torch.Tensor, torch.Tensor, dict]:
@@ -174,7 +204,7 @@ class AutoencodingEngineV11(AutoencodingEngine):
         if self.use_tiling:
             z, reg_log = self.tile_encode(x)
         else:
-            z = self.encoder(x)
+            z = self._run_encoder(x)
             z, reg_log = self.regularization(z, n_steps=self.global_step // 2)
         if return_reg_log:
             return z, reg_log
@@ -207,7 +237,7 @@ class AutoencodingEngineV11(AutoencodingEngine):
         self._set_fused_temporal()
         if self.use_tiling:
             return self.tile_decode(z)
-        return self.decoder(z)
+        return self._run_decoder(z)
 
     def _overlap_offsets(self):
         """cache_offset per decoder sub-tree when chunks carry one look-ahead latent frame: 1 at latent

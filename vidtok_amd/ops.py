@@ -18,9 +18,9 @@ _DT = {torch.float32: L.VT_F32, torch.bfloat16: L.VT_BF16}
 CH_ALIGN = 8  # channel padding granule: 16 B of bf16 (and a multiple of the 4-float fp32 granule)
 
 
-# Optional launch record for bench.py's roofline leg: when set to a list, every vt_conv launch appends
-# (descriptor, tensors it points into -- kept alive --, (pixels, Cout, K)), so the conv launches of a step can be
-# replayed on their own (replay_convs).  None in normal use.
+# Optional launch record for bench.py's roofline leg: when set to a list, every launch of an MFMA kernel (vt_conv,
+# vt_temporal_block) appends (descriptor, tensors it points into -- kept alive --, (pixels, Cout, K)), so the
+# matrix-core launches of a step can be replayed on their own (replay_convs).  None in normal use.
 CONV_RECORD = None
 
 
@@ -44,6 +44,9 @@ def replay_convs(record, conv_kernel_only=True):
     LayerNorm is a separate vt_layernorm_act launch, not conv kernel time)."""
     lib = L.load()
     for d, _keep, _label in record:
+        if isinstance(d, L.TBlockDesc):
+            L.check(lib.vt_temporal_block(C.byref(d), _stream()), "vt_temporal_block(replay)")
+            continue
         if conv_kernel_only and d.ln_mode != 0 and not conv_plan(d)["ln_fused"]:
             d2 = L.ConvDesc()
             C.memmove(C.byref(d2), C.byref(d), C.sizeof(d))
@@ -217,6 +220,8 @@ def temporal_block(x, w1, b1, w2, b2, norm1, norm2, *, tmode=L.VT_TPAD_ZERO, eps
         d.next_gamma, d.next_beta, d.ln_next_mode = next_ln[0].data_ptr(), next_ln[1].data_ptr(), (2 if next_ln[2] else 1)
     d.keep_y, d.eps = int(bool(keep_y)), float(eps)
     L.check(lib.vt_temporal_block(C.byref(d), _stream()), "vt_temporal_block")
+    if CONV_RECORD is not None:   # two K = 3C convolutions: label (pixels, C, 6C) carries their FLOPs
+        CONV_RECORD.append((d, (x, w1, b1, w2, b2, norm1, norm2, next_ln, y, n), (d.B * d.T * d.HW, d.C, 6 * d.C)))
     if next_ln is None:
         return y
     return (y, n) if keep_y else n
