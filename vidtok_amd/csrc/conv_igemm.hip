@@ -802,7 +802,7 @@ int dispatch_tile(const ConvArgs& a, int nbatch, hipStream_t stream) {
 
 extern "C" int vt_ws128_launch(const void* conv_args, void* stream);   // conv_ws128.hip
 
-extern "C" int vt_conv_max_lds_bytes(void) { return 2 * (256 + 256) * kRowBytes; }
+extern "C" int vt_conv_max_lds_bytes(void) { return 163840; }   // conv3x3_ws128_kernel: two patches + T = all of a CU's LDS
 
 namespace {
 // argument validation + the kernel's view of the descriptor; shared by vt_conv and vt_conv_plan

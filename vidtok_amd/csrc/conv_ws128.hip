@@ -13,11 +13,14 @@
 //     every fragment address is base + immediate);
 //   * K loop = 288 MFMAs per wave, fully unrolled, no barrier, no DMA wait inside; one ds_read_b128 per MFMA
 //     (LDS read traffic = half of the 256 B/clk the LDS delivers at the MFMA peak);
-//   * epilogue = the 128 x 128 fp32 tile transposed through LDS (aliased over the spent patch), rows written as whole
-//     256-B lines with + residual and LayerNorm(+SiLU) fused exactly as conv_epilogue_lds128 does;
-//   * the DMA of tile i+1 flies during the K loop of tile i; three barriers per tile.
+//   * epilogue = the 128 x 128 fp32 tile (+ bias) transposed through a third LDS buffer T; its row phase -- rows read
+//     back as whole 256-B lines, + residual, y store, LayerNorm(+SiLU) store, the arithmetic of conv_epilogue_lds128 -- is
+//     cut into 56 pieces that ride in the MFMA gaps of the NEXT tile's K loop (with one wave per SIMD nothing else would
+//     hide its ~900 VALU instructions; run on their own they cost half a K loop: 1.64 -> measured below);
+//   * the DMA of tile i+1 flies during the K loop of tile i; two barriers per tile.
 // The pipeline relies on no ordering between loads and stores: every wave drains its own vmcnt after its K loop (the
-// patch of the next tile has had the whole loop to land) and the barriers publish it.
+// patch of the next tile has had the whole loop to land, the row phase's stores were issued >= 16 groups earlier) and
+// the barriers publish it.
 #include <atomic>
 #include <type_traits>
 
@@ -31,8 +34,7 @@ namespace {
 [[maybe_unused]] constexpr int WS_ROWP = 272;                           // bytes per patch pixel row: 256 (128 bf16) + 16 pad
 [[maybe_unused]] constexpr int WS_PIECES = 48;                          // 1-KiB DMA pieces per patch (180 * 272 = 48 960 B)
 [[maybe_unused]] constexpr int WS_PATCH = WS_PIECES * 1024;             // 49 152
-[[maybe_unused]] constexpr int WS_EXTRA = 128 * 128 * 4 - WS_PATCH;     // 16 384: T = patch[cur] + extra (contiguous either way)
-[[maybe_unused]] constexpr int WS_LDS = 2 * WS_PATCH + WS_EXTRA;        // 114 688: [patch0][extra][patch1]
+[[maybe_unused]] constexpr int WS_LDS = 2 * WS_PATCH + 128 * 128 * 4;   // 163 840 = all of the CU's LDS: [patch0][patch1][T]
 [[maybe_unused]] constexpr int WS_QPW = WS_PIECES / 4;                  // pieces per wave
 
 // The register file is split by hand: the compiler's allocator, left to choose, spills part of the 288 stationary weight
@@ -47,6 +49,9 @@ __device__ __forceinline__ void static_for(F&& f) {
     static_for<I + 1, N>(f);
   }
 }
+#ifndef WS_DEPTH
+#define WS_DEPTH 1   // 2 left the LayerNorm instantiations with scratch spills (3 fragment sets + the row phase in 256 VGPRs)
+#endif
 [[maybe_unused]] constexpr int WS_W_AGPR = 63;   // 4 * 63 = 252 of 256 AGPRs; 4 * 9 = 36 VGPRs of weights
 template <bool W_IN_AGPR, bool FIRST>
 __device__ __forceinline__ void ws_mfma(const u32x4& w, const u32x4& x, f32x16& acc) {
@@ -59,6 +64,7 @@ __device__ __forceinline__ void ws_mfma(const u32x4& w, const u32x4& x, f32x16& 
   }
 }
 
+template <int LN, bool KEEP>
 __global__ __launch_bounds__(256, 1) void conv3x3_ws128_kernel(const ConvArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -83,6 +89,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_ws128_kernel(const ConvArgs p)
   const bf16_t* __restrict__ rg = reinterpret_cast<const bf16_t*>(p.res);
   bf16_t* __restrict__ ng = reinterpret_cast<bf16_t*>(p.ln_out);
   constexpr unsigned kOob = 0xFFFF0000u;
+  float* T = reinterpret_cast<float*>(smem + 2 * WS_PATCH);
 
   // ---- stationary weights: 72 A-fragments (rows n = 32 wave + lane%32, k = 16 c + 8 (lane/32) .. +8) -----------------
   u32x4 wreg[72];
@@ -95,18 +102,20 @@ __global__ __launch_bounds__(256, 1) void conv3x3_ws128_kernel(const ConvArgs p)
   // ---- DMA geometry of this lane: piece q of this wave writes LDS bytes [(wave*12+q)*1024 + 16 lane, +16) = 16-B unit
   // `unit` of patch pixel (pr, pc).  The descriptor is rebased to the tile's FRAME, so rows above / below the image are
   // out of range by themselves (negative or >= frame bytes: hardware zero fill); only the left / right halo columns of
-  // border tiles need a test.  One register per piece: bo = byte offset of the unit relative to the tile origin, low
-  // bits = "is halo column 0" (1) / "is halo column 17" (2); pad units and the tail beyond the patch get 2^31, which
-  // stays out of range for any tile (frame bytes <= 2^30 by the launcher).
+  // border tiles need a test.  One register per piece: bo = byte offset of the unit relative to the tile origin; pad
+  // units and the tail beyond the patch get 2^31, which stays out of range for any tile (frame bytes <= 2^30 by the
+  // launcher).
   int bo[WS_QPW];
+  unsigned bflags = 0;   // 2 bits per piece: halo column 0 / halo column 17 (one register for all twelve pieces)
 #pragma unroll
   for (int q = 0; q < WS_QPW; ++q) {
     const int b = (wave * WS_QPW + q) * 1024 + lane * 16;
     const int pp = b / WS_ROWP;
     const int unit = (b - pp * WS_ROWP) >> 4;
     const int pr = pp / WS_PW, pc = pp - pr * WS_PW;
-    bo[q] = (pp < WS_NPIX && unit < 16) ? ((((pr - 1) * W + (pc - 1)) * 256 + unit * 16) | (pc == 0 ? 1 : 0) | (pc == WS_PW - 1 ? 2 : 0))
-                                        : (int)0x80000000;
+    const bool valid = pp < WS_NPIX && unit < 16;
+    bo[q] = valid ? (((pr - 1) * W + (pc - 1)) * 256 + unit * 16) : (int)0x80000000;
+    bflags |= valid ? ((pc == 0 ? 1u : 0u) | (pc == WS_PW - 1 ? 2u : 0u)) << (2 * q) : 0u;
   }
   const unsigned frame_bytes = (unsigned)H * (unsigned)W * 256u;
   auto tile_coords = [&](int tile, int& f, int& h0, int& w0) {
@@ -122,143 +131,183 @@ __global__ __launch_bounds__(256, 1) void conv3x3_ws128_kernel(const ConvArgs p)
     const __amdgpu_buffer_rsrc_t rsrc =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(xg) + (long long)f * H * W * 128, 0, frame_bytes, 0x00020000);
     char* dst = smem + bufoff + wave * (WS_QPW * 1024);
-    const int tmask = (w0 == 0 ? 1 : 0) | (w0 + WS_TW == W ? 2 : 0);
+    const unsigned tmask = (w0 == 0 ? 1u : 0u) | (w0 + WS_TW == W ? 2u : 0u);
     const int toff = (h0 * W + w0) * 256;
 #pragma unroll
     for (int q = 0; q < WS_QPW; ++q) {
-      const unsigned off = (bo[q] & tmask) ? kOob : (unsigned)((bo[q] & ~3) + toff);
+      const unsigned off = (bflags & (tmask << (2 * q))) ? kOob : (unsigned)(bo[q] + toff);
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)(dst + q * 1024), 16, off, 0, 0, 0);
     }
   };
 
-  // ---- per-lane constants of the fragment reads and the epilogue ---------------------------------------------------------
+  // ---- per-lane constants of the fragment reads and of the row phase ----------------------------------------------------
   const int frag_off = (((lane & 31) >> 4) * WS_PW + (lane & 15)) * WS_ROWP + (lane >> 5) * 16;
-  const int oct_j = tid & 15, row0 = tid >> 4;   // epilogue read-back: 16 lanes per pixel row, 8 channels each
-  const bool has_res = p.res_mode != VT_RES_NONE;
+  const int oct_j = tid & 15, row0 = tid >> 4;   // rows row0 + 16 it (it < 8), channels [8 oct_j, +8)
+  // LayerNorm affine of this lane's 8 channels: re-read (L1-resident) two stages before each use instead of pinning
+  // 16 more registers for the kernel's lifetime -- the K loop runs within ~10 registers of the 256 architectural ones
+  f32x4 lg0, lg1, lb0, lb1;
 
-  issue_patch(t_begin, 0);
-  wait_vmcnt<0>();
-  int cur = 0;
-  for (int tile = t_begin; tile < t_end; ++tile, cur ^= 1) {
-    const int bufoff = cur ? (WS_PATCH + WS_EXTRA) : 0;
-    // (A) patch[cur] has landed for every wave (each drained its vmcnt before its last barrier); nobody still reads the
-    //     previous tile's T, which overlaps the buffer refilled next
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    if (tile + 1 < t_end) issue_patch(tile + 1, cur ? 0 : (WS_PATCH + WS_EXTRA));
-    int f, h0, w0;
-    tile_coords(tile, f, h0, w0);
-    const long long pix0 = ((long long)f * H + h0) * W + w0;   // global pixel of tile pixel (0,0)
-    f32x16 acc[4];
+  // ---- row phase of a FINISHED tile (its biased fp32 result sits in T, transposed): + residual, y store, LayerNorm
+  // (+SiLU) store.  It is cut into 7 stages per row iteration x 8 iterations = 56 pieces, so that the K loop of the NEXT
+  // tile can carry one piece per MFMA group: with one wave per SIMD nothing else would hide its ~900 VALU instructions
+  // per tile (LayerNorm + SiLU of 64 elements per lane), which cost as much as half a K loop when run on their own.
+  float rv[8], rmean = 0.f, rrstd = 0.f;
+  f32x4 rt0, rt1;
+  // residual rows: with no residual the registers stay zero and the adds are spent anyway -- the instantiations without
+  // these 8 registers came out of the register allocator WITH scratch spills (the ones with them did not)
+  Oct<bf16_t> rq_cur, rq_nxt;
+  rq_cur.w[0] = rq_cur.w[1] = rq_cur.w[2] = rq_cur.w[3] = 0u;
+  rq_nxt.w = rq_cur.w;
+  const bool has_res = p.res_mode == VT_RES_ADD;   // uniform
+  long long pix0_prev = 0;
+  auto res_row_ptr = [&](int it) -> const bf16_t* {
+    const int row = row0 + 16 * it;
+    return rg + (pix0_prev + (long long)(row >> 4) * W + (row & 15)) * p.ldr + 8 * oct_j;
+  };
+  auto row_piece = [&](auto piece_c) {
+    constexpr int piece = decltype(piece_c)::value;
+    constexpr int it = piece / 7, st = piece % 7;
+    const int row = row0 + 16 * it;
+    if constexpr (st == 0) {
+      const int sw = row & 31;
+      rt0 = *reinterpret_cast<const f32x4*>(T + row * 128 + (((2 * oct_j) ^ sw) << 2));
+      rt1 = *reinterpret_cast<const f32x4*>(T + row * 128 + (((2 * oct_j + 1) ^ sw) << 2));
+      if constexpr (it + 1 < 8) { if (has_res) rq_nxt.load(res_row_ptr(it + 1)); }
+    } else if constexpr (st == 1) {
+      float s = 0.f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        rv[e] = e < 4 ? rt0[e] : rt1[e - 4];
+        rv[e] = rq_cur.get(e) + rv[e];
+        s += rv[e];
+      }
+      if constexpr (LN != 0) {
+        rmean = group_sum_dpp<16>(s) * (1.0f / 128.0f);
+        lg0 = *reinterpret_cast<const f32x4*>(p.ln_gamma + 8 * oct_j);
+        lg1 = *reinterpret_cast<const f32x4*>(p.ln_gamma + 8 * oct_j + 4);
+        lb0 = *reinterpret_cast<const f32x4*>(p.ln_beta + 8 * oct_j);
+        lb1 = *reinterpret_cast<const f32x4*>(p.ln_beta + 8 * oct_j + 4);
+      }
+      if constexpr (it + 1 < 8) rq_cur = rq_nxt;
+    } else if constexpr (st == 2) {
+      const long long orow = pix0_prev + (long long)(row >> 4) * W + (row & 15);
+      if constexpr (KEEP) Oct<bf16_t>::store(yg + orow * p.ldy + 8 * oct_j, rv);
+      if constexpr (LN != 0) {
+        float q = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          rv[e] -= rmean;
+          q += rv[e] * rv[e];
+        }
+        rrstd = __builtin_amdgcn_rsqf(group_sum_dpp<16>(q) * (1.0f / 128.0f) + p.ln_eps);
+      }
+    } else if constexpr (st == 3) {
+      if constexpr (LN != 0) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) rv[e] = rv[e] * rrstd * (e < 4 ? lg0[e] : lg1[e - 4]) + (e < 4 ? lb0[e] : lb1[e - 4]);
+      }
+    } else if constexpr (st == 4) {
+      if constexpr (LN == 2) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) rv[e] = silu_fast(rv[e]);
+      }
+    } else if constexpr (st == 5) {
+      if constexpr (LN == 2) {
+#pragma unroll
+        for (int e = 4; e < 8; ++e) rv[e] = silu_fast(rv[e]);
+      }
+    } else {
+      if constexpr (LN != 0) {
+        const long long orow = pix0_prev + (long long)(row >> 4) * W + (row & 15);
+        Oct<bf16_t>::store(ng + orow * p.ldn + 8 * oct_j, rv);
+      }
+    }
+  };
+
+  // ---- K loop of one tile: 72 groups (tap, 16-channel chunk) x 4 pixel sub-tiles, an explicit software pipeline: the four
+  // B-fragments of group g+2 are requested before the MFMAs of group g (one group = 128 matrix-pipe cycles, LDS
+  // latency under load ~ 1.5 groups); sched_barrier pins that order -- left to itself the scheduler hoists ~60 fragment
+  // reads to the top of the tile and spills the stationary weights.  WITH_ROWS: groups 0..55 also carry the row phase
+  // of the previous tile, one piece each; the last 16 groups stay bare so its stores have retired by the vmcnt drain.
+  f32x16 acc[4];
+  auto k_loop = [&](auto with_rows_c, int bufoff) {
+    constexpr bool WITH_ROWS = decltype(with_rows_c)::value;
     const char* pb = smem + bufoff + frag_off;
-    // K loop: 72 groups (tap, 16-channel chunk) x 4 pixel sub-tiles, an explicit software pipeline: the four
-    // B-fragments of group g+2 are requested before the MFMAs of group g (one group = 128 matrix-pipe cycles, LDS
-    // latency under load ~ 1.5 groups); sched_barrier pins that order -- left to itself the scheduler hoists ~60
-    // fragment reads to the top of the tile and spills the stationary weights to scratch.
     auto frag_addr = [&](int g, int j) -> const u32x4* {
       const int tap = g >> 3, c = g & 7;
       const int kh = tap / 3, kw = tap - 3 * kh;
       return reinterpret_cast<const u32x4*>(pb + ((2 * j + kh) * WS_PW + kw) * WS_ROWP + c * 32);
     };
-    u32x4 xf[3][4];
+    constexpr int D = WS_DEPTH;          // fragment prefetch distance in groups
+    u32x4 xf[D + 1][4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) xf[0][j] = *frag_addr(0, j);
+    for (int d = 0; d < D; ++d)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) xf[1][j] = *frag_addr(1, j);
+      for (int j = 0; j < 4; ++j) xf[d][j] = *frag_addr(d, j);
     static_for<0, 72>([&](auto gc) {
       constexpr int g = decltype(gc)::value;
-      if constexpr (g + 2 < 72) {
+      if constexpr (g + D < 72) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) xf[(g + 2) % 3][j] = *frag_addr(g + 2, j);
+        for (int j = 0; j < 4; ++j) xf[(g + D) % (D + 1)][j] = *frag_addr(g + D, j);
       }
 #pragma unroll
-      for (int j = 0; j < 4; ++j) ws_mfma<(g < WS_W_AGPR), (g == 0)>(wreg[g], xf[g % 3][j], acc[j]);
+      for (int j = 0; j < 4; ++j) ws_mfma<(g < WS_W_AGPR), (g == 0)>(wreg[g], xf[g % (D + 1)][j], acc[j]);
+      if constexpr (WITH_ROWS && g < 56) row_piece(gc);
       __builtin_amdgcn_sched_barrier(0);
     });
     asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");   // last MFMA -> first reader of its accumulator (hipcc pads nothing around asm)
-    wait_vmcnt<0>();                 // own DMA pieces of the next patch (and the residual): landed long ago
-    __builtin_amdgcn_s_barrier();    // (B) every wave is done reading patch[cur]: T may overwrite it
-    asm volatile("" ::: "memory");
-
-    // ---- epilogue: transpose through T, rows = 16 lanes x 8 channels, + residual, LayerNorm(+SiLU) ----
-    // the residual rows are requested here: their latency rides under the transposition, and their 32 registers never
-    // coexist with the fragment pipeline (the register file holds 288 weight + 64 accumulator registers throughout)
-    Oct<bf16_t> rq[8];
-    if (has_res) {
+  };
+  // accumulators (+ bias) -> T, transposed: MFMA layout lane = pixel 32 j + lane%32, channels 32 wave + 8 g + 4 (lane/32) + e
+  auto acc_to_T = [&]() {
+    const int h = lane >> 5;
+    f32x4 bq[4];
 #pragma unroll
-      for (int it = 0; it < 8; ++it) {
-        const int row = row0 + 16 * it;
-        rq[it].load(rg + (pix0 + (long long)(row >> 4) * W + (row & 15)) * p.ldr + 8 * oct_j);
-      }
+    for (int g = 0; g < 4; ++g) {
+      if (p.bias) bq[g] = *reinterpret_cast<const f32x4*>(p.bias + wave * 32 + 8 * g + 4 * h);
+      else bq[g][0] = bq[g][1] = bq[g][2] = bq[g][3] = 0.0f;
     }
-    float* T = reinterpret_cast<float*>(smem + (cur ? WS_PATCH : 0));
-    {
-      const int h = lane >> 5;
-      f32x4 bq[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int prow = 32 * j + (lane & 31);
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        if (p.bias) bq[g] = *reinterpret_cast<const f32x4*>(p.bias + wave * 32 + 8 * g + 4 * h);
-        else bq[g][0] = bq[g][1] = bq[g][2] = bq[g][3] = 0.0f;
+        const int c = wave * 32 + 8 * g + 4 * h;
+        f32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = acc[j][4 * g + e] + bq[g][e];
+        *reinterpret_cast<f32x4*>(T + prow * 128 + (((c >> 2) ^ (prow & 31)) << 2)) = v;
       }
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {      // one pixel sub-tile at a time: 16 accumulator values leave the AGPRs per round
-        const int prow = 32 * j + (lane & 31);
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const int c = wave * 32 + 8 * g + 4 * h;
-          f32x4 v;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = acc[j][4 * g + e] + bq[g][e];
-          *reinterpret_cast<f32x4*>(T + prow * 128 + (((c >> 2) ^ (prow & 31)) << 2)) = v;
-        }
-        __builtin_amdgcn_sched_barrier(0);
-      }
+      __builtin_amdgcn_sched_barrier(0);
     }
-    __syncthreads();                 // (C)
-    float lg[8], lb[8];
-    if (p.ln_mode) {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        lg[e] = p.ln_gamma[8 * oct_j + e];
-        lb[e] = p.ln_beta[8 * oct_j + e];
-      }
+  };
+
+  issue_patch(t_begin, 0);
+  wait_vmcnt<0>();
+  int cur = 0;
+  for (int tile = t_begin; tile < t_end; ++tile, cur ^= 1) {
+    // (A) patch[cur] has landed for every wave (each drained its vmcnt before barrier B of the previous tile) and the
+    //     previous tile's T is complete
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (tile + 1 < t_end) issue_patch(tile + 1, cur ? 0 : WS_PATCH);
+    if (tile == t_begin) {
+      k_loop(std::false_type{}, cur ? WS_PATCH : 0);
+    } else {
+      if (has_res) rq_cur.load(res_row_ptr(0));
+      k_loop(std::true_type{}, cur ? WS_PATCH : 0);
     }
-#pragma unroll
-    for (int it = 0; it < 8; ++it) {
-      const int row = row0 + 16 * it;
-      const int sw = row & 31;
-      const f32x4 t0 = *reinterpret_cast<const f32x4*>(T + row * 128 + (((2 * oct_j) ^ sw) << 2));
-      const f32x4 t1 = *reinterpret_cast<const f32x4*>(T + row * 128 + (((2 * oct_j + 1) ^ sw) << 2));
-      float v[8];
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        v[e] = e < 4 ? t0[e] : t1[e - 4];
-        if (has_res) v[e] = rq[it].get(e) + v[e];
-      }
-      const long long orow = pix0 + (long long)(row >> 4) * W + (row & 15);
-      if (!p.ln_mode || p.ln_keep_y) Oct<bf16_t>::store(yg + orow * p.ldy + 8 * oct_j, v);
-      if (p.ln_mode) {   // same two-pass statistics as layernorm_act_kernel, taken before the rounding to bf16
-        float s = 0.f;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) s += v[e];
-        const float mean = group_sum_dpp<16>(s) * (1.0f / 128.0f);
-        float q = 0.f;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          v[e] -= mean;
-          q += v[e] * v[e];
-        }
-        const float rstd = __builtin_amdgcn_rsqf(group_sum_dpp<16>(q) * (1.0f / 128.0f) + p.ln_eps);
-        float o[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const float u = v[e] * rstd * lg[e] + lb[e];
-          o[e] = (p.ln_mode == 2) ? silu_fast(u) : u;
-        }
-        Oct<bf16_t>::store(ng + orow * p.ldn + 8 * oct_j, o);
-      }
-    }
+    wait_vmcnt<0>();                 // own DMA pieces of the next patch, the row phase's loads and stores: long done
+    __builtin_amdgcn_s_barrier();    // (B) every wave is done with the previous tile's T (and with patch[cur])
+    asm volatile("" ::: "memory");
+    acc_to_T();
+    int f, h0, w0;
+    tile_coords(tile, f, h0, w0);
+    pix0_prev = ((long long)f * H + h0) * W + w0;
   }
+  // row phase of the last tile, on its own
+  __syncthreads();
+  if (has_res) rq_cur.load(res_row_ptr(0));
+  static_for<0, 56>([&](auto pc) { row_piece(pc); });
 #endif
 }
 
@@ -268,16 +317,28 @@ __global__ __launch_bounds__(256, 1) void conv3x3_ws128_kernel(const ConvArgs p)
 extern "C" __attribute__((visibility("hidden"))) int vt_ws128_launch(const void* args, void* stream_) {
   const ConvArgs& a = *reinterpret_cast<const ConvArgs*>(args);
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
-  const void* kern = reinterpret_cast<const void*>(&conv3x3_ws128_kernel);
-  static std::atomic<int> cus[kMaxDevices];         // 0 = attribute not set yet on that device; else its CU count
+  // one instantiation per epilogue shape: LayerNorm none / plain / +SiLU, y kept or not
+  const bool keep = a.ln_mode == 0 || a.ln_keep_y != 0;
+  const int vi = a.ln_mode == 0 ? 0 : (a.ln_mode == 1 ? (keep ? 1 : 2) : (keep ? 3 : 4));
+  static const void* const kerns[5] = {
+      reinterpret_cast<const void*>(&conv3x3_ws128_kernel<0, true>), reinterpret_cast<const void*>(&conv3x3_ws128_kernel<1, true>),
+      reinterpret_cast<const void*>(&conv3x3_ws128_kernel<1, false>), reinterpret_cast<const void*>(&conv3x3_ws128_kernel<2, true>),
+      reinterpret_cast<const void*>(&conv3x3_ws128_kernel<2, false>)};
+  const void* kern = kerns[vi];
+  static std::atomic<int> cus[kMaxDevices];         // 0 = not queried yet on that device; else its CU count
+  static std::atomic<bool> attr_done[5][kMaxDevices];
   int dev = 0;
   VT_CHECK_HIP(hipGetDevice(&dev));
-  int ncu = (dev >= 0 && dev < kMaxDevices) ? cus[dev].load(std::memory_order_acquire) : 0;
-  if (ncu == 0) {
+  const bool dev_ok = dev >= 0 && dev < kMaxDevices;
+  if (!dev_ok || !attr_done[vi][dev].load(std::memory_order_acquire)) {
     VT_CHECK_HIP(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, WS_LDS));
+    if (dev_ok) attr_done[vi][dev].store(true, std::memory_order_release);
+  }
+  int ncu = dev_ok ? cus[dev].load(std::memory_order_acquire) : 0;
+  if (ncu == 0) {
     VT_CHECK_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
     if (ncu <= 0) ncu = 256;
-    if (dev >= 0 && dev < kMaxDevices) cus[dev].store(ncu, std::memory_order_release);
+    if (dev_ok) cus[dev].store(ncu, std::memory_order_release);
   }
   const int ntiles = (a.Wo / WS_TW) * (a.Ho / WS_TH) * a.B * a.To;
   const int grid = ntiles < ncu ? ntiles : ncu;     // one persistent workgroup per CU (114 KiB of LDS, 512 registers)
