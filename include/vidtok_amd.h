@@ -279,6 +279,29 @@ int vt_fsq_aux_stats_avg(const float* h, const int32_t* levels_host, int32_t D, 
                          float inv_temperature, float* work, float* out3, float* avg_out, vt_stream stream);
 int vt_entropy(const float* avg, int64_t J, float* out, vt_stream stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Video front / back end around model(x): the device halves of scripts/inference_reconstruct.py (the codec --
+ * decord / torchvision.io.write_video -- stays with the caller).  B = 1 like the reference's DataLoader.
+ * vt_frames_u8_to_ncthw: decoded frames uint8 [T][H0][W0][3] -> x fp32 [3][Tdst][H][W], frames t_off .. t_off+T:
+ *   v/255, torchvision Resize(size, antialias=True) to (Hr, Wr) (= ATen's separable anti-aliased bilinear filter,
+ *   horizontal pass then vertical pass in fp32; Hr == H0 and Wr == W0 is the identity), CenterCrop window
+ *   [top, top+H) x [left, left+W) of the resized frame, Normalize(0.5, 0.5) = (v-0.5)/0.5
+ *   (inference_reconstruct.py:39-45,70-73; vidtok/data/vidtok.py:180-188).  `work`: vt_frames_work_floats(T, H0, W) floats.
+ * vt_ncthw_to_frames_u8: x fp32 [3][Tsrc][H][W] frames t0 .. t0+n -> out uint8 [n][H][Wtot][3] at column w_off:
+ *   clamp(-1,1), (x+1)/2, *255, truncation (tensor_to_uint8, inference_reconstruct.py:76-80; w_off / Wtot place the
+ *   input next to the reconstruction for --concate_input, :228-235).
+ * vt_ncthw_copy_frames: dst[c][td0+k] = (clamp ? clamp(src[c][ts0+k], -1, 1) : src[c][ts0+k]), k < n, for C channels of
+ *   [C][T*][HW] tensors: the --pad_gen_frames chaining (last f-1 generated frames prepended to the next clip, :213-221).
+ * ------------------------------------------------------------------------------------------ */
+int64_t vt_frames_work_floats(int32_t T, int32_t H0, int32_t W);
+int vt_frames_u8_to_ncthw(const uint8_t* frames, int32_t T, int32_t H0, int32_t W0, int32_t Hr, int32_t Wr, int32_t top,
+                          int32_t left, float* x, int32_t Tdst, int32_t t_off, int32_t H, int32_t W, float* work,
+                          vt_stream stream);
+int vt_ncthw_to_frames_u8(const float* x, int32_t Tsrc, int32_t t0, int32_t n, int32_t H, int32_t W, uint8_t* out,
+                          int32_t Wtot, int32_t w_off, vt_stream stream);
+int vt_ncthw_copy_frames(const float* src, float* dst, int32_t C, int32_t Ts, int32_t Td, int32_t ts0, int32_t td0,
+                         int32_t n, int64_t HW, int32_t clamp, vt_stream stream);
+
 /* copy `n` frames of `frame_elems` elements each: dst frame j <- src frame idx_host[j]
  * (cache maintenance of the v1.1 chunked path, model_3dcausal_v1_1.py:172-176,230-234);
  * src/dst are [B][Ts|Td][frame_elems] with the given batch strides, element size `esize`. */

@@ -1,0 +1,137 @@
+"""the video front / back end around model(x) (scripts/inference_reconstruct.py minus the
+codec).  CPU: the oracle's restatement of torchvision's Resize(antialias) / CenterCrop / Normalize is pinned against
+the ATen operator torchvision calls (torch.nn.functional.interpolate(antialias=True)), the host loop against the
+oracle's restatement of the reference loop.  GPU (-m gpu): the three kernels and the whole device-side loop against the
+oracle."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import video_io_oracle as V
+from util import build_model, build_oracle
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# oracle pinning (CPU)
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("H0,W0,size", [(96, 128, 64), (120, 90, 64), (64, 64, 64), (70, 100, 32), (37, 53, 48), (240, 426, 128)])
+def test_oracle_resize_matches_aten_antialias(H0, W0, size):
+    x = torch.rand(2, 3, H0, W0, generator=torch.Generator().manual_seed(H0 + W0))
+    nh, nw = V.resized_size(H0, W0, size)
+    assert min(nh, nw) == size and (nh == size) == (H0 <= W0)
+    ref = F.interpolate(x, size=(nh, nw), mode="bilinear", align_corners=False, antialias=True)
+    assert (V.resize_aa(x, nh, nw) - ref).abs().max() < 5e-7
+
+
+def test_oracle_center_crop_and_uint8_conventions():
+    assert V.center_crop_offsets(455, 256, 256, 256) == (100, 0)      # 99.5 -> 100 (half to even)
+    assert V.center_crop_offsets(453, 256, 256, 256) == (98, 0)       # 98.5 -> 98
+    assert V.center_crop_offsets(256, 341, 256, 256) == (0, 42)       # 42.5 -> 42
+    t = torch.tensor([-2.0, -1.0, -0.999, 0.0, 0.5, 0.999, 1.0, 3.0])
+    assert V.tensor_to_uint8(t).tolist() == [0, 0, 0, 127, 191, 254, 255, 255]
+    ids = V.frame_id_batches(100, 30.0, 10, 16, True, False)          # every 3rd frame, clips of 17, tail dropped
+    assert [len(b) for b in ids] == [17, 17] and ids[0][:3] == [0, 3, 6] and ids[1][0] == 51
+    assert [len(b) for b in V.frame_id_batches(100, 30.0, 30, 16, True, True)] == [97]
+    assert [len(b) for b in V.frame_id_batches(100, 30.0, 30, 16, False, True)] == [96]
+    assert V.frame_id_batches(10, 30.0, 30, 16, True, False) == []
+
+
+class _FakeModel:
+    """deterministic stand-in with the attributes the loop reads (is_causal, encoder.time_downsample_factor)"""
+
+    class _Enc:
+        time_downsample_factor = 4
+
+    def __init__(self):
+        self.is_causal, self.encoder = True, self._Enc()
+
+    def __call__(self, x):
+        t = torch.arange(x.shape[2], dtype=x.dtype, device=x.device).view(1, 1, -1, 1, 1)
+        return None, 1.1 * x.flip(1) - 0.02 * t + 0.01 * x.mean(dim=2, keepdim=True), None
+
+
+@pytest.mark.parametrize("pad_gen,concat", [(False, True), (True, True), (True, False)])
+def test_host_loop_matches_oracle_loop_on_cpu(pad_gen, concat, monkeypatch):
+    import torch_ops_ref as R
+    from vidtok_amd import video_io
+
+    R.patch_ops(monkeypatch)
+    frames = torch.randint(0, 256, (60, 40, 56, 3), dtype=torch.uint8, generator=torch.Generator().manual_seed(1))
+    model = _FakeModel()
+    rec = video_io.VideoReconstructor(model, input_height=32, input_width=32, sample_fps=15, chunk_size=8,
+                                      pad_gen_frames=pad_gen, concate_input=concat)
+    got = rec.reconstruct(frames, fps=30.0)
+    ids = V.frame_id_batches(60, 30.0, 15, 8, True, False)
+    assert ids == video_io.frame_id_batches(60, 30.0, 15, 8, True, False) and len(ids) == 3
+    clips = [V.preprocess_frames(frames[b], 32, 32).unsqueeze(0) for b in ids]
+    ref = V.reconstruct(model, clips, True, 4, False, pad_gen, concat)
+    assert got.shape == ref.shape == (27, 32, 64 if concat else 32, 3)
+    assert np.array_equal(got.numpy(), ref)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# kernels and the device-side loop (GPU)
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("H0,W0,h,w", [(96, 128, 64, 64), (120, 90, 64, 48), (64, 64, 64, 64), (70, 100, 32, 40), (37, 53, 48, 48),
+                                       (240, 426, 128, 128)])
+def test_frames_to_ncthw_kernel(H0, W0, h, w):
+    from vidtok_amd import video_io
+
+    frames = torch.randint(0, 256, (5, H0, W0, 3), dtype=torch.uint8, generator=torch.Generator().manual_seed(H0))
+    ref = V.preprocess_frames(frames, h, w)
+    got = video_io.preprocess_frames(frames.cuda(), h, w)
+    assert got.shape == (1, 3, 5, h, w) and got.dtype == torch.float32
+    err = (got[0].cpu() - ref).abs().max().item()
+    print(f"preprocess {H0}x{W0} -> {h}x{w}: max abs err {err:.2e}")
+    assert err < 2e-6
+    # and against the ATen operator torchvision calls, end to end
+    x = frames.permute(0, 3, 1, 2).float() / 255.0
+    nh, nw = V.resized_size(H0, W0, h)
+    if (nh, nw) != (H0, W0):
+        x = F.interpolate(x, size=(nh, nw), mode="bilinear", align_corners=False, antialias=True)
+    top, left = V.center_crop_offsets(nh, nw, h, w)
+    aten = ((x[..., top:top + h, left:left + w] - 0.5) / 0.5).permute(1, 0, 2, 3)
+    assert (got[0].cpu() - aten).abs().max() < 2e-6
+
+
+@pytest.mark.gpu
+def test_ncthw_to_frames_and_copy_kernels_bit_exact():
+    from vidtok_amd import ops
+
+    x = (torch.rand(1, 3, 7, 24, 40, generator=torch.Generator().manual_seed(3)) * 2.6 - 1.3)
+    x[0, 0, 0, 0, :8] = torch.tensor([-1.0, 1.0, 0.0, 0.999999, -0.999999, 127.5 / 127.5 - 1, 2.0, -2.0])
+    out = torch.zeros((4, 24, 80, 3), dtype=torch.uint8, device="cuda")
+    ops.ncthw_to_frames_u8(x.cuda(), t0=2, n=4, out=out, w_off=40)
+    ref = np.transpose(V.tensor_to_uint8(x[0, :, 2:6]), (1, 2, 3, 0))
+    assert np.array_equal(out[:, :, 40:].cpu().numpy(), ref) and int(out[:, :, :40].max()) == 0
+    dst = torch.full((1, 3, 9, 24, 40), 7.0, device="cuda")
+    ops.ncthw_copy_frames(x.cuda(), dst, 4, 1, 3, clamp=True)
+    assert torch.equal(dst[0, :, 1:4].cpu(), x[0, :, 4:7].clamp(-1, 1)) and float(dst[0, :, 0].min()) == 7.0 and float(dst[0, :, 4:].min()) == 7.0
+    ops.ncthw_copy_frames(x.cuda(), dst, 0, 6, 2, clamp=False)
+    assert torch.equal(dst[0, :, 6:8].cpu(), x[0, :, 0:2])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("pad_gen", [False, True])
+def test_device_reconstruction_loop_matches_oracle(pad_gen):
+    """the whole inference_reconstruct.py loop on the GPU (real model, fp32 kernels) vs the oracle loop around the
+    oracle engine: uint8 frames may differ by one level where a value sits on a truncation boundary"""
+    from vidtok_amd import video_io
+
+    model, cfg, sd = build_model("vidtok_kl_causal_488_4chn", seed=17, device="cuda", dtype=torch.float32)
+    model.regularization.sample = False
+    ora = build_oracle(cfg, sd)
+    ora.sample = False
+    frames = torch.randint(0, 256, (40, 48, 80, 3), dtype=torch.uint8, generator=torch.Generator().manual_seed(5))
+    rec = video_io.VideoReconstructor(model, input_height=32, input_width=32, sample_fps=30, chunk_size=8, pad_gen_frames=pad_gen)
+    got = rec.reconstruct(frames.cuda(), fps=30.0).cpu().numpy()
+    ids = V.frame_id_batches(40, 30.0, 30, 8, True, False)
+    clips = [V.preprocess_frames(frames[b], 32, 32).unsqueeze(0) for b in ids]
+    ref = V.reconstruct(ora, clips, True, 4, False, pad_gen, True)
+    assert got.shape == ref.shape == (36, 32, 64, 3)
+    d = np.abs(got.astype(np.int16) - ref.astype(np.int16))
+    print(f"reconstruct pad_gen={pad_gen}: {int((d > 0).sum())} of {d.size} uint8 values differ, max {int(d.max())}")
+    assert np.array_equal(got[:, :, :32], ref[:, :, :32])          # the input half is exact
+    assert d.max() <= 1 and (d > 0).mean() < 2e-3

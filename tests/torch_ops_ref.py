@@ -266,8 +266,40 @@ def eval_psnr_ssim(x, y, raw=True):
     return M.psnr_frames(x, y), M.ssim_frames(x, y)
 
 
+def frames_u8_to_ncthw(frames, resized_hw, crop_top_left, out_hw, out=None, t_off=0):
+    """contract of vt_frames_u8_to_ncthw, stated with the oracle's pieces (oracle/video_io_oracle.py)"""
+    from oracle import video_io_oracle as V
+
+    x = frames.permute(0, 3, 1, 2).float() / 255.0
+    if tuple(resized_hw) != tuple(x.shape[-2:]):
+        x = V.resize_aa(x, *resized_hw)
+    (top, left), (h, w) = crop_top_left, out_hw
+    x = ((x[..., top:top + h, left:left + w] - 0.5) / 0.5).permute(1, 0, 2, 3)
+    if out is None:
+        return x.unsqueeze(0).contiguous()
+    out[0, :, t_off:t_off + x.shape[1]] = x
+    return out
+
+
+def ncthw_to_frames_u8(x, t0=0, n=None, out=None, w_off=0):
+    from oracle import video_io_oracle as V
+
+    n = x.shape[2] - t0 if n is None else n
+    fr = torch.from_numpy(V.tensor_to_uint8(x[0, :, t0:t0 + n])).permute(1, 2, 3, 0)   # [n, H, W, 3]
+    if out is None:
+        return fr.contiguous()
+    out[:n, :, w_off:w_off + fr.shape[2]] = fr
+    return out
+
+
+def ncthw_copy_frames(src, dst, ts0, td0, n, clamp=False):
+    v = src[0, :, ts0:ts0 + n]
+    dst[0, :, td0:td0 + n] = v.clamp(-1, 1) if clamp else v
+    return dst
+
+
 ALL = ["conv", "gemm_nt", "layernorm_act", "softmax_rows", "ncthw_to_ndhwc", "ndhwc_to_ncthw", "time_avgpool3s2",
-       "time_lerp2x", "gather_frames", "kl_sample", "fsq_quantize", "fsq_indices_to_codes", "fsq_aux_stats", "entropy", "temporal_block", "temporal_block_supported",
+       "time_lerp2x", "gather_frames", "kl_sample", "fsq_quantize", "fsq_indices_to_codes", "fsq_aux_stats", "entropy", "temporal_block", "temporal_block_supported", "frames_u8_to_ncthw", "ncthw_to_frames_u8", "ncthw_copy_frames",
        "eval_psnr_ssim", "channel_linear", "groupnorm_act"]
 
 

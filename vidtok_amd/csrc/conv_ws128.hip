@@ -53,6 +53,13 @@ __device__ __forceinline__ void static_for(F&& f) {
 #define WS_DEPTH 1   // 2 left the LayerNorm instantiations with scratch spills (3 fragment sets + the row phase in 256 VGPRs)
 #endif
 [[maybe_unused]] constexpr int WS_W_AGPR = 63;   // 4 * 63 = 252 of 256 AGPRs; 4 * 9 = 36 VGPRs of weights
+// "This value exists HERE": an empty volatile statement that reads and writes it.  Instruction selection places pure
+// arithmetic next to its use, not where the source put it -- without pins the ~900 VALU instructions of a row phase,
+// cut into 224 slices for the MFMA shadows, all sank to the seven stores they feed (sched_barrier only binds the later
+// machine scheduler).  Volatile statements keep their order, so a pinned slice stays between "its" two MFMAs.
+__device__ __forceinline__ void pin(float& v) { asm volatile("" : "+v"(v)); }
+__device__ __forceinline__ void pin_u(uint32_t& v) { asm volatile("" : "+v"(v)); }
+
 template <bool W_IN_AGPR, bool FIRST>
 __device__ __forceinline__ void ws_mfma(const u32x4& w, const u32x4& x, f32x16& acc) {
   if constexpr (FIRST) {
@@ -125,19 +132,29 @@ __global__ __launch_bounds__(256, 1) void conv3x3_ws128_kernel(const ConvArgs p)
     h0 = th * WS_TH;
     w0 = (r - th * tiles_w) * WS_TW;
   };
-  auto issue_patch = [&](int tile, int bufoff) {
+  // per-tile scalars of the patch DMA (set by patch_begin), then one piece at a time (patch_piece): the K loop issues
+  // the pieces of the NEXT tile's patch in its MFMA gaps, two per row iteration, instead of 12 back to back up front
+  __amdgpu_buffer_rsrc_t pd_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(xg), 0, 0, 0x00020000);
+  char* pd_dst = smem;
+  unsigned pd_tmask = 0;
+  int pd_toff = 0;
+  bool pd_on = false;
+  auto patch_begin = [&](int tile, int bufoff) {
     int f, h0, w0;
     tile_coords(tile, f, h0, w0);
-    const __amdgpu_buffer_rsrc_t rsrc =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(xg) + (long long)f * H * W * 128, 0, frame_bytes, 0x00020000);
-    char* dst = smem + bufoff + wave * (WS_QPW * 1024);
-    const unsigned tmask = (w0 == 0 ? 1u : 0u) | (w0 + WS_TW == W ? 2u : 0u);
-    const int toff = (h0 * W + w0) * 256;
-#pragma unroll
-    for (int q = 0; q < WS_QPW; ++q) {
-      const unsigned off = (bflags & (tmask << (2 * q))) ? kOob : (unsigned)(bo[q] + toff);
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)(dst + q * 1024), 16, off, 0, 0, 0);
-    }
+    pd_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(xg) + (long long)f * H * W * 128, 0, frame_bytes, 0x00020000);
+    pd_dst = smem + bufoff + wave * (WS_QPW * 1024);
+    pd_tmask = (w0 == 0 ? 1u : 0u) | (w0 + WS_TW == W ? 2u : 0u);
+    pd_toff = (h0 * W + w0) * 256;
+  };
+  auto patch_piece = [&](auto qc) {
+    constexpr int q = decltype(qc)::value;
+    const unsigned off = (bflags & (pd_tmask << (2 * q))) ? kOob : (unsigned)(bo[q] + pd_toff);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(pd_rsrc, (lds_ptr_t)(pd_dst + q * 1024), 16, off, 0, 0, 0);
+  };
+  auto issue_patch = [&](int tile, int bufoff) {
+    patch_begin(tile, bufoff);
+    static_for<0, WS_QPW>([&](auto qc) { patch_piece(qc); });
   };
 
   // ---- per-lane constants of the fragment reads and of the row phase ----------------------------------------------------
@@ -155,73 +172,105 @@ __global__ __launch_bounds__(256, 1) void conv3x3_ws128_kernel(const ConvArgs p)
   f32x4 rt0, rt1;
   // residual rows: with no residual the registers stay zero and the adds are spent anyway -- the instantiations without
   // these 8 registers came out of the register allocator WITH scratch spills (the ones with them did not)
-  Oct<bf16_t> rq_cur, rq_nxt;
-  rq_cur.w[0] = rq_cur.w[1] = rq_cur.w[2] = rq_cur.w[3] = 0u;
-  rq_nxt.w = rq_cur.w;
+  Oct<bf16_t> rq[2];      // row iteration `it` uses rq[it & 1]; the other one is in flight for it + 1
+  rq[0].w[0] = rq[0].w[1] = rq[0].w[2] = rq[0].w[3] = 0u;
+  rq[1].w = rq[0].w;
+  float rsum = 0.f;
+  uint32_t rw[4] = {0u, 0u, 0u, 0u};
   const bool has_res = p.res_mode == VT_RES_ADD;   // uniform
   long long pix0_prev = 0;
   auto res_row_ptr = [&](int it) -> const bf16_t* {
     const int row = row0 + 16 * it;
     return rg + (pix0_prev + (long long)(row >> 4) * W + (row & 15)) * p.ldr + 8 * oct_j;
   };
-  auto row_piece = [&](auto piece_c) {
-    constexpr int piece = decltype(piece_c)::value;
+  // piece = 7 it + stage, sub = which of the group's four MFMA shadows it sits in; ~5 VALU instructions per call
+  auto row_piece = [&](auto piece_c, auto sub_c) {
+    constexpr int piece = decltype(piece_c)::value, sub = decltype(sub_c)::value;
     constexpr int it = piece / 7, st = piece % 7;
     const int row = row0 + 16 * it;
     if constexpr (st == 0) {
       const int sw = row & 31;
-      rt0 = *reinterpret_cast<const f32x4*>(T + row * 128 + (((2 * oct_j) ^ sw) << 2));
-      rt1 = *reinterpret_cast<const f32x4*>(T + row * 128 + (((2 * oct_j + 1) ^ sw) << 2));
-      if constexpr (it + 1 < 8) { if (has_res) rq_nxt.load(res_row_ptr(it + 1)); }
-    } else if constexpr (st == 1) {
-      float s = 0.f;
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        rv[e] = e < 4 ? rt0[e] : rt1[e - 4];
-        rv[e] = rq_cur.get(e) + rv[e];
-        s += rv[e];
-      }
-      if constexpr (LN != 0) {
-        rmean = group_sum_dpp<16>(s) * (1.0f / 128.0f);
+      if constexpr (sub == 0) rt0 = *reinterpret_cast<const f32x4*>(T + row * 128 + (((2 * oct_j) ^ sw) << 2));
+      if constexpr (sub == 1) rt1 = *reinterpret_cast<const f32x4*>(T + row * 128 + (((2 * oct_j + 1) ^ sw) << 2));
+      if constexpr (sub == 2 && it + 1 < 8) { if (has_res) rq[(it + 1) & 1].load(res_row_ptr(it + 1)); }
+      if constexpr (sub == 3 && LN != 0) {
         lg0 = *reinterpret_cast<const f32x4*>(p.ln_gamma + 8 * oct_j);
         lg1 = *reinterpret_cast<const f32x4*>(p.ln_gamma + 8 * oct_j + 4);
         lb0 = *reinterpret_cast<const f32x4*>(p.ln_beta + 8 * oct_j);
         lb1 = *reinterpret_cast<const f32x4*>(p.ln_beta + 8 * oct_j + 4);
       }
-      if constexpr (it + 1 < 8) rq_cur = rq_nxt;
-    } else if constexpr (st == 2) {
-      const long long orow = pix0_prev + (long long)(row >> 4) * W + (row & 15);
-      if constexpr (KEEP) Oct<bf16_t>::store(yg + orow * p.ldy + 8 * oct_j, rv);
-      if constexpr (LN != 0) {
-        float q = 0.f;
+    } else if constexpr (st == 1) {          // rv = T row + residual; running sum; mean in the last shadow
+      if constexpr (sub == 0) rsum = 0.f;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          rv[e] -= rmean;
-          q += rv[e] * rv[e];
+      for (int e = 2 * sub; e < 2 * sub + 2; ++e) {
+        rv[e] = rq[it & 1].get(e) + (e < 4 ? rt0[e] : rt1[e - 4]);
+        rsum += rv[e];
+        pin(rv[e]);
+      }
+      pin(rsum);
+      if constexpr (sub == 3 && LN != 0) {
+        rmean = group_sum_dpp<16>(rsum) * (1.0f / 128.0f);
+        pin(rmean);
+      }
+    } else if constexpr (st == 2) {          // y store; centred values and their squares; rstd in the last shadow
+      if constexpr (sub == 0) {
+        rsum = 0.f;
+        if constexpr (KEEP) {
+          const long long orow = pix0_prev + (long long)(row >> 4) * W + (row & 15);
+          Oct<bf16_t>::store(yg + orow * p.ldy + 8 * oct_j, rv);
         }
-        rrstd = __builtin_amdgcn_rsqf(group_sum_dpp<16>(q) * (1.0f / 128.0f) + p.ln_eps);
+      }
+      if constexpr (LN != 0) {
+#pragma unroll
+        for (int e = 2 * sub; e < 2 * sub + 2; ++e) {
+          rv[e] -= rmean;
+          rsum += rv[e] * rv[e];
+          pin(rv[e]);
+        }
+        pin(rsum);
+        if constexpr (sub == 3) {
+          rrstd = __builtin_amdgcn_rsqf(group_sum_dpp<16>(rsum) * (1.0f / 128.0f) + p.ln_eps);
+          pin(rrstd);
+        }
       }
     } else if constexpr (st == 3) {
       if constexpr (LN != 0) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) rv[e] = rv[e] * rrstd * (e < 4 ? lg0[e] : lg1[e - 4]) + (e < 4 ? lb0[e] : lb1[e - 4]);
+        for (int e = 2 * sub; e < 2 * sub + 2; ++e) {
+          rv[e] = rv[e] * rrstd * (e < 4 ? lg0[e] : lg1[e - 4]) + (e < 4 ? lb0[e] : lb1[e - 4]);
+          pin(rv[e]);
+        }
       }
     } else if constexpr (st == 4) {
       if constexpr (LN == 2) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) rv[e] = silu_fast(rv[e]);
+        rv[sub] = silu_fast(rv[sub]);
+        pin(rv[sub]);
       }
     } else if constexpr (st == 5) {
       if constexpr (LN == 2) {
-#pragma unroll
-        for (int e = 4; e < 8; ++e) rv[e] = silu_fast(rv[e]);
+        rv[4 + sub] = silu_fast(rv[4 + sub]);
+        pin(rv[4 + sub]);
       }
-    } else {
+    } else {                                 // pack to bf16 (two words per shadow), then one 16-B store
       if constexpr (LN != 0) {
-        const long long orow = pix0_prev + (long long)(row >> 4) * W + (row & 15);
-        Oct<bf16_t>::store(ng + orow * p.ldn + 8 * oct_j, rv);
+        if constexpr (sub < 2) {
+#pragma unroll
+          for (int e = 2 * sub; e < 2 * sub + 2; ++e) {
+            rw[e] = f32_to_bf16_bits(rv[2 * e]) | (f32_to_bf16_bits(rv[2 * e + 1]) << 16);
+            pin_u(rw[e]);
+          }
+        }
+        if constexpr (sub == 2) {
+          const long long orow = pix0_prev + (long long)(row >> 4) * W + (row & 15);
+          u32x4 w4;
+          w4[0] = rw[0]; w4[1] = rw[1]; w4[2] = rw[2]; w4[3] = rw[3];
+          *reinterpret_cast<u32x4*>(ng + orow * p.ldn + 8 * oct_j) = w4;
+        }
       }
     }
+  };
+  auto row_piece_all = [&](auto piece_c) {
+    static_for<0, 4>([&](auto sc) { row_piece(piece_c, sc); });
   };
 
   // ---- K loop of one tile: 72 groups (tap, 16-channel chunk) x 4 pixel sub-tiles, an explicit software pipeline: the four
@@ -230,6 +279,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_ws128_kernel(const ConvArgs p)
   // reads to the top of the tile and spills the stationary weights.  WITH_ROWS: groups 0..55 also carry the row phase
   // of the previous tile, one piece each; the last 16 groups stay bare so its stores have retired by the vmcnt drain.
   f32x16 acc[4];
+  f32x4 bq[4];
   auto k_loop = [&](auto with_rows_c, int bufoff) {
     constexpr bool WITH_ROWS = decltype(with_rows_c)::value;
     const char* pb = smem + bufoff + frag_off;
@@ -246,13 +296,28 @@ __global__ __launch_bounds__(256, 1) void conv3x3_ws128_kernel(const ConvArgs p)
       for (int j = 0; j < 4; ++j) xf[d][j] = *frag_addr(d, j);
     static_for<0, 72>([&](auto gc) {
       constexpr int g = decltype(gc)::value;
-      if constexpr (g + D < 72) {
+      static_for<0, 4>([&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+        ws_mfma<(g < WS_W_AGPR), (g == 0)>(wreg[g], xf[g % (D + 1)][j], acc[j]);
+        // in this MFMA's 32-cycle shadow: the same sub-tile's fragment of group g + D, then ~5 VALU of the row phase
+        if constexpr (g + D < 72) xf[(g + D) % (D + 1)][j] = *frag_addr(g + D, j);
+        if constexpr (WITH_ROWS && g < 56) {
+          row_piece(gc, jc);
+          // the next tile's patch: pieces 2 it, 2 it + 1 ride with the light stages (0 and 6) of row iteration it < 6
+          if constexpr (j == 3 && g / 7 < 6 && (g % 7 == 0 || g % 7 == 6)) {
+            if (pd_on) patch_piece(std::integral_constant<int, (2 * (g / 7) + (g % 7 == 6 ? 1 : 0)) % WS_QPW>{});
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      });
+      if constexpr (g == 60) {             // bias quads for the transposition below: requested in a bare stretch
+        const int h = lane >> 5;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) xf[(g + D) % (D + 1)][j] = *frag_addr(g + D, j);
+        for (int q4 = 0; q4 < 4; ++q4) {
+          if (p.bias) bq[q4] = *reinterpret_cast<const f32x4*>(p.bias + wave * 32 + 8 * q4 + 4 * h);
+          else bq[q4][0] = bq[q4][1] = bq[q4][2] = bq[q4][3] = 0.0f;
+        }
       }
-#pragma unroll
-      for (int j = 0; j < 4; ++j) ws_mfma<(g < WS_W_AGPR), (g == 0)>(wreg[g], xf[g % (D + 1)][j], acc[j]);
-      if constexpr (WITH_ROWS && g < 56) row_piece(gc);
       __builtin_amdgcn_sched_barrier(0);
     });
     asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");   // last MFMA -> first reader of its accumulator (hipcc pads nothing around asm)
@@ -260,12 +325,6 @@ __global__ __launch_bounds__(256, 1) void conv3x3_ws128_kernel(const ConvArgs p)
   // accumulators (+ bias) -> T, transposed: MFMA layout lane = pixel 32 j + lane%32, channels 32 wave + 8 g + 4 (lane/32) + e
   auto acc_to_T = [&]() {
     const int h = lane >> 5;
-    f32x4 bq[4];
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      if (p.bias) bq[g] = *reinterpret_cast<const f32x4*>(p.bias + wave * 32 + 8 * g + 4 * h);
-      else bq[g][0] = bq[g][1] = bq[g][2] = bq[g][3] = 0.0f;
-    }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int prow = 32 * j + (lane & 31);
@@ -289,11 +348,13 @@ __global__ __launch_bounds__(256, 1) void conv3x3_ws128_kernel(const ConvArgs p)
     //     previous tile's T is complete
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    if (tile + 1 < t_end) issue_patch(tile + 1, cur ? 0 : WS_PATCH);
+    pd_on = tile + 1 < t_end;            // uniform
     if (tile == t_begin) {
+      if (pd_on) issue_patch(tile + 1, cur ? 0 : WS_PATCH);
       k_loop(std::false_type{}, cur ? WS_PATCH : 0);
     } else {
-      if (has_res) rq_cur.load(res_row_ptr(0));
+      if (pd_on) patch_begin(tile + 1, cur ? 0 : WS_PATCH);
+      if (has_res) rq[0].load(res_row_ptr(0));
       k_loop(std::true_type{}, cur ? WS_PATCH : 0);
     }
     wait_vmcnt<0>();                 // own DMA pieces of the next patch, the row phase's loads and stores: long done
@@ -306,8 +367,8 @@ __global__ __launch_bounds__(256, 1) void conv3x3_ws128_kernel(const ConvArgs p)
   }
   // row phase of the last tile, on its own
   __syncthreads();
-  if (has_res) rq_cur.load(res_row_ptr(0));
-  static_for<0, 56>([&](auto pc) { row_piece(pc); });
+  if (has_res) rq[0].load(res_row_ptr(0));
+  static_for<0, 56>([&](auto pc) { row_piece_all(pc); });
 #endif
 }
 

@@ -488,3 +488,47 @@ def eval_psnr_ssim(x, y, raw=True):
     L.check(lib.vt_eval_psnr_ssim(_ptr(x), _ptr(y), _ptr(psnr), _ptr(ssim), _ptr(work), B, Cc, T, H, W, int(bool(raw)),
                                   _stream()), "vt_eval_psnr_ssim")
     return psnr, ssim
+
+
+# ---- video front / back end (device halves of scripts/inference_reconstruct.py) ---------------------------------------
+def frames_u8_to_ncthw(frames, resized_hw, crop_top_left, out_hw, out=None, t_off=0):
+    """frames uint8 [T, H0, W0, 3] -> fp32 [1, 3, T, h, w] in [-1, 1]: /255, anti-aliased bilinear resize to
+    `resized_hw`, crop window at `crop_top_left` of size `out_hw`, (v-0.5)/0.5.  `out` [1, 3, Tdst, h, w] + `t_off`
+    write the frames into a larger clip buffer (--pad_gen_frames chaining)."""
+    lib = L.load()
+    _chk(frames, "frames")
+    assert frames.dtype == torch.uint8 and frames.dim() == 4 and frames.shape[3] == 3
+    T, H0, W0, _ = frames.shape
+    (Hr, Wr), (top, left), (H, W) = resized_hw, crop_top_left, out_hw
+    if out is None:
+        out = torch.empty((1, 3, T, H, W), dtype=torch.float32, device=frames.device)
+    assert out.dtype == torch.float32 and out.is_contiguous() and out.shape[0] == 1 and out.shape[1] == 3 and tuple(out.shape[3:]) == (H, W)
+    work = torch.empty((lib.vt_frames_work_floats(T, H0, W),), dtype=torch.float32, device=frames.device)
+    L.check(lib.vt_frames_u8_to_ncthw(_ptr(frames), T, H0, W0, Hr, Wr, top, left, _ptr(out), out.shape[2], t_off, H, W, _ptr(work),
+                                      _stream()), "vt_frames_u8_to_ncthw")
+    return out
+
+
+def ncthw_to_frames_u8(x, t0=0, n=None, out=None, w_off=0):
+    """x fp32 [1, 3, T, H, W] frames t0 .. t0+n -> uint8 [n, H, Wtot, 3] (clamp, (x+1)/2, *255, truncation) at column w_off"""
+    lib = L.load()
+    _chk(x, "x")
+    assert x.dtype == torch.float32 and x.dim() == 5 and x.shape[0] == 1 and x.shape[1] == 3
+    T, H, W = x.shape[2:]
+    n = T - t0 if n is None else n
+    if out is None:
+        out = torch.empty((n, H, W, 3), dtype=torch.uint8, device=x.device)
+    assert out.dtype == torch.uint8 and out.is_contiguous() and out.shape[0] >= n and out.shape[1] == H and out.shape[3] == 3
+    L.check(lib.vt_ncthw_to_frames_u8(_ptr(x), T, t0, n, H, W, _ptr(out), out.shape[2], w_off, _stream()), "vt_ncthw_to_frames_u8")
+    return out
+
+
+def ncthw_copy_frames(src, dst, ts0, td0, n, clamp=False):
+    """dst[0, :, td0:td0+n] = src[0, :, ts0:ts0+n] (optionally clamped to [-1, 1]) for fp32 [1, C, T, H, W] tensors"""
+    lib = L.load()
+    _chk(src, "src"); _chk(dst, "dst")
+    assert src.dtype == torch.float32 and dst.dtype == torch.float32 and src.shape[0] == 1 and dst.shape[0] == 1
+    assert src.shape[1] == dst.shape[1] and tuple(src.shape[3:]) == tuple(dst.shape[3:])
+    L.check(lib.vt_ncthw_copy_frames(_ptr(src), _ptr(dst), src.shape[1], src.shape[2], dst.shape[2], ts0, td0, n,
+                                     src.shape[3] * src.shape[4], int(bool(clamp)), _stream()), "vt_ncthw_copy_frames")
+    return dst
