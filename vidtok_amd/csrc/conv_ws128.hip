@@ -52,26 +52,43 @@ __device__ __forceinline__ void static_for(F&& f) {
 #ifndef WS_DEPTH
 #define WS_DEPTH 1   // 2 left the LayerNorm instantiations with scratch spills (3 fragment sets + the row phase in 256 VGPRs)
 #endif
-[[maybe_unused]] constexpr int WS_W_AGPR = 63;   // 4 * 63 = 252 of 256 AGPRs; 4 * 9 = 36 VGPRs of weights
+// ACC_A = true: accumulators (64) + the first 47 weight fragments in the accumulator half of the register file, 25
+// fragments (100 registers) in the architectural half; false: accumulators in the architectural half (no copies in
+// the epilogue), 63 fragments in the other one.  VT_WS_ACC selects at run time (A/B: an MFMA whose C / D operands sit
+// in the architectural file shares its ports with the B operand).
+template <bool ACC_A>
+struct WsSplit {
+  static constexpr int W_AGPR = ACC_A ? 47 : 63;
+};
+template <bool W_IN_AGPR, bool FIRST, bool ACC_A>
+__device__ __forceinline__ void ws_mfma(const u32x4& w, const u32x4& x, f32x16& acc) {
+  if constexpr (ACC_A) {
+    if constexpr (FIRST) {
+      if constexpr (W_IN_AGPR) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=a"(acc) : "a"(w), "v"(x));
+      else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=a"(acc) : "v"(w), "v"(x));
+    } else {
+      if constexpr (W_IN_AGPR) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc) : "a"(w), "v"(x));
+      else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(w), "v"(x));
+    }
+  } else {
+    if constexpr (FIRST) {
+      if constexpr (W_IN_AGPR) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=v"(acc) : "a"(w), "v"(x));
+      else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=v"(acc) : "v"(w), "v"(x));
+    } else {
+      if constexpr (W_IN_AGPR) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "a"(w), "v"(x));
+      else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(w), "v"(x));
+    }
+  }
+}
+
 // "This value exists HERE": an empty volatile statement that reads and writes it.  Instruction selection places pure
 // arithmetic next to its use, not where the source put it -- without pins the ~900 VALU instructions of a row phase,
-// cut into 224 slices for the MFMA shadows, all sank to the seven stores they feed (sched_barrier only binds the later
+// cut into 224 slices for the MFMA shadows, all sank to the stores they feed (sched_barrier only binds the later
 // machine scheduler).  Volatile statements keep their order, so a pinned slice stays between "its" two MFMAs.
 __device__ __forceinline__ void pin(float& v) { asm volatile("" : "+v"(v)); }
 __device__ __forceinline__ void pin_u(uint32_t& v) { asm volatile("" : "+v"(v)); }
 
-template <bool W_IN_AGPR, bool FIRST>
-__device__ __forceinline__ void ws_mfma(const u32x4& w, const u32x4& x, f32x16& acc) {
-  if constexpr (FIRST) {
-    if constexpr (W_IN_AGPR) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=v"(acc) : "a"(w), "v"(x));
-    else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=v"(acc) : "v"(w), "v"(x));
-  } else {
-    if constexpr (W_IN_AGPR) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "a"(w), "v"(x));
-    else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(w), "v"(x));
-  }
-}
-
-template <int LN, bool KEEP>
+template <int LN, bool KEEP, bool ACC_A>
 __global__ __launch_bounds__(256, 1) void conv3x3_ws128_kernel(const ConvArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -158,8 +175,29 @@ __global__ __launch_bounds__(256, 1) void conv3x3_ws128_kernel(const ConvArgs p)
   };
 
   // ---- per-lane constants of the fragment reads and of the row phase ----------------------------------------------------
-  const int frag_off = (((lane & 31) >> 4) * WS_PW + (lane & 15)) * WS_ROWP + (lane >> 5) * 16;
-  const int oct_j = tid & 15, row0 = tid >> 4;   // rows row0 + 16 it (it < 8), channels [8 oct_j, +8)
+  // MFMA column m = lane % 32 of a pixel sub-tile (2 rows x 16 columns of the tile) -> which pixel.  ds_read_b128
+  // serves a wave in four groups of 16 lanes -- {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31} and the same + 32 -- one LDS
+  // cycle each when the 16 addresses fall on 16 different 16-B bank quads.  With the 272-B pixel stride the quad of
+  // patch pixel (r, c) is (2r + c + unit) mod 16, so a group must hold 16 pixels of ONE patch row: group 0 reads row 0
+  // of the sub-tile, group 1 row 1 (the natural m -> (m / 16, m % 16) puts 8 + 8 pixels of both rows into each group:
+  // two 2-way conflicts per group = half the LDS rate, and the K loop needs half of the full rate).
+  auto subtile_pixel = [](int m, int& rsel, int& col) {
+    const bool g0 = (m < 4) | ((m >= 12) & (m < 16)) | ((m >= 20) & (m < 28));
+    rsel = g0 ? 0 : 1;
+    col = g0 ? (m < 4 ? m : (m < 16 ? m - 8 : m - 12)) : (m < 12 ? m - 4 : (m < 20 ? m - 8 : m - 16));
+  };
+  int f_rsel, f_col;
+  subtile_pixel(lane & 31, f_rsel, f_col);
+  const int frag_off = (f_rsel * WS_PW + f_col) * WS_ROWP + (lane >> 5) * 16;
+  // rows of T = MFMA order (32 j + m); the row phase handles T rows row0 + 16 it (it < 8), channels [8 oct_j, +8):
+  // T row -> tile pixel (2 (it / 2) + rsel, col) with (rsel, col) of m = row0 + 16 (it % 2)
+  const int oct_j = tid & 15, row0 = tid >> 4;
+  int tp_r[2], tp_c[2];
+  subtile_pixel(row0, tp_r[0], tp_c[0]);
+  subtile_pixel(row0 + 16, tp_r[1], tp_c[1]);
+  auto tile_pixel_off = [&](int it) -> long long {     // element-row offset of T row (row0 + 16 it) from the tile origin
+    return (long long)(2 * (it >> 1) + tp_r[it & 1]) * W + tp_c[it & 1];
+  };
   // LayerNorm affine of this lane's 8 channels: re-read (L1-resident) two stages before each use instead of pinning
   // 16 more registers for the kernel's lifetime -- the K loop runs within ~10 registers of the 256 architectural ones
   f32x4 lg0, lg1, lb0, lb1;
@@ -180,8 +218,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_ws128_kernel(const ConvArgs p)
   const bool has_res = p.res_mode == VT_RES_ADD;   // uniform
   long long pix0_prev = 0;
   auto res_row_ptr = [&](int it) -> const bf16_t* {
-    const int row = row0 + 16 * it;
-    return rg + (pix0_prev + (long long)(row >> 4) * W + (row & 15)) * p.ldr + 8 * oct_j;
+    return rg + (pix0_prev + tile_pixel_off(it)) * p.ldr + 8 * oct_j;
   };
   // piece = 7 it + stage, sub = which of the group's four MFMA shadows it sits in; ~5 VALU instructions per call
   auto row_piece = [&](auto piece_c, auto sub_c) {
@@ -216,7 +253,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_ws128_kernel(const ConvArgs p)
       if constexpr (sub == 0) {
         rsum = 0.f;
         if constexpr (KEEP) {
-          const long long orow = pix0_prev + (long long)(row >> 4) * W + (row & 15);
+          const long long orow = pix0_prev + tile_pixel_off(it);
           Oct<bf16_t>::store(yg + orow * p.ldy + 8 * oct_j, rv);
         }
       }
@@ -261,7 +298,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_ws128_kernel(const ConvArgs p)
           }
         }
         if constexpr (sub == 2) {
-          const long long orow = pix0_prev + (long long)(row >> 4) * W + (row & 15);
+          const long long orow = pix0_prev + tile_pixel_off(it);
           u32x4 w4;
           w4[0] = rw[0]; w4[1] = rw[1]; w4[2] = rw[2]; w4[3] = rw[3];
           *reinterpret_cast<u32x4*>(ng + orow * p.ldn + 8 * oct_j) = w4;
@@ -298,7 +335,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_ws128_kernel(const ConvArgs p)
       constexpr int g = decltype(gc)::value;
       static_for<0, 4>([&](auto jc) {
         constexpr int j = decltype(jc)::value;
-        ws_mfma<(g < WS_W_AGPR), (g == 0)>(wreg[g], xf[g % (D + 1)][j], acc[j]);
+        ws_mfma<(g < WsSplit<ACC_A>::W_AGPR), (g == 0), ACC_A>(wreg[g], xf[g % (D + 1)][j], acc[j]);
         // in this MFMA's 32-cycle shadow: the same sub-tile's fragment of group g + D, then ~5 VALU of the row phase
         if constexpr (g + D < 72) xf[(g + D) % (D + 1)][j] = *frag_addr(g + D, j);
         if constexpr (WITH_ROWS && g < 56) {
@@ -381,19 +418,23 @@ extern "C" __attribute__((visibility("hidden"))) int vt_ws128_launch(const void*
   // one instantiation per epilogue shape: LayerNorm none / plain / +SiLU, y kept or not
   const bool keep = a.ln_mode == 0 || a.ln_keep_y != 0;
   const int vi = a.ln_mode == 0 ? 0 : (a.ln_mode == 1 ? (keep ? 1 : 2) : (keep ? 3 : 4));
-  static const void* const kerns[5] = {
-      reinterpret_cast<const void*>(&conv3x3_ws128_kernel<0, true>), reinterpret_cast<const void*>(&conv3x3_ws128_kernel<1, true>),
-      reinterpret_cast<const void*>(&conv3x3_ws128_kernel<1, false>), reinterpret_cast<const void*>(&conv3x3_ws128_kernel<2, true>),
-      reinterpret_cast<const void*>(&conv3x3_ws128_kernel<2, false>)};
-  const void* kern = kerns[vi];
+  const int acc_a = env_int("VT_WS_ACC", 1) != 0 ? 1 : 0;
+  static const void* const kerns[2][5] = {
+      {reinterpret_cast<const void*>(&conv3x3_ws128_kernel<0, true, false>), reinterpret_cast<const void*>(&conv3x3_ws128_kernel<1, true, false>),
+       reinterpret_cast<const void*>(&conv3x3_ws128_kernel<1, false, false>), reinterpret_cast<const void*>(&conv3x3_ws128_kernel<2, true, false>),
+       reinterpret_cast<const void*>(&conv3x3_ws128_kernel<2, false, false>)},
+      {reinterpret_cast<const void*>(&conv3x3_ws128_kernel<0, true, true>), reinterpret_cast<const void*>(&conv3x3_ws128_kernel<1, true, true>),
+       reinterpret_cast<const void*>(&conv3x3_ws128_kernel<1, false, true>), reinterpret_cast<const void*>(&conv3x3_ws128_kernel<2, true, true>),
+       reinterpret_cast<const void*>(&conv3x3_ws128_kernel<2, false, true>)}};
+  const void* kern = kerns[acc_a][vi];
   static std::atomic<int> cus[kMaxDevices];         // 0 = not queried yet on that device; else its CU count
-  static std::atomic<bool> attr_done[5][kMaxDevices];
+  static std::atomic<bool> attr_done[2][5][kMaxDevices];
   int dev = 0;
   VT_CHECK_HIP(hipGetDevice(&dev));
   const bool dev_ok = dev >= 0 && dev < kMaxDevices;
-  if (!dev_ok || !attr_done[vi][dev].load(std::memory_order_acquire)) {
+  if (!dev_ok || !attr_done[acc_a][vi][dev].load(std::memory_order_acquire)) {
     VT_CHECK_HIP(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, WS_LDS));
-    if (dev_ok) attr_done[vi][dev].store(true, std::memory_order_release);
+    if (dev_ok) attr_done[acc_a][vi][dev].store(true, std::memory_order_release);
   }
   int ncu = dev_ok ? cus[dev].load(std::memory_order_acquire) : 0;
   if (ncu == 0) {

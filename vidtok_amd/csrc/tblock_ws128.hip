@@ -60,8 +60,10 @@ __device__ __forceinline__ void tb_static_for(F&& f) {
 }
 
 // accumulators in the architectural half, stationary weights in the accumulator half (see conv_ws128.hip)
+template <bool ACC_A>
 __device__ __forceinline__ void tb_mfma(const u32x4& w, const u32x4& x, f32x16& acc) {
-  asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "a"(w), "v"(x));
+  if constexpr (ACC_A) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc) : "a"(w), "v"(x));
+  else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "a"(w), "v"(x));
 }
 
 // LayerNorm (+SiLU) of one pixel row held by 16 lanes x 8 channels; two-pass statistics like layernorm_act_kernel
@@ -86,6 +88,7 @@ __device__ __forceinline__ void tb_row_norm(float (&v)[8], const float (&g)[8], 
   }
 }
 
+template <bool ACC_A>
 __global__ __launch_bounds__(256, 1) void tblock_ws128_kernel(const TBlockArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -161,7 +164,7 @@ __global__ __launch_bounds__(256, 1) void tblock_ws128_kernel(const TBlockArgs p
         for (int j = 0; j < 2; ++j) xf[(g + 2) % 3][j] = *faddr(g + 2, j);
       }
 #pragma unroll
-      for (int j = 0; j < 2; ++j) tb_mfma(wreg[WB + g], xf[g % 3][j], acc[j]);
+      for (int j = 0; j < 2; ++j) tb_mfma<ACC_A>(wreg[WB + g], xf[g % 3][j], acc[j]);
       __builtin_amdgcn_sched_barrier(0);
     });
     asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");               // last MFMA -> first VALU reader of its accumulator
@@ -315,13 +318,15 @@ extern "C" int vt_temporal_block(const vt_tblock_desc* d, vt_stream stream_) {
   a.keep_y = d->keep_y ? 1 : 0;
   a.ln_next = d->ln_next_mode;
   a.eps = d->eps;
-  const void* kern = reinterpret_cast<const void*>(&tblock_ws128_kernel);
+  const int acc_a = env_int("VT_WS_ACC", 1) != 0 ? 1 : 0;   // accumulators in the accumulator (1) / architectural (0) half
+  const void* kern = acc_a ? reinterpret_cast<const void*>(&tblock_ws128_kernel<true>) : reinterpret_cast<const void*>(&tblock_ws128_kernel<false>);
   static std::atomic<int> cus[kMaxDevices];
   int dev = 0;
   VT_CHECK_HIP(hipGetDevice(&dev));
   int ncu = (dev >= 0 && dev < kMaxDevices) ? cus[dev].load(std::memory_order_acquire) : 0;
   if (ncu == 0) {
-    VT_CHECK_HIP(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, TB_LDS));
+    VT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&tblock_ws128_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, TB_LDS));
+    VT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&tblock_ws128_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, TB_LDS));
     VT_CHECK_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
     if (ncu <= 0) ncu = 256;
     if (dev >= 0 && dev < kMaxDevices) cus[dev].store(ncu, std::memory_order_release);
