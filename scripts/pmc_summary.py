@@ -12,18 +12,21 @@ def main(root):
     for f in sorted(glob.glob(os.path.join(root, "*", "p_counter_collection.csv"))):
         agg = defaultdict(list)
         for r in csv.DictReader(open(f)):
-            if "conv_igemm" not in r["Kernel_Name"] and "conv_stream" not in r["Kernel_Name"]:
+            kn = r["Kernel_Name"]
+            fam = next((t for t in ("conv_igemm", "conv3x3_ws128", "tblock_ws128") if t in kn), None)
+            if fam is None:
                 continue
-            agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
+            agg[(fam, r["Counter_Name"])].append(float(r["Counter_Value"]))
         for k, v in agg.items():
-            out[k] = (sum(v) / len(v), len(v))
+            out[f"{k[0]}:{k[1]}"] = (sum(v) / len(v), len(v))
     kt = glob.glob(os.path.join(root, "sq1", "p_kernel_trace.csv"))
     if kt:
-        d = [float(r["End_Timestamp"]) - float(r["Start_Timestamp"]) for r in csv.DictReader(open(kt[0]))
-             if "conv_igemm" in r["Kernel_Name"] or "conv_stream" in r["Kernel_Name"]]
-        out["kernel_ns(avg)"] = (sum(d) / len(d), len(d))
+        for fam in ("conv_igemm", "conv3x3_ws128", "tblock_ws128"):
+            d = [float(r["End_Timestamp"]) - float(r["Start_Timestamp"]) for r in csv.DictReader(open(kt[0])) if fam in r["Kernel_Name"]]
+            if d:
+                out[f"{fam}:kernel_ns(avg)"] = (sum(d) / len(d), len(d))
     for k in sorted(out):
-        print(f"{k:28s} {out[k][0]:18.1f}   (n={out[k][1]})")
+        print(f"{k:52s} {out[k][0]:18.1f}   (n={out[k][1]})")
     return out
 
 

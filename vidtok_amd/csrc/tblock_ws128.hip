@@ -257,6 +257,12 @@ __global__ __launch_bounds__(256, 1) void tblock_ws128_kernel(const TBlockArgs p
       acc_to_T(acc);
       __syncthreads();                                                // (4)
       // ---- rows of conv2 + b2 + x[t] -> y[t]; LayerNorm_next -> n[t] ----
+      // The prefetched rows of the next step are "used" HERE, before this step's stores are issued: hipcc then waits
+      // for those loads now (issued a whole step ago: free) instead of at their first real use, where the just-issued
+      // stores are still pending -- with loads and stores mixed in flight it does not trust a counted vmcnt and drains
+      // everything, i.e. every step would wait out a store round trip (measured: SQ_WAIT_ANY 19 % of the wave cycles).
+#pragma unroll
+      for (int it = 0; it < 4; ++it) asm volatile("" : "+v"(xn[it].w));
       const long long ob = cb + (long long)t * frame_stride + 8 * oct_j;
 #pragma unroll
       for (int it = 0; it < 4; ++it) {
