@@ -11,11 +11,14 @@ import os
 import sys
 
 
+FAMILIES = ("conv_igemm", "conv3x3_ws128", "tblock_ws128")   # the MFMA kernels of the path (bench.py roofline.kernel)
+
+
 def collect(path, counter):
     vals = []
     for f in glob.glob(os.path.join(path, counter, "**", "*counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
-            if "conv_igemm" in r["Kernel_Name"] and r["Counter_Name"] == counter:
+            if any(t in r["Kernel_Name"] for t in FAMILIES) and r["Counter_Name"] == counter:
                 vals.append(float(r["Counter_Value"]))
     return vals
 
@@ -24,7 +27,7 @@ def main(root, out=None):
     fetch, write = collect(root, "FETCH_SIZE"), collect(root, "WRITE_SIZE")
     n = min(len(fetch), len(write))
     res = {
-        "kernel": "conv_igemm_glds_kernel", "launches_sampled": n,
+        "kernel": "conv_igemm_glds_kernel + conv3x3_ws128_kernel + tblock_ws128_kernel", "launches_sampled": n,
         "fetch_kib_reported_per_launch": sum(fetch) / max(1, len(fetch)),
         "write_kib_per_launch": sum(write) / max(1, len(write)),
         "fetch_correction": 2.0,
