@@ -182,6 +182,8 @@ typedef struct vt_tblock_desc {
   float eps;
 } vt_tblock_desc;
 
+/* sizeof(vt_tblock_desc) as compiled: lets a binding verify its struct mirror */
+int vt_tblock_desc_size(void);
 int vt_temporal_block_supported(const vt_tblock_desc* d);
 int vt_temporal_block(const vt_tblock_desc* d, vt_stream stream);
 

@@ -53,6 +53,34 @@ def test_conv_desc_field_order_matches_header_and_integration_doc():
     assert re.findall(r'"(\w+)"', blk) == names
 
 
+def test_tblock_desc_matches_header_and_integration_doc(built_lib):
+    from vidtok_amd import lib
+
+    assert built_lib.vt_tblock_desc_size() == C.sizeof(lib.TBlockDesc)
+    names = [f[0] for f in lib.TBlockDesc._fields_]
+    hdr = open(os.path.join(ROOT, "include", "vidtok_amd.h")).read()
+    body = hdr[hdr.index("typedef struct vt_tblock_desc {") + len("typedef struct vt_tblock_desc {"):hdr.index("} vt_tblock_desc;")]
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    decl = []
+    for stmt in body.split(";"):
+        m = re.match(r"\s*(?:const\s+)?(?:void|float|int32_t|int64_t)\s*\*?\s*(.+)$", stmt.strip(), flags=re.S)
+        if m:
+            decl += [n.strip() for n in m.group(1).split(",")]
+    assert decl == names, (decl, names)
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    blk = doc[doc.index("class vt_tblock_desc"):doc.index("lib.vt_temporal_block.argtypes")]
+    assert re.findall(r'"(\w+)"', blk) == names
+    # unsupported shapes are refused with a message, never launched (no GPU needed to find out)
+    d = lib.TBlockDesc()
+    d.dtype, d.C, d.ld, d.B, d.T, d.HW, d.tmode = lib.VT_F32, 128, 128, 1, 4, 64, lib.VT_TPAD_ZERO
+    assert built_lib.vt_temporal_block_supported(C.byref(d)) == 0
+    d.dtype = lib.VT_BF16
+    assert built_lib.vt_temporal_block_supported(C.byref(d)) == 1
+    d.HW = 60
+    assert built_lib.vt_temporal_block_supported(C.byref(d)) == 0
+    assert built_lib.vt_temporal_block(C.byref(d), None) != 0 and b"vt_temporal_block" in built_lib.vt_last_error()
+
+
 def test_argument_validation_without_gpu(built_lib):
     from vidtok_amd import lib
 

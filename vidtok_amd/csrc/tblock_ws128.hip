@@ -290,6 +290,8 @@ __global__ __launch_bounds__(256, 1) void tblock_ws128_kernel(const TBlockArgs p
 
 // Fused temporal residual block, see include/vidtok_amd.h (vt_temporal_block).  Returns VT_ERR_ARG with a message when
 // the shape is not one this kernel covers; vt_temporal_block_supported lets the host ask first.
+extern "C" int vt_tblock_desc_size(void) { return (int)sizeof(vt_tblock_desc); }
+
 extern "C" int vt_temporal_block_supported(const vt_tblock_desc* d) {
   if (!d) return 0;
   if (d->dtype != VT_BF16 || d->C != 128 || d->ld != 128) return 0;

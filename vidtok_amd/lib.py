@@ -79,6 +79,7 @@ SIGNATURES = {
     "vt_frames_u8_to_ncthw": (C.c_int, [_P, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _P, _I32, _I32, _I32, _I32, _P, _P]),
     "vt_ncthw_to_frames_u8": (C.c_int, [_P, _I32, _I32, _I32, _I32, _I32, _P, _I32, _I32, _P]),
     "vt_ncthw_copy_frames": (C.c_int, [_P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _I64, _I32, _P]),
+    "vt_tblock_desc_size": (C.c_int, []),
     "vt_temporal_block_supported": (C.c_int, [C.POINTER(TBlockDesc)]),
     "vt_temporal_block": (C.c_int, [C.POINTER(TBlockDesc), _P]),
     "vt_layernorm_act": (C.c_int, [_P, C.c_int, _I64, _P, C.c_int, _I64, _P, _P, _I64, _I32, _F, _I32, _P]),
