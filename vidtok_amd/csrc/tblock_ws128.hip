@@ -88,9 +88,14 @@ __device__ __forceinline__ void tb_row_norm(float (&v)[8], const float (&g)[8], 
   }
 }
 
-template <bool ACC_A>
+// "This value exists HERE" (see conv_ws128.hip): keeps a slice of row arithmetic in the MFMA shadow the source put it in
+__device__ __forceinline__ void tb_pin(float& v) { asm volatile("" : "+v"(v)); }
+
+// LNN: next norm 0 none / 1 LayerNorm / 2 LayerNorm+SiLU; KEEP: y is written
+template <int LNN, bool KEEP>
 __global__ __launch_bounds__(256, 1) void tblock_ws128_kernel(const TBlockArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)
+  constexpr bool ACC_A = true;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -124,8 +129,8 @@ __global__ __launch_bounds__(256, 1) void tblock_ws128_kernel(const TBlockArgs p
   for (int e = 0; e < 8; ++e) {
     lg1[e] = p.g1[8 * oct_j + e]; lb1[e] = p.be1[8 * oct_j + e];
     lg2[e] = p.g2[8 * oct_j + e]; lb2[e] = p.be2[8 * oct_j + e];
-    lgn[e] = p.ln_next ? p.gn[8 * oct_j + e] : 1.0f;
-    lbn[e] = p.ln_next ? p.ben[8 * oct_j + e] : 0.0f;
+    lgn[e] = LNN ? p.gn[8 * oct_j + e] : 1.0f;
+    lbn[e] = LNN ? p.ben[8 * oct_j + e] : 0.0f;
     bo1[e] = p.b1 ? p.b1[8 * oct_j + e] : 0.0f;
     bo2[e] = p.b2 ? p.b2[8 * oct_j + e] : 0.0f;
   }
@@ -138,9 +143,115 @@ __global__ __launch_bounds__(256, 1) void tblock_ws128_kernel(const TBlockArgs p
   };
   const long long frame_stride = (long long)p.HW * 128;
 
+  // ---- row jobs, cut into 48 slices (4 row iterations x 12) so that a GEMM of 48 MFMAs can carry one per shadow ----
+  // (with one wave per SIMD nothing else overlaps this block's three LayerNorm+SiLU per element with its MFMAs:
+  //  measured on the unsliced version: issuing 55 % of the wave cycles, MFMA busy 21 %)
+  float rv[8], rsum = 0.f, rmean = 0.f, rrstd = 0.f;
+  f32x4 rt0, rt1;
+  Oct<bf16_t> xp[4], xc[4], xn[4];   // x rows of the previous step (residual of its OUT job), this step, the next (prefetch)
+  // OUT job of step `vp` (its conv2 result sits in T): + b2 + x -> y store; LayerNorm_next -> n store
+  long long out_base = 0;          // element offset of (frame of vp, row 0 of the tile) + 8 oct_j
+  auto job_out = [&](auto slot_c, Oct<bf16_t> (&xrows)[4]) {
+    constexpr int slot = decltype(slot_c)::value;
+    constexpr int it = slot / 12, s = slot % 12;
+    const int row = row0 + 16 * it;
+    Oct<bf16_t>& xr = xrows[it];
+    if constexpr (s == 0) {
+      const int sw = row & 31;
+      rt0 = *reinterpret_cast<const f32x4*>(T + row * 128 + (((2 * oct_j) ^ sw) << 2));
+      rt1 = *reinterpret_cast<const f32x4*>(T + row * 128 + (((2 * oct_j + 1) ^ sw) << 2));
+    } else if constexpr (s == 1 || s == 2) {
+      if constexpr (s == 1) rsum = 0.f;
+#pragma unroll
+      for (int e = 4 * (s - 1); e < 4 * (s - 1) + 4; ++e) {
+        rv[e] = xr.get(e) + ((e < 4 ? rt0[e] : rt1[e - 4]) + bo2[e]);
+        rsum += rv[e];
+        tb_pin(rv[e]);
+      }
+      tb_pin(rsum);
+    } else if constexpr (s == 3) {
+      if constexpr (KEEP) Oct<bf16_t>::store(p.y + out_base + (long long)row * 128, rv);
+      if constexpr (LNN != 0) {
+        rmean = group_sum_dpp<16>(rsum) * (1.0f / 128.0f);
+        tb_pin(rmean);
+      }
+    } else if constexpr (s == 4 || s == 5) {
+      if constexpr (LNN != 0) {
+        if constexpr (s == 4) rsum = 0.f;
+#pragma unroll
+        for (int e = 4 * (s - 4); e < 4 * (s - 4) + 4; ++e) {
+          rv[e] -= rmean;
+          rsum += rv[e] * rv[e];
+          tb_pin(rv[e]);
+        }
+        tb_pin(rsum);
+      }
+    } else if constexpr (s == 6) {
+      if constexpr (LNN != 0) {
+        rrstd = __builtin_amdgcn_rsqf(group_sum_dpp<16>(rsum) * (1.0f / 128.0f) + p.eps);
+        tb_pin(rrstd);
+      }
+    } else if constexpr (s >= 7 && s <= 10) {
+      if constexpr (LNN != 0) {
+#pragma unroll
+        for (int e = 2 * (s - 7); e < 2 * (s - 7) + 2; ++e) {
+          const float a = rv[e] * rrstd * lgn[e] + lbn[e];
+          rv[e] = (LNN == 2) ? silu_fast(a) : a;
+          tb_pin(rv[e]);
+        }
+      }
+    } else {
+      if constexpr (LNN != 0) Oct<bf16_t>::store(p.n_out + out_base + (long long)row * 128, rv);
+    }
+  };
+  // LN1 job of step `vn` (its x rows are in xs[vn % 3]): LayerNorm1 + SiLU -> ring1[tn % 3]
+  auto job_ln1 = [&](auto slot_c, int tn) {
+    constexpr int slot = decltype(slot_c)::value;
+    constexpr int it = slot / 12, s = slot % 12;
+    const int row = row0 + 16 * it;
+    Oct<bf16_t>& xr = xn[it];
+    if constexpr (s == 1 || s == 2) {
+      if constexpr (s == 1) rsum = 0.f;
+#pragma unroll
+      for (int e = 4 * (s - 1); e < 4 * (s - 1) + 4; ++e) {
+        rv[e] = xr.get(e);
+        rsum += rv[e];
+        tb_pin(rv[e]);
+      }
+      tb_pin(rsum);
+    } else if constexpr (s == 3) {
+      rmean = group_sum_dpp<16>(rsum) * (1.0f / 128.0f);
+      tb_pin(rmean);
+    } else if constexpr (s == 4 || s == 5) {
+      if constexpr (s == 4) rsum = 0.f;
+#pragma unroll
+      for (int e = 4 * (s - 4); e < 4 * (s - 4) + 4; ++e) {
+        rv[e] -= rmean;
+        rsum += rv[e] * rv[e];
+        tb_pin(rv[e]);
+      }
+      tb_pin(rsum);
+    } else if constexpr (s == 6) {
+      rrstd = __builtin_amdgcn_rsqf(group_sum_dpp<16>(rsum) * (1.0f / 128.0f) + p.eps);
+      tb_pin(rrstd);
+    } else if constexpr (s >= 7 && s <= 10) {
+#pragma unroll
+      for (int e = 2 * (s - 7); e < 2 * (s - 7) + 2; ++e) {
+        rv[e] = silu_fast(rv[e] * rrstd * lg1[e] + lb1[e]);
+        tb_pin(rv[e]);
+      }
+    } else if constexpr (s == 11) {
+      u32x4 w;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) w[e] = f32_to_bf16_bits(rv[2 * e]) | (f32_to_bf16_bits(rv[2 * e + 1]) << 16);
+      *reinterpret_cast<u32x4*>(ring1 + (tn % 3) * TB_SLOT + row * TB_ROWP + row_lds) = w;
+    }
+  };
+
   // GEMM over the valid taps [KT0, 3) of a ring: acc[j] (j = 0, 1: pixel sub-tiles of 32) += W[kt] . ring[frame t-2+kt].
-  // Software pipeline: the two B-fragments of group g+2 are requested before the MFMAs of group g.
-  auto gemm = [&](auto kt0_c, auto wbase_c, const char* ring, int t, f32x16 (&acc)[2]) {
+  // Software pipeline: the two B-fragments of group g+2 are requested before the MFMAs of group g.  `job(slot)` is
+  // called after every MFMA of a full (KT0 = 0) GEMM: slots 0 .. 47.
+  auto gemm = [&](auto kt0_c, auto wbase_c, const char* ring, int t, f32x16 (&acc)[2], auto&& job) {
     constexpr int KT0 = decltype(kt0_c)::value, WB = decltype(wbase_c)::value;
     constexpr int G0 = KT0 * 8;
     const char* sp[3];
@@ -159,25 +270,32 @@ __global__ __launch_bounds__(256, 1) void tblock_ws128_kernel(const TBlockArgs p
     for (int j = 0; j < 2; ++j) xf[(G0 + 1) % 3][j] = *faddr(G0 + 1, j);
     tb_static_for<G0, 24>([&](auto gc) {
       constexpr int g = decltype(gc)::value;
-      if constexpr (g + 2 < 24) {
-#pragma unroll
-        for (int j = 0; j < 2; ++j) xf[(g + 2) % 3][j] = *faddr(g + 2, j);
-      }
-#pragma unroll
-      for (int j = 0; j < 2; ++j) tb_mfma<ACC_A>(wreg[WB + g], xf[g % 3][j], acc[j]);
-      __builtin_amdgcn_sched_barrier(0);
+      tb_static_for<0, 2>([&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+        tb_mfma<ACC_A>(wreg[WB + g], xf[g % 3][j], acc[j]);
+        if constexpr (g + 2 < 24) xf[(g + 2) % 3][j] = *faddr(g + 2, j);
+        if constexpr (KT0 == 0) job(std::integral_constant<int, 2 * g + j>{});
+        __builtin_amdgcn_sched_barrier(0);
+      });
     });
     asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");               // last MFMA -> first VALU reader of its accumulator
   };
-  auto gemm_taps = [&](auto wbase_c, const char* ring, int t, f32x16 (&acc)[2]) {
+  // a GEMM with its row job: the job rides in the MFMA shadows when all three taps are live, else it runs first
+  auto gemm_with_job = [&](auto wbase_c, const char* ring, int t, f32x16 (&acc)[2], bool have_job, auto&& job) {
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[j][r] = 0.0f;
+    auto nojob = [](auto) {};
     const int first = p.replicate ? 0 : max(0, 2 - t);                // uniform
-    if (first == 0) gemm(std::integral_constant<int, 0>{}, wbase_c, ring, t, acc);
-    else if (first == 1) gemm(std::integral_constant<int, 1>{}, wbase_c, ring, t, acc);
-    else gemm(std::integral_constant<int, 2>{}, wbase_c, ring, t, acc);
+    if (first == 0) {
+      if (have_job) gemm(std::integral_constant<int, 0>{}, wbase_c, ring, t, acc, job);
+      else gemm(std::integral_constant<int, 0>{}, wbase_c, ring, t, acc, nojob);
+    } else {
+      if (have_job) tb_static_for<0, 48>([&](auto sc) { job(sc); });
+      if (first == 1) gemm(std::integral_constant<int, 1>{}, wbase_c, ring, t, acc, nojob);
+      else gemm(std::integral_constant<int, 2>{}, wbase_c, ring, t, acc, nojob);
+    }
   };
   // accumulators (MFMA layout: lane = pixel 32j + lane%32, channels 32 wave + 8g + 4 (lane/32) + e) -> T, transposed
   auto acc_to_T = [&](f32x16 (&acc)[2]) {
@@ -208,81 +326,77 @@ __global__ __launch_bounds__(256, 1) void tblock_ws128_kernel(const TBlockArgs p
     for (int e = 0; e < 4; ++e) w[e] = f32_to_bf16_bits(o[2 * e]) | (f32_to_bf16_bits(o[2 * e + 1]) << 16);
     *reinterpret_cast<u32x4*>(ring + (t % 3) * TB_SLOT + row * TB_ROWP + row_lds) = w;
   };
+  auto load_rows = [&](Oct<bf16_t> (&dst)[4], long long elem_off) {
+    const bf16_t* src = p.x + elem_off + 8 * oct_j;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) dst[it].load(src + (long long)(row0 + 16 * it) * 128);
+  };
 
-  Oct<bf16_t> xr[4], xn[4];
-  {
-    const bf16_t* src = p.x + col_base(c_begin) + 8 * oct_j;
+  // ---- the walk: virtual steps v = (column, frame) in order; step v's phases:
+  //   A  GEMM1(v)  ||  OUT job of step v-1 (reads T = conv2(v-1))          barrier, acc -> T, barrier
+  //   B  rows of T + b1 -> LN2 + SiLU -> ring2[t]                          barrier
+  //   C  GEMM2(v)  ||  LN1 job of step v+1 (x rows prefetched in A)        acc -> T, barrier
+  const int nsteps = (c_end - c_begin) * p.T;
+  load_rows(xc, col_base(c_begin));
 #pragma unroll
-    for (int it = 0; it < 4; ++it) xr[it].load(src + (long long)(row0 + 16 * it) * 128);
+  for (int it = 0; it < 4; ++it) {
+    xp[it].w = xc[it].w;
+    xn[it].w = xc[it].w;
   }
-  for (int col = c_begin; col < c_end; ++col) {
-    const long long cb = col_base(col);
-    for (int t = 0; t < p.T; ++t) {
-      // ---- P0: LN1 + SiLU of x[t] -> ring1[t % 3] ----
 #pragma unroll
-      for (int it = 0; it < 4; ++it) {
-        float v[8], o[8];
+  for (int it = 0; it < 4; ++it) {                                    // LN1 of the very first step, on its own
+    float v[8], o[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = xr[it].get(e);
-        tb_row_norm<true>(v, lg1, lb1, p.eps, o);
-        ring_store(ring1, t, row0 + 16 * it, o);
-      }
-      // prefetch the rows of the next step (next frame of this column, or frame 0 of the next column)
-      {
-        const bool last_t = t + 1 == p.T;
-        const bool more = !last_t || col + 1 < c_end;                 // uniform
-        if (more) {
-          const bf16_t* src = p.x + (last_t ? col_base(col + 1) : cb + (long long)(t + 1) * frame_stride) + 8 * oct_j;
+    for (int e = 0; e < 8; ++e) v[e] = xc[it].get(e);
+    tb_row_norm<true>(v, lg1, lb1, p.eps, o);
+    ring_store(ring1, 0, row0 + 16 * it, o);
+  }
+  __syncthreads();
+  int col = c_begin, t = 0;
+  long long cb = col_base(col);
+  f32x16 acc[2];
+  for (int v = 0; v < nsteps; ++v) {
+    // next step's coordinates and its x rows (in flight during A and B)
+    const bool has_next = v + 1 < nsteps;                             // uniform
+    const int tn = (t + 1 < p.T) ? t + 1 : 0;
+    const int coln = (t + 1 < p.T) ? col : col + 1;
+    const long long cbn = (t + 1 < p.T) ? cb : (has_next ? col_base(coln) : cb);
+    if (has_next) load_rows(xn, cbn + (long long)tn * frame_stride);
+    // ---- A ----
+    gemm_with_job(std::integral_constant<int, 0>{}, ring1, t, acc, v > 0, [&](auto sc) { job_out(sc, xp); });
+    __syncthreads();                                                  // every wave is done with T (OUT job of v-1)
+    acc_to_T(acc);
+    __syncthreads();
+    // ---- B: rows of conv1 + b1 -> LN2 + SiLU -> ring2[t % 3] ----
 #pragma unroll
-          for (int it = 0; it < 4; ++it) xn[it].load(src + (long long)(row0 + 16 * it) * 128);
-        }
-      }
-      __syncthreads();                                                // (1) ring1[t] visible; T free
-      f32x16 acc[2];
-      gemm_taps(std::integral_constant<int, 0>{}, ring1, t, acc);
-      acc_to_T(acc);
-      __syncthreads();                                                // (2)
-      // ---- rows of conv1 + b1 -> LN2 + SiLU -> ring2[t % 3] ----
+    for (int it = 0; it < 4; ++it) {
+      float vv[8], o[8];
+      T_row(row0 + 16 * it, vv);
 #pragma unroll
-      for (int it = 0; it < 4; ++it) {
-        float v[8], o[8];
-        T_row(row0 + 16 * it, v);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] += bo1[e];
-        tb_row_norm<true>(v, lg2, lb2, p.eps, o);
-        ring_store(ring2, t, row0 + 16 * it, o);
-      }
-      __syncthreads();                                                // (3) ring2[t] visible; T free
-      gemm_taps(std::integral_constant<int, 24>{}, ring2, t, acc);
-      acc_to_T(acc);
-      __syncthreads();                                                // (4)
-      // ---- rows of conv2 + b2 + x[t] -> y[t]; LayerNorm_next -> n[t] ----
-      // The prefetched rows of the next step are "used" HERE, before this step's stores are issued: hipcc then waits
-      // for those loads now (issued a whole step ago: free) instead of at their first real use, where the just-issued
-      // stores are still pending -- with loads and stores mixed in flight it does not trust a counted vmcnt and drains
-      // everything, i.e. every step would wait out a store round trip (measured: SQ_WAIT_ANY 19 % of the wave cycles).
+      for (int e = 0; e < 8; ++e) vv[e] += bo1[e];
+      tb_row_norm<true>(vv, lg2, lb2, p.eps, o);
+      ring_store(ring2, t, row0 + 16 * it, o);
+    }
+    // the prefetched rows are "used" here, long after the OUT job's stores of phase A were issued: hipcc waits for
+    // them now (with loads and stores both pending it drains vmcnt entirely)
+    if (has_next) {
 #pragma unroll
       for (int it = 0; it < 4; ++it) asm volatile("" : "+v"(xn[it].w));
-      const long long ob = cb + (long long)t * frame_stride + 8 * oct_j;
+    }
+    __syncthreads();                                                  // ring2[t] visible; T free
+    // ---- C ----
+    gemm_with_job(std::integral_constant<int, 24>{}, ring2, t, acc, has_next, [&](auto sc) { job_ln1(sc, tn); });
+    acc_to_T(acc);
+    out_base = cb + (long long)t * frame_stride + 8 * oct_j;          // where step v's OUT job (next phase A) writes
+    __syncthreads();                                                  // T = conv2(v) complete; ring1[tn] visible
+    t = tn; col = coln; cb = cbn;
 #pragma unroll
-      for (int it = 0; it < 4; ++it) {
-        const int row = row0 + 16 * it;
-        float v[8];
-        T_row(row, v);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = xr[it].get(e) + (v[e] + bo2[e]);
-        if (p.keep_y) Oct<bf16_t>::store(p.y + ob + (long long)row * 128, v);
-        if (p.ln_next) {                                              // uniform
-          float o[8];
-          if (p.ln_next == 2) tb_row_norm<true>(v, lgn, lbn, p.eps, o);
-          else tb_row_norm<false>(v, lgn, lbn, p.eps, o);
-          Oct<bf16_t>::store(p.n_out + ob + (long long)row * 128, o);
-        }
-      }
-#pragma unroll
-      for (int it = 0; it < 4; ++it) xr[it] = xn[it];
+    for (int it = 0; it < 4; ++it) {                                  // rotate: this step's rows become the next OUT job's residual
+      xp[it].w = xc[it].w;
+      xc[it].w = xn[it].w;
     }
   }
+  tb_static_for<0, 48>([&](auto sc) { job_out(sc, xp); });            // OUT job of the last step
 #endif
 }
 
@@ -326,15 +440,18 @@ extern "C" int vt_temporal_block(const vt_tblock_desc* d, vt_stream stream_) {
   a.keep_y = d->keep_y ? 1 : 0;
   a.ln_next = d->ln_next_mode;
   a.eps = d->eps;
-  const int acc_a = env_int("VT_WS_ACC", 1) != 0 ? 1 : 0;   // accumulators in the accumulator (1) / architectural (0) half
-  const void* kern = acc_a ? reinterpret_cast<const void*>(&tblock_ws128_kernel<true>) : reinterpret_cast<const void*>(&tblock_ws128_kernel<false>);
+  // one instantiation per output shape: next norm none / LayerNorm / LayerNorm+SiLU, y kept or not
+  static const void* const kerns[5] = {
+      reinterpret_cast<const void*>(&tblock_ws128_kernel<0, true>), reinterpret_cast<const void*>(&tblock_ws128_kernel<1, true>),
+      reinterpret_cast<const void*>(&tblock_ws128_kernel<1, false>), reinterpret_cast<const void*>(&tblock_ws128_kernel<2, true>),
+      reinterpret_cast<const void*>(&tblock_ws128_kernel<2, false>)};
+  const void* kern = kerns[a.ln_next == 0 ? 0 : (a.ln_next == 1 ? (a.keep_y ? 1 : 2) : (a.keep_y ? 3 : 4))];
   static std::atomic<int> cus[kMaxDevices];
   int dev = 0;
   VT_CHECK_HIP(hipGetDevice(&dev));
   int ncu = (dev >= 0 && dev < kMaxDevices) ? cus[dev].load(std::memory_order_acquire) : 0;
   if (ncu == 0) {
-    VT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&tblock_ws128_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, TB_LDS));
-    VT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&tblock_ws128_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, TB_LDS));
+    for (int k = 0; k < 5; ++k) VT_CHECK_HIP(hipFuncSetAttribute(kerns[k], hipFuncAttributeMaxDynamicSharedMemorySize, TB_LDS));
     VT_CHECK_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
     if (ncu <= 0) ncu = 256;
     if (dev >= 0 && dev < kMaxDevices) cus[dev].store(ncu, std::memory_order_release);
