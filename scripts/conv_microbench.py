@@ -43,6 +43,8 @@ def main():
         cp = ops.pad_channels(cin)
         torch.manual_seed(0)
         x = torch.randn((B, T, H, W, cp), device="cuda", dtype=dtype)
+        if os.environ.get("MB_ZERO", "0") == "1":      # all-zero activations: same instructions, far fewer toggling bits (power / clock A/B)
+            x.zero_()
         w = (torch.randn((cout, taps * cp), device="cuda") / math.sqrt(taps * cin)).to(dtype)
         bias = torch.randn((cout,), device="cuda")
         To, Ho, Wo = geom.out_dims(T, H, W)
@@ -70,7 +72,8 @@ def main():
         yf = (y[0] if isinstance(y, tuple) else y).float()
         print(f"  {name:46s} {ms:8.3f} ms  {fl / ms / 1e9:8.1f} TFLOP/s   chk {yf.sum().item():+.6e} {yf.abs().sum().item():.6e}")
         del x, w, y, kw
-    print(f"  total {tot_ms:.2f} ms, {tot_fl / tot_ms / 1e9:.1f} TFLOP/s aggregate")
+    if tot_ms > 0:
+        print(f"  total {tot_ms:.2f} ms, {tot_fl / tot_ms / 1e9:.1f} TFLOP/s aggregate")
     # fused temporal residual block of the widest level (vt_temporal_block) vs its two K=384 convolutions above
     if dtype == torch.bfloat16 and (not only or "tblock" in only or "L0" in only):
         T, H, W, Cc = 20, 256, 256, 128

@@ -167,13 +167,21 @@ def time_avgpool3s2(x, tmode=L.VT_TPAD_ZERO, cache=None):
     return y.to(x.dtype)
 
 
-def time_lerp2x(x):
+def time_lerp2x(x, out=None, out_t0=0):
     y = F.interpolate(x.float().permute(0, 4, 1, 2, 3), scale_factor=[2.0, 1.0, 1.0], mode="trilinear")
-    return y.permute(0, 2, 3, 4, 1).to(x.dtype).contiguous()
+    y = y.permute(0, 2, 3, 4, 1).to(x.dtype).contiguous()
+    if out is None:
+        return y
+    out[:, out_t0:out_t0 + y.shape[1]] = y
+    return out
 
 
-def gather_frames(src, idx):
-    return src[:, list(idx)].contiguous()
+def gather_frames(src, idx, out=None, out_t0=0):
+    g = src[:, list(idx)].contiguous()
+    if out is None:
+        return g
+    out[:, out_t0:out_t0 + len(idx)] = g
+    return out
 
 
 def kl_sample(h, noise):
@@ -293,8 +301,8 @@ def ncthw_to_frames_u8(x, t0=0, n=None, out=None, w_off=0):
 
 
 def ncthw_copy_frames(src, dst, ts0, td0, n, clamp=False):
-    v = src[0, :, ts0:ts0 + n]
-    dst[0, :, td0:td0 + n] = v.clamp(-1, 1) if clamp else v
+    v = src[:, :, ts0:ts0 + n]
+    dst[:, :, td0:td0 + n] = v.clamp(-1, 1) if clamp else v
     return dst
 
 

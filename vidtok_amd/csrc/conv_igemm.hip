@@ -31,7 +31,8 @@
 //
 // Measured dead ends (kept out of the code): register-staged operand tiles
 // (ds_write_b128 pass: 627 vs 440 TFLOP/s aggregate), a 4-stage ring of 64-B rows (no gain), 256x128 tiles
-// with 8 or 4 waves (slower), 3-4 waves/SIMD with 64-B rows (slower), LayerNorm in the MFMA-layout epilogue
+// with 8 or 4 waves (slower), 256x256 on 4 waves with a 128x128 wave tile and all 512 registers (7-9 % slower: round 2),
+// 3-4 waves/SIMD with 64-B rows (slower), LayerNorm in the MFMA-layout epilogue
 // (+1.6 ms per conv), a kw-innermost K walk (less fabric traffic, more time), a persistent variant with a deferred
 // epilogue (conv_stream.hip in the git history: +3 % only, and its counted-vmcnt drain was not race-free in fp32).
 #include <atomic>

@@ -135,35 +135,126 @@ __global__ __launch_bounds__(kBlock) void fsq_aux_tables_kernel(const float* __r
   if ((threadIdx.x & 63) == 0) atomicAdd(accum + 2, commit);
 }
 
-// stage 2: thread j owns code j; loops over all tokens accumulating the batch-mean probability
-// of its code and its share of the per-token entropies (with the reference's log clamp 1e-5,
-// regularizers.py:40-45).
-__global__ __launch_bounds__(kBlock) void fsq_aux_entropy_kernel(const float* __restrict__ tables, FsqConsts k,
-                                                                 long long ntok, int J, float* __restrict__ accum,
-                                                                 float* __restrict__ avg_out) {
-  const int j = blockIdx.x * kBlock + threadIdx.x;
-  float ent = 0.f, cbe = 0.f;
-  if (j < J) {
-    int off[kMaxD];
-    for (int d = 0; d < k.D; ++d) off[d] = d * kMaxL + (j / k.basis[d]) % k.levels[d];
-    float avg = 0.f;
-    for (long long t = 0; t < ntok; ++t) {
-      const float* tb = tables + t * k.D * kMaxL;
-      float p = 1.0f;
-      for (int d = 0; d < k.D; ++d) p *= tb[off[d]];
-      avg += p;
-      ent -= p * logf(fmaxf(p, 1e-5f));
+// stage 2: the product-codebook probabilities p[t][j] = prod_d table[t][d][digit_d(j)] for all tokens x all codes
+// (20 480 x 32 768 = 671 M pairs for BASELINE configs[2]) -- needed pair by pair because of the reference's log clamp
+// (regularizers.py:40-45).  The code index splits into LOW digits (dims < dl, owned by threads: JL = prod <= 512) and
+// HIGH digits (looped in chunks of kHiChunk): a thread keeps base = prod of its low-digit table entries per token and
+// multiplies by the high-digit products staged once per token in LDS, so a pair costs one multiply, one add and the
+// entropy term.  A workgroup owns (token tile, high chunk); the per-tile sums of p go to part[tile][j] (no atomics:
+// deterministic), the entropy partials to one atomic per wave.  (The first version walked all tokens per code from
+// L2: 20 ms per call at B = 4, a quarter of an FSQ forward.)
+constexpr int kTokTiles = 64;     // token tiles (rows of `part`)
+constexpr int kHiChunk = 16;      // high-digit combinations per workgroup
+constexpr int kTokSub = 32;       // tokens staged in LDS at a time
+
+struct FsqSplit {
+  int dl;        // dims [0, dl) are thread digits, [dl, D) loop digits
+  int JL, JH;
+};
+inline FsqSplit fsq_split(const FsqConsts& k) {
+  FsqSplit s;
+  s.dl = 0;
+  s.JL = 1;
+  while (s.dl < k.D - 1 && s.JL * k.levels[s.dl] <= 512) s.JL *= k.levels[s.dl++];
+  if (s.dl == 0) s.JL = k.levels[s.dl++];      // a single huge first level still becomes the thread digit
+  s.JH = 1;
+  for (int d = s.dl; d < k.D; ++d) s.JH *= k.levels[d];
+  return s;
+}
+
+__global__ __launch_bounds__(kBlock) void fsq_aux_pairs_kernel(const float* __restrict__ tables, FsqConsts k, FsqSplit sp,
+                                                               long long ntok, long long tile_tokens, int J,
+                                                               float* __restrict__ part, float* __restrict__ accum) {
+  __shared__ float tab[kTokSub][kMaxD][kMaxL];
+  __shared__ float hi[kTokSub][kHiChunk];
+  const int tile = blockIdx.x;
+  const int hc0 = blockIdx.y * kHiChunk;
+  const long long t_begin = (long long)tile * tile_tokens;
+  const long long t_end = min(t_begin + tile_tokens, ntok);
+  constexpr int kLowPerThread = 2;              // JL <= 512 = 2 x kBlock
+  int lo_off[kLowPerThread][kMaxD];
+  bool lo_ok[kLowPerThread];
+#pragma unroll
+  for (int u = 0; u < kLowPerThread; ++u) {
+    int jl = threadIdx.x + u * kBlock;
+    lo_ok[u] = jl < sp.JL;
+#pragma unroll
+    for (int d = 0; d < kMaxD; ++d) {          // static indices: the array stays in registers
+      const int L = d < sp.dl ? k.levels[d] : 1;
+      lo_off[u][d] = lo_ok[u] ? jl % L : 0;
+      jl /= L;
     }
-    avg /= (float)ntok;
-    if (avg_out) avg_out[j] = avg;   // batch-mean code distribution: what the reference all-reduces across ranks
-    cbe = -avg * logf(fmaxf(avg, 1e-5f));
+  }
+  float acc[kLowPerThread][kHiChunk];
+#pragma unroll
+  for (int u = 0; u < kLowPerThread; ++u)
+#pragma unroll
+    for (int h = 0; h < kHiChunk; ++h) acc[u][h] = 0.f;
+  float ent = 0.f;
+  for (long long t0 = t_begin; t0 < t_end; t0 += kTokSub) {
+    const int nt = (int)min((long long)kTokSub, t_end - t0);
+    __syncthreads();
+    for (int i = threadIdx.x; i < nt * k.D * kMaxL; i += kBlock) {
+      const int tt = i / (k.D * kMaxL), r = i - tt * (k.D * kMaxL);
+      tab[tt][r / kMaxL][r % kMaxL] = tables[(t0 + tt) * k.D * kMaxL + r];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < nt * kHiChunk; i += kBlock) {
+      const int tt = i / kHiChunk, h = i - tt * kHiChunk;
+      int jh = hc0 + h;
+      float pr = jh < sp.JH ? 1.0f : 0.0f;
+      for (int d = sp.dl; d < k.D; ++d) {
+        pr *= tab[tt][d][jh % k.levels[d]];
+        jh /= k.levels[d];
+      }
+      hi[tt][h] = pr;
+    }
+    __syncthreads();
+    for (int tt = 0; tt < nt; ++tt) {
+#pragma unroll
+      for (int u = 0; u < kLowPerThread; ++u) {
+        if (!lo_ok[u]) continue;
+        float base = 1.0f;
+#pragma unroll
+        for (int d = 0; d < kMaxD; ++d)
+          if (d < sp.dl) base *= tab[tt][d][lo_off[u][d]];
+#pragma unroll
+        for (int h = 0; h < kHiChunk; ++h) {
+          const float pv = base * hi[tt][h];
+          acc[u][h] += pv;
+          ent -= pv * logf(fmaxf(pv, 1e-5f));
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < kLowPerThread; ++u) {
+    if (!lo_ok[u]) continue;
+    const int jl = threadIdx.x + u * kBlock;
+#pragma unroll
+    for (int h = 0; h < kHiChunk; ++h) {
+      const int jh = hc0 + h;
+      if (jh < sp.JH) part[(long long)tile * J + (long long)jh * sp.JL + jl] = acc[u][h];
+    }
   }
   ent = wave_sum(ent, 64);
-  cbe = wave_sum(cbe, 64);
-  if ((threadIdx.x & 63) == 0) {
-    atomicAdd(accum + 0, ent);
-    atomicAdd(accum + 1, cbe);
+  if ((threadIdx.x & 63) == 0) atomicAdd(accum + 0, ent);
+}
+
+// stage 3: avg[j] = sum over token tiles / ntok, its entropy term, optional copy out
+__global__ __launch_bounds__(kBlock) void fsq_aux_reduce_kernel(const float* __restrict__ part, int ntiles, int J, long long ntok,
+                                                                float* __restrict__ accum, float* __restrict__ avg_out) {
+  const int j = blockIdx.x * kBlock + threadIdx.x;
+  float cbe = 0.f;
+  if (j < J) {
+    float a = 0.f;
+    for (int t = 0; t < ntiles; ++t) a += part[(long long)t * J + j];
+    a /= (float)ntok;
+    if (avg_out) avg_out[j] = a;   // batch-mean code distribution: what the reference all-reduces across ranks
+    cbe = -a * logf(fmaxf(a, 1e-5f));
   }
+  cbe = wave_sum(cbe, 64);
+  if ((threadIdx.x & 63) == 0) atomicAdd(accum + 1, cbe);
 }
 
 // entropy(avg) with the reference's log clamp (regularizers.py:40-45) of a J-entry distribution: the codebook entropy
@@ -301,8 +392,9 @@ extern "C" int vt_fsq_indices_to_codes(const int32_t* indices, float* z, const i
 }
 
 extern "C" int64_t vt_fsq_aux_work_floats(const int32_t* levels_host, int32_t D, int32_t B, int64_t S) {
-  (void)levels_host;
-  return (int64_t)B * S * D * kMaxL + 4;
+  int64_t J = 1;
+  for (int d = 0; levels_host && d < D; ++d) J *= levels_host[d];
+  return (int64_t)B * S * D * kMaxL + 4 + (int64_t)kTokTiles * J;   // per-token tables, accumulators, per-tile code sums
 }
 
 extern "C" int vt_fsq_aux_stats(const float* h, const int32_t* levels_host, int32_t D, int32_t B, int64_t S,
@@ -335,8 +427,16 @@ extern "C" int vt_fsq_aux_stats_avg(const float* h, const int32_t* levels_host, 
   hipLaunchKernelGGL(fsq_aux_tables_kernel, dim3(grid_for(ntok)), dim3(kBlock), 0, stream, h, k, B, (long long)S,
                      inv_temperature, tables, accum);
   VT_CHECK_LAUNCH();
-  hipLaunchKernelGGL(fsq_aux_entropy_kernel, dim3((unsigned)((J + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream,
-                     (const float*)tables, k, ntok, (int)J, accum, avg_out);
+  float* part = accum + 4;
+  const FsqSplit sp = fsq_split(k);
+  VT_CHECK_ARG(sp.JL <= 2 * kBlock, "vt_fsq_aux_stats: first level %d too large", levels_host[0]);
+  const long long tile_tokens = (ntok + kTokTiles - 1) / kTokTiles;
+  const int ntiles = (int)((ntok + tile_tokens - 1) / tile_tokens);
+  hipLaunchKernelGGL(fsq_aux_pairs_kernel, dim3((unsigned)ntiles, (unsigned)((sp.JH + kHiChunk - 1) / kHiChunk)), dim3(kBlock), 0, stream,
+                     (const float*)tables, k, sp, ntok, tile_tokens, (int)J, part, accum);
+  VT_CHECK_LAUNCH();
+  hipLaunchKernelGGL(fsq_aux_reduce_kernel, dim3((unsigned)((J + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, (const float*)part,
+                     ntiles, (int)J, ntok, accum, avg_out);
   VT_CHECK_LAUNCH();
   hipLaunchKernelGGL(fsq_aux_finish_kernel, dim3(1), dim3(1), 0, stream, (const float*)accum, ntok,
                      ntok * (long long)D, out3);

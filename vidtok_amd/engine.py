@@ -210,23 +210,49 @@ class AutoencodingEngineV11(AutoencodingEngine):
             return z, reg_log
         return z
 
+    def _chunk_of(self, x, start, end):
+        """frames [start, end) of an NCTHW fp32 tensor as a contiguous tensor (one vt_ncthw_copy_frames launch)"""
+        if not x.is_cuda:
+            return x[:, :, start:end].contiguous()
+        x = x.contiguous().float()
+        c = torch.empty((x.shape[0], x.shape[1], end - start) + tuple(x.shape[3:]), dtype=torch.float32, device=x.device)
+        return ops.ncthw_copy_frames(x, c, start, 0, end - start)
+
     def tile_encode(self, x: Any) -> Any:
-        result_z, result_log = [], []
-        for idx, (start, end) in enumerate(self.build_chunk_start_end(x.shape[2])):
-            self._set_first_chunk(idx == 0)
-            chunk_z = self.encoder(x[:, :, start:end, :, :])
+        """chunks are encoded in order (module caches carry the causal state); their latents land in one preallocated
+        tensor -- no list + torch.cat (autoencoder_v1_1.py:244-264)"""
+        chunks = self.build_chunk_start_end(x.shape[2])
+        z, idx, logs, done = None, None, [], 0
+        for i, (start, end) in enumerate(chunks):
+            self._set_first_chunk(i == 0)
+            chunk_z = self.encoder(self._chunk_of(x, start, end))
             chunk_z, chunk_log = self.regularization(chunk_z, n_steps=self.global_step // 2)
-            result_z.append(chunk_z)
-            result_log.append(chunk_log)
-        z = torch.cat(result_z, dim=2)
-        if "kl_loss" in result_log[0]:
-            return z, {"kl_loss": torch.mean(torch.stack([d["kl_loss"] for d in result_log]))}
-        return z, {"aux_loss": torch.mean(torch.stack([d["aux_loss"] for d in result_log])),
-                   "indices": torch.cat([d["indices"] for d in result_log], dim=1)}
+            if z is None:      # a chunk of n frames is front-padded to a multiple of f: ceil(n / f) latent frames
+                f = self.encoder.time_downsample_factor
+                tz = sum(-(-(e - s) // f) for s, e in chunks)
+                z = torch.empty((chunk_z.shape[0], chunk_z.shape[1], tz) + tuple(chunk_z.shape[3:]), dtype=chunk_z.dtype,
+                                device=chunk_z.device)
+                if "indices" in chunk_log:
+                    idx = torch.empty((chunk_z.shape[0], tz) + tuple(chunk_z.shape[3:]), dtype=torch.int32, device=chunk_z.device)
+            n = chunk_z.shape[2]
+            if chunk_z.is_cuda:
+                ops.ncthw_copy_frames(chunk_z.contiguous(), z, 0, done, n)
+                if idx is not None:
+                    ops.gather_frames(chunk_log["indices"].contiguous(), list(range(n)), out=idx, out_t0=done)
+            else:
+                z[:, :, done:done + n] = chunk_z
+                if idx is not None:
+                    idx[:, done:done + n] = chunk_log["indices"]
+            done += n
+            logs.append(chunk_log)
+        assert done == z.shape[2], (done, z.shape)
+        if "kl_loss" in logs[0]:
+            return z, {"kl_loss": torch.mean(torch.stack([d["kl_loss"] for d in logs]))}
+        return z, {"aux_loss": torch.mean(torch.stack([d["aux_loss"] for d in logs])), "indices": idx}
 
     def tile_indices_to_latent(self, token_indices: torch.Tensor) -> torch.Tensor:
-        chunks = self.build_chunk_start_end(token_indices.shape[1], decoder_mode=True)
-        return torch.cat([self.indices_to_latent(token_indices[:, s:e].contiguous()) for s, e in chunks], dim=2)
+        # per-position look-up: chunking changes nothing in the result (the reference chunks to bound memory)
+        return self.indices_to_latent(token_indices.contiguous())
 
     @torch.no_grad()
     def decode(self, z: Any, decode_from_indices: bool = False) -> torch.Tensor:
@@ -256,19 +282,29 @@ class AutoencodingEngineV11(AutoencodingEngine):
             self._set_cache_offset([d.up_temporal[1].upsample, d.up_temporal[0], d.conv_out], 8)
 
     def tile_decode(self, z: Any) -> torch.Tensor:
+        """chunks decoded in order, each with one look-ahead latent frame when `use_overlap` (its f trailing output
+        frames are dropped); outputs land in one preallocated tensor (autoencoder_v1_1.py:302-331)"""
         num_frames = z.shape[2]
         f = self.encoder.time_downsample_factor
         if self.use_overlap:
             self._overlap_offsets()
-        result = []
-        for idx, (start, end) in enumerate(self.build_chunk_start_end(num_frames, decoder_mode=True)):
+        chunks = self.build_chunk_start_end(num_frames, decoder_mode=True)
+        out, done = None, 0
+        for idx, (start, end) in enumerate(chunks):
             self._set_first_chunk(idx == 0)
             look = self.use_overlap and end + 1 <= num_frames
-            chunk = self.decoder(z[:, :, start:end + 1] if look else z[:, :, start:end])
-            if look:
-                chunk = chunk[:, :, :-f]
-            result.append(chunk)
-        return torch.cat(result, dim=2)
+            chunk = self.decoder(self._chunk_of(z, start, end + 1 if look else end))
+            n = chunk.shape[2] - (f if look else 0)
+            if out is None:   # first chunk (1 latent frame) yields 1 frame, every other latent frame f frames
+                total = n + sum(f * (e - s) for s, e in chunks[1:])
+                out = torch.empty((chunk.shape[0], chunk.shape[1], total) + tuple(chunk.shape[3:]), dtype=chunk.dtype, device=chunk.device)
+            if chunk.is_cuda:
+                ops.ncthw_copy_frames(chunk.contiguous(), out, 0, done, n)
+            else:
+                out[:, :, done:done + n] = chunk[:, :, :n]
+            done += n
+        assert done == out.shape[2], (done, out.shape)
+        return out
 
     @torch.no_grad()
     def forward(self, x: Any) -> Tuple[torch.Tensor, torch.Tensor, dict]:

@@ -165,15 +165,12 @@ class _CausalState:
         if not src_c:
             new = ops.gather_frames(x, [i for _, i in src_x])
         else:
-            parts = {}
-            got_c = ops.gather_frames(self.causal_cache, [i for _, i in src_c])
-            for n, (j, _) in enumerate(src_c):
-                parts[j] = got_c[:, n:n + 1]
+            # slots taken from the old cache come first (q grows with j), the ones from x after them: two gathers into
+            # one preallocated tensor, no concatenation
+            new = torch.empty((x.shape[0], P) + tuple(x.shape[2:]), dtype=x.dtype, device=x.device)
+            ops.gather_frames(self.causal_cache, [i for _, i in src_c], out=new, out_t0=src_c[0][0])
             if src_x:
-                got_x = ops.gather_frames(x, [i for _, i in src_x])
-                for n, (j, _) in enumerate(src_x):
-                    parts[j] = got_x[:, n:n + 1]
-            new = torch.cat([parts[j] for j in range(P)], dim=1).contiguous()
+                ops.gather_frames(x, [i for _, i in src_x], out=new, out_t0=src_x[0][0])
         self.causal_cache = new
 
 
@@ -339,17 +336,21 @@ class TimeUpsampleResCausal2x(nn.Module):
         if not self.enable_cached:
             return ops.gather_frames(x, [t // 2 for t in range(2 * T)])
         if not self.is_first_chunk:
-            xc = torch.cat([self.causal_cache, x], dim=1).contiguous()
-            Tc = xc.shape[1]
+            nc = self.causal_cache.shape[1]
+            Tc = nc + T
+            xc = torch.empty((x.shape[0], Tc) + tuple(x.shape[2:]), dtype=x.dtype, device=x.device)   # [cache | x]
+            ops.gather_frames(self.causal_cache, list(range(nc)), out=xc, out_t0=0)
+            ops.gather_frames(x, list(range(T)), out=xc, out_t0=nc)
             self.causal_cache = ops.gather_frames(xc, list(range(max(0, Tc - 2 * n), Tc - n)))
             up = ops.time_lerp2x(xc)
             return ops.gather_frames(up, list(range(2 * n, 2 * Tc)))
         self.causal_cache = ops.gather_frames(x, list(range(max(0, T - n), T)))
-        head = ops.time_lerp2x(ops.gather_frames(x, list(range(0, min(n, T)))))
+        hn = min(n, T)
+        up = torch.empty((x.shape[0], 2 * T) + tuple(x.shape[2:]), dtype=x.dtype, device=x.device)
+        ops.time_lerp2x(ops.gather_frames(x, list(range(0, hn))), out=up, out_t0=0)              # head: its own interpolation
         if T > n:
-            tail = ops.time_lerp2x(ops.gather_frames(x, list(range(n, T))))
-            return torch.cat([head, tail], dim=1).contiguous()
-        return head
+            ops.time_lerp2x(ops.gather_frames(x, list(range(n, T))), out=up, out_t0=2 * hn)    # tail
+        return up
 
     def run(self, x, dt, next_norm=None):
         x = plain(x)

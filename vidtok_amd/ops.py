@@ -345,31 +345,48 @@ def time_avgpool3s2(x, tmode=L.VT_TPAD_ZERO, cache=None):
     return y
 
 
-def time_lerp2x(x):
+def time_lerp2x(x, out=None, out_t0=0):
+    """trilinear x2 along T (align_corners=False) of frames x [B, Ti, H, W, C]; `out` [B, Td, H, W, C] receives the 2 Ti
+    frames at out_t0 (one launch per clip of the batch then: the kernel's output is contiguous per clip)."""
     lib = L.load()
     _chk(x, "lerp.x")
     B, Ti, H, W, Cc = x.shape
-    y = torch.empty((B, 2 * Ti, H, W, Cc), dtype=x.dtype, device=x.device)
-    L.check(lib.vt_time_lerp2x(_ptr(x), _ptr(y), _DT[x.dtype], B, Ti, H * W * Cc, _stream()), "vt_time_lerp2x")
-    return y
+    if out is None:
+        y = torch.empty((B, 2 * Ti, H, W, Cc), dtype=x.dtype, device=x.device)
+        L.check(lib.vt_time_lerp2x(_ptr(x), _ptr(y), _DT[x.dtype], B, Ti, H * W * Cc, _stream()), "vt_time_lerp2x")
+        return y
+    assert out.is_contiguous() and out.dtype == x.dtype and out.shape[0] == B and tuple(out.shape[2:]) == (H, W, Cc)
+    assert 0 <= out_t0 and out_t0 + 2 * Ti <= out.shape[1]
+    fr = H * W * Cc
+    for b in range(B):
+        xp = C.c_void_p(x.data_ptr() + b * Ti * fr * x.element_size())
+        yp = C.c_void_p(out.data_ptr() + (b * out.shape[1] + out_t0) * fr * out.element_size())
+        L.check(lib.vt_time_lerp2x(xp, yp, _DT[x.dtype], 1, Ti, fr, _stream()), "vt_time_lerp2x")
+    return out
 
 
-def gather_frames(src, idx):
-    """dst[:, j] = src[:, idx[j]] along dim 1 of an NDHWC tensor (v1.1 cache maintenance)."""
+def gather_frames(src, idx, out=None, out_t0=0):
+    """dst[:, out_t0 + j] = src[:, idx[j]] along dim 1 of an NDHWC tensor (or any [B, T, ...] tensor: frames are copied
+    as bytes).  v1.1 cache maintenance and chunk assembly; `out` [B, Td, ...] is filled in place."""
     lib = L.load()
     _chk(src, "gather.src")
     B, Ts = src.shape[:2]
     n = len(idx)
     assert n >= 1 and all(0 <= i < Ts for i in idx), (idx, Ts)
     frame = src[0, 0].numel()
-    dst = torch.empty((B, n) + tuple(src.shape[2:]), dtype=src.dtype, device=src.device)
+    if out is None:
+        out = torch.empty((B, n) + tuple(src.shape[2:]), dtype=src.dtype, device=src.device)
+        out_t0 = 0
+    assert out.is_contiguous() and out.dtype == src.dtype and out.shape[0] == B and tuple(out.shape[2:]) == tuple(src.shape[2:])
+    Td = out.shape[1]
+    assert 0 <= out_t0 and out_t0 + n <= Td
     for j0 in range(0, n, 128):                       # the C-ABI takes up to 128 frame indices per call
         part = list(idx[j0:j0 + 128])
         arr = (C.c_int32 * len(part))(*part)
-        dptr = C.c_void_p(dst.data_ptr() + j0 * frame * dst.element_size())
-        L.check(lib.vt_gather_frames(_ptr(src), dptr, src.element_size(), B, frame, Ts * frame, n * frame, arr,
+        dptr = C.c_void_p(out.data_ptr() + (out_t0 + j0) * frame * out.element_size())
+        L.check(lib.vt_gather_frames(_ptr(src), dptr, src.element_size(), B, frame, Ts * frame, Td * frame, arr,
                                      len(part), _stream()), "vt_gather_frames")
-    return dst
+    return out
 
 
 def _levels_arr(levels):
@@ -524,11 +541,12 @@ def ncthw_to_frames_u8(x, t0=0, n=None, out=None, w_off=0):
 
 
 def ncthw_copy_frames(src, dst, ts0, td0, n, clamp=False):
-    """dst[0, :, td0:td0+n] = src[0, :, ts0:ts0+n] (optionally clamped to [-1, 1]) for fp32 [1, C, T, H, W] tensors"""
+    """dst[:, :, td0:td0+n] = src[:, :, ts0:ts0+n] (optionally clamped to [-1, 1]) for fp32 [B, C, T, H, W] tensors of equal
+    B and C (the (b, c) planes are the kernel's "channels")"""
     lib = L.load()
     _chk(src, "src"); _chk(dst, "dst")
-    assert src.dtype == torch.float32 and dst.dtype == torch.float32 and src.shape[0] == 1 and dst.shape[0] == 1
-    assert src.shape[1] == dst.shape[1] and tuple(src.shape[3:]) == tuple(dst.shape[3:])
-    L.check(lib.vt_ncthw_copy_frames(_ptr(src), _ptr(dst), src.shape[1], src.shape[2], dst.shape[2], ts0, td0, n,
+    assert src.dtype == torch.float32 and dst.dtype == torch.float32 and src.dim() == 5 and dst.dim() == 5
+    assert tuple(src.shape[:2]) == tuple(dst.shape[:2]) and tuple(src.shape[3:]) == tuple(dst.shape[3:])
+    L.check(lib.vt_ncthw_copy_frames(_ptr(src), _ptr(dst), src.shape[0] * src.shape[1], src.shape[2], dst.shape[2], ts0, td0, n,
                                      src.shape[3] * src.shape[4], int(bool(clamp)), _stream()), "vt_ncthw_copy_frames")
     return dst
