@@ -389,6 +389,9 @@ def test_time_lerp2x(dtype, Ti):
     y = ops.time_lerp2x(x)
     yr = R.time_lerp2x(x.cpu())
     assert y.shape == yr.shape and rel_err(y, yr) < (1e-6 if dtype == torch.float32 else 8e-3)
+    out = torch.zeros((2, 2 * Ti + 3, 4, 4, 128), dtype=dtype, device=DEV)                  # in place at a frame offset
+    ops.time_lerp2x(x, out=out, out_t0=2)
+    assert torch.equal(out[:, 2:2 + 2 * Ti], y) and float(out[:, :2].float().abs().max()) == 0
 
 
 def test_gather_frames():
@@ -397,6 +400,16 @@ def test_gather_frames():
     assert torch.equal(ops.gather_frames(x, idx), x[:, idx])
     xf = _act(1, 3, 2, 2, 8, torch.float32, 2)
     assert torch.equal(ops.gather_frames(xf, [2]), xf[:, 2:3])
+    # into a preallocated destination at a frame offset (v1.1 cache / chunk assembly: no torch.cat)
+    out = torch.full((2, 9, 4, 4, 128), 3.0, dtype=torch.bfloat16, device=DEV)
+    ops.gather_frames(x, [1, 4], out=out, out_t0=3)
+    ops.gather_frames(x, [0], out=out, out_t0=8)
+    assert torch.equal(out[:, 3:5], x[:, [1, 4]]) and torch.equal(out[:, 8:9], x[:, 0:1])
+    assert float(out[:, :3].float().min()) == 3.0 and float(out[:, 5:8].float().max()) == 3.0
+    ii = torch.arange(2 * 3 * 5, dtype=torch.int32, device=DEV).reshape(2, 3, 5)          # any [B, T, ...] tensor: bytes
+    oi = torch.zeros((2, 7, 5), dtype=torch.int32, device=DEV)
+    ops.gather_frames(ii, [0, 1, 2], out=oi, out_t0=4)
+    assert torch.equal(oi[:, 4:7], ii) and int(oi[:, :4].abs().max()) == 0
 
 
 @pytest.mark.parametrize("with_noise", [True, False])
