@@ -24,8 +24,9 @@ Launch: `python bench.py --gpus N` spawns its N ranks itself (re-executes under 
               hipGraph that contains nothing else, bracketed by HIP events on the launch stream -- no
               per-launch event overhead, so it is <= ms_per_step by construction; the rocprofv3
               --kernel-trace average of the same command is committed under profiles/.  peak = dense MFMA
-              peak of the dtype; traffic = HBM-side bytes per launch from the committed rocprofv3 PMC
-              pass of this command (profiles/; counters cannot be read inside an un-profiled run)
+              peak of the dtype; traffic = HBM-side bytes per launch, measured by two rocprofv3 PMC passes
+              (FETCH_SIZE x2 + WRITE_SIZE) over a child run of this command (counters cannot be read inside
+              an un-profiled process); falls back to the committed pass under profiles/
   cpu_baseline  the CPU oracle (port of the reference, oracle/vidtok_oracle.py) timed on this host's
               cores on a bounded sample of the same workload; a baseline, not a target
 """
@@ -103,6 +104,47 @@ def cpu_baseline():
                       f"{cores} host threads ({CONFIG_1GPU})"}
 
 
+MFMA_KERNELS = ("conv_igemm", "conv3x3_ws128", "tblock_ws128")
+
+
+def measure_traffic(dtype, batch, timeout_s=200):
+    """HBM-side bytes per MFMA-kernel launch, measured NOW: two rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE cannot
+    share one; counters only with --kernel-trace) over a child run of this file that does three eager steps and
+    nothing else.  FETCH_SIZE is doubled (gfx950 reports half the bytes of wide streaming reads, MI355X_MICROARCH.md
+    section HBM); both are KiB.  Returns (bytes_per_launch, note) or (None, why)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+
+    if shutil.which("rocprofv3") is None:
+        return None, "rocprofv3 not on PATH"
+    out = tempfile.mkdtemp(prefix="vt_pmc_", dir="/tmp")
+    vals = {}
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            cmd = ["rocprofv3", "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", os.path.join(out, counter), "-o", "p",
+                   "--", sys.executable, os.path.abspath(__file__), "--pmc-child", "--dtype", dtype, "--batch", str(batch)]
+            env = dict(os.environ, TMPDIR="/tmp")
+            for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+                env.pop(k, None)
+            r = subprocess.run(cmd, cwd="/tmp", env=env, timeout=timeout_s, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+            v = []
+            for f in glob.glob(os.path.join(out, counter, "**", "*counter_collection.csv"), recursive=True):
+                for row in csv.DictReader(open(f)):
+                    if row["Counter_Name"] == counter and any(t in row["Kernel_Name"] for t in MFMA_KERNELS):
+                        v.append(float(row["Counter_Value"]))
+            if not v:
+                return None, f"no {counter} samples (rocprofv3 rc={r.returncode})"
+            vals[counter] = sum(v) / len(v)
+        return (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0, "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this run"
+    except Exception as e:  # a profiler problem must not cost the bench line
+        return None, f"{type(e).__name__}: {e}"
+    finally:
+        shutil.rmtree(out, ignore_errors=True)
+
+
 def spawn_ranks(n):
     """`python bench.py --gpus N` outside a launcher: re-execute under torch.distributed.run, one rank per GPU."""
     import socket
@@ -130,6 +172,9 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--breakdown", action="store_true", help="print the per-layer-shape conv timeline to stderr")
+    ap.add_argument("--traffic", choices=["pmc", "profile", "none"], default="pmc",
+                    help="roofline.traffic: measure now with two rocprofv3 PMC passes (default, N=1 only), quote profiles/, or null")
+    ap.add_argument("--pmc-child", action="store_true", help="internal: three eager steps for the PMC passes, no output")
     ap.add_argument("--selftest-spawn", action="store_true",
                     help="CPU/gloo check of the N-rank launch path only (no GPU work): prints the world size reached")
     ap.add_argument("--config", default=None, help="override the workload's YAML (default: BASELINE configs[1] / [3])")
@@ -189,6 +234,11 @@ def main():
     def step():
         return model(x)
 
+    if args.pmc_child:           # the profiler's subject: a few eager steps (every kernel of the path), nothing else
+        for _ in range(3):
+            step()
+        torch.cuda.synchronize()
+        return
     # launch mode: the engine's own per-shape hipGraph cache (vidtok_amd/graphs.py: encoder and decoder launch
     # sequences captured on their second call, replayed afterwards); --no-graph launches every kernel eagerly
     model.enable_graphs(not args.no_graph)
@@ -259,17 +309,22 @@ def main():
         # unit over kernel time -- is an effective rate; the executed rate is reported next to it
         executed = sum(2.0 * M * N * K for (M, N, K) in tl)
         peak = PEAK_TFLOPS[args.dtype]
-        # HBM-side bytes per launch come from rocprofv3 PMC passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE,
-        # scripts/pmc_bench.sh + scripts/pmc_traffic.py); counters cannot be read inside a normal run, so the
-        # figure of the committed pass for this dtype is quoted (null when there is none)
-        traffic = None
-        for rnd in ("r02", "r01"):
-            tpath = os.path.join(ROOT, "profiles", f"{rnd}_conv_traffic_pmc{'' if args.dtype == 'bf16' else '_' + args.dtype}.json")
-            if os.path.exists(tpath) and B == 4 and world == 1:
-                traffic = round(json.load(open(tpath))["traffic_bytes_per_launch"])
-                break
+        # HBM-side bytes per launch: PMC counters cannot be read inside an un-profiled process, so (N = 1) two
+        # rocprofv3 passes over a child run of this command measure them now; the committed pass of profiles/ is the
+        # fallback (and what --traffic profile quotes)
+        traffic, traffic_src = None, "not measured"
+        if args.traffic == "pmc" and world == 1:
+            t, traffic_src = measure_traffic(args.dtype, B)
+            traffic = None if t is None else round(t)
+        if traffic is None and args.traffic != "none":
+            for rnd in ("r02", "r01"):
+                tpath = os.path.join(ROOT, "profiles", f"{rnd}_conv_traffic_pmc{'' if args.dtype == 'bf16' else '_' + args.dtype}.json")
+                if os.path.exists(tpath) and B == 4 and world == 1:
+                    traffic = round(json.load(open(tpath))["traffic_bytes_per_launch"])
+                    traffic_src = f"profiles/{os.path.basename(tpath)} (committed pass; live measurement: {traffic_src})"
+                    break
         roof = {"bound": "mfma", "kernel": "conv_igemm_glds_kernel + conv3x3_ws128_kernel + tblock_ws128_kernel", "achieved": round(achieved, 2), "peak": peak,
-                "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic,
+                "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_source": traffic_src,
                 "launches_per_step": len(tl), "kernel_ms_per_step": round(conv_ms, 3),
                 "avg_launch_ms": round(conv_ms / max(1, len(tl)), 4), "algorithmic_tflop_per_step": round(flops / 1e12, 3),
                 "executed_tflop_per_step": round(executed / 1e12, 3),

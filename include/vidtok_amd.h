@@ -215,6 +215,8 @@ int vt_groupnorm_act(const void* x, int in_dtype, int64_t ldx, void* y, int out_
 
 /* row softmax(scale * s) over the last dim; s fp32 [rows][cols] -> p (out_dtype) [rows][ldp].
  * The softmax inside F.scaled_dot_product_attention (model_3dcausal.py:140), scale = C^-0.5. */
+/* x = tanh(x) in place on n fp32 elements: the decoders' `tanh_out` option (model_3dcausal.py:866-869) */
+int vt_tanh_inplace(float* x, int64_t n, vt_stream stream);
 int vt_softmax_rows(const float* s, void* p, int out_dtype, int64_t rows, int32_t cols,
                     int64_t ldp, float scale, vt_stream stream);
 

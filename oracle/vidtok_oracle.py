@@ -229,14 +229,25 @@ def encoder_forward(sd, params, x, version="v1_0", state: Optional[ChunkState] =
     T = x.shape[2]
     if T % f != 0:
         npad = f - 1 if version == "v1_0" else f - T % f
-        x = torch.cat([x[:, :, :1].repeat(1, 1, npad, 1, 1), x], dim=2)  # replicate pad in front
+        pad_mode = params.get("init_pad_mode", "replicate")          # pad_at_dim, R/modules/model_3dcausal.py:37-43,680,688
+        if pad_mode == "replicate":
+            x = torch.cat([x[:, :, :1].repeat(1, 1, npad, 1, 1), x], dim=2)
+        elif pad_mode == "constant":
+            x = torch.cat([torch.zeros_like(x[:, :, :1]).repeat(1, 1, npad, 1, 1), x], dim=2)
+        else:                                                          # reflect: x[npad], ..., x[1] in front
+            assert pad_mode == "reflect"
+            x = torch.cat([x[:, :, 1:npad + 1].flip(2), x], dim=2)
+    with_conv = params.get("resamp_with_conv", True)
     h = causal_conv(sd, f"{prefix}.conv_in.conv", x, version, state)
     for lvl in range(nres):
         for blk in range(params["num_res_blocks"]):
             h = resnet_block_2d(sd, f"{prefix}.down.{lvl}.block.{blk}", h)
             h = resnet_block_causal(sd, f"{prefix}.down_temporal.{lvl}.block.{blk}", h, version, state)
         if lvl in spatial_ds:
-            h = conv2d_frames(sd, f"{prefix}.down.{lvl}.downsample.conv", h, stride=2, pad=(0, 1, 0, 1))
+            if with_conv:
+                h = conv2d_frames(sd, f"{prefix}.down.{lvl}.downsample.conv", h, stride=2, pad=(0, 1, 0, 1))
+            else:                                                      # Downsample(with_conv=False), :228-229: avg_pool2d(2, 2) per frame
+                h = F.avg_pool3d(h, kernel_size=(1, 2, 2), stride=(1, 2, 2))
             if lvl in tempo_ds:
                 h = time_downsample(sd, f"{prefix}.down_temporal.{lvl}.downsample", h, version, state)
     h = resnet_block_causal(sd, f"{prefix}.mid.block_1", h, version, state)
@@ -272,11 +283,15 @@ def decoder_forward(sd, params, z, version="v1_0", state: Optional[ChunkState] =
             h = resnet_block_causal(sd, f"{prefix}.up_temporal.{lvl}.block.{blk}", h, version, state)
         if lvl in spatial_us:
             h = F.interpolate(h, scale_factor=[1.0, 2.0, 2.0], mode="nearest")  # Upsample, :208-212
-            h = conv2d_frames(sd, f"{prefix}.up.{lvl}.upsample.conv", h)
+            if params.get("resamp_with_conv", True):
+                h = conv2d_frames(sd, f"{prefix}.up.{lvl}.upsample.conv", h)
             if lvl in tempo_us:
                 h = time_upsample(sd, f"{prefix}.up_temporal.{lvl}.upsample", h, version, state, mode, n_of[lvl])
-    h = silu(norm_c(sd, f"{prefix}.norm_out", h, "frame"))
-    h = causal_conv(sd, f"{prefix}.conv_out.conv", h, version, state)
+    if not params.get("give_pre_end", False):                            # :862-869
+        h = silu(norm_c(sd, f"{prefix}.norm_out", h, "frame"))
+        h = causal_conv(sd, f"{prefix}.conv_out.conv", h, version, state)
+        if params.get("tanh_out", False):
+            h = torch.tanh(h)
     return h[:, :, f - 1:] if version == "v1_0" else h
 
 

@@ -333,3 +333,24 @@ def test_engine_graph_cache_replays_bit_exact(name, shape, dtype):
     model.load_state_dict(sd2)                             # invalidates: the next calls must use the new weights
     outs = [model(xs[0])[1] for _ in range(3)]
     assert not torch.equal(outs[0], eager[0][1]) and torch.equal(outs[0], outs[1]) and torch.equal(outs[1], outs[2])
+
+
+@pytest.mark.parametrize("ov,T", [(dict(resamp_with_conv=False), 5), (dict(init_pad_mode="constant"), 6),
+                                  (dict(init_pad_mode="reflect"), 6), (dict(tanh_out=True), 5), (dict(give_pre_end=True), 5)],
+                         ids=["no_resamp_conv", "pad_constant", "pad_reflect", "tanh_out", "give_pre_end"])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+def test_rare_constructor_options_match_oracle(ov, T, dtype):
+    """constructor options of the reference no shipped YAML sets (model_3dcausal.py:200-230, 37-43/680/688, 862-869)"""
+    model, cfg, sd = build_model("vidtok_kl_causal_488_4chn", seed=9, device=DEV, dtype=dtype, overrides=ov)
+    ora = build_oracle(cfg, sd)
+    x = torch.rand(1, 3, T, 64, 64, generator=torch.Generator().manual_seed(6)) * 2 - 1
+    torch.manual_seed(2)
+    z = model.encode(x.to(DEV))
+    dec = model.decoder(z)
+    torch.manual_seed(2)
+    z2, _ = ora.encode(x)
+    dec2 = ora.decode(z2)
+    ez, ed = rel_err(z, z2), rel_err(dec, dec2)
+    print(f"{ov} {dtype}: z rel {ez:.2e} dec rel {ed:.2e}")
+    assert dec.shape == dec2.shape
+    assert (ez < 1e-3 and ed < 1e-3) if dtype == torch.float32 else (ez < BF16_Z and ed < BF16_RECON)

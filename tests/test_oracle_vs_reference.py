@@ -128,3 +128,33 @@ def test_oracle_matches_reference_groupnorm(cfg, shape, tiled):
         torch.manual_seed(7)
         z2, dec2, log2 = ora(x)
     assert rel_err(z2, z) < 2e-5 and rel_err(dec2, dec) < 1e-4
+
+
+RARE = [  # constructor options no shipped YAML sets (VERDICT r1 "unused reference branches"); (overrides, input frames)
+    (dict(resamp_with_conv=False), 5),
+    (dict(init_pad_mode="constant"), 6),
+    (dict(init_pad_mode="reflect"), 6),
+    (dict(tanh_out=True), 5),
+    (dict(give_pre_end=True), 5),
+]
+
+
+@pytest.mark.parametrize("ov,T", RARE, ids=[next(iter(o)) + "=" + str(next(iter(o.values()))) for o, _ in RARE])
+def test_oracle_matches_reference_rare_options(ov, T):
+    """Upsample / Downsample(with_conv=False) (model_3dcausal.py:200-230), init_pad_mode constant / reflect (:37-43,680,688),
+    tanh_out / give_pre_end (:862-869)."""
+    ref, c = load_reference_model("vidtok_kl_causal_488_4chn", overrides=ov)
+    randomize_weights(ref)
+    if "resamp_with_conv" in ov:
+        assert not any(".downsample.conv." in k and "down_temporal" not in k for k in ref.state_dict())
+    ora = OracleEngine(c["model"]["params"], ref.state_dict())
+    x = torch.rand(1, 3, T, 32, 32) * 2 - 1
+    with torch.no_grad():
+        torch.manual_seed(7)
+        z = ref.encode(x)
+        dec = ref.decoder(z)
+        torch.manual_seed(7)
+        z2, _ = ora.encode(x)
+        dec2 = ora.decode(z2)
+    assert dec.shape == dec2.shape and (dec.shape[1] == (128 if "give_pre_end" in ov else 3))
+    assert rel_err(z2, z) < 2e-5 and rel_err(dec2, dec) < 5e-5

@@ -230,6 +230,10 @@ def temporal_block(x, w1, b1, w2, b2, norm1, norm2, *, tmode=L.VT_TPAD_ZERO, eps
     return conv(h, w2, b2, g, cout=c, tmode=tmode, res=x, res_mode=L.VT_RES_ADD, **kw)
 
 
+def tanh_(x):
+    return x.tanh_()
+
+
 def entropy(avg):
     return (-avg * avg.clamp(min=1e-5).log()).sum()
 
@@ -307,7 +311,7 @@ def ncthw_copy_frames(src, dst, ts0, td0, n, clamp=False):
 
 
 ALL = ["conv", "gemm_nt", "layernorm_act", "softmax_rows", "ncthw_to_ndhwc", "ndhwc_to_ncthw", "time_avgpool3s2",
-       "time_lerp2x", "gather_frames", "kl_sample", "fsq_quantize", "fsq_indices_to_codes", "fsq_aux_stats", "entropy", "temporal_block", "temporal_block_supported", "frames_u8_to_ncthw", "ncthw_to_frames_u8", "ncthw_copy_frames",
+       "time_lerp2x", "gather_frames", "kl_sample", "fsq_quantize", "fsq_indices_to_codes", "fsq_aux_stats", "entropy", "tanh_", "temporal_block", "temporal_block_supported", "frames_u8_to_ncthw", "ncthw_to_frames_u8", "ncthw_copy_frames",
        "eval_psnr_ssim", "channel_linear", "groupnorm_act"]
 
 

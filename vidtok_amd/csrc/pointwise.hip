@@ -347,6 +347,22 @@ extern "C" int vt_layernorm_act(const void* x, int in_dtype, int64_t ldx, void* 
   return VT_ERR_ARG;
 }
 
+// tanh in place on an fp32 tensor: the `tanh_out` option of the decoders (model_3dcausal.py:866-869)
+__global__ __launch_bounds__(256) void tanh_inplace_kernel(float* __restrict__ x, long long n) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) x[i] = tanhf(x[i]);
+}
+
+extern "C" int vt_tanh_inplace(float* x, int64_t n, vt_stream stream_) {
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  VT_CHECK_ARG(x != nullptr && n >= 0, "vt_tanh_inplace: bad arguments");
+  if (n == 0) return VT_OK;
+  long long blocks = (n + 255) / 256;
+  if (blocks > 65536) blocks = 65536;
+  hipLaunchKernelGGL(tanh_inplace_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, x, (long long)n);
+  VT_CHECK_LAUNCH();
+  return VT_OK;
+}
+
 extern "C" int vt_softmax_rows(const float* s, void* p, int out_dtype, int64_t rows, int32_t cols, int64_t ldp,
                                float scale, vt_stream stream_) {
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);

@@ -83,6 +83,7 @@ SIGNATURES = {
     "vt_temporal_block_supported": (C.c_int, [C.POINTER(TBlockDesc)]),
     "vt_temporal_block": (C.c_int, [C.POINTER(TBlockDesc), _P]),
     "vt_layernorm_act": (C.c_int, [_P, C.c_int, _I64, _P, C.c_int, _I64, _P, _P, _I64, _I32, _F, _I32, _P]),
+    "vt_tanh_inplace": (C.c_int, [_P, _I64, _P]),
     "vt_softmax_rows": (C.c_int, [_P, _P, C.c_int, _I64, _I32, _I64, _F, _P]),
     "vt_ncthw_to_ndhwc": (C.c_int, [_P, _P, C.c_int, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _P]),
     "vt_ndhwc_to_ncthw": (C.c_int, [_P, C.c_int, _P, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _P]),

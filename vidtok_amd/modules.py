@@ -247,9 +247,11 @@ class Upsample(nn.Module):
 
     def __init__(self, in_channels, with_conv):
         super().__init__()
-        if not with_conv:
-            raise NotImplementedError("Upsample(with_conv=False) is not used by any VidTok config")
         self.with_conv = with_conv
+        self.in_channels = in_channels
+        self._ident = {}
+        if not with_conv:       # nearest x2 only (model_3dcausal.py:208-212): no parameters, no `conv` key
+            return
         self.conv = nn.Conv2d(in_channels, in_channels, kernel_size=3, stride=1, padding=1)
         # up(x)[Y][X] = x[Y>>1][X>>1]: an output pixel of parity (py, px) sees a 2x2 window of x, so the 3x3 conv over
         # the up-sampled frame is four 2x2 convs over x with pre-summed taps (4/9 of the MACs), each writing its
@@ -261,6 +263,13 @@ class Upsample(nn.Module):
     def run(self, x, dt, next_norm=None):
         x = plain(x)
         B, T, H, W, C = x.shape
+        if not self.with_conv:
+            # no shipped config uses this: the gather's folded x2 up-sampling under a 1x1 identity convolution copies
+            # every input pixel to its four output pixels exactly (1.0 * x plus zeros)
+            key = (dt, x.device, C)
+            if key not in self._ident:
+                self._ident[key] = torch.eye(C, dtype=torch.float32, device=x.device).to(dt).contiguous()
+            return ops.conv(x, self._ident[key], None, ConvGeom(ups_s=1), cout=self.in_channels, ldy=C)
         cout = self.conv.out_channels
         ld = ops.pad_channels(cout)
         y = (torch.empty if ld == cout else torch.zeros)((B, T, 2 * H, 2 * W, ld), dtype=dt, device=x.device)
@@ -275,13 +284,27 @@ class Downsample(nn.Module):
 
     def __init__(self, in_channels, with_conv):
         super().__init__()
-        if not with_conv:
-            raise NotImplementedError("Downsample(with_conv=False) is not used by any VidTok config")
         self.with_conv = with_conv
+        self.in_channels = in_channels
+        self._pool_w = {}
+        if not with_conv:       # avg_pool2d(2, 2) (model_3dcausal.py:228-229): no parameters
+            return
         self.conv = nn.Conv2d(in_channels, in_channels, kernel_size=3, stride=2, padding=0)
         self._pack = PackedCache()
 
     def run(self, x, dt, next_norm=None):
+        if not self.with_conv:
+            # no shipped config uses this: 2x2 average pooling as a stride-2 2x2 convolution with 0.25 * identity taps
+            # (products exact, the four-term sum accumulated in fp32)
+            xp = plain(x)
+            C = xp.shape[-1]
+            key = (dt, xp.device, C)
+            if key not in self._pool_w:
+                w = (0.25 * torch.eye(C, dtype=torch.float32, device=xp.device)).repeat(1, 4)     # [C, 4 taps * C]
+                self._pool_w[key] = w.to(dt).contiguous()
+            y = ops.conv(xp, self._pool_w[key], None, ConvGeom(kh=2, kw=2, sh=2, sw=2), cout=self.in_channels, ldy=C,
+                         **_emit(next_norm))
+            return _wrap(y, next_norm)
         g = ConvGeom(kh=3, kw=3, sh=2, sw=2, ph=0, pw=0, ph_hi=1, pw_hi=1)
         return _wrap(_Conv2dHolder.run(self.conv, self._pack, plain(x), dt, g, **_emit(next_norm)), next_norm)
 
@@ -576,8 +599,7 @@ class EncoderCausal3DPadding(nn.Module):
         self.is_causal = True
         self.time_downsample_factor = ignore_kwargs.get("time_downsample_factor", 4)
         self.init_pad_mode = ignore_kwargs.get("init_pad_mode", "replicate")
-        if self.init_pad_mode != "replicate":
-            raise NotImplementedError("init_pad_mode other than 'replicate' is not used by any VidTok config")
+        assert self.init_pad_mode in ("constant", "replicate", "reflect")          # pad_at_dim, model_3dcausal.py:37-43
         self.time_padding = self.time_downsample_factor - 1
         self.out_channels = 2 * z_channels if double_z else z_channels
         self.compute_dtype = torch.float32
@@ -623,7 +645,18 @@ class EncoderCausal3DPadding(nn.Module):
     def forward(self, x):
         assert x.dim() == 5, "input should be 5D tensor, but got {}D tensor".format(x.dim())
         dt = self.compute_dtype
-        h = ops.ncthw_to_ndhwc(x.contiguous().float(), dt, tpad=self._front_pad(x.shape[2]))
+        npad = self._front_pad(x.shape[2])
+        if npad and self.init_pad_mode != "replicate":
+            # no shipped config uses these modes: the padded clip is assembled frame by frame, then converted unpadded
+            xc = x.contiguous().float()
+            xp = torch.zeros((x.shape[0], x.shape[1], x.shape[2] + npad) + tuple(x.shape[3:]), dtype=torch.float32, device=x.device)
+            ops.ncthw_copy_frames(xc, xp, 0, npad, x.shape[2])
+            if self.init_pad_mode == "reflect":                       # x[npad], ..., x[1] in front
+                for i in range(npad):
+                    ops.ncthw_copy_frames(xc, xp, npad - i, i, 1)
+            h = ops.ncthw_to_ndhwc(xp, dt, tpad=0)
+        else:
+            h = ops.ncthw_to_ndhwc(x.contiguous().float(), dt, tpad=npad)
         stages = []
         for i_level in range(self.num_resolutions):
             for i_block in range(self.num_res_blocks):
@@ -650,8 +683,7 @@ class DecoderCausal3DPadding(nn.Module):
                  norm_type="layernorm", **ignorekwargs):
         super().__init__()
         _check_norm(norm_type)
-        if give_pre_end or tanh_out:
-            raise NotImplementedError("give_pre_end / tanh_out are never set by a VidTok config")
+        self.give_pre_end, self.tanh_out = give_pre_end, tanh_out     # model_3dcausal.py:862-869; no shipped config sets them
         v = self.version
         self.ch, self.temb_ch = ch, 0
         self.num_resolutions = len(ch_mult)
@@ -721,9 +753,13 @@ class DecoderCausal3DPadding(nn.Module):
                     stages.append(self.up_temporal[i_level].upsample)
         h = run_stages(stages, self.conv_in.run(h, dt, **_emit(first_norm_of(stages[0], dt))), dt,
                        last_norm=(self.norm_out, True), first=first_norm_of(stages[0], dt))
-        h = self.norm_out.apply_ndhwc(h, True, dt, SITE_FRAME)
         trim = self.time_padding if self.version == "v1_0" else 0
-        return self.conv_out.run(h, dt, out_layout=L.VT_NCTHW, t_trim=trim)
+        if self.give_pre_end:
+            hp = plain(h)
+            return ops.ndhwc_to_ncthw(hp, self.up[0].block[-1].out_channels, ttrim=trim)
+        h = self.norm_out.apply_ndhwc(h, True, dt, SITE_FRAME)
+        y = self.conv_out.run(h, dt, out_layout=L.VT_NCTHW, t_trim=trim)
+        return ops.tanh_(y) if self.tanh_out else y
 
 
 class EncoderCausal3DPaddingV11(EncoderCausal3DPadding):

@@ -296,6 +296,14 @@ def groupnorm_act(x, gamma, beta, *, scope, silu, eps=1e-6, out_dtype=None, c=No
     return y
 
 
+def tanh_(x):
+    """x = tanh(x) in place (fp32)"""
+    _chk(x, "tanh.x")
+    assert x.dtype == torch.float32
+    L.check(L.load().vt_tanh_inplace(_ptr(x), x.numel(), _stream()), "vt_tanh_inplace")
+    return x
+
+
 def softmax_rows(s, scale: float, out_dtype, ld_out=None):
     """softmax(scale*s) over the last dim; ld_out > cols pads the output rows with zeros."""
     lib = L.load()
