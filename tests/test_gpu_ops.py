@@ -2,6 +2,7 @@
 contract (tests/torch_ops_ref.py) on the same seeded inputs.  fp32 arithmetic must agree to fp32
 round-off (fmaf-chain MFMA), bf16 to bf16 round-off of the output; integer results bit-exactly."""
 import math
+import os
 
 import pytest
 import torch
@@ -193,6 +194,42 @@ def test_temporal_block_fused(shape, tmode, nxt, keep):
     assert not ops.temporal_block_supported(_act(1, 2, 8, 8, 256, dt, 1), tmode)
     assert not ops.temporal_block_supported(_act(1, 2, 5, 7, 128, dt, 1), tmode)
     assert not ops.temporal_block_supported(x, L.VT_TPAD_CACHE)
+
+
+def test_weight_stationary_kernels_are_split_independent():
+    """A pixel's bits must not depend on which workgroup / code path computed it: run-to-run equality and
+    batch slice == batch of one for the persistent kernels (their row phases exist in a sliced and a plain version);
+    the 3x3 kernel without LayerNorm is moreover bit-identical to the tile-per-workgroup kernel (same fp32 sums)."""
+    dt, C_ = torch.bfloat16, 128
+    B, T, H, W = 2, 5, 128, 128
+    x, res = _act(B, T, H, W, C_, dt, 1), _act(B, T, H, W, C_, dt, 2)
+    g = torch.Generator().manual_seed(3)
+    w = pack_conv_weight(torch.randn((C_, C_, 3, 3), generator=g) / math.sqrt(9 * C_), dt, cin_stored=C_).to(DEV)
+    bias = _rand((C_,), torch.float32, 4, 0.1)
+    ln = (_rand((C_,), torch.float32, 5, 0.3) + 1.0, _rand((C_,), torch.float32, 6, 0.2), 1e-6, True)
+    tup = lambda o: o if isinstance(o, tuple) else (o,)
+    for kw in ({}, dict(res=res, res_mode=L.VT_RES_ADD), dict(res=res, res_mode=L.VT_RES_ADD, ln=ln), dict(ln=ln, ln_keep_y=False)):
+        a = tup(ops.conv(x, w, bias, ConvGeom(**G3), cout=C_, **kw))
+        b = tup(ops.conv(x, w, bias, ConvGeom(**G3), cout=C_, **kw))
+        kw1 = dict(kw, res=res[1:2].contiguous()) if "res" in kw else kw
+        one = tup(ops.conv(x[1:2].contiguous(), w, bias, ConvGeom(**G3), cout=C_, **kw1))
+        assert all(torch.equal(u, v) for u, v in zip(a, b)) and all(torch.equal(u[1:2], v) for u, v in zip(a, one)), kw.keys()
+        if "ln" not in kw:
+            os.environ["VT_CONV_WS"] = "0"
+            try:
+                ig = tup(ops.conv(x, w, bias, ConvGeom(**G3), cout=C_, **kw))
+            finally:
+                del os.environ["VT_CONV_WS"]
+            assert torch.equal(a[0], ig[0])
+    ws = [pack_conv_weight(torch.randn((C_, C_, 3), generator=g) / math.sqrt(3 * C_), dt, cin_stored=C_).to(DEV) for _ in range(2)]
+    bs = [_rand((C_,), torch.float32, 7 + i, 0.1) for i in range(2)]
+    nm = (ln[0], ln[1])
+    for tmode in (L.VT_TPAD_ZERO, L.VT_TPAD_REPLICATE):
+        for nxt in (None, (ln[0], ln[1], True)):
+            a = tup(ops.temporal_block(x, ws[0], bs[0], ws[1], bs[1], nm, nm, tmode=tmode, next_ln=nxt))
+            b = tup(ops.temporal_block(x, ws[0], bs[0], ws[1], bs[1], nm, nm, tmode=tmode, next_ln=nxt))
+            one = tup(ops.temporal_block(x[1:2].contiguous(), ws[0], bs[0], ws[1], bs[1], nm, nm, tmode=tmode, next_ln=nxt))
+            assert all(torch.equal(u, v) for u, v in zip(a, b)) and all(torch.equal(u[1:2], v) for u, v in zip(a, one)), (tmode, nxt is None)
 
 
 def test_conv_weight_stationary_not_for_fp32_or_other_shapes():

@@ -220,6 +220,9 @@ __global__ __launch_bounds__(256, 1) void conv3x3_ws128_kernel(const ConvArgs p)
   auto res_row_ptr = [&](int it) -> const bf16_t* {
     return rg + (pix0_prev + tile_pixel_off(it)) * p.ldr + 8 * oct_j;
   };
+  // All row arithmetic is spelled with explicit-rounding intrinsics: the same source is instantiated inside the K loop and
+  // once more for the last tile of a workgroup, and context-dependent FMA contraction would make a pixel's bits depend on
+  // which of the two computed it (i.e. on how tiles were split over workgroups).
   // The row phase runs as TWO sweeps over the 8 row iterations, 28 groups each (piece = group index):
   //   sweep 1 (groups 0..27, 3.5 per iteration -> 14 shadows): T row + residual -> y, LayerNorm(+SiLU) -> both packed to
   //            bf16 and written back IN PLACE over the row's own two 16-B units of T.  Only loads are in flight.
@@ -244,8 +247,8 @@ __global__ __launch_bounds__(256, 1) void conv3x3_ws128_kernel(const ConvArgs p)
         if constexpr (u == 0) rsum = 0.f;
 #pragma unroll
         for (int e = 2 * u; e < 2 * u + 2; ++e) {
-          rv[e] = rq[it % 3].get(e) + (e < 4 ? rt0[e] : rt1[e - 4]);
-          rsum += rv[e];
+          rv[e] = __fadd_rn(rq[it % 3].get(e), e < 4 ? rt0[e] : rt1[e - 4]);
+          rsum = __fadd_rn(rsum, rv[e]);
           pin(rv[e]);
         }
         pin(rsum);
@@ -266,15 +269,15 @@ __global__ __launch_bounds__(256, 1) void conv3x3_ws128_kernel(const ConvArgs p)
           if constexpr (u == 0) rsum = 0.f;
 #pragma unroll
           for (int e = 4 * u; e < 4 * u + 4; ++e) {
-            rv[e] -= rmean;
-            rsum += rv[e] * rv[e];
+            rv[e] = __fsub_rn(rv[e], rmean);
+            rsum = __fmaf_rn(rv[e], rv[e], rsum);
             pin(rv[e]);
           }
           pin(rsum);
         }
       } else if constexpr (s == 8) {
         if constexpr (LN != 0) {
-          rrstd = __builtin_amdgcn_rsqf(group_sum_dpp<16>(rsum) * (1.0f / 128.0f) + p.ln_eps);
+          rrstd = __builtin_amdgcn_rsqf(__fmaf_rn(group_sum_dpp<16>(rsum), 1.0f / 128.0f, p.ln_eps));
           pin(rrstd);
         }
       } else if constexpr (s >= 9 && s <= 12) {        // affine (+SiLU), two channels per shadow
@@ -282,7 +285,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_ws128_kernel(const ConvArgs p)
           constexpr int u = s - 9;
 #pragma unroll
           for (int e = 2 * u; e < 2 * u + 2; ++e) {
-            const float a = rv[e] * rrstd * lg[e] + lb[e];
+            const float a = __fmaf_rn(__fmul_rn(rv[e], rrstd), lg[e], lb[e]);
             rv[e] = (LN == 2) ? silu_fast(a) : a;
             pin(rv[e]);
           }

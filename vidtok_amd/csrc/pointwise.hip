@@ -305,7 +305,10 @@ struct GatherIdx {
   int idx[128];
 };
 
-__global__ __launch_bounds__(kBlock) void gather_frames_kernel(const u32x4* __restrict__ src, u32x4* __restrict__ dst,
+// VT = u32x4 when frames and strides are multiples of 16 bytes (every activation frame), uint32_t otherwise (small
+// index maps of odd sizes): the unit counts are in VT units
+template <typename VT>
+__global__ __launch_bounds__(kBlock) void gather_frames_kernel(const VT* __restrict__ src, VT* __restrict__ dst,
                                                                int B, long long F16, long long sbs16,
                                                                long long dbs16, GatherIdx gi, int n) {
   const long long total = (long long)B * n * F16;
@@ -464,18 +467,27 @@ extern "C" int vt_gather_frames(const void* src, void* dst, int32_t esize, int32
   VT_CHECK_ARG(src && dst && idx_host && B > 0 && n > 0 && n <= 128 && frame_elems > 0,
                "vt_gather_frames: bad arguments (n=%d)", n);
   VT_CHECK_ARG(esize == 2 || esize == 4, "vt_gather_frames: esize %d", esize);
-  VT_CHECK_ARG((frame_elems * esize) % 16 == 0 && (src_bstride * esize) % 16 == 0 && (dst_bstride * esize) % 16 == 0,
-               "vt_gather_frames: frames must be multiples of 16 bytes");
+  const bool v16 = (frame_elems * esize) % 16 == 0 && (src_bstride * esize) % 16 == 0 && (dst_bstride * esize) % 16 == 0 &&
+                   ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15) == 0;
+  VT_CHECK_ARG(v16 || ((frame_elems * esize) % 4 == 0 && (src_bstride * esize) % 4 == 0 && (dst_bstride * esize) % 4 == 0 &&
+                       ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 3) == 0),
+               "vt_gather_frames: frames, strides and pointers must be multiples of 4 bytes");
   GatherIdx gi;
   for (int j = 0; j < n; ++j) {
     VT_CHECK_ARG(idx_host[j] >= 0, "vt_gather_frames: negative index");
     gi.idx[j] = idx_host[j];
   }
-  const long long F16 = frame_elems * esize / 16;
+  const int unit = v16 ? 16 : 4;
+  const long long F16 = frame_elems * esize / unit;
   const long long total = (long long)B * n * F16;
-  hipLaunchKernelGGL(gather_frames_kernel, dim3(grid_for(total)), dim3(kBlock), 0, stream, (const u32x4*)src,
-                     (u32x4*)dst, B, F16, (long long)(src_bstride * esize / 16), (long long)(dst_bstride * esize / 16),
-                     gi, n);
+  if (v16)
+    hipLaunchKernelGGL(gather_frames_kernel<u32x4>, dim3(grid_for(total)), dim3(kBlock), 0, stream, (const u32x4*)src,
+                       (u32x4*)dst, B, F16, (long long)(src_bstride * esize / 16), (long long)(dst_bstride * esize / 16),
+                       gi, n);
+  else
+    hipLaunchKernelGGL(gather_frames_kernel<uint32_t>, dim3(grid_for(total)), dim3(kBlock), 0, stream, (const uint32_t*)src,
+                       (uint32_t*)dst, B, F16, (long long)(src_bstride * esize / 4), (long long)(dst_bstride * esize / 4),
+                       gi, n);
   VT_CHECK_LAUNCH();
   return VT_OK;
 }

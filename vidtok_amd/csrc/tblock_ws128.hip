@@ -67,25 +67,29 @@ __device__ __forceinline__ void tb_mfma(const u32x4& w, const u32x4& x, f32x16& 
 }
 
 // LayerNorm (+SiLU) of one pixel row held by 16 lanes x 8 channels; two-pass statistics like layernorm_act_kernel
+// Every row phase exists twice -- sliced into MFMA shadows, and plain (first / last step of a workgroup, steps with
+// skipped taps) -- so the arithmetic is spelled with explicit-rounding intrinsics: context-dependent FMA contraction
+// would make a pixel's bits depend on which version computed it, i.e. on how columns were split over workgroups.
+__device__ __forceinline__ float tb_affine_act(float d, float rstd, float g, float b, bool silu) {
+  const float u = __fmaf_rn(__fmul_rn(d, rstd), g, b);
+  return silu ? silu_fast(u) : u;
+}
 template <bool SILU>
 __device__ __forceinline__ void tb_row_norm(float (&v)[8], const float (&g)[8], const float (&b)[8], float eps, float (&o)[8]) {
   float s = 0.f;
 #pragma unroll
-  for (int e = 0; e < 8; ++e) s += v[e];
+  for (int e = 0; e < 8; ++e) s = __fadd_rn(s, v[e]);
   const float mean = group_sum_dpp<16>(s) * (1.0f / 128.0f);
   float q = 0.f;
   float d[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
-    d[e] = v[e] - mean;
-    q += d[e] * d[e];
+    d[e] = __fsub_rn(v[e], mean);
+    q = __fmaf_rn(d[e], d[e], q);
   }
-  const float rstd = __builtin_amdgcn_rsqf(group_sum_dpp<16>(q) * (1.0f / 128.0f) + eps);
+  const float rstd = __builtin_amdgcn_rsqf(__fmaf_rn(group_sum_dpp<16>(q), 1.0f / 128.0f, eps));
 #pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    const float u = d[e] * rstd * g[e] + b[e];
-    o[e] = SILU ? silu_fast(u) : u;
-  }
+  for (int e = 0; e < 8; ++e) o[e] = tb_affine_act(d[e], rstd, g[e], b[e], SILU);
 }
 
 // "This value exists HERE" (see conv_ws128.hip): keeps a slice of row arithmetic in the MFMA shadow the source put it in
@@ -164,8 +168,8 @@ __global__ __launch_bounds__(256, 1) void tblock_ws128_kernel(const TBlockArgs p
       if constexpr (s == 1) rsum = 0.f;
 #pragma unroll
       for (int e = 4 * (s - 1); e < 4 * (s - 1) + 4; ++e) {
-        rv[e] = xr.get(e) + ((e < 4 ? rt0[e] : rt1[e - 4]) + bo2[e]);
-        rsum += rv[e];
+        rv[e] = __fadd_rn(xr.get(e), __fadd_rn(e < 4 ? rt0[e] : rt1[e - 4], bo2[e]));
+        rsum = __fadd_rn(rsum, rv[e]);
         tb_pin(rv[e]);
       }
       tb_pin(rsum);
@@ -180,23 +184,22 @@ __global__ __launch_bounds__(256, 1) void tblock_ws128_kernel(const TBlockArgs p
         if constexpr (s == 4) rsum = 0.f;
 #pragma unroll
         for (int e = 4 * (s - 4); e < 4 * (s - 4) + 4; ++e) {
-          rv[e] -= rmean;
-          rsum += rv[e] * rv[e];
+          rv[e] = __fsub_rn(rv[e], rmean);
+          rsum = __fmaf_rn(rv[e], rv[e], rsum);
           tb_pin(rv[e]);
         }
         tb_pin(rsum);
       }
     } else if constexpr (s == 6) {
       if constexpr (LNN != 0) {
-        rrstd = __builtin_amdgcn_rsqf(group_sum_dpp<16>(rsum) * (1.0f / 128.0f) + p.eps);
+        rrstd = __builtin_amdgcn_rsqf(__fmaf_rn(group_sum_dpp<16>(rsum), 1.0f / 128.0f, p.eps));
         tb_pin(rrstd);
       }
     } else if constexpr (s >= 7 && s <= 10) {
       if constexpr (LNN != 0) {
 #pragma unroll
         for (int e = 2 * (s - 7); e < 2 * (s - 7) + 2; ++e) {
-          const float a = rv[e] * rrstd * lgn[e] + lbn[e];
-          rv[e] = (LNN == 2) ? silu_fast(a) : a;
+          rv[e] = tb_affine_act(rv[e], rrstd, lgn[e], lbn[e], LNN == 2);
           tb_pin(rv[e]);
         }
       }
@@ -215,7 +218,7 @@ __global__ __launch_bounds__(256, 1) void tblock_ws128_kernel(const TBlockArgs p
 #pragma unroll
       for (int e = 4 * (s - 1); e < 4 * (s - 1) + 4; ++e) {
         rv[e] = xr.get(e);
-        rsum += rv[e];
+        rsum = __fadd_rn(rsum, rv[e]);
         tb_pin(rv[e]);
       }
       tb_pin(rsum);
@@ -226,18 +229,18 @@ __global__ __launch_bounds__(256, 1) void tblock_ws128_kernel(const TBlockArgs p
       if constexpr (s == 4) rsum = 0.f;
 #pragma unroll
       for (int e = 4 * (s - 4); e < 4 * (s - 4) + 4; ++e) {
-        rv[e] -= rmean;
-        rsum += rv[e] * rv[e];
+        rv[e] = __fsub_rn(rv[e], rmean);
+        rsum = __fmaf_rn(rv[e], rv[e], rsum);
         tb_pin(rv[e]);
       }
       tb_pin(rsum);
     } else if constexpr (s == 6) {
-      rrstd = __builtin_amdgcn_rsqf(group_sum_dpp<16>(rsum) * (1.0f / 128.0f) + p.eps);
+      rrstd = __builtin_amdgcn_rsqf(__fmaf_rn(group_sum_dpp<16>(rsum), 1.0f / 128.0f, p.eps));
       tb_pin(rrstd);
     } else if constexpr (s >= 7 && s <= 10) {
 #pragma unroll
       for (int e = 2 * (s - 7); e < 2 * (s - 7) + 2; ++e) {
-        rv[e] = silu_fast(rv[e] * rrstd * lg1[e] + lb1[e]);
+        rv[e] = tb_affine_act(rv[e], rrstd, lg1[e], lb1[e], true);
         tb_pin(rv[e]);
       }
     } else if constexpr (s == 11) {
@@ -373,7 +376,7 @@ __global__ __launch_bounds__(256, 1) void tblock_ws128_kernel(const TBlockArgs p
       float vv[8], o[8];
       T_row(row0 + 16 * it, vv);
 #pragma unroll
-      for (int e = 0; e < 8; ++e) vv[e] += bo1[e];
+      for (int e = 0; e < 8; ++e) vv[e] = __fadd_rn(vv[e], bo1[e]);
       tb_row_norm<true>(vv, lg2, lb2, p.eps, o);
       ring_store(ring2, t, row0 + 16 * it, o);
     }
