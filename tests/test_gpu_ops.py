@@ -86,6 +86,11 @@ CONV_CASES = [
     ("conv2d_ln_fallback_ragged", (1, 3, 5, 7), 128, 128, (3, 3), ConvGeom(**G3), dict(ln="only")),
     ("conv2d_ln_fallback_256", (1, 2, 8, 8), 128, 256, (3, 3), ConvGeom(**G3), dict(ln="keep")),
     ("conv3d_ln_fallback_512", (1, 3, 4, 4), 512, 512, (3, 3, 3), ConvGeom(**G333), dict(ln="only")),
+    # Cout = 256 on full 256-pixel tiles: fused in the 8-wave tile's LDS-transposed epilogue when that tile is chosen
+    # (test_conv_forced_256_tile / test_conv_large), conv + vt_layernorm_act on the 128 tile (test_conv)
+    ("conv2d_ln256_only", (1, 2, 16, 16), 256, 256, (3, 3), ConvGeom(**G3), dict(ln="only")),
+    ("conv2d_ln256_res_keep", (2, 2, 16, 16), 128, 256, (3, 3), ConvGeom(**G3), dict(res="add", ln="keep")),
+    ("temporal_ln256_only", (1, 4, 16, 16), 256, 256, (3,), ConvGeom(kt=3, pt=2), dict(ln="only")),
 ]
 
 
@@ -109,6 +114,8 @@ CONV_CASES_LARGE = [
     ("L_v11_cache_3d_256", (1, 6, 128, 128), 256, 256, (3, 3, 3), ConvGeom(**G333), dict(tmode="cache")),
     ("L_v11_cache_1d_128", (1, 8, 128, 128), 128, 128, (3,), ConvGeom(kt=3, pt=2), dict(tmode="cache", res="add")),
     ("L_conv2d_128_128_ln", (1, 4, 256, 256), 128, 128, (3, 3), ConvGeom(**G3), dict(res="add", ln="keep")),
+    ("L_conv2d_256_256_ln", (2, 3, 128, 128), 256, 256, (3, 3), ConvGeom(**G3), dict(res="add", ln="keep")),
+    ("L_temporal_k3_256_ln_only", (1, 8, 128, 128), 256, 256, (3,), ConvGeom(kt=3, pt=2), dict(ln="only")),
 ]
 
 
@@ -116,7 +123,11 @@ CONV_CASES_LARGE = [
 @pytest.mark.parametrize("case", BIG256, ids=[c[0] for c in BIG256])
 def test_conv_forced_256_tile(case, dtype, monkeypatch):
     monkeypatch.setenv("VT_CONV_TILE", "256")
-    assert _check_conv(case, dtype)["tile"] == (256, 256)
+    plan = _check_conv(case, dtype)
+    assert plan["tile"] == (256, 256)
+    (B, T, H, W), cout = case[1], case[3]
+    if "ln" in case[6] and cout == 256 and (B * T * H * W) % 256 == 0:
+        assert plan["ln_fused"] and plan["launches"] == 1       # conv_epilogue_lds256
 
 
 @pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])

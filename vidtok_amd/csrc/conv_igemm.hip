@@ -290,6 +290,105 @@ __device__ __forceinline__ void conv_epilogue_lds128(const ConvArgs& p, f32x16 (
   }
 }
 
+// LayerNorm-fusing epilogue of the 8-wave 256 x 256 tile for Cout = 256 (the second pyramid level: its conv1 -> norm2
+// and "emit the consumer's norm" cases ran as conv + a separate layernorm_act_kernel pass: 5.5 ms of a 93 ms step).
+// A pixel's 256 channels are spread over two waves, so the statistics need the tile transposed anyway: the two
+// 128 x 256 fp32 halves of the tile (128 KiB = the two LDS stages the K loop no longer needs) go through the LDS one
+// after the other.  Rows are read back by 32 lanes, lane j taking channels [4j, 4j+4) and [128+4j, 128+4j+4) -- the two
+// 16-B chunks j and 32+j, so the 16 lanes of a ds_read_b128 service group hit 16 different bank quads -- adds the
+// residual, stores y (8-B pieces, 256 contiguous bytes per half row) and LayerNorm(+SiLU) of the fp32 values
+// (statistics over the 32 lanes: DPP + one cross-half shuffle).  Row arithmetic in explicit-rounding intrinsics.
+template <typename TOut>
+__device__ __forceinline__ void conv_epilogue_lds256(const ConvArgs& p, f32x16 (&acc)[4][2], int m_blk, int wm, int wn, int lane,
+                                                     int tid, char* smem, long long z) {
+  TOut* __restrict__ yg = reinterpret_cast<TOut*>(p.y) + z * p.ys_z;
+  const TOut* __restrict__ rg = reinterpret_cast<const TOut*>(p.res) + z * p.rs_z;
+  TOut* __restrict__ ng = reinterpret_cast<TOut*>(p.ln_out);
+  float* T = reinterpret_cast<float*>(smem);
+  const bool has_res = p.res_mode == VT_RES_ADD;
+  const int j = tid & 31, rsub = tid >> 5;              // row phase: 32 lanes per row, 16 rows per sweep of the block
+  float lg[8], lb[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int c = (e < 4 ? 4 * j : 128 + 4 * j) + (e & 3);
+    lg[e] = p.ln_gamma[c];
+    lb[e] = p.ln_beta[c];
+  }
+#pragma unroll 1
+  for (int pz = 0; pz < 2; ++pz) {
+    __syncthreads();                                    // K loop / previous half: everybody is done with this LDS
+    if ((wm >> 1) == pz) {
+      const int h = lane >> 5;
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        const int prl = ((wm & 1) * 2 + b) * 32 + (lane & 31);       // row inside the half
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const int c = wn * 128 + 32 * a + 8 * g + 4 * h;
+            f32x4 bq;
+            if (p.bias) bq = *reinterpret_cast<const f32x4*>(p.bias + c);
+            else bq[0] = bq[1] = bq[2] = bq[3] = 0.0f;
+            f32x4 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = __fadd_rn(acc[a][b][4 * g + e], bq[e]);
+            *reinterpret_cast<f32x4*>(T + prl * 256 + (((c >> 2) ^ (prl & 63)) << 2)) = v;
+          }
+      }
+    }
+    __syncthreads();
+#pragma unroll 2
+    for (int it = 0; it < 8; ++it) {
+      const int r = rsub + 16 * it;
+      const long long m = (long long)m_blk + 128 * pz + r;
+      const long long orow = out_row(p, (int)m);
+      const f32x4 t0 = *reinterpret_cast<const f32x4*>(T + r * 256 + ((j ^ (r & 63)) << 2));
+      const f32x4 t1 = *reinterpret_cast<const f32x4*>(T + r * 256 + (((32 + j) ^ (r & 63)) << 2));
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = e < 4 ? t0[e] : t1[e - 4];
+      if (has_res) {
+        Quad<TOut> q0, q1;
+        q0.v = *reinterpret_cast<const decltype(q0.v)*>(rg + m * p.ldr + 4 * j);
+        q1.v = *reinterpret_cast<const decltype(q1.v)*>(rg + m * p.ldr + 128 + 4 * j);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          v[e] = __fadd_rn(q0.get(e), v[e]);
+          v[4 + e] = __fadd_rn(q1.get(e), v[4 + e]);
+        }
+      }
+      if (p.ln_keep_y) {
+        const float (&lo)[4] = reinterpret_cast<const float (&)[4]>(v[0]);
+        const float (&hi)[4] = reinterpret_cast<const float (&)[4]>(v[4]);
+        store_quad<TOut>(yg + orow * p.ldy + 4 * j, lo);
+        store_quad<TOut>(yg + orow * p.ldy + 128 + 4 * j, hi);
+      }
+      float s = 0.f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s = __fadd_rn(s, v[e]);
+      const float mean = group_sum_dpp<32>(s) * (1.0f / 256.0f);
+      float q = 0.f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        v[e] = __fsub_rn(v[e], mean);
+        q = __fmaf_rn(v[e], v[e], q);
+      }
+      const float rstd = __builtin_amdgcn_rsqf(__fmaf_rn(group_sum_dpp<32>(q), 1.0f / 256.0f, p.ln_eps));
+      float o[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float u = __fmaf_rn(__fmul_rn(v[e], rstd), lg[e], lb[e]);
+        o[e] = (p.ln_mode == 2) ? silu_fast(u) : u;
+      }
+      const float (&olo)[4] = reinterpret_cast<const float (&)[4]>(o[0]);
+      const float (&ohi)[4] = reinterpret_cast<const float (&)[4]>(o[4]);
+      store_quad<TOut>(ng + orow * p.ldn + 4 * j, olo);
+      store_quad<TOut>(ng + orow * p.ldn + 128 + 4 * j, ohi);
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // The operand tiles go global -> LDS with LDS-DMA (no VGPR round trip, no ds_write pass -- a
 // register-staged first version spent ~415 LDS cycles per K step on ds_write_b128 against 512 MFMA cycles).  The DMA writes each wave's 64
@@ -314,7 +413,9 @@ __device__ __forceinline__ void conv_epilogue_lds128(const ConvArgs& p, f32x16 (
 //        taps / ragged rows need no zero-page select and no 64-bit pointer arithmetic (the K loop of the
 //        short-K layers is instruction-issue bound: ~13 VALU per MFMA with pointers).  Needs the tensors
 //        below 4 GiB and no cache-mode time padding; otherwise the pointer form is used.
-template <typename MT, typename TOut, int WAVES_M, int WAVES_N, int TM, int TN, bool FAST, int ROWB, int STAGES, bool BUF>
+// LN256  the 8-wave tile with the LayerNorm-fusing epilogue (conv_epilogue_lds256) -- its own instantiation: the mere
+//        presence of a second epilogue path slowed every 256-tile convolution by 8 % through register allocation (round 1)
+template <typename MT, typename TOut, int WAVES_M, int WAVES_N, int TM, int TN, bool FAST, int ROWB, int STAGES, bool BUF, bool LN256 = false>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_igemm_glds_kernel(const ConvArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)   // device pass only: the host pass needs just the launch stub (buffer-descriptor types are device-only)
   constexpr int THREADS = 64 * WAVES_M * WAVES_N;   // 4 waves (128x128, 256x32/64 tiles) or 8 waves (256x256)
@@ -677,6 +778,12 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_igemm_glds_ker
     stage = (stage + 1 == STAGES) ? 0 : stage + 1;
   }
   if constexpr (BUF) wait_vmcnt<0>();   // the trailing zero-fill pieces must land before the LDS allocation is released
+  if constexpr (LN256) {
+    static_assert(WAVES_M == 4 && WAVES_N == 2 && TM == 2 && TN == 4 && std::is_same<MT, TOut>::value, "LN256: the 8-wave 256 x 256 tile");
+    if constexpr (!BUF) wait_vmcnt<0>();
+    conv_epilogue_lds256<TOut>(p, acc, m_blk, wm, wn, lane, tid, smem, z);
+    return;
+  }
   if constexpr (WAVES_M == 2 && WAVES_N == 2 && TM == 2 && TN == 2 && STAGES * STAGE_BYTES >= 128 * 128 * 4) {
     // full tile, NDHWC, 4-aligned strides (uniform): the coalesced epilogue through the LDS
     if (p.lds_epi && m_blk + BM <= p.M && n_blk + BN <= p.Cout) {
@@ -698,7 +805,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_igemm_glds_ker
 inline bool conv_buf() { return env_int("VT_CONV_BUF", 1) != 0; }
 inline bool conv_tinner() { return env_int("VT_CONV_TINNER", 1) != 0; }
 
-template <typename MT, typename TOut, int WAVES_M, int WAVES_N, int TM, int TN, bool FAST>
+template <typename MT, typename TOut, int WAVES_M, int WAVES_N, int TM, int TN, bool FAST, bool LN256 = false>
 int launch_variant(const ConvArgs& a_in, int nbatch, hipStream_t stream) {
   constexpr int ROWB = kRowBytes, STAGES = 2;
   constexpr int BM = WAVES_M * TM * 32;
@@ -729,9 +836,9 @@ int launch_variant(const ConvArgs& a_in, int nbatch, hipStream_t stream) {
   if (buf) {
     a.x_bytes = (unsigned)xb;
     a.w_bytes = (unsigned)wb;
-    kern = reinterpret_cast<const void*>(&conv_igemm_glds_kernel<MT, TOut, WAVES_M, WAVES_N, TM, TN, FAST, ROWB, STAGES, true>);
+    kern = reinterpret_cast<const void*>(&conv_igemm_glds_kernel<MT, TOut, WAVES_M, WAVES_N, TM, TN, FAST, ROWB, STAGES, true, LN256>);
   } else {
-    kern = reinterpret_cast<const void*>(&conv_igemm_glds_kernel<MT, TOut, WAVES_M, WAVES_N, TM, TN, FAST, ROWB, STAGES, false>);
+    kern = reinterpret_cast<const void*>(&conv_igemm_glds_kernel<MT, TOut, WAVES_M, WAVES_N, TM, TN, FAST, ROWB, STAGES, false, LN256>);
   }
   // the attribute is per device: one flag per (instantiation, gather form, device), set race-free
   static std::atomic<bool> attr_done[2][kMaxDevices];
@@ -794,7 +901,11 @@ int dispatch_tile(const ConvArgs& a, int nbatch, hipStream_t stream) {
   switch (select_tile(a, nbatch)) {
     case TILE_256x32: return launch_fast_or_general<MT, TOut, 4, 1, 2, 1>(a, nbatch, stream);
     case TILE_256x64: return launch_fast_or_general<MT, TOut, 4, 1, 2, 2>(a, nbatch, stream);
-    case TILE_256x256: return launch_fast_or_general<MT, TOut, 4, 2, 2, 4>(a, nbatch, stream);   // 8 waves
+    case TILE_256x256:                                                                           // 8 waves
+      if constexpr (std::is_same<MT, TOut>::value) {
+        if (a.ln_mode != 0) return launch_variant<MT, TOut, 4, 2, 2, 4, true, true>(a, nbatch, stream);   // conv_prepare checked Cin % BK
+      }
+      return launch_fast_or_general<MT, TOut, 4, 2, 2, 4>(a, nbatch, stream);
     default: return launch_fast_or_general<MT, TOut, 2, 2, 2, 2>(a, nbatch, stream);
   }
 }
@@ -891,6 +1002,12 @@ int conv_prepare(const vt_conv_desc* d, ConvArgs& a, bool& ln_fused, int& nbatch
   ln_fused = d->ln_mode != 0 && (use_ws || (d->Cout == 128 && M % 128 == 0 && (d->ldy & 7) == 0 && (d->ldn & 7) == 0 &&
                         (d->res_mode == VT_RES_NONE || (d->ldr & 7) == 0) && env_int("VT_CONV_LDSEPI", 1) != 0 &&
                         env_int("VT_CONV_FUSE_LN", 1) != 0));
+  // ... or inside the 8-wave 256 x 256 tile's epilogue for Cout = 256 (conv_epilogue_lds256): full tiles, plain rows
+  if (d->ln_mode != 0 && !ln_fused && d->Cout == 256 && M % 256 == 0 && d->dtype == d->out_dtype && nbatch == 1 &&
+      d->Cin % (kRowBytes / (d->dtype == VT_F32 ? 4 : 2)) == 0 && (d->ldy & 3) == 0 && (d->ldn & 3) == 0 &&
+      (d->res_mode == VT_RES_NONE || (d->res_mode == VT_RES_ADD && (d->ldr & 3) == 0 && d->Tr == d->To && d->res_tshift == 0)) &&
+      env_int("VT_CONV_FUSE_LN256", 1) != 0 && select_tile(a, nbatch) == TILE_256x256)
+    ln_fused = true;
   if (ln_fused) {
     a.ln_gamma = d->ln_gamma; a.ln_beta = d->ln_beta; a.ln_out = (char*)d->ln_out;
     a.ln_mode = d->ln_mode; a.ln_keep_y = d->ln_keep_y; a.ldn = d->ldn; a.ln_eps = d->ln_eps;
