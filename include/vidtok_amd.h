@@ -240,7 +240,8 @@ int vt_ndhwc_to_ncthw(const void* x, int in_dtype, float* y, int32_t B, int32_t 
  *   xp = [pad, x]; pad frame = 0 (tmode ZERO, v1.0 model_3dcausal.py:249-250), x[0]
  *   (REPLICATE, v1.1 first chunk) or `cache` (one frame [B][1][H][W][C], v1.1 later chunks,
  *   model_3dcausal_v1_1.py:293-300); VT_TPAD_ZERO_BACK: xp = [x, 0] instead (non-causal family,
- *   model_3dnoncausal.py:86-89).  x [B][Ti][HW][C] -> y [B][Ti/2][HW][C], same dtype.
+ *   model_3dnoncausal.py:86-89).  x [B][Ti][HW][C] -> y [B][Ti/2][HW][C] (floor: an odd Ti loses its
+ *   last frame, as avg_pool3d does), same dtype.
  * vt_time_lerp2x: F.interpolate(scale (2,1,1), "trilinear", align_corners=False) along T of a
  *   sequence of Ti frames -> 2*Ti frames (model_3dcausal_v1_1.py:327-341); fp32 arithmetic.
  * ---------------------------------------------------------------------------------------- */

@@ -424,7 +424,8 @@ extern "C" int vt_ndhwc_to_ncthw(const void* x, int in_dtype, float* y, int32_t 
 extern "C" int vt_time_avgpool3s2(const void* x, const void* cache, void* y, int dtype, int32_t B, int32_t Ti,
                                   int64_t HW, int32_t C, int32_t tmode, vt_stream stream_) {
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
-  VT_CHECK_ARG(x && y && B > 0 && Ti >= 2 && (Ti % 2) == 0 && HW > 0 && C > 0, "vt_time_avgpool3s2: bad dims (Ti=%d)", Ti);
+  // To = Ti / 2 (floor): an odd Ti drops its last frame, as avg_pool3d(kernel 3, stride 2) over Ti + 1 padded frames does
+  VT_CHECK_ARG(x && y && B > 0 && Ti >= 2 && HW > 0 && C > 0, "vt_time_avgpool3s2: bad dims (Ti=%d)", Ti);
   VT_CHECK_ARG((HW * C) % 4 == 0, "vt_time_avgpool3s2: frame size must be a multiple of 4 elements");
   VT_CHECK_ARG(tmode >= VT_TPAD_ZERO && tmode <= VT_TPAD_ZERO_BACK, "vt_time_avgpool3s2: tmode %d", tmode);
   VT_CHECK_ARG(tmode != VT_TPAD_CACHE || cache != nullptr, "vt_time_avgpool3s2: cache mode without cache");
