@@ -168,5 +168,15 @@ def test_conv_plan_tile_selection(built_lib, monkeypatch):
     monkeypatch.setenv("VT_CONV_WS", "0")
     assert ops.conv_plan(desc((256, 256), 128, 128))["kernel"] == "igemm"
     monkeypatch.delenv("VT_CONV_WS")
+    # the narrow-output kernel: the decoder's conv_out at the benchmark size (B = 4, 20 frames, 3 trimmed, 256 x 256)
+    co = dict(KT=3, pt=2, ldw=27 * 128, out_dtype=L.VT_F32, out_layout=L.VT_NCTHW, t_trim=3, B=4, Ti=20, To=20)
+    p = ops.conv_plan(desc((256, 256), 128, 3, **co))
+    assert p["kernel"] == "narrow" and p["tile"] == (8 * 14, 16) and p["launches"] == 1
+    assert p["workgroups"] == 4 * 2 * 32 * 5                     # clips x time segments x row blocks x groups of 4 windows
+    assert ops.conv_plan(desc((256, 256), 128, 3, **dict(co, out_layout=L.VT_NDHWC, t_trim=0, ldy=4)))["kernel"] == "igemm"
+    assert ops.conv_plan(desc((256, 256), 128, 8, **co))["kernel"] == "igemm"
+    monkeypatch.setenv("VT_CONV_NARROW", "0")
+    assert ops.conv_plan(desc((256, 256), 128, 3, **co))["kernel"] == "igemm"
+    monkeypatch.delenv("VT_CONV_NARROW")
     with pytest.raises(L.VtError):
         ops.conv_plan(desc((64, 64), 100, 128))                  # same validation as vt_conv

@@ -335,6 +335,33 @@ def test_engine_graph_cache_replays_bit_exact(name, shape, dtype):
     assert not torch.equal(outs[0], eager[0][1]) and torch.equal(outs[0], outs[1]) and torch.equal(outs[1], outs[2])
 
 
+@pytest.mark.parametrize("name,dtype,overlap", [("vidtok_v1_1/vidtok_kl_causal_488_16chn_v1_1", torch.bfloat16, True),
+                                                ("vidtok_v1_1/vidtok_fsq_causal_488_32768_v1_1", torch.float32, False)])
+def test_tiled_chunks_replay_bit_exact(name, dtype, overlap):
+    """v1.1 temporal tiling under enable_graphs(): chunks of a kind seen twice replay from a captured graph; the module
+    caches live in persistent buffers updated in place, so replays must equal the eager chunk loop bit for bit -- on the
+    first clip (eager / capture / replay mixed), on later clips (all replays) and on a clip of another length."""
+    model, cfg, sd = build_model(name, seed=14, device=DEV, dtype=dtype)
+    if hasattr(model.regularization, "sample"):
+        model.regularization.sample = False
+    model.use_tiling, model.t_chunk_enc, model.use_overlap = True, 8, overlap
+    model.t_chunk_dec = model.t_chunk_enc // model.encoder.time_downsample_factor
+    xs = [(torch.rand((1, 3, T, 64, 64), generator=torch.Generator().manual_seed(200 + i)) * 2 - 1).to(DEV)
+          for i, T in enumerate([41, 41, 29, 41])]                 # 1 + 5 x 8 frames; 1 + 3 x 8 + 4: a ragged last chunk
+    eager = [model(x) for x in xs]
+    model.enable_graphs()
+    for rnd in range(2):
+        for x, (z0, d0, l0) in zip(xs, eager):
+            z, d, l = model(x)
+            assert z.shape == z0.shape and d.shape == d0.shape
+            assert torch.equal(z, z0) and torch.equal(d, d0), (rnd, x.shape)
+            if "indices" in l0:
+                assert torch.equal(l["indices"], l0["indices"])
+    kinds = [e for e in model._genc.entries.values() if isinstance(e, tuple)]
+    assert len(kinds) >= 3                                         # first chunk, the chunk after it, the steady state
+    assert len([e for e in model._gdec.entries.values() if isinstance(e, tuple)]) >= 3
+
+
 @pytest.mark.parametrize("ov,T", [(dict(resamp_with_conv=False), 5), (dict(init_pad_mode="constant"), 6),
                                   (dict(init_pad_mode="reflect"), 6), (dict(tanh_out=True), 5), (dict(give_pre_end=True), 5)],
                          ids=["no_resamp_conv", "pad_constant", "pad_reflect", "tanh_out", "give_pre_end"])

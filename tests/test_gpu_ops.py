@@ -164,6 +164,45 @@ def test_conv_weight_stationary(case, ws, monkeypatch):
         assert plan["ln_fused"]
 
 
+GC = dict(kt=3, kh=3, kw=3, pt=1, pt_hi=1, ph=1, pw=1, ph_hi=1, pw_hi=1)    # centred in time (non-causal family)
+NARROW_CASES = [   # conv3d_narrow_kernel: bf16 -> fp32 NCTHW, Cin 128, Cout <= 4, 3x3x3
+    ("nw_conv_out_trim", (1, 8, 16, 16), 128, 3, (3, 3, 3), ConvGeom(**G333), dict(ncthw=3)),
+    ("nw_ragged_rows_cols", (2, 5, 20, 37), 128, 3, (3, 3, 3), ConvGeom(**G333), dict(ncthw=0)),      # H % 8, W % 14 != 0
+    ("nw_one_window", (1, 4, 8, 10), 128, 3, (3, 3, 3), ConvGeom(**G333), dict(ncthw=1)),            # W < 14, 3 idle waves
+    ("nw_single_frame", (1, 1, 8, 16), 128, 3, (3, 3, 3), ConvGeom(**G333), dict(ncthw=0)),
+    ("nw_replicate", (1, 6, 16, 30), 128, 3, (3, 3, 3), ConvGeom(**G333), dict(ncthw=0, tmode="replicate")),
+    ("nw_cache", (2, 4, 16, 16), 128, 3, (3, 3, 3), ConvGeom(**G333), dict(ncthw=0, tmode="cache")),
+    ("nw_centred", (1, 5, 16, 16), 128, 3, (3, 3, 3), ConvGeom(**GC), dict(ncthw=0)),
+    ("nw_cout4_nobias", (1, 4, 8, 16), 128, 4, (3, 3, 3), ConvGeom(**G333), dict(ncthw=0, nobias=True)),
+    ("nw_cout1", (1, 4, 8, 16), 128, 1, (3, 3, 3), ConvGeom(**G333), dict(ncthw=0)),
+    ("nw_time_segments", (1, 20, 64, 64), 128, 3, (3, 3, 3), ConvGeom(**G333), dict(ncthw=3)),       # 17 frames in 2 segments
+    ("nw_segments_cache", (1, 14, 32, 32), 128, 3, (3, 3, 3), ConvGeom(**G333), dict(ncthw=0, tmode="cache")),
+    ("nw_full_frame", (1, 5, 256, 256), 128, 3, (3, 3, 3), ConvGeom(**G333), dict(ncthw=0)),
+]
+
+
+@pytest.mark.parametrize("nw", ["1", "0"], ids=["narrow", "igemm"])
+@pytest.mark.parametrize("case", NARROW_CASES, ids=[c[0] for c in NARROW_CASES])
+def test_conv_narrow_output(case, nw, monkeypatch):
+    monkeypatch.setenv("VT_CONV_NARROW", nw)
+    plan = _check_conv(case, torch.bfloat16)
+    assert plan["kernel"] == ("narrow" if nw == "1" else "igemm")
+
+
+def test_conv_narrow_is_tiling_independent():
+    """same clip alone and inside a batch, same frames in one time segment or two: bit-identical planes"""
+    name, (B, T, H, W), cin, cout, kdims, geom, ex = NARROW_CASES[9]
+    x = _act(2, T, H, W, cin, torch.bfloat16, 1)
+    wt = torch.randn((cout, cin) + tuple(kdims), generator=torch.Generator().manual_seed(2)) / math.sqrt(cin * 27)
+    w = pack_conv_weight(wt, torch.bfloat16, cin_stored=cin).to(DEV)
+    bias = _rand((cout,), torch.float32, 3, 0.1)
+    both = ops.conv(x, w, bias, geom, cout=cout, out_layout=L.VT_NCTHW, t_trim=3)
+    one = ops.conv(x[1:].contiguous(), w, bias, geom, cout=cout, out_layout=L.VT_NCTHW, t_trim=3)
+    assert torch.equal(both[1:], one)
+    late = ops.conv(x[1:].contiguous(), w, bias, geom, cout=cout, out_layout=L.VT_NCTHW, t_trim=12)   # 8 frames: one segment
+    assert torch.equal(late, one[:, :, 9:])
+
+
 TBLOCK_CASES = [  # (B, T, H, W), tmode, next norm (None | silu flag), keep_y
     ((1, 5, 8, 8), L.VT_TPAD_ZERO, None, True),
     ((2, 7, 16, 16), L.VT_TPAD_ZERO, True, True),
@@ -245,6 +284,7 @@ def test_weight_stationary_kernels_are_split_independent():
 
 def test_conv_weight_stationary_not_for_fp32_or_other_shapes():
     assert _check_conv(WS_CASES[0], torch.float32)["kernel"] == "igemm"
+    assert _check_conv(NARROW_CASES[0], torch.float32)["kernel"] == "igemm"
     assert _check_conv(("ws_ragged_w", (1, 1, 8, 24), 128, 128, (3, 3), ConvGeom(**G3), {}), torch.bfloat16)["kernel"] == "igemm"
 
 

@@ -884,6 +884,19 @@ inline bool ws128_eligible(const ConvArgs& a, int nbatch, bool bf16_io) {
   return true;
 }
 
+// Narrow-output 3x3x3 convolution (conv_narrow.hip): bf16 in, fp32 NCTHW out, Cin = 128, Cout <= 4 -- the decoder's
+// conv_out (reference model_3dcausal.py:862-870).  VT_CONV_NARROW=0 keeps it on the 256 x 32 implicit-GEMM tile.
+inline bool narrow_eligible(const ConvArgs& a, int nbatch, int dtype, int out_dtype, int ln_mode) {
+  if (dtype != VT_BF16 || out_dtype != VT_F32 || a.out_layout != VT_NCTHW || env_int("VT_CONV_NARROW", 1) == 0) return false;
+  if (a.Cin != 128 || a.Cout > 4 || a.KT != 3 || a.KH != 3 || a.KW != 3) return false;
+  if (a.st != 1 || a.sh != 1 || a.sw != 1 || a.ph != 1 || a.pw != 1 || a.pt < 1 || a.pt > 2) return false;
+  if (a.ups_t || a.ups_s || a.Ho != a.Hi || a.Wo != a.Wi || a.To != a.Ti) return false;
+  if (a.res_mode != VT_RES_NONE || ln_mode != 0 || nbatch != 1 || a.yt_mul != 1 || a.ys_mul == 2) return false;
+  if ((long long)a.Ho * a.Wo * 256 > (1ll << 30)) return false;
+  if (a.tmode == VT_TPAD_CACHE && a.ncache < a.pt) return false;
+  return true;
+}
+
 inline TileKind select_tile(const ConvArgs& a, int nbatch) {
   auto blocks = [&](int bm, int bn) {
     return (long long)((a.M + bm - 1) / bm) * ((a.Cout + bn - 1) / bn) * nbatch;
@@ -913,6 +926,8 @@ int dispatch_tile(const ConvArgs& a, int nbatch, hipStream_t stream) {
 }  // namespace
 
 extern "C" int vt_ws128_launch(const void* conv_args, void* stream);   // conv_ws128.hip
+extern "C" int vt_conv_narrow_launch(const void* conv_args, void* stream);   // conv_narrow.hip
+extern "C" void vt_conv_narrow_plan(const void* conv_args, int32_t* plan4);
 
 extern "C" int vt_conv_max_lds_bytes(void) { return 163840; }   // conv3x3_ws128_kernel: two patches + T = all of a CU's LDS
 
@@ -1023,7 +1038,7 @@ int conv_prepare(const vt_conv_desc* d, ConvArgs& a, bool& ln_fused, int& nbatch
 // What vt_conv(d) will do, without launching: out[0..1] = pixel x channel tile, out[2] = waves per workgroup,
 // out[3] = workgroups (tiles for the persistent kernel), out[4] = 1 when LayerNorm is produced by the conv kernel's
 // epilogue (0: second launch of vt_layernorm_act, or no LayerNorm requested), out[5] = kernel launches the call
-// performs, out[6] = kernel: 0 = conv_igemm_glds_kernel, 1 = conv3x3_ws128_kernel (weight-stationary), out[7] = 0.  Lets tests assert which
+// performs, out[6] = kernel: 0 = conv_igemm_glds_kernel, 1 = conv3x3_ws128_kernel (weight-stationary), 2 = conv3d_narrow_kernel, out[7] = 0.  Lets tests assert which
 // instantiation a parity case exercises and lets bench.py separate conv kernel time from LayerNorm passes.
 extern "C" int vt_conv_plan(const vt_conv_desc* d, int32_t* out8) {
   VT_CHECK_ARG(out8 != nullptr, "vt_conv_plan: null output");
@@ -1034,6 +1049,11 @@ extern "C" int vt_conv_plan(const vt_conv_desc* d, int32_t* out8) {
   if (rc != VT_OK) return rc;
   out8[6] = use_ws ? 1 : 0;
   out8[7] = 0;
+  if (narrow_eligible(a, nbatch, d->dtype, d->out_dtype, d->ln_mode)) {   // independent waves: 8 x 14 output pixels x all frames of a time segment
+    vt_conv_narrow_plan(&a, out8);
+    out8[4] = 0; out8[5] = 1; out8[6] = 2;
+    return VT_OK;
+  }
   if (use_ws) {   // persistent: 8 x 16-pixel tiles x all 128 channels, at most one workgroup per CU
     out8[0] = 128; out8[1] = 128; out8[2] = 4;
     out8[3] = (a.Wo / 16) * (a.Ho / 8) * a.B * a.To;
@@ -1058,6 +1078,7 @@ extern "C" int vt_conv(const vt_conv_desc* d, vt_stream stream_) {
   int rc = conv_prepare(d, a, ln_fused, nbatch, use_ws);
   if (rc != VT_OK) return rc;
   if (use_ws) return vt_ws128_launch(&a, stream_);
+  if (narrow_eligible(a, nbatch, d->dtype, d->out_dtype, d->ln_mode)) return vt_conv_narrow_launch(&a, stream_);
   const long long M = a.M;
   if (d->dtype == VT_F32) rc = dispatch_tile<float, float>(a, nbatch, stream);
   else if (d->out_dtype == VT_F32) rc = dispatch_tile<bf16_t, float>(a, nbatch, stream);

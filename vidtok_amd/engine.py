@@ -55,8 +55,8 @@ class AutoencodingEngine(nn.Module):
         if self.version == "v1_0" and self.use_tiling:
             raise NotImplementedError("temporal tiling exists only in the v1.1 models of the reference")
         self.use_graphs = False
-        self._genc = GraphedCall(lambda t: self.encoder(t))
-        self._gdec = GraphedCall(lambda t: self.decoder(t))
+        self._genc = GraphedCall(lambda t: self.encoder(t), lambda: self._chunk_state(self.encoder), self._set_chunk_state)
+        self._gdec = GraphedCall(lambda t: self.decoder(t), lambda: self._chunk_state(self.decoder), self._set_chunk_state)
         if verbose:
             _print0(f"[vidtok_amd.engine][AutoencodingEngine] Use ckpt_path: {ckpt_path}")
         if ckpt_path is not None:
@@ -90,6 +90,16 @@ class AutoencodingEngine(nn.Module):
     def load_state_dict(self, *a, **kw):
         self.invalidate_graphs()
         return super().load_state_dict(*a, **kw)
+
+    @staticmethod
+    def _chunk_state(root):
+        """[(module, its chunk-to-chunk cache)] of a sub-tree (v1.1 tiling; empty for v1.0 models)"""
+        return [(m, m.causal_cache) for m in root.modules() if hasattr(m, "causal_cache")]
+
+    @staticmethod
+    def _set_chunk_state(state):
+        for m, c in state:
+            m.causal_cache = c
 
     def _run_encoder(self, x):
         return self._genc(x, (self.encoder.compute_dtype,)) if self.use_graphs else self.encoder(x)
@@ -218,6 +228,17 @@ class AutoencodingEngineV11(AutoencodingEngine):
         c = torch.empty((x.shape[0], x.shape[1], end - start) + tuple(x.shape[3:]), dtype=torch.float32, device=x.device)
         return ops.ncthw_copy_frames(x, c, start, 0, end - start)
 
+    def _chunk_call(self, graphed, module, x, start, end, first):
+        """module(frames [start, end) of x).  With the graph cache on, a chunk replays once its kind has been seen
+        twice; the kind is the chunk shape plus everything that shapes the launch sequence: first / later chunk, the
+        cache offsets of an overlapped decode, and how many frames each module's cache holds right now (the chunk
+        after the single-frame first one meets shorter caches than the ones after it)."""
+        if not (self.use_graphs and x.is_cuda):
+            return module(self._chunk_of(x, start, end))
+        sig = tuple(0 if c is None else c.shape[1] for _, c in self._chunk_state(module))
+        key = (module.compute_dtype, "chunk", bool(first), bool(self.use_overlap), sig)
+        return graphed(x, key, stateful=True, frames=(start, end), borrow=True)
+
     def tile_encode(self, x: Any) -> Any:
         """chunks are encoded in order (module caches carry the causal state); their latents land in one preallocated
         tensor -- no list + torch.cat (autoencoder_v1_1.py:244-264)"""
@@ -225,7 +246,7 @@ class AutoencodingEngineV11(AutoencodingEngine):
         z, idx, logs, done = None, None, [], 0
         for i, (start, end) in enumerate(chunks):
             self._set_first_chunk(i == 0)
-            chunk_z = self.encoder(self._chunk_of(x, start, end))
+            chunk_z = self._chunk_call(self._genc, self.encoder, x, start, end, i == 0)
             chunk_z, chunk_log = self.regularization(chunk_z, n_steps=self.global_step // 2)
             if z is None:      # a chunk of n frames is front-padded to a multiple of f: ceil(n / f) latent frames
                 f = self.encoder.time_downsample_factor
@@ -293,7 +314,7 @@ class AutoencodingEngineV11(AutoencodingEngine):
         for idx, (start, end) in enumerate(chunks):
             self._set_first_chunk(idx == 0)
             look = self.use_overlap and end + 1 <= num_frames
-            chunk = self.decoder(self._chunk_of(z, start, end + 1 if look else end))
+            chunk = self._chunk_call(self._gdec, self.decoder, z, start, end + 1 if look else end, idx == 0)
             n = chunk.shape[2] - (f if look else 0)
             if out is None:   # first chunk (1 latent frame) yields 1 frame, every other latent frame f frames
                 total = n + sum(f * (e - s) for s, e in chunks[1:])

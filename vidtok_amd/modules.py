@@ -128,6 +128,11 @@ def Normalize(in_channels, norm_type="layernorm"):
     return GroupNorm32(in_channels) if norm_type == "groupnorm" else LayerNorm(in_channels, eps=1e-6)
 
 
+def _persistent_cache(module, shape, like):
+    """see _CausalState._persistent (the time resamplers carry a cache without being causal convolutions)"""
+    return _CausalState._persistent(module, shape, like)
+
+
 class _CausalState:
     """v1.1 chunk-to-chunk state shared by the causal convs (model_3dcausal_v1_1.py:155-178)."""
 
@@ -144,6 +149,18 @@ class _CausalState:
         if self.causal_cache is None or self.causal_cache.shape[1] < time_pad:
             raise RuntimeError("causal cache missing: run the first chunk with is_first_chunk=True")
         return L.VT_TPAD_CACHE, self.causal_cache
+
+    def _persistent(self, shape, like):
+        """The cache lives in one buffer per (module, shape), allocated on first use and rewritten in place afterwards:
+        a chunk of a given kind reads and writes the same addresses every time, which is what lets a captured chunk
+        (vidtok_amd/graphs.py) be replayed.  `causal_cache` (the reference's attribute, reset to None between clips) is
+        bound to the buffer after each update; `_cache_bufs` survives the reset."""
+        bufs = self.__dict__.setdefault("_cache_bufs", {})
+        key = (tuple(shape), like.dtype, like.device)
+        buf = bufs.get(key)
+        if buf is None:
+            buf = bufs[key] = torch.empty(tuple(shape), dtype=like.dtype, device=like.device)
+        return buf
 
     def _update_cache(self, x, time_pad):
         """Keep the last `time_pad` frames of padded[:len-cache_offset] where
@@ -162,16 +179,16 @@ class _CausalState:
                 src_x.append((j, 0))
             else:
                 src_c.append((j, q))
-        if not src_c:
-            new = ops.gather_frames(x, [i for _, i in src_x])
-        else:
-            # slots taken from the old cache come first (q grows with j), the ones from x after them: two gathers into
-            # one preallocated tensor, no concatenation
-            new = torch.empty((x.shape[0], P) + tuple(x.shape[2:]), dtype=x.dtype, device=x.device)
-            ops.gather_frames(self.causal_cache, [i for _, i in src_c], out=new, out_t0=src_c[0][0])
-            if src_x:
-                ops.gather_frames(x, [i for _, i in src_x], out=new, out_t0=src_x[0][0])
-        self.causal_cache = new
+        # slots taken from the old cache come first (q grows with j), the ones from x after them.  The old frames move
+        # inside the buffer they are read from: through a temporary (launches are stream-ordered, so the buffer is
+        # rewritten only after the copy -- and after the convolution that read it -- has finished)
+        kept = ops.gather_frames(self.causal_cache, [i for _, i in src_c]) if src_c else None
+        buf = self._persistent((x.shape[0], P) + tuple(x.shape[2:]), x)
+        if kept is not None:
+            ops.gather_frames(kept, list(range(len(src_c))), out=buf, out_t0=src_c[0][0])
+        if src_x:
+            ops.gather_frames(x, [i for _, i in src_x], out=buf, out_t0=src_x[0][0])
+        self.causal_cache = buf
 
 
 class CausalConv3d(nn.Module, _CausalState):
@@ -330,7 +347,7 @@ class TimeDownsampleResCausal2x(nn.Module):
                 x1 = ops.time_avgpool3s2(x, L.VT_TPAD_REPLICATE)
             else:
                 x1 = ops.time_avgpool3s2(x, L.VT_TPAD_CACHE, cache=self.causal_cache)
-            self.causal_cache = ops.gather_frames(x, [x.shape[1] - 1])
+            self.causal_cache = ops.gather_frames(x, [x.shape[1] - 1], out=_persistent_cache(self, (x.shape[0], 1) + tuple(x.shape[2:]), x))
         return _wrap(self.conv.run(x, dt, res=x1, res_mode=L.VT_RES_MIX, mix_factor=self.mix_factor.detach(),
                                    **_emit(next_norm)), next_norm)
 
@@ -364,10 +381,12 @@ class TimeUpsampleResCausal2x(nn.Module):
             xc = torch.empty((x.shape[0], Tc) + tuple(x.shape[2:]), dtype=x.dtype, device=x.device)   # [cache | x]
             ops.gather_frames(self.causal_cache, list(range(nc)), out=xc, out_t0=0)
             ops.gather_frames(x, list(range(T)), out=xc, out_t0=nc)
-            self.causal_cache = ops.gather_frames(xc, list(range(max(0, Tc - 2 * n), Tc - n)))
+            keep = list(range(max(0, Tc - 2 * n), Tc - n))       # (xc is a copy: the cache buffer is free to be rewritten)
+            self.causal_cache = ops.gather_frames(xc, keep, out=_persistent_cache(self, (x.shape[0], len(keep)) + tuple(x.shape[2:]), x))
             up = ops.time_lerp2x(xc)
             return ops.gather_frames(up, list(range(2 * n, 2 * Tc)))
-        self.causal_cache = ops.gather_frames(x, list(range(max(0, T - n), T)))
+        keep = list(range(max(0, T - n), T))
+        self.causal_cache = ops.gather_frames(x, keep, out=_persistent_cache(self, (x.shape[0], len(keep)) + tuple(x.shape[2:]), x))
         hn = min(n, T)
         up = torch.empty((x.shape[0], 2 * T) + tuple(x.shape[2:]), dtype=x.dtype, device=x.device)
         ops.time_lerp2x(ops.gather_frames(x, list(range(0, hn))), out=up, out_t0=0)              # head: its own interpolation

@@ -31,11 +31,11 @@ def _conv_launch(lib, d, what, keep=()):
 
 
 def conv_plan(d):
-    """vt_conv_plan(d) -> dict(tile=(BM, BN), waves, workgroups, ln_fused, launches, kernel="igemm" | "ws128")"""
+    """vt_conv_plan(d) -> dict(tile=(BM, BN), waves, workgroups, ln_fused, launches, kernel="igemm" | "ws128" | "narrow")"""
     out = (C.c_int32 * 8)()
     L.check(L.load().vt_conv_plan(C.byref(d), out), "vt_conv_plan")
     return dict(tile=(out[0], out[1]), waves=out[2], workgroups=out[3], ln_fused=bool(out[4]), launches=out[5],
-                kernel="ws128" if out[6] == 1 else "igemm")
+                kernel={1: "ws128", 2: "narrow"}.get(out[6], "igemm"))
 
 
 def replay_convs(record, conv_kernel_only=True):
