@@ -147,6 +147,9 @@ int vt_conv(const vt_conv_desc* d, vt_stream stream);
  * Cin = Cout = 128 bf16), 0}.  Validates `d` exactly like vt_conv.  Test / measurement aid: which kernel and
  * instantiation does a parity case exercise. */
 int vt_conv_plan(const vt_conv_desc* d, int32_t* out8);
+/* Measurement aid (scripts/conv_profile.py): vt_conv(d) on the bf16 8-wave 256 x 256 tile (no LayerNorm) with shader-clock
+ * stamps at the phase boundaries of K steps 8..11 of workgroup 0: stamps_out (device, 8*4*8 uint64) = [wave][step][stamp] */
+int vt_conv_profile(const vt_conv_desc* d, uint64_t* stamps_out, vt_stream stream);
 /* sizeof(vt_conv_desc) as compiled: lets a binding verify its struct mirror */
 int vt_conv_desc_size(void);
 
@@ -186,6 +189,9 @@ typedef struct vt_tblock_desc {
 int vt_tblock_desc_size(void);
 int vt_temporal_block_supported(const vt_tblock_desc* d);
 int vt_temporal_block(const vt_tblock_desc* d, vt_stream stream);
+/* Measurement aid (scripts/tblock_profile.py): the same launch (ln_next_mode 2, keep_y 1 only) with shader-clock
+ * stamps at the phase boundaries of four steps of workgroup 0: stamps_out (device, 4*4*16 uint64) = [wave][step][stamp] */
+int vt_temporal_block_profile(const vt_tblock_desc* d, uint64_t* stamps_out, vt_stream stream);
 
 /* ------------------------------------------------------------------------------------------
  * vt_layernorm_act -- per-position LayerNorm over C (eps inside the sqrt, biased variance,

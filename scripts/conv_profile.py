@@ -1,0 +1,55 @@
+"""Where does a K step of the 8-wave 256x256 implicit-GEMM tile spend its cycles?  Records the descriptor of a
+benchmark-sized layer (3x3x3 256->256 at 128x128, B=4, 20 frames: M = 1.3 M pixels, 108 K steps of 64), replays it
+through vt_conv_profile and prints, per wave of workgroup 0, the shader-clock ticks between phase boundaries of K steps
+8..11: [wait for my DMA pieces] [barrier] [address set-up of the step after next] [32 MFMAs with 8 DMA pieces and 24
+ds_read_b128 in between].  MFMA-bound time of a step: 32 MFMAs x 32 cycles = 1 024 per wave, two waves per SIMD."""
+import ctypes as C
+import math
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from vidtok_amd import lib as L  # noqa: E402
+from vidtok_amd import ops  # noqa: E402
+from vidtok_amd.ops import ConvGeom  # noqa: E402
+
+NAMES = ["wait my DMA (vmcnt)", "barrier", "prep_step (addresses)", "MFMAs + DMA issue + ds_read"]
+
+
+def main():
+    dev = "cuda:0"
+    cases = [("3x3x3 256->256 @128^2 (K = 6912)", (4, 20, 128, 128), 256, 256, ConvGeom(kt=3, kh=3, kw=3, pt=2, ph=1, pw=1, ph_hi=1, pw_hi=1), 27),
+             ("3x3 512->512 @64^2 (K = 4608)", (4, 10, 64, 64), 512, 512, ConvGeom(kh=3, kw=3, ph=1, pw=1, ph_hi=1, pw_hi=1), 9)]
+    for label, (B, T, H, W), cin, cout, geom, taps in cases:
+        torch.manual_seed(0)
+        x = torch.randn((B, T, H, W, cin), device=dev, dtype=torch.bfloat16)
+        w = (torch.randn((cout, taps * cin), device=dev) / math.sqrt(taps * cin)).to(torch.bfloat16)
+        bias = torch.randn((cout,), device=dev)
+        ops.CONV_RECORD = []
+        y = ops.conv(x, w, bias, geom, cout=cout)
+        rec, ops.CONV_RECORD = ops.CONV_RECORD, None
+        d = rec[0][0]
+        plan = ops.conv_plan(d)
+        stamps = torch.zeros((8, 4, 8), dtype=torch.int64, device=dev)
+        lib = L.load()
+        for _ in range(2):
+            L.check(lib.vt_conv_profile(C.byref(d), stamps.data_ptr(), None), "vt_conv_profile")
+        torch.cuda.synchronize()
+        s = stamps.cpu()
+        print(f"{label}: tile {plan['tile']}, {plan['workgroups']} workgroups")
+        for wv in range(8):
+            for st in range(4):
+                dl = [int(s[wv, st, k + 1] - s[wv, st, k]) for k in range(4)]
+                nxt = int(s[wv, st + 1, 0] - s[wv, st, 0]) if st < 3 else sum(dl)
+                print(f"  wave {wv} step {8 + st}: step period {nxt:6d} | " + " | ".join(f"{n} {v}" for n, v in zip(NAMES, dl)))
+        avg = [sum(int(s[wv, st, k + 1] - s[wv, st, k]) for wv in range(8) for st in range(4)) / 32 for k in range(4)]
+        per = sum(int(s[wv, st + 1, 0] - s[wv, st, 0]) for wv in range(8) for st in range(3)) / 24
+        print(f"  average step period {per:.0f} cycles (MFMA-bound: 2048 per SIMD = 2 waves x 32 MFMAs x 32); phases of one wave:")
+        for n, v in zip(NAMES, avg):
+            print(f"    {n:32s} {v:8.1f}")
+
+
+if __name__ == "__main__":
+    main()

@@ -68,6 +68,7 @@ struct ConvArgs {
   int hw_tiles;                // > 0: pixel tiles per frame, tile order (b, hw tile, t) -- see launch_variant
   unsigned x_bytes, w_bytes;   // BUF path: descriptor extents (0 = tensors too large, use pointers)
   long long xs_z, ws_z, ys_z, rs_z;
+  unsigned long long* prof;    // PROF instantiation only (vt_conv_profile): cycle stamps of workgroup 0
 };
 
 template <typename MT>

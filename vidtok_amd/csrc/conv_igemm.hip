@@ -415,7 +415,7 @@ __device__ __forceinline__ void conv_epilogue_lds256(const ConvArgs& p, f32x16 (
 //        below 4 GiB and no cache-mode time padding; otherwise the pointer form is used.
 // LN256  the 8-wave tile with the LayerNorm-fusing epilogue (conv_epilogue_lds256) -- its own instantiation: the mere
 //        presence of a second epilogue path slowed every 256-tile convolution by 8 % through register allocation (round 1)
-template <typename MT, typename TOut, int WAVES_M, int WAVES_N, int TM, int TN, bool FAST, int ROWB, int STAGES, bool BUF, bool LN256 = false>
+template <typename MT, typename TOut, int WAVES_M, int WAVES_N, int TM, int TN, bool FAST, int ROWB, int STAGES, bool BUF, bool LN256 = false, bool PROF = false, int SCHED = 0>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_igemm_glds_kernel(const ConvArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)   // device pass only: the host pass needs just the launch stub (buffer-descriptor types are device-only)
   constexpr int THREADS = 64 * WAVES_M * WAVES_N;   // 4 waves (128x128, 256x32/64 tiles) or 8 waves (256x256)
@@ -699,43 +699,88 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_igemm_glds_ker
   const int swz = ((lane & 31) >> SWZ_SHIFT) & (NS - 1);
   const int khalf = lane >> 5;
   constexpr int NM = KS * TM * TN;                    // MFMA groups (one per 16-B fragment pair) per stage
-  constexpr int MPP = (NM + IPS - 1) / IPS;           // ... per DMA piece
+  constexpr bool EIGHT_WAVES = (WAVES_M * WAVES_N == 8);
+  // SCHED 1 (8-wave tile; measured with vt_conv_profile, profiles/r02_igemm_step_cycles.txt): a K step of the plain
+  // schedule lasts ~3 590 cycles against 2 048 of MFMA work per SIMD -- the two waves of a SIMD sit in the same phase,
+  // the older one wins every arbitration, finishes its 32 MFMAs in ~1 550 cycles and then waits > 1 000 at the barrier
+  // while the younger one finishes alone (its DMA issue and ds_reads covered by nobody); and ~700 cycles per step pass
+  // with no MFMA at all: the last DMA piece is issued after the last MFMA and awaited at once, then barrier, then the
+  // address set-up of the next step.  So: all pieces go out in the FIRST half of the stage (they have the second half
+  // to land), the address set-up of the step after next runs in the middle of the stage (VALU in the other wave's MFMA
+  // shadow), and the two waves of a SIMD swap issue priority at half time.
+  constexpr bool S1 = SCHED == 1 && EIGHT_WAVES;
+  constexpr int FIRE_SPAN = S1 ? NM / 2 : NM;         // MFMA groups over which the DMA pieces of the next stage are spread
+  constexpr int MPP = (FIRE_SPAN + IPS - 1) / IPS;    // ... per DMA piece
+  const int wgrp = (tid >> 6) >> 2;                   // 8 waves: 0 = first wave of its SIMD, 1 = second
 
   // stage `stage` -> MFMAs; if FIRE, the IPS DMA pieces of the prepared step go to ring slot `dst`,
   // one after every MPP MFMA groups, so their issue cost hides under the matrix pipe.  Fragments are
   // read KSB sub-steps at a time (all of the stage for the 4-wave tiles, half for the 8-wave tile whose
   // 128 accumulators leave no room for 24 live fragments).
-  constexpr bool EIGHT_WAVES = (WAVES_M * WAVES_N == 8);
   constexpr int KSB = (TM * TN >= 8 && KS > 2) ? 2 : KS;
-  auto compute_stage = [&](int stage, auto fire_tag, bool fire_rt, int dst) {
+  auto compute_stage = [&](int stage, auto fire_tag, bool fire_rt, int dst, auto&& at_half) {
     constexpr bool FIRE = decltype(fire_tag)::value;
     const char* As = smem + stage * STAGE_BYTES + (wm * TM * 32) * ROWB + frag_row;
     const char* Bs = smem + stage * STAGE_BYTES + A_BYTES + (wn * TN * 32) * ROWB + frag_row;
+    if constexpr (S1) {
+      // fragments one 32-B sub-step ahead of the MFMAs that use them (two sets of TN + TM fragments, the register
+      // budget of the plain schedule's two-sub-step block): no LDS round trip in front of any MFMA but the first.
+      // Issue priority alternates between the two waves of a SIMD every sub-step: a fair share of the matrix pipe
+      // (left alone, the older wave wins every arbitration and its sibling finishes ~700 cycles later, alone).
+      u32x4 wf[2][TN], xf[2][TM];
+      auto read_frags = [&](int k, int set) {
+        const int slot = ((k * 2 + khalf) ^ swz) * 16;
 #pragma unroll
-    for (int k0 = 0; k0 < KS; k0 += KSB) {
-      u32x4 wf[KSB][TN], xf[KSB][TM];
+        for (int a = 0; a < TN; ++a) wf[set][a] = *reinterpret_cast<const u32x4*>(Bs + a * 32 * ROWB + slot);
 #pragma unroll
-      for (int kk = 0; kk < KSB; ++kk) {
-        const int slot = (((k0 + kk) * 2 + khalf) ^ swz) * 16;
+        for (int b = 0; b < TM; ++b) xf[set][b] = *reinterpret_cast<const u32x4*>(As + b * 32 * ROWB + slot);
+      };
+      read_frags(0, 0);
 #pragma unroll
-        for (int a = 0; a < TN; ++a) wf[kk][a] = *reinterpret_cast<const u32x4*>(Bs + a * 32 * ROWB + slot);
+      for (int k = 0; k < KS; ++k) {
+        if (((k ^ wgrp) & 1) == 0) __builtin_amdgcn_s_setprio(2);
+        else __builtin_amdgcn_s_setprio(0);
+        if (k + 1 < KS) read_frags(k + 1, (k + 1) & 1);
 #pragma unroll
-        for (int b = 0; b < TM; ++b) xf[kk][b] = *reinterpret_cast<const u32x4*>(As + b * 32 * ROWB + slot);
+        for (int qq = 0; qq < TM * TN; ++qq) {
+          const int a = qq / TM, b = qq % TM;
+          const int q = k * TM * TN + qq;
+          mma_step<MT>(wf[k & 1][a], xf[k & 1][b], acc[a][b]);
+          if (FIRE && (q + 1) % MPP == 0) {
+            const int piece = q / MPP;
+            if (piece < IPS && fire_rt) fire_piece(piece, dst);
+          }
+          if (q + 1 == NM / 2) at_half();
+        }
       }
+      __builtin_amdgcn_s_setprio(0);
+    } else {
 #pragma unroll
-      for (int qq = 0; qq < KSB * TM * TN; ++qq) {
-        const int kk = qq / (TM * TN), a = (qq / TM) % TN, b = qq % TM;
-        const int q = k0 * TM * TN + qq;
-        mma_step<MT>(wf[kk][a], xf[kk][b], acc[a][b]);
-        if (FIRE && (q + 1) % MPP == 0) {
-          const int piece = q / MPP;
-          if (piece < IPS && fire_rt) fire_piece(piece, dst);
+      for (int k0 = 0; k0 < KS; k0 += KSB) {
+        u32x4 wf[KSB][TN], xf[KSB][TM];
+#pragma unroll
+        for (int kk = 0; kk < KSB; ++kk) {
+          const int slot = (((k0 + kk) * 2 + khalf) ^ swz) * 16;
+#pragma unroll
+          for (int a = 0; a < TN; ++a) wf[kk][a] = *reinterpret_cast<const u32x4*>(Bs + a * 32 * ROWB + slot);
+#pragma unroll
+          for (int b = 0; b < TM; ++b) xf[kk][b] = *reinterpret_cast<const u32x4*>(As + b * 32 * ROWB + slot);
+        }
+#pragma unroll
+        for (int qq = 0; qq < KSB * TM * TN; ++qq) {
+          const int kk = qq / (TM * TN), a = (qq / TM) % TN, b = qq % TM;
+          const int q = k0 * TM * TN + qq;
+          mma_step<MT>(wf[kk][a], xf[kk][b], acc[a][b]);
+          if (FIRE && (q + 1) % MPP == 0) {
+            const int piece = q / MPP;
+            if (piece < IPS && fire_rt) fire_piece(piece, dst);
+          }
         }
       }
     }
     if (FIRE && fire_rt) {   // pieces the MFMA groups did not cover (more DMA pieces than MFMA groups: narrow tiles)
 #pragma unroll
-      for (int piece = NM / MPP; piece < IPS; ++piece) fire_piece(piece, dst);
+      for (int piece = FIRE_SPAN / MPP; piece < IPS; ++piece) fire_piece(piece, dst);
     }
   };
 
@@ -746,26 +791,52 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_igemm_glds_ker
 #pragma unroll
       for (int q = 0; q < IPS; ++q) fire_piece(q, d);
     }
+  if constexpr (S1) {                        // the addresses of a step are ready one stage before its pieces are fired
+    if (D < p.nsteps) prep_step(D);
+  }
   int stage = 0;
   const int n_fire = p.nsteps - D;          // steps that still have a successor to prefetch
+  // PROF (vt_conv_profile): s_memtime at the phase boundaries of K steps [8, 12) of workgroup 0, parked in the LDS
+  // behind the ring and copied out after the loop
+  unsigned long long* stamps = reinterpret_cast<unsigned long long*>(smem + STAGES * STAGE_BYTES);
+  int s_cur = 0;
+  auto stamp = [&](int k) {
+    if constexpr (PROF) {
+      if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && s_cur >= 8 && s_cur < 12) {
+        const unsigned long long ts = __builtin_amdgcn_s_memtime();
+        if (lane == 0) stamps[((s_cur - 8) * (THREADS / 64) + (tid >> 6)) * 8 + k] = ts;
+      }
+    }
+  };
   for (int s = 0; s < p.nsteps; ++s) {
+    s_cur = s;
+    stamp(0);
     // my DMA pieces of step s have landed once at most `newer` younger steps are still outstanding
     const int newer = min(D - 1, p.nsteps - 1 - s);
     if (D >= 3 && newer >= 2) wait_vmcnt<2 * IPS>();
     else if (D >= 2 && newer >= 1) wait_vmcnt<IPS>();
     else wait_vmcnt<0>();
+    stamp(1);
     __builtin_amdgcn_s_barrier();   // everyone's have; and everyone finished reading the slot refilled next
     asm volatile("" ::: "memory");
+    stamp(2);
     // exactly ONE instantiation of the MFMA body per kernel: with two (a firing and a non-firing copy)
     // the register allocator parked the accumulators in VGPRs across the loop edge and copied all of
     // them to AGPRs and back every step (128 v_accvgpr moves per 16 MFMAs).
     const bool fire = s < n_fire;
-    if (fire) prep_step(s + D);
-    else if (BUF) ext_x = ext_w = 0u;        // past the last prefetch: the pieces below turn into zero fills
+    if constexpr (!S1) {
+      if (fire) prep_step(s + D);
+    }
+    if (!fire && BUF) ext_x = ext_w = 0u;    // past the last prefetch: the pieces below turn into zero fills
     const bool fire_rt = BUF || fire;        // pointer form keeps the uniform branch around its pieces
+    stamp(3);
     if (EIGHT_WAVES) {
       // 8-wave tile: the DMA pieces are issued between MFMA groups; measured 7 % faster than issuing them up front
-      compute_stage(stage, TagTrue{}, fire_rt, (stage + D) % STAGES);
+      compute_stage(stage, TagTrue{}, fire_rt, (stage + D) % STAGES, [&]() {
+        if constexpr (S1) {
+          if (s + 1 < n_fire) prep_step(s + 1 + D);   // all pieces of step s + D are out: their registers are free
+        }
+      });
     } else {
       // 4-wave tiles: two workgroups share the CU and cover each other's DMA issue, and the prefetch is
       // only one step deep, so the whole next stage is requested first (interleaving measured 10-20 % slower)
@@ -773,11 +844,18 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_igemm_glds_ker
 #pragma unroll
         for (int q = 0; q < IPS; ++q) fire_piece(q, (stage + D) % STAGES);
       }
-      compute_stage(stage, TagFalse{}, false, 0);
+      compute_stage(stage, TagFalse{}, false, 0, []() {});
     }
     stage = (stage + 1 == STAGES) ? 0 : stage + 1;
+    stamp(4);
   }
   if constexpr (BUF) wait_vmcnt<0>();   // the trailing zero-fill pieces must land before the LDS allocation is released
+  if constexpr (PROF) {
+    if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && lane == 0 && p.prof != nullptr) {
+      constexpr int NW = THREADS / 64;
+      for (int i = 0; i < 4 * 8; ++i) p.prof[(tid >> 6) * 32 + i] = stamps[((i / 8) * NW + (tid >> 6)) * 8 + (i % 8)];
+    }
+  }
   if constexpr (LN256) {
     static_assert(WAVES_M == 4 && WAVES_N == 2 && TM == 2 && TN == 4 && std::is_same<MT, TOut>::value, "LN256: the 8-wave 256 x 256 tile");
     if constexpr (!BUF) wait_vmcnt<0>();
@@ -833,25 +911,44 @@ int launch_variant(const ConvArgs& a_in, int nbatch, hipStream_t stream) {
   const bool buf = conv_buf() && xb < 0xFFFF0000ull && wb < 0xFFFF0000ull && a.tmode != VT_TPAD_CACHE &&
                    a.KH <= 8 && a.KW <= 8;   // the per-row padding mask of the FAST form holds 8 bits per axis
   const void* kern;
+  // VT_CONV_SCHED=0: the plain K-step schedule of the 8-wave tile (A/B runs); default 1, see the kernel
+  constexpr bool HAS_S1 = WAVES_M * WAVES_N == 8 && FAST;
+  const bool s1 = HAS_S1 && buf && env_int("VT_CONV_SCHED", 1) != 0;
   if (buf) {
     a.x_bytes = (unsigned)xb;
     a.w_bytes = (unsigned)wb;
     kern = reinterpret_cast<const void*>(&conv_igemm_glds_kernel<MT, TOut, WAVES_M, WAVES_N, TM, TN, FAST, ROWB, STAGES, true, LN256>);
+    if constexpr (HAS_S1) {
+      if (s1) kern = reinterpret_cast<const void*>(&conv_igemm_glds_kernel<MT, TOut, WAVES_M, WAVES_N, TM, TN, FAST, ROWB, STAGES, true, LN256, false, 1>);
+    }
   } else {
     kern = reinterpret_cast<const void*>(&conv_igemm_glds_kernel<MT, TOut, WAVES_M, WAVES_N, TM, TN, FAST, ROWB, STAGES, false, LN256>);
   }
+  int lds_bytes = LDS;
+  if (a.prof != nullptr) {   // vt_conv_profile: only the plain 8-wave bf16 instantiation carries the stamps
+    if constexpr (std::is_same<MT, bf16_t>::value && std::is_same<TOut, bf16_t>::value && WAVES_M == 4 && WAVES_N == 2 && FAST && !LN256) {
+      VT_CHECK_ARG(buf, "vt_conv_profile: descriptor gather only");
+      kern = s1 ? reinterpret_cast<const void*>(&conv_igemm_glds_kernel<MT, TOut, WAVES_M, WAVES_N, TM, TN, FAST, ROWB, STAGES, true, false, true, 1>)
+                : reinterpret_cast<const void*>(&conv_igemm_glds_kernel<MT, TOut, WAVES_M, WAVES_N, TM, TN, FAST, ROWB, STAGES, true, false, true, 0>);
+      lds_bytes = LDS + 4096;
+      VT_CHECK_HIP(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+    } else {
+      VT_CHECK_ARG(false, "vt_conv_profile: only the bf16 8-wave 256 x 256 tile without fused LayerNorm is instrumented");
+    }
+  }
   // the attribute is per device: one flag per (instantiation, gather form, device), set race-free
-  static std::atomic<bool> attr_done[2][kMaxDevices];
+  static std::atomic<bool> attr_done[3][kMaxDevices];
+  const int ki = buf ? (s1 ? 2 : 1) : 0;
   int dev = 0;
   VT_CHECK_HIP(hipGetDevice(&dev));
-  if (dev < 0 || dev >= kMaxDevices || !attr_done[buf][dev].load(std::memory_order_acquire)) {
+  if (dev < 0 || dev >= kMaxDevices || !attr_done[ki][dev].load(std::memory_order_acquire)) {
     VT_CHECK_HIP(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
-    if (dev >= 0 && dev < kMaxDevices) attr_done[buf][dev].store(true, std::memory_order_release);
+    if (dev >= 0 && dev < kMaxDevices) attr_done[ki][dev].store(true, std::memory_order_release);
   }
   const long long nblk = (long long)a.m_tiles * a.n_tiles;
   VT_CHECK_ARG(nblk < (1ll << 31), "vt_conv: too many tiles (%lld)", nblk);
   void* kargs[] = {&a};
-  VT_CHECK_HIP(hipLaunchKernel(kern, dim3((unsigned)nblk, 1, (unsigned)nbatch), dim3(THREADS), kargs, LDS, stream));
+  VT_CHECK_HIP(hipLaunchKernel(kern, dim3((unsigned)nblk, 1, (unsigned)nbatch), dim3(THREADS), kargs, lds_bytes, stream));
   return VT_OK;
 }
 
@@ -1068,6 +1165,21 @@ extern "C" int vt_conv_plan(const vt_conv_desc* d, int32_t* out8) {
   out8[4] = ln_fused ? 1 : 0;
   out8[5] = (d->ln_mode != 0 && !ln_fused) ? 2 : 1;
   return VT_OK;
+}
+
+// Measurement aid (scripts/conv_profile.py): vt_conv on the 8-wave 256 x 256 bf16 tile with shader-clock stamps at the
+// phase boundaries of K steps 8..11 of workgroup 0; stamps_out (device, 8 waves x 4 steps x 8 uint64).
+extern "C" int vt_conv_profile(const vt_conv_desc* d, uint64_t* stamps_out, vt_stream stream_) {
+  VT_CHECK_ARG(stamps_out != nullptr, "vt_conv_profile: null output");
+  ConvArgs a;
+  bool ln_fused = false, use_ws = false;
+  int nbatch = 1;
+  const int rc = conv_prepare(d, a, ln_fused, nbatch, use_ws);
+  if (rc != VT_OK) return rc;
+  VT_CHECK_ARG(!use_ws && d->dtype == VT_BF16 && d->out_dtype == VT_BF16 && d->ln_mode == 0 && select_tile(a, nbatch) == TILE_256x256,
+               "vt_conv_profile: bf16 launches on the 256 x 256 tile without LayerNorm only");
+  a.prof = reinterpret_cast<unsigned long long*>(stamps_out);
+  return dispatch_tile<bf16_t, bf16_t>(a, nbatch, reinterpret_cast<hipStream_t>(stream_));
 }
 
 extern "C" int vt_conv(const vt_conv_desc* d, vt_stream stream_) {

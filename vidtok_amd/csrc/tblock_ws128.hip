@@ -49,7 +49,11 @@ struct TBlockArgs {
   int keep_y;         // write y (0 only with ln_next != 0: the consumer needs just the normalised tensor)
   int ln_next;        // 0 none, 1 LayerNorm, 2 LayerNorm + SiLU
   float eps;
+  unsigned long long* prof;   // PROF instantiation only (vt_temporal_block_profile): cycle stamps of workgroup 0
+  int prof_mode;              // PROF only: 1 = row jobs skipped (wrong results; times the bare GEMMs), VT_TBLOCK_PROF_MODE
 };
+[[maybe_unused]] constexpr int TB_PROF_STEPS = 4, TB_PROF_FIRST = 8, TB_PROF_STAMPS = 16;
+[[maybe_unused]] constexpr int TB_PROF_BYTES = TB_PROF_STEPS * 4 * TB_PROF_STAMPS * 8;
 
 template <int I, int N, typename F>
 __device__ __forceinline__ void tb_static_for(F&& f) {
@@ -66,37 +70,65 @@ __device__ __forceinline__ void tb_mfma(const u32x4& w, const u32x4& x, f32x16& 
   else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "a"(w), "v"(x));
 }
 
-// LayerNorm (+SiLU) of one pixel row held by 16 lanes x 8 channels; two-pass statistics like layernorm_act_kernel
+// LayerNorm (+SiLU) of one pixel row held by 16 lanes x 8 channels; two-pass statistics like layernorm_act_kernel.
 // Every row phase exists twice -- sliced into MFMA shadows, and plain (first / last step of a workgroup, steps with
-// skipped taps) -- so the arithmetic is spelled with explicit-rounding intrinsics: context-dependent FMA contraction
-// would make a pixel's bits depend on which version computed it, i.e. on how columns were split over workgroups.
-__device__ __forceinline__ float tb_affine_act(float d, float rstd, float g, float b, bool silu) {
-  const float u = __fmaf_rn(__fmul_rn(d, rstd), g, b);
-  return silu ? silu_fast(u) : u;
+// skipped taps) -- so nothing here may depend on FMA contraction (off for this file; fused multiply-adds are spelled
+// out): a pixel's bits must not depend on which version computed it, i.e. on how columns were split over workgroups.
+//
+// The block is bound by its VALU work, not by the MFMAs (three LayerNorm+SiLU per element against 2 x 24 MFMAs per 64
+// pixels: per step and wave ~1200 VALU + 200 transcendental instructions = ~8 000 issue cycles against 3 072 MFMA
+// cycles, counted on the ISA), so the row arithmetic runs on channel PAIRS: v_pk_add / v_pk_mul / v_pk_fma_f32 carry two
+// elements per instruction, one v_cvt_pk_bf16_f32 packs a pair; only exp and rcp stay per element.
+#pragma clang fp contract(off)
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 tb_bf16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 tb_unpack2(uint32_t w) {            // bf16 pair (low half = even channel) -> fp32 pair
+  f32x2 r;
+  r[0] = __uint_as_float(w << 16);
+  r[1] = __uint_as_float(w & 0xffff0000u);
+  return r;
+}
+__device__ __forceinline__ uint32_t tb_pack2(f32x2 v) {              // round-to-nearest-even, one v_cvt_pk_bf16_f32
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, tb_bf16x2));
+}
+__device__ __forceinline__ f32x2 tb_silu2(f32x2 u) {                 // u * sigmoid(u), the arithmetic of silu_fast
+  const f32x2 t = u * -1.4426950408889634f;
+  f32x2 e;
+  e[0] = __builtin_amdgcn_exp2f(t[0]);
+  e[1] = __builtin_amdgcn_exp2f(t[1]);
+  const f32x2 d = e + 1.0f;
+  f32x2 r;
+  r[0] = __builtin_amdgcn_rcpf(d[0]);
+  r[1] = __builtin_amdgcn_rcpf(d[1]);
+  return u * r;
+}
+__device__ __forceinline__ f32x2 tb_affine_act2(f32x2 d, float rstd, f32x2 g, f32x2 b, bool silu) {
+  const f32x2 u = __builtin_elementwise_fma(d * rstd, g, b);
+  return silu ? tb_silu2(u) : u;
 }
 template <bool SILU>
-__device__ __forceinline__ void tb_row_norm(float (&v)[8], const float (&g)[8], const float (&b)[8], float eps, float (&o)[8]) {
-  float s = 0.f;
+__device__ __forceinline__ void tb_row_norm2(f32x2 (&v)[4], const f32x2 (&g)[4], const f32x2 (&b)[4], float eps, f32x2 (&o)[4]) {
+  f32x2 s = v[0];
 #pragma unroll
-  for (int e = 0; e < 8; ++e) s = __fadd_rn(s, v[e]);
-  const float mean = group_sum_dpp<16>(s) * (1.0f / 128.0f);
-  float q = 0.f;
-  float d[8];
+  for (int q = 1; q < 4; ++q) s = s + v[q];
+  const float mean = group_sum_dpp<16>(s[0] + s[1]) * (1.0f / 128.0f);
+  f32x2 d[4], qq = {0.f, 0.f};
 #pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    d[e] = __fsub_rn(v[e], mean);
-    q = __fmaf_rn(d[e], d[e], q);
+  for (int q = 0; q < 4; ++q) {
+    d[q] = v[q] - mean;
+    qq = __builtin_elementwise_fma(d[q], d[q], qq);
   }
-  const float rstd = __builtin_amdgcn_rsqf(__fmaf_rn(group_sum_dpp<16>(q), 1.0f / 128.0f, eps));
+  const float rstd = __builtin_amdgcn_rsqf(__builtin_fmaf(group_sum_dpp<16>(qq[0] + qq[1]), 1.0f / 128.0f, eps));
 #pragma unroll
-  for (int e = 0; e < 8; ++e) o[e] = tb_affine_act(d[e], rstd, g[e], b[e], SILU);
+  for (int q = 0; q < 4; ++q) o[q] = tb_affine_act2(d[q], rstd, g[q], b[q], SILU);
 }
 
 // "This value exists HERE" (see conv_ws128.hip): keeps a slice of row arithmetic in the MFMA shadow the source put it in
 __device__ __forceinline__ void tb_pin(float& v) { asm volatile("" : "+v"(v)); }
+__device__ __forceinline__ void tb_pin2(f32x2& v) { asm volatile("" : "+v"(v)); }
 
 // LNN: next norm 0 none / 1 LayerNorm / 2 LayerNorm+SiLU; KEEP: y is written
-template <int LNN, bool KEEP>
+template <int LNN, bool KEEP, bool PROF = false>
 __global__ __launch_bounds__(256, 1) void tblock_ws128_kernel(const TBlockArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr bool ACC_A = true;
@@ -128,16 +160,19 @@ __global__ __launch_bounds__(256, 1) void tblock_ws128_kernel(const TBlockArgs p
   }
   // ---- per-lane row geometry: rows row0 + 16*it (it < 4), channels [8 oct_j, +8) -------------------------------------
   const int oct_j = tid & 15, row0 = tid >> 4;
-  float lg1[8], lb1[8], lg2[8], lb2[8], lgn[8], lbn[8], bo1[8], bo2[8];
+  f32x2 lg1[4], lb1[4], lg2[4], lb2[4], lgn[4], lbn[4], bo1[4], bo2[4];   // channel pairs (8 oct_j + 2q, + 1)
 #pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    lg1[e] = p.g1[8 * oct_j + e]; lb1[e] = p.be1[8 * oct_j + e];
-    lg2[e] = p.g2[8 * oct_j + e]; lb2[e] = p.be2[8 * oct_j + e];
-    lgn[e] = LNN ? p.gn[8 * oct_j + e] : 1.0f;
-    lbn[e] = LNN ? p.ben[8 * oct_j + e] : 0.0f;
-    bo1[e] = p.b1 ? p.b1[8 * oct_j + e] : 0.0f;
-    bo2[e] = p.b2 ? p.b2[8 * oct_j + e] : 0.0f;
-  }
+  for (int q = 0; q < 4; ++q)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int c = 8 * oct_j + 2 * q + h;
+      lg1[q][h] = p.g1[c]; lb1[q][h] = p.be1[c];
+      lg2[q][h] = p.g2[c]; lb2[q][h] = p.be2[c];
+      lgn[q][h] = LNN ? p.gn[c] : 1.0f;
+      lbn[q][h] = LNN ? p.ben[c] : 0.0f;
+      bo1[q][h] = p.b1 ? p.b1[c] : 0.0f;
+      bo2[q][h] = p.b2 ? p.b2[c] : 0.0f;
+    }
   const int frag_off = (lane & 31) * TB_ROWP + (lane >> 5) * 16;     // B-fragment of pixel lane%32, k half lane/32
   const int row_lds = oct_j * 16;                                    // + row * TB_ROWP : this lane's 16 B of a ring row
   auto col_base = [&](int col) -> long long {                        // element offset of (b, frame 0, first pixel of the tile)
@@ -150,9 +185,16 @@ __global__ __launch_bounds__(256, 1) void tblock_ws128_kernel(const TBlockArgs p
   // ---- row jobs, cut into 48 slices (4 row iterations x 12) so that a GEMM of 48 MFMAs can carry one per shadow ----
   // (with one wave per SIMD nothing else overlaps this block's three LayerNorm+SiLU per element with its MFMAs:
   //  measured on the unsliced version: issuing 55 % of the wave cycles, MFMA busy 21 %)
-  float rv[8], rsum = 0.f, rmean = 0.f, rrstd = 0.f;
+  f32x2 rv[4], rsum = {0.f, 0.f};
+  float rmean = 0.f, rrstd = 0.f;
   f32x4 rt0, rt1;
   Oct<bf16_t> xp[4], xc[4], xn[4];   // x rows of the previous step (residual of its OUT job), this step, the next (prefetch)
+  auto store_row = [&](bf16_t* dst) {                                // rv -> 8 bf16 channels of one pixel row
+    u32x4 w;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) w[q] = tb_pack2(rv[q]);
+    *reinterpret_cast<u32x4*>(dst) = w;
+  };
   // OUT job of step `vp` (its conv2 result sits in T): + b2 + x -> y store; LayerNorm_next -> n store
   long long out_base = 0;          // element offset of (frame of vp, row 0 of the tile) + 8 oct_j
   auto job_out = [&](auto slot_c, Oct<bf16_t> (&xrows)[4]) {
@@ -165,46 +207,45 @@ __global__ __launch_bounds__(256, 1) void tblock_ws128_kernel(const TBlockArgs p
       rt0 = *reinterpret_cast<const f32x4*>(T + row * 128 + (((2 * oct_j) ^ sw) << 2));
       rt1 = *reinterpret_cast<const f32x4*>(T + row * 128 + (((2 * oct_j + 1) ^ sw) << 2));
     } else if constexpr (s == 1 || s == 2) {
-      if constexpr (s == 1) rsum = 0.f;
+      if constexpr (s == 1) rsum = f32x2{0.f, 0.f};
 #pragma unroll
-      for (int e = 4 * (s - 1); e < 4 * (s - 1) + 4; ++e) {
-        rv[e] = __fadd_rn(xr.get(e), __fadd_rn(e < 4 ? rt0[e] : rt1[e - 4], bo2[e]));
-        rsum = __fadd_rn(rsum, rv[e]);
-        tb_pin(rv[e]);
+      for (int q = 2 * (s - 1); q < 2 * (s - 1) + 2; ++q) {
+        const f32x2 tq = q < 2 ? f32x2{rt0[2 * q], rt0[2 * q + 1]} : f32x2{rt1[2 * (q - 2)], rt1[2 * (q - 2) + 1]};
+        rv[q] = tb_unpack2(xr.w[q]) + (tq + bo2[q]);
+        rsum = rsum + rv[q];
+        tb_pin2(rv[q]);
       }
-      tb_pin(rsum);
+      tb_pin2(rsum);
     } else if constexpr (s == 3) {
-      if constexpr (KEEP) Oct<bf16_t>::store(p.y + out_base + (long long)row * 128, rv);
+      if constexpr (KEEP) store_row(p.y + out_base + (long long)row * 128);
       if constexpr (LNN != 0) {
-        rmean = group_sum_dpp<16>(rsum) * (1.0f / 128.0f);
+        rmean = group_sum_dpp<16>(rsum[0] + rsum[1]) * (1.0f / 128.0f);
         tb_pin(rmean);
       }
     } else if constexpr (s == 4 || s == 5) {
       if constexpr (LNN != 0) {
-        if constexpr (s == 4) rsum = 0.f;
+        if constexpr (s == 4) rsum = f32x2{0.f, 0.f};
 #pragma unroll
-        for (int e = 4 * (s - 4); e < 4 * (s - 4) + 4; ++e) {
-          rv[e] = __fsub_rn(rv[e], rmean);
-          rsum = __fmaf_rn(rv[e], rv[e], rsum);
-          tb_pin(rv[e]);
+        for (int q = 2 * (s - 4); q < 2 * (s - 4) + 2; ++q) {
+          rv[q] = rv[q] - rmean;
+          rsum = __builtin_elementwise_fma(rv[q], rv[q], rsum);
+          tb_pin2(rv[q]);
         }
-        tb_pin(rsum);
+        tb_pin2(rsum);
       }
     } else if constexpr (s == 6) {
       if constexpr (LNN != 0) {
-        rrstd = __builtin_amdgcn_rsqf(__fmaf_rn(group_sum_dpp<16>(rsum), 1.0f / 128.0f, p.eps));
+        rrstd = __builtin_amdgcn_rsqf(__builtin_fmaf(group_sum_dpp<16>(rsum[0] + rsum[1]), 1.0f / 128.0f, p.eps));
         tb_pin(rrstd);
       }
     } else if constexpr (s >= 7 && s <= 10) {
       if constexpr (LNN != 0) {
-#pragma unroll
-        for (int e = 2 * (s - 7); e < 2 * (s - 7) + 2; ++e) {
-          rv[e] = tb_affine_act(rv[e], rrstd, lgn[e], lbn[e], LNN == 2);
-          tb_pin(rv[e]);
-        }
+        constexpr int q = s - 7;
+        rv[q] = tb_affine_act2(rv[q], rrstd, lgn[q], lbn[q], LNN == 2);
+        tb_pin2(rv[q]);
       }
     } else {
-      if constexpr (LNN != 0) Oct<bf16_t>::store(p.n_out + out_base + (long long)row * 128, rv);
+      if constexpr (LNN != 0) store_row(p.n_out + out_base + (long long)row * 128);
     }
   };
   // LN1 job of step `vn` (its x rows are in xs[vn % 3]): LayerNorm1 + SiLU -> ring1[tn % 3]
@@ -214,39 +255,37 @@ __global__ __launch_bounds__(256, 1) void tblock_ws128_kernel(const TBlockArgs p
     const int row = row0 + 16 * it;
     Oct<bf16_t>& xr = xn[it];
     if constexpr (s == 1 || s == 2) {
-      if constexpr (s == 1) rsum = 0.f;
+      if constexpr (s == 1) rsum = f32x2{0.f, 0.f};
 #pragma unroll
-      for (int e = 4 * (s - 1); e < 4 * (s - 1) + 4; ++e) {
-        rv[e] = xr.get(e);
-        rsum = __fadd_rn(rsum, rv[e]);
-        tb_pin(rv[e]);
+      for (int q = 2 * (s - 1); q < 2 * (s - 1) + 2; ++q) {
+        rv[q] = tb_unpack2(xr.w[q]);
+        rsum = rsum + rv[q];
+        tb_pin2(rv[q]);
       }
-      tb_pin(rsum);
+      tb_pin2(rsum);
     } else if constexpr (s == 3) {
-      rmean = group_sum_dpp<16>(rsum) * (1.0f / 128.0f);
+      rmean = group_sum_dpp<16>(rsum[0] + rsum[1]) * (1.0f / 128.0f);
       tb_pin(rmean);
     } else if constexpr (s == 4 || s == 5) {
-      if constexpr (s == 4) rsum = 0.f;
+      if constexpr (s == 4) rsum = f32x2{0.f, 0.f};
 #pragma unroll
-      for (int e = 4 * (s - 4); e < 4 * (s - 4) + 4; ++e) {
-        rv[e] = __fsub_rn(rv[e], rmean);
-        rsum = __fmaf_rn(rv[e], rv[e], rsum);
-        tb_pin(rv[e]);
+      for (int q = 2 * (s - 4); q < 2 * (s - 4) + 2; ++q) {
+        rv[q] = rv[q] - rmean;
+        rsum = __builtin_elementwise_fma(rv[q], rv[q], rsum);
+        tb_pin2(rv[q]);
       }
-      tb_pin(rsum);
+      tb_pin2(rsum);
     } else if constexpr (s == 6) {
-      rrstd = __builtin_amdgcn_rsqf(__fmaf_rn(group_sum_dpp<16>(rsum), 1.0f / 128.0f, p.eps));
+      rrstd = __builtin_amdgcn_rsqf(__builtin_fmaf(group_sum_dpp<16>(rsum[0] + rsum[1]), 1.0f / 128.0f, p.eps));
       tb_pin(rrstd);
     } else if constexpr (s >= 7 && s <= 10) {
-#pragma unroll
-      for (int e = 2 * (s - 7); e < 2 * (s - 7) + 2; ++e) {
-        rv[e] = tb_affine_act(rv[e], rrstd, lg1[e], lb1[e], true);
-        tb_pin(rv[e]);
-      }
+      constexpr int q = s - 7;
+      rv[q] = tb_affine_act2(rv[q], rrstd, lg1[q], lb1[q], true);
+      tb_pin2(rv[q]);
     } else if constexpr (s == 11) {
       u32x4 w;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) w[e] = f32_to_bf16_bits(rv[2 * e]) | (f32_to_bf16_bits(rv[2 * e + 1]) << 16);
+      for (int q = 0; q < 4; ++q) w[q] = tb_pack2(rv[q]);
       *reinterpret_cast<u32x4*>(ring1 + (tn % 3) * TB_SLOT + row * TB_ROWP + row_lds) = w;
     }
   };
@@ -316,17 +355,17 @@ __global__ __launch_bounds__(256, 1) void tblock_ws128_kernel(const TBlockArgs p
       }
     }
   };
-  auto T_row = [&](int row, float (&v)[8]) {
+  auto T_row = [&](int row, f32x2 (&v)[4]) {
     const int sw = row & 31;
     const f32x4 t0 = *reinterpret_cast<const f32x4*>(T + row * 128 + (((2 * oct_j) ^ sw) << 2));
     const f32x4 t1 = *reinterpret_cast<const f32x4*>(T + row * 128 + (((2 * oct_j + 1) ^ sw) << 2));
-#pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] = e < 4 ? t0[e] : t1[e - 4];
+    v[0] = f32x2{t0[0], t0[1]}; v[1] = f32x2{t0[2], t0[3]};
+    v[2] = f32x2{t1[0], t1[1]}; v[3] = f32x2{t1[2], t1[3]};
   };
-  auto ring_store = [&](char* ring, int t, int row, const float (&o)[8]) {
+  auto ring_store = [&](char* ring, int t, int row, const f32x2 (&o)[4]) {
     u32x4 w;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) w[e] = f32_to_bf16_bits(o[2 * e]) | (f32_to_bf16_bits(o[2 * e + 1]) << 16);
+    for (int q = 0; q < 4; ++q) w[q] = tb_pack2(o[q]);
     *reinterpret_cast<u32x4*>(ring + (t % 3) * TB_SLOT + row * TB_ROWP + row_lds) = w;
   };
   auto load_rows = [&](Oct<bf16_t> (&dst)[4], long long elem_off) {
@@ -348,17 +387,31 @@ __global__ __launch_bounds__(256, 1) void tblock_ws128_kernel(const TBlockArgs p
   }
 #pragma unroll
   for (int it = 0; it < 4; ++it) {                                    // LN1 of the very first step, on its own
-    float v[8], o[8];
+    f32x2 v[4], o[4];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] = xc[it].get(e);
-    tb_row_norm<true>(v, lg1, lb1, p.eps, o);
+    for (int q = 0; q < 4; ++q) v[q] = tb_unpack2(xc[it].w[q]);
+    tb_row_norm2<true>(v, lg1, lb1, p.eps, o);
     ring_store(ring1, 0, row0 + 16 * it, o);
   }
   __syncthreads();
   int col = c_begin, t = 0;
   long long cb = col_base(col);
   f32x16 acc[2];
+  // PROF: s_memtime at the phase boundaries of steps [TB_PROF_FIRST, +TB_PROF_STEPS) of workgroup 0, kept in the LDS
+  // (behind [ring1][ring2][T]) until the end of the kernel -- no memory traffic inside the measured steps
+  unsigned long long* stamps = reinterpret_cast<unsigned long long*>(smem + TB_LDS);
+  int vcur = 0;
+  auto stamp = [&](int k) {
+    if constexpr (PROF) {
+      if (blockIdx.x == 0 && vcur >= TB_PROF_FIRST && vcur < TB_PROF_FIRST + TB_PROF_STEPS) {
+        const unsigned long long ts = __builtin_amdgcn_s_memtime();
+        if (lane == 0) stamps[((vcur - TB_PROF_FIRST) * 4 + wave) * TB_PROF_STAMPS + k] = ts;
+      }
+    }
+  };
   for (int v = 0; v < nsteps; ++v) {
+    vcur = v;
+    stamp(0);
     // next step's coordinates and its x rows (in flight during A and B)
     const bool has_next = v + 1 < nsteps;                             // uniform
     const int tn = (t + 1 < p.T) ? t + 1 : 0;
@@ -366,32 +419,41 @@ __global__ __launch_bounds__(256, 1) void tblock_ws128_kernel(const TBlockArgs p
     const long long cbn = (t + 1 < p.T) ? cb : (has_next ? col_base(coln) : cb);
     if (has_next) load_rows(xn, cbn + (long long)tn * frame_stride);
     // ---- A ----
-    gemm_with_job(std::integral_constant<int, 0>{}, ring1, t, acc, v > 0, [&](auto sc) { job_out(sc, xp); });
+    gemm_with_job(std::integral_constant<int, 0>{}, ring1, t, acc, v > 0 && !(PROF && p.prof_mode == 1), [&](auto sc) { job_out(sc, xp); });
+    stamp(1);
     __syncthreads();                                                  // every wave is done with T (OUT job of v-1)
+    stamp(2);
     acc_to_T(acc);
     __syncthreads();
+    stamp(3);
     // ---- B: rows of conv1 + b1 -> LN2 + SiLU -> ring2[t % 3] ----
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
-      float vv[8], o[8];
+      f32x2 vv[4], o[4];
       T_row(row0 + 16 * it, vv);
 #pragma unroll
-      for (int e = 0; e < 8; ++e) vv[e] = __fadd_rn(vv[e], bo1[e]);
-      tb_row_norm<true>(vv, lg2, lb2, p.eps, o);
+      for (int q = 0; q < 4; ++q) vv[q] = vv[q] + bo1[q];
+      tb_row_norm2<true>(vv, lg2, lb2, p.eps, o);
       ring_store(ring2, t, row0 + 16 * it, o);
     }
     // the prefetched rows are "used" here, long after the OUT job's stores of phase A were issued: hipcc waits for
     // them now (with loads and stores both pending it drains vmcnt entirely)
+    stamp(4);
     if (has_next) {
 #pragma unroll
       for (int it = 0; it < 4; ++it) asm volatile("" : "+v"(xn[it].w));
     }
+    stamp(5);
     __syncthreads();                                                  // ring2[t] visible; T free
+    stamp(6);
     // ---- C ----
-    gemm_with_job(std::integral_constant<int, 24>{}, ring2, t, acc, has_next, [&](auto sc) { job_ln1(sc, tn); });
+    gemm_with_job(std::integral_constant<int, 24>{}, ring2, t, acc, has_next && !(PROF && p.prof_mode == 1), [&](auto sc) { job_ln1(sc, tn); });
+    stamp(7);
     acc_to_T(acc);
     out_base = cb + (long long)t * frame_stride + 8 * oct_j;          // where step v's OUT job (next phase A) writes
+    stamp(8);
     __syncthreads();                                                  // T = conv2(v) complete; ring1[tn] visible
+    stamp(9);
     t = tn; col = coln; cb = cbn;
 #pragma unroll
     for (int it = 0; it < 4; ++it) {                                  // rotate: this step's rows become the next OUT job's residual
@@ -400,6 +462,12 @@ __global__ __launch_bounds__(256, 1) void tblock_ws128_kernel(const TBlockArgs p
     }
   }
   tb_static_for<0, 48>([&](auto sc) { job_out(sc, xp); });            // OUT job of the last step
+  if constexpr (PROF) {
+    if (blockIdx.x == 0 && lane == 0) {
+      for (int i = 0; i < TB_PROF_STEPS * TB_PROF_STAMPS; ++i) p.prof[wave * TB_PROF_STEPS * TB_PROF_STAMPS + i] =
+          stamps[((i / TB_PROF_STAMPS) * 4 + wave) * TB_PROF_STAMPS + (i % TB_PROF_STAMPS)];
+    }
+  }
 #endif
 }
 
@@ -419,7 +487,8 @@ extern "C" int vt_temporal_block_supported(const vt_tblock_desc* d) {
   return 1;
 }
 
-extern "C" int vt_temporal_block(const vt_tblock_desc* d, vt_stream stream_) {
+namespace {
+int tblock_launch(const vt_tblock_desc* d, vt_stream stream_, unsigned long long* prof) {
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
   VT_CHECK_ARG(d != nullptr, "vt_temporal_block: null descriptor");
   VT_CHECK_ARG(vt_temporal_block_supported(d),
@@ -443,12 +512,21 @@ extern "C" int vt_temporal_block(const vt_tblock_desc* d, vt_stream stream_) {
   a.keep_y = d->keep_y ? 1 : 0;
   a.ln_next = d->ln_next_mode;
   a.eps = d->eps;
+  a.prof = prof;
+  a.prof_mode = prof ? env_int("VT_TBLOCK_PROF_MODE", 0) : 0;
   // one instantiation per output shape: next norm none / LayerNorm / LayerNorm+SiLU, y kept or not
   static const void* const kerns[5] = {
       reinterpret_cast<const void*>(&tblock_ws128_kernel<0, true>), reinterpret_cast<const void*>(&tblock_ws128_kernel<1, true>),
       reinterpret_cast<const void*>(&tblock_ws128_kernel<1, false>), reinterpret_cast<const void*>(&tblock_ws128_kernel<2, true>),
       reinterpret_cast<const void*>(&tblock_ws128_kernel<2, false>)};
   const void* kern = kerns[a.ln_next == 0 ? 0 : (a.ln_next == 1 ? (a.keep_y ? 1 : 2) : (a.keep_y ? 3 : 4))];
+  int lds = TB_LDS;
+  if (prof != nullptr) {                      // measurement aid: the LayerNorm+SiLU, y kept instantiation with cycle stamps
+    VT_CHECK_ARG(a.ln_next == 2 && a.keep_y, "vt_temporal_block_profile: ln_next_mode 2 and keep_y only");
+    kern = reinterpret_cast<const void*>(&tblock_ws128_kernel<2, true, true>);
+    lds = TB_LDS + TB_PROF_BYTES;
+    VT_CHECK_HIP(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+  }
   static std::atomic<int> cus[kMaxDevices];
   int dev = 0;
   VT_CHECK_HIP(hipGetDevice(&dev));
@@ -462,6 +540,16 @@ extern "C" int vt_temporal_block(const vt_tblock_desc* d, vt_stream stream_) {
   const long long ncols = (long long)d->B * (d->HW / TB_PIX);
   const int grid = ncols < ncu ? (int)ncols : ncu;
   void* kargs[] = {&a};
-  VT_CHECK_HIP(hipLaunchKernel(kern, dim3((unsigned)grid), dim3(256), kargs, TB_LDS, stream));
+  VT_CHECK_HIP(hipLaunchKernel(kern, dim3((unsigned)grid), dim3(256), kargs, lds, stream));
   return VT_OK;
+}
+}  // namespace
+
+extern "C" int vt_temporal_block(const vt_tblock_desc* d, vt_stream stream) { return tblock_launch(d, stream, nullptr); }
+
+// Measurement aid (scripts/tblock_profile.py): the same launch with s_memtime stamps at the phase boundaries of four
+// steps of workgroup 0; stamps [wave][step][16] (uint64 shader-clock ticks) land in `stamps_out` (4*4*16 values).
+extern "C" int vt_temporal_block_profile(const vt_tblock_desc* d, uint64_t* stamps_out, vt_stream stream) {
+  VT_CHECK_ARG(stamps_out != nullptr, "vt_temporal_block_profile: null output");
+  return tblock_launch(d, stream, reinterpret_cast<unsigned long long*>(stamps_out));
 }

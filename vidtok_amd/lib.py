@@ -75,6 +75,7 @@ SIGNATURES = {
     "vt_conv": (C.c_int, [C.POINTER(ConvDesc), _P]),
     "vt_conv_desc_size": (C.c_int, []),
     "vt_conv_plan": (C.c_int, [C.POINTER(ConvDesc), C.POINTER(_I32)]),
+    "vt_conv_profile": (C.c_int, [C.POINTER(ConvDesc), _P, _P]),
     "vt_frames_work_floats": (_I64, [_I32, _I32, _I32]),
     "vt_frames_u8_to_ncthw": (C.c_int, [_P, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _P, _I32, _I32, _I32, _I32, _P, _P]),
     "vt_ncthw_to_frames_u8": (C.c_int, [_P, _I32, _I32, _I32, _I32, _I32, _P, _I32, _I32, _P]),
@@ -82,6 +83,7 @@ SIGNATURES = {
     "vt_tblock_desc_size": (C.c_int, []),
     "vt_temporal_block_supported": (C.c_int, [C.POINTER(TBlockDesc)]),
     "vt_temporal_block": (C.c_int, [C.POINTER(TBlockDesc), _P]),
+    "vt_temporal_block_profile": (C.c_int, [C.POINTER(TBlockDesc), _P, _P]),
     "vt_layernorm_act": (C.c_int, [_P, C.c_int, _I64, _P, C.c_int, _I64, _P, _P, _I64, _I32, _F, _I32, _P]),
     "vt_tanh_inplace": (C.c_int, [_P, _I64, _P]),
     "vt_softmax_rows": (C.c_int, [_P, _P, C.c_int, _I64, _I32, _I64, _F, _P]),

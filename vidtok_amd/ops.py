@@ -199,7 +199,7 @@ def temporal_block_supported(x, tmode) -> bool:
     return bool(L.load().vt_temporal_block_supported(C.byref(_tblock_desc(x, tmode))))
 
 
-def temporal_block(x, w1, b1, w2, b2, norm1, norm2, *, tmode=L.VT_TPAD_ZERO, eps=1e-6, next_ln=None, keep_y=True):
+def temporal_block(x, w1, b1, w2, b2, norm1, norm2, *, tmode=L.VT_TPAD_ZERO, eps=1e-6, next_ln=None, keep_y=True, profile_out=None):
     """y = x + conv2(SiLU(LN2(conv1(SiLU(LN1(x)))))) with causal k=3 temporal convs, one launch (vt_temporal_block).
     norm1 / norm2 = (gamma, beta) fp32; w packed [C, 3C].  next_ln = (gamma, beta, silu) additionally returns
     n = [SiLU](LayerNorm(y)): (y, n), or just n with keep_y=False."""
@@ -219,6 +219,9 @@ def temporal_block(x, w1, b1, w2, b2, norm1, norm2, *, tmode=L.VT_TPAD_ZERO, eps
         assert next_ln[0].dtype == torch.float32 and next_ln[1].dtype == torch.float32
         d.next_gamma, d.next_beta, d.ln_next_mode = next_ln[0].data_ptr(), next_ln[1].data_ptr(), (2 if next_ln[2] else 1)
     d.keep_y, d.eps = int(bool(keep_y)), float(eps)
+    if profile_out is not None:       # measurement aid: cycle stamps of workgroup 0 (scripts/tblock_profile.py)
+        L.check(lib.vt_temporal_block_profile(C.byref(d), profile_out.data_ptr(), _stream()), "vt_temporal_block_profile")
+        return (y, n)
     L.check(lib.vt_temporal_block(C.byref(d), _stream()), "vt_temporal_block")
     if CONV_RECORD is not None:   # two K = 3C convolutions: label (pixels, C, 6C) carries their FLOPs
         CONV_RECORD.append((d, (x, w1, b1, w2, b2, norm1, norm2, next_ln, y, n), (d.B * d.T * d.HW, d.C, 6 * d.C)))
