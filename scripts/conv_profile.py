@@ -15,7 +15,13 @@ from vidtok_amd import lib as L  # noqa: E402
 from vidtok_amd import ops  # noqa: E402
 from vidtok_amd.ops import ConvGeom  # noqa: E402
 
-NAMES = ["wait my DMA (vmcnt)", "barrier", "prep_step (addresses)", "MFMAs + DMA issue + ds_read"]
+# plain schedule (VT_CONV_SCHED=0): stamps at stage start / after the vmcnt wait / after the barrier / after the address
+# set-up / at stage end; schedule 1: stage start / in front of the waits of the last sub-step / after vmcnt / after the
+# barrier / stage end
+if os.environ.get("VT_CONV_SCHED", "1") == "0":
+    NAMES = ["wait my DMA (vmcnt)", "barrier", "prep_step (addresses)", "MFMAs + DMA issue + ds_read"]
+else:
+    NAMES = ["sub-steps 0-2: 24 MFMAs + 8 DMA pieces + set-up", "wait lgkm + my DMA (vmcnt)", "barrier", "sub-step 3: 8 MFMAs + next fragments"]
 
 
 def main():
@@ -48,7 +54,7 @@ def main():
         per = sum(int(s[wv, st + 1, 0] - s[wv, st, 0]) for wv in range(8) for st in range(3)) / 24
         print(f"  average step period {per:.0f} cycles (MFMA-bound: 2048 per SIMD = 2 waves x 32 MFMAs x 32); phases of one wave:")
         for n, v in zip(NAMES, avg):
-            print(f"    {n:32s} {v:8.1f}")
+            print(f"    {n:50s} {v:8.1f}")
 
 
 if __name__ == "__main__":

@@ -718,63 +718,29 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_igemm_glds_ker
   // read KSB sub-steps at a time (all of the stage for the 4-wave tiles, half for the 8-wave tile whose
   // 128 accumulators leave no room for 24 live fragments).
   constexpr int KSB = (TM * TN >= 8 && KS > 2) ? 2 : KS;
-  auto compute_stage = [&](int stage, auto fire_tag, bool fire_rt, int dst, auto&& at_half) {
+  auto compute_stage = [&](int stage, auto fire_tag, bool fire_rt, int dst) {
     constexpr bool FIRE = decltype(fire_tag)::value;
     const char* As = smem + stage * STAGE_BYTES + (wm * TM * 32) * ROWB + frag_row;
     const char* Bs = smem + stage * STAGE_BYTES + A_BYTES + (wn * TN * 32) * ROWB + frag_row;
-    if constexpr (S1) {
-      // fragments one 32-B sub-step ahead of the MFMAs that use them (two sets of TN + TM fragments, the register
-      // budget of the plain schedule's two-sub-step block): no LDS round trip in front of any MFMA but the first.
-      // Issue priority alternates between the two waves of a SIMD every sub-step: a fair share of the matrix pipe
-      // (left alone, the older wave wins every arbitration and its sibling finishes ~700 cycles later, alone).
-      u32x4 wf[2][TN], xf[2][TM];
-      auto read_frags = [&](int k, int set) {
-        const int slot = ((k * 2 + khalf) ^ swz) * 16;
 #pragma unroll
-        for (int a = 0; a < TN; ++a) wf[set][a] = *reinterpret_cast<const u32x4*>(Bs + a * 32 * ROWB + slot);
+    for (int k0 = 0; k0 < KS; k0 += KSB) {
+      u32x4 wf[KSB][TN], xf[KSB][TM];
 #pragma unroll
-        for (int b = 0; b < TM; ++b) xf[set][b] = *reinterpret_cast<const u32x4*>(As + b * 32 * ROWB + slot);
-      };
-      read_frags(0, 0);
+      for (int kk = 0; kk < KSB; ++kk) {
+        const int slot = (((k0 + kk) * 2 + khalf) ^ swz) * 16;
 #pragma unroll
-      for (int k = 0; k < KS; ++k) {
-        if (((k ^ wgrp) & 1) == 0) __builtin_amdgcn_s_setprio(2);
-        else __builtin_amdgcn_s_setprio(0);
-        if (k + 1 < KS) read_frags(k + 1, (k + 1) & 1);
+        for (int a = 0; a < TN; ++a) wf[kk][a] = *reinterpret_cast<const u32x4*>(Bs + a * 32 * ROWB + slot);
 #pragma unroll
-        for (int qq = 0; qq < TM * TN; ++qq) {
-          const int a = qq / TM, b = qq % TM;
-          const int q = k * TM * TN + qq;
-          mma_step<MT>(wf[k & 1][a], xf[k & 1][b], acc[a][b]);
-          if (FIRE && (q + 1) % MPP == 0) {
-            const int piece = q / MPP;
-            if (piece < IPS && fire_rt) fire_piece(piece, dst);
-          }
-          if (q + 1 == NM / 2) at_half();
-        }
+        for (int b = 0; b < TM; ++b) xf[kk][b] = *reinterpret_cast<const u32x4*>(As + b * 32 * ROWB + slot);
       }
-      __builtin_amdgcn_s_setprio(0);
-    } else {
 #pragma unroll
-      for (int k0 = 0; k0 < KS; k0 += KSB) {
-        u32x4 wf[KSB][TN], xf[KSB][TM];
-#pragma unroll
-        for (int kk = 0; kk < KSB; ++kk) {
-          const int slot = (((k0 + kk) * 2 + khalf) ^ swz) * 16;
-#pragma unroll
-          for (int a = 0; a < TN; ++a) wf[kk][a] = *reinterpret_cast<const u32x4*>(Bs + a * 32 * ROWB + slot);
-#pragma unroll
-          for (int b = 0; b < TM; ++b) xf[kk][b] = *reinterpret_cast<const u32x4*>(As + b * 32 * ROWB + slot);
-        }
-#pragma unroll
-        for (int qq = 0; qq < KSB * TM * TN; ++qq) {
-          const int kk = qq / (TM * TN), a = (qq / TM) % TN, b = qq % TM;
-          const int q = k0 * TM * TN + qq;
-          mma_step<MT>(wf[kk][a], xf[kk][b], acc[a][b]);
-          if (FIRE && (q + 1) % MPP == 0) {
-            const int piece = q / MPP;
-            if (piece < IPS && fire_rt) fire_piece(piece, dst);
-          }
+      for (int qq = 0; qq < KSB * TM * TN; ++qq) {
+        const int kk = qq / (TM * TN), a = (qq / TM) % TN, b = qq % TM;
+        const int q = k0 * TM * TN + qq;
+        mma_step<MT>(wf[kk][a], xf[kk][b], acc[a][b]);
+        if (FIRE && (q + 1) % MPP == 0) {
+          const int piece = q / MPP;
+          if (piece < IPS && fire_rt) fire_piece(piece, dst);
         }
       }
     }
@@ -808,6 +774,76 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_igemm_glds_ker
       }
     }
   };
+  if constexpr (S1) {
+    // Schedule 1: one K loop body, software-pipelined across stages.  Fragments are requested one 32-B sub-step ahead
+    // of their MFMAs (two register sets).  The stage barrier sits in front of the LAST FOUR MFMA groups of a stage: by
+    // then this wave has every fragment of the current slot in registers (so the slot may be refilled) and its own
+    // pieces of the next stage have had most of a stage to land (measured: in front of the last EIGHT groups they had
+    // not -- 400 cycles of vmcnt wait); after the barrier the first fragments of the next stage are requested and the
+    // remaining MFMAs cover their latency: no MFMA waits for an LDS round trip.
+    static_assert(STAGES == 2 && D == 1 && KS % 2 == 0, "schedule 1: two-slot ring, one stage in flight");
+    constexpr int BAR_AT = TM * TN - 4;      // MFMA groups of the last sub-step issued before the barrier
+    const char* a_base = smem + (wm * TM * 32) * ROWB + frag_row;
+    const char* b_base = smem + A_BYTES + (wn * TN * 32) * ROWB + frag_row;
+    u32x4 wf[2][TN], xf[2][TM];
+    auto read_frags = [&](int stg, int k, int set) {
+      const char* As = a_base + stg * STAGE_BYTES;
+      const char* Bs = b_base + stg * STAGE_BYTES;
+      const int slot = ((k * 2 + khalf) ^ swz) * 16;
+#pragma unroll
+      for (int a = 0; a < TN; ++a) wf[set][a] = *reinterpret_cast<const u32x4*>(Bs + a * 32 * ROWB + slot);
+#pragma unroll
+      for (int b = 0; b < TM; ++b) xf[set][b] = *reinterpret_cast<const u32x4*>(As + b * 32 * ROWB + slot);
+    };
+    wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    read_frags(0, 0, 0);
+    for (int s = 0; s < p.nsteps; ++s) {
+      s_cur = s;
+      stamp(0);
+      const bool fire = s < n_fire;
+      if (!fire && BUF) ext_x = ext_w = 0u;    // past the last prefetch: the pieces below turn into zero fills
+      const bool fire_rt = BUF || fire;
+      const int dst = stage ^ 1;
+#pragma unroll
+      for (int k = 0; k < KS; ++k) {
+        // issue priority alternates between the two waves of a SIMD every sub-step (left alone the older wave wins
+        // every arbitration, finishes early and idles at the barrier while its sibling runs uncovered)
+        if (((k ^ wgrp) & 1) == 0) __builtin_amdgcn_s_setprio(2);
+        else __builtin_amdgcn_s_setprio(0);
+        if (k + 1 < KS) read_frags(stage, k + 1, (k + 1) & 1);
+#pragma unroll
+        for (int qq = 0; qq < TM * TN; ++qq) {
+          const int a = qq / TM, b = qq % TM;
+          const int q = k * TM * TN + qq;
+          if (k + 1 == KS && qq == BAR_AT) {
+            if (s + 1 < p.nsteps) {
+              stamp(1);
+              asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // my last fragments of this slot are in registers
+              wait_vmcnt<0>();                                      // my pieces of the next stage have landed
+              stamp(2);
+              __builtin_amdgcn_s_barrier();
+              asm volatile("" ::: "memory");
+              stamp(3);
+              read_frags(stage ^ 1, 0, 0);
+            }
+          }
+          mma_step<MT>(wf[k & 1][a], xf[k & 1][b], acc[a][b]);
+          if ((q + 1) % MPP == 0) {
+            const int piece = q / MPP;
+            if (piece < IPS && fire_rt) fire_piece(piece, dst);
+          }
+          if (q + 1 == NM / 2) {
+            if (s + 1 < n_fire) prep_step(s + 1 + D);   // all pieces of step s + D are out: their registers are free
+          }
+        }
+      }
+      stage ^= 1;
+      stamp(4);
+    }
+    __builtin_amdgcn_s_setprio(0);
+  } else {
   for (int s = 0; s < p.nsteps; ++s) {
     s_cur = s;
     stamp(0);
@@ -824,19 +860,13 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_igemm_glds_ker
     // the register allocator parked the accumulators in VGPRs across the loop edge and copied all of
     // them to AGPRs and back every step (128 v_accvgpr moves per 16 MFMAs).
     const bool fire = s < n_fire;
-    if constexpr (!S1) {
-      if (fire) prep_step(s + D);
-    }
-    if (!fire && BUF) ext_x = ext_w = 0u;    // past the last prefetch: the pieces below turn into zero fills
+    if (fire) prep_step(s + D);
+    else if (BUF) ext_x = ext_w = 0u;        // past the last prefetch: the pieces below turn into zero fills
     const bool fire_rt = BUF || fire;        // pointer form keeps the uniform branch around its pieces
     stamp(3);
     if (EIGHT_WAVES) {
       // 8-wave tile: the DMA pieces are issued between MFMA groups; measured 7 % faster than issuing them up front
-      compute_stage(stage, TagTrue{}, fire_rt, (stage + D) % STAGES, [&]() {
-        if constexpr (S1) {
-          if (s + 1 < n_fire) prep_step(s + 1 + D);   // all pieces of step s + D are out: their registers are free
-        }
-      });
+      compute_stage(stage, TagTrue{}, fire_rt, (stage + D) % STAGES);
     } else {
       // 4-wave tiles: two workgroups share the CU and cover each other's DMA issue, and the prefetch is
       // only one step deep, so the whole next stage is requested first (interleaving measured 10-20 % slower)
@@ -844,10 +874,11 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_igemm_glds_ker
 #pragma unroll
         for (int q = 0; q < IPS; ++q) fire_piece(q, (stage + D) % STAGES);
       }
-      compute_stage(stage, TagFalse{}, false, 0, []() {});
+      compute_stage(stage, TagFalse{}, false, 0);
     }
     stage = (stage + 1 == STAGES) ? 0 : stage + 1;
     stamp(4);
+  }
   }
   if constexpr (BUF) wait_vmcnt<0>();   // the trailing zero-fill pieces must land before the LDS allocation is released
   if constexpr (PROF) {
