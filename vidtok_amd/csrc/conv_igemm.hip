@@ -1207,9 +1207,10 @@ extern "C" int vt_conv_profile(const vt_conv_desc* d, uint64_t* stamps_out, vt_s
   int nbatch = 1;
   const int rc = conv_prepare(d, a, ln_fused, nbatch, use_ws);
   if (rc != VT_OK) return rc;
-  VT_CHECK_ARG(!use_ws && d->dtype == VT_BF16 && d->out_dtype == VT_BF16 && d->ln_mode == 0 && select_tile(a, nbatch) == TILE_256x256,
-               "vt_conv_profile: bf16 launches on the 256 x 256 tile without LayerNorm only");
   a.prof = reinterpret_cast<unsigned long long*>(stamps_out);
+  if (use_ws) return vt_ws128_launch(&a, stream_);     // stamps [wave][16] of workgroup 0's fourth tile
+  VT_CHECK_ARG(d->dtype == VT_BF16 && d->out_dtype == VT_BF16 && d->ln_mode == 0 && select_tile(a, nbatch) == TILE_256x256,
+               "vt_conv_profile: bf16 launches on the 256 x 256 tile without LayerNorm, or on the weight-stationary kernel");
   return dispatch_tile<bf16_t, bf16_t>(a, nbatch, reinterpret_cast<hipStream_t>(stream_));
 }
 

@@ -88,7 +88,7 @@ __device__ __forceinline__ void ws_mfma(const u32x4& w, const u32x4& x, f32x16& 
 __device__ __forceinline__ void pin(float& v) { asm volatile("" : "+v"(v)); }
 __device__ __forceinline__ void pin_u(uint32_t& v) { asm volatile("" : "+v"(v)); }
 
-template <int LN, bool KEEP, bool ACC_A>
+template <int LN, bool KEEP, bool ACC_A, bool PROF = false>
 __global__ __launch_bounds__(256, 1) void conv3x3_ws128_kernel(const ConvArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -141,6 +141,16 @@ __global__ __launch_bounds__(256, 1) void conv3x3_ws128_kernel(const ConvArgs p)
   unsigned pd_tmask = 0;
   int pd_toff = 0;
   bool pd_on = false;
+  // PROF (vt_conv_profile): shader-clock stamps of workgroup 0's fourth tile, written straight to memory (the LDS is full)
+  bool prof_tile = false;
+  auto stamp = [&](int k) {
+    if constexpr (PROF) {
+      if (prof_tile) {
+        const unsigned long long ts = __builtin_amdgcn_s_memtime();
+        if (lane == 0) p.prof[wave * 16 + k] = ts;
+      }
+    }
+  };
   auto patch_begin = [&](int tile, int bufoff) {
     int f, h0, w0;
     tile_coords(tile, f, h0, w0);
@@ -355,6 +365,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_ws128_kernel(const ConvArgs p)
         }
         __builtin_amdgcn_sched_barrier(0);
       });
+      if constexpr (PROF && (g == 17 || g == 35 || g == 55)) stamp(2 + (g + 1) / 18);   // 3, 4, 5: after 72 / 144 / 224 MFMAs
       if constexpr (g == 60) {             // bias quads for the transposition below: requested in a bare stretch
         const int h = lane >> 5;
 #pragma unroll
@@ -391,8 +402,11 @@ __global__ __launch_bounds__(256, 1) void conv3x3_ws128_kernel(const ConvArgs p)
   for (int tile = t_begin; tile < t_end; ++tile, cur ^= 1) {
     // (A) patch[cur] has landed for every wave (each drained its vmcnt before barrier B of the previous tile) and the
     //     previous tile's T is complete
+    if constexpr (PROF) prof_tile = blockIdx.x == 0 && tile == t_begin + 3;
+    stamp(0);
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
+    stamp(1);
     pd_on = tile + 1 < t_end;            // uniform
     if (tile == t_begin) {
       if (pd_on) issue_patch(tile + 1, cur ? 0 : WS_PATCH);
@@ -403,12 +417,17 @@ __global__ __launch_bounds__(256, 1) void conv3x3_ws128_kernel(const ConvArgs p)
         rq[0].load(res_row_ptr(0));
         rq[1].load(res_row_ptr(1));
       }
+      stamp(2);
       k_loop(std::true_type{}, cur ? WS_PATCH : 0);
     }
+    stamp(6);
     wait_vmcnt<0>();                 // own DMA pieces of the next patch, the row phase's loads and stores: long done
+    stamp(7);
     __builtin_amdgcn_s_barrier();    // (B) every wave is done with the previous tile's T (and with patch[cur])
     asm volatile("" ::: "memory");
+    stamp(8);
     acc_to_T();
+    stamp(9);
     int f, h0, w0;
     tile_coords(tile, f, h0, w0);
     pix0_prev = ((long long)f * H + h0) * W + w0;
@@ -441,6 +460,12 @@ extern "C" __attribute__((visibility("hidden"))) int vt_ws128_launch(const void*
        reinterpret_cast<const void*>(&conv3x3_ws128_kernel<1, false, true>), reinterpret_cast<const void*>(&conv3x3_ws128_kernel<2, true, true>),
        reinterpret_cast<const void*>(&conv3x3_ws128_kernel<2, false, true>)}};
   const void* kern = kerns[acc_a][vi];
+  if (a.prof != nullptr) {           // vt_conv_profile: the plain and the LayerNorm+SiLU (y kept) instantiations carry stamps
+    VT_CHECK_ARG(vi == 0 || vi == 3, "vt_conv_profile (weight-stationary kernel): ln_mode 0, or 2 with ln_keep_y");
+    kern = vi == 0 ? reinterpret_cast<const void*>(&conv3x3_ws128_kernel<0, true, false, true>)
+                   : reinterpret_cast<const void*>(&conv3x3_ws128_kernel<2, true, false, true>);
+    VT_CHECK_HIP(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, WS_LDS));
+  }
   static std::atomic<int> cus[kMaxDevices];         // 0 = not queried yet on that device; else its CU count
   static std::atomic<bool> attr_done[2][5][kMaxDevices];
   int dev = 0;
