@@ -100,7 +100,7 @@ def test_conv(case, dtype):
     _check_conv(case, dtype)
 
 
-# The 8-wave 256x256 instantiation is chosen only for Cout % 256 == 0 with >= 384 tiles (M >= ~98 K pixels): every
+# The 8-wave 256x256 instantiation is chosen only for Cout % 256 == 0 with >= 128 tiles (VT_CONV_TILE_MIN): every
 # Cout % 256 == 0 case above is replayed with VT_CONV_TILE=256 (forces that tile however few tiles there are: ragged
 # pixel tiles, every padding / cache / residual mode), and the cases below reach it -- and the frames-innermost
 # order, the parity interleave, cache mode -- at sizes where the dispatcher picks it by itself (BASELINE-sized layers).

@@ -1033,7 +1033,9 @@ inline TileKind select_tile(const ConvArgs& a, int nbatch) {
   if (a.Cout <= 32) return TILE_256x32;
   if (a.Cout <= 64) return TILE_256x64;
   const int force = env_int("VT_CONV_TILE", 0);
-  if (a.Cout % 256 == 0 && vec_epi && force != 128 && (blocks(256, 256) >= 384 || force == 256)) return TILE_256x256;
+  // at least VT_CONV_TILE_MIN (default 128) tiles: with K-step schedule 1 even half-filled single rounds of the 8-wave
+  // tile beat 1.25 rounds of 128 x 128 tiles (M = 20 480, Cout = 512: 0.143 -> 0.121 ms at K = 4 608, 0.38 -> 0.29 at 13 824)
+  if (a.Cout % 256 == 0 && vec_epi && force != 128 && (blocks(256, 256) >= env_int("VT_CONV_TILE_MIN", 128) || force == 256)) return TILE_256x256;
   return TILE_128x128;
 }
 
