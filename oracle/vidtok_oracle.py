@@ -421,22 +421,31 @@ def fsq_constants(levels):
     return lv, half_l, offset, shift, half_w, basis
 
 
-def fsq_regularize(h, levels, entropy_loss_weight=0.0, entropy_loss_annealing_steps=0,
-                   entropy_loss_annealing_factor=1.0, commitment_loss_weight=0.0, diversity_gamma=1.0,
-                   inv_temperature=100.0, n_steps=0, with_aux=True):
-    """FSQRegularizer.forward for dim == len(levels), num_codebooks == 1,
-    R/modules/regularizers.py:206-268 (bound :153, quantize :160, codes_to_indices :174)."""
+def fsq_regularize(h, levels, num_codebooks=1, keep_num_codebooks_dim=None, scale=None, entropy_loss_weight=0.0,
+                   entropy_loss_annealing_steps=0, entropy_loss_annealing_factor=1.0, commitment_loss_weight=0.0,
+                   diversity_gamma=1.0, inv_temperature=100.0, n_steps=0, with_aux=True):
+    """FSQRegularizer.forward behind project_in, R/modules/regularizers.py:206-268 (bound :153, quantize :160,
+    codes_to_indices :174): h [b, c*d, ...] holds `num_codebooks` = c groups of d = len(levels) channels
+    ("b n (c d) -> b n c d", :227), each quantised on its own; indices [b, ...] or, with keep_num_codebooks_dim
+    (forced for c > 1, :131-133), [b, ..., c]."""
     lv, half_l, offset, shift, half_w, basis = fsq_constants(levels)
-    zf = h.float().movedim(1, -1)                      # b ... d
+    c, d = int(num_codebooks), len(levels)
+    keep = (c > 1) if keep_num_codebooks_dim is None else bool(keep_num_codebooks_dim)
+    assert not (c > 1 and not keep)
+    zf = h.float().movedim(1, -1)                      # b ... (c d)
+    assert zf.shape[-1] == c * d
+    zf = zf.reshape(zf.shape[:-1] + (c, d))             # b ... c d
     bounded = (zf + shift).tanh() * half_l - offset
     codes = bounded.round() / half_w                    # round_ste == round in value
-    indices = ((codes * half_w + half_w) * basis).sum(dim=-1).to(torch.int32)
+    indices = ((codes * half_w + half_w) * basis).sum(dim=-1).to(torch.int32)      # b ... c
     aux = torch.tensor(0.0)
     if with_aux and (entropy_loss_weight > 0 or commitment_loss_weight > 0):
+        # with the codebook axis kept the reference's implicit codebook is 1-D and its einsum raises (:143-146,191-192,234)
+        assert not keep, "the reference cannot compute the FSQ aux loss with keep_num_codebooks_dim"
         J = int(torch.prod(lv))
         allidx = torch.arange(J)[:, None]
         codebook = ((allidx // basis) % lv - half_w) / half_w            # indices_to_codes :186-187,170-172
-        flat = zf.reshape(-1, zf.shape[-1])
+        flat = zf.reshape(-1, d)
         ent_sum, avg = 0.0, torch.zeros(J)
         for s in range(0, flat.shape[0], 2048):                           # chunked: [n, J] is large
             logits = (2.0 * flat[s:s + 2048] @ codebook.t()) * inv_temperature
@@ -453,13 +462,19 @@ def fsq_regularize(h, levels, entropy_loss_weight=0.0, entropy_loss_annealing_st
             start = entropy_loss_annealing_factor * entropy_loss_weight
             w = start - (n_steps / entropy_loss_annealing_steps) * (start - entropy_loss_weight)
         aux = (per_sample_entropy - diversity_gamma * codebook_entropy) * w + commit * commitment_loss_weight
+    codes = codes.reshape(codes.shape[:-2] + (c * d,))
+    if not keep:
+        indices = indices[..., 0]
     return codes.movedim(-1, 1), {"indices": indices, "aux_loss": aux}
 
 
-def fsq_indices_to_codes(indices, levels):
-    """FSQRegularizer.indices_to_codes (video form), R/modules/regularizers.py:180-198."""
+def fsq_indices_to_codes(indices, levels, keep_num_codebooks_dim=False):
+    """FSQRegularizer.indices_to_codes (video form), R/modules/regularizers.py:180-198: indices [b, ...] or, with
+    keep_num_codebooks_dim, [b, ..., c] -> codes [b, d, ...] / [b, c*d, ...]."""
     lv, _, _, _, half_w, basis = fsq_constants(levels)
     codes = ((indices[..., None] // basis) % lv - half_w) / half_w
+    if keep_num_codebooks_dim:
+        codes = codes.reshape(codes.shape[:-2] + (-1,))                   # "... c d -> ... (c d)"
     return codes.movedim(-1, 1)
 
 
@@ -552,7 +567,9 @@ class OracleEngine:
                    "indices": torch.cat([d["indices"] for d in logs], dim=1)}
 
     def indices_to_latent(self, idx):
-        z = fsq_indices_to_codes(idx, self.reg_params["levels"])
+        nc = int(self.reg_params.get("num_codebooks", 1))
+        keep = self.reg_params.get("keep_num_codebooks_dim")
+        z = fsq_indices_to_codes(idx, self.reg_params["levels"], (nc > 1) if keep is None else bool(keep))
         return self._project("project_out", z) if "regularization.project_out.weight" in self.sd else z
 
     def _overlap_rules(self):

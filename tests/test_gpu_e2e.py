@@ -143,6 +143,28 @@ def test_fsq_with_projections_matches_oracle():
     assert torch.equal(log["indices"].cpu(), log2["indices"])
 
 
+# with the codebook axis kept the reference's own forward raises as soon as an aux-loss weight is non-zero
+# (its implicit codebook is flattened to 1-D, regularizers.py:143-146,191-192,234): these options exist without aux loss
+NO_AUX = dict(entropy_loss_weight=0.0, commitment_loss_weight=0.0)
+
+
+@pytest.mark.parametrize("zc,reg", [(6, dict(levels=[8, 5, 5], num_codebooks=2, **NO_AUX)),
+                                    (8, dict(levels=[8, 5, 5], num_codebooks=2, dim=8, **NO_AUX)),
+                                    (3, dict(levels=[8, 5, 5], keep_num_codebooks_dim=True, **NO_AUX))],
+                         ids=["two_codebooks", "two_codebooks_projected", "one_codebook_kept_axis"])
+def test_fsq_num_codebooks_matches_oracle(zc, reg):
+    """num_codebooks > 1 / keep_num_codebooks_dim of the reference's FSQRegularizer (regularizers.py:100-150,227,247-262)"""
+    model, cfg, sd = build_model("vidtok_fsq_causal_488_32768", seed=5, device=DEV, overrides=dict(z_channels=zc), reg_overrides=reg)
+    ora = build_oracle(cfg, sd)
+    x = torch.rand((1, 3, 5, 32, 32), generator=torch.Generator().manual_seed(2)) * 2 - 1
+    z, dec, log = model(x.to(DEV))
+    z2, dec2, log2 = ora(x)
+    assert log["indices"].shape == (1, 2, 4, 4, reg.get("num_codebooks", 1)) and torch.equal(log["indices"].cpu(), log2["indices"])
+    assert z.shape == (1, zc, 2, 4, 4) and rel_err(z, z2) < 1e-3 and rel_err(dec, dec2) < 1e-3
+    assert abs(float(log["aux_loss"]) - float(log2["aux_loss"])) < 1e-3 * max(1.0, abs(float(log2["aux_loss"])))
+    assert torch.equal(model.decode(log["indices"], decode_from_indices=True), dec)
+
+
 def test_v11_long_video_tiled_matches_oracle():
     name = "vidtok_v1_1/vidtok_kl_causal_488_16chn_v1_1"
     model, cfg, sd = build_model(name, seed=22, device=DEV, dtype=torch.float32)

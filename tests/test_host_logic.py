@@ -88,6 +88,9 @@ def test_fsq_with_projections_matches_oracle(emulated_ops):
     assert z.shape == (1, 8, 2, 4, 4) and rel_err(z, z2) < 2e-5 and rel_err(dec, dec2) < 5e-5
     assert torch.equal(log["indices"], log2["indices"])
     assert rel_err(model.decode(log["indices"], decode_from_indices=True), dec) < 1e-6
+    model.regularization.entropy_loss_weight = 0.1           # ... and, like the reference, not with an aux loss
+    with pytest.raises(NotImplementedError):
+        model(x)
 
 
 def test_api_surface_and_aliases(emulated_ops):
@@ -120,8 +123,34 @@ def test_unsupported_variants_fail_loudly():
     with pytest.raises(NotImplementedError):
         EncoderCausal3DPadding(ch=32, out_ch=3, ch_mult=(1, 2), num_res_blocks=1, in_channels=3, z_channels=4,
                                norm_type="batchnorm")
+    with pytest.raises(AssertionError):                      # as in the reference: several codebooks keep their axis
+        FSQRegularizer(levels=[8, 8, 8], num_codebooks=2, keep_num_codebooks_dim=False)
+
+
+# with the codebook axis kept the reference's own forward raises as soon as an aux-loss weight is non-zero
+# (its implicit codebook is flattened to 1-D, regularizers.py:143-146,191-192,234): these options exist without aux loss
+NO_AUX = dict(entropy_loss_weight=0.0, commitment_loss_weight=0.0)
+
+
+@pytest.mark.parametrize("zc,reg", [(6, dict(levels=[8, 5, 5], num_codebooks=2, **NO_AUX)),
+                                    (8, dict(levels=[8, 5, 5], num_codebooks=2, dim=8, **NO_AUX)),
+                                    (3, dict(levels=[8, 5, 5], keep_num_codebooks_dim=True, **NO_AUX))],
+                         ids=["two_codebooks", "two_codebooks_projected", "one_codebook_kept_axis"])
+def test_fsq_num_codebooks_matches_oracle(zc, reg, emulated_ops):
+    """several FSQ codebooks / the kept codebook axis: host graph on the same operators vs the oracle (which is pinned
+    to the reference for these options in test_oracle_vs_reference.py)"""
+    model, cfg, sd = build_model("vidtok_fsq_causal_488_32768", seed=5, overrides=dict(z_channels=zc), reg_overrides=reg)
+    ora = build_oracle(cfg, sd)
+    x = torch.rand((1, 3, 5, 32, 32), generator=torch.Generator().manual_seed(2)) * 2 - 1
+    z, dec, log = model(x)
+    z2, dec2, log2 = ora(x)
+    assert log["indices"].shape == (1, 2, 4, 4, reg.get("num_codebooks", 1)) and torch.equal(log["indices"], log2["indices"])
+    assert z.shape == (1, zc, 2, 4, 4) and rel_err(z, z2) < 2e-5 and rel_err(dec, dec2) < 5e-5
+    assert abs(float(log["aux_loss"]) - float(log2["aux_loss"])) < 1e-4 * max(1.0, abs(float(log2["aux_loss"])))
+    assert rel_err(model.decode(log["indices"], decode_from_indices=True), dec) < 1e-6
+    model.regularization.entropy_loss_weight = 0.1           # ... and, like the reference, not with an aux loss
     with pytest.raises(NotImplementedError):
-        FSQRegularizer(levels=[8, 8, 8], num_codebooks=2)
+        model(x)
 
 
 def test_product_path_has_no_cpu_fallback():

@@ -95,6 +95,36 @@ def test_oracle_matches_reference_fsq_with_projections():
     assert rel_err(ora.decode(log2["indices"], decode_from_indices=True), dec) < 5e-5
 
 
+# with the codebook axis kept the reference's own forward raises as soon as an aux-loss weight is non-zero
+# (its implicit codebook is flattened to 1-D, regularizers.py:143-146,191-192,234): these options exist without aux loss
+NO_AUX = dict(entropy_loss_weight=0.0, commitment_loss_weight=0.0)
+
+
+@pytest.mark.parametrize("zc,reg", [(6, dict(levels=[8, 5, 5], num_codebooks=2, **NO_AUX)),
+                                    (8, dict(levels=[8, 5, 5], num_codebooks=2, dim=8, **NO_AUX)),
+                                    (3, dict(levels=[8, 5, 5], keep_num_codebooks_dim=True, **NO_AUX))],
+                         ids=["two_codebooks", "two_codebooks_projected", "one_codebook_kept_axis"])
+def test_oracle_matches_reference_fsq_num_codebooks(zc, reg):
+    """num_codebooks > 1 / keep_num_codebooks_dim (regularizers.py:100-150,227,247-262): no shipped YAML sets them
+    (VERDICT r1 "unused reference branches"); indices carry a trailing codebook axis, the entropy terms are per codebook."""
+    ref, c = load_reference_model("vidtok_fsq_causal_488_32768", overrides=dict(z_channels=zc), reg_overrides=reg)
+    randomize_weights(ref)
+    ora = OracleEngine(c["model"]["params"], ref.state_dict())
+    x = torch.rand(1, 3, 5, 32, 32) * 2 - 1
+    with torch.no_grad():
+        z, dec, log = ref(x)
+        z2, dec2, log2 = ora(x)
+    assert log["indices"].shape == log2["indices"].shape == (1, 2, 4, 4, reg.get("num_codebooks", 1))
+    assert torch.equal(log["indices"], log2["indices"])
+    assert z.shape == z2.shape == (1, zc, 2, 4, 4) and rel_err(z2, z) < 2e-5 and rel_err(dec2, dec) < 5e-5
+    assert abs(float(log["aux_loss"]) - float(log2["aux_loss"])) < 2e-5 * max(1.0, abs(float(log["aux_loss"])))
+    # (the reference ENGINE's indices_to_latent only takes index maps without the codebook axis, autoencoder.py:204-213;
+    #  its regularizer's indices_to_codes is the defined inverse)
+    with torch.no_grad():
+        back = ref.decoder(ref.regularization.indices_to_codes(log["indices"]))
+    assert rel_err(ora.decode(log2["indices"], decode_from_indices=True), back) < 5e-5
+
+
 def _perturb_norm_affines(model, seed=3):
     g = torch.Generator().manual_seed(seed)
     with torch.no_grad():

@@ -254,7 +254,8 @@ class AutoencodingEngineV11(AutoencodingEngine):
                 z = torch.empty((chunk_z.shape[0], chunk_z.shape[1], tz) + tuple(chunk_z.shape[3:]), dtype=chunk_z.dtype,
                                 device=chunk_z.device)
                 if "indices" in chunk_log:
-                    idx = torch.empty((chunk_z.shape[0], tz) + tuple(chunk_z.shape[3:]), dtype=torch.int32, device=chunk_z.device)
+                    # [B, T', H', W'] (+ a trailing codebook axis with keep_num_codebooks_dim)
+                    idx = torch.empty((chunk_z.shape[0], tz) + tuple(chunk_log["indices"].shape[2:]), dtype=torch.int32, device=chunk_z.device)
             n = chunk_z.shape[2]
             if chunk_z.is_cuda:
                 ops.ncthw_copy_frames(chunk_z.contiguous(), z, 0, done, n)

@@ -55,14 +55,14 @@ class FSQRegularizer(nn.Module):
                  diversity_gamma: float = 1.0, compute_aux_loss: bool = True):
         super().__init__()
         self.levels = [int(v) for v in levels]
-        if num_codebooks != 1:
-            raise NotImplementedError("num_codebooks > 1 is not used by any VidTok config")
-        self.num_codebooks = 1
+        self.num_codebooks = int(num_codebooks)
+        assert self.num_codebooks >= 1
         self.codebook_dim = len(self.levels)
-        self.effective_codebook_dim = self.codebook_dim
-        self.keep_num_codebooks_dim = False if keep_num_codebooks_dim is None else keep_num_codebooks_dim
-        assert not self.keep_num_codebooks_dim
-        self.dim = self.codebook_dim if dim is None else dim
+        self.effective_codebook_dim = self.codebook_dim * self.num_codebooks
+        # regularizers.py:131-133: several codebooks always keep their axis on the indices
+        self.keep_num_codebooks_dim = (self.num_codebooks > 1) if keep_num_codebooks_dim is None else bool(keep_num_codebooks_dim)
+        assert not (self.num_codebooks > 1 and not self.keep_num_codebooks_dim)
+        self.dim = self.effective_codebook_dim if dim is None else dim
         self.has_projections = self.dim != self.effective_codebook_dim
         # same parameter names as the reference (regularizers.py:137-139): checkpoints load unchanged
         self.project_in = nn.Linear(self.dim, self.effective_codebook_dim) if self.has_projections else _Identity()
@@ -97,9 +97,20 @@ class FSQRegularizer(nn.Module):
 
     @torch.no_grad()
     def indices_to_codes(self, indices: torch.Tensor, project_out=True) -> torch.Tensor:
-        """indices int32 [B, ...] -> codes [B, D, ...] (regularizers.py:180-198, image/video form)."""
-        assert indices.dim() >= 3, "expects [B, T, H, W] (or [B, H, W]) index maps"
-        codes = ops.fsq_indices_to_codes(indices.to(torch.int32).contiguous(), self.levels)
+        """indices int32 [B, ...] (with keep_num_codebooks_dim: [B, ..., c]) -> codes [B, D, ...]
+        (regularizers.py:180-198, image/video form)."""
+        assert indices.dim() >= 3 + int(self.keep_num_codebooks_dim), "expects [B, T, H, W] (or [B, H, W]) index maps"
+        idx = indices.to(torch.int32)
+        if self.keep_num_codebooks_dim:
+            # codebook k of clip b is row b*c + k of a [B*c, ...] batch: its d code channels land at [k*d, (k+1)*d)
+            c = self.num_codebooks
+            assert idx.shape[-1] == c
+            sp = tuple(idx.shape[1:-1])
+            idx = idx.movedim(-1, 1).reshape((idx.shape[0] * c,) + sp)
+            codes = ops.fsq_indices_to_codes(idx.contiguous(), self.levels)
+            codes = codes.reshape((indices.shape[0], c * self.codebook_dim) + sp)
+        else:
+            codes = ops.fsq_indices_to_codes(idx.contiguous(), self.levels)
         if project_out and self.has_projections:
             codes = self._linear(self.project_out, codes)
         return codes
@@ -130,11 +141,25 @@ class FSQRegularizer(nn.Module):
         h = z.float().contiguous()
         if self.has_projections:
             h = self._linear(self.project_in, h)
-        codes, indices = ops.fsq_quantize(h, self.levels)
-        if self.compute_aux_loss and (self.entropy_loss_weight > 0 or self.commitment_loss_weight > 0):
+        c, d = self.num_codebooks, self.codebook_dim
+        B, sp = h.shape[0], tuple(h.shape[2:])
+        # "b n (c d) -> b n c d" (regularizers.py:227): in NCTHW the d channels of codebook k of clip b are contiguous,
+        # i.e. clip b*c + k of a [B*c, d, ...] batch -- a view, the kernels see c times as many clips
+        hv = h.reshape((B * c, d) + sp)
+        codes, indices = ops.fsq_quantize(hv, self.levels)
+        codes = codes.reshape((B, c * d) + sp)
+        if self.keep_num_codebooks_dim:
+            indices = indices.reshape((B, c) + sp).movedim(1, -1).contiguous()        # [B, ..., c]
+        want_aux = self.compute_aux_loss and (self.entropy_loss_weight > 0 or self.commitment_loss_weight > 0)
+        if want_aux and not self.keep_num_codebooks_dim:
             st, codebook_entropy = self._aux_stats(h, inv_temperature)
             entropy_aux = st[0] - self.diversity_gamma * codebook_entropy
             aux = entropy_aux * self.calculate_entropy_loss_weight(n_steps) + st[2] * self.commitment_loss_weight
+        elif want_aux:
+            # the reference cannot run this combination either: with the codebook axis kept, its implicit codebook is
+            # flattened to one dimension and the distance einsum raises (regularizers.py:143-146,191-192,234)
+            raise NotImplementedError("FSQ entropy / commitment loss with keep_num_codebooks_dim (num_codebooks > 1): "
+                                      "the reference's forward raises for it (regularizers.py:234); set both weights to 0")
         else:
             aux = self.zero.to(z.device) * 1.0
         if self.has_projections:
