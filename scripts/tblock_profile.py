@@ -23,12 +23,23 @@ def main():
     ws = [(torch.randn((C_, 3 * C_), device=dev) / math.sqrt(3 * C_)).to(torch.bfloat16) for _ in range(2)]
     bs = [torch.randn((C_,), device=dev) * 0.1 for _ in range(2)]
     norms = [(torch.ones(C_, device=dev), torch.zeros(C_, device=dev)) for _ in range(3)]
-    stamps = torch.zeros((4, 4, 16), dtype=torch.int64, device=dev)
+    v3 = os.environ.get("VT_TBLOCK_V3", "1") != "0"
+    stamps = torch.zeros((8, 4, 8) if v3 else (4, 4, 16), dtype=torch.int64, device=dev)
     for _ in range(2):
         ops.temporal_block(x, ws[0], bs[0], ws[1], bs[1], norms[0], norms[1], tmode=L.VT_TPAD_ZERO,
                            next_ln=(norms[2][0], norms[2][1], True), keep_y=True, profile_out=stamps)
     torch.cuda.synchronize()
     s = stamps.cpu()
+    if v3:
+        mn = ["A: G1(k)", "barrier", "T1 <- acc", "B: G2(k-1)", "barrier", "T2 <- acc"]
+        vn = ["A: L2(k-1) rows", "barrier", "B: O(k-2) rows + stores", "B: L1(k+1) rows", "barrier", "-"]
+        for w in range(8):
+            names = mn if w < 4 else vn
+            for st in range(4):
+                d = [int(s[w, st, i + 1] - s[w, st, i]) for i in range(6)]
+                per = int(s[w, st + 1, 0] - s[w, st, 0]) if st < 3 else sum(d)
+                print(f"  {'matrix' if w < 4 else 'row   '} wave {w} step {8 + st}: period {per:6d} | " + " | ".join(f"{nm} {v}" for nm, v in zip(names, d)))
+        return
     for w in range(4):
         print(f"wave {w}:")
         for st in range(4):

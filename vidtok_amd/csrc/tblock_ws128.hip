@@ -471,6 +471,389 @@ __global__ __launch_bounds__(256, 1) void tblock_ws128_kernel(const TBlockArgs p
 #endif
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// v3: the same block on EIGHT waves with two roles.  What the cycle stamps of the kernel above showed
+// (profiles/r02_tblock_phase_cycles.txt): a 64-pixel step costs 14 960 cycles of which 3 072 are
+// MFMA; the three LayerNorm+SiLU per element are ~6 300 issue cycles of VALU work that a single wave per SIMD cannot put
+// behind its own MFMAs (an MFMA hides at most ~6 plain VALU instructions, and no packed-fp32 one).  So the SIMD gets a
+// second wave: waves 0-3 ("matrix waves", one per SIMD) keep the stationary weights and do nothing but the two GEMMs and
+// the accumulator transposes; waves 4-7 ("row waves") do every row phase.  The dependency chain of a step,
+//     L1(t) -> G1(t) -> L2(t) -> G2(t) -> O(t)        (L = LayerNorm+SiLU rows, G = GEMM, O = + x, y / next-norm stores)
+// is software-pipelined over the virtual steps k of a workgroup, two phases per step, one barrier each:
+//     phase A_k:  matrix: T2 <- acc2 (conv2 of step k-2), G1(k) -> acc1        rows: L2(k-1): T1 -> ring2
+//     phase B_k:  matrix: T1 <- acc1 (conv1 of step k), G2(k-1) -> acc2        rows: O(k-2): T2 (+ x) -> y, n;  L1(k+1) -> ring1
+// Every buffer is written in one phase and read in the next one (or later): ring slots by virtual step mod 3 (slot k+1 of
+// ring1 is rewritten in B_k, last read by G1(k) in A_k; slot k-1 of ring2 in A_k, last read by G2(k-2) in B_{k-1}); T1
+// holds conv1 as bf16 (272-B rows; b1 is added by the row waves), T2 conv2 in fp32.
+// LDS: 2 x 52 224 + 17 408 + 32 768 = 154 624 B.  Registers: 256 per wave (two waves per SIMD): 192 weights + 2 x 32
+// accumulators would not fit, so G1 and G2 share ONE accumulator set (each is parked in its T buffer right after the
+// barrier that ends its phase).
+// ---------------------------------------------------------------------------------------------------------------------
+[[maybe_unused]] constexpr int T3_T1P = 272;                              // bytes per T1 row: 128 bf16 + 16 pad (16-B aligned rows)
+[[maybe_unused]] constexpr int T3_OFF_T1 = 2 * TB_RING;
+[[maybe_unused]] constexpr int T3_OFF_T2 = 2 * TB_RING + TB_PIX * T3_T1P;
+[[maybe_unused]] constexpr int T3_LDS = T3_OFF_T2 + TB_T;                 // 154 624
+#ifndef T3_WA
+#define T3_WA 32     // weight fragments (of 48) kept in the accumulator half; the rest + the accumulators in the architectural half
+#endif
+// Row arithmetic of the row waves: plain (unpacked) fp32.  A packed-fp32 instruction does not execute next to an MFMA of
+// the OTHER wave of the SIMD either: with `v_pk_*` rows the row waves' LayerNorm passes stretched by the length of the
+// matrix waves' GEMMs (L2 4 430 cycles next to G1, 2 020 with the matrix pipe idle; profiles/r02_tblock_v3_phase_cycles.txt).
+// The pins keep the SLP vectoriser from re-pairing the elements.
+template <bool SILU>
+__device__ __forceinline__ void t3_row_norm(float (&v)[8], const float (&g)[8], const float (&b)[8], float eps, float (&o)[8]) {
+  float s = 0.f;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) s = s + v[e];
+  const float mean = group_sum_dpp<16>(s) * (1.0f / 128.0f);
+  float q = 0.f, d[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    d[e] = v[e] - mean;
+    tb_pin(d[e]);
+    q = __builtin_fmaf(d[e], d[e], q);
+  }
+  const float rstd = __builtin_amdgcn_rsqf(__builtin_fmaf(group_sum_dpp<16>(q), 1.0f / 128.0f, eps));
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    float u = __builtin_fmaf(d[e] * rstd, g[e], b[e]);
+    tb_pin(u);
+    if constexpr (SILU) {
+      const float ex = __builtin_amdgcn_exp2f(u * -1.4426950408889634f);
+      u = u * __builtin_amdgcn_rcpf(ex + 1.0f);
+      tb_pin(u);
+    }
+    o[e] = u;
+  }
+}
+__device__ __forceinline__ void t3_unpack8(const u32x4& w, float (&v)[8]) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    v[2 * q] = __uint_as_float(w[q] << 16);
+    v[2 * q + 1] = __uint_as_float(w[q] & 0xffff0000u);
+  }
+}
+__device__ __forceinline__ u32x4 t3_pack8(const float (&o)[8]) {
+  u32x4 w;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) w[q] = tb_pack2(f32x2{o[2 * q], o[2 * q + 1]});
+  return w;
+}
+
+template <bool W_IN_AGPR>
+__device__ __forceinline__ void t3_mfma(const u32x4& w, const u32x4& x, f32x16& acc) {
+  if constexpr (W_IN_AGPR) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "a"(w), "v"(x));
+  else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(w), "v"(x));
+}
+
+template <int LNN, bool KEEP, bool PROF = false>
+__global__ __launch_bounds__(512, 1) void tblock_split_kernel(const TBlockArgs p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ptiles = p.HW / TB_PIX;
+  const int ncols = p.B * ptiles;
+  const int G = gridDim.x;
+  const int slot_id = xcd_remap(blockIdx.x, G);
+  const int cq = ncols / G, cr = ncols - cq * G;
+  const int c_begin = slot_id * cq + min(slot_id, cr);
+  const int c_end = c_begin + cq + (slot_id < cr ? 1 : 0);
+  if (c_begin >= c_end) return;
+  const int n = (c_end - c_begin) * p.T;                             // virtual steps of this workgroup
+  char* ring1 = smem;
+  char* ring2 = smem + TB_RING;
+  char* T1 = smem + T3_OFF_T1;
+  float* T2 = reinterpret_cast<float*>(smem + T3_OFF_T2);
+  auto coords = [&](int k, int& col, int& t) {
+    const int q = k / p.T;
+    col = c_begin + q;
+    t = k - q * p.T;
+  };
+  auto col_base = [&](int col) -> long long {                        // element offset of (b, frame 0, first pixel of the tile)
+    const int b = col / ptiles;
+    const int pt = col - b * ptiles;
+    return ((long long)b * p.T * p.HW + (long long)pt * TB_PIX) * 128;
+  };
+  const long long frame_stride = (long long)p.HW * 128;
+  // PROF: stamps of workgroup 0, steps [8, 12): [wave][step][8] in the LDS behind T2, copied out at the end
+  unsigned long long* stamps = reinterpret_cast<unsigned long long*>(smem + T3_LDS);
+  int kcur = 0;
+  auto stamp = [&](int i) {
+    if constexpr (PROF) {
+      if (blockIdx.x == 0 && kcur >= 8 && kcur < 12) {
+        const unsigned long long ts = __builtin_amdgcn_s_memtime();
+        if (lane == 0) stamps[((kcur - 8) * 8 + wave) * 8 + i] = ts;
+      }
+    }
+  };
+  auto dump = [&]() {
+    if constexpr (PROF) {
+      if (blockIdx.x == 0 && lane == 0)
+        for (int i = 0; i < 32; ++i) p.prof[wave * 32 + i] = stamps[((i / 8) * 8 + wave) * 8 + (i % 8)];
+    }
+  };
+
+  if (wave < 4) {
+    // =================================================== matrix waves ===================================================
+    u32x4 wreg[48];
+    {
+      const long long roff = (long long)(wave * 32 + (lane & 31)) * 384 + (lane >> 5) * 8;
+#pragma unroll
+      for (int g = 0; g < 24; ++g) wreg[g] = *reinterpret_cast<const u32x4*>(p.w1 + roff + g * 16);
+#pragma unroll
+      for (int g = 0; g < 24; ++g) wreg[24 + g] = *reinterpret_cast<const u32x4*>(p.w2 + roff + g * 16);
+    }
+    const int h = lane >> 5;
+    const int frag_off = (lane & 31) * TB_ROWP + h * 16;             // B-fragment of pixel lane%32, k half lane/32
+    f32x16 acc[2];
+    // GEMM of virtual step k (frame t of its column) over the live taps [KT0, 3) of `ring`
+    auto gemm = [&](auto kt0_c, auto wbase_c, const char* ring, int k, int t) {
+      constexpr int KT0 = decltype(kt0_c)::value, WB = decltype(wbase_c)::value;
+      constexpr int G0 = KT0 * 8;
+      const char* sp[3];
+#pragma unroll
+      for (int kt = 0; kt < 3; ++kt) {
+        const int vs = (t - 2 + kt >= 0) ? k - 2 + kt : k - t;         // replicate: frames before the clip = its frame 0
+        sp[kt] = ring + (vs % 3) * TB_SLOT + frag_off;
+      }
+      auto faddr = [&](int g, int j) -> const u32x4* {
+        return reinterpret_cast<const u32x4*>(sp[g >> 3] + j * (32 * TB_ROWP) + (g & 7) * 32);
+      };
+      // fragments in MFMA order m = 2 g + j, a ring of four: the one used three MFMAs from now is requested behind each MFMA
+      // (two whole groups ahead, as in the 4-wave kernel, would take 24 registers; this path has 16 to spare)
+      constexpr int M0 = 2 * G0;
+      u32x4 xf[4];
+#pragma unroll
+      for (int m = M0; m < M0 + 3; ++m) xf[m % 4] = *faddr(m >> 1, m & 1);
+      tb_static_for<M0, 48>([&](auto mc) {
+        constexpr int m = decltype(mc)::value;
+        t3_mfma<(WB + (m >> 1) < T3_WA)>(wreg[WB + (m >> 1)], xf[m % 4], acc[m & 1]);
+        if constexpr (m + 3 < 48) xf[(m + 3) % 4] = *faddr((m + 3) >> 1, (m + 3) & 1);
+        __builtin_amdgcn_sched_barrier(0);
+      });
+      asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");             // last MFMA -> first VALU reader of its accumulator
+    };
+    auto run_gemm = [&](auto wbase_c, const char* ring, int k) {
+      int col, t;
+      coords(k, col, t);
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.0f;
+      const int first = p.replicate ? 0 : max(0, 2 - t);             // uniform
+      if (first == 0) gemm(std::integral_constant<int, 0>{}, wbase_c, ring, k, t);
+      else if (first == 1) gemm(std::integral_constant<int, 1>{}, wbase_c, ring, k, t);
+      else gemm(std::integral_constant<int, 2>{}, wbase_c, ring, k, t);
+    };
+    // accumulators: lane = pixel 32 j + lane % 32, channels 32 wave + 8 g + 4 h + e
+    auto acc_to_T1 = [&]() {                                         // rounded to bf16 (8 B per quad); b1 is added by the row waves
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int prow = 32 * j + (lane & 31);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int c = wave * 32 + 8 * g + 4 * h;
+          u32x2 w;
+          w[0] = tb_pack2(f32x2{acc[j][4 * g], acc[j][4 * g + 1]});
+          w[1] = tb_pack2(f32x2{acc[j][4 * g + 2], acc[j][4 * g + 3]});
+          *reinterpret_cast<u32x2*>(T1 + prow * T3_T1P + c * 2) = w;
+        }
+      }
+    };
+    auto acc_to_T2 = [&]() {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int prow = 32 * j + (lane & 31);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int c = wave * 32 + 8 * g + 4 * h;
+          f32x4 v;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = acc[j][4 * g + e];
+          *reinterpret_cast<f32x4*>(T2 + prow * 128 + (((c >> 2) ^ (prow & 31)) << 2)) = v;
+        }
+      }
+    };
+    __syncthreads();                                                 // L1(0) is in ring1
+    for (int k = 0; k < n + 2; ++k) {
+      kcur = k;
+      stamp(0);
+      // ---- phase A_k: G1(k); its result stays in the accumulators across the barrier
+      if (k < n && !(PROF && p.prof_mode == 1)) run_gemm(std::integral_constant<int, 0>{}, ring1, k);
+      stamp(1);
+      __syncthreads();
+      stamp(2);
+      // ---- phase B_k: park conv1(k) in T1, G2(k-1), park conv2(k-1) in T2 (read by the row waves in B_{k+1})
+      if (k < n) acc_to_T1();
+      stamp(3);
+      if (k >= 1 && k - 1 < n && !(PROF && p.prof_mode == 1)) {
+        run_gemm(std::integral_constant<int, 24>{}, ring2, k - 1);
+      }
+      stamp(4);
+      __syncthreads();
+      stamp(5);
+      // (start of A_{k+1}) conv2(k-1) -> T2: nobody reads T2 in an A phase
+      if (k >= 1 && k - 1 < n) acc_to_T2();
+      stamp(6);
+    }
+    dump();
+  } else {
+    // ===================================================== row waves =====================================================
+    // The row waves issue first: left at equal priority the older matrix wave of a SIMD wins every arbitration -- also
+    // while its next MFMA cannot issue yet -- and the row wave next to it stands still for the length of a GEMM (measured:
+    // L2 next to G1 = L2 alone + G1).  The matrix wave needs one issue slot per 32 cycles; it gets them in the row wave's
+    // dependency stalls.
+    __builtin_amdgcn_s_setprio(3);
+    const int vt = tid - 256;
+    const int oct_j = vt & 15, row0 = vt >> 4;                        // rows row0 + 16 it (it < 4), channels [8 oct_j, +8)
+    float lg1[8], lb1[8], lg2[8], lb2[8], lgn[8], lbn[8], bo1[8], bo2[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int c = 8 * oct_j + e;
+      bo1[e] = p.b1 ? p.b1[c] : 0.0f;
+      lg1[e] = p.g1[c]; lb1[e] = p.be1[c];
+      lg2[e] = p.g2[c]; lb2[e] = p.be2[c];
+      lgn[e] = LNN ? p.gn[c] : 1.0f;
+      lbn[e] = LNN ? p.ben[c] : 0.0f;
+      bo2[e] = p.b2 ? p.b2[c] : 0.0f;
+    }
+    const int row_lds = oct_j * 16;
+    auto ring_store = [&](char* ring, int vs, int row, const float (&o)[8]) {
+      *reinterpret_cast<u32x4*>(ring + (vs % 3) * TB_SLOT + row * TB_ROWP + row_lds) = t3_pack8(o);
+    };
+    auto load_rows = [&](Oct<bf16_t> (&dst)[4], int k) {            // x rows of virtual step k
+      int col, t;
+      coords(k, col, t);
+      const bf16_t* src = p.x + col_base(col) + (long long)t * frame_stride + 8 * oct_j;
+#pragma unroll
+      for (int it = 0; it < 4; ++it) dst[it].load(src + (long long)(row0 + 16 * it) * 128);
+    };
+    auto ln1_rows = [&](Oct<bf16_t> (&xr)[4], int k) {              // L1(k): LayerNorm1 + SiLU of x rows -> ring1
+      // L1 runs behind O, when the matrix waves have finished G2 and wait at the barrier: nothing for packed fp32 to
+      // collide with, and a packed row costs 2 080 cycles against 2 700
+      f32x2 g2v[4], b2v[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        g2v[q] = f32x2{lg1[2 * q], lg1[2 * q + 1]};
+        b2v[q] = f32x2{lb1[2 * q], lb1[2 * q + 1]};
+      }
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        f32x2 v[4], o[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = tb_unpack2(xr[it].w[q]);
+        tb_row_norm2<true>(v, g2v, b2v, p.eps, o);
+        u32x4 w;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) w[q] = tb_pack2(o[q]);
+        *reinterpret_cast<u32x4*>(ring1 + (k % 3) * TB_SLOT + (row0 + 16 * it) * TB_ROWP + row_lds) = w;
+      }
+    };
+    // x rows: of step k+1 for L1 and -- read a second time, from the L2 -- of step k-2 for the residual of O.  They are
+    // requested one whole step ahead, at the top of phase B and BEFORE that phase's y / n stores, into the register set
+    // the phase does not use (two sets, the loop body exists twice): a load issued behind stores would make its first use
+    // (and any reuse of the stores' operand registers) wait for those stores, and under this kernel's write traffic a
+    // store takes ~5 000 cycles to retire -- with the requests at the top of phase A, right behind the stores of
+    // phase B, L2 took 5 000 cycles instead of 2 100 (profiles/r02_tblock_v3_phase_cycles.txt).
+    struct XSet { Oct<bf16_t> xn[4], xr[4]; };
+    XSet sa, sb;
+    load_rows(sa.xn, 0);
+    ln1_rows(sa.xn, 0);
+    if (1 < n) load_rows(sa.xn, 1);                                  // x(1) for L1(1) in B_0
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      sa.xr[it].w = sa.xn[it].w;
+      sb.xn[it].w = sa.xn[it].w;
+      sb.xr[it].w = sa.xn[it].w;
+    }
+    __syncthreads();                                                 // L1(0) is in ring1
+    // GUARD = false: a step in the middle of the walk -- every load, store and phase is live, the body is straight-line
+    // code (with conditional loads / stores in it hipcc cannot count what is in flight and waits for everything)
+    auto body = [&](auto guard_c, int k, XSet& cur, XSet& nxt) {
+      constexpr bool GUARD = decltype(guard_c)::value;
+      kcur = k;
+      stamp(0);
+      // ---- phase A_k: L2(k-1): rows of T1 (conv1, bf16) + b1 -> LayerNorm2 + SiLU -> ring2
+      if (!GUARD || (k >= 1 && k - 1 < n)) {
+        u32x4 tw[4];
+#pragma unroll
+        for (int it = 0; it < 4; ++it) tw[it] = *reinterpret_cast<const u32x4*>(T1 + (row0 + 16 * it) * T3_T1P + row_lds);
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+          float v[8], o[8];
+          t3_unpack8(tw[it], v);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = v[e] + bo1[e];
+          t3_row_norm<true>(v, lg2, lb2, p.eps, o);
+          ring_store(ring2, k - 1, row0 + 16 * it, o);
+        }
+      }
+      stamp(1);
+      __syncthreads();
+      stamp(2);
+      // ---- phase B_k: requests for B_{k+1}; O(k-2): rows of T2 + b2 + x(k-2) -> y, LayerNorm_next -> n;  L1(k+1) -> ring1
+      if (!GUARD || k + 2 < n) load_rows(nxt.xn, k + 2);
+      if (!GUARD || (k >= 1 && k - 1 < n)) load_rows(nxt.xr, k - 1);
+      if (!GUARD || (k >= 2 && k - 2 < n)) {
+        int col, t;
+        coords(k - 2, col, t);
+        const long long ob = col_base(col) + (long long)t * frame_stride + 8 * oct_j;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+          f32x4 tq[2][2];
+#pragma unroll
+          for (int i2 = 0; i2 < 2; ++i2) {
+            const int row = row0 + 16 * (2 * half + i2);
+            const int sw = row & 31;
+            tq[i2][0] = *reinterpret_cast<const f32x4*>(T2 + row * 128 + (((2 * oct_j) ^ sw) << 2));
+            tq[i2][1] = *reinterpret_cast<const f32x4*>(T2 + row * 128 + (((2 * oct_j + 1) ^ sw) << 2));
+          }
+#pragma unroll
+          for (int i2 = 0; i2 < 2; ++i2) {
+            const int it = 2 * half + i2;
+            const int row = row0 + 16 * it;
+            const f32x4 t0 = tq[i2][0], t1 = tq[i2][1];
+            float v[8], xv[8];
+            t3_unpack8(cur.xr[it].w, xv);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              v[e] = xv[e] + ((e < 4 ? t0[e] : t1[e - 4]) + bo2[e]);
+              tb_pin(v[e]);
+            }
+            if constexpr (KEEP) *reinterpret_cast<u32x4*>(p.y + ob + (long long)row * 128) = t3_pack8(v);
+            if constexpr (LNN != 0) {
+              float o[8];
+              t3_row_norm<(LNN == 2)>(v, lgn, lbn, p.eps, o);
+              *reinterpret_cast<u32x4*>(p.n_out + ob + (long long)row * 128) = t3_pack8(o);
+            }
+          }
+        }
+      }
+      stamp(3);
+      if (!GUARD || k + 1 < n) ln1_rows(cur.xn, k + 1);
+      stamp(4);
+      __syncthreads();
+      stamp(5);
+      stamp(6);
+    };
+    // steps k in [2, n - 2) need no guards: k-2 >= 0 and k+2 < n
+    for (int k = 0; k < n + 2; k += 2) {
+      if (k >= 2 && k + 3 < n) {
+        body(std::false_type{}, k, sa, sb);
+        body(std::false_type{}, k + 1, sb, sa);
+      } else {
+        body(std::true_type{}, k, sa, sb);
+        if (k + 1 < n + 2) body(std::true_type{}, k + 1, sb, sa);
+      }
+    }
+    dump();
+  }
+#endif
+}
+
 }  // namespace
 
 // Fused temporal residual block, see include/vidtok_amd.h (vt_temporal_block).  Returns VT_ERR_ARG with a message when
@@ -521,7 +904,24 @@ int tblock_launch(const vt_tblock_desc* d, vt_stream stream_, unsigned long long
       reinterpret_cast<const void*>(&tblock_ws128_kernel<2, false>)};
   const void* kern = kerns[a.ln_next == 0 ? 0 : (a.ln_next == 1 ? (a.keep_y ? 1 : 2) : (a.keep_y ? 3 : 4))];
   int lds = TB_LDS;
-  if (prof != nullptr) {                      // measurement aid: the LayerNorm+SiLU, y kept instantiation with cycle stamps
+  unsigned threads = 256;
+  if (prof == nullptr && env_int("VT_TBLOCK_V3", 1) != 0) {      // two-role kernel (8 waves); VT_TBLOCK_V3=0: the 4-wave kernel
+    static const void* const kerns3[5] = {
+        reinterpret_cast<const void*>(&tblock_split_kernel<0, true>), reinterpret_cast<const void*>(&tblock_split_kernel<1, true>),
+        reinterpret_cast<const void*>(&tblock_split_kernel<1, false>), reinterpret_cast<const void*>(&tblock_split_kernel<2, true>),
+        reinterpret_cast<const void*>(&tblock_split_kernel<2, false>)};
+    kern = kerns3[a.ln_next == 0 ? 0 : (a.ln_next == 1 ? (a.keep_y ? 1 : 2) : (a.keep_y ? 3 : 4))];
+    lds = T3_LDS;
+    threads = 512;
+    VT_CHECK_HIP(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+  }
+  if (prof != nullptr && env_int("VT_TBLOCK_V3", 1) != 0) {   // stamps of the two-role kernel: [wave 0..7][step][8]
+    VT_CHECK_ARG(a.ln_next == 2 && a.keep_y, "vt_temporal_block_profile: ln_next_mode 2 and keep_y only");
+    kern = reinterpret_cast<const void*>(&tblock_split_kernel<2, true, true>);
+    lds = T3_LDS + 2048;
+    threads = 512;
+    VT_CHECK_HIP(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+  } else if (prof != nullptr) {               // measurement aid: the LayerNorm+SiLU, y kept instantiation with cycle stamps
     VT_CHECK_ARG(a.ln_next == 2 && a.keep_y, "vt_temporal_block_profile: ln_next_mode 2 and keep_y only");
     kern = reinterpret_cast<const void*>(&tblock_ws128_kernel<2, true, true>);
     lds = TB_LDS + TB_PROF_BYTES;
@@ -540,7 +940,7 @@ int tblock_launch(const vt_tblock_desc* d, vt_stream stream_, unsigned long long
   const long long ncols = (long long)d->B * (d->HW / TB_PIX);
   const int grid = ncols < ncu ? (int)ncols : ncu;
   void* kargs[] = {&a};
-  VT_CHECK_HIP(hipLaunchKernel(kern, dim3((unsigned)grid), dim3(256), kargs, lds, stream));
+  VT_CHECK_HIP(hipLaunchKernel(kern, dim3((unsigned)grid), dim3(threads), kargs, lds, stream));
   return VT_OK;
 }
 }  // namespace
