@@ -17,7 +17,7 @@ Launch: `python bench.py --gpus N` spawns its N ranks itself (re-executes under 
 --gpus N` it reads RANK / LOCAL_RANK / WORLD_SIZE from the environment.
 
   value       real frames/s over the whole job = N*B*17*K / max-over-ranks(time of K steps)
-  roofline    the MFMA kernels (conv_igemm_glds_kernel, conv3x3_ws128_kernel, conv3d_narrow_kernel, tblock_ws128_kernel: all
+  roofline    the MFMA kernels (conv_igemm_glds_kernel, conv3x3_ws128_kernel, conv3d_narrow_kernel, tblock_split_kernel: all
               convolutions + the attention GEMMs = every MFMA FLOP of the path): algorithmic FLOPs of one step (1.0345 TFLOP per padded 256x256 frame, SURVEY.md
               section 8d) / that kernel's time in one step.  The kernel time is measured live: the conv
               launches of one step (same descriptors, same tensors) are replayed back to back from a
@@ -104,7 +104,7 @@ def cpu_baseline():
                       f"{cores} host threads ({CONFIG_1GPU})"}
 
 
-MFMA_KERNELS = ("conv_igemm", "conv3x3_ws128", "conv3d_narrow", "tblock_ws128")
+MFMA_KERNELS = ("conv_igemm", "conv3x3_ws128", "conv3d_narrow", "tblock_ws128", "tblock_split")
 
 
 def measure_traffic(dtype, batch, timeout_s=200):
@@ -323,7 +323,7 @@ def main():
                     traffic = round(json.load(open(tpath))["traffic_bytes_per_launch"])
                     traffic_src = f"profiles/{os.path.basename(tpath)} (committed pass; live measurement: {traffic_src})"
                     break
-        roof = {"bound": "mfma", "kernel": "conv_igemm_glds_kernel + conv3x3_ws128_kernel + conv3d_narrow_kernel + tblock_ws128_kernel", "achieved": round(achieved, 2), "peak": peak,
+        roof = {"bound": "mfma", "kernel": "conv_igemm_glds_kernel + conv3x3_ws128_kernel + conv3d_narrow_kernel + tblock_split_kernel", "achieved": round(achieved, 2), "peak": peak,
                 "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_source": traffic_src,
                 "launches_per_step": len(tl), "kernel_ms_per_step": round(conv_ms, 3),
                 "avg_launch_ms": round(conv_ms / max(1, len(tl)), 4), "algorithmic_tflop_per_step": round(flops / 1e12, 3),
