@@ -97,6 +97,13 @@ def test_argument_validation_without_gpu(built_lib):
     assert b"Cin" in built_lib.vt_last_error()
     assert built_lib.vt_layernorm_act(16, 0, 104, 16, 0, 104, 16, 16, 10, 100, 1e-6, 1, None) == -1
     assert b"unsupported channel count" in built_lib.vt_last_error()
+    # the measurement aids validate like the calls they wrap, before anything is launched
+    assert built_lib.vt_conv_profile(C.byref(d), None, None) == -1 and b"null output" in built_lib.vt_last_error()
+    assert built_lib.vt_conv_profile(C.byref(d), 16, None) == -1 and b"Cin" in built_lib.vt_last_error()
+    t = lib.TBlockDesc()
+    assert built_lib.vt_temporal_block_profile(C.byref(t), None, None) == -1 and b"null output" in built_lib.vt_last_error()
+    assert built_lib.vt_temporal_block_profile(C.byref(t), 16, None) == -1 and b"only bf16" in built_lib.vt_last_error()
+    assert built_lib.vt_temporal_block(C.byref(t), None) == -1
 
 
 def test_fsq_constants_match_reference_formula(built_lib):
