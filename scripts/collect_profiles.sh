@@ -1,5 +1,6 @@
 #!/bin/bash
-# final numbers of the round: bench line with live PMC traffic + CPU baseline, breakdown, kernel table
+# what profiles/rNN_bench_bf16{.json,_conv_breakdown.txt,_kernel_stats.md} are made from: bench line with live PMC traffic +
+# CPU baseline, per-layer breakdown, rocprofv3 kernel table (run on the GPU box: gpurun -- bash scripts/collect_profiles.sh)
 export TMPDIR=/tmp
 mkdir -p gpurun_out
 R=/root/repo
