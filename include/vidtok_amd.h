@@ -66,6 +66,32 @@ int vt_version(void);
 int vt_conv_max_lds_bytes(void);
 
 /* ------------------------------------------------------------------------------------------
+ * Process-wide tuning / test switches.  Which kernel a call runs is a function of its descriptor and of this
+ * table only -- no launch path reads the environment.  The table is filled once, on first use, from the
+ * environment (variable VT_<NAME>, e.g. VT_CONV_SCHED=0, so shell A/B runs work) and changes afterwards only
+ * through vt_set_option; vt_reset_options() re-reads the environment defaults.  Every option selects between
+ * implementations of the SAME operator contract (the parity tests run both sides of each switch), so none of them
+ * is part of the reference's interface.  Names (default):
+ *   conv_buf (1)        gather through buffer descriptors; 0 = 64-bit pointers (always used for > 4 GiB tensors / cache mode)
+ *   conv_tinner (1)     temporal convolutions walk their tiles frames-innermost (L2 reuse of the kt taps)
+ *   conv_ldsepi (1)     128 x 128 tile: epilogue transposed through the LDS (whole-line stores, carries the fused LayerNorm)
+ *   conv_sched (1)      K-step schedule of the 8-wave 256 x 256 tile: 0 plain loop, 1 schedule 1, 2 two-group ping-pong
+ *   conv_ws (1)         weight-stationary persistent kernel for bf16 3x3 128 -> 128 convolutions
+ *   conv_narrow (1)     conv3d_narrow_kernel for Cout <= 4 (the decoder's conv_out)
+ *   conv_tile (0)       128 / 256: force that tile wherever it is legal; 0 = choose by size
+ *   conv_tile_min (128) fewest 256 x 256 tiles for which the 8-wave tile is chosen
+ *   conv_fuse_ln (1), conv_fuse_ln256 (1)   LayerNorm of the result inside the epilogue for Cout = 128 / 256
+ *   conv_ln256_v (1)    form of the Cout = 256 LayerNorm epilogue (0: round-2 form)
+ *   ws_acc (0), tblock_fused (1), tblock_prof_mode (0)   measurement aids
+ * Returns VT_ERR_ARG for an unknown name.
+ * ---------------------------------------------------------------------------------------- */
+int vt_set_option(const char* name, int32_t value);
+int vt_get_option(const char* name, int32_t* value);
+int vt_reset_options(void);
+int vt_option_count(void);
+const char* vt_option_name(int32_t i);    /* i < vt_option_count(), else NULL */
+
+/* ------------------------------------------------------------------------------------------
  * vt_conv -- implicit-GEMM convolution on NDHWC, M = B*To*Ho*Wo pixels x N = Cout x K = taps*Cin.
  * One entry point covers every convolution of the path:
  *   nn.Conv2d 3x3 s1 p1      ResnetBlock.conv1/conv2            model_3dcausal.py:296,301
@@ -190,7 +216,7 @@ int vt_tblock_desc_size(void);
 int vt_temporal_block_supported(const vt_tblock_desc* d);
 int vt_temporal_block(const vt_tblock_desc* d, vt_stream stream);
 /* Measurement aid (scripts/tblock_profile.py): the same launch (ln_next_mode 2, keep_y 1 only) with shader-clock
- * stamps at the phase boundaries of four steps of workgroup 0: stamps_out (device, 4*4*16 uint64) = [wave][step][stamp] */
+ * stamps at the phase boundaries of four steps of workgroup 0: stamps_out (device, 8*4*8 uint64) = [wave][step][stamp] */
 int vt_temporal_block_profile(const vt_tblock_desc* d, uint64_t* stamps_out, vt_stream stream);
 
 /* ------------------------------------------------------------------------------------------

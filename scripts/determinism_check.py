@@ -41,9 +41,8 @@ for shape in [(2, 5, 128, 128), (2, 17, 256, 256)]:
         o0 = outs[0] if isinstance(outs[0], tuple) else (outs[0],)
         sl = tuple(t[1:2] for t in o0)
         bi = eq(sl, one)
-        os.environ["VT_CONV_WS"] = "0"
-        ig = ops.conv(x, w, bias, G3, cout=C_, **kw)
-        os.environ["VT_CONV_WS"] = "1"
+        with L.options(conv_ws=0):
+            ig = ops.conv(x, w, bias, G3, cout=C_, **kw)
         ig = ig if isinstance(ig, tuple) else (ig,)
         dmax = max(float((a.float() - b.float()).abs().max()) for a, b in zip(o0, ig))
         print(f"ws128 {shape} {name:8s}: repeatable {rep}, batch-independent {bi}, max |ws - igemm| {dmax:.3e}")

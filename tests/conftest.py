@@ -36,3 +36,16 @@ def built_lib():
 
     build.build(verbose=False)
     return lib.load()
+
+
+@pytest.fixture
+def vt_opts():
+    """set process-wide switches of libvidtok_amd.so for one test (vt_set_option); the defaults come back afterwards"""
+    from vidtok_amd import lib
+
+    def setter(**kv):
+        for k, v in kv.items():
+            lib.set_option(k, int(v))
+
+    yield setter
+    lib.load().vt_reset_options()

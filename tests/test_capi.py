@@ -129,8 +129,8 @@ def test_missing_library_fails_loudly(tmp_path, monkeypatch):
 
 
 def test_conv_plan_tile_selection(built_lib, monkeypatch):
-    """vt_conv_plan (no GPU): the 8-wave 256x256 tile is what BASELINE-sized Cout % 256 == 0 layers get, VT_CONV_TILE
-    forces / forbids it for small parity cases, LayerNorm is fused only for Cout = 128 on full tiles."""
+    """vt_conv_plan (no GPU): the 8-wave 256x256 tile is what BASELINE-sized Cout % 256 == 0 layers get, the conv_tile option
+    forces / forbids it for small parity cases (option conv_tile), LayerNorm is fused only for Cout = 128 on full tiles."""
     from vidtok_amd import lib as L
     from vidtok_amd import ops
 
@@ -148,18 +148,18 @@ def test_conv_plan_tile_selection(built_lib, monkeypatch):
             setattr(d, k, v)
         return d
 
-    monkeypatch.delenv("VT_CONV_TILE", raising=False)
+    L.load().vt_reset_options()
     big = ops.conv_plan(desc((1280, 1024), 256, 256))            # the 256-channel level of the benchmark (B=4: 20 frames)
     assert big["tile"] == (256, 256) and big["waves"] == 8 and big["workgroups"] == 5120
     assert ops.conv_plan(desc((64, 64), 256, 256))["tile"] == (128, 128)
     assert ops.conv_plan(desc((64, 64), 128, 8))["tile"] == (256, 32)
     assert ops.conv_plan(desc((64, 64), 128, 64))["tile"] == (256, 64)
-    monkeypatch.setenv("VT_CONV_TILE", "256")
-    assert ops.conv_plan(desc((64, 64), 256, 256))["tile"] == (256, 256)
-    assert ops.conv_plan(desc((64, 64), 256, 128))["tile"] == (128, 128)     # not legal there
-    monkeypatch.setenv("VT_CONV_TILE", "128")
-    assert ops.conv_plan(desc((1280, 1024), 256, 256))["tile"] == (128, 128)
-    monkeypatch.delenv("VT_CONV_TILE")
+    with L.options(conv_tile=256):
+        assert ops.conv_plan(desc((64, 64), 256, 256))["tile"] == (256, 256)
+        assert ops.conv_plan(desc((64, 64), 256, 128))["tile"] == (128, 128)     # not legal there
+    with L.options(conv_tile=128):
+        assert ops.conv_plan(desc((1280, 1024), 256, 256))["tile"] == (128, 128)
+    assert L.get_option("conv_tile") == 0
     ln = dict(ln_mode=2, ln_gamma=4096, ln_beta=4096, ln_out=4096, ldn=128, ln_eps=1e-6)
     p = ops.conv_plan(desc((64, 64), 128, 128, **ln))
     assert p["ln_fused"] and p["launches"] == 1
@@ -172,9 +172,8 @@ def test_conv_plan_tile_selection(built_lib, monkeypatch):
     assert ops.conv_plan(desc((256, 256), 128, 128, **dict(ln, ldn=128)))["ln_fused"]
     assert ops.conv_plan(desc((256, 250), 128, 128))["kernel"] == "igemm"
     assert ops.conv_plan(desc((256, 256), 128, 128, dtype=L.VT_F32, out_dtype=L.VT_F32))["kernel"] == "igemm"
-    monkeypatch.setenv("VT_CONV_WS", "0")
-    assert ops.conv_plan(desc((256, 256), 128, 128))["kernel"] == "igemm"
-    monkeypatch.delenv("VT_CONV_WS")
+    with L.options(conv_ws=0):
+        assert ops.conv_plan(desc((256, 256), 128, 128))["kernel"] == "igemm"
     # the narrow-output kernel: the decoder's conv_out at the benchmark size (B = 4, 20 frames, 3 trimmed, 256 x 256)
     co = dict(KT=3, pt=2, ldw=27 * 128, out_dtype=L.VT_F32, out_layout=L.VT_NCTHW, t_trim=3, B=4, Ti=20, To=20)
     p = ops.conv_plan(desc((256, 256), 128, 3, **co))
@@ -182,8 +181,36 @@ def test_conv_plan_tile_selection(built_lib, monkeypatch):
     assert p["workgroups"] == 4 * 2 * 32 * 5                     # clips x time segments x row blocks x groups of 4 windows
     assert ops.conv_plan(desc((256, 256), 128, 3, **dict(co, out_layout=L.VT_NDHWC, t_trim=0, ldy=4)))["kernel"] == "igemm"
     assert ops.conv_plan(desc((256, 256), 128, 8, **co))["kernel"] == "igemm"
-    monkeypatch.setenv("VT_CONV_NARROW", "0")
-    assert ops.conv_plan(desc((256, 256), 128, 3, **co))["kernel"] == "igemm"
-    monkeypatch.delenv("VT_CONV_NARROW")
+    with L.options(conv_narrow=0):
+        assert ops.conv_plan(desc((256, 256), 128, 3, **co))["kernel"] == "igemm"
     with pytest.raises(L.VtError):
         ops.conv_plan(desc((64, 64), 100, 128))                  # same validation as vt_conv
+
+
+def test_options_table(built_lib, monkeypatch):
+    """vt_set_option / vt_get_option / vt_reset_options: every option is listed in the header's comment, unknown names are
+    errors, the environment only provides the defaults (read by vt_reset_options, never by a launch)."""
+    from vidtok_amd import lib as L
+
+    names = L.option_names()
+    hdr = open(os.path.join(ROOT, "include", "vidtok_amd.h")).read()
+    doc = hdr[hdr.index("Process-wide tuning / test switches"):hdr.index("int vt_set_option")]
+    assert len(names) == built_lib.vt_option_count() >= 12 and built_lib.vt_option_name(len(names)) is None
+    for n in names:
+        assert re.search(r"\b" + n + r"\b", doc), f"option {n} is not documented in include/vidtok_amd.h"
+    with pytest.raises(L.VtError):
+        L.set_option("no_such_option", 1)
+    with pytest.raises(L.VtError):
+        L.get_option("no_such_option")
+    built_lib.vt_reset_options()
+    assert L.get_option("conv_sched") == 1 and L.get_option("conv_tile_min") == 128
+    with L.options(conv_sched=0, conv_tile_min=7):
+        assert L.get_option("conv_sched") == 0 and L.get_option("conv_tile_min") == 7
+        monkeypatch.setenv("VT_CONV_SCHED", "2")          # the environment is not consulted after start-up ...
+        assert L.get_option("conv_sched") == 0
+    assert L.get_option("conv_sched") == 1
+    built_lib.vt_reset_options()                           # ... except by an explicit reset
+    assert L.get_option("conv_sched") == 2
+    monkeypatch.delenv("VT_CONV_SCHED")
+    built_lib.vt_reset_options()
+    assert L.get_option("conv_sched") == 1

@@ -205,3 +205,61 @@ def test_rare_constructor_options_match_oracle(ov, T, emulated_ops):
     z2, _ = ora.encode(x)
     dec2 = ora.decode(z2)
     assert dec.shape == dec2.shape and rel_err(z, z2) < 2e-5 and rel_err(dec, dec2) < 5e-5
+
+
+def test_chunk_cache_buffers_are_released_between_eager_passes(emulated_ops):
+    """ADVICE r2: the persistent v1.1 chunk-cache buffers (modules.py::_CausalState._persistent) must not accumulate:
+    an eager tiled pass leaves one buffer per (module, shape), the next encode / decode starts by dropping them, and
+    invalidate_graphs() / .to() drop them when the graph cache is on."""
+    model, cfg, sd = build_model("vidtok_v1_1/vidtok_kl_causal_488_16chn_v1_1", seed=3)
+    model.use_tiling, model.t_chunk_enc, model.use_overlap = True, 8, True
+    model.t_chunk_dec = 2
+
+    def n_bufs():
+        return sum(len(m.__dict__.get("_cache_bufs", {})) for m in model.modules())
+
+    x = torch.rand(1, 3, 17, 16, 16) * 2 - 1
+    model(x)
+    assert n_bufs() > 0
+    per_pass = n_bufs()
+    model(torch.rand(1, 3, 17, 16, 24) * 2 - 1)             # another resolution: the first one's buffers are gone
+    assert n_bufs() <= per_pass
+    model._empty_causal_cached(model)
+    assert n_bufs() == 0 and all(getattr(m, "causal_cache", None) is None for m in model.modules())
+    model.use_graphs = True                                   # (no capture on the host; only the bookkeeping is tested)
+    model(x)
+    model._empty_causal_cached(model.encoder)
+    assert n_bufs() > 0                                       # captured chunks would replay against these: kept ...
+    model.invalidate_graphs()
+    assert n_bufs() == 0                                      # ... until the graphs go
+
+
+def test_graph_cache_bookkeeping_and_engine_copies():
+    """GraphedCall keeps at most MAX_ENTRIES shapes (LRU; stateful chunk graphs are only dropped by the owner between
+    passes), and a deep copy / pickle of an engine runs ITS OWN encoder and decoder (closures over `self`)."""
+    import copy
+    import pickle
+
+    from vidtok_amd.graphs import GraphedCall
+
+    g = GraphedCall(lambda t: t)
+    for i in range(GraphedCall.MAX_ENTRIES + 5):
+        g.entries[i] = "warm" if i % 2 else (None, None, None, None)
+        g._touch(i)
+    assert len(g.entries) == GraphedCall.MAX_ENTRIES and 0 not in g.entries and not g.overfull
+    g._touch(5)
+    assert list(g.entries)[-1] == 5
+    for i in range(100, 100 + GraphedCall.MAX_ENTRIES + 3):    # stateful entries pile up until the owner resets
+        g.entries[i] = (None, None, None, [("module", "cache")])
+        g._touch(i)
+    assert g.overfull and all(k >= 100 for k in g.entries)
+    g.clear()
+    assert not g.entries and not g.overfull
+
+    model, cfg, sd = build_model("vidtok_kl_causal_488_4chn", seed=3)
+    model._genc.entries["x"] = "warm"
+    for other in (copy.deepcopy(model), pickle.loads(pickle.dumps(model))):
+        assert other._genc is not model._genc and not other._genc.entries
+        assert other._genc.fn.__self__ is other and other._gdec.fn.__self__ is other
+        assert other._genc.state_get.__self__ is other and other._genc.fn.__func__ is type(model)._encoder_fn
+        assert torch.equal(other.state_dict()["encoder.conv_in.conv.weight"], model.state_dict()["encoder.conv_in.conv.weight"])

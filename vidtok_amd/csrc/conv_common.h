@@ -1,8 +1,7 @@
 // Types and helpers of the convolution kernel (conv_igemm.hip).
 #pragma once
-#include <stdlib.h>
-
 #include "common.h"
+#include "options.h"
 
 namespace {
 
@@ -182,12 +181,6 @@ __device__ __forceinline__ long long out_row(const ConvArgs& p, int m) {
   }
   if (p.yt_mul == 1) return m;                                    // uniform
   return (long long)m + (long long)fast_div((unsigned)m, p.fd_hw) * p.yt_step + p.yt_base;
-}
-
-// environment switch helper for same-run A/B measurements: value of `name` or `dflt`
-inline int env_int(const char* name, int dflt) {
-  const char* e = getenv(name);
-  return e ? atoi(e) : dflt;
 }
 
 }  // namespace

@@ -911,8 +911,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_igemm_glds_ker
 //   VT_CONV_TINNER=0  plain pixel order for temporal convs
 //   VT_CONV_TILE=256  force the 8-wave 256x256 tile wherever it is legal (Cout % 256 == 0, vector epilogue), however
 //                     few tiles that gives; =128 forbids it -- lets small parity cases reach either instantiation
-inline bool conv_buf() { return env_int("VT_CONV_BUF", 1) != 0; }
-inline bool conv_tinner() { return env_int("VT_CONV_TINNER", 1) != 0; }
+inline bool conv_buf() { return vt_opt(OPT_CONV_BUF) != 0; }
+inline bool conv_tinner() { return vt_opt(OPT_CONV_TINNER) != 0; }
 
 template <typename MT, typename TOut, int WAVES_M, int WAVES_N, int TM, int TN, bool FAST, bool LN256 = false>
 int launch_variant(const ConvArgs& a_in, int nbatch, hipStream_t stream) {
@@ -932,7 +932,7 @@ int launch_variant(const ConvArgs& a_in, int nbatch, hipStream_t stream) {
   // producers of those lines right before their consumer on the same XCD (xcd_remap keeps the sequence
   // contiguous): 298 -> 340 TFLOP/s on that layer, +3 % on the 27-tap up-sampler conv (same-run A/B).
   constexpr int kOctAlign = 16 / (int)sizeof(TOut) > 4 ? 8 : 4;   // elements per 16 bytes, at least a quad
-  a.lds_epi = (env_int("VT_CONV_LDSEPI", 1) != 0 && a.out_layout == VT_NDHWC && a.ldy % kOctAlign == 0 &&
+  a.lds_epi = (vt_opt(OPT_CONV_LDSEPI) != 0 && a.out_layout == VT_NDHWC && a.ldy % kOctAlign == 0 &&
                (a.res_mode == VT_RES_NONE || a.ldr % kOctAlign == 0) && (a.ln_mode == 0 || a.ldn % kOctAlign == 0)) ? 1 : 0;
   a.hw_tiles = 0;
   if (conv_tinner() && a.KT > 1 && a.To > 1 && ((long long)a.Ho * a.Wo) % BM == 0) a.hw_tiles = (int)(((long long)a.Ho * a.Wo) / BM);
@@ -944,7 +944,7 @@ int launch_variant(const ConvArgs& a_in, int nbatch, hipStream_t stream) {
   const void* kern;
   // VT_CONV_SCHED=0: the plain K-step schedule of the 8-wave tile (A/B runs); default 1, see the kernel
   constexpr bool HAS_S1 = WAVES_M * WAVES_N == 8 && FAST;
-  const bool s1 = HAS_S1 && buf && env_int("VT_CONV_SCHED", 1) != 0;
+  const bool s1 = HAS_S1 && buf && vt_opt(OPT_CONV_SCHED) != 0;
   if (buf) {
     a.x_bytes = (unsigned)xb;
     a.w_bytes = (unsigned)wb;
@@ -1000,7 +1000,7 @@ enum TileKind { TILE_256x32 = 0, TILE_256x64, TILE_256x256, TILE_128x128 };
 // frames that tile by 8 x 16 pixels -- the nine ResnetBlock convolutions of the widest level.  VT_CONV_WS=0 keeps them
 // on the tile-per-workgroup kernel (A/B runs, and the parity tests run both).
 inline bool ws128_eligible(const ConvArgs& a, int nbatch, bool bf16_io) {
-  if (!bf16_io || env_int("VT_CONV_WS", 1) == 0) return false;
+  if (!bf16_io || vt_opt(OPT_CONV_WS) == 0) return false;
   if (a.Cin != 128 || a.Cout != 128 || a.ldw != 1152 || a.ldy != 128) return false;
   if (a.KT != 1 || a.KH != 3 || a.KW != 3 || a.st != 1 || a.sh != 1 || a.sw != 1 || a.ph != 1 || a.pw != 1) return false;
   if (a.ups_t || a.ups_s || a.Ho != a.Hi || a.Wo != a.Wi || a.To != a.Ti) return false;
@@ -1015,7 +1015,7 @@ inline bool ws128_eligible(const ConvArgs& a, int nbatch, bool bf16_io) {
 // Narrow-output 3x3x3 convolution (conv_narrow.hip): bf16 in, fp32 NCTHW out, Cin = 128, Cout <= 4 -- the decoder's
 // conv_out (reference model_3dcausal.py:862-870).  VT_CONV_NARROW=0 keeps it on the 256 x 32 implicit-GEMM tile.
 inline bool narrow_eligible(const ConvArgs& a, int nbatch, int dtype, int out_dtype, int ln_mode) {
-  if (dtype != VT_BF16 || out_dtype != VT_F32 || a.out_layout != VT_NCTHW || env_int("VT_CONV_NARROW", 1) == 0) return false;
+  if (dtype != VT_BF16 || out_dtype != VT_F32 || a.out_layout != VT_NCTHW || vt_opt(OPT_CONV_NARROW) == 0) return false;
   if (a.Cin != 128 || a.Cout > 4 || a.KT != 3 || a.KH != 3 || a.KW != 3) return false;
   if (a.st != 1 || a.sh != 1 || a.sw != 1 || a.ph != 1 || a.pw != 1 || a.pt < 1 || a.pt > 2) return false;
   if (a.ups_t || a.ups_s || a.Ho != a.Hi || a.Wo != a.Wi || a.To != a.Ti) return false;
@@ -1032,10 +1032,10 @@ inline TileKind select_tile(const ConvArgs& a, int nbatch) {
   const bool vec_epi = a.out_layout == VT_NDHWC && (a.ldy & 3) == 0 && (a.res_mode == VT_RES_NONE || (a.ldr & 3) == 0);
   if (a.Cout <= 32) return TILE_256x32;
   if (a.Cout <= 64) return TILE_256x64;
-  const int force = env_int("VT_CONV_TILE", 0);
+  const int force = vt_opt(OPT_CONV_TILE);
   // at least VT_CONV_TILE_MIN (default 128) tiles: with K-step schedule 1 even half-filled single rounds of the 8-wave
   // tile beat 1.25 rounds of 128 x 128 tiles (M = 20 480, Cout = 512: 0.143 -> 0.121 ms at K = 4 608, 0.38 -> 0.29 at 13 824)
-  if (a.Cout % 256 == 0 && vec_epi && force != 128 && (blocks(256, 256) >= env_int("VT_CONV_TILE_MIN", 128) || force == 256)) return TILE_256x256;
+  if (a.Cout % 256 == 0 && vec_epi && force != 128 && (blocks(256, 256) >= vt_opt(OPT_CONV_TILE_MIN) || force == 256)) return TILE_256x256;
   return TILE_128x128;
 }
 
@@ -1145,13 +1145,13 @@ int conv_prepare(const vt_conv_desc* d, ConvArgs& a, bool& ln_fused, int& nbatch
   const bool ws_ln_ok = d->ln_mode == 0 || (d->ldn == 128 && (reinterpret_cast<uintptr_t>(d->ln_out) & 15) == 0);
   use_ws = ws_ln_ok && ws128_eligible(a, nbatch, bf16_io);
   ln_fused = d->ln_mode != 0 && (use_ws || (d->Cout == 128 && M % 128 == 0 && (d->ldy & 7) == 0 && (d->ldn & 7) == 0 &&
-                        (d->res_mode == VT_RES_NONE || (d->ldr & 7) == 0) && env_int("VT_CONV_LDSEPI", 1) != 0 &&
-                        env_int("VT_CONV_FUSE_LN", 1) != 0));
+                        (d->res_mode == VT_RES_NONE || (d->ldr & 7) == 0) && vt_opt(OPT_CONV_LDSEPI) != 0 &&
+                        vt_opt(OPT_CONV_FUSE_LN) != 0));
   // ... or inside the 8-wave 256 x 256 tile's epilogue for Cout = 256 (conv_epilogue_lds256): full tiles, plain rows
   if (d->ln_mode != 0 && !ln_fused && d->Cout == 256 && M % 256 == 0 && d->dtype == d->out_dtype && nbatch == 1 &&
       d->Cin % (kRowBytes / (d->dtype == VT_F32 ? 4 : 2)) == 0 && (d->ldy & 3) == 0 && (d->ldn & 3) == 0 &&
       (d->res_mode == VT_RES_NONE || (d->res_mode == VT_RES_ADD && (d->ldr & 3) == 0 && d->Tr == d->To && d->res_tshift == 0)) &&
-      env_int("VT_CONV_FUSE_LN256", 1) != 0 && select_tile(a, nbatch) == TILE_256x256)
+      vt_opt(OPT_CONV_FUSE_LN256) != 0 && select_tile(a, nbatch) == TILE_256x256)
     ln_fused = true;
   if (ln_fused) {
     a.ln_gamma = d->ln_gamma; a.ln_beta = d->ln_beta; a.ln_out = (char*)d->ln_out;

@@ -451,7 +451,7 @@ extern "C" __attribute__((visibility("hidden"))) int vt_ws128_launch(const void*
   // one instantiation per epilogue shape: LayerNorm none / plain / +SiLU, y kept or not
   const bool keep = a.ln_mode == 0 || a.ln_keep_y != 0;
   const int vi = a.ln_mode == 0 ? 0 : (a.ln_mode == 1 ? (keep ? 1 : 2) : (keep ? 3 : 4));
-  const int acc_a = env_int("VT_WS_ACC", 0) != 0 ? 1 : 0;   // measured: no difference; the architectural placement compiles without spills
+  const int acc_a = vt_opt(OPT_WS_ACC) != 0 ? 1 : 0;   // measured: no difference; the architectural placement compiles without spills
   static const void* const kerns[2][5] = {
       {reinterpret_cast<const void*>(&conv3x3_ws128_kernel<0, true, false>), reinterpret_cast<const void*>(&conv3x3_ws128_kernel<1, true, false>),
        reinterpret_cast<const void*>(&conv3x3_ws128_kernel<1, false, false>), reinterpret_cast<const void*>(&conv3x3_ws128_kernel<2, true, false>),

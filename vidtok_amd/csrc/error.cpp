@@ -14,5 +14,5 @@ void vt_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* vt_last_error(void) { return g_err; }
-extern "C" int vt_version(void) { return 100; }
+extern "C" int vt_version(void) { return 103; }
 extern "C" int vt_conv_desc_size(void) { return (int)sizeof(vt_conv_desc); }

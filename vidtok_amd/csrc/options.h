@@ -1,0 +1,26 @@
+// Process-wide tuning / test switches of libvidtok_amd (vt_set_option / vt_get_option, include/vidtok_amd.h).
+// Kernel selection is a function of the descriptor and of THIS table only: the table is filled once from the
+// environment (VT_<NAME> of the option, so shell A/B runs keep working) and changed afterwards only through
+// vt_set_option -- no launch path reads the environment.
+#pragma once
+
+enum VtOpt {
+  OPT_CONV_BUF = 0,        // 1: gather through buffer descriptors (buffer_load ... lds); 0: 64-bit pointers (global_load_lds)
+  OPT_CONV_TINNER,         // 1: temporal convs walk the tiles frames-innermost
+  OPT_CONV_LDSEPI,         // 1: 128 x 128 tile: epilogue transposed through the LDS (needed by its fused LayerNorm)
+  OPT_CONV_SCHED,          // K-step schedule of the 8-wave tile: 0 plain loop, 1 schedule 1, 2 two-group ping-pong
+  OPT_CONV_WS,             // 1: weight-stationary persistent kernel for the 3x3 128 -> 128 convolutions
+  OPT_CONV_NARROW,         // 1: conv3d_narrow_kernel for Cout <= 4
+  OPT_CONV_TILE,           // 0 auto, 128 / 256: force the tile where legal
+  OPT_CONV_TILE_MIN,       // fewest 256 x 256 tiles for which the 8-wave tile is chosen
+  OPT_CONV_FUSE_LN,        // 1: LayerNorm in the 128 x 128 tile's epilogue (Cout = 128)
+  OPT_CONV_FUSE_LN256,     // 1: LayerNorm in the 8-wave tile's epilogue (Cout = 256)
+  OPT_CONV_LN256_V,        // LN256 epilogue variant: 0 = round-2 form, 1 = residual prefetch + packed row arithmetic
+  OPT_WS_ACC,              // ws128: accumulator placement (measurement aid)
+  OPT_TBLOCK_FUSED,        // 1: vt_temporal_block_supported may answer yes
+  OPT_TBLOCK_PROF_MODE,    // vt_temporal_block_profile: 1 = row jobs skipped
+  OPT_COUNT
+};
+
+// current value of an option (atomic load; first call reads the environment)
+int vt_opt(int id);

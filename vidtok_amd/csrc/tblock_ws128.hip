@@ -7,18 +7,18 @@
 // input, the intermediate twice, the residual, the result and the next norm -- ~2 KiB -- in two launches of 1.45 ms.
 // Here a block reads x once and writes y (+ the next norm) once: 512-768 B per pixel, one launch.
 //
-// Structure (weight-stationary like conv_ws128.hip): one workgroup per CU, 4 waves = one per SIMD with the whole
-// register file; wave w keeps output channels [32w, 32w+32) of BOTH convolutions (2 x 24 MFMA A-fragments = 192
-// registers, all in the accumulator half) for the lifetime of the kernel.  A workgroup owns pixel columns -- 64
-// consecutive pixels of one clip -- and walks each column through time:
-//   step t:  x[t] rows (prefetched into registers one step ahead) -> LN1+SiLU -> ring1[t % 3]          (LDS, bf16)
-//            GEMM1: taps = ring1 slots of frames t-2, t-1, t                 -> T (fp32, transposed)   (LDS)
-//            rows of T + b1 -> LN2+SiLU -> ring2[t % 3]
-//            GEMM2: taps = ring2 slots                                        -> T
-//            rows of T + b2 + x[t] (still in registers) -> y[t], LayerNorm_next -> n[t]                (HBM)
+// Structure (weight-stationary like conv_ws128.hip): one workgroup per CU; the weights of BOTH convolutions stay in
+// registers for the lifetime of the kernel.  A workgroup owns pixel columns -- 64 consecutive pixels of one clip -- and
+// walks each column through time:
+//   step t:  x[t] rows (prefetched into registers) -> LN1+SiLU -> ring1[t % 3]                         (LDS, bf16)
+//            GEMM1: taps = ring1 slots of frames t-2, t-1, t                 -> T1 (bf16, transposed)  (LDS)
+//            rows of T1 + b1 -> LN2+SiLU -> ring2[t % 3]
+//            GEMM2: taps = ring2 slots                                        -> T2 (fp32)
+//            rows of T2 + b2 + x[t] -> y[t], LayerNorm_next -> n[t]                                     (HBM)
 // Causal padding: frames before the clip are zeros (v1.0: their taps are skipped) or the first frame repeated (v1.1
 // first chunk / un-tiled).  Chunk-to-chunk caches (v1.1 tiling) are not handled here: the host keeps those blocks on
-// the unfused path.  Four barriers per step; nothing depends on load / store ordering.
+// the unfused path.  (The first generation of this kernel -- four waves, one per SIMD, every phase on the same wave:
+// 14 960 cycles per step -- is in the history at commit da80542.)
 #include <atomic>
 #include <type_traits>
 
@@ -31,7 +31,6 @@ namespace {
 [[maybe_unused]] constexpr int TB_SLOT = TB_PIX * TB_ROWP;       // 17 408
 [[maybe_unused]] constexpr int TB_RING = 3 * TB_SLOT;            // 52 224
 [[maybe_unused]] constexpr int TB_T = TB_PIX * 128 * 4;          // 32 768
-[[maybe_unused]] constexpr int TB_LDS = 2 * TB_RING + TB_T;      // 137 216: [ring1][ring2][T]
 
 struct TBlockArgs {
   const bf16_t* x;
@@ -52,8 +51,6 @@ struct TBlockArgs {
   unsigned long long* prof;   // PROF instantiation only (vt_temporal_block_profile): cycle stamps of workgroup 0
   int prof_mode;              // PROF only: 1 = row jobs skipped (wrong results; times the bare GEMMs), VT_TBLOCK_PROF_MODE
 };
-[[maybe_unused]] constexpr int TB_PROF_STEPS = 4, TB_PROF_FIRST = 8, TB_PROF_STAMPS = 16;
-[[maybe_unused]] constexpr int TB_PROF_BYTES = TB_PROF_STEPS * 4 * TB_PROF_STAMPS * 8;
 
 template <int I, int N, typename F>
 __device__ __forceinline__ void tb_static_for(F&& f) {
@@ -61,13 +58,6 @@ __device__ __forceinline__ void tb_static_for(F&& f) {
     f(std::integral_constant<int, I>{});
     tb_static_for<I + 1, N>(f);
   }
-}
-
-// accumulators in the architectural half, stationary weights in the accumulator half (see conv_ws128.hip)
-template <bool ACC_A>
-__device__ __forceinline__ void tb_mfma(const u32x4& w, const u32x4& x, f32x16& acc) {
-  if constexpr (ACC_A) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc) : "a"(w), "v"(x));
-  else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "a"(w), "v"(x));
 }
 
 // LayerNorm (+SiLU) of one pixel row held by 16 lanes x 8 channels; two-pass statistics like layernorm_act_kernel.
@@ -127,353 +117,8 @@ __device__ __forceinline__ void tb_row_norm2(f32x2 (&v)[4], const f32x2 (&g)[4],
 __device__ __forceinline__ void tb_pin(float& v) { asm volatile("" : "+v"(v)); }
 __device__ __forceinline__ void tb_pin2(f32x2& v) { asm volatile("" : "+v"(v)); }
 
-// LNN: next norm 0 none / 1 LayerNorm / 2 LayerNorm+SiLU; KEEP: y is written
-template <int LNN, bool KEEP, bool PROF = false>
-__global__ __launch_bounds__(256, 1) void tblock_ws128_kernel(const TBlockArgs p) {
-#if defined(__HIP_DEVICE_COMPILE__)
-  constexpr bool ACC_A = true;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int ptiles = p.HW / TB_PIX;
-  const int ncols = p.B * ptiles;
-  const int G = gridDim.x;
-  const int slot_id = xcd_remap(blockIdx.x, G);
-  const int cq = ncols / G, cr = ncols - cq * G;
-  const int c_begin = slot_id * cq + min(slot_id, cr);
-  const int c_end = c_begin + cq + (slot_id < cr ? 1 : 0);
-  if (c_begin >= c_end) return;
-
-  char* ring1 = smem;
-  char* ring2 = smem + TB_RING;
-  float* T = reinterpret_cast<float*>(smem + 2 * TB_RING);
-
-  // ---- stationary weights: fragments [0,24) = conv1, [24,48) = conv2; g = kt*8 + c (k = kt*128 + 16c + 8*(lane/32) ..+8)
-  u32x4 wreg[48];
-  {
-    const long long roff = (long long)(wave * 32 + (lane & 31)) * 384 + (lane >> 5) * 8;
-#pragma unroll
-    for (int g = 0; g < 24; ++g) wreg[g] = *reinterpret_cast<const u32x4*>(p.w1 + roff + g * 16);
-#pragma unroll
-    for (int g = 0; g < 24; ++g) wreg[24 + g] = *reinterpret_cast<const u32x4*>(p.w2 + roff + g * 16);
-  }
-  // ---- per-lane row geometry: rows row0 + 16*it (it < 4), channels [8 oct_j, +8) -------------------------------------
-  const int oct_j = tid & 15, row0 = tid >> 4;
-  f32x2 lg1[4], lb1[4], lg2[4], lb2[4], lgn[4], lbn[4], bo1[4], bo2[4];   // channel pairs (8 oct_j + 2q, + 1)
-#pragma unroll
-  for (int q = 0; q < 4; ++q)
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const int c = 8 * oct_j + 2 * q + h;
-      lg1[q][h] = p.g1[c]; lb1[q][h] = p.be1[c];
-      lg2[q][h] = p.g2[c]; lb2[q][h] = p.be2[c];
-      lgn[q][h] = LNN ? p.gn[c] : 1.0f;
-      lbn[q][h] = LNN ? p.ben[c] : 0.0f;
-      bo1[q][h] = p.b1 ? p.b1[c] : 0.0f;
-      bo2[q][h] = p.b2 ? p.b2[c] : 0.0f;
-    }
-  const int frag_off = (lane & 31) * TB_ROWP + (lane >> 5) * 16;     // B-fragment of pixel lane%32, k half lane/32
-  const int row_lds = oct_j * 16;                                    // + row * TB_ROWP : this lane's 16 B of a ring row
-  auto col_base = [&](int col) -> long long {                        // element offset of (b, frame 0, first pixel of the tile)
-    const int b = col / ptiles;
-    const int pt = col - b * ptiles;
-    return ((long long)b * p.T * p.HW + (long long)pt * TB_PIX) * 128;
-  };
-  const long long frame_stride = (long long)p.HW * 128;
-
-  // ---- row jobs, cut into 48 slices (4 row iterations x 12) so that a GEMM of 48 MFMAs can carry one per shadow ----
-  // (with one wave per SIMD nothing else overlaps this block's three LayerNorm+SiLU per element with its MFMAs:
-  //  measured on the unsliced version: issuing 55 % of the wave cycles, MFMA busy 21 %)
-  f32x2 rv[4], rsum = {0.f, 0.f};
-  float rmean = 0.f, rrstd = 0.f;
-  f32x4 rt0, rt1;
-  Oct<bf16_t> xp[4], xc[4], xn[4];   // x rows of the previous step (residual of its OUT job), this step, the next (prefetch)
-  auto store_row = [&](bf16_t* dst) {                                // rv -> 8 bf16 channels of one pixel row
-    u32x4 w;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) w[q] = tb_pack2(rv[q]);
-    *reinterpret_cast<u32x4*>(dst) = w;
-  };
-  // OUT job of step `vp` (its conv2 result sits in T): + b2 + x -> y store; LayerNorm_next -> n store
-  long long out_base = 0;          // element offset of (frame of vp, row 0 of the tile) + 8 oct_j
-  auto job_out = [&](auto slot_c, Oct<bf16_t> (&xrows)[4]) {
-    constexpr int slot = decltype(slot_c)::value;
-    constexpr int it = slot / 12, s = slot % 12;
-    const int row = row0 + 16 * it;
-    Oct<bf16_t>& xr = xrows[it];
-    if constexpr (s == 0) {
-      const int sw = row & 31;
-      rt0 = *reinterpret_cast<const f32x4*>(T + row * 128 + (((2 * oct_j) ^ sw) << 2));
-      rt1 = *reinterpret_cast<const f32x4*>(T + row * 128 + (((2 * oct_j + 1) ^ sw) << 2));
-    } else if constexpr (s == 1 || s == 2) {
-      if constexpr (s == 1) rsum = f32x2{0.f, 0.f};
-#pragma unroll
-      for (int q = 2 * (s - 1); q < 2 * (s - 1) + 2; ++q) {
-        const f32x2 tq = q < 2 ? f32x2{rt0[2 * q], rt0[2 * q + 1]} : f32x2{rt1[2 * (q - 2)], rt1[2 * (q - 2) + 1]};
-        rv[q] = tb_unpack2(xr.w[q]) + (tq + bo2[q]);
-        rsum = rsum + rv[q];
-        tb_pin2(rv[q]);
-      }
-      tb_pin2(rsum);
-    } else if constexpr (s == 3) {
-      if constexpr (KEEP) store_row(p.y + out_base + (long long)row * 128);
-      if constexpr (LNN != 0) {
-        rmean = group_sum_dpp<16>(rsum[0] + rsum[1]) * (1.0f / 128.0f);
-        tb_pin(rmean);
-      }
-    } else if constexpr (s == 4 || s == 5) {
-      if constexpr (LNN != 0) {
-        if constexpr (s == 4) rsum = f32x2{0.f, 0.f};
-#pragma unroll
-        for (int q = 2 * (s - 4); q < 2 * (s - 4) + 2; ++q) {
-          rv[q] = rv[q] - rmean;
-          rsum = __builtin_elementwise_fma(rv[q], rv[q], rsum);
-          tb_pin2(rv[q]);
-        }
-        tb_pin2(rsum);
-      }
-    } else if constexpr (s == 6) {
-      if constexpr (LNN != 0) {
-        rrstd = __builtin_amdgcn_rsqf(__builtin_fmaf(group_sum_dpp<16>(rsum[0] + rsum[1]), 1.0f / 128.0f, p.eps));
-        tb_pin(rrstd);
-      }
-    } else if constexpr (s >= 7 && s <= 10) {
-      if constexpr (LNN != 0) {
-        constexpr int q = s - 7;
-        rv[q] = tb_affine_act2(rv[q], rrstd, lgn[q], lbn[q], LNN == 2);
-        tb_pin2(rv[q]);
-      }
-    } else {
-      if constexpr (LNN != 0) store_row(p.n_out + out_base + (long long)row * 128);
-    }
-  };
-  // LN1 job of step `vn` (its x rows are in xs[vn % 3]): LayerNorm1 + SiLU -> ring1[tn % 3]
-  auto job_ln1 = [&](auto slot_c, int tn) {
-    constexpr int slot = decltype(slot_c)::value;
-    constexpr int it = slot / 12, s = slot % 12;
-    const int row = row0 + 16 * it;
-    Oct<bf16_t>& xr = xn[it];
-    if constexpr (s == 1 || s == 2) {
-      if constexpr (s == 1) rsum = f32x2{0.f, 0.f};
-#pragma unroll
-      for (int q = 2 * (s - 1); q < 2 * (s - 1) + 2; ++q) {
-        rv[q] = tb_unpack2(xr.w[q]);
-        rsum = rsum + rv[q];
-        tb_pin2(rv[q]);
-      }
-      tb_pin2(rsum);
-    } else if constexpr (s == 3) {
-      rmean = group_sum_dpp<16>(rsum[0] + rsum[1]) * (1.0f / 128.0f);
-      tb_pin(rmean);
-    } else if constexpr (s == 4 || s == 5) {
-      if constexpr (s == 4) rsum = f32x2{0.f, 0.f};
-#pragma unroll
-      for (int q = 2 * (s - 4); q < 2 * (s - 4) + 2; ++q) {
-        rv[q] = rv[q] - rmean;
-        rsum = __builtin_elementwise_fma(rv[q], rv[q], rsum);
-        tb_pin2(rv[q]);
-      }
-      tb_pin2(rsum);
-    } else if constexpr (s == 6) {
-      rrstd = __builtin_amdgcn_rsqf(__builtin_fmaf(group_sum_dpp<16>(rsum[0] + rsum[1]), 1.0f / 128.0f, p.eps));
-      tb_pin(rrstd);
-    } else if constexpr (s >= 7 && s <= 10) {
-      constexpr int q = s - 7;
-      rv[q] = tb_affine_act2(rv[q], rrstd, lg1[q], lb1[q], true);
-      tb_pin2(rv[q]);
-    } else if constexpr (s == 11) {
-      u32x4 w;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) w[q] = tb_pack2(rv[q]);
-      *reinterpret_cast<u32x4*>(ring1 + (tn % 3) * TB_SLOT + row * TB_ROWP + row_lds) = w;
-    }
-  };
-
-  // GEMM over the valid taps [KT0, 3) of a ring: acc[j] (j = 0, 1: pixel sub-tiles of 32) += W[kt] . ring[frame t-2+kt].
-  // Software pipeline: the two B-fragments of group g+2 are requested before the MFMAs of group g.  `job(slot)` is
-  // called after every MFMA of a full (KT0 = 0) GEMM: slots 0 .. 47.
-  auto gemm = [&](auto kt0_c, auto wbase_c, const char* ring, int t, f32x16 (&acc)[2], auto&& job) {
-    constexpr int KT0 = decltype(kt0_c)::value, WB = decltype(wbase_c)::value;
-    constexpr int G0 = KT0 * 8;
-    const char* sp[3];
-#pragma unroll
-    for (int kt = 0; kt < 3; ++kt) {
-      const int fr = max(t - 2 + kt, 0);                             // replicate: frames before the clip = frame 0
-      sp[kt] = ring + (fr % 3) * TB_SLOT + frag_off;
-    }
-    auto faddr = [&](int g, int j) -> const u32x4* {
-      return reinterpret_cast<const u32x4*>(sp[g >> 3] + j * (32 * TB_ROWP) + (g & 7) * 32);
-    };
-    u32x4 xf[3][2];
-#pragma unroll
-    for (int j = 0; j < 2; ++j) xf[G0 % 3][j] = *faddr(G0, j);
-#pragma unroll
-    for (int j = 0; j < 2; ++j) xf[(G0 + 1) % 3][j] = *faddr(G0 + 1, j);
-    tb_static_for<G0, 24>([&](auto gc) {
-      constexpr int g = decltype(gc)::value;
-      tb_static_for<0, 2>([&](auto jc) {
-        constexpr int j = decltype(jc)::value;
-        tb_mfma<ACC_A>(wreg[WB + g], xf[g % 3][j], acc[j]);
-        if constexpr (g + 2 < 24) xf[(g + 2) % 3][j] = *faddr(g + 2, j);
-        if constexpr (KT0 == 0) job(std::integral_constant<int, 2 * g + j>{});
-        __builtin_amdgcn_sched_barrier(0);
-      });
-    });
-    asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");               // last MFMA -> first VALU reader of its accumulator
-  };
-  // a GEMM with its row job: the job rides in the MFMA shadows when all three taps are live, else it runs first
-  auto gemm_with_job = [&](auto wbase_c, const char* ring, int t, f32x16 (&acc)[2], bool have_job, auto&& job) {
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[j][r] = 0.0f;
-    auto nojob = [](auto) {};
-    const int first = p.replicate ? 0 : max(0, 2 - t);                // uniform
-    if (first == 0) {
-      if (have_job) gemm(std::integral_constant<int, 0>{}, wbase_c, ring, t, acc, job);
-      else gemm(std::integral_constant<int, 0>{}, wbase_c, ring, t, acc, nojob);
-    } else {
-      if (have_job) tb_static_for<0, 48>([&](auto sc) { job(sc); });
-      if (first == 1) gemm(std::integral_constant<int, 1>{}, wbase_c, ring, t, acc, nojob);
-      else gemm(std::integral_constant<int, 2>{}, wbase_c, ring, t, acc, nojob);
-    }
-  };
-  // accumulators (MFMA layout: lane = pixel 32j + lane%32, channels 32 wave + 8g + 4 (lane/32) + e) -> T, transposed
-  auto acc_to_T = [&](f32x16 (&acc)[2]) {
-    const int h = lane >> 5;
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int prow = 32 * j + (lane & 31);
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int c = wave * 32 + 8 * g + 4 * h;
-        f32x4 v;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = acc[j][4 * g + e];
-        *reinterpret_cast<f32x4*>(T + prow * 128 + (((c >> 2) ^ (prow & 31)) << 2)) = v;
-      }
-    }
-  };
-  auto T_row = [&](int row, f32x2 (&v)[4]) {
-    const int sw = row & 31;
-    const f32x4 t0 = *reinterpret_cast<const f32x4*>(T + row * 128 + (((2 * oct_j) ^ sw) << 2));
-    const f32x4 t1 = *reinterpret_cast<const f32x4*>(T + row * 128 + (((2 * oct_j + 1) ^ sw) << 2));
-    v[0] = f32x2{t0[0], t0[1]}; v[1] = f32x2{t0[2], t0[3]};
-    v[2] = f32x2{t1[0], t1[1]}; v[3] = f32x2{t1[2], t1[3]};
-  };
-  auto ring_store = [&](char* ring, int t, int row, const f32x2 (&o)[4]) {
-    u32x4 w;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) w[q] = tb_pack2(o[q]);
-    *reinterpret_cast<u32x4*>(ring + (t % 3) * TB_SLOT + row * TB_ROWP + row_lds) = w;
-  };
-  auto load_rows = [&](Oct<bf16_t> (&dst)[4], long long elem_off) {
-    const bf16_t* src = p.x + elem_off + 8 * oct_j;
-#pragma unroll
-    for (int it = 0; it < 4; ++it) dst[it].load(src + (long long)(row0 + 16 * it) * 128);
-  };
-
-  // ---- the walk: virtual steps v = (column, frame) in order; step v's phases:
-  //   A  GEMM1(v)  ||  OUT job of step v-1 (reads T = conv2(v-1))          barrier, acc -> T, barrier
-  //   B  rows of T + b1 -> LN2 + SiLU -> ring2[t]                          barrier
-  //   C  GEMM2(v)  ||  LN1 job of step v+1 (x rows prefetched in A)        acc -> T, barrier
-  const int nsteps = (c_end - c_begin) * p.T;
-  load_rows(xc, col_base(c_begin));
-#pragma unroll
-  for (int it = 0; it < 4; ++it) {
-    xp[it].w = xc[it].w;
-    xn[it].w = xc[it].w;
-  }
-#pragma unroll
-  for (int it = 0; it < 4; ++it) {                                    // LN1 of the very first step, on its own
-    f32x2 v[4], o[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) v[q] = tb_unpack2(xc[it].w[q]);
-    tb_row_norm2<true>(v, lg1, lb1, p.eps, o);
-    ring_store(ring1, 0, row0 + 16 * it, o);
-  }
-  __syncthreads();
-  int col = c_begin, t = 0;
-  long long cb = col_base(col);
-  f32x16 acc[2];
-  // PROF: s_memtime at the phase boundaries of steps [TB_PROF_FIRST, +TB_PROF_STEPS) of workgroup 0, kept in the LDS
-  // (behind [ring1][ring2][T]) until the end of the kernel -- no memory traffic inside the measured steps
-  unsigned long long* stamps = reinterpret_cast<unsigned long long*>(smem + TB_LDS);
-  int vcur = 0;
-  auto stamp = [&](int k) {
-    if constexpr (PROF) {
-      if (blockIdx.x == 0 && vcur >= TB_PROF_FIRST && vcur < TB_PROF_FIRST + TB_PROF_STEPS) {
-        const unsigned long long ts = __builtin_amdgcn_s_memtime();
-        if (lane == 0) stamps[((vcur - TB_PROF_FIRST) * 4 + wave) * TB_PROF_STAMPS + k] = ts;
-      }
-    }
-  };
-  for (int v = 0; v < nsteps; ++v) {
-    vcur = v;
-    stamp(0);
-    // next step's coordinates and its x rows (in flight during A and B)
-    const bool has_next = v + 1 < nsteps;                             // uniform
-    const int tn = (t + 1 < p.T) ? t + 1 : 0;
-    const int coln = (t + 1 < p.T) ? col : col + 1;
-    const long long cbn = (t + 1 < p.T) ? cb : (has_next ? col_base(coln) : cb);
-    if (has_next) load_rows(xn, cbn + (long long)tn * frame_stride);
-    // ---- A ----
-    gemm_with_job(std::integral_constant<int, 0>{}, ring1, t, acc, v > 0 && !(PROF && p.prof_mode == 1), [&](auto sc) { job_out(sc, xp); });
-    stamp(1);
-    __syncthreads();                                                  // every wave is done with T (OUT job of v-1)
-    stamp(2);
-    acc_to_T(acc);
-    __syncthreads();
-    stamp(3);
-    // ---- B: rows of conv1 + b1 -> LN2 + SiLU -> ring2[t % 3] ----
-#pragma unroll
-    for (int it = 0; it < 4; ++it) {
-      f32x2 vv[4], o[4];
-      T_row(row0 + 16 * it, vv);
-#pragma unroll
-      for (int q = 0; q < 4; ++q) vv[q] = vv[q] + bo1[q];
-      tb_row_norm2<true>(vv, lg2, lb2, p.eps, o);
-      ring_store(ring2, t, row0 + 16 * it, o);
-    }
-    // the prefetched rows are "used" here, long after the OUT job's stores of phase A were issued: hipcc waits for
-    // them now (with loads and stores both pending it drains vmcnt entirely)
-    stamp(4);
-    if (has_next) {
-#pragma unroll
-      for (int it = 0; it < 4; ++it) asm volatile("" : "+v"(xn[it].w));
-    }
-    stamp(5);
-    __syncthreads();                                                  // ring2[t] visible; T free
-    stamp(6);
-    // ---- C ----
-    gemm_with_job(std::integral_constant<int, 24>{}, ring2, t, acc, has_next && !(PROF && p.prof_mode == 1), [&](auto sc) { job_ln1(sc, tn); });
-    stamp(7);
-    acc_to_T(acc);
-    out_base = cb + (long long)t * frame_stride + 8 * oct_j;          // where step v's OUT job (next phase A) writes
-    stamp(8);
-    __syncthreads();                                                  // T = conv2(v) complete; ring1[tn] visible
-    stamp(9);
-    t = tn; col = coln; cb = cbn;
-#pragma unroll
-    for (int it = 0; it < 4; ++it) {                                  // rotate: this step's rows become the next OUT job's residual
-      xp[it].w = xc[it].w;
-      xc[it].w = xn[it].w;
-    }
-  }
-  tb_static_for<0, 48>([&](auto sc) { job_out(sc, xp); });            // OUT job of the last step
-  if constexpr (PROF) {
-    if (blockIdx.x == 0 && lane == 0) {
-      for (int i = 0; i < TB_PROF_STEPS * TB_PROF_STAMPS; ++i) p.prof[wave * TB_PROF_STEPS * TB_PROF_STAMPS + i] =
-          stamps[((i / TB_PROF_STAMPS) * 4 + wave) * TB_PROF_STAMPS + (i % TB_PROF_STAMPS)];
-    }
-  }
-#endif
-}
-
-
 // ---------------------------------------------------------------------------------------------------------------------
-// v3: the same block on EIGHT waves with two roles.  What the cycle stamps of the kernel above showed
+// The block on EIGHT waves with two roles.  What the cycle stamps of the one-role kernel showed
 // (profiles/r02_tblock_phase_cycles.txt): a 64-pixel step costs 14 960 cycles of which 3 072 are
 // MFMA; the three LayerNorm+SiLU per element are ~6 300 issue cycles of VALU work that a single wave per SIMD cannot put
 // behind its own MFMAs (an MFMA hides at most ~6 plain VALU instructions, and no packed-fp32 one).  So the SIMD gets a
@@ -866,7 +511,7 @@ extern "C" int vt_temporal_block_supported(const vt_tblock_desc* d) {
   if (d->B <= 0 || d->T <= 0 || d->HW <= 0 || d->HW % TB_PIX != 0) return 0;
   if (d->tmode != VT_TPAD_ZERO && d->tmode != VT_TPAD_REPLICATE) return 0;
   if (d->ln_next_mode < 0 || d->ln_next_mode > 2) return 0;
-  if (env_int("VT_TBLOCK_FUSED", 1) == 0) return 0;
+  if (vt_opt(OPT_TBLOCK_FUSED) == 0) return 0;
   return 1;
 }
 
@@ -896,43 +541,29 @@ int tblock_launch(const vt_tblock_desc* d, vt_stream stream_, unsigned long long
   a.ln_next = d->ln_next_mode;
   a.eps = d->eps;
   a.prof = prof;
-  a.prof_mode = prof ? env_int("VT_TBLOCK_PROF_MODE", 0) : 0;
+  a.prof_mode = prof ? vt_opt(OPT_TBLOCK_PROF_MODE) : 0;
   // one instantiation per output shape: next norm none / LayerNorm / LayerNorm+SiLU, y kept or not
-  static const void* const kerns[5] = {
-      reinterpret_cast<const void*>(&tblock_ws128_kernel<0, true>), reinterpret_cast<const void*>(&tblock_ws128_kernel<1, true>),
-      reinterpret_cast<const void*>(&tblock_ws128_kernel<1, false>), reinterpret_cast<const void*>(&tblock_ws128_kernel<2, true>),
-      reinterpret_cast<const void*>(&tblock_ws128_kernel<2, false>)};
-  const void* kern = kerns[a.ln_next == 0 ? 0 : (a.ln_next == 1 ? (a.keep_y ? 1 : 2) : (a.keep_y ? 3 : 4))];
-  int lds = TB_LDS;
-  unsigned threads = 256;
-  if (prof == nullptr && env_int("VT_TBLOCK_V3", 1) != 0) {      // two-role kernel (8 waves); VT_TBLOCK_V3=0: the 4-wave kernel
-    static const void* const kerns3[5] = {
-        reinterpret_cast<const void*>(&tblock_split_kernel<0, true>), reinterpret_cast<const void*>(&tblock_split_kernel<1, true>),
-        reinterpret_cast<const void*>(&tblock_split_kernel<1, false>), reinterpret_cast<const void*>(&tblock_split_kernel<2, true>),
-        reinterpret_cast<const void*>(&tblock_split_kernel<2, false>)};
-    kern = kerns3[a.ln_next == 0 ? 0 : (a.ln_next == 1 ? (a.keep_y ? 1 : 2) : (a.keep_y ? 3 : 4))];
-    lds = T3_LDS;
-    threads = 512;
-    VT_CHECK_HIP(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-  }
-  if (prof != nullptr && env_int("VT_TBLOCK_V3", 1) != 0) {   // stamps of the two-role kernel: [wave 0..7][step][8]
+  static const void* const kerns[6] = {
+      reinterpret_cast<const void*>(&tblock_split_kernel<0, true>), reinterpret_cast<const void*>(&tblock_split_kernel<1, true>),
+      reinterpret_cast<const void*>(&tblock_split_kernel<1, false>), reinterpret_cast<const void*>(&tblock_split_kernel<2, true>),
+      reinterpret_cast<const void*>(&tblock_split_kernel<2, false>), reinterpret_cast<const void*>(&tblock_split_kernel<2, true, true>)};
+  int ki = a.ln_next == 0 ? 0 : (a.ln_next == 1 ? (a.keep_y ? 1 : 2) : (a.keep_y ? 3 : 4));
+  int lds = T3_LDS;
+  const unsigned threads = 512;
+  if (prof != nullptr) {                      // measurement aid: stamps [wave 0..7][step][8] of the LayerNorm+SiLU, y kept instantiation
     VT_CHECK_ARG(a.ln_next == 2 && a.keep_y, "vt_temporal_block_profile: ln_next_mode 2 and keep_y only");
-    kern = reinterpret_cast<const void*>(&tblock_split_kernel<2, true, true>);
+    ki = 5;
     lds = T3_LDS + 2048;
-    threads = 512;
-    VT_CHECK_HIP(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-  } else if (prof != nullptr) {               // measurement aid: the LayerNorm+SiLU, y kept instantiation with cycle stamps
-    VT_CHECK_ARG(a.ln_next == 2 && a.keep_y, "vt_temporal_block_profile: ln_next_mode 2 and keep_y only");
-    kern = reinterpret_cast<const void*>(&tblock_ws128_kernel<2, true, true>);
-    lds = TB_LDS + TB_PROF_BYTES;
-    VT_CHECK_HIP(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
   }
+  const void* kern = kerns[ki];
+  // per device, once: the dynamic-LDS attribute of every instantiation and the CU count (not a per-launch runtime call)
   static std::atomic<int> cus[kMaxDevices];
   int dev = 0;
   VT_CHECK_HIP(hipGetDevice(&dev));
   int ncu = (dev >= 0 && dev < kMaxDevices) ? cus[dev].load(std::memory_order_acquire) : 0;
   if (ncu == 0) {
-    for (int k = 0; k < 5; ++k) VT_CHECK_HIP(hipFuncSetAttribute(kerns[k], hipFuncAttributeMaxDynamicSharedMemorySize, TB_LDS));
+    for (int k = 0; k < 6; ++k)
+      VT_CHECK_HIP(hipFuncSetAttribute(kerns[k], hipFuncAttributeMaxDynamicSharedMemorySize, k == 5 ? T3_LDS + 2048 : T3_LDS));
     VT_CHECK_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
     if (ncu <= 0) ncu = 256;
     if (dev >= 0 && dev < kMaxDevices) cus[dev].store(ncu, std::memory_order_release);

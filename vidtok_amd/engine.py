@@ -55,8 +55,9 @@ class AutoencodingEngine(nn.Module):
         if self.version == "v1_0" and self.use_tiling:
             raise NotImplementedError("temporal tiling exists only in the v1.1 models of the reference")
         self.use_graphs = False
-        self._genc = GraphedCall(lambda t: self.encoder(t), lambda: self._chunk_state(self.encoder), self._set_chunk_state)
-        self._gdec = GraphedCall(lambda t: self.decoder(t), lambda: self._chunk_state(self.decoder), self._set_chunk_state)
+        # bound methods, not closures: copy.deepcopy / pickle of the engine then rebind them to the copy
+        self._genc = GraphedCall(self._encoder_fn, self._encoder_state, self._set_chunk_state)
+        self._gdec = GraphedCall(self._decoder_fn, self._decoder_state, self._set_chunk_state)
         if verbose:
             _print0(f"[vidtok_amd.engine][AutoencodingEngine] Use ckpt_path: {ckpt_path}")
         if ckpt_path is not None:
@@ -79,9 +80,31 @@ class AutoencodingEngine(nn.Module):
         return self
 
     def invalidate_graphs(self):
-        """forget captured graphs (call after editing parameters in place)"""
+        """forget captured graphs (call after editing parameters in place) and the v1.1 chunk-cache buffers they replay
+        against (vidtok_amd/modules.py::_CausalState._persistent)"""
         self._genc.clear()
         self._gdec.clear()
+        self._drop_cache_buffers(self)
+
+    @staticmethod
+    def _drop_cache_buffers(root):
+        for m in root.modules():
+            if "_cache_bufs" in m.__dict__:
+                m.__dict__["_cache_bufs"].clear()
+                if hasattr(m, "causal_cache"):
+                    m.causal_cache = None
+
+    def _encoder_fn(self, t):
+        return self.encoder(t)
+
+    def _decoder_fn(self, t):
+        return self.decoder(t)
+
+    def _encoder_state(self):
+        return self._chunk_state(self.encoder)
+
+    def _decoder_state(self):
+        return self._chunk_state(self.decoder)
 
     def _apply(self, fn, *a, **kw):           # .to() / .cuda() / .float(): parameters move, captured graphs are stale
         self.invalidate_graphs()
@@ -176,6 +199,14 @@ class AutoencodingEngineV11(AutoencodingEngine):
         for _, module in parent.named_modules():
             if hasattr(module, "causal_cache"):
                 module.causal_cache = None
+        if not self.use_graphs:
+            # eager passes own no captured addresses: the chunk-cache buffers go back to the allocator between clips, as
+            # the reference's caches do
+            self._drop_cache_buffers(parent)
+        elif self._genc.overfull or self._gdec.overfull:
+            # captured chunks replay against those buffers, so they live as long as the graphs: a process that keeps
+            # meeting new chunk kinds (clip lengths, resolutions) starts over here, between two passes
+            self.invalidate_graphs()
 
     def _set_first_chunk(self, is_first_chunk=True):
         for module in self.modules():

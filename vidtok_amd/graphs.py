@@ -9,7 +9,8 @@ graph's static output), so the reference's "caller owns the outputs" contract ho
 
 Opt-in (`AutoencodingEngine.enable_graphs()`): a replay does not see in-place edits of parameters made after the
 capture -- `load_state_dict`, `.to()`, `set_compute_dtype` and `enable_graphs` reset the cache, anything else needs
-`invalidate_graphs()`.
+`invalidate_graphs()`.  A call site keeps at most `GraphedCall.MAX_ENTRIES` shapes (least recently used out first) and its
+graphs share one memory pool, so a process that sees many clip lengths / resolutions does not accumulate working sets.
 
 Stateful chunked passes (v1.1 temporal tiling) replay too: the modules keep their chunk-to-chunk caches in persistent
 buffers that are updated in place (vidtok_amd/modules.py::_CausalState), so a captured chunk reads and writes the same
@@ -23,15 +24,54 @@ import torch
 
 
 class GraphedCall:
+    MAX_ENTRIES = 12     # shapes / chunk kinds kept per call site; the least recently used one is dropped beyond that
+
     def __init__(self, fn, state_get=None, state_set=None):
         self.fn = fn
         self.entries = {}
         # stateful calls: host-side state the function leaves behind (module attributes bound to cache buffers), read
         # after the capture and re-applied after every replay -- a replay runs no Python
         self.state_get, self.state_set = state_get, state_set
+        # one memory pool for all graphs of this call site: they never run concurrently, and what a caller may still
+        # hold of a graph (its static input / output) stays allocated as long as the entry lives
+        self._pool = None
 
     def clear(self):
         self.entries.clear()
+        self._pool = None
+
+    # a copy / pickle of the owner starts with an empty cache (graphs hold device state and are not copyable)
+    def __deepcopy__(self, memo):
+        import copy
+
+        return GraphedCall(copy.deepcopy(self.fn, memo), copy.deepcopy(self.state_get, memo), copy.deepcopy(self.state_set, memo))
+
+    def __getstate__(self):
+        return {"fn": self.fn, "state_get": self.state_get, "state_set": self.state_set}
+
+    def __setstate__(self, st):
+        self.__init__(st["fn"], st["state_get"], st["state_set"])
+
+    @staticmethod
+    def _is_stateful(e):
+        return isinstance(e, tuple) and e[3] is not None
+
+    @property
+    def overfull(self):
+        """more entries than MAX_ENTRIES: only stateful ones can pile up (see _touch); the owner resets between passes"""
+        return len(self.entries) > self.MAX_ENTRIES
+
+    def _touch(self, key):
+        """LRU bookkeeping: `key` becomes the most recent entry; beyond MAX_ENTRIES the oldest stateless entries go.
+        Stateful entries replay against addresses they captured (the modules' persistent chunk-cache buffers) in the
+        middle of a chunked pass, so they are never dropped from here: the owner checks `overfull` between passes and
+        resets everything together with those buffers (AutoencodingEngineV11._empty_causal_cached)."""
+        self.entries[key] = self.entries.pop(key)
+        for old in list(self.entries):
+            if len(self.entries) <= self.MAX_ENTRIES:
+                break
+            if old != key and not self._is_stateful(self.entries[old]):
+                del self.entries[old]
 
     def __call__(self, x, key_extra=(), stateful=False, frames=None, borrow=False):
         if not x.is_cuda:
@@ -55,6 +95,7 @@ class GraphedCall:
         if e is None:                       # first sight of this shape: eager (packs weights, sizes the allocator)
             y = self.fn(x if frames is None else fill(torch.empty(shape, dtype=x.dtype, device=x.device)))
             self.entries[key] = "warm"
+            self._touch(key)
             return y
         if e == "warm":
             sx = fill(torch.empty(shape, dtype=x.dtype, device=x.device))
@@ -65,10 +106,13 @@ class GraphedCall:
                 with torch.cuda.stream(side):
                     self.fn(sx)
                 cur.wait_stream(side)
+            if self._pool is None:
+                self._pool = torch.cuda.graph_pool_handle()
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            with torch.cuda.graph(g, pool=self._pool):
                 sy = self.fn(sx)
             self.entries[key] = e = (g, sx, sy, self.state_get() if stateful and self.state_get else None)
+        self._touch(key)
         g, sx, sy, state = e
         fill(sx)
         g.replay()

@@ -72,6 +72,11 @@ SIGNATURES = {
     "vt_last_error": (C.c_char_p, []),
     "vt_version": (C.c_int, []),
     "vt_conv_max_lds_bytes": (C.c_int, []),
+    "vt_set_option": (C.c_int, [C.c_char_p, _I32]),
+    "vt_get_option": (C.c_int, [C.c_char_p, C.POINTER(_I32)]),
+    "vt_reset_options": (C.c_int, []),
+    "vt_option_count": (C.c_int, []),
+    "vt_option_name": (C.c_char_p, [_I32]),
     "vt_conv": (C.c_int, [C.POINTER(ConvDesc), _P]),
     "vt_conv_desc_size": (C.c_int, []),
     "vt_conv_plan": (C.c_int, [C.POINTER(ConvDesc), C.POINTER(_I32)]),
@@ -135,3 +140,37 @@ def check(rc: int, what: str = ""):
     if rc != 0:
         msg = load().vt_last_error()
         raise VtError(f"{what} failed (status {rc}): {msg.decode() if msg else '?'}")
+
+
+def set_option(name: str, value: int):
+    """vt_set_option: process-wide switch between implementations of one operator contract (include/vidtok_amd.h)"""
+    check(load().vt_set_option(name.encode(), int(value)), f"vt_set_option({name})")
+
+
+def get_option(name: str) -> int:
+    v = _I32()
+    check(load().vt_get_option(name.encode(), C.byref(v)), f"vt_get_option({name})")
+    return int(v.value)
+
+
+def option_names():
+    lib = load()
+    return [lib.vt_option_name(i).decode() for i in range(lib.vt_option_count())]
+
+
+class options:
+    """with lib.options(conv_ws=0, conv_tile=256): ... -- set switches, restore the previous values on exit"""
+
+    def __init__(self, **kv):
+        self.kv, self.old = kv, {}
+
+    def __enter__(self):
+        for k, v in self.kv.items():
+            self.old[k] = get_option(k)
+            set_option(k, v)
+        return self
+
+    def __exit__(self, *exc):
+        for k, v in self.old.items():
+            set_option(k, v)
+        return False

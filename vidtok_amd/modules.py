@@ -14,6 +14,7 @@ decoder drops 3 frames; "v1_1" = first-frame-replicate / cached causal padding, 
 up-sampling, chunk-to-chunk caches (`causal_cache`, `is_first_chunk`, `cache_offset` attributes
 exactly as model_3dcausal_v1_1.py:155-157,212-214 so an engine can drive them).
 """
+import functools
 import os
 
 import torch
@@ -273,7 +274,7 @@ class Upsample(nn.Module):
         # up(x)[Y][X] = x[Y>>1][X>>1]: an output pixel of parity (py, px) sees a 2x2 window of x, so the 3x3 conv over
         # the up-sampled frame is four 2x2 convs over x with pre-summed taps (4/9 of the MACs), each writing its
         # parity class of the output: rows (a-1, a) for py = 0, (a, a+1) for py = 1, likewise for columns
-        self._parity = [(py, px, PackedCache(lambda w, py=py, px=px: space_upsample_parity_weights(w, py, px)),
+        self._parity = [(py, px, PackedCache(functools.partial(space_upsample_parity_weights, py=py, px=px)),
                          ConvGeom(kh=2, kw=2, ph=1 - py, pw=1 - px, ph_hi=py, pw_hi=px))
                         for py in (0, 1) for px in (0, 1)]
 
@@ -368,8 +369,8 @@ class TimeUpsampleResCausal2x(nn.Module):
         self.version = version
         self.is_first_chunk = True
         self.causal_cache = None
-        self._parity_packs = (PackedCache(lambda w: time_upsample_parity_weights(w, early=True)),
-                              PackedCache(lambda w: time_upsample_parity_weights(w, early=False)))
+        self._parity_packs = (PackedCache(functools.partial(time_upsample_parity_weights, early=True)),
+                              PackedCache(functools.partial(time_upsample_parity_weights, early=False)))
 
     def _interp_v11(self, x):
         n, T = self.num_temp_upsample, x.shape[1]
@@ -504,25 +505,27 @@ class ResnetCausalBlock1D(nn.Module):
         """may run as ONE launch (ops.temporal_block): LayerNorm variant, C -> C, bf16, no live v1.1 chunk state"""
         if not _FUSE_TBLOCK or dt != torch.bfloat16 or self.in_channels != self.out_channels:
             return False
-        if not (self.norm1.fusable and self.norm2.fusable):
+        if not (self.norm1.fusable and self.norm2.fusable) or self.norm1.norm.eps != self.norm2.norm.eps:
+            return False
+        if self.in_channels != 128:          # the kernel's LayerNorm statistics span exactly 128 REAL channels
             return False
         return self.conv1.version == "v1_0" or (self.allow_fused and self.conv1.is_first_chunk)
 
     def first_norm(self, dt=None):
         # a fused block normalises x itself: its producer must not spend a write on LayerNorm1(x)
-        if dt is not None and self._fusable(dt) and self.in_channels == 128:
+        if dt is not None and self._fusable(dt):
             return None
         return (self.norm1, True)
 
     def run(self, x, dt, next_norm=None):
         xp = plain(x)
         tmode = L.VT_TPAD_ZERO if self.conv1.version == "v1_0" else L.VT_TPAD_REPLICATE
-        if self._fusable(dt) and ops.temporal_block_supported(xp, tmode):
+        if self._fusable(dt) and ops.temporal_block_supported(xp, tmode, self.in_channels):
             c = xp.shape[-1]
             w1, b1 = self.conv1._pack.get(self.conv1.conv.weight, self.conv1.conv.bias, dt, cin_stored=c)
             w2, b2 = self.conv2._pack.get(self.conv2.conv.weight, self.conv2.conv.bias, dt, cin_stored=c)
             nxt = None
-            if next_norm is not None and _EMIT_NEXT_NORM and next_norm[0].fusable:
+            if next_norm is not None and _EMIT_NEXT_NORM and next_norm[0].fusable and next_norm[0].norm.eps == self.norm1.norm.eps:
                 g, b = next_norm[0].affine()
                 nxt = (g, b, next_norm[1])
             out = ops.temporal_block(xp, w1, b1, w2, b2, self.norm1.affine(), self.norm2.affine(), tmode=tmode,

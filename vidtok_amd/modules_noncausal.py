@@ -10,6 +10,8 @@ What differs from the causal family (vidtok_amd/modules.py):
   * the encoder pads nothing in front: T must be a multiple of the temporal compression factor.
 The spatial blocks (ResnetBlock, Upsample, Downsample) are the same classes as in the causal family.
 """
+import functools
+
 import torch
 import torch.nn as nn
 
@@ -68,9 +70,9 @@ class TimeUpsampleRes2x(nn.Module):
         self.conv = nn.Conv3d(in_channels, out_channels, 3, padding=1)
         self.mix_factor = nn.Parameter(torch.Tensor([mix_factor]))
         # centred window over up(x)[t] = x[t >> 1]:  o[2j] = W0 x[j-1] + (W1+W2) x[j],  o[2j+1] = (W0+W1) x[j] + W2 x[j+1]
-        self._parity = ((PackedCache(lambda w: time_upsample_parity_weights(w, early=False)),
+        self._parity = ((PackedCache(functools.partial(time_upsample_parity_weights, early=False)),
                          ConvGeom(kt=2, kh=3, kw=3, pt=1, pt_hi=0, ph=1, pw=1, ph_hi=1, pw_hi=1)),
-                        (PackedCache(lambda w: time_upsample_parity_weights(w, early=True)),
+                        (PackedCache(functools.partial(time_upsample_parity_weights, early=True)),
                          ConvGeom(kt=2, kh=3, kw=3, pt=0, pt_hi=1, ph=1, pw=1, ph_hi=1, pw_hi=1)))
 
     def run(self, x, dt, next_norm=None):

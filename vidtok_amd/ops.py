@@ -184,28 +184,29 @@ def conv(x, w, bias, geom: ConvGeom, *, cout: int, out_dtype=None, tmode=L.VT_TP
     return (y, n) if ln_keep_y else n
 
 
-def _tblock_desc(x, tmode):
+def _tblock_desc(x, tmode, c=None):
     d = L.TBlockDesc()
     B, T, H, W, ld = x.shape
-    d.dtype, d.C, d.ld, d.B, d.T, d.HW, d.tmode = _DT.get(x.dtype, -1), ld, ld, B, T, H * W, tmode
+    d.dtype, d.C, d.ld, d.B, d.T, d.HW, d.tmode = _DT.get(x.dtype, -1), (ld if c is None else c), ld, B, T, H * W, tmode
     return d
 
 
-def temporal_block_supported(x, tmode) -> bool:
-    """True if vt_temporal_block covers a block on this activation (bf16, C = ld = 128, HW % 64 == 0, zero / replicate
-    time padding): the fused launch for ResnetCausalBlock1D (reference model_3dcausal.py:473-499)."""
+def temporal_block_supported(x, tmode, c=None) -> bool:
+    """True if vt_temporal_block covers a block of `c` real channels (default: the stored count) on this activation
+    (bf16, C = ld = 128 -- a block whose channels are PADDED to 128 is not covered: the statistics span C --, HW % 64 == 0,
+    zero / replicate time padding): the fused launch for ResnetCausalBlock1D (reference model_3dcausal.py:473-499)."""
     if not x.is_cuda or x.dtype not in _DT:
         return False
-    return bool(L.load().vt_temporal_block_supported(C.byref(_tblock_desc(x, tmode))))
+    return bool(L.load().vt_temporal_block_supported(C.byref(_tblock_desc(x, tmode, c))))
 
 
-def temporal_block(x, w1, b1, w2, b2, norm1, norm2, *, tmode=L.VT_TPAD_ZERO, eps=1e-6, next_ln=None, keep_y=True, profile_out=None):
+def temporal_block(x, w1, b1, w2, b2, norm1, norm2, *, tmode=L.VT_TPAD_ZERO, eps=1e-6, next_ln=None, keep_y=True, profile_out=None, c=None):
     """y = x + conv2(SiLU(LN2(conv1(SiLU(LN1(x)))))) with causal k=3 temporal convs, one launch (vt_temporal_block).
     norm1 / norm2 = (gamma, beta) fp32; w packed [C, 3C].  next_ln = (gamma, beta, silu) additionally returns
     n = [SiLU](LayerNorm(y)): (y, n), or just n with keep_y=False."""
     lib = L.load()
     _chk(x, "tblock.x"); _chk(w1, "tblock.w1"); _chk(w2, "tblock.w2")
-    d = _tblock_desc(x, tmode)
+    d = _tblock_desc(x, tmode, c)
     y = torch.empty_like(x) if keep_y else None
     n = torch.empty_like(x) if next_ln is not None else None
     d.x, d.y, d.n_out = x.data_ptr(), (y.data_ptr() if keep_y else None), (n.data_ptr() if n is not None else None)
