@@ -26,9 +26,13 @@ Launch: `python bench.py --gpus N` spawns its N ranks itself (re-executes under 
               --kernel-trace average of the same command is committed under profiles/.  peak = dense MFMA
               peak of the dtype; traffic = HBM-side bytes per launch, measured by two rocprofv3 PMC passes
               (FETCH_SIZE x2 + WRITE_SIZE) over a child run of this command (counters cannot be read inside
-              an un-profiled process); falls back to the committed pass under profiles/
+              an un-profiled process); falls back to the committed pass under profiles/ (committed_traffic).
+              roofline.hbm: the HBM-shaped kernel classes (LayerNorm passes, conv_in, 1x1 convolutions, conv_out, the
+              temporal k3 convolutions and the fused temporal block: FLOP per byte below the 312 FLOP/B ridge), each
+              replayed alone the same way: algorithmic bytes (every operand / result once) / time, against 8 TB/s
   cpu_baseline  the CPU oracle (port of the reference, oracle/vidtok_oracle.py) timed on this host's
-              cores on a bounded sample of the same workload; a baseline, not a target
+              cores on a bounded sample of the same workload; a baseline, not a target.  At N > 1 rank 0 runs it (and
+              the traffic passes) after the process group is gone, so the line of a scaling run carries both too
 """
 import argparse
 import json
@@ -44,6 +48,7 @@ sys.path.insert(0, ROOT)
 
 FLOP_PER_PADDED_FRAME_256 = 1.0345e12     # SURVEY.md section 8(d), conv + attention MACs x 2
 PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}   # MI355X_MICROARCH.md: dense MFMA peaks
+PEAK_HBM_GBS = 8000.0                           # MI355X_MICROARCH.md: HBM3E 8 TB/s (6.3 TB/s achievable by a copy)
 T_REAL, T_PADDED, RES = 17, 20, 256
 CONFIG_1GPU = "vidtok_kl_causal_488_4chn"       # BASELINE.json configs[1]
 CONFIG_NGPU = "vidtok_kl_causal_488_16chn"      # BASELINE.json configs[3]
@@ -107,7 +112,7 @@ def cpu_baseline():
 MFMA_KERNELS = ("conv_igemm", "conv3x3_ws128", "conv3d_narrow", "tblock_ws128", "tblock_split")
 
 
-def measure_traffic(dtype, batch, timeout_s=200):
+def measure_traffic(dtype, batch, config, timeout_s=200):
     """HBM-side bytes per MFMA-kernel launch, measured NOW: two rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE cannot
     share one; counters only with --kernel-trace) over a child run of this file that does three eager steps and
     nothing else.  FETCH_SIZE is doubled (gfx950 reports half the bytes of wide streaming reads, MI355X_MICROARCH.md
@@ -125,9 +130,10 @@ def measure_traffic(dtype, batch, timeout_s=200):
     try:
         for counter in ("FETCH_SIZE", "WRITE_SIZE"):
             cmd = ["rocprofv3", "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", os.path.join(out, counter), "-o", "p",
-                   "--", sys.executable, os.path.abspath(__file__), "--pmc-child", "--dtype", dtype, "--batch", str(batch)]
+                   "--", sys.executable, os.path.abspath(__file__), "--pmc-child", "--dtype", dtype, "--batch", str(batch), "--config", config]
             env = dict(os.environ, TMPDIR="/tmp")
-            for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+            for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "GROUP_RANK", "LOCAL_WORLD_SIZE",
+                      "TORCHELASTIC_RUN_ID", "ROLE_RANK", "ROLE_WORLD_SIZE"):
                 env.pop(k, None)
             r = subprocess.run(cmd, cwd="/tmp", env=env, timeout=timeout_s, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
             v = []
@@ -143,6 +149,27 @@ def measure_traffic(dtype, batch, timeout_s=200):
         return None, f"{type(e).__name__}: {e}"
     finally:
         shutil.rmtree(out, ignore_errors=True)
+
+
+def committed_traffic(dtype, batch):
+    """HBM-side bytes per MFMA-kernel launch from the committed PMC passes under profiles/ (newest round first) -- the
+    fallback when the live rocprofv3 passes are not possible (no rocprofv3, time-out, empty CSV).  The files of
+    different rounds name the figure differently; both spellings are read.  Returns (bytes | None, source)."""
+    if batch != 4:
+        return None, "committed passes are for B=4"
+    sfx = "" if dtype == "bf16" else "_" + dtype
+    for rnd in ("r03", "r02", "r01"):
+        tpath = os.path.join(ROOT, "profiles", f"{rnd}_conv_traffic_pmc{sfx}.json")
+        if not os.path.exists(tpath):
+            continue
+        try:
+            rec = json.load(open(tpath))
+        except (OSError, ValueError):
+            continue
+        for key in ("bytes_per_launch", "traffic_bytes_per_launch"):
+            if key in rec:
+                return round(float(rec[key])), f"profiles/{os.path.basename(tpath)} (committed pass)"
+    return None, "no committed pass under profiles/"
 
 
 def spawn_ranks(n):
@@ -173,7 +200,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--breakdown", action="store_true", help="print the per-layer-shape conv timeline to stderr")
     ap.add_argument("--traffic", choices=["pmc", "profile", "none"], default="pmc",
-                    help="roofline.traffic: measure now with two rocprofv3 PMC passes (default, N=1 only), quote profiles/, or null")
+                    help="roofline.traffic: measure now with two rocprofv3 PMC passes over a child run on rank 0's GPU (default), quote profiles/, or null")
     ap.add_argument("--pmc-child", action="store_true", help="internal: three eager steps for the PMC passes, no output")
     ap.add_argument("--selftest-spawn", action="store_true",
                     help="CPU/gloo check of the N-rank launch path only (no GPU work): prints the world size reached")
@@ -270,17 +297,18 @@ def main():
     roof = None
     if rank == 0:
         model.enable_graphs(False)
-        ops.CONV_RECORD = []
+        ops.CONV_RECORD, ops.LN_RECORD = [], []
         step()                                          # eager: records descriptors + keeps their tensors alive
         torch.cuda.synchronize()
         rec, ops.CONV_RECORD = ops.CONV_RECORD, None
+        lnrec, ops.LN_RECORD = ops.LN_RECORD, None
         tl = [lab for _, _, lab in rec]
 
-        def time_replay(records, reps=3):
-            """ms per replay of `records` (conv kernel only) from a hipGraph, HIP events on the launch stream"""
+        def time_replay(records, reps=3, fn=ops.replay_convs):
+            """ms per replay of `records` (that kernel only) from a hipGraph, HIP events on the launch stream"""
             g2 = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g2):
-                ops.replay_convs(records)
+                fn(records)
             g2.replay()
             torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -302,6 +330,28 @@ def main():
             for (M, N, K), n, ms in sorted(rows, key=lambda r: -r[2]):
                 print(f"[bench]   M={M:8d} N={N:4d} K={K:6d}  x{n:3d}  {ms:8.3f} ms  {2.0 * M * N * K * n / ms / 1e9:8.1f} TFLOP/s"
                       f"  {100 * ms / tot:5.1f}%", file=sys.stderr)
+        # HBM-shaped kernel classes (SURVEY.md section 8d asks for both roofs): LayerNorm passes and the MFMA-kernel
+        # launches whose FLOP per byte is below the ridge, each class replayed alone; algorithmic bytes = every operand
+        # and result moved once (vidtok_amd/ops.py::launch_class)
+        hbm = []
+        classes = {}
+        for r in rec:
+            c = ops.launch_class(r[0])
+            if c is not None:
+                e = classes.setdefault(c[0], [[], 0])
+                e[0].append(r)
+                e[1] += c[1]
+        for name, (rs, nbytes) in classes.items():
+            ms = time_replay(rs)
+            hbm.append({"class": name, "launches": len(rs), "ms_per_step": round(ms, 3), "GB_per_step": round(nbytes / 1e9, 3),
+                        "achieved": round(nbytes / ms / 1e6, 1), "frac": round(nbytes / ms / 1e6 / PEAK_HBM_GBS, 4)})
+        if lnrec:
+            nbytes = sum(M_ * x_.shape[-1] * (x_.element_size() + y_.element_size()) for x_, y_, _, _, M_, _, _, _ in lnrec)
+            ms = time_replay(lnrec, fn=ops.replay_layernorms)
+            hbm.append({"class": "layernorm_act_kernel (LayerNorm + SiLU passes not fused into a producer)", "launches": len(lnrec),
+                        "ms_per_step": round(ms, 3), "GB_per_step": round(nbytes / 1e9, 3), "achieved": round(nbytes / ms / 1e6, 1),
+                        "frac": round(nbytes / ms / 1e6 / PEAK_HBM_GBS, 4)})
+        hbm.sort(key=lambda h: -h["ms_per_step"])
         flops = FLOP_PER_PADDED_FRAME_256 * B * T_PADDED
         achieved = flops / (conv_ms * 1e-3) / 1e12
         # MACs the launches really execute: the up-sampler convs run as parity classes with pre-summed taps (2/3 resp.
@@ -309,49 +359,56 @@ def main():
         # unit over kernel time -- is an effective rate; the executed rate is reported next to it
         executed = sum(2.0 * M * N * K for (M, N, K) in tl)
         peak = PEAK_TFLOPS[args.dtype]
-        # HBM-side bytes per launch: PMC counters cannot be read inside an un-profiled process, so (N = 1) two
-        # rocprofv3 passes over a child run of this command measure them now; the committed pass of profiles/ is the
-        # fallback (and what --traffic profile quotes)
-        traffic, traffic_src = None, "not measured"
-        if args.traffic == "pmc" and world == 1:
-            t, traffic_src = measure_traffic(args.dtype, B)
-            traffic = None if t is None else round(t)
-        if traffic is None and args.traffic != "none":
-            for rnd in ("r02", "r01"):
-                tpath = os.path.join(ROOT, "profiles", f"{rnd}_conv_traffic_pmc{'' if args.dtype == 'bf16' else '_' + args.dtype}.json")
-                if os.path.exists(tpath) and B == 4 and world == 1:
-                    traffic = round(json.load(open(tpath))["traffic_bytes_per_launch"])
-                    traffic_src = f"profiles/{os.path.basename(tpath)} (committed pass; live measurement: {traffic_src})"
-                    break
         roof = {"bound": "mfma", "kernel": "conv_igemm_glds_kernel + conv3x3_ws128_kernel + conv3d_narrow_kernel + tblock_split_kernel", "achieved": round(achieved, 2), "peak": peak,
-                "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_source": traffic_src,
+                "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": None, "traffic_source": "not measured",
                 "launches_per_step": len(tl), "kernel_ms_per_step": round(conv_ms, 3),
                 "avg_launch_ms": round(conv_ms / max(1, len(tl)), 4), "algorithmic_tflop_per_step": round(flops / 1e12, 3),
                 "executed_tflop_per_step": round(executed / 1e12, 3),
                 "achieved_executed": round(executed / (conv_ms * 1e-3) / 1e12, 2),
-                "frac_executed": round(executed / (conv_ms * 1e-3) / 1e12 / peak, 4)}
+                "frac_executed": round(executed / (conv_ms * 1e-3) / 1e12 / peak, 4),
+                "hbm": {"peak": PEAK_HBM_GBS, "unit": "GB/s", "classes": hbm}}
+        del rec, lnrec
 
-    cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline()
-
-    if rank == 0:
-        ms = elapsed / args.steps * 1e3
-        value = total_frames / elapsed
-        line = {
-            "metric": f"encode+decode frames/sec, {config} 17x256x256", "value": round(value, 2),
-            "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": args.dtype, "data": "synthetic uniform[-1,1] clips, random-init weights (temporal convs un-zeroed)",
-            "config": {"workload": f"{config} forward (encode+KL+decode), {args.dtype}, B={B} clips/GPU, 17x256x256",
-                       "global_batch": world * B, "parallelism": f"dp{world} (batch-sharded, no data-path collective)",
-                       "launch": "hipGraph replay (engine graph cache)" if graph is not None else "eager"},
-            "output_finite": ok, "roofline": roof, "cpu_baseline": cpu,
-        }
-        print(json.dumps(line), flush=True)
+    # the remaining legs belong to rank 0 alone (a profiled child run of this command on its GPU, the CPU baseline on the
+    # host cores): the other ranks are done -- the job's time was taken above, between the barriers
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    if rank != 0:
+        return
+
+    # HBM-side bytes per launch: PMC counters cannot be read inside an un-profiled process, so two rocprofv3 passes over
+    # a child run of this command measure them now; the committed pass of profiles/ is the fallback (and what
+    # --traffic profile quotes)
+    if args.traffic == "pmc":
+        del model, out, z, dec
+        torch.cuda.empty_cache()
+        tb, src = measure_traffic(args.dtype, B, config)
+        if tb is not None:
+            roof["traffic"], roof["traffic_source"] = round(tb), src
+        else:
+            roof["traffic_source"] = f"live measurement failed: {src}"
+    if roof["traffic"] is None and args.traffic != "none":
+        tb, src = committed_traffic(args.dtype, B)
+        if tb is not None:
+            roof["traffic"] = tb
+            roof["traffic_source"] = src + ("" if args.traffic == "profile" else f"; {roof['traffic_source']}")
+
+    cpu = None if args.no_cpu_baseline else cpu_baseline()
+
+    ms = elapsed / args.steps * 1e3
+    value = total_frames / elapsed
+    line = {
+        "metric": f"encode+decode frames/sec, {config} 17x256x256", "value": round(value, 2),
+        "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": args.dtype, "data": "synthetic uniform[-1,1] clips, random-init weights (temporal convs un-zeroed)",
+        "config": {"workload": f"{config} forward (encode+KL+decode), {args.dtype}, B={B} clips/GPU, 17x256x256",
+                   "global_batch": world * B, "parallelism": f"dp{world} (batch-sharded, no data-path collective)",
+                   "launch": "hipGraph replay (engine graph cache)" if graph is not None else "eager"},
+        "output_finite": ok, "roofline": roof, "cpu_baseline": cpu,
+    }
+    print(json.dumps(line), flush=True)
 
 
 if __name__ == "__main__":

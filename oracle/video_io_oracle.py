@@ -15,6 +15,13 @@ torchvision 0.17 (pinned by R/environment.yaml next to torch 2.2.2) implements, 
 `_compute_indices_weights_aa` + separable horizontal-then-vertical passes, fp32) and is PINNED in tests against
 torch.nn.functional.interpolate of this image -- the operator the reference reaches through torchvision.
 
+PARITY PINNED: `frame_id_batches`, `preprocess_frames` (with the ATen resize), `tensor_to_uint8` and `reconstruct` are
+checked against the reference's own script run UNMODIFIED in the build container (oracle/refscript.py executes
+R/scripts/inference_reconstruct.py::main() with stand-ins for the absent codec / torchvision packages): bit-exact uint8
+output for causal + --pad_gen_frames, FSQ without concatenation on a portrait source, v1.1 --read_long_video tiling and a
+non-causal model (tests/test_video_io.py::test_oracle_loop_equals_reference_script), and the script's outputs are
+committed as tests/golden/video_io.safetensors (scripts/make_golden_video_io.py) for replay where R is absent.
+
 Call sites restated: R/scripts/inference_reconstruct.py:28-82 (SingleVideoDataset), :76-82 (tensor_to_uint8),
 :206-239 (main loop with --pad_gen_frames chaining and --concate_input), R/vidtok/data/vidtok.py:180-188, 204-265."""
 import math

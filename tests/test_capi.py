@@ -214,3 +214,35 @@ def test_options_table(built_lib, monkeypatch):
     monkeypatch.delenv("VT_CONV_SCHED")
     built_lib.vt_reset_options()
     assert L.get_option("conv_sched") == 1
+
+
+def test_bench_committed_traffic_fallback(tmp_path, monkeypatch):
+    """bench.py's roofline.traffic fallback reads every committed PMC pass under profiles/ (the r02
+    file spells the key `bytes_per_launch`, r01 `traffic_bytes_per_launch`; a KeyError there cost the whole JSON line)."""
+    import json
+    import sys
+
+    sys.path.insert(0, ROOT)
+    import bench
+
+    v, src = bench.committed_traffic("bf16", 4)
+    newest = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if re.fullmatch(r"r\d+_conv_traffic_pmc\.json", f))[-1]
+    rec = json.load(open(os.path.join(ROOT, "profiles", newest)))
+    assert v == round(rec.get("bytes_per_launch", rec.get("traffic_bytes_per_launch"))) and newest in src and v > 1e8
+    v32, src32 = bench.committed_traffic("fp32", 4)
+    assert v32 is not None and v32 > v and "fp32" in src32
+    assert bench.committed_traffic("bf16", 8)[0] is None                     # the committed passes are B=4 runs
+    # every committed file parses under one of the two spellings
+    for f in os.listdir(os.path.join(ROOT, "profiles")):
+        if re.fullmatch(r"r\d+_conv_traffic_pmc(_fp32)?\.json", f):
+            r = json.load(open(os.path.join(ROOT, "profiles", f)))
+            assert "bytes_per_launch" in r or "traffic_bytes_per_launch" in r, f
+    # synthetic profiles/: a broken newest file and an unknown spelling are skipped, the older spelling is found
+    prof = tmp_path / "profiles"
+    prof.mkdir()
+    (prof / "r03_conv_traffic_pmc.json").write_text("{not json")
+    (prof / "r02_conv_traffic_pmc.json").write_text(json.dumps({"something_else": 1}))
+    (prof / "r01_conv_traffic_pmc.json").write_text(json.dumps({"traffic_bytes_per_launch": 123.4}))
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    assert bench.committed_traffic("bf16", 4) == (123, "profiles/r01_conv_traffic_pmc.json (committed pass)")
+    assert bench.committed_traffic("fp32", 4)[0] is None

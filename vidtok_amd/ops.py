@@ -260,6 +260,11 @@ def gemm_nt(a, b, *, out_dtype=None, bias=None, ld_out=None):
     return y
 
 
+# Optional record of the vt_layernorm_act launches of a step (bench.py's per-class HBM roofline): tuples
+# (x, y, gamma, beta, M, c, eps, silu) with the tensors kept alive; None in normal use.
+LN_RECORD = None
+
+
 def layernorm_act(x, gamma, beta, *, silu: bool, eps: float = 1e-6, out_dtype=None, c: int = None):
     """Per-position LayerNorm over the last dim (+SiLU)."""
     lib = L.load()
@@ -273,7 +278,51 @@ def layernorm_act(x, gamma, beta, *, silu: bool, eps: float = 1e-6, out_dtype=No
     assert gamma.dtype == torch.float32 and beta.dtype == torch.float32 and gamma.numel() == c
     L.check(lib.vt_layernorm_act(_ptr(x), _DT[x.dtype], ld, _ptr(y), _DT[out_dtype], ld, _ptr(gamma), _ptr(beta),
                                  M, c, float(eps), int(bool(silu)), _stream()), "vt_layernorm_act")
+    if LN_RECORD is not None:
+        LN_RECORD.append((x, y, gamma, beta, M, c, float(eps), bool(silu)))
     return y
+
+
+def replay_layernorms(record):
+    """Re-issue recorded vt_layernorm_act launches on the current stream (same tensors)."""
+    lib = L.load()
+    for x, y, gamma, beta, M, c, eps, silu in record:
+        ld = x.shape[-1]
+        L.check(lib.vt_layernorm_act(_ptr(x), _DT[x.dtype], ld, _ptr(y), _DT[y.dtype], ld, _ptr(gamma), _ptr(beta), M, c, eps,
+                                     int(silu), _stream()), "vt_layernorm_act(replay)")
+
+
+def launch_class(d):
+    """(class name, algorithmic HBM bytes) of a recorded MFMA-kernel launch whose FLOP per byte sits below the chip's
+    ridge (2.5 PFLOP/s over 8 TB/s = 312): the launches bench.py prices against the HBM roofline.  None for the
+    matrix-bound ones.  Bytes: the input once, the weights once, the result(s) once, the residual once."""
+    if isinstance(d, L.TBlockDesc):
+        es = 2
+        px = d.B * d.T * d.HW
+        return "temporal block fused (C=128)", px * d.ld * es * (1 + (1 if d.keep_y else 0) + (1 if d.ln_next_mode else 0)) + 2 * d.C * 3 * d.C * es
+    es = 4 if d.dtype == L.VT_F32 else 2
+    eo = 4 if d.out_dtype == L.VT_F32 else 2
+    M = d.B * d.To * d.Ho * d.Wo * max(1, d.nbatch)
+    taps = d.KT * d.KH * d.KW
+    plan = conv_plan(d)
+    if plan["kernel"] == "narrow":
+        name = "conv_out 3x3x3 128->3 (conv3d_narrow_kernel)"
+    elif taps == 1 and d.nbatch <= 1:
+        name = "1x1 convolutions (nin_shortcut, attention projections)"
+    elif d.Cin <= 8:
+        name = "conv_in 3x3x3 (3 -> C)"
+    elif d.KH == 1 and d.KW == 1 and d.KT == 3 and d.Cin <= 256:
+        name = f"temporal k3 convolutions, unfused (C={d.Cin})"
+    else:
+        return None
+    nbytes = d.B * d.Ti * d.Hi * d.Wi * d.Cin * es * max(1, d.nbatch) + d.Cout * d.ldw * es
+    if not (d.ln_mode != 0 and plan["ln_fused"] and not d.ln_keep_y):
+        nbytes += M * d.Cout * eo
+    if d.res_mode != L.VT_RES_NONE:
+        nbytes += M * d.Cout * eo
+    if d.ln_mode != 0 and plan["ln_fused"]:
+        nbytes += M * d.Cout * eo
+    return name, nbytes
 
 
 GN_POS = 3   # host-level scope: statistics per position over the C/groups channels of a group (see groupnorm_act)
