@@ -46,6 +46,7 @@ CONV_CASES = [
     ("conv2d_3x3_256_128_res", (1, 2, 16, 24), 256, 128, (3, 3), ConvGeom(**G3), dict(res="add")),
     ("conv2d_3x3_64_192_ragged", (1, 3, 5, 7), 64, 192, (3, 3), ConvGeom(**G3), dict(res="add")),
     ("nin_1x1_128_256", (1, 2, 16, 16), 128, 256, (1, 1), ConvGeom(), {}),
+    ("nin_1x1_64_256_one_kstep", (1, 2, 16, 16), 64, 256, (1, 1), ConvGeom(), dict(res="add")),
     ("downsample_s2", (1, 2, 16, 16), 128, 128, (3, 3), ConvGeom(kh=3, kw=3, sh=2, sw=2, ph_hi=1, pw_hi=1), {}),
     ("upsample_fold", (1, 2, 8, 8), 128, 128, (3, 3), ConvGeom(ups_s=1, **G3), {}),
     ("temporal_k3_res", (2, 6, 8, 8), 128, 128, (3,), ConvGeom(kt=3, pt=2), dict(res="add")),
@@ -308,7 +309,7 @@ def test_conv_pointer_gather(case, dtype, tile, vt_opts):
 # the K-step schedules of the 8-wave tile (conv_sched 0 plain / 1 schedule 1 / 2 two-group ping-pong), the Cout = 256
 # LayerNorm epilogue (fused or conv + vt_layernorm_act; both of its forms), the 128 x 128 tile with and without the
 # LDS-transposed epilogue (without it LayerNorm cannot be fused either).
-SCHED_CASES = [c for c in BIG256 if c[0] in ("nin_1x1_128_256", "temporal_k3_512", "conv3d_333_256", "v11_cache_1d", "nc_conv1d_sym_512",
+SCHED_CASES = [c for c in BIG256 if c[0] in ("nin_1x1_128_256", "nin_1x1_64_256_one_kstep", "temporal_k3_512", "conv3d_333_256", "v11_cache_1d", "nc_conv1d_sym_512",
                                              "conv3d_333_tinner_256", "conv2d_ln256_only", "conv2d_ln256_res_keep", "temporal_ln256_only")]
 
 

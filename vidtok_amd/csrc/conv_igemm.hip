@@ -389,6 +389,118 @@ __device__ __forceinline__ void conv_epilogue_lds256(const ConvArgs& p, f32x16 (
   }
 }
 
+// Second form of the same epilogue (bf16 storage; option conv_ln256_v = 1).  What the first form costs
+// (scripts/kernel_regs.py: 48 spilled registers, 196 B of scratch in every LN256 instantiation; per-tile overhead of the
+// Cout = 256 layers 26-28 us against 19-57 us of K loop, profiles/r02_bench_bf16_conv_breakdown.txt):
+//   * the tile went through the LDS as its upper / lower 128 pixel rows, so half of the waves carried their 128
+//     accumulators through the other half's row loop -- here the halves are the waves' pixel sub-tiles b = 0 / 1, every
+//     wave parks 64 accumulators per half and nothing spills;
+//   * residual rows were loaded inside the row loop and used at once (one exposed memory latency per two rows) -- here the
+//     eight rows a lane handles in a half are requested before the transposition and its two barriers;
+//   * a lane owned two 4-channel quads (8-B loads / stores) -- here 8 consecutive channels: 16-B accesses, a row is 512
+//     contiguous bytes of 32 lanes;
+//   * row arithmetic in scalar fp32 -- here on channel pairs (v_pk_add / mul / fma_f32: no MFMA runs on this CU during an
+//     epilogue, so packed fp32 costs what it says, 3 cycles per element instead of 5).
+// LDS layout: T[128 rows][64 chunks of 4 floats], chunk index XOR (row & 63); row w*32 + l of half b = tile pixel
+// w*64 + b*32 + l.  A lane's two chunks (2j, 2j+1) make its ds_read_b128 pair 2-way bank-conflicted (16 lanes of a service
+// group hit 8 bank quads); the LDS is idle here, the 16-B global accesses are what counts.
+template <typename TOut>
+__device__ __forceinline__ void conv_epilogue_lds256_v1(const ConvArgs& p, f32x16 (&acc)[4][2], int m_blk, int wm, int wn, int lane,
+                                                        int tid, char* smem, long long z) {
+#pragma clang fp contract(off)
+  static_assert(std::is_same<TOut, bf16_t>::value, "bf16 storage");
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+  TOut* __restrict__ yg = reinterpret_cast<TOut*>(p.y) + z * p.ys_z;
+  const TOut* __restrict__ rg = reinterpret_cast<const TOut*>(p.res) + z * p.rs_z;
+  TOut* __restrict__ ng = reinterpret_cast<TOut*>(p.ln_out);
+  float* T = reinterpret_cast<float*>(smem);
+  const bool has_res = p.res_mode == VT_RES_ADD;
+  const int j = tid & 31, rsub = tid >> 5;              // lane j: channels [8j, 8j+8) of T rows rsub + 16 it
+  f32x2 lg[4], lb[4];
+  {
+    const f32x4 g0 = *reinterpret_cast<const f32x4*>(p.ln_gamma + 8 * j), g1 = *reinterpret_cast<const f32x4*>(p.ln_gamma + 8 * j + 4);
+    const f32x4 b0 = *reinterpret_cast<const f32x4*>(p.ln_beta + 8 * j), b1 = *reinterpret_cast<const f32x4*>(p.ln_beta + 8 * j + 4);
+    lg[0] = f32x2{g0[0], g0[1]}; lg[1] = f32x2{g0[2], g0[3]}; lg[2] = f32x2{g1[0], g1[1]}; lg[3] = f32x2{g1[2], g1[3]};
+    lb[0] = f32x2{b0[0], b0[1]}; lb[1] = f32x2{b0[2], b0[3]}; lb[2] = f32x2{b1[0], b1[1]}; lb[3] = f32x2{b1[2], b1[3]};
+  }
+  auto unpack2 = [](uint32_t w) -> f32x2 { return f32x2{__uint_as_float(w << 16), __uint_as_float(w & 0xffff0000u)}; };
+  auto pack2 = [](f32x2 v) -> uint32_t { return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t)); };
+  const int h = lane >> 5;
+  auto half = [&](auto pz_c) {
+    constexpr int PZ = decltype(pz_c)::value;            // compile-time: acc[.][PZ] must not become a dynamic register index
+    // tile pixel of T row r = rsub + 16 it:  (r >> 5) * 64 + PZ * 32 + (r & 31),  r >> 5 = it >> 1 (rsub < 16)
+    u32x4 rq[8];
+    if (has_res) {
+#pragma unroll
+      for (int it = 0; it < 8; ++it) {
+        const long long m = (long long)m_blk + (it >> 1) * 64 + PZ * 32 + rsub + 16 * (it & 1);
+        rq[it] = *reinterpret_cast<const u32x4*>(rg + m * p.ldr + 8 * j);
+      }
+    }
+    __syncthreads();                                    // K loop / previous half: everybody is done with this LDS
+    {
+      const int prl = wm * 32 + (lane & 31);
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int c = wn * 128 + 32 * a + 8 * g + 4 * h;
+          f32x4 bq;
+          if (p.bias) bq = *reinterpret_cast<const f32x4*>(p.bias + c);
+          else bq[0] = bq[1] = bq[2] = bq[3] = 0.0f;
+          f32x4 v;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = acc[a][PZ][4 * g + e] + bq[e];
+          *reinterpret_cast<f32x4*>(T + prl * 256 + (((c >> 2) ^ (prl & 63)) << 2)) = v;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int r = rsub + 16 * it;
+      const int m = m_blk + (it >> 1) * 64 + PZ * 32 + rsub + 16 * (it & 1);
+      const long long orow = out_row(p, m);
+      const f32x4 t0 = *reinterpret_cast<const f32x4*>(T + r * 256 + (((2 * j) ^ (r & 63)) << 2));
+      const f32x4 t1 = *reinterpret_cast<const f32x4*>(T + r * 256 + (((2 * j + 1) ^ (r & 63)) << 2));
+      f32x2 v[4] = {f32x2{t0[0], t0[1]}, f32x2{t0[2], t0[3]}, f32x2{t1[0], t1[1]}, f32x2{t1[2], t1[3]}};
+      if (has_res) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = unpack2(rq[it][q]) + v[q];
+      }
+      if (p.ln_keep_y) {
+        u32x4 w;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) w[q] = pack2(v[q]);
+        *reinterpret_cast<u32x4*>(yg + orow * p.ldy + 8 * j) = w;
+      }
+      const f32x2 s = (v[0] + v[1]) + (v[2] + v[3]);
+      const float mean = group_sum_dpp<32>(s[0] + s[1]) * (1.0f / 256.0f);
+      f32x2 d[4], qq = {0.f, 0.f};
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        d[q] = v[q] - mean;
+        qq = __builtin_elementwise_fma(d[q], d[q], qq);
+      }
+      const float rstd = __builtin_amdgcn_rsqf(__builtin_fmaf(group_sum_dpp<32>(qq[0] + qq[1]), 1.0f / 256.0f, p.ln_eps));
+      u32x4 w;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        f32x2 u = __builtin_elementwise_fma(d[q] * rstd, lg[q], lb[q]);
+        if (p.ln_mode == 2) {                            // u * sigmoid(u), the arithmetic of silu_fast on a pair
+          const f32x2 t = u * -1.4426950408889634f;
+          const f32x2 e = f32x2{__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])} + 1.0f;
+          u = u * f32x2{__builtin_amdgcn_rcpf(e[0]), __builtin_amdgcn_rcpf(e[1])};
+        }
+        w[q] = pack2(u);
+      }
+      *reinterpret_cast<u32x4*>(ng + orow * p.ldn + 8 * j) = w;
+    }
+  };
+  half(std::integral_constant<int, 0>{});
+  half(std::integral_constant<int, 1>{});
+}
+
 // ------------------------------------------------------------------------------------------------
 // The operand tiles go global -> LDS with LDS-DMA (no VGPR round trip, no ds_write pass -- a
 // register-staged first version spent ~415 LDS cycles per K step on ds_write_b128 against 512 MFMA cycles).  The DMA writes each wave's 64
@@ -413,9 +525,10 @@ __device__ __forceinline__ void conv_epilogue_lds256(const ConvArgs& p, f32x16 (
 //        taps / ragged rows need no zero-page select and no 64-bit pointer arithmetic (the K loop of the
 //        short-K layers is instruction-issue bound: ~13 VALU per MFMA with pointers).  Needs the tensors
 //        below 4 GiB and no cache-mode time padding; otherwise the pointer form is used.
-// LN256  the 8-wave tile with the LayerNorm-fusing epilogue (conv_epilogue_lds256) -- its own instantiation: the mere
-//        presence of a second epilogue path slowed every 256-tile convolution by 8 % through register allocation (round 1)
-template <typename MT, typename TOut, int WAVES_M, int WAVES_N, int TM, int TN, bool FAST, int ROWB, int STAGES, bool BUF, bool LN256 = false, bool PROF = false, int SCHED = 0>
+// LN256  the 8-wave tile with a LayerNorm-fusing epilogue (1: conv_epilogue_lds256, 2: conv_epilogue_lds256_v1) -- its own
+//        instantiations: the mere presence of a second epilogue path slowed every 256-tile convolution by 8 % through
+//        register allocation (round 1)
+template <typename MT, typename TOut, int WAVES_M, int WAVES_N, int TM, int TN, bool FAST, int ROWB, int STAGES, bool BUF, int LN256 = 0, bool PROF = false, int SCHED = 0>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_igemm_glds_kernel(const ConvArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)   // device pass only: the host pass needs just the launch stub (buffer-descriptor types are device-only)
   constexpr int THREADS = 64 * WAVES_M * WAVES_N;   // 4 waves (128x128, 256x32/64 tiles) or 8 waves (256x256)
@@ -503,9 +616,14 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_igemm_glds_ker
   }
   const MT* b_row[B_VECS];
   unsigned b_off[B_VECS];
+  // SCHED 2 stages the weight rows as two half-tiles (rows [0, 128) = the channel sub-tiles a = 0, 1 of both wave columns,
+  // rows [128, 256) = a = 2, 3), each refilled as soon as its own last fragment read is over: LDS row
+  // (a >> 1) * 128 + wn * 64 + (a & 1) * 32 + l holds channel wn * 128 + a * 32 + l of the tile
+  constexpr bool S2 = SCHED == 2 && (WAVES_M * WAVES_N == 8) && FAST && BUF;
 #pragma unroll
   for (int j = 0; j < B_VECS; ++j) {
-    const int n = n_blk + srow + RSTEP * j;
+    const int lr = srow + RSTEP * j;
+    const int n = n_blk + (S2 ? ((lr >> 6) & 1) * 128 + ((((lr >> 7) & 1) << 1) | ((lr >> 5) & 1)) * 32 + (lr & 31) : lr);
     b_row[j] = (n < p.Cout) ? wg + (long long)n * p.ldw : nullptr;
     b_off[j] = (n < p.Cout) ? (unsigned)n * (unsigned)p.ldw * (unsigned)sizeof(MT) + (FAST ? (unsigned)chunk * 16u : 0u) : kOob;
   }
@@ -750,13 +868,15 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_igemm_glds_ker
     }
   };
 
+  if constexpr (!S2) {
 #pragma unroll
-  for (int d = 0; d < D; ++d)
-    if (d < p.nsteps) {
-      prep_step(d);
+    for (int d = 0; d < D; ++d)
+      if (d < p.nsteps) {
+        prep_step(d);
 #pragma unroll
-      for (int q = 0; q < IPS; ++q) fire_piece(q, d);
-    }
+        for (int q = 0; q < IPS; ++q) fire_piece(q, d);
+      }
+  }
   if constexpr (S1) {                        // the addresses of a step are ready one stage before its pieces are fired
     if (D < p.nsteps) prep_step(D);
   }
@@ -774,7 +894,104 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_igemm_glds_ker
       }
     }
   };
-  if constexpr (S1) {
+  if constexpr (S2) {
+    // Schedule 2, "ping-pong" (the structure of the guide's 256 x 256 template, adapted to the gather).
+    // What the stamps of schedule 1 show (profiles/r02_igemm_step_cycles_sched1.txt): the two waves of a SIMD run the same
+    // mixed stream of fragment reads, DMA pieces and MFMAs side by side, the older one wins every arbitration, finishes
+    // its 32 MFMAs after ~2 200 cycles and parks 850-980 cycles at the stage barrier while the younger one completes alone
+    // -- 3 180 cycles per K step against 2 048 of matrix work.  Here a wave alternates between a LOAD phase (fragment
+    // reads + DMA pieces, no MFMA) and a COMPUTE phase (16 back-to-back MFMAs, nothing else), a barrier after each, and
+    // waves 4-7 (the second wave of every SIMD) run one barrier behind waves 0-3: at any time one wave of a SIMD feeds
+    // the matrix pipe and the other owns the rest of the issue slots.
+    //   phase 2s:    LOAD  x fragments of both pixel sub-tiles + w fragments of channel sub-tiles 0, 1  (16 ds_read_b128),
+    //                      DMA of W1(s+1);      COMPUTE acc[0..1][*] += ...   (16 MFMAs)
+    //   phase 2s+1:  LOAD  w fragments of channel sub-tiles 2, 3 (8 reads; x stays in registers),
+    //                      address set-up of step s+2, DMA of XX(s+2) and W0(s+2);   COMPUTE acc[2..3][*]
+    // Half-tiles of a stage: XX = the 256 pixel rows (4 DMA pieces per lane), W0 / W1 = weight rows [0,128) / [128,256) (2
+    // pieces each).  A half-tile's LDS region is refilled for step s+2 right behind its last read of step s (both
+    // groups' reads are retired -- lgkmcnt(0) in front of the barrier that ends a LOAD phase -- one barrier before the
+    // first piece goes out), so a piece has three phases (~3 000 cycles) to land instead of the half stage of schedule 1.
+    // In issue order a wave's pieces are ... [XX(s) W0(s)] [W1(s)] [XX(s+1) W0(s+1)] [W1(s+1)] ...: with 6 + 2 pieces per
+    // two phases, "everything but the youngest 8" = vmcnt(8) at the end of EVERY load phase is exactly what the next
+    // phase reads, and a barrier lies between that wait and any other wave's read (guide: read a staged buffer one
+    // phase after the wait that retires it).
+    static_assert(STAGES == 2 && D == 1 && KS == 4 && TM == 2 && TN == 4 && A_VECS == 4 && B_VECS == 4, "schedule 2: the 8-wave 256 x 256 tile");
+    const int grp = __builtin_amdgcn_readfirstlane((int)(tid >> 8));     // 0: waves 0-3, 1: waves 4-7 (one barrier behind)
+    const char* a_base = smem + (wm * TM * 32) * ROWB + frag_row;
+    const char* b_base = smem + A_BYTES + (wn * 64) * ROWB + frag_row;
+    u32x4 xf[TM][KS], wf[2][KS];
+    auto read_x = [&](int stg) {
+      const char* As = a_base + stg * STAGE_BYTES;
+#pragma unroll
+      for (int b = 0; b < TM; ++b)
+#pragma unroll
+        for (int k = 0; k < KS; ++k) xf[b][k] = *reinterpret_cast<const u32x4*>(As + b * 32 * ROWB + (((k * 2 + khalf) ^ swz) * 16));
+    };
+    auto read_w = [&](int stg, int hf) {
+      const char* Bs = b_base + stg * STAGE_BYTES + hf * 128 * ROWB;
+#pragma unroll
+      for (int a2 = 0; a2 < 2; ++a2)
+#pragma unroll
+        for (int k = 0; k < KS; ++k) wf[a2][k] = *reinterpret_cast<const u32x4*>(Bs + a2 * 32 * ROWB + (((k * 2 + khalf) ^ swz) * 16));
+    };
+    auto end_load = [&]() {   // my pieces for the next phase's reads have landed, my reads of this phase are retired
+      asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    auto compute = [&](auto hf_c) {
+      constexpr int HF = decltype(hf_c)::value;
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int k = 0; k < KS; ++k)
+#pragma unroll
+        for (int a2 = 0; a2 < 2; ++a2)
+#pragma unroll
+          for (int b = 0; b < TM; ++b) mma_step<MT>(wf[a2][k], xf[b][k], acc[2 * HF + a2][b]);
+      __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    // prologue: [XX(0) W0(0)] [W1(0)] [XX(1) W0(1)] -- 14 pieces whatever nsteps is (pieces of steps that do not exist go out
+    // against extent 0: zero fill, no traffic), then the common start barrier
+    prep_step(0);
+#pragma unroll
+    for (int q = 0; q < IPS; ++q) fire_piece(q, 0);
+    if (1 < p.nsteps) prep_step(1);
+    else ext_x = ext_w = 0u;
+#pragma unroll
+    for (int q = 0; q < A_VECS + 2; ++q) fire_piece(q, 1);
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    if (grp == 1) {
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    for (int s = 0; s < p.nsteps; ++s) {
+      const int stg = s & 1;
+      // ---- phase 2s
+      read_x(stg);
+      read_w(stg, 0);
+      fire_piece(A_VECS + 2, stg ^ 1);             // W1(s+1): addresses of step s+1 are the last ones prepared
+      fire_piece(A_VECS + 3, stg ^ 1);
+      end_load();
+      compute(std::integral_constant<int, 0>{});
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      // ---- phase 2s+1
+      read_w(stg, 1);
+      if (s + 2 < p.nsteps) prep_step(s + 2);
+      else ext_x = ext_w = 0u;                     // past the last step: the pieces below turn into zero fills
+#pragma unroll
+      for (int q = 0; q < A_VECS + 2; ++q) fire_piece(q, stg);   // XX(s+2), W0(s+2) into the regions read for the last time in phase 2s
+      end_load();
+      compute(std::integral_constant<int, 1>{});
+      if (!(grp == 1 && s + 1 == p.nsteps)) {      // waves 4-7 entered one barrier late: they leave without the last one
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  } else if constexpr (S1) {
     // Schedule 1: one K loop body, software-pipelined across stages.  Fragments are requested one 32-B sub-step ahead
     // of their MFMAs (two register sets).  The stage barrier sits in front of the LAST FOUR MFMA groups of a stage: by
     // then this wave has every fragment of the current slot in registers (so the slot may be refilled) and its own
@@ -887,10 +1104,11 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_igemm_glds_ker
       for (int i = 0; i < 4 * 8; ++i) p.prof[(tid >> 6) * 32 + i] = stamps[((i / 8) * NW + (tid >> 6)) * 8 + (i % 8)];
     }
   }
-  if constexpr (LN256) {
+  if constexpr (LN256 != 0) {
     static_assert(WAVES_M == 4 && WAVES_N == 2 && TM == 2 && TN == 4 && std::is_same<MT, TOut>::value, "LN256: the 8-wave 256 x 256 tile");
     if constexpr (!BUF) wait_vmcnt<0>();
-    conv_epilogue_lds256<TOut>(p, acc, m_blk, wm, wn, lane, tid, smem, z);
+    if constexpr (LN256 == 2) conv_epilogue_lds256_v1<TOut>(p, acc, m_blk, wm, wn, lane, tid, smem, z);
+    else conv_epilogue_lds256<TOut>(p, acc, m_blk, wm, wn, lane, tid, smem, z);
     return;
   }
   if constexpr (WAVES_M == 2 && WAVES_N == 2 && TM == 2 && TN == 2 && STAGES * STAGE_BYTES >= 128 * 128 * 4) {
@@ -914,7 +1132,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_igemm_glds_ker
 inline bool conv_buf() { return vt_opt(OPT_CONV_BUF) != 0; }
 inline bool conv_tinner() { return vt_opt(OPT_CONV_TINNER) != 0; }
 
-template <typename MT, typename TOut, int WAVES_M, int WAVES_N, int TM, int TN, bool FAST, bool LN256 = false>
+template <typename MT, typename TOut, int WAVES_M, int WAVES_N, int TM, int TN, bool FAST, int LN256 = 0>
 int launch_variant(const ConvArgs& a_in, int nbatch, hipStream_t stream) {
   constexpr int ROWB = kRowBytes, STAGES = 2;
   constexpr int BM = WAVES_M * TM * 32;
@@ -944,7 +1162,10 @@ int launch_variant(const ConvArgs& a_in, int nbatch, hipStream_t stream) {
   const void* kern;
   // VT_CONV_SCHED=0: the plain K-step schedule of the 8-wave tile (A/B runs); default 1, see the kernel
   constexpr bool HAS_S1 = WAVES_M * WAVES_N == 8 && FAST;
-  const bool s1 = HAS_S1 && buf && vt_opt(OPT_CONV_SCHED) != 0;
+  constexpr bool HAS_S2 = HAS_S1 && std::is_same<MT, bf16_t>::value;    // schedule 2 (ping-pong): bf16 operands only
+  const int sched_opt = vt_opt(OPT_CONV_SCHED);
+  const bool s2 = HAS_S2 && buf && sched_opt == 2;
+  const bool s1 = HAS_S1 && buf && sched_opt != 0 && !s2;
   if (buf) {
     a.x_bytes = (unsigned)xb;
     a.w_bytes = (unsigned)wb;
@@ -952,15 +1173,18 @@ int launch_variant(const ConvArgs& a_in, int nbatch, hipStream_t stream) {
     if constexpr (HAS_S1) {
       if (s1) kern = reinterpret_cast<const void*>(&conv_igemm_glds_kernel<MT, TOut, WAVES_M, WAVES_N, TM, TN, FAST, ROWB, STAGES, true, LN256, false, 1>);
     }
+    if constexpr (HAS_S2) {
+      if (s2) kern = reinterpret_cast<const void*>(&conv_igemm_glds_kernel<MT, TOut, WAVES_M, WAVES_N, TM, TN, FAST, ROWB, STAGES, true, LN256, false, 2>);
+    }
   } else {
     kern = reinterpret_cast<const void*>(&conv_igemm_glds_kernel<MT, TOut, WAVES_M, WAVES_N, TM, TN, FAST, ROWB, STAGES, false, LN256>);
   }
   int lds_bytes = LDS;
   if (a.prof != nullptr) {   // vt_conv_profile: only the plain 8-wave bf16 instantiation carries the stamps
-    if constexpr (std::is_same<MT, bf16_t>::value && std::is_same<TOut, bf16_t>::value && WAVES_M == 4 && WAVES_N == 2 && FAST && !LN256) {
-      VT_CHECK_ARG(buf, "vt_conv_profile: descriptor gather only");
-      kern = s1 ? reinterpret_cast<const void*>(&conv_igemm_glds_kernel<MT, TOut, WAVES_M, WAVES_N, TM, TN, FAST, ROWB, STAGES, true, false, true, 1>)
-                : reinterpret_cast<const void*>(&conv_igemm_glds_kernel<MT, TOut, WAVES_M, WAVES_N, TM, TN, FAST, ROWB, STAGES, true, false, true, 0>);
+    if constexpr (std::is_same<MT, bf16_t>::value && std::is_same<TOut, bf16_t>::value && WAVES_M == 4 && WAVES_N == 2 && FAST && LN256 == 0) {
+      VT_CHECK_ARG(buf && !s2, "vt_conv_profile: descriptor gather, K-step schedule 0 or 1 only");
+      kern = s1 ? reinterpret_cast<const void*>(&conv_igemm_glds_kernel<MT, TOut, WAVES_M, WAVES_N, TM, TN, FAST, ROWB, STAGES, true, 0, true, 1>)
+                : reinterpret_cast<const void*>(&conv_igemm_glds_kernel<MT, TOut, WAVES_M, WAVES_N, TM, TN, FAST, ROWB, STAGES, true, 0, true, 0>);
       lds_bytes = LDS + 4096;
       VT_CHECK_HIP(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
     } else {
@@ -968,8 +1192,8 @@ int launch_variant(const ConvArgs& a_in, int nbatch, hipStream_t stream) {
     }
   }
   // the attribute is per device: one flag per (instantiation, gather form, device), set race-free
-  static std::atomic<bool> attr_done[3][kMaxDevices];
-  const int ki = buf ? (s1 ? 2 : 1) : 0;
+  static std::atomic<bool> attr_done[4][kMaxDevices];
+  const int ki = buf ? (s2 ? 3 : (s1 ? 2 : 1)) : 0;
   int dev = 0;
   VT_CHECK_HIP(hipGetDevice(&dev));
   if (dev < 0 || dev >= kMaxDevices || !attr_done[ki][dev].load(std::memory_order_acquire)) {
@@ -1046,7 +1270,12 @@ int dispatch_tile(const ConvArgs& a, int nbatch, hipStream_t stream) {
     case TILE_256x64: return launch_fast_or_general<MT, TOut, 4, 1, 2, 2>(a, nbatch, stream);
     case TILE_256x256:                                                                           // 8 waves
       if constexpr (std::is_same<MT, TOut>::value) {
-        if (a.ln_mode != 0) return launch_variant<MT, TOut, 4, 2, 2, 4, true, true>(a, nbatch, stream);   // conv_prepare checked Cin % BK
+        if (a.ln_mode != 0) {                                                                     // conv_prepare checked Cin % BK
+          if constexpr (std::is_same<TOut, bf16_t>::value) {
+            if (vt_opt(OPT_CONV_LN256_V) != 0) return launch_variant<MT, TOut, 4, 2, 2, 4, true, 2>(a, nbatch, stream);
+          }
+          return launch_variant<MT, TOut, 4, 2, 2, 4, true, 1>(a, nbatch, stream);
+        }
       }
       return launch_fast_or_general<MT, TOut, 4, 2, 2, 4>(a, nbatch, stream);
     default: return launch_fast_or_general<MT, TOut, 2, 2, 2, 2>(a, nbatch, stream);
