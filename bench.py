@@ -112,7 +112,7 @@ def cpu_baseline():
 MFMA_KERNELS = ("conv_igemm", "conv3x3_ws128", "conv3d_narrow", "tblock_ws128", "tblock_split")
 
 
-def measure_traffic(dtype, batch, config, timeout_s=200):
+def measure_traffic(dtype, batch, config, timeout_s=200, table=None):
     """HBM-side bytes per MFMA-kernel launch, measured NOW: two rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE cannot
     share one; counters only with --kernel-trace) over a child run of this file that does three eager steps and
     nothing else.  FETCH_SIZE is doubled (gfx950 reports half the bytes of wide streaming reads, MI355X_MICROARCH.md
@@ -126,11 +126,13 @@ def measure_traffic(dtype, batch, config, timeout_s=200):
     if shutil.which("rocprofv3") is None:
         return None, "rocprofv3 not on PATH"
     out = tempfile.mkdtemp(prefix="vt_pmc_", dir="/tmp")
-    vals = {}
+    vals, per = {}, {}
+    labels_path = os.path.join(out, "labels.json")
     try:
         for counter in ("FETCH_SIZE", "WRITE_SIZE"):
             cmd = ["rocprofv3", "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", os.path.join(out, counter), "-o", "p",
-                   "--", sys.executable, os.path.abspath(__file__), "--pmc-child", "--dtype", dtype, "--batch", str(batch), "--config", config]
+                   "--", sys.executable, os.path.abspath(__file__), "--pmc-child", "--dtype", dtype, "--batch", str(batch), "--config", config,
+                   "--pmc-labels", labels_path]
             env = dict(os.environ, TMPDIR="/tmp")
             for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "GROUP_RANK", "LOCAL_WORLD_SIZE",
                       "TORCHELASTIC_RUN_ID", "ROLE_RANK", "ROLE_WORLD_SIZE"):
@@ -140,10 +142,27 @@ def measure_traffic(dtype, batch, config, timeout_s=200):
             for f in glob.glob(os.path.join(out, counter, "**", "*counter_collection.csv"), recursive=True):
                 for row in csv.DictReader(open(f)):
                     if row["Counter_Name"] == counter and any(t in row["Kernel_Name"] for t in MFMA_KERNELS):
-                        v.append(float(row["Counter_Value"]))
+                        v.append((int(row.get("Dispatch_Id", len(v))), float(row["Counter_Value"])))
             if not v:
                 return None, f"no {counter} samples (rocprofv3 rc={r.returncode})"
-            vals[counter] = sum(v) / len(v)
+            vals[counter] = sum(x for _, x in v) / len(v)
+            per[counter] = [x for _, x in sorted(v)]
+        if table is not None and os.path.exists(labels_path):
+            # per layer group: the child's MFMA launches come in the order it recorded them, step after step
+            labs = json.load(open(labels_path))
+            n = len(labs)
+            if n and all(len(per[c]) % n == 0 for c in per):
+                groups = {}
+                for c, mul in (("FETCH_SIZE", 2.0), ("WRITE_SIZE", 1.0)):
+                    steps = len(per[c]) // n
+                    for i, val in enumerate(per[c]):
+                        g = groups.setdefault(tuple(labs[i % n]["label"]), {"launches": 0, "algorithmic": 0.0, "measured": 0.0})
+                        g["measured"] += mul * val * 1024.0 / steps
+                for lab in labs:
+                    g = groups[tuple(lab["label"])]
+                    g["launches"] += 1
+                    g["algorithmic"] += lab["bytes"]
+                table.extend({"M": k[0], "N": k[1], "K": k[2], **g} for k, g in groups.items())
         return (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0, "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this run"
     except Exception as e:  # a profiler problem must not cost the bench line
         return None, f"{type(e).__name__}: {e}"
@@ -202,6 +221,7 @@ def main():
     ap.add_argument("--traffic", choices=["pmc", "profile", "none"], default="pmc",
                     help="roofline.traffic: measure now with two rocprofv3 PMC passes over a child run on rank 0's GPU (default), quote profiles/, or null")
     ap.add_argument("--pmc-child", action="store_true", help="internal: three eager steps for the PMC passes, no output")
+    ap.add_argument("--pmc-labels", default=None, help="internal: where the PMC child writes its per-launch labels")
     ap.add_argument("--selftest-spawn", action="store_true",
                     help="CPU/gloo check of the N-rank launch path only (no GPU work): prints the world size reached")
     ap.add_argument("--config", default=None, help="override the workload's YAML (default: BASELINE configs[1] / [3])")
@@ -262,8 +282,12 @@ def main():
         return model(x)
 
     if args.pmc_child:           # the profiler's subject: a few eager steps (every kernel of the path), nothing else
-        for _ in range(3):
+        ops.CONV_RECORD = []
+        for i in range(3):
             step()
+            if i == 0 and args.pmc_labels:   # what each MFMA launch of a step is, in launch order (joined with the counters by the parent)
+                json.dump([{"label": list(lab), "bytes": ops.launch_bytes(d)} for d, _, lab in ops.CONV_RECORD], open(args.pmc_labels, "w"))
+            ops.CONV_RECORD = None
         torch.cuda.synchronize()
         return
     # launch mode: the engine's own per-shape hipGraph cache (vidtok_amd/graphs.py: encoder and decoder launch
@@ -383,9 +407,18 @@ def main():
     if args.traffic == "pmc":
         del model, out, z, dec
         torch.cuda.empty_cache()
-        tb, src = measure_traffic(args.dtype, B, config)
+        ttab = [] if args.breakdown else None
+        tb, src = measure_traffic(args.dtype, B, config, table=ttab)
         if tb is not None:
             roof["traffic"], roof["traffic_source"] = round(tb), src
+            if ttab:
+                print("[bench] HBM-side traffic per step by (pixels, Cout, K) group: measured (PMC FETCH_SIZE x2 + WRITE_SIZE) vs algorithmic "
+                      "(operands and results once):", file=sys.stderr)
+                for g in sorted(ttab, key=lambda g: -g["measured"]):
+                    print(f"[bench]   M={g['M']:8d} N={g['N']:4d} K={g['K']:6d}  x{g['launches']:3d}  measured {g['measured'] / 1e9:8.3f} GB  "
+                          f"algorithmic {g['algorithmic'] / 1e9:8.3f} GB  ratio {g['measured'] / max(g['algorithmic'], 1):5.2f}", file=sys.stderr)
+                print(f"[bench]   total measured {sum(g['measured'] for g in ttab) / 1e9:.1f} GB, algorithmic "
+                      f"{sum(g['algorithmic'] for g in ttab) / 1e9:.1f} GB per step", file=sys.stderr)
         else:
             roof["traffic_source"] = f"live measurement failed: {src}"
     if roof["traffic"] is None and args.traffic != "none":

@@ -75,7 +75,7 @@ int vt_conv_max_lds_bytes(void);
  *   conv_buf (1)        gather through buffer descriptors; 0 = 64-bit pointers (always used for > 4 GiB tensors / cache mode)
  *   conv_tinner (1)     temporal convolutions walk their tiles frames-innermost (L2 reuse of the kt taps)
  *   conv_ldsepi (1)     128 x 128 tile: epilogue transposed through the LDS (whole-line stores, carries the fused LayerNorm)
- *   conv_sched (1)      K-step schedule of the 8-wave 256 x 256 tile: 0 plain loop, 1 schedule 1, 2 two-group ping-pong
+ *   conv_sched (1)      K-step schedule of the 8-wave 256 x 256 tile: 0 plain loop, 1 schedule 1, 2 / 3 two-group ping-pong (bf16)
  *   conv_ws (1)         weight-stationary persistent kernel for bf16 3x3 128 -> 128 convolutions
  *   conv_narrow (1)     conv3d_narrow_kernel for Cout <= 4 (the decoder's conv_out)
  *   conv_tile (0)       128 / 256: force that tile wherever it is legal; 0 = choose by size

@@ -17,11 +17,17 @@ from vidtok_amd.ops import ConvGeom  # noqa: E402
 
 # plain schedule (VT_CONV_SCHED=0): stamps at stage start / after the vmcnt wait / after the barrier / after the address
 # set-up / at stage end; schedule 1: stage start / in front of the waits of the last sub-step / after vmcnt / after the
-# barrier / stage end
-if os.environ.get("VT_CONV_SCHED", "1") == "0":
+# barrier / stage end; schedules 2 / 3 (two-group ping-pong): the eight phase boundaries of a step
+SCHED = int(os.environ.get("VT_CONV_SCHED", "1"))
+if SCHED == 0:
     NAMES = ["wait my DMA (vmcnt)", "barrier", "prep_step (addresses)", "MFMAs + DMA issue + ds_read"]
-else:
+elif SCHED == 1:
     NAMES = ["sub-steps 0-2: 24 MFMAs + 8 DMA pieces + set-up", "wait lgkm + my DMA (vmcnt)", "barrier", "sub-step 3: 8 MFMAs + next fragments"]
+else:
+    NAMES = ["LOAD(2s): 16 ds_read" + (" + 2 pieces" if SCHED == 2 else ""), "waits + barrier", "COMPUTE(2s): 16 MFMAs" + (" + 2 pieces" if SCHED == 3 else ""),
+             "barrier", "LOAD(2s+1): 8 ds_read + set-up + " + ("6" if SCHED == 2 else "2") + " pieces", "waits + barrier",
+             "COMPUTE(2s+1): 16 MFMAs" + (" + 4 pieces" if SCHED == 3 else "")]
+NS = len(NAMES)
 
 
 def main():
@@ -47,10 +53,10 @@ def main():
         print(f"{label}: tile {plan['tile']}, {plan['workgroups']} workgroups")
         for wv in range(8):
             for st in range(4):
-                dl = [int(s[wv, st, k + 1] - s[wv, st, k]) for k in range(4)]
+                dl = [int(s[wv, st, k + 1] - s[wv, st, k]) for k in range(NS)]
                 nxt = int(s[wv, st + 1, 0] - s[wv, st, 0]) if st < 3 else sum(dl)
                 print(f"  wave {wv} step {8 + st}: step period {nxt:6d} | " + " | ".join(f"{n} {v}" for n, v in zip(NAMES, dl)))
-        avg = [sum(int(s[wv, st, k + 1] - s[wv, st, k]) for wv in range(8) for st in range(4)) / 32 for k in range(4)]
+        avg = [sum(int(s[wv, st, k + 1] - s[wv, st, k]) for wv in range(8) for st in range(4)) / 32 for k in range(NS)]
         per = sum(int(s[wv, st + 1, 0] - s[wv, st, 0]) for wv in range(8) for st in range(3)) / 24
         print(f"  average step period {per:.0f} cycles (MFMA-bound: 2048 per SIMD = 2 waves x 32 MFMAs x 32); phases of one wave:")
         for n, v in zip(NAMES, avg):

@@ -619,7 +619,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_igemm_glds_ker
   // SCHED 2 stages the weight rows as two half-tiles (rows [0, 128) = the channel sub-tiles a = 0, 1 of both wave columns,
   // rows [128, 256) = a = 2, 3), each refilled as soon as its own last fragment read is over: LDS row
   // (a >> 1) * 128 + wn * 64 + (a & 1) * 32 + l holds channel wn * 128 + a * 32 + l of the tile
-  constexpr bool S2 = SCHED == 2 && (WAVES_M * WAVES_N == 8) && FAST && BUF;
+  constexpr bool S2 = (SCHED == 2 || SCHED == 3) && (WAVES_M * WAVES_N == 8) && FAST && BUF;
 #pragma unroll
   for (int j = 0; j < B_VECS; ++j) {
     const int lr = srow + RSTEP * j;
@@ -916,6 +916,16 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_igemm_glds_ker
     // phase reads, and a barrier lies between that wait and any other wave's read (guide: read a staged buffer one
     // phase after the wait that retires it).
     static_assert(STAGES == 2 && D == 1 && KS == 4 && TM == 2 && TN == 4 && A_VECS == 4 && B_VECS == 4, "schedule 2: the 8-wave 256 x 256 tile");
+    // SCHED 3 = the same phases with the DMA pieces moved out of the load phases: six pieces back to back next to eight
+    // fragment reads made the odd load phase the longest interval of a step (measured: schedule 2 gained 3 % on the
+    // long-K layers where the phase count promised 20 %; the guide prices a piece at 100-185 cycles inside such a phase
+    // against ~60 between bare MFMAs).  Pieces per phase:   LOAD(2s) none            COMPUTE(2s)   W1(s+1)              (2)
+    //                                                      LOAD(2s+1) XX(s+2) 0,1   COMPUTE(2s+1) XX(s+2) 2,3 W0(s+2)  (4)
+    // issue order ... L(2s+1):2 C(2s+1):4 C(2s+2):2 L(2s+3):2 ...  =>  the next phase's operands are everything but the
+    // youngest 4 (end of an odd load phase) / youngest 6 (end of an even one).  A half-tile is requested at the earliest
+    // in the interval after both groups' last reads of its region are retired (same argument as schedule 2, one barrier
+    // later for the pieces that moved into a compute phase).
+    constexpr bool PC = SCHED == 3;
     const int grp = __builtin_amdgcn_readfirstlane((int)(tid >> 8));     // 0: waves 0-3, 1: waves 4-7 (one barrier behind)
     const char* a_base = smem + (wm * TM * 32) * ROWB + frag_row;
     const char* b_base = smem + A_BYTES + (wn * 64) * ROWB + frag_row;
@@ -934,23 +944,33 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_igemm_glds_ker
 #pragma unroll
         for (int k = 0; k < KS; ++k) wf[a2][k] = *reinterpret_cast<const u32x4*>(Bs + a2 * 32 * ROWB + (((k * 2 + khalf) ^ swz) * 16));
     };
-    auto end_load = [&]() {   // my pieces for the next phase's reads have landed, my reads of this phase are retired
-      asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+    auto end_load = [&](auto odd_c) {   // my pieces for the next phase's reads have landed, my reads of this phase are retired
+      if constexpr (!PC) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+      else if constexpr (decltype(odd_c)::value) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
     };
-    auto compute = [&](auto hf_c) {
-      constexpr int HF = decltype(hf_c)::value;
+    // COMPUTE phase of channel half HF; with PC the pieces [Q0, Q1) of the prepared step go out behind every EVERY-th MFMA
+    auto compute = [&](auto hf_c, auto q0_c, auto q1_c, int dst) {
+      constexpr int HF = decltype(hf_c)::value, Q0 = decltype(q0_c)::value, Q1 = decltype(q1_c)::value;
+      constexpr int NQ = Q1 - Q0, EVERY = NQ > 0 ? 16 / (NQ + 1) : 16;
       __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int k = 0; k < KS; ++k)
 #pragma unroll
         for (int a2 = 0; a2 < 2; ++a2)
 #pragma unroll
-          for (int b = 0; b < TM; ++b) mma_step<MT>(wf[a2][k], xf[b][k], acc[2 * HF + a2][b]);
+          for (int b = 0; b < TM; ++b) {
+            mma_step<MT>(wf[a2][k], xf[b][k], acc[2 * HF + a2][b]);
+            const int m = (k * 2 + a2) * TM + b + 1;       // MFMAs issued so far in this phase
+            if (NQ > 0 && m % EVERY == 0 && m / EVERY <= NQ) fire_piece(Q0 + m / EVERY - 1, dst);
+          }
       __builtin_amdgcn_s_setprio(0);
       __builtin_amdgcn_sched_barrier(0);
     };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
     // prologue: [XX(0) W0(0)] [W1(0)] [XX(1) W0(1)] -- 14 pieces whatever nsteps is (pieces of steps that do not exist go out
     // against extent 0: zero fill, no traffic), then the common start barrier
     prep_step(0);
@@ -967,25 +987,46 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_igemm_glds_ker
       __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
     }
+    // PROF stamps per step: 0 L(2s) start, 1 reads / pieces issued, 2 C(2s) start (wait + barrier over), 3 C(2s) end,
+    // 4 L(2s+1) start (barrier over), 5 issued, 6 C(2s+1) start, 7 C(2s+1) end
     for (int s = 0; s < p.nsteps; ++s) {
       const int stg = s & 1;
+      s_cur = s;
+      stamp(0);
       // ---- phase 2s
       read_x(stg);
       read_w(stg, 0);
-      fire_piece(A_VECS + 2, stg ^ 1);             // W1(s+1): addresses of step s+1 are the last ones prepared
-      fire_piece(A_VECS + 3, stg ^ 1);
-      end_load();
-      compute(std::integral_constant<int, 0>{});
+      if constexpr (!PC) {
+        fire_piece(A_VECS + 2, stg ^ 1);           // W1(s+1): addresses of step s+1 are the last ones prepared
+        fire_piece(A_VECS + 3, stg ^ 1);
+      }
+      stamp(1);
+      end_load(I0{});
+      stamp(2);
+      if constexpr (PC) compute(I0{}, std::integral_constant<int, A_VECS + 2>{}, std::integral_constant<int, A_VECS + 4>{}, stg ^ 1);
+      else compute(I0{}, I0{}, I0{}, 0);
+      stamp(3);
       __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
+      stamp(4);
       // ---- phase 2s+1
       read_w(stg, 1);
       if (s + 2 < p.nsteps) prep_step(s + 2);
       else ext_x = ext_w = 0u;                     // past the last step: the pieces below turn into zero fills
+      // XX(s+2), W0(s+2) into the regions read for the last time in phase 2s
+      if constexpr (PC) {
+        fire_piece(0, stg);
+        fire_piece(1, stg);
+      } else {
 #pragma unroll
-      for (int q = 0; q < A_VECS + 2; ++q) fire_piece(q, stg);   // XX(s+2), W0(s+2) into the regions read for the last time in phase 2s
-      end_load();
-      compute(std::integral_constant<int, 1>{});
+        for (int q = 0; q < A_VECS + 2; ++q) fire_piece(q, stg);
+      }
+      stamp(5);
+      end_load(I1{});
+      stamp(6);
+      if constexpr (PC) compute(I1{}, std::integral_constant<int, 2>{}, std::integral_constant<int, A_VECS + 2>{}, stg);
+      else compute(I1{}, I0{}, I0{}, 0);
+      stamp(7);
       if (!(grp == 1 && s + 1 == p.nsteps)) {      // waves 4-7 entered one barrier late: they leave without the last one
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
@@ -1164,8 +1205,9 @@ int launch_variant(const ConvArgs& a_in, int nbatch, hipStream_t stream) {
   constexpr bool HAS_S1 = WAVES_M * WAVES_N == 8 && FAST;
   constexpr bool HAS_S2 = HAS_S1 && std::is_same<MT, bf16_t>::value;    // schedule 2 (ping-pong): bf16 operands only
   const int sched_opt = vt_opt(OPT_CONV_SCHED);
+  const bool s3 = HAS_S2 && buf && sched_opt == 3;
   const bool s2 = HAS_S2 && buf && sched_opt == 2;
-  const bool s1 = HAS_S1 && buf && sched_opt != 0 && !s2;
+  const bool s1 = HAS_S1 && buf && sched_opt != 0 && !s2 && !s3;
   if (buf) {
     a.x_bytes = (unsigned)xb;
     a.w_bytes = (unsigned)wb;
@@ -1175,6 +1217,7 @@ int launch_variant(const ConvArgs& a_in, int nbatch, hipStream_t stream) {
     }
     if constexpr (HAS_S2) {
       if (s2) kern = reinterpret_cast<const void*>(&conv_igemm_glds_kernel<MT, TOut, WAVES_M, WAVES_N, TM, TN, FAST, ROWB, STAGES, true, LN256, false, 2>);
+      if (s3) kern = reinterpret_cast<const void*>(&conv_igemm_glds_kernel<MT, TOut, WAVES_M, WAVES_N, TM, TN, FAST, ROWB, STAGES, true, LN256, false, 3>);
     }
   } else {
     kern = reinterpret_cast<const void*>(&conv_igemm_glds_kernel<MT, TOut, WAVES_M, WAVES_N, TM, TN, FAST, ROWB, STAGES, false, LN256>);
@@ -1182,8 +1225,10 @@ int launch_variant(const ConvArgs& a_in, int nbatch, hipStream_t stream) {
   int lds_bytes = LDS;
   if (a.prof != nullptr) {   // vt_conv_profile: only the plain 8-wave bf16 instantiation carries the stamps
     if constexpr (std::is_same<MT, bf16_t>::value && std::is_same<TOut, bf16_t>::value && WAVES_M == 4 && WAVES_N == 2 && FAST && LN256 == 0) {
-      VT_CHECK_ARG(buf && !s2, "vt_conv_profile: descriptor gather, K-step schedule 0 or 1 only");
-      kern = s1 ? reinterpret_cast<const void*>(&conv_igemm_glds_kernel<MT, TOut, WAVES_M, WAVES_N, TM, TN, FAST, ROWB, STAGES, true, 0, true, 1>)
+      VT_CHECK_ARG(buf, "vt_conv_profile: descriptor gather only");
+      kern = s3 ? reinterpret_cast<const void*>(&conv_igemm_glds_kernel<MT, TOut, WAVES_M, WAVES_N, TM, TN, FAST, ROWB, STAGES, true, 0, true, 3>)
+           : s2 ? reinterpret_cast<const void*>(&conv_igemm_glds_kernel<MT, TOut, WAVES_M, WAVES_N, TM, TN, FAST, ROWB, STAGES, true, 0, true, 2>)
+           : s1 ? reinterpret_cast<const void*>(&conv_igemm_glds_kernel<MT, TOut, WAVES_M, WAVES_N, TM, TN, FAST, ROWB, STAGES, true, 0, true, 1>)
                 : reinterpret_cast<const void*>(&conv_igemm_glds_kernel<MT, TOut, WAVES_M, WAVES_N, TM, TN, FAST, ROWB, STAGES, true, 0, true, 0>);
       lds_bytes = LDS + 4096;
       VT_CHECK_HIP(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
@@ -1192,8 +1237,8 @@ int launch_variant(const ConvArgs& a_in, int nbatch, hipStream_t stream) {
     }
   }
   // the attribute is per device: one flag per (instantiation, gather form, device), set race-free
-  static std::atomic<bool> attr_done[4][kMaxDevices];
-  const int ki = buf ? (s2 ? 3 : (s1 ? 2 : 1)) : 0;
+  static std::atomic<bool> attr_done[5][kMaxDevices];
+  const int ki = buf ? (s3 ? 4 : (s2 ? 3 : (s1 ? 2 : 1))) : 0;
   int dev = 0;
   VT_CHECK_HIP(hipGetDevice(&dev));
   if (dev < 0 || dev >= kMaxDevices || !attr_done[ki][dev].load(std::memory_order_acquire)) {

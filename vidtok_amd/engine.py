@@ -363,8 +363,13 @@ class AutoencodingEngineV11(AutoencodingEngine):
     def forward(self, x: Any) -> Tuple[torch.Tensor, torch.Tensor, dict]:
         z, reg_log = self.encode(x, return_reg_log=True)
         dec = self.decode(z)
-        if dec.shape[2] != x.shape[2]:
-            dec = dec[:, :, -x.shape[2]:, ...]
+        if dec.shape[2] != x.shape[2]:               # drop the frames that decode the encoder's front padding (:339-341)
+            n = x.shape[2]
+            if dec.is_cuda:                           # as a tensor of its own (one vt_ncthw_copy_frames), not a strided view
+                out = torch.empty(tuple(dec.shape[:2]) + (n,) + tuple(dec.shape[3:]), dtype=dec.dtype, device=dec.device)
+                dec = ops.ncthw_copy_frames(dec.contiguous(), out, dec.shape[2] - n, 0, n)
+            else:
+                dec = dec[:, :, -n:, ...]
         return z, dec, reg_log
 
     encode_decode = forward

@@ -292,20 +292,36 @@ def replay_layernorms(record):
                                      int(silu), _stream()), "vt_layernorm_act(replay)")
 
 
-def launch_class(d):
-    """(class name, algorithmic HBM bytes) of a recorded MFMA-kernel launch whose FLOP per byte sits below the chip's
-    ridge (2.5 PFLOP/s over 8 TB/s = 312): the launches bench.py prices against the HBM roofline.  None for the
-    matrix-bound ones.  Bytes: the input once, the weights once, the result(s) once, the residual once."""
+def launch_bytes(d):
+    """Algorithmic HBM bytes of one recorded MFMA-kernel launch: the input once, the weights once, the result(s) once,
+    the residual once (what a perfectly cached launch would move)."""
     if isinstance(d, L.TBlockDesc):
         es = 2
         px = d.B * d.T * d.HW
-        return "temporal block fused (C=128)", px * d.ld * es * (1 + (1 if d.keep_y else 0) + (1 if d.ln_next_mode else 0)) + 2 * d.C * 3 * d.C * es
+        return px * d.ld * es * (1 + (1 if d.keep_y else 0) + (1 if d.ln_next_mode else 0)) + 2 * d.C * 3 * d.C * es
     es = 4 if d.dtype == L.VT_F32 else 2
     eo = 4 if d.out_dtype == L.VT_F32 else 2
-    M = d.B * d.To * d.Ho * d.Wo * max(1, d.nbatch)
-    taps = d.KT * d.KH * d.KW
+    nb = max(1, d.nbatch)
+    M = d.B * d.To * d.Ho * d.Wo * nb
     plan = conv_plan(d)
-    if plan["kernel"] == "narrow":
+    nbytes = d.B * d.Ti * d.Hi * d.Wi * d.Cin * es * (nb if d.xs_z or nb == 1 else 1) + d.Cout * d.ldw * es * nb
+    if not (d.ln_mode != 0 and plan["ln_fused"] and not d.ln_keep_y):
+        nbytes += M * d.Cout * eo
+    if d.res_mode != L.VT_RES_NONE:
+        nbytes += M * d.Cout * eo
+    if d.ln_mode != 0 and plan["ln_fused"]:
+        nbytes += M * d.Cout * eo
+    return nbytes
+
+
+def launch_class(d):
+    """(class name, algorithmic HBM bytes) of a recorded MFMA-kernel launch whose FLOP per byte sits below the chip's
+    ridge (2.5 PFLOP/s over 8 TB/s = 312): the launches bench.py prices against the HBM roofline.  None for the
+    matrix-bound ones."""
+    if isinstance(d, L.TBlockDesc):
+        return "temporal block fused (C=128)", launch_bytes(d)
+    taps = d.KT * d.KH * d.KW
+    if conv_plan(d)["kernel"] == "narrow":
         name = "conv_out 3x3x3 128->3 (conv3d_narrow_kernel)"
     elif taps == 1 and d.nbatch <= 1:
         name = "1x1 convolutions (nin_shortcut, attention projections)"
@@ -315,14 +331,7 @@ def launch_class(d):
         name = f"temporal k3 convolutions, unfused (C={d.Cin})"
     else:
         return None
-    nbytes = d.B * d.Ti * d.Hi * d.Wi * d.Cin * es * max(1, d.nbatch) + d.Cout * d.ldw * es
-    if not (d.ln_mode != 0 and plan["ln_fused"] and not d.ln_keep_y):
-        nbytes += M * d.Cout * eo
-    if d.res_mode != L.VT_RES_NONE:
-        nbytes += M * d.Cout * eo
-    if d.ln_mode != 0 and plan["ln_fused"]:
-        nbytes += M * d.Cout * eo
-    return name, nbytes
+    return name, launch_bytes(d)
 
 
 GN_POS = 3   # host-level scope: statistics per position over the C/groups channels of a group (see groupnorm_act)
