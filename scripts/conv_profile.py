@@ -24,9 +24,9 @@ if SCHED == 0:
 elif SCHED == 1:
     NAMES = ["sub-steps 0-2: 24 MFMAs + 8 DMA pieces + set-up", "wait lgkm + my DMA (vmcnt)", "barrier", "sub-step 3: 8 MFMAs + next fragments"]
 else:
-    NAMES = ["LOAD(2s): 16 ds_read" + (" + 2 pieces" if SCHED == 2 else ""), "waits + barrier", "COMPUTE(2s): 16 MFMAs" + (" + 2 pieces" if SCHED == 3 else ""),
-             "barrier", "LOAD(2s+1): 8 ds_read + set-up + " + ("6" if SCHED == 2 else "2") + " pieces", "waits + barrier",
-             "COMPUTE(2s+1): 16 MFMAs" + (" + 4 pieces" if SCHED == 3 else "")]
+    NAMES = ["LOAD(2s): 16 ds_read" + (" + 2 pieces" if SCHED == 2 else ""), "waits + barrier", "COMPUTE(2s): 16 MFMAs" + (" + 2 pieces" if SCHED >= 3 else ""),
+             "barrier", "LOAD(2s+1): 8 ds_read + set-up + " + {2: "6", 3: "2", 4: "0"}[SCHED] + " pieces", "waits + barrier",
+             "COMPUTE(2s+1): 16 MFMAs" + {2: "", 3: " + 4 pieces", 4: " + 6 pieces"}[SCHED]]
 NS = len(NAMES)
 
 

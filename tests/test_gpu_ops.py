@@ -145,6 +145,8 @@ def test_conv_large(case, dtype):
 # runs with option conv_ws = 0 so the tile-per-workgroup kernel keeps its coverage of the same shapes.
 WS_CASES = [
     ("ws_single_tile", (1, 1, 8, 16), 128, 128, (3, 3), ConvGeom(**G3), {}),
+    ("ws_two_tiles_one_wg", (1, 1, 16, 16), 128, 128, (3, 3), ConvGeom(**G3), dict(res="add", ln="keep")),
+    ("ws_more_tiles_than_cus", (2, 5, 128, 128), 128, 128, (3, 3), ConvGeom(**G3), dict(res="add", ln="only")),
     ("ws_one_tile_column", (1, 2, 24, 16), 128, 128, (3, 3), ConvGeom(**G3), dict(res="add")),
     ("ws_one_tile_row", (1, 2, 8, 48), 128, 128, (3, 3), ConvGeom(**G3), dict(res="add", ln="keep")),
     ("ws_3x3_tiles_frames", (2, 3, 24, 48), 128, 128, (3, 3), ConvGeom(**G3), dict(ln="only")),
@@ -154,12 +156,12 @@ WS_CASES = [
 ]
 
 
-@pytest.mark.parametrize("ws", ["1", "0"], ids=["ws128", "igemm"])
+@pytest.mark.parametrize("ws", ["1", "2", "0"], ids=["ws128", "ws2", "igemm"])
 @pytest.mark.parametrize("case", WS_CASES, ids=[c[0] for c in WS_CASES])
 def test_conv_weight_stationary(case, ws, vt_opts):
     vt_opts(conv_ws=ws)
     plan = _check_conv(case, torch.bfloat16)
-    assert plan["kernel"] == ("ws128" if ws == "1" else "igemm")
+    assert plan["kernel"] == ("igemm" if ws == "0" else "ws128")
     if "ln" in case[6]:
         assert plan["ln_fused"]
 
@@ -259,15 +261,21 @@ def test_weight_stationary_kernels_are_split_independent():
     ln = (_rand((C_,), torch.float32, 5, 0.3) + 1.0, _rand((C_,), torch.float32, 6, 0.2), 1e-6, True)
     tup = lambda o: o if isinstance(o, tuple) else (o,)
     for kw in ({}, dict(res=res, res_mode=L.VT_RES_ADD), dict(res=res, res_mode=L.VT_RES_ADD, ln=ln), dict(ln=ln, ln_keep_y=False)):
-        a = tup(ops.conv(x, w, bias, ConvGeom(**G3), cout=C_, **kw))
-        b = tup(ops.conv(x, w, bias, ConvGeom(**G3), cout=C_, **kw))
-        kw1 = dict(kw, res=res[1:2].contiguous()) if "res" in kw else kw
-        one = tup(ops.conv(x[1:2].contiguous(), w, bias, ConvGeom(**G3), cout=C_, **kw1))
-        assert all(torch.equal(u, v) for u, v in zip(a, b)) and all(torch.equal(u[1:2], v) for u, v in zip(a, one)), kw.keys()
+        gens = {}
+        for gen in (1, 2):                               # both generations of the weight-stationary kernel
+            with L.options(conv_ws=gen):
+                a = tup(ops.conv(x, w, bias, ConvGeom(**G3), cout=C_, **kw))
+                b = tup(ops.conv(x, w, bias, ConvGeom(**G3), cout=C_, **kw))
+                kw1 = dict(kw, res=res[1:2].contiguous()) if "res" in kw else kw
+                one = tup(ops.conv(x[1:2].contiguous(), w, bias, ConvGeom(**G3), cout=C_, **kw1))
+            assert all(torch.equal(u, v) for u, v in zip(a, b)) and all(torch.equal(u[1:2], v) for u, v in zip(a, one)), (gen, kw.keys())
+            gens[gen] = a
+        # same fp32 chains and the same row arithmetic in both generations
+        assert all(torch.equal(u, v) for u, v in zip(gens[1], gens[2])), kw.keys()
         if "ln" not in kw:
             with L.options(conv_ws=0):
                 ig = tup(ops.conv(x, w, bias, ConvGeom(**G3), cout=C_, **kw))
-            assert torch.equal(a[0], ig[0])
+            assert torch.equal(gens[1][0], ig[0])
     ws = [pack_conv_weight(torch.randn((C_, C_, 3), generator=g) / math.sqrt(3 * C_), dt, cin_stored=C_).to(DEV) for _ in range(2)]
     bs = [_rand((C_,), torch.float32, 7 + i, 0.1) for i in range(2)]
     nm = (ln[0], ln[1])
@@ -306,14 +314,14 @@ def test_conv_pointer_gather(case, dtype, tile, vt_opts):
 
 
 # Every switch that selects between two implementations of one contract is exercised on both sides:
-# the K-step schedules of the 8-wave tile (conv_sched 0 plain / 1 schedule 1 / 2, 3 two-group ping-pong), the Cout = 256
+# the K-step schedules of the 8-wave tile (conv_sched 0 plain / 1 schedule 1 / 2, 3, 4 two-group ping-pong), the Cout = 256
 # LayerNorm epilogue (fused or conv + vt_layernorm_act; both of its forms), the 128 x 128 tile with and without the
 # LDS-transposed epilogue (without it LayerNorm cannot be fused either).
 SCHED_CASES = [c for c in BIG256 if c[0] in ("nin_1x1_128_256", "nin_1x1_64_256_one_kstep", "temporal_k3_512", "conv3d_333_256", "v11_cache_1d", "nc_conv1d_sym_512",
                                              "conv3d_333_tinner_256", "conv2d_ln256_only", "conv2d_ln256_res_keep", "temporal_ln256_only")]
 
 
-@pytest.mark.parametrize("sched", [0, 1, 2, 3])
+@pytest.mark.parametrize("sched", [0, 1, 2, 3, 4])
 @pytest.mark.parametrize("case", SCHED_CASES + CONV_CASES_LARGE, ids=[c[0] for c in SCHED_CASES + CONV_CASES_LARGE])
 def test_conv_8wave_schedules(case, sched, vt_opts):
     vt_opts(conv_sched=sched)

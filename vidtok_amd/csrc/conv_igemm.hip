@@ -619,7 +619,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_igemm_glds_ker
   // SCHED 2 stages the weight rows as two half-tiles (rows [0, 128) = the channel sub-tiles a = 0, 1 of both wave columns,
   // rows [128, 256) = a = 2, 3), each refilled as soon as its own last fragment read is over: LDS row
   // (a >> 1) * 128 + wn * 64 + (a & 1) * 32 + l holds channel wn * 128 + a * 32 + l of the tile
-  constexpr bool S2 = (SCHED == 2 || SCHED == 3) && (WAVES_M * WAVES_N == 8) && FAST && BUF;
+  constexpr bool S2 = (SCHED >= 2 && SCHED <= 4) && (WAVES_M * WAVES_N == 8) && FAST && BUF;
 #pragma unroll
   for (int j = 0; j < B_VECS; ++j) {
     const int lr = srow + RSTEP * j;
@@ -785,7 +785,10 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_igemm_glds_ker
     if (q < A_VECS) {
       if constexpr (BUF) {
         const __amdgpu_buffer_rsrc_t rsrc_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<MT*>(xg), 0, ext_x, 0x00020000);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (lds_ptr_t)(As + (RSTEP * q) * ROWB), 16, a_off[q], s_a, 0, 0);
+        // (x_nt: the activation rows stream through -- each is used by one tile and its halo neighbours -- while the weight slab
+        // of the channel tile is re-read by every pixel tile of the XCD: the hint asks the L2 to let go of x first)
+        if (p.x_nt) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (lds_ptr_t)(As + (RSTEP * q) * ROWB), 16, a_off[q], s_a, 0, 2);
+        else __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (lds_ptr_t)(As + (RSTEP * q) * ROWB), 16, a_off[q], s_a, 0, 0);
       } else {
         const MT* src = a_ptr[q] ? a_ptr[q] + coff : zero;
         __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)(As + (RSTEP * q) * ROWB), 16, 0, 0);
@@ -925,7 +928,17 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_igemm_glds_ker
     // youngest 4 (end of an odd load phase) / youngest 6 (end of an even one).  A half-tile is requested at the earliest
     // in the interval after both groups' last reads of its region are retired (same argument as schedule 2, one barrier
     // later for the pieces that moved into a compute phase).
-    constexpr bool PC = SCHED == 3;
+    // SCHED 4 = what the stamps of 2 and 3 ask for (profiles/r03_igemm_step_cycles_sched{2,3}.txt): a load phase issues its
+    // 16 ds_read_b128 in ~480 cycles and then sat 200-300 more at lgkmcnt(0) in front of the barrier while the partner's
+    // 16 MFMAs (~640 next to a loading wave) were long done -- every interval lasted ~830 cycles instead of 512.  Here the
+    // barrier comes FIRST and the wave waits for its fragments behind it, at the head of its compute phase (they have had
+    // the barrier's own latency to arrive).  The reads of a phase are then no longer retired when the next interval
+    // starts, so no piece may be requested in a load phase any more (schedule 2 / 3 refill a region in the interval right
+    // after its last read): ALL pieces ride in compute phases -- C(2s): W1(s+1) (2), C(2s+1): XX(s+2) W0(s+2) (6) --, one
+    // barrier further down than any wave's lgkmcnt(0) for the reads of that region.  Issue order ... C(2s+1):6 C(2s+2):2 ...
+    // => everything but the youngest 2 (end of an odd load phase) / youngest 6 (even) is what the next phase reads.
+    constexpr bool PC = SCHED >= 3;
+    constexpr bool LATE_WAIT = SCHED == 4;
     const int grp = __builtin_amdgcn_readfirstlane((int)(tid >> 8));     // 0: waves 0-3, 1: waves 4-7 (one barrier behind)
     const char* a_base = smem + (wm * TM * 32) * ROWB + frag_row;
     const char* b_base = smem + A_BYTES + (wn * 64) * ROWB + frag_row;
@@ -945,10 +958,14 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_igemm_glds_ker
         for (int k = 0; k < KS; ++k) wf[a2][k] = *reinterpret_cast<const u32x4*>(Bs + a2 * 32 * ROWB + (((k * 2 + khalf) ^ swz) * 16));
     };
     auto end_load = [&](auto odd_c) {   // my pieces for the next phase's reads have landed, my reads of this phase are retired
-      if constexpr (!PC) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+      if constexpr (LATE_WAIT) {
+        if constexpr (decltype(odd_c)::value) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      } else if constexpr (!PC) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
       else if constexpr (decltype(odd_c)::value) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
+      if constexpr (LATE_WAIT) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_sched_barrier(0);
     };
     // COMPUTE phase of channel half HF; with PC the pieces [Q0, Q1) of the prepared step go out behind every EVERY-th MFMA
@@ -1014,7 +1031,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_igemm_glds_ker
       if (s + 2 < p.nsteps) prep_step(s + 2);
       else ext_x = ext_w = 0u;                     // past the last step: the pieces below turn into zero fills
       // XX(s+2), W0(s+2) into the regions read for the last time in phase 2s
-      if constexpr (PC) {
+      if constexpr (LATE_WAIT) {
+      } else if constexpr (PC) {
         fire_piece(0, stg);
         fire_piece(1, stg);
       } else {
@@ -1024,7 +1042,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_igemm_glds_ker
       stamp(5);
       end_load(I1{});
       stamp(6);
-      if constexpr (PC) compute(I1{}, std::integral_constant<int, 2>{}, std::integral_constant<int, A_VECS + 2>{}, stg);
+      if constexpr (LATE_WAIT) compute(I1{}, I0{}, std::integral_constant<int, A_VECS + 2>{}, stg);
+      else if constexpr (PC) compute(I1{}, std::integral_constant<int, 2>{}, std::integral_constant<int, A_VECS + 2>{}, stg);
       else compute(I1{}, I0{}, I0{}, 0);
       stamp(7);
       if (!(grp == 1 && s + 1 == p.nsteps)) {      // waves 4-7 entered one barrier late: they leave without the last one
@@ -1205,12 +1224,14 @@ int launch_variant(const ConvArgs& a_in, int nbatch, hipStream_t stream) {
   constexpr bool HAS_S1 = WAVES_M * WAVES_N == 8 && FAST;
   constexpr bool HAS_S2 = HAS_S1 && std::is_same<MT, bf16_t>::value;    // schedule 2 (ping-pong): bf16 operands only
   const int sched_opt = vt_opt(OPT_CONV_SCHED);
+  const bool s4 = HAS_S2 && buf && sched_opt == 4;
   const bool s3 = HAS_S2 && buf && sched_opt == 3;
   const bool s2 = HAS_S2 && buf && sched_opt == 2;
-  const bool s1 = HAS_S1 && buf && sched_opt != 0 && !s2 && !s3;
+  const bool s1 = HAS_S1 && buf && sched_opt != 0 && !s2 && !s3 && !s4;
   if (buf) {
     a.x_bytes = (unsigned)xb;
     a.w_bytes = (unsigned)wb;
+    a.x_nt = vt_opt(OPT_CONV_X_NT) != 0 ? 1 : 0;
     kern = reinterpret_cast<const void*>(&conv_igemm_glds_kernel<MT, TOut, WAVES_M, WAVES_N, TM, TN, FAST, ROWB, STAGES, true, LN256>);
     if constexpr (HAS_S1) {
       if (s1) kern = reinterpret_cast<const void*>(&conv_igemm_glds_kernel<MT, TOut, WAVES_M, WAVES_N, TM, TN, FAST, ROWB, STAGES, true, LN256, false, 1>);
@@ -1218,6 +1239,7 @@ int launch_variant(const ConvArgs& a_in, int nbatch, hipStream_t stream) {
     if constexpr (HAS_S2) {
       if (s2) kern = reinterpret_cast<const void*>(&conv_igemm_glds_kernel<MT, TOut, WAVES_M, WAVES_N, TM, TN, FAST, ROWB, STAGES, true, LN256, false, 2>);
       if (s3) kern = reinterpret_cast<const void*>(&conv_igemm_glds_kernel<MT, TOut, WAVES_M, WAVES_N, TM, TN, FAST, ROWB, STAGES, true, LN256, false, 3>);
+      if (s4) kern = reinterpret_cast<const void*>(&conv_igemm_glds_kernel<MT, TOut, WAVES_M, WAVES_N, TM, TN, FAST, ROWB, STAGES, true, LN256, false, 4>);
     }
   } else {
     kern = reinterpret_cast<const void*>(&conv_igemm_glds_kernel<MT, TOut, WAVES_M, WAVES_N, TM, TN, FAST, ROWB, STAGES, false, LN256>);
@@ -1226,7 +1248,8 @@ int launch_variant(const ConvArgs& a_in, int nbatch, hipStream_t stream) {
   if (a.prof != nullptr) {   // vt_conv_profile: only the plain 8-wave bf16 instantiation carries the stamps
     if constexpr (std::is_same<MT, bf16_t>::value && std::is_same<TOut, bf16_t>::value && WAVES_M == 4 && WAVES_N == 2 && FAST && LN256 == 0) {
       VT_CHECK_ARG(buf, "vt_conv_profile: descriptor gather only");
-      kern = s3 ? reinterpret_cast<const void*>(&conv_igemm_glds_kernel<MT, TOut, WAVES_M, WAVES_N, TM, TN, FAST, ROWB, STAGES, true, 0, true, 3>)
+      kern = s4 ? reinterpret_cast<const void*>(&conv_igemm_glds_kernel<MT, TOut, WAVES_M, WAVES_N, TM, TN, FAST, ROWB, STAGES, true, 0, true, 4>)
+           : s3 ? reinterpret_cast<const void*>(&conv_igemm_glds_kernel<MT, TOut, WAVES_M, WAVES_N, TM, TN, FAST, ROWB, STAGES, true, 0, true, 3>)
            : s2 ? reinterpret_cast<const void*>(&conv_igemm_glds_kernel<MT, TOut, WAVES_M, WAVES_N, TM, TN, FAST, ROWB, STAGES, true, 0, true, 2>)
            : s1 ? reinterpret_cast<const void*>(&conv_igemm_glds_kernel<MT, TOut, WAVES_M, WAVES_N, TM, TN, FAST, ROWB, STAGES, true, 0, true, 1>)
                 : reinterpret_cast<const void*>(&conv_igemm_glds_kernel<MT, TOut, WAVES_M, WAVES_N, TM, TN, FAST, ROWB, STAGES, true, 0, true, 0>);
@@ -1237,8 +1260,8 @@ int launch_variant(const ConvArgs& a_in, int nbatch, hipStream_t stream) {
     }
   }
   // the attribute is per device: one flag per (instantiation, gather form, device), set race-free
-  static std::atomic<bool> attr_done[5][kMaxDevices];
-  const int ki = buf ? (s3 ? 4 : (s2 ? 3 : (s1 ? 2 : 1))) : 0;
+  static std::atomic<bool> attr_done[6][kMaxDevices];
+  const int ki = buf ? (s4 ? 5 : (s3 ? 4 : (s2 ? 3 : (s1 ? 2 : 1)))) : 0;
   int dev = 0;
   VT_CHECK_HIP(hipGetDevice(&dev));
   if (dev < 0 || dev >= kMaxDevices || !attr_done[ki][dev].load(std::memory_order_acquire)) {
@@ -1330,6 +1353,7 @@ int dispatch_tile(const ConvArgs& a, int nbatch, hipStream_t stream) {
 }  // namespace
 
 extern "C" int vt_ws128_launch(const void* conv_args, void* stream);   // conv_ws128.hip
+extern "C" int vt_ws2_launch(const void* conv_args, void* stream);     // conv_ws2.hip (option conv_ws = 2)
 extern "C" int vt_conv_narrow_launch(const void* conv_args, void* stream);   // conv_narrow.hip
 extern "C" void vt_conv_narrow_plan(const void* conv_args, int32_t* plan4);
 
@@ -1497,7 +1521,7 @@ extern "C" int vt_conv(const vt_conv_desc* d, vt_stream stream_) {
   int nbatch = 1;
   int rc = conv_prepare(d, a, ln_fused, nbatch, use_ws);
   if (rc != VT_OK) return rc;
-  if (use_ws) return vt_ws128_launch(&a, stream_);
+  if (use_ws) return vt_opt(OPT_CONV_WS) == 2 ? vt_ws2_launch(&a, stream_) : vt_ws128_launch(&a, stream_);
   if (narrow_eligible(a, nbatch, d->dtype, d->out_dtype, d->ln_mode)) return vt_conv_narrow_launch(&a, stream_);
   const long long M = a.M;
   if (d->dtype == VT_F32) rc = dispatch_tile<float, float>(a, nbatch, stream);
