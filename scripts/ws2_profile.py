@@ -1,0 +1,47 @@
+"""Where does an iteration of conv3x3_ws2_kernel spend its cycles?  Replays a benchmark-sized 3x3 128->128 convolution
+(B=4, 20 frames, 256x256, + residual + LayerNorm+SiLU) through vt_conv_profile with option conv_ws = 2 and prints, per wave
+of workgroup 0, the shader-clock ticks between the phase boundaries of iterations 8 and 9 (waves 0-3 = group 0: MFMA
+phase then row slot; waves 4-7 = group 1: row slot + DMA requests then MFMA phase).  An iteration = one 4 x 16-pixel tile."""
+import ctypes as C
+import math
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from vidtok_amd import lib as L  # noqa: E402
+from vidtok_amd import ops  # noqa: E402
+from vidtok_amd.ops import ConvGeom  # noqa: E402
+
+
+def main():
+    dev = "cuda:0"
+    L.set_option("conv_ws", 2)
+    B, T, H, W, C_ = 4, 20, 256, 256, 128
+    torch.manual_seed(0)
+    x = torch.randn((B, T, H, W, C_), device=dev, dtype=torch.bfloat16)
+    res = torch.randn((B, T, H, W, C_), device=dev, dtype=torch.bfloat16)
+    w = (torch.randn((C_, 9 * C_), device=dev) / math.sqrt(9 * C_)).to(torch.bfloat16)
+    bias = torch.randn((C_,), device=dev)
+    ln = (torch.ones(C_, device=dev), torch.zeros(C_, device=dev), 1e-6, True)
+    for label, kw in (("plain", {}), ("+ residual + LayerNorm+SiLU, y kept", dict(res=res, res_mode=L.VT_RES_ADD, ln=ln, ln_keep_y=True))):
+        ops.CONV_RECORD = []
+        ops.conv(x, w, bias, ConvGeom(kh=3, kw=3, ph=1, pw=1, ph_hi=1, pw_hi=1), cout=C_, **kw)
+        rec, ops.CONV_RECORD = ops.CONV_RECORD, None
+        d = rec[0][0]
+        stamps = torch.zeros((8, 16), dtype=torch.int64, device=dev)
+        for _ in range(2):
+            L.check(L.load().vt_conv_profile(C.byref(d), stamps.data_ptr(), None), "vt_conv_profile")
+        torch.cuda.synchronize()
+        s = stamps.cpu()
+        print(f"3x3 128->128 @256^2 {label}: MFMA-bound time of an iteration = 144 MFMAs x 32 = 4 608 cycles per SIMD")
+        for wv in range(8):
+            for it in range(2):
+                d5 = [int(s[wv, 5 * it + k + 1] - s[wv, 5 * it + k]) for k in range(4)]
+                names = ["M0: 72 MFMAs", "barrier", "rows [32,64)", "barrier"] if wv < 4 else ["DMA requests + rows [0,32)", "barrier", "M1: 72 MFMAs + wait", "barrier"]
+                print(f"  wave {wv} iteration {8 + it}: total {sum(d5):6d} | " + " | ".join(f"{n} {v}" for n, v in zip(names, d5)))
+
+
+if __name__ == "__main__":
+    main()

@@ -1508,7 +1508,8 @@ extern "C" int vt_conv_profile(const vt_conv_desc* d, uint64_t* stamps_out, vt_s
   const int rc = conv_prepare(d, a, ln_fused, nbatch, use_ws);
   if (rc != VT_OK) return rc;
   a.prof = reinterpret_cast<unsigned long long*>(stamps_out);
-  if (use_ws) return vt_ws128_launch(&a, stream_);     // stamps [wave][16] of workgroup 0's fourth tile
+  if (use_ws)                                          // stamps [wave][16]: conv_ws128.hip workgroup 0's fourth tile (4 waves), conv_ws2.hip iterations 8, 9 (8 waves)
+    return vt_opt(OPT_CONV_WS) == 2 ? vt_ws2_launch(&a, stream_) : vt_ws128_launch(&a, stream_);
   VT_CHECK_ARG(d->dtype == VT_BF16 && d->out_dtype == VT_BF16 && d->ln_mode == 0 && select_tile(a, nbatch) == TILE_256x256,
                "vt_conv_profile: bf16 launches on the 256 x 256 tile without LayerNorm, or on the weight-stationary kernel");
   return dispatch_tile<bf16_t, bf16_t>(a, nbatch, reinterpret_cast<hipStream_t>(stream_));

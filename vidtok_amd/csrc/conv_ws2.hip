@@ -9,24 +9,32 @@
 // 22 500 when it also emits a LayerNorm.
 //
 // Here a SIMD runs TWO waves that split K: wave (w, kh) keeps output channels [32w, 32w+32) x K-half kh (36 MFMA
-// A-fragments = 144 registers, 128 of them in the accumulator half of the file), w = wave % 4, kh = wave / 4.  A tile is processed
-// as two half-tiles ("units") of 64 pixels; per unit
+// A-fragments = 144 registers, 128 of them in the accumulator half of the file), w = wave % 4, kh = wave / 4.  Tiles are
+// 4 x 16 pixels (64); per tile u
 //     M0(u): group 0 (kh = 0): 72 MFMAs over K-half 0 from zero                  -> partial sums P(u)      (LDS, fp32)
 //     M1(u): group 1 (kh = 1): accumulators <- P(u), 72 MFMAs over K-half 1     -> T(u), in place over P(u)
-//     R(u):  rows of T(u) (+ bias, added by M1) + residual -> y, LayerNorm(+SiLU) -> n; rows [0,32) by group 1, [32,64) by group 0
+//     R(u):  rows of T(u) + bias + residual -> y, LayerNorm(+SiLU) -> n; rows [0,32) by group 1, rows [32,64) by group 0
 // and the two groups alternate, one barrier per half-step, so that a SIMD always has one wave in an MFMA phase and one in
-// a row phase (plain-fp32 VALU work of a wave overlaps the other wave's MFMAs):
-//     iteration u, first half:    group 0: M0(u)                 |  group 1: R(u-1) rows [0,32)  (+ patch DMA pieces)
-//     iteration u, second half:   group 1: M1(u)                 |  group 0: R(u-1) rows [32,64) (+ patch DMA pieces)
+// a row slot (plain-fp32 VALU work of a wave overlaps the other wave's MFMAs):
+//     iteration u, first half:    group 0: M0(u)                 |  group 1: R(u-1) rows [0,32), DMA requests
+//     iteration u, second half:   group 1: M1(u)                 |  group 0: R(u-1) rows [32,64)
 // The fp32 sum of an output element is the same chain as in the first generation (K groups 0..35 from zero, then 36..71
-// on top), so the result without LayerNorm is bit-identical to conv_ws128.hip and to the tile-per-workgroup kernel.
+// on top) and the row arithmetic is the same, so results are bit-identical to conv_ws128.hip (and, without LayerNorm,
+// to the tile-per-workgroup kernel).
 //
-// LDS: two halo patches (2 x 49 152 B, rows padded to 272 B, see conv_ws128.hip) + two P/T buffers of 64 rows x 512 B
-// = 163 840 B, all of the CU.  Buffers are handed over by barriers only; every LDS write is retired (lgkmcnt(0)) before
-// the barrier that publishes it.  Global loads (residual rows) are requested at the START of a wave's MFMA phase for the
-// row phase that follows it; each MFMA phase ends with vmcnt(0) -- by then the stores and DMA pieces of the wave's
-// previous row phase have had ~2 500 cycles -- so loads and stores of a wave are never in flight together and nothing
-// depends on their relative order.
+// Memory side.  Loads and stores of a wave retire through ONE in-order counter, and under this kernel's write traffic a
+// store needs ~5 000 cycles to retire -- nearly two MFMA phases.  A wave that waits for a load it issued behind a store
+// therefore stalls for thousands of cycles (first version of this file: rows requested at the head of an MFMA phase,
+// vmcnt(0) at its end -- no faster than the first generation), and registers with a load in flight across a phase get
+// copied by the allocator at block ends before the load has landed (second version).  So NOTHING is loaded into
+// registers here: the halo patch of the next tile AND the residual rows of the current one come in by LDS-DMA
+// (buffer_load ... lds), requested by the waves of group 1 at the head of their row slot, in front of that slot's
+// stores, and awaited by a COUNTED wait at the end of their following MFMA phase that leaves exactly those stores
+// outstanding; the barrier behind it publishes both buffers for the next iteration.  Group 0 only stores.
+//
+// LDS: two halo patches (6 x 18 pixel rows padded to 272 B: 2 x 29 696) + two P/T buffers (64 rows x 512 B) + two residual
+// tiles (64 rows x 272 B) = 159 744 B.  Buffers are handed over by barriers only; every LDS write is retired
+// (lgkmcnt(0)) before the barrier that publishes it.  The LayerNorm affine and the bias sit in the pad bytes of patch 0.
 #include <atomic>
 #include <type_traits>
 
@@ -34,15 +42,19 @@
 
 namespace {
 
-[[maybe_unused]] constexpr int W2_TH = 8, W2_TW = 16;
+[[maybe_unused]] constexpr int W2_TH = 4, W2_TW = 16;
 [[maybe_unused]] constexpr int W2_PH = W2_TH + 2, W2_PW = W2_TW + 2;
-[[maybe_unused]] constexpr int W2_NPIX = W2_PH * W2_PW;                // 180 pixel rows
-[[maybe_unused]] constexpr int W2_ROWP = 272;                          // bytes per patch pixel row: 256 + 16 pad
-[[maybe_unused]] constexpr int W2_PIECES = 48;                         // 1-KiB DMA pieces per patch
-[[maybe_unused]] constexpr int W2_PATCH = W2_PIECES * 1024;            // 49 152
+[[maybe_unused]] constexpr int W2_NPIX = W2_PH * W2_PW;                // 108 pixel rows
+[[maybe_unused]] constexpr int W2_ROWP = 272;                          // bytes per patch / residual pixel row: 256 + 16 pad
+[[maybe_unused]] constexpr int W2_PPIECES = 29;                        // 1-KiB DMA pieces per patch (108 * 272 = 29 376 B)
+[[maybe_unused]] constexpr int W2_PATCH = W2_PPIECES * 1024;           // 29 696
 [[maybe_unused]] constexpr int W2_TBUF = 64 * 128 * 4;                 // one P / T buffer: 64 rows x 128 fp32
-[[maybe_unused]] constexpr int W2_LDS = 2 * W2_PATCH + 2 * W2_TBUF;    // 163 840
-[[maybe_unused]] constexpr int W2_QPW = W2_PIECES / 8;                 // DMA pieces per wave and patch
+[[maybe_unused]] constexpr int W2_RPIECES = 17;                        // 1-KiB DMA pieces per residual tile (64 * 272 = 17 408 B)
+[[maybe_unused]] constexpr int W2_RBUF = W2_RPIECES * 1024;            // 17 408
+[[maybe_unused]] constexpr int W2_OFF_T = 2 * W2_PATCH;
+[[maybe_unused]] constexpr int W2_OFF_R = W2_OFF_T + 2 * W2_TBUF;
+[[maybe_unused]] constexpr int W2_LDS = W2_OFF_R + 2 * W2_RBUF;        // 159 744
+[[maybe_unused]] constexpr int W2_DMA_PER_WAVE = 12;                   // 46 pieces per tile over the four waves of group 1
 
 template <int I, int N, typename F>
 __device__ __forceinline__ void w2_static_for(F&& f) {
@@ -69,7 +81,7 @@ __device__ __forceinline__ void w2_mfma(const u32x4& w, const u32x4& x, f32x16& 
   }
 }
 
-template <int LN, bool KEEP>
+template <int LN, bool KEEP, bool PROF = false>
 __global__ __launch_bounds__(512, 1) void conv3x3_ws2_kernel(const ConvArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -89,14 +101,15 @@ __global__ __launch_bounds__(512, 1) void conv3x3_ws2_kernel(const ConvArgs p) {
   const int t_begin = slot * tq + min(slot, tr);
   const int t_end = t_begin + tq + (slot < tr ? 1 : 0);
   if (t_begin >= t_end) return;
-  const int U = 2 * (t_end - t_begin);                                 // units (half-tiles) of this workgroup
+  const int U = t_end - t_begin;                                       // tiles of this workgroup
 
   const bf16_t* __restrict__ xg = reinterpret_cast<const bf16_t*>(p.x);
   bf16_t* __restrict__ yg = reinterpret_cast<bf16_t*>(p.y);
   const bf16_t* __restrict__ rg = reinterpret_cast<const bf16_t*>(p.res);
   bf16_t* __restrict__ ng = reinterpret_cast<bf16_t*>(p.ln_out);
   constexpr unsigned kOob = 0xFFFF0000u;
-  float* Tb = reinterpret_cast<float*>(smem + 2 * W2_PATCH);           // [2][64][128]
+  float* Tb = reinterpret_cast<float*>(smem + W2_OFF_T);               // [2][64][128]
+  const bool has_res = p.res_mode == VT_RES_ADD;                        // uniform
 
   // ---- stationary weights: K groups [36 grp, 36 grp + 36) of the 72 (group g = tap * 8 + 16-channel chunk) -------------
   u32x4 wreg[36];
@@ -105,9 +118,18 @@ __global__ __launch_bounds__(512, 1) void conv3x3_ws2_kernel(const ConvArgs p) {
 #pragma unroll
     for (int c = 0; c < 36; ++c) wreg[c] = *reinterpret_cast<const u32x4*>(row + c * 16);
   }
+  // ---- LayerNorm affine and bias of the 128 channels, parked in the LDS: the 16 pad bytes behind patch pixel rows 0 .. 95 of
+  // patch buffer 0 (value i at row i / 4, float i % 4: gamma 0..127, beta 128..255, bias 256..383).  The patch DMA never
+  // writes pad bytes (its lanes there are switched off), so a row slot reads its 24 values with six ds_read_b128 instead
+  // of keeping 24 registers through the MFMA phases.
+  if (tid < 384) {
+    float v = 0.0f;
+    if (tid < 128) v = LN != 0 ? p.ln_gamma[tid] : 1.0f;
+    else if (tid < 256) v = LN != 0 ? p.ln_beta[tid - 128] : 0.0f;
+    else v = p.bias ? p.bias[tid - 256] : 0.0f;
+    *reinterpret_cast<float*>(smem + (tid >> 2) * W2_ROWP + 256 + (tid & 3) * 4) = v;
+  }
 
-  // ---- patch DMA (geometry as in conv_ws128.hip; 6 pieces per wave) -------------------------------------------------------
-  const unsigned frame_bytes = (unsigned)H * (unsigned)W * 256u;
   auto tile_coords = [&](int tile, int& f, int& h0, int& w0) {
     f = tile / tiles_pf;
     const int r = tile - f * tiles_pf;
@@ -115,87 +137,115 @@ __global__ __launch_bounds__(512, 1) void conv3x3_ws2_kernel(const ConvArgs p) {
     h0 = th * W2_TH;
     w0 = (r - th * tiles_w) * W2_TW;
   };
-  auto issue_patch = [&](int tile, int bufoff) {
+  // ---- LDS-DMA of a tile's operands: pieces 0 .. 28 = the 6 x 18 halo patch of x (descriptor rebased to the tile's frame:
+  // rows above / below the image are out of range by themselves, the left / right halo columns of border tiles are
+  // tested), pieces 29 .. 45 = the 4 x 16 residual rows.  A piece is 1 KiB of the 272-B-row image; the lanes that fall
+  // on pad bytes are switched off.  Wave `w4` (0..3) sends pieces [12 w4, 12 w4 + 12) of the 46.
+  const unsigned frame_bytes = (unsigned)H * (unsigned)W * 256u;
+  auto issue_dma = [&](int w4, int ptile, int pbuf, int rtile, int rbuf, bool want_patch, bool want_res) {
     int f, h0, w0;
-    tile_coords(tile, f, h0, w0);
-    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(xg) + (long long)f * H * W * 128, 0, frame_bytes, 0x00020000);
-    char* dst = smem + bufoff + wave * (W2_QPW * 1024);
+    tile_coords(ptile, f, h0, w0);
+    const __amdgpu_buffer_rsrc_t prsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(xg) + (long long)f * H * W * 128, 0, frame_bytes, 0x00020000);
     const unsigned tmask = (w0 == 0 ? 1u : 0u) | (w0 + W2_TW == W ? 2u : 0u);
-    const int toff = (h0 * W + w0) * 256;
-    w2_static_for<0, W2_QPW>([&](auto qc) {
+    const int ptoff = (h0 * W + w0) * 256;
+    int rf, rh0, rw0;
+    tile_coords(rtile, rf, rh0, rw0);
+    const __amdgpu_buffer_rsrc_t rrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(rg) + (long long)rf * H * W * 128, 0, frame_bytes, 0x00020000);
+    const int rtoff = (rh0 * W + rw0) * 256;
+    int lo = lane;
+    asm volatile("" : "+v"(lo));
+    w2_static_for<0, W2_DMA_PER_WAVE>([&](auto qc) {
       constexpr int q = decltype(qc)::value;
-      const int b = (wave * W2_QPW + q) * 1024 + lane * 16;
-      const int pp = b / W2_ROWP;
-      const int unit = (b - pp * W2_ROWP) >> 4;
-      const int pr = pp / W2_PW, pc = pp - pr * W2_PW;
-      const bool ok = (pp < W2_NPIX) & (unit < 16) & !((pc == 0) & ((tmask & 1u) != 0)) & !((pc == W2_PW - 1) & ((tmask & 2u) != 0));
-      const unsigned off = ok ? (unsigned)(((pr - 1) * W + (pc - 1)) * 256 + unit * 16 + toff) : kOob;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)(dst + q * 1024), 16, off, 0, 0, 0);
+      const int piece = w4 * W2_DMA_PER_WAVE + q;              // uniform
+      if (piece < W2_PPIECES) {
+        if (want_patch) {
+          const int b = piece * 1024 + lo * 16;
+          const int pp = b / W2_ROWP;
+          const int unit = (b - pp * W2_ROWP) >> 4;
+          const int pr = pp / W2_PW, pc = pp - pr * W2_PW;
+          const bool ok = (pp < W2_NPIX) & !((pc == 0) & ((tmask & 1u) != 0)) & !((pc == W2_PW - 1) & ((tmask & 2u) != 0));
+          const unsigned off = ok ? (unsigned)(((pr - 1) * W + (pc - 1)) * 256 + unit * 16 + ptoff) : kOob;
+          if (unit < 16) __builtin_amdgcn_raw_ptr_buffer_load_lds(prsrc, (lds_ptr_t)(smem + pbuf * W2_PATCH + piece * 1024), 16, off, 0, 0, 0);
+        }
+      } else if (piece < W2_PPIECES + W2_RPIECES) {
+        if (want_res) {
+          const int b = (piece - W2_PPIECES) * 1024 + lo * 16;
+          const int rr = b / W2_ROWP;                          // residual row 16 r + c of the tile
+          const int unit = (b - rr * W2_ROWP) >> 4;
+          const unsigned off = (unsigned)(((rr >> 4) * W + (rr & 15)) * 256 + unit * 16 + rtoff);
+          if (unit < 16) __builtin_amdgcn_raw_ptr_buffer_load_lds(rrsrc, (lds_ptr_t)(smem + W2_OFF_R + rbuf * W2_RBUF + (piece - W2_PPIECES) * 1024), 16, off, 0, 0, 0);
+        }
+      }
     });
   };
 
-  // ---- per-lane constants (lane -> pixel map of a sub-tile: conv_ws128.hip, conflict-free ds_read_b128 groups) ----------
+  // ---- lane -> pixel map of a sub-tile (conv_ws128.hip: conflict-free ds_read_b128 groups) -------------------------------------
   auto subtile_pixel = [](int m, int& rsel, int& col) {
     const bool g0 = (m < 4) | ((m >= 12) & (m < 16)) | ((m >= 20) & (m < 28));
     rsel = g0 ? 0 : 1;
     col = g0 ? (m < 4 ? m : (m < 16 ? m - 8 : m - 12)) : (m < 12 ? m - 4 : (m < 20 ? m - 8 : m - 16));
   };
-  int f_rsel, f_col;
-  subtile_pixel(lane & 31, f_rsel, f_col);
-  const int frag_off = (f_rsel * W2_PW + f_col) * W2_ROWP + (lane >> 5) * 16;
-  // row phase: a group's 256 threads handle 32 T rows of a unit in two iterations; lane slot: row row_l + 16 it, channels [8 oct_j, +8)
-  const int tg = tid & 255;
-  const int oct_j = tg & 15, row_l = tg >> 4;
-  int tp_r[2], tp_c[2];
-  subtile_pixel(row_l, tp_r[0], tp_c[0]);
-  subtile_pixel(row_l + 16, tp_r[1], tp_c[1]);
-
-  const bool has_res = p.res_mode == VT_RES_ADD;   // uniform
-
-  // unit v = (local tile v >> 1, half v & 1); T row r = 32 jj + m of the unit = pixel (2 (2 half + jj) + rsel(m), col(m)) of the tile
-  auto unit_pix0 = [&](int v) -> long long {       // element-row index of the tile origin of unit v
-    int f, h0, w0;
-    tile_coords(t_begin + (v >> 1), f, h0, w0);
-    return ((long long)f * H + h0) * W + w0;
-  };
-  auto row_pixel = [&](int v, int jj, int it) -> long long {
-    return unit_pix0(v) + (long long)(2 * (2 * (v & 1) + jj) + tp_r[it]) * W + tp_c[it];
-  };
-  // residual rows of the row slot (unit v, sub-tile jj): requested at the start of the MFMA phase in front of it
-  Oct<bf16_t> rq[2];
-  rq[0].w[0] = rq[0].w[1] = rq[0].w[2] = rq[0].w[3] = 0u;
-  rq[1].w = rq[0].w;
-  auto prefetch_rows = [&](int v, int jj) {
-    if (has_res) {
-#pragma unroll
-      for (int it = 0; it < 2; ++it) rq[it].load(rg + row_pixel(v, jj, it) * p.ldr + 8 * oct_j);
+  // PROF (vt_conv_profile): shader-clock stamps of workgroup 0's iterations 8 and 9, straight to memory
+  int prof_u = -1;
+  auto stamp = [&](int k) {
+    if constexpr (PROF) {
+      if (prof_u >= 0) {
+        const unsigned long long ts = __builtin_amdgcn_s_memtime();
+        if (lane == 0) p.prof[wave * 16 + 5 * prof_u + k] = ts;
+      }
     }
   };
-  // row slot: T rows [32 jj, 32 jj + 32) of unit v (bias already in): + residual -> y, LayerNorm(+SiLU) -> n.  Row arithmetic
-  // in explicit-rounding intrinsics, the operation order of conv_ws128.hip
+
+  // ---- row slot: T rows [32 jj, 32 jj + 32) of tile v: + bias + residual -> y, LayerNorm(+SiLU) -> n.  A group's 256 threads:
+  // lane slot = row row_l + 16 it of sub-tile jj, channels [8 oct_j, +8).  Per-lane geometry is recomputed from an opaque
+  // lane id in every slot instead of living in registers across the MFMA phases (144 weight registers per wave: anything
+  // resident pushed the allocator into scratch, and a scratch reload waits -- vmcnt(0) -- behind the slot's own stores).
+  // Row arithmetic in explicit-rounding intrinsics, the operation order of conv_ws128.hip (bias joined the tile before the
+  // transposition there); every intermediate is pinned so the vectoriser cannot pair the elements -- packed fp32 does not
+  // run beside the other wave's MFMAs (scripts/mfma_issue_bench.hip).
+  auto pinf = [](float& v) { asm volatile("" : "+v"(v)); };
   auto row_slot = [&](int v, int jj) {
-    const float* T = Tb + (v & 1) * (64 * 128);
-    // LayerNorm affine of this lane's 8 channels: fetched per slot (L1-resident, 64 B per lane) rather than kept -- 16
-    // registers less through the MFMA phases, which otherwise spill (144 stationary weight registers per wave)
+    int tt = tid;
+    asm volatile("" : "+v"(tt));
+    const int tg = tt & 255;
+    const int oct_j = tg & 15, row_l = tg >> 4;
+    int f, h0, w0;
+    tile_coords(t_begin + v, f, h0, w0);
+    const long long pix0 = ((long long)f * H + h0) * W + w0;
+    const char* pads = smem + 2 * oct_j * W2_ROWP + 256;       // gamma of channels [8 oct_j, +4), next row: +4 ..; beta + 32 rows, bias + 64 rows
     f32x4 g0, g1, b0, b1;
     if constexpr (LN != 0) {
-      g0 = *reinterpret_cast<const f32x4*>(p.ln_gamma + 8 * oct_j);
-      g1 = *reinterpret_cast<const f32x4*>(p.ln_gamma + 8 * oct_j + 4);
-      b0 = *reinterpret_cast<const f32x4*>(p.ln_beta + 8 * oct_j);
-      b1 = *reinterpret_cast<const f32x4*>(p.ln_beta + 8 * oct_j + 4);
+      g0 = *reinterpret_cast<const f32x4*>(pads);
+      g1 = *reinterpret_cast<const f32x4*>(pads + W2_ROWP);
+      b0 = *reinterpret_cast<const f32x4*>(pads + 32 * W2_ROWP);
+      b1 = *reinterpret_cast<const f32x4*>(pads + 33 * W2_ROWP);
     }
+    const f32x4 o0 = *reinterpret_cast<const f32x4*>(pads + 64 * W2_ROWP);
+    const f32x4 o1 = *reinterpret_cast<const f32x4*>(pads + 65 * W2_ROWP);
+    const float* T = Tb + (v & 1) * (64 * 128);
+    const char* R = smem + W2_OFF_R + (v & 1) * W2_RBUF;
 #pragma unroll
     for (int it = 0; it < 2; ++it) {
-      const int row = 32 * jj + row_l + 16 * it;
+      int rsel, col;
+      subtile_pixel(row_l + 16 * it, rsel, col);
+      const int prow = 2 * jj + rsel;                          // pixel (prow, col) of the 4 x 16 tile
+      const int row = 32 * jj + row_l + 16 * it;               // its T row (MFMA order)
       const int sw = row & 31;
       const f32x4 t0 = *reinterpret_cast<const f32x4*>(T + row * 128 + (((2 * oct_j) ^ sw) << 2));
       const f32x4 t1 = *reinterpret_cast<const f32x4*>(T + row * 128 + (((2 * oct_j + 1) ^ sw) << 2));
-      const long long pix = row_pixel(v, jj, it);
+      u32x4 rw;
+      if (has_res) rw = *reinterpret_cast<const u32x4*>(R + (16 * prow + col) * W2_ROWP + oct_j * 16);
+      else rw[0] = rw[1] = rw[2] = rw[3] = 0u;
+      const long long pix = pix0 + (long long)prow * W + col;
       float rv[8], s = 0.f;
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        rv[e] = __fadd_rn(rq[it].get(e), e < 4 ? t0[e] : t1[e - 4]);
+        const uint32_t w2 = rw[e >> 1];
+        const float r = __uint_as_float((e & 1) ? (w2 & 0xffff0000u) : (w2 << 16));
+        rv[e] = __fadd_rn(r, __fadd_rn(e < 4 ? t0[e] : t1[e - 4], e < 4 ? o0[e] : o1[e - 4]));
+        pinf(rv[e]);
         s = __fadd_rn(s, rv[e]);
+        pinf(s);
       }
       if constexpr (KEEP) {
         u32x4 w4;
@@ -209,14 +259,18 @@ __global__ __launch_bounds__(512, 1) void conv3x3_ws2_kernel(const ConvArgs p) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           rv[e] = __fsub_rn(rv[e], mean);
+          pinf(rv[e]);
           q = __fmaf_rn(rv[e], rv[e], q);
+          pinf(q);
         }
         const float rstd = __builtin_amdgcn_rsqf(__fmaf_rn(group_sum_dpp<16>(q), 1.0f / 128.0f, p.ln_eps));
         u32x4 w4;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-          const float a = __fmaf_rn(__fmul_rn(rv[e], rstd), e < 4 ? g0[e] : g1[e - 4], e < 4 ? b0[e] : b1[e - 4]);
+          float a = __fmaf_rn(__fmul_rn(rv[e], rstd), e < 4 ? g0[e] : g1[e - 4], e < 4 ? b0[e] : b1[e - 4]);
+          pinf(a);
           rv[e] = (LN == 2) ? silu_fast(a) : a;
+          pinf(rv[e]);
         }
 #pragma unroll
         for (int e = 0; e < 4; ++e) w4[e] = f32_to_bf16_bits(rv[2 * e]) | (f32_to_bf16_bits(rv[2 * e + 1]) << 16);
@@ -225,12 +279,9 @@ __global__ __launch_bounds__(512, 1) void conv3x3_ws2_kernel(const ConvArgs p) {
     }
   };
 
-  // ---- MFMA phase of unit u for K-half KH: 36 groups x 2 sub-tiles, fragments three MFMAs ahead ------------------------
+  // ---- MFMA phase of tile u for K-half KH: 36 groups x 2 sub-tiles, fragments three MFMAs ahead ------------------------
   f32x16 acc[2];
-  const int hq = lane >> 5;
-  // this lane's quad of (sub-tile jj, channel quad g) in the P / T buffer.  Recomputed from the lane id at every use (made
-  // opaque so the eight offsets are not hoisted out of the unit loop): kept resident they were the registers the allocator
-  // spilled, and a scratch reload waits behind vmcnt(0) -- i.e. behind the residual rows just requested
+  // this lane's quad of (sub-tile jj, channel quad g) in the P / T buffer, recomputed at every use (see row_slot)
   auto t_slot = [&](int u, int jj, int g) -> float* {
     int l = lane;
     asm volatile("" : "+v"(l));
@@ -238,9 +289,8 @@ __global__ __launch_bounds__(512, 1) void conv3x3_ws2_kernel(const ConvArgs p) {
     const int c4 = cw * 8 + 2 * g + (l >> 5);                  // 16-B chunk of channels [32 cw + 8 g + 4 (lane / 32), +4)
     return Tb + (u & 1) * (64 * 128) + prow * 128 + ((c4 ^ (l & 31)) << 2);
   };
-  auto mfma_phase = [&](auto kh_c, int u, int bufoff) {
+  auto mfma_phase = [&](auto kh_c, int u) {
     constexpr int KH = decltype(kh_c)::value;
-    f32x4 bq[4];                                               // K-half 1 adds the bias before it parks the finished sums
     if constexpr (KH == 1) {                                   // continue the sum of K-half 0
 #pragma unroll
       for (int jj = 0; jj < 2; ++jj)
@@ -251,7 +301,11 @@ __global__ __launch_bounds__(512, 1) void conv3x3_ws2_kernel(const ConvArgs p) {
           for (int e = 0; e < 4; ++e) acc[jj][4 * g + e] = v[e];
         }
     }
-    const char* pb = smem + bufoff + frag_off + (4 * (u & 1)) * W2_PW * W2_ROWP;   // sub-tile 2 half + jj starts at patch row 4 half + 2 jj
+    int f_rsel, f_col, lo = lane;
+    asm volatile("" : "+v"(lo));
+    subtile_pixel(lo & 31, f_rsel, f_col);
+    const int frag_off = (f_rsel * W2_PW + f_col) * W2_ROWP + (lo >> 5) * 16;
+    const char* pb = smem + (u & 1) * W2_PATCH + frag_off;
     auto frag_addr = [&](int m) -> const u32x4* {              // MFMA m = 2 g + jj of the phase
       const int gg = 36 * KH + (m >> 1), jj = m & 1;
       const int tap = gg >> 3, c = gg & 7;
@@ -266,13 +320,6 @@ __global__ __launch_bounds__(512, 1) void conv3x3_ws2_kernel(const ConvArgs p) {
       constexpr int m = decltype(mc)::value;
       w2_mfma<(KH == 0 && m < 2), ((m >> 1) < W2_WA)>(wreg[m >> 1], xf[m % 4], acc[m & 1]);
       if constexpr (m + 3 < 72) xf[(m + 3) % 4] = *frag_addr(m + 3);
-      if constexpr (KH == 1 && m == 58) {                      // requested late: 16 registers that must not live through the phase
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          if (p.bias) bq[g] = *reinterpret_cast<const f32x4*>(p.bias + cw * 32 + 8 * g + 4 * hq);
-          else bq[g][0] = bq[g][1] = bq[g][2] = bq[g][3] = 0.0f;
-        }
-      }
       __builtin_amdgcn_sched_barrier(0);
     });
     __builtin_amdgcn_s_setprio(0);
@@ -283,7 +330,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_ws2_kernel(const ConvArgs p) {
       for (int g = 0; g < 4; ++g) {
         f32x4 v;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = KH == 1 ? acc[jj][4 * g + e] + bq[g][e] : acc[jj][4 * g + e];
+        for (int e = 0; e < 4; ++e) v[e] = acc[jj][4 * g + e];
         *reinterpret_cast<f32x4*>(t_slot(u, jj, g)) = v;
       }
   };
@@ -293,36 +340,41 @@ __global__ __launch_bounds__(512, 1) void conv3x3_ws2_kernel(const ConvArgs p) {
     __builtin_amdgcn_sched_barrier(0);
   };
 
-  issue_patch(t_begin, 0);
+  // prologue: patch and residual rows of the first tile (every wave of group 1 its share), parameters, first barrier
+  if (grp == 1) issue_dma(cw, t_begin, 0, t_begin, 0, true, has_res);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   publish();
+  constexpr int NS = 2 * ((KEEP ? 1 : 0) + (LN != 0 ? 1 : 0));  // stores of a row slot
+  // iteration u: M phases of tile u, rows of tile u-1; group 1 requests patch(u+1) and the residual rows of tile u
   for (int u = 0; u <= U; ++u) {
-    const int tl = u >> 1;                                     // local tile of unit u
-    const int bufoff = (tl & 1) * W2_PATCH;
-    const bool next_patch = (u & 1) == 0 && t_begin + tl + 1 < t_end && u < U;   // uniform: this iteration requests the next tile's patch
-    // ---- first half: group 0 M0(u) | group 1 rows [0,32) of unit u-1
+    if constexpr (PROF) prof_u = (blockIdx.x == 0 && (u == 8 || u == 9)) ? u - 8 : -1;
+    stamp(0);
+    // ---- first half: group 0 M0(u) | group 1: requests, rows [0,32) of tile u-1
     if (grp == 0) {
-      if (u >= 1) prefetch_rows(u - 1, 1);                     // for my row slot in the second half
-      if (u < U) mfma_phase(std::integral_constant<int, 0>{}, u, bufoff);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // residual rows here; stores / DMA pieces of my last row slot long retired
+      if (u < U) mfma_phase(std::integral_constant<int, 0>{}, u);
     } else {
+      // patch(u+1) goes where patch(u-1) was (read for the last time in iteration u-1), the residual rows of tile u where
+      // those of tile u-2 were; both are needed in iteration u+1.  (The rows of the FIRST tile came with the prologue.)
+      if (u < U) issue_dma(cw, t_begin + min(u + 1, U - 1), (u + 1) & 1, t_begin + u, u & 1, u + 1 < U, has_res && u >= 1);
       if (u >= 1) row_slot(u - 1, 0);
-      if (next_patch) issue_patch(t_begin + tl + 1, ((tl + 1) & 1) * W2_PATCH);
     }
+    stamp(1);
     publish();
-    // ---- second half: group 1 M1(u) | group 0 rows [32,64) of unit u-1
+    stamp(2);
+    // ---- second half: group 1 M1(u) | group 0 rows [32,64) of tile u-1
     if (grp == 1) {
-      if (u < U) {
-        prefetch_rows(u, 0);                                   // for my row slot in the next iteration's first half
-        mfma_phase(std::integral_constant<int, 1>{}, u, bufoff);
-      }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (u < U) mfma_phase(std::integral_constant<int, 1>{}, u);
+      // my requests of this iteration have landed once only the stores I issued behind them are outstanding
+      if (u >= 1) wait_vmcnt<NS>();
+      else wait_vmcnt<0>();
     } else {
       if (u >= 1) row_slot(u - 1, 1);
-      if (next_patch) issue_patch(t_begin + tl + 1, ((tl + 1) & 1) * W2_PATCH);
     }
+    stamp(3);
     publish();
+    stamp(4);
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
 }
 
@@ -332,26 +384,30 @@ __global__ __launch_bounds__(512, 1) void conv3x3_ws2_kernel(const ConvArgs p) {
 extern "C" __attribute__((visibility("hidden"))) int vt_ws2_launch(const void* args, void* stream_) {
   const ConvArgs& a = *reinterpret_cast<const ConvArgs*>(args);
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
-  VT_CHECK_ARG(a.prof == nullptr, "vt_conv_profile: the two-group weight-stationary kernel carries no stamps (use conv_ws = 1)");
   const bool keep = a.ln_mode == 0 || a.ln_keep_y != 0;
-  const int vi = a.ln_mode == 0 ? 0 : (a.ln_mode == 1 ? (keep ? 1 : 2) : (keep ? 3 : 4));
-  static const void* const kerns[5] = {
+  int vi = a.ln_mode == 0 ? 0 : (a.ln_mode == 1 ? (keep ? 1 : 2) : (keep ? 3 : 4));
+  static const void* const kerns[7] = {
       reinterpret_cast<const void*>(&conv3x3_ws2_kernel<0, true>), reinterpret_cast<const void*>(&conv3x3_ws2_kernel<1, true>),
       reinterpret_cast<const void*>(&conv3x3_ws2_kernel<1, false>), reinterpret_cast<const void*>(&conv3x3_ws2_kernel<2, true>),
-      reinterpret_cast<const void*>(&conv3x3_ws2_kernel<2, false>)};
+      reinterpret_cast<const void*>(&conv3x3_ws2_kernel<2, false>), reinterpret_cast<const void*>(&conv3x3_ws2_kernel<0, true, true>),
+      reinterpret_cast<const void*>(&conv3x3_ws2_kernel<2, true, true>)};
+  if (a.prof != nullptr) {           // vt_conv_profile: the plain and the LayerNorm+SiLU (y kept) instantiations carry stamps [8 waves][16]
+    VT_CHECK_ARG(vi == 0 || vi == 3, "vt_conv_profile (weight-stationary kernel): ln_mode 0, or 2 with ln_keep_y");
+    vi = vi == 0 ? 5 : 6;
+  }
   static std::atomic<int> cus[kMaxDevices];         // 0 = not set up on that device yet; else its CU count
   int dev = 0;
   VT_CHECK_HIP(hipGetDevice(&dev));
   const bool dev_ok = dev >= 0 && dev < kMaxDevices;
   int ncu = dev_ok ? cus[dev].load(std::memory_order_acquire) : 0;
   if (ncu == 0) {
-    for (int k = 0; k < 5; ++k) VT_CHECK_HIP(hipFuncSetAttribute(kerns[k], hipFuncAttributeMaxDynamicSharedMemorySize, W2_LDS));
+    for (int k = 0; k < 7; ++k) VT_CHECK_HIP(hipFuncSetAttribute(kerns[k], hipFuncAttributeMaxDynamicSharedMemorySize, W2_LDS));
     VT_CHECK_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
     if (ncu <= 0) ncu = 256;
     if (dev_ok) cus[dev].store(ncu, std::memory_order_release);
   }
-  const int ntiles = (a.Wo / W2_TW) * (a.Ho / W2_TH) * a.B * a.To;
-  const int grid = ntiles < ncu ? ntiles : ncu;     // one persistent workgroup per CU (all of its LDS)
+  const int ntiles = (a.Wo / W2_TW) * (a.Ho / W2_TH) * a.B * a.To;   // 4 x 16-pixel tiles (ws128_eligible guarantees Ho % 8 == 0, Wo % 16 == 0)
+  const int grid = ntiles < ncu ? ntiles : ncu;     // one persistent workgroup per CU (nearly all of its LDS)
   ConvArgs args_copy = a;
   void* kargs[] = {&args_copy};
   VT_CHECK_HIP(hipLaunchKernel(kerns[vi], dim3((unsigned)grid), dim3(512), kargs, W2_LDS, stream));
