@@ -33,8 +33,8 @@
 // outstanding; the barrier behind it publishes both buffers for the next iteration.  Group 0 only stores.
 //
 // LDS: two halo patches (6 x 18 pixel rows padded to 272 B: 2 x 29 696) + two P/T buffers (64 rows x 512 B) + two residual
-// tiles (64 rows x 272 B) = 159 744 B.  Buffers are handed over by barriers only; every LDS write is retired
-// (lgkmcnt(0)) before the barrier that publishes it.  The LayerNorm affine and the bias sit in the pad bytes of patch 0.
+// tiles (64 rows x 272 B) + the LayerNorm affine and the bias (1.5 KB) = 161 280 B.  Buffers are handed over by barriers
+// only; every LDS write is retired (lgkmcnt(0)) before the barrier that publishes it.
 #include <atomic>
 #include <type_traits>
 
@@ -53,8 +53,9 @@ namespace {
 [[maybe_unused]] constexpr int W2_RBUF = W2_RPIECES * 1024;            // 17 408
 [[maybe_unused]] constexpr int W2_OFF_T = 2 * W2_PATCH;
 [[maybe_unused]] constexpr int W2_OFF_R = W2_OFF_T + 2 * W2_TBUF;
-[[maybe_unused]] constexpr int W2_LDS = W2_OFF_R + 2 * W2_RBUF;        // 159 744
-[[maybe_unused]] constexpr int W2_DMA_PER_WAVE = 12;                   // 46 pieces per tile over the four waves of group 1
+[[maybe_unused]] constexpr int W2_OFF_PRM = W2_OFF_R + 2 * W2_RBUF;    // 159 744: LayerNorm gamma | beta | bias, 3 x 128 fp32
+[[maybe_unused]] constexpr int W2_LDS = W2_OFF_PRM + 3 * 128 * 4;      // 161 280
+[[maybe_unused]] constexpr int W2_PSLOTS = 8, W2_RSLOTS = 5;           // DMA pieces per wave of group 1: patch pieces w + 4 q (< 29), residual pieces w + 4 q (< 17)
 
 template <int I, int N, typename F>
 __device__ __forceinline__ void w2_static_for(F&& f) {
@@ -118,16 +119,15 @@ __global__ __launch_bounds__(512, 1) void conv3x3_ws2_kernel(const ConvArgs p) {
 #pragma unroll
     for (int c = 0; c < 36; ++c) wreg[c] = *reinterpret_cast<const u32x4*>(row + c * 16);
   }
-  // ---- LayerNorm affine and bias of the 128 channels, parked in the LDS: the 16 pad bytes behind patch pixel rows 0 .. 95 of
-  // patch buffer 0 (value i at row i / 4, float i % 4: gamma 0..127, beta 128..255, bias 256..383).  The patch DMA never
-  // writes pad bytes (its lanes there are switched off), so a row slot reads its 24 values with six ds_read_b128 instead
-  // of keeping 24 registers through the MFMA phases.
+  // ---- LayerNorm affine and bias of the 128 channels, parked in the LDS (a row slot reads its 24 values with six
+  // ds_read_b128 instead of keeping 24 registers through the MFMA phases)
+  float* prm = reinterpret_cast<float*>(smem + W2_OFF_PRM);
   if (tid < 384) {
     float v = 0.0f;
     if (tid < 128) v = LN != 0 ? p.ln_gamma[tid] : 1.0f;
     else if (tid < 256) v = LN != 0 ? p.ln_beta[tid - 128] : 0.0f;
     else v = p.bias ? p.bias[tid - 256] : 0.0f;
-    *reinterpret_cast<float*>(smem + (tid >> 2) * W2_ROWP + 256 + (tid & 3) * 4) = v;
+    prm[tid] = v;
   }
 
   auto tile_coords = [&](int tile, int& f, int& h0, int& w0) {
@@ -137,46 +137,60 @@ __global__ __launch_bounds__(512, 1) void conv3x3_ws2_kernel(const ConvArgs p) {
     h0 = th * W2_TH;
     w0 = (r - th * tiles_w) * W2_TW;
   };
-  // ---- LDS-DMA of a tile's operands: pieces 0 .. 28 = the 6 x 18 halo patch of x (descriptor rebased to the tile's frame:
-  // rows above / below the image are out of range by themselves, the left / right halo columns of border tiles are
-  // tested), pieces 29 .. 45 = the 4 x 16 residual rows.  A piece is 1 KiB of the 272-B-row image; the lanes that fall
-  // on pad bytes are switched off.  Wave `w4` (0..3) sends pieces [12 w4, 12 w4 + 12) of the 46.
+  // ---- LDS-DMA of a tile's operands by the waves of group 1: the 6 x 18 halo patch of x (29 pieces of 1 KiB of the
+  // 272-B-row image; descriptor rebased to the tile's frame: rows above / below the image are out of range by themselves,
+  // the left / right halo columns of border tiles are tested) and its 4 x 16 residual rows (17 pieces).  Wave w sends
+  // patch pieces w, w + 4, ... and residual pieces w, w + 4, ...  What a lane fetches for a piece depends on the tile only
+  // through the tile's byte offset in its frame, so the geometry is worked out ONCE per lane and piece slot (13 registers:
+  // bits 4.. = byte offset relative to the tile origin, bit 0 / 1 = left / right halo column, bit 2 = never fetched: pad
+  // bytes, image tail); a request then costs five instructions instead of the ~100 of the divide-by-272 arithmetic (first
+  // measurement of this file: 5 000 cycles of request code per tile).
   const unsigned frame_bytes = (unsigned)H * (unsigned)W * 256u;
-  auto issue_dma = [&](int w4, int ptile, int pbuf, int rtile, int rbuf, bool want_patch, bool want_res) {
-    int f, h0, w0;
-    tile_coords(ptile, f, h0, w0);
-    const __amdgpu_buffer_rsrc_t prsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(xg) + (long long)f * H * W * 128, 0, frame_bytes, 0x00020000);
-    const unsigned tmask = (w0 == 0 ? 1u : 0u) | (w0 + W2_TW == W ? 2u : 0u);
-    const int ptoff = (h0 * W + w0) * 256;
-    int rf, rh0, rw0;
-    tile_coords(rtile, rf, rh0, rw0);
-    const __amdgpu_buffer_rsrc_t rrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(rg) + (long long)rf * H * W * 128, 0, frame_bytes, 0x00020000);
-    const int rtoff = (rh0 * W + rw0) * 256;
-    int lo = lane;
-    asm volatile("" : "+v"(lo));
-    w2_static_for<0, W2_DMA_PER_WAVE>([&](auto qc) {
-      constexpr int q = decltype(qc)::value;
-      const int piece = w4 * W2_DMA_PER_WAVE + q;              // uniform
-      if (piece < W2_PPIECES) {
-        if (want_patch) {
-          const int b = piece * 1024 + lo * 16;
-          const int pp = b / W2_ROWP;
-          const int unit = (b - pp * W2_ROWP) >> 4;
-          const int pr = pp / W2_PW, pc = pp - pr * W2_PW;
-          const bool ok = (pp < W2_NPIX) & !((pc == 0) & ((tmask & 1u) != 0)) & !((pc == W2_PW - 1) & ((tmask & 2u) != 0));
-          const unsigned off = ok ? (unsigned)(((pr - 1) * W + (pc - 1)) * 256 + unit * 16 + ptoff) : kOob;
-          if (unit < 16) __builtin_amdgcn_raw_ptr_buffer_load_lds(prsrc, (lds_ptr_t)(smem + pbuf * W2_PATCH + piece * 1024), 16, off, 0, 0, 0);
+  unsigned pgeo[W2_PSLOTS], rgeo[W2_RSLOTS];
+#pragma unroll
+  for (int q = 0; q < W2_PSLOTS; ++q) {
+    const int b = (cw + 4 * q) * 1024 + lane * 16;
+    const int pp = b / W2_ROWP;
+    const int unit = (b - pp * W2_ROWP) >> 4;
+    const int pr = pp / W2_PW, pc = pp - pr * W2_PW;
+    const int rel = ((pr - 1) * W + (pc - 1)) * 256 + unit * 16;         // may be negative: wraps, and wraps back when the tile offset is added
+    pgeo[q] = (unsigned)rel | (pc == 0 ? 1u : 0u) | (pc == W2_PW - 1 ? 2u : 0u) | ((pp >= W2_NPIX || unit >= 16) ? 4u : 0u);
+  }
+#pragma unroll
+  for (int q = 0; q < W2_RSLOTS; ++q) {
+    const int b = (cw + 4 * q) * 1024 + lane * 16;
+    const int rr = b / W2_ROWP;                                          // residual row 16 r + c of the tile
+    const int unit = (b - rr * W2_ROWP) >> 4;
+    rgeo[q] = (unsigned)(((rr >> 4) * W + (rr & 15)) * 256 + unit * 16) | ((rr >= 64 || unit >= 16) ? 4u : 0u);
+  }
+  auto issue_dma = [&](int ptile, int pbuf, int rtile, int rbuf, bool want_patch, bool want_res) {
+    if (want_patch) {
+      int f, h0, w0;
+      tile_coords(ptile, f, h0, w0);
+      const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(xg) + (long long)f * H * W * 128, 0, frame_bytes, 0x00020000);
+      const unsigned tmask = (w0 == 0 ? 1u : 0u) | (w0 + W2_TW == W ? 2u : 0u) | 4u;
+      const unsigned toff = (unsigned)((h0 * W + w0) * 256);
+      w2_static_for<0, W2_PSLOTS>([&](auto qc) {
+        constexpr int q = decltype(qc)::value;
+        if (cw + 4 * q < W2_PPIECES) {                                     // uniform
+          const unsigned off = (pgeo[q] & tmask) ? kOob : (pgeo[q] & ~15u) + toff;
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)(smem + pbuf * W2_PATCH + (cw + 4 * q) * 1024), 16, off, 0, 0, 0);
         }
-      } else if (piece < W2_PPIECES + W2_RPIECES) {
-        if (want_res) {
-          const int b = (piece - W2_PPIECES) * 1024 + lo * 16;
-          const int rr = b / W2_ROWP;                          // residual row 16 r + c of the tile
-          const int unit = (b - rr * W2_ROWP) >> 4;
-          const unsigned off = (unsigned)(((rr >> 4) * W + (rr & 15)) * 256 + unit * 16 + rtoff);
-          if (unit < 16) __builtin_amdgcn_raw_ptr_buffer_load_lds(rrsrc, (lds_ptr_t)(smem + W2_OFF_R + rbuf * W2_RBUF + (piece - W2_PPIECES) * 1024), 16, off, 0, 0, 0);
+      });
+    }
+    if (want_res) {
+      int f, h0, w0;
+      tile_coords(rtile, f, h0, w0);
+      const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(rg) + (long long)f * H * W * 128, 0, frame_bytes, 0x00020000);
+      const unsigned toff = (unsigned)((h0 * W + w0) * 256);
+      w2_static_for<0, W2_RSLOTS>([&](auto qc) {
+        constexpr int q = decltype(qc)::value;
+        if (cw + 4 * q < W2_RPIECES) {                                     // uniform
+          const unsigned off = (rgeo[q] & 4u) ? kOob : (rgeo[q] & ~15u) + toff;
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)(smem + W2_OFF_R + rbuf * W2_RBUF + (cw + 4 * q) * 1024), 16, off, 0, 0, 0);
         }
-      }
-    });
+      });
+    }
   };
 
   // ---- lane -> pixel map of a sub-tile (conv_ws128.hip: conflict-free ds_read_b128 groups) -------------------------------------
@@ -212,16 +226,16 @@ __global__ __launch_bounds__(512, 1) void conv3x3_ws2_kernel(const ConvArgs p) {
     int f, h0, w0;
     tile_coords(t_begin + v, f, h0, w0);
     const long long pix0 = ((long long)f * H + h0) * W + w0;
-    const char* pads = smem + 2 * oct_j * W2_ROWP + 256;       // gamma of channels [8 oct_j, +4), next row: +4 ..; beta + 32 rows, bias + 64 rows
+    const float* pl = prm + 8 * oct_j;                         // gamma of channels [8 oct_j, +8); beta + 128, bias + 256
     f32x4 g0, g1, b0, b1;
     if constexpr (LN != 0) {
-      g0 = *reinterpret_cast<const f32x4*>(pads);
-      g1 = *reinterpret_cast<const f32x4*>(pads + W2_ROWP);
-      b0 = *reinterpret_cast<const f32x4*>(pads + 32 * W2_ROWP);
-      b1 = *reinterpret_cast<const f32x4*>(pads + 33 * W2_ROWP);
+      g0 = *reinterpret_cast<const f32x4*>(pl);
+      g1 = *reinterpret_cast<const f32x4*>(pl + 4);
+      b0 = *reinterpret_cast<const f32x4*>(pl + 128);
+      b1 = *reinterpret_cast<const f32x4*>(pl + 132);
     }
-    const f32x4 o0 = *reinterpret_cast<const f32x4*>(pads + 64 * W2_ROWP);
-    const f32x4 o1 = *reinterpret_cast<const f32x4*>(pads + 65 * W2_ROWP);
+    const f32x4 o0 = *reinterpret_cast<const f32x4*>(pl + 256);
+    const f32x4 o1 = *reinterpret_cast<const f32x4*>(pl + 260);
     const float* T = Tb + (v & 1) * (64 * 128);
     const char* R = smem + W2_OFF_R + (v & 1) * W2_RBUF;
 #pragma unroll
@@ -341,7 +355,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_ws2_kernel(const ConvArgs p) {
   };
 
   // prologue: patch and residual rows of the first tile (every wave of group 1 its share), parameters, first barrier
-  if (grp == 1) issue_dma(cw, t_begin, 0, t_begin, 0, true, has_res);
+  if (grp == 1) issue_dma(t_begin, 0, t_begin, 0, true, has_res);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   publish();
   constexpr int NS = 2 * ((KEEP ? 1 : 0) + (LN != 0 ? 1 : 0));  // stores of a row slot
@@ -355,7 +369,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_ws2_kernel(const ConvArgs p) {
     } else {
       // patch(u+1) goes where patch(u-1) was (read for the last time in iteration u-1), the residual rows of tile u where
       // those of tile u-2 were; both are needed in iteration u+1.  (The rows of the FIRST tile came with the prologue.)
-      if (u < U) issue_dma(cw, t_begin + min(u + 1, U - 1), (u + 1) & 1, t_begin + u, u & 1, u + 1 < U, has_res && u >= 1);
+      if (u < U) issue_dma(t_begin + u + 1, (u + 1) & 1, t_begin + u, u & 1, u + 1 < U, has_res && u >= 1);
       if (u >= 1) row_slot(u - 1, 0);
     }
     stamp(1);
