@@ -16,8 +16,8 @@
 //     R(u):  rows of T(u) + bias + residual -> y, LayerNorm(+SiLU) -> n; rows [0,32) by group 1, rows [32,64) by group 0
 // and the two groups alternate, one barrier per half-step, so that a SIMD always has one wave in an MFMA phase and one in
 // a row slot (plain-fp32 VALU work of a wave overlaps the other wave's MFMAs):
-//     iteration u, first half:    group 0: M0(u)                 |  group 1: R(u-1) rows [0,32), DMA requests
-//     iteration u, second half:   group 1: M1(u)                 |  group 0: R(u-1) rows [32,64)
+//     iteration u, first half:    group 0: M0(u)                 |  group 1: request patch(u+1), R(u-1) rows [0,32)
+//     iteration u, second half:   group 1: M1(u)                 |  group 0: request residual(u), R(u-1) rows [32,64)
 // The fp32 sum of an output element is the same chain as in the first generation (K groups 0..35 from zero, then 36..71
 // on top) and the row arithmetic is the same, so results are bit-identical to conv_ws128.hip (and, without LayerNorm,
 // to the tile-per-workgroup kernel).
@@ -28,9 +28,10 @@
 // vmcnt(0) at its end -- no faster than the first generation), and registers with a load in flight across a phase get
 // copied by the allocator at block ends before the load has landed (second version).  So NOTHING is loaded into
 // registers here: the halo patch of the next tile AND the residual rows of the current one come in by LDS-DMA
-// (buffer_load ... lds), requested by the waves of group 1 at the head of their row slot, in front of that slot's
-// stores, and awaited by a COUNTED wait at the end of their following MFMA phase that leaves exactly those stores
-// outstanding; the barrier behind it publishes both buffers for the next iteration.  Group 0 only stores.
+// (buffer_load ... lds), requested at the head of a row slot, in front of that slot's stores -- the patch by the waves
+// of group 1, the residual rows by those of group 0 -- and awaited by a COUNTED wait that leaves exactly those stores
+// outstanding (group 1: at the end of its following MFMA phase; group 0: at the end of the slot itself, ~3 000 cycles
+// after the request); the barrier behind it publishes the buffers for the next iteration.
 //
 // LDS: two halo patches (6 x 18 pixel rows padded to 272 B: 2 x 29 696) + two P/T buffers (64 rows x 512 B) + two residual
 // tiles (64 rows x 272 B) + the LayerNorm affine and the bias (1.5 KB) = 161 280 B.  Buffers are handed over by barriers
@@ -55,6 +56,7 @@ namespace {
 [[maybe_unused]] constexpr int W2_OFF_R = W2_OFF_T + 2 * W2_TBUF;
 [[maybe_unused]] constexpr int W2_OFF_PRM = W2_OFF_R + 2 * W2_RBUF;    // 159 744: LayerNorm gamma | beta | bias, 3 x 128 fp32
 [[maybe_unused]] constexpr int W2_LDS = W2_OFF_PRM + 3 * 128 * 4;      // 161 280
+[[maybe_unused]] constexpr int W2_FD = 6;                               // fragment prefetch distance of an MFMA phase, in MFMAs
 [[maybe_unused]] constexpr int W2_PSLOTS = 8, W2_RSLOTS = 5;           // DMA pieces per wave of group 1: patch pieces w + 4 q (< 29), residual pieces w + 4 q (< 17)
 
 template <int I, int N, typename F>
@@ -293,7 +295,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_ws2_kernel(const ConvArgs p) {
     }
   };
 
-  // ---- MFMA phase of tile u for K-half KH: 36 groups x 2 sub-tiles, fragments three MFMAs ahead ------------------------
+  // ---- MFMA phase of tile u for K-half KH: 36 groups x 2 sub-tiles ------------------------
   f32x16 acc[2];
   // this lane's quad of (sub-tile jj, channel quad g) in the P / T buffer, recomputed at every use (see row_slot)
   auto t_slot = [&](int u, int jj, int g) -> float* {
@@ -326,14 +328,16 @@ __global__ __launch_bounds__(512, 1) void conv3x3_ws2_kernel(const ConvArgs p) {
       const int kh = tap / 3, kw = tap - 3 * kh;
       return reinterpret_cast<const u32x4*>(pb + ((2 * jj + kh) * W2_PW + kw) * W2_ROWP + c * 32);
     };
-    u32x4 xf[4];
+    // fragment ring: a read is requested W2_FD MFMAs (~200 cycles) ahead of its use -- three ahead (~100 cycles) left every
+    // MFMA waiting for the LDS: 51 cycles per MFMA instead of ~36 (profiles/r03_ws2_iteration_cycles.txt, first measurement)
+    u32x4 xf[W2_FD + 1];
 #pragma unroll
-    for (int m = 0; m < 3; ++m) xf[m] = *frag_addr(m);
+    for (int m = 0; m < W2_FD; ++m) xf[m] = *frag_addr(m);
     __builtin_amdgcn_s_setprio(1);
     w2_static_for<0, 72>([&](auto mc) {
       constexpr int m = decltype(mc)::value;
-      w2_mfma<(KH == 0 && m < 2), ((m >> 1) < W2_WA)>(wreg[m >> 1], xf[m % 4], acc[m & 1]);
-      if constexpr (m + 3 < 72) xf[(m + 3) % 4] = *frag_addr(m + 3);
+      w2_mfma<(KH == 0 && m < 2), ((m >> 1) < W2_WA)>(wreg[m >> 1], xf[m % (W2_FD + 1)], acc[m & 1]);
+      if constexpr (m + W2_FD < 72) xf[(m + W2_FD) % (W2_FD + 1)] = *frag_addr(m + W2_FD);
       __builtin_amdgcn_sched_barrier(0);
     });
     __builtin_amdgcn_s_setprio(0);
@@ -354,8 +358,9 @@ __global__ __launch_bounds__(512, 1) void conv3x3_ws2_kernel(const ConvArgs p) {
     __builtin_amdgcn_sched_barrier(0);
   };
 
-  // prologue: patch and residual rows of the first tile (every wave of group 1 its share), parameters, first barrier
-  if (grp == 1) issue_dma(t_begin, 0, t_begin, 0, true, has_res);
+  // prologue: patch (group 1) and residual rows (group 0) of the first tile, parameters, first barrier
+  if (grp == 1) issue_dma(t_begin, 0, 0, 0, true, false);
+  else issue_dma(0, 0, t_begin, 0, false, has_res);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   publish();
   constexpr int NS = 2 * ((KEEP ? 1 : 0) + (LN != 0 ? 1 : 0));  // stores of a row slot
@@ -367,9 +372,9 @@ __global__ __launch_bounds__(512, 1) void conv3x3_ws2_kernel(const ConvArgs p) {
     if (grp == 0) {
       if (u < U) mfma_phase(std::integral_constant<int, 0>{}, u);
     } else {
-      // patch(u+1) goes where patch(u-1) was (read for the last time in iteration u-1), the residual rows of tile u where
-      // those of tile u-2 were; both are needed in iteration u+1.  (The rows of the FIRST tile came with the prologue.)
-      if (u < U) issue_dma(t_begin + u + 1, (u + 1) & 1, t_begin + u, u & 1, u + 1 < U, has_res && u >= 1);
+      // patch(u+1) goes where patch(u-1) was (read for the last time in iteration u-1); needed in iteration u+1, awaited
+      // at the end of my MFMA phase below
+      if (u < U) issue_dma(t_begin + u + 1, (u + 1) & 1, 0, 0, u + 1 < U, false);
       if (u >= 1) row_slot(u - 1, 0);
     }
     stamp(1);
@@ -382,7 +387,14 @@ __global__ __launch_bounds__(512, 1) void conv3x3_ws2_kernel(const ConvArgs p) {
       if (u >= 1) wait_vmcnt<NS>();
       else wait_vmcnt<0>();
     } else {
-      if (u >= 1) row_slot(u - 1, 1);
+      // the residual rows of tile u go where those of tile u-2 were (read for the last time in iteration u-1); needed in
+      // iteration u+1.  Requested ahead of my rows and stores, awaited behind them with the stores left outstanding.  (The
+      // rows of the first tile came with the prologue.)
+      if (u >= 1 && u < U) issue_dma(0, 0, t_begin + u, u & 1, false, has_res);
+      if (u >= 1) {
+        row_slot(u - 1, 1);
+        wait_vmcnt<NS>();
+      }
     }
     stamp(3);
     publish();
