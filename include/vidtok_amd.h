@@ -83,7 +83,7 @@ int vt_conv_max_lds_bytes(void);
  *   conv_tile_min (128) fewest 256 x 256 tiles for which the 8-wave tile is chosen
  *   conv_fuse_ln (1), conv_fuse_ln256 (1)   LayerNorm of the result inside the epilogue for Cout = 128 / 256
  *   conv_ln256_v (1)    form of the Cout = 256 LayerNorm epilogue (0: round-2 form)
- *   conv_x_nt (0), ws_acc (0), tblock_fused (1), tblock_prof_mode (0)   measurement aids
+ *   conv_x_nt (0), ws_acc (0), tblock_fused (1), tblock_prof_mode (0), ws_prof_mode (0)   measurement aids
  * Returns VT_ERR_ARG for an unknown name.
  * ---------------------------------------------------------------------------------------- */
 int vt_set_option(const char* name, int32_t value);

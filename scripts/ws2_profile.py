@@ -30,17 +30,25 @@ def main():
         ops.conv(x, w, bias, ConvGeom(kh=3, kw=3, ph=1, pw=1, ph_hi=1, pw_hi=1), cout=C_, **kw)
         rec, ops.CONV_RECORD = ops.CONV_RECORD, None
         d = rec[0][0]
-        stamps = torch.zeros((8, 16), dtype=torch.int64, device=dev)
-        for _ in range(2):
-            L.check(L.load().vt_conv_profile(C.byref(d), stamps.data_ptr(), None), "vt_conv_profile")
-        torch.cuda.synchronize()
-        s = stamps.cpu()
-        print(f"3x3 128->128 @256^2 {label}: MFMA-bound time of an iteration = 144 MFMAs x 32 = 4 608 cycles per SIMD")
-        for wv in range(8):
-            for it in range(2):
-                d5 = [int(s[wv, 5 * it + k + 1] - s[wv, 5 * it + k]) for k in range(4)]
-                names = ["M0: 72 MFMAs", "barrier", "rows [32,64)", "barrier"] if wv < 4 else ["DMA requests + rows [0,32)", "barrier", "M1: 72 MFMAs + wait", "barrier"]
-                print(f"  wave {wv} iteration {8 + it}: total {sum(d5):6d} | " + " | ".join(f"{n} {v}" for n, v in zip(names, d5)))
+        for mode, mlabel in ((0, "as shipped"), (1, "row slots skipped"), (2, "LDS-DMA requests skipped"), (3, "row slots and requests skipped")):
+            L.set_option("ws_prof_mode", mode)
+            stamps = torch.zeros((8, 16), dtype=torch.int64, device=dev)
+            for _ in range(2):
+                L.check(L.load().vt_conv_profile(C.byref(d), stamps.data_ptr(), None), "vt_conv_profile")
+            torch.cuda.synchronize()
+            s = stamps.cpu()
+            print(f"3x3 128->128 @256^2 {label}, {mlabel}: MFMA-bound time of an iteration = 144 MFMAs x 32 = 4 608 cycles per SIMD")
+            for wv in range(8):
+                for it in range(2):
+                    t = [int(s[wv, 8 * it + k]) for k in range(8)]
+                    if wv < 4:     # group 0: stamps 0 [first fragments] 5 [72 MFMAs] 6 [T writes] 1 [barrier] 2 [requests + rows] 3 [barrier] 4
+                        seg = [("first fragments", t[5] - t[0]), ("72 MFMAs", t[6] - t[5]), ("partial sums -> LDS", t[1] - t[6]), ("barrier", t[2] - t[1]),
+                               ("requests + rows [32,64) + wait", t[3] - t[2]), ("barrier", t[4] - t[3])]
+                    else:          # group 1: 0 [requests + rows] 1 [barrier] 2 [partial sums + fragments] 5 [72 MFMAs] 6 [T writes] 7 [wait] 3 [barrier] 4
+                        seg = [("requests + rows [0,32)", t[1] - t[0]), ("barrier", t[2] - t[1]), ("partial sums <- LDS + first fragments", t[5] - t[2]),
+                               ("72 MFMAs", t[6] - t[5]), ("sums -> LDS", t[7] - t[6]), ("wait for my requests", t[3] - t[7]), ("barrier", t[4] - t[3])]
+                    print(f"  wave {wv} iteration {8 + it}: total {t[4] - t[0]:6d} | " + " | ".join(f"{n} {v}" for n, v in seg))
+        L.set_option("ws_prof_mode", 0)
 
 
 if __name__ == "__main__":

@@ -16,6 +16,12 @@ LIB = os.path.join(HERE, "libvidtok_amd.so")
 SOURCES = ["conv_igemm.hip", "conv_ws128.hip", "conv_ws2.hip", "conv_narrow.hip", "tblock_ws128.hip", "pointwise.hip", "groupnorm.hip", "regularizers.hip", "metrics.hip", "video_io.hip", "error.cpp", "options.cpp"]
 HEADERS = ["common.h", "conv_common.h", "options.h", os.path.join("..", "..", "include", "vidtok_amd.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+# per-file additions.  conv_ws2.hip: its row arithmetic runs beside the partner wave's MFMAs, where packed fp32
+# (v_pk_*_f32, what the SLP vectoriser makes of eight parallel scalar chains) stalls the matrix pipe
+# (profiles/r02_mfma_issue_microbench.txt) -- so no SLP there, and the instruction scheduler stays free to interleave
+# the chains (the asm pins that used to keep the elements apart also kept every chain in program order: 63 s_nop of
+# hazard padding in a 540-instruction row slot)
+EXTRA_FLAGS = {"conv_ws2.hip": ["-fno-slp-vectorize"]}
 
 
 def _hipcc():
@@ -31,6 +37,7 @@ def _digest():
         with open(os.path.join(CSRC, f), "rb") as fh:
             h.update(fh.read())
     h.update(" ".join(FLAGS).encode())
+    h.update(repr(sorted(EXTRA_FLAGS.items())).encode())
     return h.hexdigest()
 
 
@@ -46,7 +53,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
     procs = []
     for src in SOURCES:
         obj = os.path.join(objdir, os.path.splitext(src)[0] + ".o")
-        cmd = [hipcc, *FLAGS, "-x", "hip", "-c", os.path.join(CSRC, src), "-o", obj]
+        cmd = [hipcc, *FLAGS, *EXTRA_FLAGS.get(src, []), "-x", "hip", "-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print("[vidtok_amd.build]", " ".join(cmd), flush=True)
         procs.append((src, subprocess.Popen(cmd)))

@@ -51,6 +51,14 @@ __device__ __forceinline__ float bf16_bits_to_f32(uint32_t bits16) {
 __device__ __forceinline__ uint32_t f32_to_bf16_bits(float f) {
   return (uint32_t)__builtin_bit_cast(uint16_t, (__bf16)f);
 }
+// two values -> one word (lo in bits 0..15): ONE v_cvt_pk_bf16_f32, same rounding as f32_to_bf16_bits (the scalar form
+// packs with two conversions, a shift and an OR -- four issue slots a pair)
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+  typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+  typedef float f32x2_t __attribute__((ext_vector_type(2)));
+  const f32x2_t v = {lo, hi};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
+}
 
 template <typename T>
 __device__ __forceinline__ float to_f32(T v);

@@ -69,6 +69,7 @@ struct ConvArgs {
   int x_nt;                    // BUF path: 1 = activation gathers carry the non-temporal hint (option conv_x_nt, measurement aid)
   long long xs_z, ws_z, ys_z, rs_z;
   unsigned long long* prof;    // PROF instantiation only (vt_conv_profile): cycle stamps of workgroup 0
+  int prof_mode;               // PROF instantiation of conv_ws2.hip only: option ws_prof_mode
 };
 
 template <typename MT>

@@ -1508,6 +1508,7 @@ extern "C" int vt_conv_profile(const vt_conv_desc* d, uint64_t* stamps_out, vt_s
   const int rc = conv_prepare(d, a, ln_fused, nbatch, use_ws);
   if (rc != VT_OK) return rc;
   a.prof = reinterpret_cast<unsigned long long*>(stamps_out);
+  a.prof_mode = vt_opt(OPT_WS_PROF_MODE);
   if (use_ws)                                          // stamps [wave][16]: conv_ws128.hip workgroup 0's fourth tile (4 waves), conv_ws2.hip iterations 8, 9 (8 waves)
     return vt_opt(OPT_CONV_WS) == 2 ? vt_ws2_launch(&a, stream_) : vt_ws128_launch(&a, stream_);
   VT_CHECK_ARG(d->dtype == VT_BF16 && d->out_dtype == VT_BF16 && d->ln_mode == 0 && select_tile(a, nbatch) == TILE_256x256,

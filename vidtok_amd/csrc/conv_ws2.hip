@@ -111,7 +111,6 @@ __global__ __launch_bounds__(512, 1) void conv3x3_ws2_kernel(const ConvArgs p) {
   const bf16_t* __restrict__ rg = reinterpret_cast<const bf16_t*>(p.res);
   bf16_t* __restrict__ ng = reinterpret_cast<bf16_t*>(p.ln_out);
   constexpr unsigned kOob = 0xFFFF0000u;
-  float* Tb = reinterpret_cast<float*>(smem + W2_OFF_T);               // [2][64][128]
   const bool has_res = p.res_mode == VT_RES_ADD;                        // uniform
 
   // ---- stationary weights: K groups [36 grp, 36 grp + 36) of the 72 (group g = tap * 8 + 16-channel chunk) -------------
@@ -132,12 +131,32 @@ __global__ __launch_bounds__(512, 1) void conv3x3_ws2_kernel(const ConvArgs p) {
     prm[tid] = v;
   }
 
-  auto tile_coords = [&](int tile, int& f, int& h0, int& w0) {
-    f = tile / tiles_pf;
-    const int r = tile - f * tiles_pf;
+  // Tile cursor: (frame, h0, w0) of a tile, stepped through the workgroup's run of tiles by additions -- a wave issues one
+  // instruction every four cycles whatever the instruction is, and the two divisions of "tile index -> coordinates" were
+  // ~60 scalar instructions a call, three calls an iteration (profiles/r03_ws2_iteration_cycles.txt: the row slots and the
+  // phase prologues were issue-bound, 4 cycles x instruction count, not MFMA- or memory-bound).
+  struct TileCur {
+    int f, h0, w0;
+  };
+  auto cur_at = [&](int tile) {
+    TileCur c;
+    c.f = tile / tiles_pf;
+    const int r = tile - c.f * tiles_pf;
     const int th = r / tiles_w;
-    h0 = th * W2_TH;
-    w0 = (r - th * tiles_w) * W2_TW;
+    c.h0 = th * W2_TH;
+    c.w0 = (r - th * tiles_w) * W2_TW;
+    return c;
+  };
+  auto cur_step = [&](TileCur& c) {
+    c.w0 += W2_TW;
+    if (c.w0 == W) {
+      c.w0 = 0;
+      c.h0 += W2_TH;
+      if (c.h0 == H) {
+        c.h0 = 0;
+        c.f += 1;
+      }
+    }
   };
   // ---- LDS-DMA of a tile's operands by the waves of group 1: the 6 x 18 halo patch of x (29 pieces of 1 KiB of the
   // 272-B-row image; descriptor rebased to the tile's frame: rows above / below the image are out of range by themselves,
@@ -165,10 +184,12 @@ __global__ __launch_bounds__(512, 1) void conv3x3_ws2_kernel(const ConvArgs p) {
     const int unit = (b - rr * W2_ROWP) >> 4;
     rgeo[q] = (unsigned)(((rr >> 4) * W + (rr & 15)) * 256 + unit * 16) | ((rr >= 64 || unit >= 16) ? 4u : 0u);
   }
-  auto issue_dma = [&](int ptile, int pbuf, int rtile, int rbuf, bool want_patch, bool want_res) {
+  auto issue_dma = [&](const TileCur& pt, int pbuf, const TileCur& rt, int rbuf, bool want_patch, bool want_res) {
+    if constexpr (PROF) {
+      if (p.prof_mode & 2) return;
+    }
     if (want_patch) {
-      int f, h0, w0;
-      tile_coords(ptile, f, h0, w0);
+      const int f = pt.f, h0 = pt.h0, w0 = pt.w0;
       const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(xg) + (long long)f * H * W * 128, 0, frame_bytes, 0x00020000);
       const unsigned tmask = (w0 == 0 ? 1u : 0u) | (w0 + W2_TW == W ? 2u : 0u) | 4u;
       const unsigned toff = (unsigned)((h0 * W + w0) * 256);
@@ -181,8 +202,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_ws2_kernel(const ConvArgs p) {
       });
     }
     if (want_res) {
-      int f, h0, w0;
-      tile_coords(rtile, f, h0, w0);
+      const int f = rt.f, h0 = rt.h0, w0 = rt.w0;
       const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(rg) + (long long)f * H * W * 128, 0, frame_bytes, 0x00020000);
       const unsigned toff = (unsigned)((h0 * W + w0) * 256);
       w2_static_for<0, W2_RSLOTS>([&](auto qc) {
@@ -196,10 +216,12 @@ __global__ __launch_bounds__(512, 1) void conv3x3_ws2_kernel(const ConvArgs p) {
   };
 
   // ---- lane -> pixel map of a sub-tile (conv_ws128.hip: conflict-free ds_read_b128 groups) -------------------------------------
+  // quads of m alternate between the two pixel rows in the order 0 1 1 0 1 0 0 1 (bit m/4 of 0x96), columns advance by 4
+  // every second quad -- in bit operations, not compares: the compare form compiled into ~60 instructions of exec-mask
+  // branches at the head of every MFMA phase and row slot
   auto subtile_pixel = [](int m, int& rsel, int& col) {
-    const bool g0 = (m < 4) | ((m >= 12) & (m < 16)) | ((m >= 20) & (m < 28));
-    rsel = g0 ? 0 : 1;
-    col = g0 ? (m < 4 ? m : (m < 16 ? m - 8 : m - 12)) : (m < 12 ? m - 4 : (m < 20 ? m - 8 : m - 16));
+    rsel = (0x96 >> (m >> 2)) & 1;
+    col = (m & 3) | ((m >> 1) & 12);
   };
   // PROF (vt_conv_profile): shader-clock stamps of workgroup 0's iterations 8 and 9, straight to memory
   int prof_u = -1;
@@ -207,7 +229,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_ws2_kernel(const ConvArgs p) {
     if constexpr (PROF) {
       if (prof_u >= 0) {
         const unsigned long long ts = __builtin_amdgcn_s_memtime();
-        if (lane == 0) p.prof[wave * 16 + 5 * prof_u + k] = ts;
+        if (lane == 0) p.prof[wave * 16 + 8 * prof_u + k] = ts;
       }
     }
   };
@@ -219,15 +241,26 @@ __global__ __launch_bounds__(512, 1) void conv3x3_ws2_kernel(const ConvArgs p) {
   // Row arithmetic in explicit-rounding intrinsics, the operation order of conv_ws128.hip (bias joined the tile before the
   // transposition there); every intermediate is pinned so the vectoriser cannot pair the elements -- packed fp32 does not
   // run beside the other wave's MFMAs (scripts/mfma_issue_bench.hip).
-  auto pinf = [](float& v) { asm volatile("" : "+v"(v)); };
-  auto row_slot = [&](int v, int jj) {
+  auto pinf = [](float&) {};
+  // y / n go out through buffer descriptors rebased to the tile's frame (as the DMA requests come in): the per-lane byte
+  // offset is tile-invariant and 32-bit, the tile's own offset is one more addition -- no 64-bit address arithmetic per
+  // store (rows of y and n are 128 channels wide: ws128_eligible).  The tile offset does NOT ride in the instruction's
+  // scalar-offset operand: a 16-byte store with an SGPR offset reads its data registers late, and the compiler's one
+  // wait state did not cover it here -- the second y store of a slot went out with registers 1 of lanes 12-15 (mod 16)
+  // already overwritten by the LayerNorm arithmetic behind it, in a few tiles per launch (tests/test_gpu_ops.py:
+  // test_weight_stationary_kernels_are_split_independent caught it).
+  auto row_slot = [&](const TileCur& tc, int par, int jj) {
+    if constexpr (PROF) {
+      if (p.prof_mode & 1) return;
+    }
     int tt = tid;
     asm volatile("" : "+v"(tt));
     const int tg = tt & 255;
     const int oct_j = tg & 15, row_l = tg >> 4;
-    int f, h0, w0;
-    tile_coords(t_begin + v, f, h0, w0);
-    const long long pix0 = ((long long)f * H + h0) * W + w0;
+    const int tile_pix = tc.h0 * W + tc.w0;
+    __amdgpu_buffer_rsrc_t yrs, nrs;
+    if constexpr (KEEP) yrs = __builtin_amdgcn_make_buffer_rsrc(yg + (long long)tc.f * H * W * 128, 0, frame_bytes, 0x00020000);
+    if constexpr (LN != 0) nrs = __builtin_amdgcn_make_buffer_rsrc(ng + (long long)tc.f * H * W * 128, 0, frame_bytes, 0x00020000);
     const float* pl = prm + 8 * oct_j;                         // gamma of channels [8 oct_j, +8); beta + 128, bias + 256
     f32x4 g0, g1, b0, b1;
     if constexpr (LN != 0) {
@@ -238,21 +271,23 @@ __global__ __launch_bounds__(512, 1) void conv3x3_ws2_kernel(const ConvArgs p) {
     }
     const f32x4 o0 = *reinterpret_cast<const f32x4*>(pl + 256);
     const f32x4 o1 = *reinterpret_cast<const f32x4*>(pl + 260);
-    const float* T = Tb + (v & 1) * (64 * 128);
-    const char* R = smem + W2_OFF_R + (v & 1) * W2_RBUF;
+    // lane slot `it`: row m = row_l + 16 it of the sub-tile; subtile_pixel(m + 16) = (1 - rsel(m), col(m) + 8)
+    int rsel0, col0;
+    subtile_pixel(row_l, rsel0, col0);
+    const int tbase = W2_OFF_T + par * W2_TBUF + (32 * jj + row_l) * 512 + (((2 * oct_j) ^ row_l) << 4);   // T row, my first 16-B chunk
+    const int rbase = W2_OFF_R + par * W2_RBUF + oct_j * 16;
 #pragma unroll
     for (int it = 0; it < 2; ++it) {
-      int rsel, col;
-      subtile_pixel(row_l + 16 * it, rsel, col);
-      const int prow = 2 * jj + rsel;                          // pixel (prow, col) of the 4 x 16 tile
-      const int row = 32 * jj + row_l + 16 * it;               // its T row (MFMA order)
-      const int sw = row & 31;
-      const f32x4 t0 = *reinterpret_cast<const f32x4*>(T + row * 128 + (((2 * oct_j) ^ sw) << 2));
-      const f32x4 t1 = *reinterpret_cast<const f32x4*>(T + row * 128 + (((2 * oct_j + 1) ^ sw) << 2));
+      const int prow = 2 * jj + (it == 0 ? rsel0 : 1 - rsel0);   // pixel (prow, col) of the 4 x 16 tile
+      const int col = col0 + 8 * it;
+      // T row of slot 1 = row + 16: chunk index ^ 16 (the swizzle is row & 31), 16 rows further
+      const int toff = it == 0 ? tbase : ((tbase ^ 256) + 16 * 512);
+      const f32x4 t0 = *reinterpret_cast<const f32x4*>(smem + toff);
+      const f32x4 t1 = *reinterpret_cast<const f32x4*>(smem + (toff ^ 16));
       u32x4 rw;
-      if (has_res) rw = *reinterpret_cast<const u32x4*>(R + (16 * prow + col) * W2_ROWP + oct_j * 16);
+      if (has_res) rw = *reinterpret_cast<const u32x4*>(smem + rbase + (16 * prow + col) * W2_ROWP);
       else rw[0] = rw[1] = rw[2] = rw[3] = 0u;
-      const long long pix = pix0 + (long long)prow * W + col;
+      const int pix = prow * W + col;                          // relative to the tile's first pixel
       float rv[8], s = 0.f;
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
@@ -266,8 +301,8 @@ __global__ __launch_bounds__(512, 1) void conv3x3_ws2_kernel(const ConvArgs p) {
       if constexpr (KEEP) {
         u32x4 w4;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) w4[e] = f32_to_bf16_bits(rv[2 * e]) | (f32_to_bf16_bits(rv[2 * e + 1]) << 16);
-        *reinterpret_cast<u32x4*>(yg + pix * p.ldy + 8 * oct_j) = w4;
+        for (int e = 0; e < 4; ++e) w4[e] = pack_bf16x2(rv[2 * e], rv[2 * e + 1]);
+        __builtin_amdgcn_raw_buffer_store_b128(w4, yrs, (tile_pix + pix) * 256 + oct_j * 16, 0, 0);
       }
       if constexpr (LN != 0) {
         const float mean = group_sum_dpp<16>(s) * (1.0f / 128.0f);
@@ -289,30 +324,35 @@ __global__ __launch_bounds__(512, 1) void conv3x3_ws2_kernel(const ConvArgs p) {
           pinf(rv[e]);
         }
 #pragma unroll
-        for (int e = 0; e < 4; ++e) w4[e] = f32_to_bf16_bits(rv[2 * e]) | (f32_to_bf16_bits(rv[2 * e + 1]) << 16);
-        *reinterpret_cast<u32x4*>(ng + pix * p.ldn + 8 * oct_j) = w4;
+        for (int e = 0; e < 4; ++e) w4[e] = pack_bf16x2(rv[2 * e], rv[2 * e + 1]);
+        __builtin_amdgcn_raw_buffer_store_b128(w4, nrs, (tile_pix + pix) * 256 + oct_j * 16, 0, 0);
       }
     }
   };
 
   // ---- MFMA phase of tile u for K-half KH: 36 groups x 2 sub-tiles ------------------------
   f32x16 acc[2];
-  // this lane's quad of (sub-tile jj, channel quad g) in the P / T buffer, recomputed at every use (see row_slot)
-  auto t_slot = [&](int u, int jj, int g) -> float* {
+  // this lane's quad of (sub-tile jj, channel quad g) in the P / T buffer: row 32 jj + lane % 32, 16-B chunk
+  // (8 cw + 2 g + lane / 32) ^ (lane % 32) -- 8 cw + lane / 32 and 2 g share no bits, so the chunk of quad g is the chunk of
+  // quad 0 with g << 1 XORed in: ONE base per phase (recomputed from an opaque lane id, see row_slot), one XOR per quad,
+  // the sub-tile in the instruction's offset field (the eight independent address computations of the first version
+  // were 64 instructions between the last MFMA of a phase and its barrier)
+  auto t_base = [&](int par) -> int {
     int l = lane;
     asm volatile("" : "+v"(l));
-    const int prow = 32 * jj + (l & 31);
-    const int c4 = cw * 8 + 2 * g + (l >> 5);                  // 16-B chunk of channels [32 cw + 8 g + 4 (lane / 32), +4)
-    return Tb + (u & 1) * (64 * 128) + prow * 128 + ((c4 ^ (l & 31)) << 2);
+    const int l31 = l & 31;
+    return W2_OFF_T + par * W2_TBUF + l31 * 512 + (((cw * 8 + (l >> 5)) ^ l31) << 4);
   };
+  auto t_slot = [&](int tb, int jj, int g) -> float* { return reinterpret_cast<float*>(smem + ((tb ^ (g << 5)) + jj * (32 * 512))); };
   auto mfma_phase = [&](auto kh_c, int u) {
     constexpr int KH = decltype(kh_c)::value;
+    const int tb = t_base(u & 1);
     if constexpr (KH == 1) {                                   // continue the sum of K-half 0
 #pragma unroll
       for (int jj = 0; jj < 2; ++jj)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-          const f32x4 v = *reinterpret_cast<const f32x4*>(t_slot(u, jj, g));
+          const f32x4 v = *reinterpret_cast<const f32x4*>(t_slot(tb, jj, g));
 #pragma unroll
           for (int e = 0; e < 4; ++e) acc[jj][4 * g + e] = v[e];
         }
@@ -333,6 +373,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_ws2_kernel(const ConvArgs p) {
     u32x4 xf[W2_FD + 1];
 #pragma unroll
     for (int m = 0; m < W2_FD; ++m) xf[m] = *frag_addr(m);
+    stamp(5);
     __builtin_amdgcn_s_setprio(1);
     w2_static_for<0, 72>([&](auto mc) {
       constexpr int m = decltype(mc)::value;
@@ -341,6 +382,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_ws2_kernel(const ConvArgs p) {
       __builtin_amdgcn_sched_barrier(0);
     });
     __builtin_amdgcn_s_setprio(0);
+    stamp(6);
     asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");         // last MFMA -> first reader of its accumulator
 #pragma unroll
     for (int jj = 0; jj < 2; ++jj)
@@ -349,7 +391,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_ws2_kernel(const ConvArgs p) {
         f32x4 v;
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = acc[jj][4 * g + e];
-        *reinterpret_cast<f32x4*>(t_slot(u, jj, g)) = v;
+        *reinterpret_cast<f32x4*>(t_slot(tb, jj, g)) = v;
       }
   };
   auto publish = [&]() {                                       // my LDS writes are retired, then the barrier hands the buffers over
@@ -359,12 +401,14 @@ __global__ __launch_bounds__(512, 1) void conv3x3_ws2_kernel(const ConvArgs p) {
   };
 
   // prologue: patch (group 1) and residual rows (group 0) of the first tile, parameters, first barrier
-  if (grp == 1) issue_dma(t_begin, 0, 0, 0, true, false);
-  else issue_dma(0, 0, t_begin, 0, false, has_res);
+  TileCur c_prev = cur_at(t_begin), c_cur = c_prev, c_next = c_prev;   // tiles u - 1 (from iteration 1 on), u, u + 1
+  cur_step(c_next);
+  if (grp == 1) issue_dma(c_cur, 0, c_cur, 0, true, false);
+  else issue_dma(c_cur, 0, c_cur, 0, false, has_res);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   publish();
   constexpr int NS = 2 * ((KEEP ? 1 : 0) + (LN != 0 ? 1 : 0));  // stores of a row slot
-  // iteration u: M phases of tile u, rows of tile u-1; group 1 requests patch(u+1) and the residual rows of tile u
+  // iteration u: M phases of tile u, rows of tile u-1; group 1 requests patch(u+1), group 0 the residual rows of tile u
   for (int u = 0; u <= U; ++u) {
     if constexpr (PROF) prof_u = (blockIdx.x == 0 && (u == 8 || u == 9)) ? u - 8 : -1;
     stamp(0);
@@ -374,8 +418,9 @@ __global__ __launch_bounds__(512, 1) void conv3x3_ws2_kernel(const ConvArgs p) {
     } else {
       // patch(u+1) goes where patch(u-1) was (read for the last time in iteration u-1); needed in iteration u+1, awaited
       // at the end of my MFMA phase below
-      if (u < U) issue_dma(t_begin + u + 1, (u + 1) & 1, 0, 0, u + 1 < U, false);
-      if (u >= 1) row_slot(u - 1, 0);
+      if (u < U) issue_dma(c_next, (u + 1) & 1, c_next, 0, u + 1 < U, false);
+      __builtin_amdgcn_sched_barrier(0);                       // the counted waits below rely on "requests, then stores" in issue order
+      if (u >= 1) row_slot(c_prev, (u - 1) & 1, 0);
     }
     stamp(1);
     publish();
@@ -383,6 +428,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_ws2_kernel(const ConvArgs p) {
     // ---- second half: group 1 M1(u) | group 0 rows [32,64) of tile u-1
     if (grp == 1) {
       if (u < U) mfma_phase(std::integral_constant<int, 1>{}, u);
+      stamp(7);
       // my requests of this iteration have landed once only the stores I issued behind them are outstanding
       if (u >= 1) wait_vmcnt<NS>();
       else wait_vmcnt<0>();
@@ -390,15 +436,20 @@ __global__ __launch_bounds__(512, 1) void conv3x3_ws2_kernel(const ConvArgs p) {
       // the residual rows of tile u go where those of tile u-2 were (read for the last time in iteration u-1); needed in
       // iteration u+1.  Requested ahead of my rows and stores, awaited behind them with the stores left outstanding.  (The
       // rows of the first tile came with the prologue.)
-      if (u >= 1 && u < U) issue_dma(0, 0, t_begin + u, u & 1, false, has_res);
+      if (u >= 1 && u < U) issue_dma(c_cur, 0, c_cur, u & 1, false, has_res);
+      __builtin_amdgcn_sched_barrier(0);
       if (u >= 1) {
-        row_slot(u - 1, 1);
+        row_slot(c_prev, (u - 1) & 1, 1);
+        __builtin_amdgcn_sched_barrier(0);
         wait_vmcnt<NS>();
       }
     }
     stamp(3);
     publish();
     stamp(4);
+    c_prev = c_cur;
+    c_cur = c_next;
+    cur_step(c_next);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif

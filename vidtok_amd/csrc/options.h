@@ -20,6 +20,7 @@ enum VtOpt {
   OPT_WS_ACC,              // ws128: accumulator placement (measurement aid)
   OPT_TBLOCK_FUSED,        // 1: vt_temporal_block_supported may answer yes
   OPT_TBLOCK_PROF_MODE,    // vt_temporal_block_profile: 1 = row jobs skipped
+  OPT_WS_PROF_MODE,        // vt_conv_profile on conv_ws2.hip: bit 0 = row slots skipped, bit 1 = LDS-DMA requests skipped (wrong results)
   OPT_COUNT
 };
 
