@@ -75,15 +75,16 @@ int vt_conv_max_lds_bytes(void);
  *   conv_buf (1)        gather through buffer descriptors; 0 = 64-bit pointers (always used for > 4 GiB tensors / cache mode)
  *   conv_tinner (1)     temporal convolutions walk their tiles frames-innermost (L2 reuse of the kt taps)
  *   conv_ldsepi (1)     128 x 128 tile: epilogue transposed through the LDS (whole-line stores, carries the fused LayerNorm)
- *   conv_sched (1)      K-step schedule of the 8-wave 256 x 256 tile: 0 plain loop, 1 schedule 1, 2 / 3 / 4 two-group ping-pong (bf16)
- *   conv_ws (1)         weight-stationary persistent kernel for bf16 3x3 128 -> 128 convolutions: 0 off, 1 conv_ws128.hip,
+ *   conv_sched (2)      K-step schedule of the 8-wave 256 x 256 tile: 0 plain loop, 1 schedule 1, 2 two-group ping-pong (bf16)
+ *   conv_ws (2)         weight-stationary persistent kernel for bf16 3x3 128 -> 128 convolutions: 0 off, 1 conv_ws128.hip,
  *                       2 conv_ws2.hip (two waves per SIMD splitting K)
  *   conv_narrow (1)     conv3d_narrow_kernel for Cout <= 4 (the decoder's conv_out)
  *   conv_tile (0)       128 / 256: force that tile wherever it is legal; 0 = choose by size
  *   conv_tile_min (128) fewest 256 x 256 tiles for which the 8-wave tile is chosen
  *   conv_fuse_ln (1), conv_fuse_ln256 (1)   LayerNorm of the result inside the epilogue for Cout = 128 / 256
  *   conv_ln256_v (1)    form of the Cout = 256 LayerNorm epilogue (0: round-2 form)
- *   conv_x_nt (0), ws_acc (0), tblock_fused (1), tblock_prof_mode (0), ws_prof_mode (0)   measurement aids
+ *   ws_acc (0), tblock_prof_mode (0), ws_prof_mode (0)   measurement aids
+ *   tblock_fused (1)   0: vt_temporal_block_supported answers no (blocks stay on the unfused operators)
  * Returns VT_ERR_ARG for an unknown name.
  * ---------------------------------------------------------------------------------------- */
 int vt_set_option(const char* name, int32_t value);

@@ -17,16 +17,17 @@ from vidtok_amd.ops import ConvGeom  # noqa: E402
 
 # plain schedule (VT_CONV_SCHED=0): stamps at stage start / after the vmcnt wait / after the barrier / after the address
 # set-up / at stage end; schedule 1: stage start / in front of the waits of the last sub-step / after vmcnt / after the
-# barrier / stage end; schedules 2 / 3 (two-group ping-pong): the eight phase boundaries of a step
-SCHED = int(os.environ.get("VT_CONV_SCHED", "1"))
+# barrier / stage end; schedule 2 (two-group ping-pong): the eight phase boundaries of a step.  NB: a stamp is an s_memtime plus
+# its lgkmcnt(0) -- it drains the fragment reads in flight, so the stamped kernel is slower than the shipped one (K = 13 824
+# layers: ~2 400 cycles per step by the launch time against ~3 100 here); the PROPORTIONS are what to read
+SCHED = int(os.environ.get("VT_CONV_SCHED", "2"))
 if SCHED == 0:
     NAMES = ["wait my DMA (vmcnt)", "barrier", "prep_step (addresses)", "MFMAs + DMA issue + ds_read"]
 elif SCHED == 1:
     NAMES = ["sub-steps 0-2: 24 MFMAs + 8 DMA pieces + set-up", "wait lgkm + my DMA (vmcnt)", "barrier", "sub-step 3: 8 MFMAs + next fragments"]
 else:
-    NAMES = ["LOAD(2s): 16 ds_read" + (" + 2 pieces" if SCHED == 2 else ""), "waits + barrier", "COMPUTE(2s): 16 MFMAs" + (" + 2 pieces" if SCHED >= 3 else ""),
-             "barrier", "LOAD(2s+1): 8 ds_read + set-up + " + {2: "6", 3: "2", 4: "0"}[SCHED] + " pieces", "waits + barrier",
-             "COMPUTE(2s+1): 16 MFMAs" + {2: "", 3: " + 4 pieces", 4: " + 6 pieces"}[SCHED]]
+    NAMES = ["LOAD(2s): 16 ds_read + 2 pieces", "waits + barrier", "COMPUTE(2s): 16 MFMAs", "barrier", "LOAD(2s+1): 8 ds_read + set-up + 6 pieces",
+             "waits + barrier", "COMPUTE(2s+1): 16 MFMAs"]
 NS = len(NAMES)
 
 
@@ -44,23 +45,26 @@ def main():
         rec, ops.CONV_RECORD = ops.CONV_RECORD, None
         d = rec[0][0]
         plan = ops.conv_plan(d)
-        stamps = torch.zeros((8, 4, 8), dtype=torch.int64, device=dev)
-        lib = L.load()
-        for _ in range(2):
-            L.check(lib.vt_conv_profile(C.byref(d), stamps.data_ptr(), None), "vt_conv_profile")
-        torch.cuda.synchronize()
-        s = stamps.cpu()
-        print(f"{label}: tile {plan['tile']}, {plan['workgroups']} workgroups")
-        for wv in range(8):
-            for st in range(4):
-                dl = [int(s[wv, st, k + 1] - s[wv, st, k]) for k in range(NS)]
-                nxt = int(s[wv, st + 1, 0] - s[wv, st, 0]) if st < 3 else sum(dl)
-                print(f"  wave {wv} step {8 + st}: step period {nxt:6d} | " + " | ".join(f"{n} {v}" for n, v in zip(NAMES, dl)))
-        avg = [sum(int(s[wv, st, k + 1] - s[wv, st, k]) for wv in range(8) for st in range(4)) / 32 for k in range(NS)]
-        per = sum(int(s[wv, st + 1, 0] - s[wv, st, 0]) for wv in range(8) for st in range(3)) / 24
-        print(f"  average step period {per:.0f} cycles (MFMA-bound: 2048 per SIMD = 2 waves x 32 MFMAs x 32); phases of one wave:")
-        for n, v in zip(NAMES, avg):
-            print(f"    {n:50s} {v:8.1f}")
+        for pm, pml in ((0, "as shipped"), (1, "activation pieces = zero fills"), (2, "weight pieces = zero fills"), (3, "no memory traffic in the K loop"), (4, "no DMA requests"), (8, "no address arithmetic"), (12, "no DMA requests, no address arithmetic")):
+            L.set_option("ws_prof_mode", pm)
+            stamps = torch.zeros((8, 4, 8), dtype=torch.int64, device=dev)
+            lib = L.load()
+            for _ in range(2):
+                L.check(lib.vt_conv_profile(C.byref(d), stamps.data_ptr(), None), "vt_conv_profile")
+            torch.cuda.synchronize()
+            s = stamps.cpu()
+            print(f"{label}: tile {plan['tile']}, {plan['workgroups']} workgroups, {pml}")
+            for wv in range(8 if pm == 0 else 0):
+                for st in range(4):
+                    dl = [int(s[wv, st, k + 1] - s[wv, st, k]) for k in range(NS)]
+                    nxt = int(s[wv, st + 1, 0] - s[wv, st, 0]) if st < 3 else sum(dl)
+                    print(f"  wave {wv} step {8 + st}: step period {nxt:6d} | " + " | ".join(f"{n} {v}" for n, v in zip(NAMES, dl)))
+            L.set_option("ws_prof_mode", 0)
+            avg = [sum(int(s[wv, st, k + 1] - s[wv, st, k]) for wv in range(8) for st in range(4)) / 32 for k in range(NS)]
+            per = sum(int(s[wv, st + 1, 0] - s[wv, st, 0]) for wv in range(8) for st in range(3)) / 24
+            print(f"  average step period {per:.0f} cycles (MFMA-bound: 2048 per SIMD = 2 waves x 32 MFMAs x 32); phases of one wave:")
+            for n, v in zip(NAMES, avg):
+                print(f"    {n:50s} {v:8.1f}")
 
 
 if __name__ == "__main__":

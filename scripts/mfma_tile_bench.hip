@@ -1,0 +1,166 @@
+// The K-loop skeleton of the 8-wave 256 x 256 tile in isolation: what does a K step (per wave 32 MFMAs 32x32x16 bf16, 24
+// ds_read_b128 fragment reads from 128-B swizzled tile rows, one barrier) cost when NOTHING else is in it -- no DMA, no
+// address arithmetic, no memory traffic?  (scripts/conv_profile.py with ws_prof_mode = 12 says 3 040 cycles against 2 048 of
+// matrix work, every schedule.)  One workgroup on one CU, s_memtime on every wave, cycles per K step.
+//   hipcc --offload-arch=gfx950 -O3 -o scripts/build/mfma_tile_bench scripts/mfma_tile_bench.hip
+#include <hip/hip_runtime.h>
+#include <cstdio>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+template <int I, int N, typename F>
+__device__ __forceinline__ void sfor(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    sfor<I + 1, N>(f);
+  }
+}
+#define MFMA(acc, a, b) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b))
+
+// BAR: barrier per K step; READS: 0 none, 1 real addressing, 2 one address for all; FD: read-ahead in MFMAs (stream form) or
+// 0 = the batch form of schedule 1 (the six reads of sub-step k+1 in front of the eight MFMAs of sub-step k); PRIO: 0 none,
+// 1 alternate s_setprio between the waves of a SIMD per sub-step (schedule 1), 2 setprio 1 always
+template <bool BAR, int READS, int FD, int PRIO>
+__global__ __launch_bounds__(512, 1) void kloop(unsigned long long* out, float* sink, int steps) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = wave & 1, wn = wave >> 1, wgrp = wave >> 2;
+  for (int i = threadIdx.x; i < 131072 / 16; i += blockDim.x) ((u32x4*)lds)[i] = u32x4{0x3f803f80u, 0x3e803f80u + (unsigned)i, 0x3f803f80u, 0x3f803e80u};
+  __syncthreads();
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
+  const int row = lane & 31, khalf = lane >> 5, swz = (row >> 1) & 7;
+  const char* a_base = lds + (wm * 64) * 128 + row * 128;               // A tile: 256 rows x 128 B, wave rows [64 wm, +64)
+  const char* b_base = lds + 32768 + (wn * 128) * 128 + row * 128;      // B tile: 256 rows, wave rows [128 wn... (4 waves along N)
+  auto frag = [&](int stg, int k, int i) -> const u32x4* {              // i < 2: A fragment i, else B fragment i - 2
+    const int slot = READS == 2 ? 0 : ((k * 2 + khalf) ^ swz) * 16;
+    const char* base = (i < 2 ? a_base + i * 32 * 128 : b_base + (i - 2) * 32 * 128) + stg * 65536;
+    return reinterpret_cast<const u32x4*>(READS == 2 ? lds + lane * 16 : base + slot);
+  };
+  u32x4 fr[2][6];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) fr[0][i] = fr[1][i] = u32x4{0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
+  __syncthreads();
+  const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  int stage = 0;
+  if constexpr (FD == 0) {
+    if (READS) {
+#pragma unroll
+      for (int i = 0; i < 6; ++i) fr[0][i] = *frag(0, 0, i);
+    }
+    for (int s = 0; s < steps; ++s) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        if (PRIO == 1) {
+          if (((k ^ wgrp) & 1) == 0) __builtin_amdgcn_s_setprio(2);
+          else __builtin_amdgcn_s_setprio(0);
+        }
+        if (READS && k + 1 < 4) {
+#pragma unroll
+          for (int i = 0; i < 6; ++i) fr[(k + 1) & 1][i] = *frag(stage, k + 1, i);
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          if (k == 3 && q == 4) {
+            if (BAR) {
+              asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+              __builtin_amdgcn_s_barrier();
+              asm volatile("" ::: "memory");
+            }
+            if (READS) {
+#pragma unroll
+              for (int i = 0; i < 6; ++i) fr[0][i] = *frag(stage ^ 1, 0, i);
+            }
+          }
+          MFMA(acc[q >> 1][q & 1], fr[k & 1][2 + (q >> 1)], fr[k & 1][q & 1]);
+        }
+      }
+      stage ^= 1;
+    }
+  } else {
+    // stream form: MFMA m of the step uses fragments of sub-step m / 8; the read issued behind MFMA m is the one needed
+    // soonest: reads in use order, FD MFMAs ahead (a sub-step's six fragments are all needed by its first MFMAs, so
+    // "ahead" is counted to the first MFMA of that sub-step)
+    for (int s = 0; s < steps; ++s) {
+      if (PRIO == 2) __builtin_amdgcn_s_setprio(1);
+      sfor<0, 32>([&](auto mc) {
+        constexpr int m = decltype(mc)::value;
+        constexpr int k = m >> 3, q = m & 7;
+        if constexpr (k == 3 && q == 4 && BAR) {
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          __builtin_amdgcn_s_barrier();
+          asm volatile("" ::: "memory");
+        }
+        MFMA(acc[q >> 1][q & 1], fr[k & 1][2 + (q >> 1)], fr[k & 1][q & 1]);
+        // behind MFMAs 1..6 of sub-step k: the six fragments of sub-step k + 1 (other register set)
+        if constexpr (READS != 0 && q >= 1 && q <= 6) {
+          constexpr int kn = (k + 1) & 3;
+          fr[(k + 1) & 1][q - 1] = *frag(k == 3 ? stage ^ 1 : stage, kn, q - 1);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      });
+      stage ^= 1;
+    }
+    if (PRIO == 2) __builtin_amdgcn_s_setprio(0);
+  }
+  asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+  const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+  const unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
+  float sum = 0.f;
+#pragma unroll
+  for (int a = 0; a < 4; ++a) sum += acc[a][0][0] + acc[a][1][3];
+  if (lane == 0 && blockIdx.x == 0) {
+    out[wave] = t1 - t0;
+    out[8 + wave] = r1 - r0;
+  }
+  if (sum == 12345.678f) sink[threadIdx.x] = sum;
+}
+
+template <bool BAR, int READS, int FD, int PRIO>
+void run(const char* what, unsigned long long* d_out, float* d_sink, int waves = 8, int grid = 1) {
+  const int steps = 200;
+  auto k = kloop<BAR, READS, FD, PRIO>;
+  hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+  unsigned long long t[16] = {0};
+  for (int i = 0; i < 2; ++i) {
+    hipLaunchKernelGGL(k, dim3(grid), dim3(64 * waves), 131072, 0, d_out, d_sink, steps);
+    hipError_t e = hipMemcpy(t, d_out, sizeof(t), hipMemcpyDeviceToHost);
+    if (e != hipSuccess) { printf("%s: %s\n", what, hipGetErrorString(e)); return; }
+  }
+  double lo = 1e30, hi = 0;
+  for (int w = 0; w < waves; ++w) { lo = t[w] < lo ? t[w] : lo; hi = t[w] > hi ? t[w] : hi; }
+  printf("%-100s %7.0f .. %7.0f s_memtime ticks per K step (matrix work: %d); %.1f ns per step by s_memrealtime (100 MHz) -> %.2f ticks per ns\n", what, lo / steps, hi / steps,
+         waves == 8 ? 2048 : 1024, (double)t[8] * 10.0 / steps, (double)t[0] / ((double)t[8] * 10.0));
+  fflush(stdout);
+}
+
+int main() {
+  unsigned long long* d_out; float* d_sink;
+  hipMalloc(&d_out, 256); hipMalloc(&d_sink, 4096);
+  run<false, 0, 0, 0>("MFMAs only, 8 waves", d_out, d_sink);
+  run<false, 0, 0, 0>("MFMAs only, 4 waves (one per SIMD)", d_out, d_sink, 4);
+  run<true, 0, 0, 0>("MFMAs + barrier per step", d_out, d_sink);
+  run<false, 1, 0, 0>("batch reads (schedule 1 form), no barrier", d_out, d_sink);
+  run<true, 1, 0, 0>("batch reads + barrier", d_out, d_sink);
+  run<true, 1, 0, 1>("batch reads + barrier + alternating priority (= schedule 1's skeleton)", d_out, d_sink);
+  run<true, 2, 0, 1>("... all reads from one conflict-free address pattern", d_out, d_sink);
+  run<true, 1, 0, 1>("... 4 waves (one per SIMD)", d_out, d_sink, 4);
+  run<false, 1, 6, 0>("stream form: one read behind each of MFMAs 1-6 of a sub-step, no barrier", d_out, d_sink);
+  run<true, 1, 6, 0>("stream form + barrier", d_out, d_sink);
+  run<true, 1, 6, 2>("stream form + barrier + setprio 1", d_out, d_sink);
+  run<true, 2, 6, 0>("stream form + barrier, one address pattern", d_out, d_sink);
+  run<true, 1, 6, 0>("stream form + barrier, 4 waves", d_out, d_sink, 4);
+  printf("the same on every CU (grid 256) and oversubscribed (grid 1024):\n");
+  run<false, 0, 0, 0>("MFMAs only, 8 waves", d_out, d_sink, 8, 256);
+  run<true, 1, 0, 1>("batch reads + barrier + alternating priority (= schedule 1's skeleton)", d_out, d_sink, 8, 256);
+  run<true, 1, 6, 0>("stream form + barrier", d_out, d_sink, 8, 256);
+  run<true, 1, 0, 1>("batch reads + barrier + alternating priority, grid 1024", d_out, d_sink, 8, 1024);
+  return 0;
+}

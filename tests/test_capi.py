@@ -203,17 +203,17 @@ def test_options_table(built_lib, monkeypatch):
     with pytest.raises(L.VtError):
         L.get_option("no_such_option")
     built_lib.vt_reset_options()
-    assert L.get_option("conv_sched") == 1 and L.get_option("conv_tile_min") == 128
+    assert L.get_option("conv_sched") == 2 and L.get_option("conv_tile_min") == 128
     with L.options(conv_sched=0, conv_tile_min=7):
         assert L.get_option("conv_sched") == 0 and L.get_option("conv_tile_min") == 7
-        monkeypatch.setenv("VT_CONV_SCHED", "2")          # the environment is not consulted after start-up ...
+        monkeypatch.setenv("VT_CONV_SCHED", "1")          # the environment is not consulted after start-up ...
         assert L.get_option("conv_sched") == 0
-    assert L.get_option("conv_sched") == 1
-    built_lib.vt_reset_options()                           # ... except by an explicit reset
     assert L.get_option("conv_sched") == 2
+    built_lib.vt_reset_options()                           # ... except by an explicit reset
+    assert L.get_option("conv_sched") == 1
     monkeypatch.delenv("VT_CONV_SCHED")
     built_lib.vt_reset_options()
-    assert L.get_option("conv_sched") == 1
+    assert L.get_option("conv_sched") == 2
 
 
 def test_bench_committed_traffic_fallback(tmp_path, monkeypatch):

@@ -21,7 +21,7 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-u
 # (profiles/r02_mfma_issue_microbench.txt) -- so no SLP there, and the instruction scheduler stays free to interleave
 # the chains (the asm pins that used to keep the elements apart also kept every chain in program order: 63 s_nop of
 # hazard padding in a 540-instruction row slot)
-EXTRA_FLAGS = {"conv_ws2.hip": ["-fno-slp-vectorize"]}
+EXTRA_FLAGS = {"conv_ws2.hip": ["-fno-slp-vectorize"], "tblock_ws128.hip": ["-fno-slp-vectorize"]}
 
 
 def _hipcc():

@@ -584,6 +584,10 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_igemm_glds_ker
   // against extent 0 (every lane out of range: zeros into a slot nobody reads again, no memory traffic), so
   // the K loop has no branch around any piece and ONE straight-line body
   unsigned ext_x = BUF ? p.x_bytes : 0u, ext_w = BUF ? p.w_bytes : 0u;
+  if constexpr (PROF) {            // measurement (option ws_prof_mode): bit 0 / bit 1 = activation / weight pieces become zero fills (no memory traffic)
+    if (p.prof_mode & 1) ext_x = 0u;
+    if (p.prof_mode & 2) ext_w = 0u;
+  }
 
   const int pos = tid % NS;                                  // 16-B slot this lane writes in its rows
   const int srow = tid / NS;                                 // rows srow + RSTEP*i
@@ -619,7 +623,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_igemm_glds_ker
   // SCHED 2 stages the weight rows as two half-tiles (rows [0, 128) = the channel sub-tiles a = 0, 1 of both wave columns,
   // rows [128, 256) = a = 2, 3), each refilled as soon as its own last fragment read is over: LDS row
   // (a >> 1) * 128 + wn * 64 + (a & 1) * 32 + l holds channel wn * 128 + a * 32 + l of the tile
-  constexpr bool S2 = (SCHED >= 2 && SCHED <= 4) && (WAVES_M * WAVES_N == 8) && FAST && BUF;
+  constexpr bool S2 = SCHED == 2 && (WAVES_M * WAVES_N == 8) && FAST && BUF;
 #pragma unroll
   for (int j = 0; j < B_VECS; ++j) {
     const int lr = srow + RSTEP * j;
@@ -711,6 +715,9 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_igemm_glds_ker
   // addresses of the NEXT pipeline step (VALU/SALU only; the DMA pieces are fired separately so they can
   // be interleaved with the MFMAs of the stage being computed)
   auto prep_step = [&](int s) {
+    if constexpr (PROF) {
+      if (p.prof_mode & 8) return;             // measurement: no address arithmetic (the pieces keep their first addresses)
+    }
     if (FAST) {
       if (q_cc == 0) {               // uniform branch: new tap -> new gather addresses
         if constexpr (BUF) {
@@ -781,14 +788,17 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_igemm_glds_ker
   };
   // DMA piece q (0 .. IPS-1) of the prepared step into ring slot `stage`
   auto fire_piece = [&](int q, int stage) {
+    if constexpr (PROF) {
+      if (p.prof_mode & 4) return;             // measurement: no DMA requests at all (the K loop computes on stale tiles)
+    }
     char* As = smem + stage * STAGE_BYTES + lds_row_off;
     if (q < A_VECS) {
       if constexpr (BUF) {
         const __amdgpu_buffer_rsrc_t rsrc_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<MT*>(xg), 0, ext_x, 0x00020000);
-        // (x_nt: the activation rows stream through -- each is used by one tile and its halo neighbours -- while the weight slab
-        // of the channel tile is re-read by every pixel tile of the XCD: the hint asks the L2 to let go of x first)
-        if (p.x_nt) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (lds_ptr_t)(As + (RSTEP * q) * ROWB), 16, a_off[q], s_a, 0, 2);
-        else __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (lds_ptr_t)(As + (RSTEP * q) * ROWB), 16, a_off[q], s_a, 0, 0);
+        // (a non-temporal hint on these gathers -- "let the L2 drop x first, keep the weight slab" -- was measured and lost:
+        // 833 -> 778-793 frames/s, profiles/r03_traffic_by_layer_group.txt; and a run-time switch in front of every piece is a
+        // branch in the K loop)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (lds_ptr_t)(As + (RSTEP * q) * ROWB), 16, a_off[q], s_a, 0, 0);
       } else {
         const MT* src = a_ptr[q] ? a_ptr[q] + coff : zero;
         __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)(As + (RSTEP * q) * ROWB), 16, 0, 0);
@@ -832,7 +842,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_igemm_glds_ker
   constexpr bool S1 = SCHED == 1 && EIGHT_WAVES;
   constexpr int FIRE_SPAN = S1 ? NM / 2 : NM;         // MFMA groups over which the DMA pieces of the next stage are spread
   constexpr int MPP = (FIRE_SPAN + IPS - 1) / IPS;    // ... per DMA piece
-  const int wgrp = (tid >> 6) >> 2;                   // 8 waves: 0 = first wave of its SIMD, 1 = second
+  const int wgrp = __builtin_amdgcn_readfirstlane((int)(tid >> 8));   // 8 waves: 0 = first wave of its SIMD, 1 = second (uniform: a scalar branch, not an exec mask)
 
   // stage `stage` -> MFMAs; if FIRE, the IPS DMA pieces of the prepared step go to ring slot `dst`,
   // one after every MPP MFMA groups, so their issue cost hides under the matrix pipe.  Fragments are
@@ -919,26 +929,10 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_igemm_glds_ker
     // phase reads, and a barrier lies between that wait and any other wave's read (guide: read a staged buffer one
     // phase after the wait that retires it).
     static_assert(STAGES == 2 && D == 1 && KS == 4 && TM == 2 && TN == 4 && A_VECS == 4 && B_VECS == 4, "schedule 2: the 8-wave 256 x 256 tile");
-    // SCHED 3 = the same phases with the DMA pieces moved out of the load phases: six pieces back to back next to eight
-    // fragment reads made the odd load phase the longest interval of a step (measured: schedule 2 gained 3 % on the
-    // long-K layers where the phase count promised 20 %; the guide prices a piece at 100-185 cycles inside such a phase
-    // against ~60 between bare MFMAs).  Pieces per phase:   LOAD(2s) none            COMPUTE(2s)   W1(s+1)              (2)
-    //                                                      LOAD(2s+1) XX(s+2) 0,1   COMPUTE(2s+1) XX(s+2) 2,3 W0(s+2)  (4)
-    // issue order ... L(2s+1):2 C(2s+1):4 C(2s+2):2 L(2s+3):2 ...  =>  the next phase's operands are everything but the
-    // youngest 4 (end of an odd load phase) / youngest 6 (end of an even one).  A half-tile is requested at the earliest
-    // in the interval after both groups' last reads of its region are retired (same argument as schedule 2, one barrier
-    // later for the pieces that moved into a compute phase).
-    // SCHED 4 = what the stamps of 2 and 3 ask for (profiles/r03_igemm_step_cycles_sched{2,3}.txt): a load phase issues its
-    // 16 ds_read_b128 in ~480 cycles and then sat 200-300 more at lgkmcnt(0) in front of the barrier while the partner's
-    // 16 MFMAs (~640 next to a loading wave) were long done -- every interval lasted ~830 cycles instead of 512.  Here the
-    // barrier comes FIRST and the wave waits for its fragments behind it, at the head of its compute phase (they have had
-    // the barrier's own latency to arrive).  The reads of a phase are then no longer retired when the next interval
-    // starts, so no piece may be requested in a load phase any more (schedule 2 / 3 refill a region in the interval right
-    // after its last read): ALL pieces ride in compute phases -- C(2s): W1(s+1) (2), C(2s+1): XX(s+2) W0(s+2) (6) --, one
-    // barrier further down than any wave's lgkmcnt(0) for the reads of that region.  Issue order ... C(2s+1):6 C(2s+2):2 ...
-    // => everything but the youngest 2 (end of an odd load phase) / youngest 6 (even) is what the next phase reads.
-    constexpr bool PC = SCHED >= 3;
-    constexpr bool LATE_WAIT = SCHED == 4;
+    // Two variations were measured and dropped (history: commits 1d8f768..c099519, profiles/r03_igemm_step_cycles_sched{3,4}.txt):
+    // the DMA pieces moved from the load phases into the compute phases (847 against 863 frames/s), and that plus the
+    // barrier in front of the fragment wait (818 against 841).  What the K loop costs when nothing but MFMAs, fragment reads
+    // and one barrier per step is in it: scripts/mfma_tile_bench.hip (2 130-2 260 cycles per step against 2 048).
     const int grp = __builtin_amdgcn_readfirstlane((int)(tid >> 8));     // 0: waves 0-3, 1: waves 4-7 (one barrier behind)
     const char* a_base = smem + (wm * TM * 32) * ROWB + frag_row;
     const char* b_base = smem + A_BYTES + (wn * 64) * ROWB + frag_row;
@@ -957,32 +951,21 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_igemm_glds_ker
 #pragma unroll
         for (int k = 0; k < KS; ++k) wf[a2][k] = *reinterpret_cast<const u32x4*>(Bs + a2 * 32 * ROWB + (((k * 2 + khalf) ^ swz) * 16));
     };
-    auto end_load = [&](auto odd_c) {   // my pieces for the next phase's reads have landed, my reads of this phase are retired
-      if constexpr (LATE_WAIT) {
-        if constexpr (decltype(odd_c)::value) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-      } else if constexpr (!PC) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
-      else if constexpr (decltype(odd_c)::value) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+    auto end_load = [&]() {   // my pieces for the next phase's reads have landed, my reads of this phase are retired
+      asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
-      if constexpr (LATE_WAIT) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_sched_barrier(0);
     };
-    // COMPUTE phase of channel half HF; with PC the pieces [Q0, Q1) of the prepared step go out behind every EVERY-th MFMA
-    auto compute = [&](auto hf_c, auto q0_c, auto q1_c, int dst) {
-      constexpr int HF = decltype(hf_c)::value, Q0 = decltype(q0_c)::value, Q1 = decltype(q1_c)::value;
-      constexpr int NQ = Q1 - Q0, EVERY = NQ > 0 ? 16 / (NQ + 1) : 16;
+    // COMPUTE phase of channel half HF: 16 MFMAs, nothing else
+    auto compute = [&](auto hf_c) {
+      constexpr int HF = decltype(hf_c)::value;
       __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int k = 0; k < KS; ++k)
 #pragma unroll
         for (int a2 = 0; a2 < 2; ++a2)
 #pragma unroll
-          for (int b = 0; b < TM; ++b) {
-            mma_step<MT>(wf[a2][k], xf[b][k], acc[2 * HF + a2][b]);
-            const int m = (k * 2 + a2) * TM + b + 1;       // MFMAs issued so far in this phase
-            if (NQ > 0 && m % EVERY == 0 && m / EVERY <= NQ) fire_piece(Q0 + m / EVERY - 1, dst);
-          }
+          for (int b = 0; b < TM; ++b) mma_step<MT>(wf[a2][k], xf[b][k], acc[2 * HF + a2][b]);
       __builtin_amdgcn_s_setprio(0);
       __builtin_amdgcn_sched_barrier(0);
     };
@@ -1013,15 +996,12 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_igemm_glds_ker
       // ---- phase 2s
       read_x(stg);
       read_w(stg, 0);
-      if constexpr (!PC) {
-        fire_piece(A_VECS + 2, stg ^ 1);           // W1(s+1): addresses of step s+1 are the last ones prepared
-        fire_piece(A_VECS + 3, stg ^ 1);
-      }
+      fire_piece(A_VECS + 2, stg ^ 1);             // W1(s+1): addresses of step s+1 are the last ones prepared
+      fire_piece(A_VECS + 3, stg ^ 1);
       stamp(1);
-      end_load(I0{});
+      end_load();
       stamp(2);
-      if constexpr (PC) compute(I0{}, std::integral_constant<int, A_VECS + 2>{}, std::integral_constant<int, A_VECS + 4>{}, stg ^ 1);
-      else compute(I0{}, I0{}, I0{}, 0);
+      compute(I0{});
       stamp(3);
       __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
@@ -1031,20 +1011,12 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_igemm_glds_ker
       if (s + 2 < p.nsteps) prep_step(s + 2);
       else ext_x = ext_w = 0u;                     // past the last step: the pieces below turn into zero fills
       // XX(s+2), W0(s+2) into the regions read for the last time in phase 2s
-      if constexpr (LATE_WAIT) {
-      } else if constexpr (PC) {
-        fire_piece(0, stg);
-        fire_piece(1, stg);
-      } else {
 #pragma unroll
-        for (int q = 0; q < A_VECS + 2; ++q) fire_piece(q, stg);
-      }
+      for (int q = 0; q < A_VECS + 2; ++q) fire_piece(q, stg);
       stamp(5);
-      end_load(I1{});
+      end_load();
       stamp(6);
-      if constexpr (LATE_WAIT) compute(I1{}, I0{}, std::integral_constant<int, A_VECS + 2>{}, stg);
-      else if constexpr (PC) compute(I1{}, std::integral_constant<int, 2>{}, std::integral_constant<int, A_VECS + 2>{}, stg);
-      else compute(I1{}, I0{}, I0{}, 0);
+      compute(I1{});
       stamp(7);
       if (!(grp == 1 && s + 1 == p.nsteps)) {      // waves 4-7 entered one barrier late: they leave without the last one
         __builtin_amdgcn_s_barrier();
@@ -1095,16 +1067,16 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_igemm_glds_ker
           const int a = qq / TM, b = qq % TM;
           const int q = k * TM * TN + qq;
           if (k + 1 == KS && qq == BAR_AT) {
-            if (s + 1 < p.nsteps) {
-              stamp(1);
-              asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // my last fragments of this slot are in registers
-              wait_vmcnt<0>();                                      // my pieces of the next stage have landed
-              stamp(2);
-              __builtin_amdgcn_s_barrier();
-              asm volatile("" ::: "memory");
-              stamp(3);
-              read_frags(stage ^ 1, 0, 0);
-            }
+            // also in the last step (nothing in the loop body is conditional): the barrier is matched by every wave, the
+            // fragments read behind it come from a slot nobody writes any more and are never used
+            stamp(1);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // my last fragments of this slot are in registers
+            wait_vmcnt<0>();                                      // my pieces of the next stage have landed
+            stamp(2);
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            stamp(3);
+            read_frags(stage ^ 1, 0, 0);
           }
           mma_step<MT>(wf[k & 1][a], xf[k & 1][b], acc[a][b]);
           if ((q + 1) % MPP == 0) {
@@ -1220,26 +1192,21 @@ int launch_variant(const ConvArgs& a_in, int nbatch, hipStream_t stream) {
   const bool buf = conv_buf() && xb < 0xFFFF0000ull && wb < 0xFFFF0000ull && a.tmode != VT_TPAD_CACHE &&
                    a.KH <= 8 && a.KW <= 8;   // the per-row padding mask of the FAST form holds 8 bits per axis
   const void* kern;
-  // VT_CONV_SCHED=0: the plain K-step schedule of the 8-wave tile (A/B runs); default 1, see the kernel
+  // option conv_sched: 0 = the plain K-step loop of the 8-wave tile, 1 = schedule 1, 2 (default) = ping-pong; see the kernel
   constexpr bool HAS_S1 = WAVES_M * WAVES_N == 8 && FAST;
   constexpr bool HAS_S2 = HAS_S1 && std::is_same<MT, bf16_t>::value;    // schedule 2 (ping-pong): bf16 operands only
   const int sched_opt = vt_opt(OPT_CONV_SCHED);
-  const bool s4 = HAS_S2 && buf && sched_opt == 4;
-  const bool s3 = HAS_S2 && buf && sched_opt == 3;
-  const bool s2 = HAS_S2 && buf && sched_opt == 2;
-  const bool s1 = HAS_S1 && buf && sched_opt != 0 && !s2 && !s3 && !s4;
+  const bool s2 = HAS_S2 && buf && sched_opt >= 2;
+  const bool s1 = HAS_S1 && buf && sched_opt != 0 && !s2;
   if (buf) {
     a.x_bytes = (unsigned)xb;
     a.w_bytes = (unsigned)wb;
-    a.x_nt = vt_opt(OPT_CONV_X_NT) != 0 ? 1 : 0;
     kern = reinterpret_cast<const void*>(&conv_igemm_glds_kernel<MT, TOut, WAVES_M, WAVES_N, TM, TN, FAST, ROWB, STAGES, true, LN256>);
     if constexpr (HAS_S1) {
       if (s1) kern = reinterpret_cast<const void*>(&conv_igemm_glds_kernel<MT, TOut, WAVES_M, WAVES_N, TM, TN, FAST, ROWB, STAGES, true, LN256, false, 1>);
     }
     if constexpr (HAS_S2) {
       if (s2) kern = reinterpret_cast<const void*>(&conv_igemm_glds_kernel<MT, TOut, WAVES_M, WAVES_N, TM, TN, FAST, ROWB, STAGES, true, LN256, false, 2>);
-      if (s3) kern = reinterpret_cast<const void*>(&conv_igemm_glds_kernel<MT, TOut, WAVES_M, WAVES_N, TM, TN, FAST, ROWB, STAGES, true, LN256, false, 3>);
-      if (s4) kern = reinterpret_cast<const void*>(&conv_igemm_glds_kernel<MT, TOut, WAVES_M, WAVES_N, TM, TN, FAST, ROWB, STAGES, true, LN256, false, 4>);
     }
   } else {
     kern = reinterpret_cast<const void*>(&conv_igemm_glds_kernel<MT, TOut, WAVES_M, WAVES_N, TM, TN, FAST, ROWB, STAGES, false, LN256>);
@@ -1248,9 +1215,7 @@ int launch_variant(const ConvArgs& a_in, int nbatch, hipStream_t stream) {
   if (a.prof != nullptr) {   // vt_conv_profile: only the plain 8-wave bf16 instantiation carries the stamps
     if constexpr (std::is_same<MT, bf16_t>::value && std::is_same<TOut, bf16_t>::value && WAVES_M == 4 && WAVES_N == 2 && FAST && LN256 == 0) {
       VT_CHECK_ARG(buf, "vt_conv_profile: descriptor gather only");
-      kern = s4 ? reinterpret_cast<const void*>(&conv_igemm_glds_kernel<MT, TOut, WAVES_M, WAVES_N, TM, TN, FAST, ROWB, STAGES, true, 0, true, 4>)
-           : s3 ? reinterpret_cast<const void*>(&conv_igemm_glds_kernel<MT, TOut, WAVES_M, WAVES_N, TM, TN, FAST, ROWB, STAGES, true, 0, true, 3>)
-           : s2 ? reinterpret_cast<const void*>(&conv_igemm_glds_kernel<MT, TOut, WAVES_M, WAVES_N, TM, TN, FAST, ROWB, STAGES, true, 0, true, 2>)
+      kern = s2 ? reinterpret_cast<const void*>(&conv_igemm_glds_kernel<MT, TOut, WAVES_M, WAVES_N, TM, TN, FAST, ROWB, STAGES, true, 0, true, 2>)
            : s1 ? reinterpret_cast<const void*>(&conv_igemm_glds_kernel<MT, TOut, WAVES_M, WAVES_N, TM, TN, FAST, ROWB, STAGES, true, 0, true, 1>)
                 : reinterpret_cast<const void*>(&conv_igemm_glds_kernel<MT, TOut, WAVES_M, WAVES_N, TM, TN, FAST, ROWB, STAGES, true, 0, true, 0>);
       lds_bytes = LDS + 4096;
@@ -1260,8 +1225,8 @@ int launch_variant(const ConvArgs& a_in, int nbatch, hipStream_t stream) {
     }
   }
   // the attribute is per device: one flag per (instantiation, gather form, device), set race-free
-  static std::atomic<bool> attr_done[6][kMaxDevices];
-  const int ki = buf ? (s4 ? 5 : (s3 ? 4 : (s2 ? 3 : (s1 ? 2 : 1)))) : 0;
+  static std::atomic<bool> attr_done[4][kMaxDevices];
+  const int ki = buf ? (s2 ? 3 : (s1 ? 2 : 1)) : 0;
   int dev = 0;
   VT_CHECK_HIP(hipGetDevice(&dev));
   if (dev < 0 || dev >= kMaxDevices || !attr_done[ki][dev].load(std::memory_order_acquire)) {

@@ -8,7 +8,7 @@ enum VtOpt {
   OPT_CONV_BUF = 0,        // 1: gather through buffer descriptors (buffer_load ... lds); 0: 64-bit pointers (global_load_lds)
   OPT_CONV_TINNER,         // 1: temporal convs walk the tiles frames-innermost
   OPT_CONV_LDSEPI,         // 1: 128 x 128 tile: epilogue transposed through the LDS (needed by its fused LayerNorm)
-  OPT_CONV_SCHED,          // K-step schedule of the 8-wave tile: 0 plain loop, 1 schedule 1, 2 / 3 / 4 two-group ping-pong
+  OPT_CONV_SCHED,          // K-step schedule of the 8-wave tile: 0 plain loop, 1 schedule 1, 2 two-group ping-pong
   OPT_CONV_WS,             // weight-stationary persistent kernel for the 3x3 128 -> 128 convolutions: 0 off, 1 conv_ws128.hip, 2 conv_ws2.hip
   OPT_CONV_NARROW,         // 1: conv3d_narrow_kernel for Cout <= 4
   OPT_CONV_TILE,           // 0 auto, 128 / 256: force the tile where legal
@@ -16,10 +16,9 @@ enum VtOpt {
   OPT_CONV_FUSE_LN,        // 1: LayerNorm in the 128 x 128 tile's epilogue (Cout = 128)
   OPT_CONV_FUSE_LN256,     // 1: LayerNorm in the 8-wave tile's epilogue (Cout = 256)
   OPT_CONV_LN256_V,        // LN256 epilogue variant: 0 = round-2 form, 1 = residual prefetch + packed row arithmetic
-  OPT_CONV_X_NT,           // 1: activation gathers of the implicit-GEMM kernel carry the non-temporal hint (measurement aid)
   OPT_WS_ACC,              // ws128: accumulator placement (measurement aid)
-  OPT_TBLOCK_FUSED,        // 1: vt_temporal_block_supported may answer yes
-  OPT_TBLOCK_PROF_MODE,    // vt_temporal_block_profile: 1 = row jobs skipped
+  OPT_TBLOCK_FUSED,        // 0: vt_temporal_block_supported answers no (the host keeps the blocks on the unfused operators)
+  OPT_TBLOCK_PROF_MODE,    // vt_temporal_block_profile: bit 0 GEMMs skipped, bit 1 row units skipped, bit 4 no stores (wrong results)
   OPT_WS_PROF_MODE,        // vt_conv_profile on conv_ws2.hip: bit 0 = row slots skipped, bit 1 = LDS-DMA requests skipped (wrong results)
   OPT_COUNT
 };

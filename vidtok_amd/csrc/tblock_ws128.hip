@@ -7,9 +7,9 @@
 // input, the intermediate twice, the residual, the result and the next norm -- ~2 KiB -- in two launches of 1.45 ms.
 // Here a block reads x once and writes y (+ the next norm) once: 512-768 B per pixel, one launch.
 //
-// Structure (weight-stationary like conv_ws128.hip): one workgroup per CU; the weights of BOTH convolutions stay in
-// registers for the lifetime of the kernel.  A workgroup owns pixel columns -- 64 consecutive pixels of one clip -- and
-// walks each column through time:
+// Structure (weight-stationary): one workgroup per CU; the weights of BOTH convolutions stay in registers for the
+// lifetime of the kernel (conv1 in waves 0-3, conv2 in waves 4-7).  A workgroup owns pixel columns -- 64 consecutive
+// pixels of one clip -- and walks each column through time:
 //   step t:  x[t] rows (prefetched into registers) -> LN1+SiLU -> ring1[t % 3]                         (LDS, bf16)
 //            GEMM1: taps = ring1 slots of frames t-2, t-1, t                 -> T1 (bf16, transposed)  (LDS)
 //            rows of T1 + b1 -> LN2+SiLU -> ring2[t % 3]
@@ -17,8 +17,9 @@
 //            rows of T2 + b2 + x[t] -> y[t], LayerNorm_next -> n[t]                                     (HBM)
 // Causal padding: frames before the clip are zeros (v1.0: their taps are skipped) or the first frame repeated (v1.1
 // first chunk / un-tiled).  Chunk-to-chunk caches (v1.1 tiling) are not handled here: the host keeps those blocks on
-// the unfused path.  (The first generation of this kernel -- four waves, one per SIMD, every phase on the same wave:
-// 14 960 cycles per step -- is in the history at commit da80542.)
+// the unfused path.  Earlier arrangements are in the history: four waves, every phase on the same wave (14 960 cycles
+// per step; commit da80542), and eight waves in two roles -- matrix waves / row waves (11 000 cycles; commit ee72952,
+// profiles/r02_tblock_v3_phase_cycles.txt).
 #include <atomic>
 #include <type_traits>
 
@@ -49,7 +50,7 @@ struct TBlockArgs {
   int ln_next;        // 0 none, 1 LayerNorm, 2 LayerNorm + SiLU
   float eps;
   unsigned long long* prof;   // PROF instantiation only (vt_temporal_block_profile): cycle stamps of workgroup 0
-  int prof_mode;              // PROF only: 1 = row jobs skipped (wrong results; times the bare GEMMs), VT_TBLOCK_PROF_MODE
+  int prof_mode;              // PROF only (option tblock_prof_mode): bit 0 GEMMs skipped, bit 1 row units skipped, bit 4 no stores (wrong results)
 };
 
 template <int I, int N, typename F>
@@ -60,118 +61,27 @@ __device__ __forceinline__ void tb_static_for(F&& f) {
   }
 }
 
-// LayerNorm (+SiLU) of one pixel row held by 16 lanes x 8 channels; two-pass statistics like layernorm_act_kernel.
-// Every row phase exists twice -- sliced into MFMA shadows, and plain (first / last step of a workgroup, steps with
-// skipped taps) -- so nothing here may depend on FMA contraction (off for this file; fused multiply-adds are spelled
-// out): a pixel's bits must not depend on which version computed it, i.e. on how columns were split over workgroups.
-//
-// The block is bound by its VALU work, not by the MFMAs (three LayerNorm+SiLU per element against 2 x 24 MFMAs per 64
-// pixels: per step and wave ~1200 VALU + 200 transcendental instructions = ~8 000 issue cycles against 3 072 MFMA
-// cycles, counted on the ISA), so the row arithmetic runs on channel PAIRS: v_pk_add / v_pk_mul / v_pk_fma_f32 carry two
-// elements per instruction, one v_cvt_pk_bf16_f32 packs a pair; only exp and rcp stay per element.
+// Row arithmetic: LayerNorm (+SiLU) of a pixel row held by 16 lanes x 8 channels, two-pass statistics like
+// layernorm_act_kernel, plain (unpacked) fp32 -- a packed-fp32 instruction does not execute while an MFMA of the OTHER
+// wave of its SIMD is in flight (profiles/r02_tblock_v3_phase_cycles.txt: an L2 pass in v_pk_* form took 4 430 cycles next
+// to a GEMM, 2 020 with the matrix pipe idle).  Nothing may depend on FMA contraction (off for this file; fused
+// multiply-adds are spelled out): a pixel's bits must not depend on the code path that computed it (guarded first /
+// last steps and straight-line middle steps are separate instantiations of the same source).
 #pragma clang fp contract(off)
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 tb_bf16x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ f32x2 tb_unpack2(uint32_t w) {            // bf16 pair (low half = even channel) -> fp32 pair
-  f32x2 r;
-  r[0] = __uint_as_float(w << 16);
-  r[1] = __uint_as_float(w & 0xffff0000u);
-  return r;
-}
 __device__ __forceinline__ uint32_t tb_pack2(f32x2 v) {              // round-to-nearest-even, one v_cvt_pk_bf16_f32
   return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, tb_bf16x2));
 }
-__device__ __forceinline__ f32x2 tb_silu2(f32x2 u) {                 // u * sigmoid(u), the arithmetic of silu_fast
-  const f32x2 t = u * -1.4426950408889634f;
-  f32x2 e;
-  e[0] = __builtin_amdgcn_exp2f(t[0]);
-  e[1] = __builtin_amdgcn_exp2f(t[1]);
-  const f32x2 d = e + 1.0f;
-  f32x2 r;
-  r[0] = __builtin_amdgcn_rcpf(d[0]);
-  r[1] = __builtin_amdgcn_rcpf(d[1]);
-  return u * r;
-}
-__device__ __forceinline__ f32x2 tb_affine_act2(f32x2 d, float rstd, f32x2 g, f32x2 b, bool silu) {
-  const f32x2 u = __builtin_elementwise_fma(d * rstd, g, b);
-  return silu ? tb_silu2(u) : u;
-}
-template <bool SILU>
-__device__ __forceinline__ void tb_row_norm2(f32x2 (&v)[4], const f32x2 (&g)[4], const f32x2 (&b)[4], float eps, f32x2 (&o)[4]) {
-  f32x2 s = v[0];
-#pragma unroll
-  for (int q = 1; q < 4; ++q) s = s + v[q];
-  const float mean = group_sum_dpp<16>(s[0] + s[1]) * (1.0f / 128.0f);
-  f32x2 d[4], qq = {0.f, 0.f};
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    d[q] = v[q] - mean;
-    qq = __builtin_elementwise_fma(d[q], d[q], qq);
-  }
-  const float rstd = __builtin_amdgcn_rsqf(__builtin_fmaf(group_sum_dpp<16>(qq[0] + qq[1]), 1.0f / 128.0f, eps));
-#pragma unroll
-  for (int q = 0; q < 4; ++q) o[q] = tb_affine_act2(d[q], rstd, g[q], b[q], SILU);
-}
-
-// "This value exists HERE" (see conv_ws128.hip): keeps a slice of row arithmetic in the MFMA shadow the source put it in
-__device__ __forceinline__ void tb_pin(float& v) { asm volatile("" : "+v"(v)); }
-__device__ __forceinline__ void tb_pin2(f32x2& v) { asm volatile("" : "+v"(v)); }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// The block on EIGHT waves with two roles.  What the cycle stamps of the one-role kernel showed
-// (profiles/r02_tblock_phase_cycles.txt): a 64-pixel step costs 14 960 cycles of which 3 072 are
-// MFMA; the three LayerNorm+SiLU per element are ~6 300 issue cycles of VALU work that a single wave per SIMD cannot put
-// behind its own MFMAs (an MFMA hides at most ~6 plain VALU instructions, and no packed-fp32 one).  So the SIMD gets a
-// second wave: waves 0-3 ("matrix waves", one per SIMD) keep the stationary weights and do nothing but the two GEMMs and
-// the accumulator transposes; waves 4-7 ("row waves") do every row phase.  The dependency chain of a step,
-//     L1(t) -> G1(t) -> L2(t) -> G2(t) -> O(t)        (L = LayerNorm+SiLU rows, G = GEMM, O = + x, y / next-norm stores)
-// is software-pipelined over the virtual steps k of a workgroup, two phases per step, one barrier each:
-//     phase A_k:  matrix: T2 <- acc2 (conv2 of step k-2), G1(k) -> acc1        rows: L2(k-1): T1 -> ring2
-//     phase B_k:  matrix: T1 <- acc1 (conv1 of step k), G2(k-1) -> acc2        rows: O(k-2): T2 (+ x) -> y, n;  L1(k+1) -> ring1
-// Every buffer is written in one phase and read in the next one (or later): ring slots by virtual step mod 3 (slot k+1 of
-// ring1 is rewritten in B_k, last read by G1(k) in A_k; slot k-1 of ring2 in A_k, last read by G2(k-2) in B_{k-1}); T1
-// holds conv1 as bf16 (272-B rows; b1 is added by the row waves), T2 conv2 in fp32.
-// LDS: 2 x 52 224 + 17 408 + 32 768 = 154 624 B.  Registers: 256 per wave (two waves per SIMD): 192 weights + 2 x 32
-// accumulators would not fit, so G1 and G2 share ONE accumulator set (each is parked in its T buffer right after the
-// barrier that ends its phase).
+// LDS: two rings of three 64-row slots (bf16 rows of 272 B: 256 + 16 pad), T1 (conv1 rounded to bf16, 272-B rows; b1 is
+// added by the rows that read it), T2 (conv2 in fp32, 16-B chunks XOR-swizzled by row), the LayerNorm affines and biases.
 // ---------------------------------------------------------------------------------------------------------------------
 [[maybe_unused]] constexpr int T3_T1P = 272;                              // bytes per T1 row: 128 bf16 + 16 pad (16-B aligned rows)
 [[maybe_unused]] constexpr int T3_OFF_T1 = 2 * TB_RING;
 [[maybe_unused]] constexpr int T3_OFF_T2 = 2 * TB_RING + TB_PIX * T3_T1P;
 [[maybe_unused]] constexpr int T3_LDS = T3_OFF_T2 + TB_T;                 // 154 624
-#ifndef T3_WA
-#define T3_WA 32     // weight fragments (of 48) kept in the accumulator half; the rest + the accumulators in the architectural half
-#endif
-// Row arithmetic of the row waves: plain (unpacked) fp32.  A packed-fp32 instruction does not execute next to an MFMA of
-// the OTHER wave of the SIMD either: with `v_pk_*` rows the row waves' LayerNorm passes stretched by the length of the
-// matrix waves' GEMMs (L2 4 430 cycles next to G1, 2 020 with the matrix pipe idle; profiles/r02_tblock_v3_phase_cycles.txt).
-// The pins keep the SLP vectoriser from re-pairing the elements.
-template <bool SILU>
-__device__ __forceinline__ void t3_row_norm(float (&v)[8], const float (&g)[8], const float (&b)[8], float eps, float (&o)[8]) {
-  float s = 0.f;
-#pragma unroll
-  for (int e = 0; e < 8; ++e) s = s + v[e];
-  const float mean = group_sum_dpp<16>(s) * (1.0f / 128.0f);
-  float q = 0.f, d[8];
-#pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    d[e] = v[e] - mean;
-    tb_pin(d[e]);
-    q = __builtin_fmaf(d[e], d[e], q);
-  }
-  const float rstd = __builtin_amdgcn_rsqf(__builtin_fmaf(group_sum_dpp<16>(q), 1.0f / 128.0f, eps));
-#pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    float u = __builtin_fmaf(d[e] * rstd, g[e], b[e]);
-    tb_pin(u);
-    if constexpr (SILU) {
-      const float ex = __builtin_amdgcn_exp2f(u * -1.4426950408889634f);
-      u = u * __builtin_amdgcn_rcpf(ex + 1.0f);
-      tb_pin(u);
-    }
-    o[e] = u;
-  }
-}
 __device__ __forceinline__ void t3_unpack8(const u32x4& w, float (&v)[8]) {
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
@@ -186,19 +96,100 @@ __device__ __forceinline__ u32x4 t3_pack8(const float (&o)[8]) {
   return w;
 }
 
-template <bool W_IN_AGPR>
-__device__ __forceinline__ void t3_mfma(const u32x4& w, const u32x4& x, f32x16& acc) {
-  if constexpr (W_IN_AGPR) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "a"(w), "v"(x));
-  else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(w), "v"(x));
+// ---------------------------------------------------------------------------------------------------------------------
+// Two EQUAL groups.  What the stamps of the two-role arrangement showed
+// (profiles/r02_tblock_v3_phase_cycles.txt): a step takes ~11 000 cycles because the row waves carry 10 400 cycles of row
+// work while the matrix waves are busy for 5 800 and idle for the rest -- and a wave issues one instruction every four
+// cycles at best, whatever the instruction (profiles/r03_ws2_iteration_cycles.txt), so the row waves' ~2 000 instructions
+// a step cannot go faster than that.  Here the two convolutions go to different waves of a SIMD and BOTH do rows:
+//     group 0 (waves 0-3): the weights of conv1 (24 fragments, all in the accumulator half), G1, T1 <- acc, rows
+//     group 1 (waves 4-7): the weights of conv2,                                             G2, T2 <- acc, rows
+//     phase A_k:   group 0: G1(k)                                  | group 1: T2 <- acc2(k-2), L2(k-1) (4 row units)
+//     phase B_k:   group 0: T1 <- acc1(k), O(k-2) (4 units), L1(k+1) unit 0 | group 1: G2(k-1), L1(k+1) units 1-3
+// (row unit = 16 pixel rows x 128 channels on a group's 256 threads).  Buffers and their hand-over are those of the
+// two-role kernel: written in one phase, read in a later one, one barrier per phase.  Group 1 never stores to memory,
+// so its loads (x rows of its L1 units, requested a step ahead) never queue behind stores; group 0 requests its x rows
+// (O's residual, its L1 unit) at the top of phase B in front of that phase's stores, into the register set the phase
+// does not use -- the same two-set, two-body arrangement as above.
+// The LayerNorm affines and the biases live in the LDS (4 KiB; a unit reads what it needs: two ds_read_b128 an array),
+// all addressing is 32-bit through buffer descriptors rebased to the frame, the (column, frame) of a virtual step is
+// carried by additions.  Row arithmetic: plain fp32, element order of the two-role kernel (L1 sums the even and the odd
+// channels separately, as its packed form did): the two arrangements agreed to the bit when both existed.
+// LDS: 154 624 + 4 096 = 158 720 B.
+// ---------------------------------------------------------------------------------------------------------------------
+[[maybe_unused]] constexpr int T4_OFF_PRM = T3_LDS;                       // g1 | be1 | g2 | be2 | gn | ben | b1 | b2, 128 fp32 each
+[[maybe_unused]] constexpr int T4_LDS = T4_OFF_PRM + 8 * 128 * 4;         // 158 720
+[[maybe_unused]] constexpr int T4_FD = 3;                                 // fragment prefetch distance of a GEMM, in MFMAs
+
+template <bool FIRST>
+__device__ __forceinline__ void t4_mfma(const u32x4& w, const u32x4& x, f32x16& acc) {
+  if constexpr (FIRST) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=v"(acc) : "a"(w), "v"(x));
+  else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "a"(w), "v"(x));
+}
+// LayerNorm(+SiLU) of a row slice, even and odd channels summed separately and then together (the order of the packed-fp32
+// form this row phase once had; kept so that results did not move when the arrangement changed)
+template <bool SILU>
+__device__ __forceinline__ void t4_row_norm_pairs(float (&v)[8], const float (&g)[8], const float (&b)[8], float eps, float (&o)[8]) {
+  float s0 = v[0], s1 = v[1];
+#pragma unroll
+  for (int q = 1; q < 4; ++q) {
+    s0 = s0 + v[2 * q];
+    s1 = s1 + v[2 * q + 1];
+  }
+  const float mean = group_sum_dpp<16>(s0 + s1) * (1.0f / 128.0f);
+  float d[8], q0 = 0.f, q1 = 0.f;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    d[2 * q] = v[2 * q] - mean;
+    d[2 * q + 1] = v[2 * q + 1] - mean;
+    q0 = __builtin_fmaf(d[2 * q], d[2 * q], q0);
+    q1 = __builtin_fmaf(d[2 * q + 1], d[2 * q + 1], q1);
+  }
+  const float rstd = __builtin_amdgcn_rsqf(__builtin_fmaf(group_sum_dpp<16>(q0 + q1), 1.0f / 128.0f, eps));
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    float u = __builtin_fmaf(d[e] * rstd, g[e], b[e]);
+    if constexpr (SILU) {
+      const float ex = __builtin_amdgcn_exp2f(u * -1.4426950408889634f);
+      u = u * __builtin_amdgcn_rcpf(ex + 1.0f);
+    }
+    o[e] = u;
+  }
+}
+// the same with the channels summed in order (no pins between the elements: this file is compiled without the SLP
+// vectoriser, see build.py)
+template <bool SILU>
+__device__ __forceinline__ void t4_row_norm(float (&v)[8], const float (&g)[8], const float (&b)[8], float eps, float (&o)[8]) {
+  float s = 0.f;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) s = s + v[e];
+  const float mean = group_sum_dpp<16>(s) * (1.0f / 128.0f);
+  float q = 0.f, d[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    d[e] = v[e] - mean;
+    q = __builtin_fmaf(d[e], d[e], q);
+  }
+  const float rstd = __builtin_amdgcn_rsqf(__builtin_fmaf(group_sum_dpp<16>(q), 1.0f / 128.0f, eps));
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    float u = __builtin_fmaf(d[e] * rstd, g[e], b[e]);
+    if constexpr (SILU) {
+      const float ex = __builtin_amdgcn_exp2f(u * -1.4426950408889634f);
+      u = u * __builtin_amdgcn_rcpf(ex + 1.0f);
+    }
+    o[e] = u;
+  }
 }
 
 template <int LNN, bool KEEP, bool PROF = false>
-__global__ __launch_bounds__(512, 1) void tblock_split_kernel(const TBlockArgs p) {
+__global__ __launch_bounds__(512, 1) void tblock_pair_kernel(const TBlockArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int cw = wave & 3, grp = wave >> 2;
   const int ptiles = p.HW / TB_PIX;
   const int ncols = p.B * ptiles;
   const int G = gridDim.x;
@@ -208,25 +199,55 @@ __global__ __launch_bounds__(512, 1) void tblock_split_kernel(const TBlockArgs p
   const int c_end = c_begin + cq + (slot_id < cr ? 1 : 0);
   if (c_begin >= c_end) return;
   const int n = (c_end - c_begin) * p.T;                             // virtual steps of this workgroup
-  char* ring1 = smem;
-  char* ring2 = smem + TB_RING;
-  char* T1 = smem + T3_OFF_T1;
-  float* T2 = reinterpret_cast<float*>(smem + T3_OFF_T2);
-  auto coords = [&](int k, int& col, int& t) {
+  constexpr int R1 = 0, R2 = TB_RING;                                // ring offsets in the LDS
+  const unsigned frame_bytes = (unsigned)p.HW * 256u;
+
+  // ---- parameters -> LDS
+  float* prm = reinterpret_cast<float*>(smem + T4_OFF_PRM);
+  {
+    const int c = tid & 127, a = tid >> 7;                           // arrays a and a + 4
+    const float* src0 = a == 0 ? p.g1 : (a == 1 ? p.be1 : (a == 2 ? p.g2 : p.be2));
+    prm[a * 128 + c] = src0[c];
+    float v;
+    if (a == 0) v = LNN ? p.gn[c] : 1.0f;
+    else if (a == 1) v = LNN ? p.ben[c] : 0.0f;
+    else if (a == 2) v = p.b1 ? p.b1[c] : 0.0f;
+    else v = p.b2 ? p.b2[c] : 0.0f;
+    prm[(a + 4) * 128 + c] = v;
+  }
+
+  // ---- virtual step -> (batch, pixel tile, frame), carried by additions
+  struct Cur {
+    int b, pt, t;
+  };
+  auto cur_at = [&](int k) __attribute__((always_inline)) {
+    Cur c;
     const int q = k / p.T;
-    col = c_begin + q;
-    t = k - q * p.T;
+    c.t = k - q * p.T;
+    const int col = c_begin + q;
+    c.b = col / ptiles;
+    c.pt = col - c.b * ptiles;
+    return c;
   };
-  auto col_base = [&](int col) -> long long {                        // element offset of (b, frame 0, first pixel of the tile)
-    const int b = col / ptiles;
-    const int pt = col - b * ptiles;
-    return ((long long)b * p.T * p.HW + (long long)pt * TB_PIX) * 128;
+  auto cur_step = [&](Cur& c) __attribute__((always_inline)) {
+    c.t += 1;
+    if (c.t == p.T) {
+      c.t = 0;
+      c.pt += 1;
+      if (c.pt == ptiles) {
+        c.pt = 0;
+        c.b += 1;
+      }
+    }
   };
-  const long long frame_stride = (long long)p.HW * 128;
-  // PROF: stamps of workgroup 0, steps [8, 12): [wave][step][8] in the LDS behind T2, copied out at the end
-  unsigned long long* stamps = reinterpret_cast<unsigned long long*>(smem + T3_LDS);
+  auto frame_rsrc = [&](const bf16_t* base, const Cur& c) __attribute__((always_inline)) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(base) + ((long long)c.b * p.T + c.t) * p.HW * 128, 0, frame_bytes, 0x00020000);
+  };
+
+  // PROF: stamps of workgroup 0, steps [8, 12): [step][wave][8] in the LDS behind the parameters, copied out at the end
+  unsigned long long* stamps = reinterpret_cast<unsigned long long*>(smem + T4_LDS);
   int kcur = 0;
-  auto stamp = [&](int i) {
+  auto stamp = [&](int i) __attribute__((always_inline)) {
     if constexpr (PROF) {
       if (blockIdx.x == 0 && kcur >= 8 && kcur < 12) {
         const unsigned long long ts = __builtin_amdgcn_s_memtime();
@@ -234,257 +255,297 @@ __global__ __launch_bounds__(512, 1) void tblock_split_kernel(const TBlockArgs p
       }
     }
   };
-  auto dump = [&]() {
+  auto dump = [&]() __attribute__((always_inline)) {
     if constexpr (PROF) {
       if (blockIdx.x == 0 && lane == 0)
         for (int i = 0; i < 32; ++i) p.prof[wave * 32 + i] = stamps[((i / 8) * 8 + wave) * 8 + (i % 8)];
     }
   };
 
-  if (wave < 4) {
-    // =================================================== matrix waves ===================================================
-    u32x4 wreg[48];
-    {
-      const long long roff = (long long)(wave * 32 + (lane & 31)) * 384 + (lane >> 5) * 8;
+  // ---- stationary weights of my convolution
+  u32x4 wreg[24];
+  {
+    const bf16_t* wsrc = grp == 0 ? p.w1 : p.w2;
+    const long long roff = (long long)(cw * 32 + (lane & 31)) * 384 + (lane >> 5) * 8;
 #pragma unroll
-      for (int g = 0; g < 24; ++g) wreg[g] = *reinterpret_cast<const u32x4*>(p.w1 + roff + g * 16);
+    for (int g = 0; g < 24; ++g) wreg[g] = *reinterpret_cast<const u32x4*>(wsrc + roff + g * 16);
+    // a REAL s_waitcnt (the builtin, not asm): the compiler's wait-count bookkeeping then knows the weights have landed.
+    // Left pending at the loop entry, it re-waited for them in front of every MFMA of every step -- vmcnt(7) ... vmcnt(0) --
+    // i.e. for whatever the wave had in flight, including the stores this kernel wants to keep in flight across a GEMM.
+    __builtin_amdgcn_s_waitcnt(0x0F70);                              // vmcnt(0)
+  }
+  f32x16 acc[2];
+  // GEMM of the step at frame t whose ring slot is s3 (= virtual step % 3) over the live taps [KT0, 3) of the ring at `roff`
+  auto gemm = [&](auto kt0_c, int roff, int s3, int t) __attribute__((always_inline)) {
+    constexpr int KT0 = decltype(kt0_c)::value;
+    constexpr int M0 = 16 * KT0;
+    int lo = lane;
+    asm volatile("" : "+v"(lo));
+    const int frag_off = roff + (lo & 31) * TB_ROWP + (lo >> 5) * 16;   // B-fragment of pixel lane%32, k half lane/32
+    int sp[3];
 #pragma unroll
-      for (int g = 0; g < 24; ++g) wreg[24 + g] = *reinterpret_cast<const u32x4*>(p.w2 + roff + g * 16);
+    for (int kt = 0; kt < 3; ++kt) {
+      // tap kt = frame t - 2 + kt; replicate: frames before the clip = its frame 0 (virtual step k - t)
+      const int back = (t - 2 + kt >= 0) ? 2 - kt : t;
+      int sl = s3 - back;
+      sl = sl < 0 ? sl + 3 : sl;
+      sp[kt] = frag_off + sl * TB_SLOT;
     }
-    const int h = lane >> 5;
-    const int frag_off = (lane & 31) * TB_ROWP + h * 16;             // B-fragment of pixel lane%32, k half lane/32
-    f32x16 acc[2];
-    // GEMM of virtual step k (frame t of its column) over the live taps [KT0, 3) of `ring`
-    auto gemm = [&](auto kt0_c, auto wbase_c, const char* ring, int k, int t) {
-      constexpr int KT0 = decltype(kt0_c)::value, WB = decltype(wbase_c)::value;
-      constexpr int G0 = KT0 * 8;
-      const char* sp[3];
-#pragma unroll
-      for (int kt = 0; kt < 3; ++kt) {
-        const int vs = (t - 2 + kt >= 0) ? k - 2 + kt : k - t;         // replicate: frames before the clip = its frame 0
-        sp[kt] = ring + (vs % 3) * TB_SLOT + frag_off;
-      }
-      auto faddr = [&](int g, int j) -> const u32x4* {
-        return reinterpret_cast<const u32x4*>(sp[g >> 3] + j * (32 * TB_ROWP) + (g & 7) * 32);
-      };
-      // fragments in MFMA order m = 2 g + j, a ring of four: the one used three MFMAs from now is requested behind each MFMA
-      // (two whole groups ahead, as in the 4-wave kernel, would take 24 registers; this path has 16 to spare)
-      constexpr int M0 = 2 * G0;
-      u32x4 xf[4];
-#pragma unroll
-      for (int m = M0; m < M0 + 3; ++m) xf[m % 4] = *faddr(m >> 1, m & 1);
-      tb_static_for<M0, 48>([&](auto mc) {
-        constexpr int m = decltype(mc)::value;
-        t3_mfma<(WB + (m >> 1) < T3_WA)>(wreg[WB + (m >> 1)], xf[m % 4], acc[m & 1]);
-        if constexpr (m + 3 < 48) xf[(m + 3) % 4] = *faddr((m + 3) >> 1, (m + 3) & 1);
-        __builtin_amdgcn_sched_barrier(0);
-      });
-      asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");             // last MFMA -> first VALU reader of its accumulator
+    auto faddr = [&](int m) __attribute__((always_inline)) -> const u32x4* {
+      const int g = m >> 1, j = m & 1;
+      return reinterpret_cast<const u32x4*>(smem + sp[g >> 3] + j * (32 * TB_ROWP) + (g & 7) * 32);
     };
-    auto run_gemm = [&](auto wbase_c, const char* ring, int k) {
-      int col, t;
-      coords(k, col, t);
+    u32x4 xf[T4_FD + 1];
 #pragma unroll
-      for (int j = 0; j < 2; ++j)
+    for (int m = M0; m < M0 + T4_FD; ++m) xf[m % (T4_FD + 1)] = *faddr(m);
+    __builtin_amdgcn_s_setprio(1);
+    tb_static_for<M0, 48>([&](auto mc) __attribute__((always_inline)) {
+      constexpr int m = decltype(mc)::value;
+      t4_mfma<(m < M0 + 2)>(wreg[m >> 1], xf[m % (T4_FD + 1)], acc[m & 1]);
+      if constexpr (m + T4_FD < 48) xf[(m + T4_FD) % (T4_FD + 1)] = *faddr(m + T4_FD);
+      __builtin_amdgcn_sched_barrier(0);
+    });
+    __builtin_amdgcn_s_setprio(0);
+    asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");             // last MFMA -> first VALU reader of its accumulator
+  };
+  auto run_gemm = [&](int roff, int s3, int t) __attribute__((always_inline)) {
+    const int first = p.replicate ? 0 : max(0, 2 - t);               // uniform
+    if (first == 0) gemm(std::integral_constant<int, 0>{}, roff, s3, t);
+    else if (first == 1) gemm(std::integral_constant<int, 1>{}, roff, s3, t);
+    else gemm(std::integral_constant<int, 2>{}, roff, s3, t);
+  };
+  // accumulators: lane = pixel 32 j + lane % 32, channels 32 cw + 8 g + 4 h + e
+  auto acc_to_T1 = [&]() __attribute__((always_inline)) {                                           // rounded to bf16 (8 B per quad); b1 is added by the rows
+    int lo = lane;
+    asm volatile("" : "+v"(lo));
+    const int base = T3_OFF_T1 + (lo & 31) * T3_T1P + (cw * 32 + 4 * (lo >> 5)) * 2;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[j][r] = 0.0f;
-      const int first = p.replicate ? 0 : max(0, 2 - t);             // uniform
-      if (first == 0) gemm(std::integral_constant<int, 0>{}, wbase_c, ring, k, t);
-      else if (first == 1) gemm(std::integral_constant<int, 1>{}, wbase_c, ring, k, t);
-      else gemm(std::integral_constant<int, 2>{}, wbase_c, ring, k, t);
-    };
-    // accumulators: lane = pixel 32 j + lane % 32, channels 32 wave + 8 g + 4 h + e
-    auto acc_to_T1 = [&]() {                                         // rounded to bf16 (8 B per quad); b1 is added by the row waves
+    for (int j = 0; j < 2; ++j)
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const int prow = 32 * j + (lane & 31);
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const int c = wave * 32 + 8 * g + 4 * h;
-          u32x2 w;
-          w[0] = tb_pack2(f32x2{acc[j][4 * g], acc[j][4 * g + 1]});
-          w[1] = tb_pack2(f32x2{acc[j][4 * g + 2], acc[j][4 * g + 3]});
-          *reinterpret_cast<u32x2*>(T1 + prow * T3_T1P + c * 2) = w;
-        }
+      for (int g = 0; g < 4; ++g) {
+        u32x2 w;
+        w[0] = tb_pack2(f32x2{acc[j][4 * g], acc[j][4 * g + 1]});
+        w[1] = tb_pack2(f32x2{acc[j][4 * g + 2], acc[j][4 * g + 3]});
+        *reinterpret_cast<u32x2*>(smem + base + j * (32 * T3_T1P) + g * 16) = w;
       }
-    };
-    auto acc_to_T2 = [&]() {
+  };
+  auto acc_to_T2 = [&]() __attribute__((always_inline)) {                                           // fp32, 16-B chunk (8 cw + 2 g + h) ^ (row % 32) of row 32 j + lane % 32
+    int lo = lane;
+    asm volatile("" : "+v"(lo));
+    const int l31 = lo & 31;
+    const int base = T3_OFF_T2 + l31 * 512 + (((cw * 8 + (lo >> 5)) ^ l31) << 4);
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const int prow = 32 * j + (lane & 31);
+    for (int j = 0; j < 2; ++j)
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const int c = wave * 32 + 8 * g + 4 * h;
-          f32x4 v;
+      for (int g = 0; g < 4; ++g) {
+        f32x4 v;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = acc[j][4 * g + e];
-          *reinterpret_cast<f32x4*>(T2 + prow * 128 + (((c >> 2) ^ (prow & 31)) << 2)) = v;
-        }
+        for (int e = 0; e < 4; ++e) v[e] = acc[j][4 * g + e];
+        *reinterpret_cast<f32x4*>(smem + ((base ^ (g << 5)) + j * (32 * 512))) = v;
       }
-    };
-    __syncthreads();                                                 // L1(0) is in ring1
-    for (int k = 0; k < n + 2; ++k) {
-      kcur = k;
-      stamp(0);
-      // ---- phase A_k: G1(k); its result stays in the accumulators across the barrier
-      if (k < n && !(PROF && p.prof_mode == 1)) run_gemm(std::integral_constant<int, 0>{}, ring1, k);
-      stamp(1);
-      __syncthreads();
-      stamp(2);
-      // ---- phase B_k: park conv1(k) in T1, G2(k-1), park conv2(k-1) in T2 (read by the row waves in B_{k+1})
-      if (k < n) acc_to_T1();
-      stamp(3);
-      if (k >= 1 && k - 1 < n && !(PROF && p.prof_mode == 1)) {
-        run_gemm(std::integral_constant<int, 24>{}, ring2, k - 1);
-      }
-      stamp(4);
-      __syncthreads();
-      stamp(5);
-      // (start of A_{k+1}) conv2(k-1) -> T2: nobody reads T2 in an A phase
-      if (k >= 1 && k - 1 < n) acc_to_T2();
-      stamp(6);
+  };
+
+  // ---- row units: thread (oct_j, row0) of a group handles channels [8 oct_j, +8) of row row0 + 16 it of unit it
+  auto unit_geom = [&](int& oct_j, int& row0) __attribute__((always_inline)) {                      // recomputed per phase from an opaque id: nothing resident
+    int tt = tid;
+    asm volatile("" : "+v"(tt));
+    const int vt = tt & 255;
+    oct_j = vt & 15;
+    row0 = vt >> 4;
+  };
+  auto ld_prm = [&](int arr, int oct_j, float (&o)[8]) {
+    const f32x4 a = *reinterpret_cast<const f32x4*>(prm + arr * 128 + 8 * oct_j);
+    const f32x4 b = *reinterpret_cast<const f32x4*>(prm + arr * 128 + 8 * oct_j + 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      o[e] = a[e];
+      o[4 + e] = b[e];
     }
-    dump();
+  };
+  // x rows of the step at cursor c: units [U0, U1) of my group
+  auto load_rows = [&](auto u0_c, auto u1_c, u32x4 (&dst)[4], const Cur& c) {
+    constexpr int U0 = decltype(u0_c)::value, U1 = decltype(u1_c)::value;
+    int oct_j, row0;
+    unit_geom(oct_j, row0);
+    const __amdgpu_buffer_rsrc_t rs = frame_rsrc(p.x, c);
+    const int vo = (c.pt * TB_PIX + row0) * 256 + oct_j * 16;
+#pragma unroll
+    for (int it = U0; it < U1; ++it) dst[it] = __builtin_amdgcn_raw_buffer_load_b128(rs, vo + it * (16 * 256), 0, 0);
+  };
+  // L1 of units [U0, U1): LayerNorm1 + SiLU of x rows -> ring1 slot s3
+  auto ln1_units = [&](auto u0_c, auto u1_c, const u32x4 (&xr)[4], int s3) {
+    constexpr int U0 = decltype(u0_c)::value, U1 = decltype(u1_c)::value;
+    int oct_j, row0;
+    unit_geom(oct_j, row0);
+    float g[8], b[8];
+    ld_prm(0, oct_j, g);
+    ld_prm(1, oct_j, b);
+    const int wo = R1 + s3 * TB_SLOT + row0 * TB_ROWP + oct_j * 16;
+#pragma unroll
+    for (int it = U0; it < U1; ++it) {
+      float v[8], o[8];
+      t3_unpack8(xr[it], v);
+      t4_row_norm_pairs<true>(v, g, b, p.eps, o);
+      *reinterpret_cast<u32x4*>(smem + wo + it * (16 * TB_ROWP)) = t3_pack8(o);
+    }
+  };
+
+  auto out_store = [&](const u32x4& w, __amdgpu_buffer_rsrc_t rs, int vo) __attribute__((always_inline)) {
+    if constexpr (PROF) {
+      if (p.prof_mode & 16) return;                                  // measurement: no stores at all
+    }
+    __builtin_amdgcn_raw_buffer_store_b128(w, rs, vo, 0, 0);
+  };
+  // ---- prologue: L1(0) -> ring1 slot 0; x(1) rows for the L1 units of phase B_0
+  struct XSet {
+    u32x4 xn[4], xr[4];
+  };
+  XSet sa, sb;
+  Cur c_p2 = cur_at(0);          // cursors of virtual steps k + 2, k + 1, k, k - 1, k - 2 (valid where those steps exist)
+  Cur c_p1 = c_p2, c_0 = c_p2, c_m1 = c_p2, c_m2 = c_p2;
+  __syncthreads();               // parameters are in the LDS
+  if (grp == 0) {
+    load_rows(std::integral_constant<int, 0>{}, std::integral_constant<int, 3>{}, sa.xn, c_0);
+    ln1_units(std::integral_constant<int, 0>{}, std::integral_constant<int, 3>{}, sa.xn, 0);
   } else {
-    // ===================================================== row waves =====================================================
-    // The row waves issue first: left at equal priority the older matrix wave of a SIMD wins every arbitration -- also
-    // while its next MFMA cannot issue yet -- and the row wave next to it stands still for the length of a GEMM (measured:
-    // L2 next to G1 = L2 alone + G1).  The matrix wave needs one issue slot per 32 cycles; it gets them in the row wave's
-    // dependency stalls.
-    __builtin_amdgcn_s_setprio(3);
-    const int vt = tid - 256;
-    const int oct_j = vt & 15, row0 = vt >> 4;                        // rows row0 + 16 it (it < 4), channels [8 oct_j, +8)
-    float lg1[8], lb1[8], lg2[8], lb2[8], lgn[8], lbn[8], bo1[8], bo2[8];
+    load_rows(std::integral_constant<int, 3>{}, std::integral_constant<int, 4>{}, sa.xn, c_0);
+    ln1_units(std::integral_constant<int, 3>{}, std::integral_constant<int, 4>{}, sa.xn, 0);
+  }
+  cur_step(c_p1);
+  c_p2 = c_p1;
+  cur_step(c_p2);
+  if (1 < n) {
+    if (grp == 0) load_rows(std::integral_constant<int, 0>{}, std::integral_constant<int, 3>{}, sa.xn, c_p1);
+    else load_rows(std::integral_constant<int, 3>{}, std::integral_constant<int, 4>{}, sa.xn, c_p1);
+  }
+  // every register of both sets is defined before the loop (guarded steps skip loads, not uses); a group touches only
+  // its own units: group 0 xn[0..2] and xr[0..1], group 1 xn[3] and xr[2..3]
+  if (grp == 0) {
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const int c = 8 * oct_j + e;
-      bo1[e] = p.b1 ? p.b1[c] : 0.0f;
-      lg1[e] = p.g1[c]; lb1[e] = p.be1[c];
-      lg2[e] = p.g2[c]; lb2[e] = p.be2[c];
-      lgn[e] = LNN ? p.gn[c] : 1.0f;
-      lbn[e] = LNN ? p.ben[c] : 0.0f;
-      bo2[e] = p.b2 ? p.b2[c] : 0.0f;
+    for (int it = 0; it < 3; ++it) sb.xn[it] = sa.xn[it];
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      sa.xr[it] = sa.xn[0];
+      sb.xr[it] = sa.xn[0];
     }
-    const int row_lds = oct_j * 16;
-    auto ring_store = [&](char* ring, int vs, int row, const float (&o)[8]) {
-      *reinterpret_cast<u32x4*>(ring + (vs % 3) * TB_SLOT + row * TB_ROWP + row_lds) = t3_pack8(o);
-    };
-    auto load_rows = [&](Oct<bf16_t> (&dst)[4], int k) {            // x rows of virtual step k
-      int col, t;
-      coords(k, col, t);
-      const bf16_t* src = p.x + col_base(col) + (long long)t * frame_stride + 8 * oct_j;
+  } else {
+    sb.xn[3] = sa.xn[3];
 #pragma unroll
-      for (int it = 0; it < 4; ++it) dst[it].load(src + (long long)(row0 + 16 * it) * 128);
-    };
-    auto ln1_rows = [&](Oct<bf16_t> (&xr)[4], int k) {              // L1(k): LayerNorm1 + SiLU of x rows -> ring1
-      // L1 runs behind O, when the matrix waves have finished G2 and wait at the barrier: nothing for packed fp32 to
-      // collide with, and a packed row costs 2 080 cycles against 2 700
-      f32x2 g2v[4], b2v[4];
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        g2v[q] = f32x2{lg1[2 * q], lg1[2 * q + 1]};
-        b2v[q] = f32x2{lb1[2 * q], lb1[2 * q + 1]};
-      }
-#pragma unroll
-      for (int it = 0; it < 4; ++it) {
-        f32x2 v[4], o[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) v[q] = tb_unpack2(xr[it].w[q]);
-        tb_row_norm2<true>(v, g2v, b2v, p.eps, o);
-        u32x4 w;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) w[q] = tb_pack2(o[q]);
-        *reinterpret_cast<u32x4*>(ring1 + (k % 3) * TB_SLOT + (row0 + 16 * it) * TB_ROWP + row_lds) = w;
-      }
-    };
-    // x rows: of step k+1 for L1 and -- read a second time, from the L2 -- of step k-2 for the residual of O.  They are
-    // requested one whole step ahead, at the top of phase B and BEFORE that phase's y / n stores, into the register set
-    // the phase does not use (two sets, the loop body exists twice): a load issued behind stores would make its first use
-    // (and any reuse of the stores' operand registers) wait for those stores, and under this kernel's write traffic a
-    // store takes ~5 000 cycles to retire -- with the requests at the top of phase A, right behind the stores of
-    // phase B, L2 took 5 000 cycles instead of 2 100 (profiles/r02_tblock_v3_phase_cycles.txt).
-    struct XSet { Oct<bf16_t> xn[4], xr[4]; };
-    XSet sa, sb;
-    load_rows(sa.xn, 0);
-    ln1_rows(sa.xn, 0);
-    if (1 < n) load_rows(sa.xn, 1);                                  // x(1) for L1(1) in B_0
-#pragma unroll
-    for (int it = 0; it < 4; ++it) {
-      sa.xr[it].w = sa.xn[it].w;
-      sb.xn[it].w = sa.xn[it].w;
-      sb.xr[it].w = sa.xn[it].w;
+    for (int it = 2; it < 4; ++it) {
+      sa.xr[it] = sa.xn[3];
+      sb.xr[it] = sa.xn[3];
     }
-    __syncthreads();                                                 // L1(0) is in ring1
-    // GUARD = false: a step in the middle of the walk -- every load, store and phase is live, the body is straight-line
-    // code (with conditional loads / stores in it hipcc cannot count what is in flight and waits for everything)
-    auto body = [&](auto guard_c, int k, XSet& cur, XSet& nxt) {
+  }
+  int s3 = 0;                    // k % 3
+  auto advance = [&]() __attribute__((always_inline)) {
+    c_m2 = c_m1;
+    c_m1 = c_0;
+    c_0 = c_p1;
+    c_p1 = c_p2;
+    cur_step(c_p2);
+    s3 = s3 == 2 ? 0 : s3 + 1;
+  };
+  auto slot_back = [&](int back) __attribute__((always_inline)) {                                   // (k - back) % 3
+    const int s = s3 - back;
+    return s < 0 ? s + 3 : s;
+  };
+  __syncthreads();               // L1(0) is in ring1
+
+  // L2 of units [U0, U1) of the step whose ring slot is sl: rows of T1 (conv1, bf16) + b1 -> LayerNorm2 + SiLU -> ring2
+  auto l2_units = [&](auto u0_c, auto u1_c, int sl) __attribute__((always_inline)) {
+    constexpr int U0 = decltype(u0_c)::value, U1 = decltype(u1_c)::value;
+    int oct_j, row0;
+    unit_geom(oct_j, row0);
+    float bo1[8], g[8], b[8];
+    ld_prm(6, oct_j, bo1);
+    ld_prm(2, oct_j, g);
+    ld_prm(3, oct_j, b);
+    const int ro = T3_OFF_T1 + row0 * T3_T1P + oct_j * 16;
+    const int wo = R2 + sl * TB_SLOT + row0 * TB_ROWP + oct_j * 16;
+    u32x4 tw[4];
+#pragma unroll
+    for (int it = U0; it < U1; ++it) tw[it] = *reinterpret_cast<const u32x4*>(smem + ro + it * (16 * T3_T1P));
+#pragma unroll
+    for (int it = U0; it < U1; ++it) {
+      float v[8], o[8];
+      t3_unpack8(tw[it], v);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = v[e] + bo1[e];
+      t4_row_norm<true>(v, g, b, p.eps, o);
+      *reinterpret_cast<u32x4*>(smem + wo + it * (16 * TB_ROWP)) = t3_pack8(o);
+    }
+  };
+  // O of unit IT of the step at cursor c: rows of T2 + b2 + x -> y, LayerNorm_next -> n
+  auto o_unit = [&](auto it_c, const u32x4& xrow, const Cur& c) __attribute__((always_inline)) {
+    constexpr int it = decltype(it_c)::value;
+    int oct_j, row0;
+    unit_geom(oct_j, row0);
+    float bo2[8], gn[8], bn[8];
+    ld_prm(7, oct_j, bo2);
+    if constexpr (LNN != 0) {
+      ld_prm(4, oct_j, gn);
+      ld_prm(5, oct_j, bn);
+    }
+    const int vo = (c.pt * TB_PIX + row0) * 256 + oct_j * 16 + it * (16 * 256);
+    // row row0 + 16 it: the swizzle key (row % 32) flips bit 4 for odd it
+    const int tb = T3_OFF_T2 + row0 * 512 + (((2 * oct_j) ^ row0) << 4);
+    const int to = ((it & 1) ? (tb ^ 256) : tb) + it * (16 * 512);
+    const f32x4 t0 = *reinterpret_cast<const f32x4*>(smem + to);
+    const f32x4 t1 = *reinterpret_cast<const f32x4*>(smem + (to ^ 16));
+    float v[8], xv[8];
+    t3_unpack8(xrow, xv);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = xv[e] + ((e < 4 ? t0[e] : t1[e - 4]) + bo2[e]);
+    if constexpr (KEEP) out_store(t3_pack8(v), frame_rsrc(p.y, c), vo);
+    if constexpr (LNN != 0) {
+      float o[8];
+      t4_row_norm<(LNN == 2)>(v, gn, bn, p.eps, o);
+      out_store(t3_pack8(o), frame_rsrc(p.n_out, c), vo);
+    }
+  };
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+  using I2 = std::integral_constant<int, 2>;
+  using I3 = std::integral_constant<int, 3>;
+  using I4 = std::integral_constant<int, 4>;
+
+  // Who does which row unit (unit = 16 pixel rows on a group's 256 threads; ~630-730 cycles each, a GEMM ~2 100-2 400):
+  //   phase A_k:  group 0: G1(k), L2(k-1) unit 3                         | group 1: T2 <- conv2(k-2), L2(k-1) units 0-2
+  //   phase B_k:  group 0: T1 <- conv1(k), O0, L1_0, O1, L1_1, L1_2      | group 1: G2(k-1), O2, L1_3, O3
+  // The y / n stores (two per O unit and thread) are kept apart on purpose: a CU retires ~13 B of stores a cycle
+  // (scripts/hbm_bw_bench.hip: 6.7 TB/s over 256 CUs), so a step's 32 KiB take 2 500 cycles of the store path, and a wave
+  // issuing into a full store queue stands still -- with all of O in one group back to back its eight stores cost it
+  // 2 500 cycles on top of 2 900 of arithmetic (profiles/r03_tblock_pair_phase_cycles.txt).
+  if (grp == 0) {
+    // ======================================================= group 0 =======================================================
+    auto body = [&](auto guard_c, int k, XSet& cur, XSet& nxt) __attribute__((always_inline)) {
       constexpr bool GUARD = decltype(guard_c)::value;
       kcur = k;
       stamp(0);
-      // ---- phase A_k: L2(k-1): rows of T1 (conv1, bf16) + b1 -> LayerNorm2 + SiLU -> ring2
-      if (!GUARD || (k >= 1 && k - 1 < n)) {
-        u32x4 tw[4];
-#pragma unroll
-        for (int it = 0; it < 4; ++it) tw[it] = *reinterpret_cast<const u32x4*>(T1 + (row0 + 16 * it) * T3_T1P + row_lds);
-#pragma unroll
-        for (int it = 0; it < 4; ++it) {
-          float v[8], o[8];
-          t3_unpack8(tw[it], v);
-#pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] = v[e] + bo1[e];
-          t3_row_norm<true>(v, lg2, lb2, p.eps, o);
-          ring_store(ring2, k - 1, row0 + 16 * it, o);
-        }
-      }
+      // ---- phase A_k: G1(k) (the result stays in the accumulators across the barrier), one unit of L2(k-1)
+      if ((!GUARD || k < n) && !(PROF && (p.prof_mode & 1))) run_gemm(R1, s3, c_0.t);
       stamp(1);
-      __syncthreads();
+      if ((!GUARD || (k >= 1 && k - 1 < n)) && !(PROF && (p.prof_mode & 2))) l2_units(I3{}, I4{}, slot_back(1));
       stamp(2);
-      // ---- phase B_k: requests for B_{k+1}; O(k-2): rows of T2 + b2 + x(k-2) -> y, LayerNorm_next -> n;  L1(k+1) -> ring1
-      if (!GUARD || k + 2 < n) load_rows(nxt.xn, k + 2);
-      if (!GUARD || (k >= 1 && k - 1 < n)) load_rows(nxt.xr, k - 1);
-      if (!GUARD || (k >= 2 && k - 2 < n)) {
-        int col, t;
-        coords(k - 2, col, t);
-        const long long ob = col_base(col) + (long long)t * frame_stride + 8 * oct_j;
-#pragma unroll
-        for (int half = 0; half < 2; ++half) {
-          f32x4 tq[2][2];
-#pragma unroll
-          for (int i2 = 0; i2 < 2; ++i2) {
-            const int row = row0 + 16 * (2 * half + i2);
-            const int sw = row & 31;
-            tq[i2][0] = *reinterpret_cast<const f32x4*>(T2 + row * 128 + (((2 * oct_j) ^ sw) << 2));
-            tq[i2][1] = *reinterpret_cast<const f32x4*>(T2 + row * 128 + (((2 * oct_j + 1) ^ sw) << 2));
-          }
-#pragma unroll
-          for (int i2 = 0; i2 < 2; ++i2) {
-            const int it = 2 * half + i2;
-            const int row = row0 + 16 * it;
-            const f32x4 t0 = tq[i2][0], t1 = tq[i2][1];
-            float v[8], xv[8];
-            t3_unpack8(cur.xr[it].w, xv);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-              v[e] = xv[e] + ((e < 4 ? t0[e] : t1[e - 4]) + bo2[e]);
-              tb_pin(v[e]);
-            }
-            if constexpr (KEEP) *reinterpret_cast<u32x4*>(p.y + ob + (long long)row * 128) = t3_pack8(v);
-            if constexpr (LNN != 0) {
-              float o[8];
-              t3_row_norm<(LNN == 2)>(v, lgn, lbn, p.eps, o);
-              *reinterpret_cast<u32x4*>(p.n_out + ob + (long long)row * 128) = t3_pack8(o);
-            }
-          }
-        }
-      }
-      stamp(3);
-      if (!GUARD || k + 1 < n) ln1_rows(cur.xn, k + 1);
-      stamp(4);
       __syncthreads();
+      // ---- phase B_k: requests for B_{k+1} in front of this phase's stores, T1 <- conv1(k), my units of O(k-2) and L1(k+1)
+      if (!GUARD || k + 2 < n) load_rows(I0{}, I3{}, nxt.xn, c_p2);
+      if (!GUARD || (k >= 1 && k - 1 < n)) load_rows(I0{}, I2{}, nxt.xr, c_m1);
+      __builtin_amdgcn_sched_barrier(0);
+      if (!GUARD || k < n) acc_to_T1();
+      stamp(3);
+      const bool do_o = (!GUARD || (k >= 2 && k - 2 < n)) && !(PROF && (p.prof_mode & 2));
+      const bool do_l1 = (!GUARD || k + 1 < n) && !(PROF && (p.prof_mode & 2));
+      if (do_o) o_unit(I0{}, cur.xr[0], c_m2);
+      if (do_l1) ln1_units(I0{}, I1{}, cur.xn, slot_back(2));       // (k + 1) % 3 = (k - 2) % 3
+      if (do_o) o_unit(I1{}, cur.xr[1], c_m2);
+      stamp(4);
+      if (do_l1) ln1_units(I1{}, I3{}, cur.xn, slot_back(2));
       stamp(5);
+      __syncthreads();
       stamp(6);
+      advance();
     };
-    // steps k in [2, n - 2) need no guards: k-2 >= 0 and k+2 < n
     for (int k = 0; k < n + 2; k += 2) {
       if (k >= 2 && k + 3 < n) {
         body(std::false_type{}, k, sa, sb);
@@ -494,8 +555,46 @@ __global__ __launch_bounds__(512, 1) void tblock_split_kernel(const TBlockArgs p
         if (k + 1 < n + 2) body(std::true_type{}, k + 1, sb, sa);
       }
     }
-    dump();
+  } else {
+    // ======================================================= group 1 =======================================================
+    auto body = [&](auto guard_c, int k, XSet& cur, XSet& nxt) __attribute__((always_inline)) {
+      constexpr bool GUARD = decltype(guard_c)::value;
+      kcur = k;
+      stamp(0);
+      // ---- phase A_k: T2 <- conv2(k-2) (nobody reads T2 in an A phase), three units of L2(k-1)
+      if (!GUARD || (k >= 2 && k - 2 < n)) acc_to_T2();
+      stamp(1);
+      if ((!GUARD || (k >= 1 && k - 1 < n)) && !(PROF && (p.prof_mode & 2))) l2_units(I0{}, I3{}, slot_back(1));
+      stamp(2);
+      __syncthreads();
+      // ---- phase B_k: requests for B_{k+1}; G2(k-1); my units of O(k-2) and L1(k+1)
+      if (!GUARD || k + 2 < n) load_rows(I3{}, I4{}, nxt.xn, c_p2);
+      if (!GUARD || (k >= 1 && k - 1 < n)) load_rows(I2{}, I4{}, nxt.xr, c_m1);
+      __builtin_amdgcn_sched_barrier(0);
+      if ((!GUARD || (k >= 1 && k - 1 < n)) && !(PROF && (p.prof_mode & 1))) run_gemm(R2, slot_back(1), c_m1.t);
+      stamp(3);
+      const bool do_o = (!GUARD || (k >= 2 && k - 2 < n)) && !(PROF && (p.prof_mode & 2));
+      const bool do_l1 = (!GUARD || k + 1 < n) && !(PROF && (p.prof_mode & 2));
+      if (do_o) o_unit(I2{}, cur.xr[2], c_m2);
+      stamp(4);
+      if (do_l1) ln1_units(I3{}, I4{}, cur.xn, slot_back(2));
+      if (do_o) o_unit(I3{}, cur.xr[3], c_m2);
+      stamp(5);
+      __syncthreads();
+      stamp(6);
+      advance();
+    };
+    for (int k = 0; k < n + 2; k += 2) {
+      if (k >= 2 && k + 3 < n) {
+        body(std::false_type{}, k, sa, sb);
+        body(std::false_type{}, k + 1, sb, sa);
+      } else {
+        body(std::true_type{}, k, sa, sb);
+        if (k + 1 < n + 2) body(std::true_type{}, k + 1, sb, sa);
+      }
+    }
   }
+  dump();
 #endif
 }
 
@@ -542,20 +641,21 @@ int tblock_launch(const vt_tblock_desc* d, vt_stream stream_, unsigned long long
   a.eps = d->eps;
   a.prof = prof;
   a.prof_mode = prof ? vt_opt(OPT_TBLOCK_PROF_MODE) : 0;
+  VT_CHECK_ARG((long long)d->HW * 256 < (1ll << 31), "vt_temporal_block: frames of at most 2^23 pixels");
   // one instantiation per output shape: next norm none / LayerNorm / LayerNorm+SiLU, y kept or not
-  static const void* const kerns[6] = {
-      reinterpret_cast<const void*>(&tblock_split_kernel<0, true>), reinterpret_cast<const void*>(&tblock_split_kernel<1, true>),
-      reinterpret_cast<const void*>(&tblock_split_kernel<1, false>), reinterpret_cast<const void*>(&tblock_split_kernel<2, true>),
-      reinterpret_cast<const void*>(&tblock_split_kernel<2, false>), reinterpret_cast<const void*>(&tblock_split_kernel<2, true, true>)};
+  static const void* const kerns2[6] = {
+      reinterpret_cast<const void*>(&tblock_pair_kernel<0, true>), reinterpret_cast<const void*>(&tblock_pair_kernel<1, true>),
+      reinterpret_cast<const void*>(&tblock_pair_kernel<1, false>), reinterpret_cast<const void*>(&tblock_pair_kernel<2, true>),
+      reinterpret_cast<const void*>(&tblock_pair_kernel<2, false>), reinterpret_cast<const void*>(&tblock_pair_kernel<2, true, true>)};
   int ki = a.ln_next == 0 ? 0 : (a.ln_next == 1 ? (a.keep_y ? 1 : 2) : (a.keep_y ? 3 : 4));
-  int lds = T3_LDS;
+  int lds = T4_LDS;
   const unsigned threads = 512;
   if (prof != nullptr) {                      // measurement aid: stamps [wave 0..7][step][8] of the LayerNorm+SiLU, y kept instantiation
     VT_CHECK_ARG(a.ln_next == 2 && a.keep_y, "vt_temporal_block_profile: ln_next_mode 2 and keep_y only");
     ki = 5;
-    lds = T3_LDS + 2048;
+    lds += 2048;
   }
-  const void* kern = kerns[ki];
+  const void* kern = kerns2[ki];
   // per device, once: the dynamic-LDS attribute of every instantiation and the CU count (not a per-launch runtime call)
   static std::atomic<int> cus[kMaxDevices];
   int dev = 0;
@@ -563,7 +663,7 @@ int tblock_launch(const vt_tblock_desc* d, vt_stream stream_, unsigned long long
   int ncu = (dev >= 0 && dev < kMaxDevices) ? cus[dev].load(std::memory_order_acquire) : 0;
   if (ncu == 0) {
     for (int k = 0; k < 6; ++k)
-      VT_CHECK_HIP(hipFuncSetAttribute(kerns[k], hipFuncAttributeMaxDynamicSharedMemorySize, k == 5 ? T3_LDS + 2048 : T3_LDS));
+      VT_CHECK_HIP(hipFuncSetAttribute(kerns2[k], hipFuncAttributeMaxDynamicSharedMemorySize, k == 5 ? T4_LDS + 2048 : T4_LDS));
     VT_CHECK_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
     if (ncu <= 0) ncu = 256;
     if (dev >= 0 && dev < kMaxDevices) cus[dev].store(ncu, std::memory_order_release);
