@@ -17,7 +17,7 @@ Launch: `python bench.py --gpus N` spawns its N ranks itself (re-executes under 
 --gpus N` it reads RANK / LOCAL_RANK / WORLD_SIZE from the environment.
 
   value       real frames/s over the whole job = N*B*17*K / max-over-ranks(time of K steps)
-  roofline    the MFMA kernels (conv_igemm_glds_kernel, conv3x3_ws128_kernel, conv3d_narrow_kernel, tblock_split_kernel: all
+  roofline    the MFMA kernels (conv_igemm_glds_kernel, conv3x3_ws2_kernel, conv3d_narrow_kernel, tblock_pair_kernel: all
               convolutions + the attention GEMMs = every MFMA FLOP of the path): algorithmic FLOPs of one step (1.0345 TFLOP per padded 256x256 frame, SURVEY.md
               section 8d) / that kernel's time in one step.  The kernel time is measured live: the conv
               launches of one step (same descriptors, same tensors) are replayed back to back from a
@@ -383,7 +383,7 @@ def main():
         # unit over kernel time -- is an effective rate; the executed rate is reported next to it
         executed = sum(2.0 * M * N * K for (M, N, K) in tl)
         peak = PEAK_TFLOPS[args.dtype]
-        roof = {"bound": "mfma", "kernel": "conv_igemm_glds_kernel + conv3x3_ws128_kernel + conv3d_narrow_kernel + tblock_split_kernel", "achieved": round(achieved, 2), "peak": peak,
+        roof = {"bound": "mfma", "kernel": "conv_igemm_glds_kernel + conv3x3_ws2_kernel + conv3d_narrow_kernel + tblock_pair_kernel", "achieved": round(achieved, 2), "peak": peak,
                 "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": None, "traffic_source": "not measured",
                 "launches_per_step": len(tl), "kernel_ms_per_step": round(conv_ms, 3),
                 "avg_launch_ms": round(conv_ms / max(1, len(tl)), 4), "algorithmic_tflop_per_step": round(flops / 1e12, 3),

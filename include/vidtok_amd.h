@@ -189,8 +189,12 @@ int vt_conv_desc_size(void);
  * on an NDHWC activation x [B][T][HW][ld]; optionally also n_out = [SiLU](LayerNorm_next(y)), the norm the consumer
  * of y starts with (same contract as vt_conv's ln_mode / ln_keep_y).  LayerNorms are per position over C, eps as
  * given, statistics in fp32.  w1 / w2 are packed like vt_conv weights: [C][3*C], k = kt*C + c.
- * tmode: VT_TPAD_ZERO (frames before the clip are zeros) or VT_TPAD_REPLICATE (first frame repeated); the
- * chunk-to-chunk cache mode of v1.1 tiling is not covered -- callers keep such blocks on vt_layernorm_act + vt_conv.
+ * tmode: VT_TPAD_ZERO (frames before the clip are zeros), VT_TPAD_REPLICATE (first frame repeated) or VT_TPAD_CACHE
+ * (the two frames a previous chunk left: v1.1 tiling, CausalConv1d.causal_cache of model_3dcausal_v1_1.py:159-178).
+ * The cached tensors are the INPUTS of the two convolutions -- SiLU(LN1(x)) and SiLU(LN2(conv1)), which a fused launch
+ * never writes out -- so the launch keeps them itself: cache1 / cache2 [B][2][HW][ld] are read in cache mode and, when
+ * given (any tmode), rewritten in place with frames T - cache_offset - 2, T - cache_offset - 1 of this clip (the
+ * reference's padded[:len - cache_offset][-2:]); T - cache_offset >= 3 is required.
  * Covered shapes: bf16, C = ld = 128, HW % 64 == 0 (the widest level of every 488 / 41616 / 288 config);
  * vt_temporal_block_supported(d) says so without launching (1 / 0); anything else returns VT_ERR_ARG.
  * ------------------------------------------------------------------------------------------ */
@@ -207,10 +211,13 @@ typedef struct vt_tblock_desc {
   int32_t C, ld;
   int32_t B, T;
   int64_t HW;
-  int32_t tmode;                 /* VT_TPAD_ZERO | VT_TPAD_REPLICATE                           */
+  int32_t tmode;                 /* VT_TPAD_ZERO | VT_TPAD_REPLICATE | VT_TPAD_CACHE           */
   int32_t keep_y;                /* 0: only n_out is needed (y is never written)               */
   int32_t ln_next_mode;          /* 0 none, 1 LayerNorm, 2 LayerNorm + SiLU                    */
   float eps;
+  int32_t cache_offset;          /* frames at the end of the clip that the kept chunk state skips */
+  void* cache1;                  /* [B][2][HW][ld] chunk state of conv1 (see above), or NULL    */
+  void* cache2;                  /* ... of conv2                                               */
 } vt_tblock_desc;
 
 /* sizeof(vt_tblock_desc) as compiled: lets a binding verify its struct mirror */

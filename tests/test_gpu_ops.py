@@ -245,7 +245,42 @@ def test_temporal_block_fused(shape, tmode, nxt, keep):
     assert not ops.temporal_block_supported(_act(1, 2, 8, 8, 128, torch.float32, 1), tmode)
     assert not ops.temporal_block_supported(_act(1, 2, 8, 8, 256, dt, 1), tmode)
     assert not ops.temporal_block_supported(_act(1, 2, 5, 7, 128, dt, 1), tmode)
-    assert not ops.temporal_block_supported(x, L.VT_TPAD_CACHE)
+    assert not ops.temporal_block_supported(x, L.VT_TPAD_CACHE)          # cache mode without caches
+
+
+@pytest.mark.parametrize("shape,off,cuts", [((2, 14, 16, 16), 0, (5, 9)), ((1, 26, 64, 64), 4, (9, 17)), ((3, 12, 24, 48), 2, (6,))],
+                         ids=["two_cuts", "lookahead_4_256_columns", "lookahead_2_uneven_split"])
+def test_temporal_block_chunked(shape, off, cuts):
+    """v1.1 tiling through the fused launch (VERDICT r2 #5a): a clip run as chunks -- first chunk with replicate padding,
+    later ones from the chunk state the launch itself keeps (caches of BOTH convolutions' inputs, rewritten in place,
+    `cache_offset` look-ahead frames recomputed by the next chunk: reference model_3dcausal_v1_1.py:159-178) -- must give
+    the bits of the same clip run in one launch: the ring rows a chunk restores are the ring rows the previous one had."""
+    B, T, H, W = shape
+    dt, C_ = torch.bfloat16, 128
+    x = _act(B, T, H, W, C_, dt, 1)
+    g = torch.Generator().manual_seed(2)
+    ws = [pack_conv_weight(torch.randn((C_, C_, 3), generator=g) / math.sqrt(3 * C_), dt, cin_stored=C_).to(DEV) for _ in range(2)]
+    bs = [_rand((C_,), torch.float32, 3 + i, 0.1) for i in range(2)]
+    norms = [(_rand((C_,), torch.float32, 10 + i, 0.3) + 1.0, _rand((C_,), torch.float32, 20 + i, 0.2)) for i in range(3)]
+    nxt = (norms[2][0], norms[2][1], True)
+    run = lambda xs, **kw: ops.temporal_block(xs.contiguous(), ws[0], bs[0], ws[1], bs[1], norms[0], norms[1], next_ln=nxt, **kw)
+    whole = run(x, tmode=L.VT_TPAD_REPLICATE)
+    caches = tuple(torch.full((B, 2, H, W, C_), float("nan"), dtype=dt, device=DEV) for _ in range(2))
+    # chunk i covers frames [start_i, end_i); the next one starts `off` frames before end_i (they are computed twice)
+    bounds, start = [], 0
+    for cpos in list(cuts) + [T]:
+        bounds.append((start, cpos))
+        start = cpos - off
+    for i, (t0, t1) in enumerate(bounds):
+        tmode = L.VT_TPAD_REPLICATE if i == 0 else L.VT_TPAD_CACHE
+        assert ops.temporal_block_supported(x[:, t0:t1].contiguous(), tmode, None, caches, off)
+        part = run(x[:, t0:t1], tmode=tmode, caches=caches, cache_offset=off)
+        torch.cuda.synchronize()
+        for o, w_ in zip(part, whole):
+            assert torch.equal(o, w_[:, t0:t1]), (i, t0, t1)
+        assert all(torch.isfinite(c_.float()).all() for c_ in caches)
+    # a clip too short to leave two frames behind its look-ahead is not covered (the host keeps such blocks unfused)
+    assert not ops.temporal_block_supported(x[:, :off + 2].contiguous(), L.VT_TPAD_CACHE, None, caches, off)
 
 
 def test_weight_stationary_kernels_are_split_independent():

@@ -16,8 +16,10 @@
 //            GEMM2: taps = ring2 slots                                        -> T2 (fp32)
 //            rows of T2 + b2 + x[t] -> y[t], LayerNorm_next -> n[t]                                     (HBM)
 // Causal padding: frames before the clip are zeros (v1.0: their taps are skipped) or the first frame repeated (v1.1
-// first chunk / un-tiled).  Chunk-to-chunk caches (v1.1 tiling) are not handled here: the host keeps those blocks on
-// the unfused path.  Earlier arrangements are in the history: four waves, every phase on the same wave (14 960 cycles
+// first chunk / un-tiled) or the two frames a previous chunk left behind (v1.1 tiling: CausalConv1d.causal_cache of both
+// convolutions, reference model_3dcausal_v1_1.py:159-178 -- here the INPUTS of the two convolutions are intermediates
+// that never reach memory, so the kernel keeps the caches itself: at the start of a column it fills the ring slots of
+// frames -2, -1 from them, and it writes the rows of frames T - cache_offset - 2, T - cache_offset - 1 back).  Earlier arrangements are in the history: four waves, every phase on the same wave (14 960 cycles
 // per step; commit da80542), and eight waves in two roles -- matrix waves / row waves (11 000 cycles; commit ee72952,
 // profiles/r02_tblock_v3_phase_cycles.txt).
 #include <atomic>
@@ -45,7 +47,10 @@ struct TBlockArgs {
   const float* g2; const float* be2;
   const float* gn; const float* ben;
   int B, T, HW;
-  int replicate;      // 0: zero frames before the clip, 1: first frame repeated
+  int replicate;      // frames before the clip: 0 zeros, 1 the first frame repeated, 2 the two cached frames (cache1 / cache2)
+  bf16_t* cache1;     // [B][2][HW][128]: conv1's input (SiLU(LN1(x))) at frames -2, -1; rewritten in place with frames
+  bf16_t* cache2;     //   T - cache_off - 2, T - cache_off - 1 of this clip (NULL: no chunk state kept); conv2's input likewise
+  int cache_off;
   int keep_y;         // write y (0 only with ln_next != 0: the consumer needs just the normalised tensor)
   int ln_next;        // 0 none, 1 LayerNorm, 2 LayerNorm + SiLU
   float eps;
@@ -182,7 +187,10 @@ __device__ __forceinline__ void t4_row_norm(float (&v)[8], const float (&g)[8], 
   }
 }
 
-template <int LNN, bool KEEP, bool PROF = false>
+// CACHE: the instantiation that keeps v1.1 chunk state (cache1 / cache2).  Separate because its loads and stores are
+// conditional (a column starts, a kept frame goes by), and with conditional memory operations in the step body the
+// compiler no longer counts what is in flight -- it waits for everything.
+template <int LNN, bool KEEP, bool CACHE, bool PROF = false>
 __global__ __launch_bounds__(512, 1) void tblock_pair_kernel(const TBlockArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -285,8 +293,9 @@ __global__ __launch_bounds__(512, 1) void tblock_pair_kernel(const TBlockArgs p)
     int sp[3];
 #pragma unroll
     for (int kt = 0; kt < 3; ++kt) {
-      // tap kt = frame t - 2 + kt; replicate: frames before the clip = its frame 0 (virtual step k - t)
-      const int back = (t - 2 + kt >= 0) ? 2 - kt : t;
+      // tap kt = frame t - 2 + kt; replicate: frames before the clip = its frame 0 (virtual step k - t); cache: their own
+      // slots (filled from the cache at the start of the column)
+      const int back = (t - 2 + kt >= 0 || (CACHE && p.replicate == 2)) ? 2 - kt : t;
       int sl = s3 - back;
       sl = sl < 0 ? sl + 3 : sl;
       sp[kt] = frag_off + sl * TB_SLOT;
@@ -309,7 +318,7 @@ __global__ __launch_bounds__(512, 1) void tblock_pair_kernel(const TBlockArgs p)
     asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");             // last MFMA -> first VALU reader of its accumulator
   };
   auto run_gemm = [&](int roff, int s3, int t) __attribute__((always_inline)) {
-    const int first = p.replicate ? 0 : max(0, 2 - t);               // uniform
+    const int first = p.replicate != 0 ? 0 : max(0, 2 - t);          // uniform
     if (first == 0) gemm(std::integral_constant<int, 0>{}, roff, s3, t);
     else if (first == 1) gemm(std::integral_constant<int, 1>{}, roff, s3, t);
     else gemm(std::integral_constant<int, 2>{}, roff, s3, t);
@@ -353,7 +362,7 @@ __global__ __launch_bounds__(512, 1) void tblock_pair_kernel(const TBlockArgs p)
     oct_j = vt & 15;
     row0 = vt >> 4;
   };
-  auto ld_prm = [&](int arr, int oct_j, float (&o)[8]) {
+  auto ld_prm = [&](int arr, int oct_j, float (&o)[8]) __attribute__((always_inline)) {
     const f32x4 a = *reinterpret_cast<const f32x4*>(prm + arr * 128 + 8 * oct_j);
     const f32x4 b = *reinterpret_cast<const f32x4*>(prm + arr * 128 + 8 * oct_j + 4);
 #pragma unroll
@@ -363,7 +372,7 @@ __global__ __launch_bounds__(512, 1) void tblock_pair_kernel(const TBlockArgs p)
     }
   };
   // x rows of the step at cursor c: units [U0, U1) of my group
-  auto load_rows = [&](auto u0_c, auto u1_c, u32x4 (&dst)[4], const Cur& c) {
+  auto load_rows = [&](auto u0_c, auto u1_c, u32x4 (&dst)[4], const Cur& c) __attribute__((always_inline)) {
     constexpr int U0 = decltype(u0_c)::value, U1 = decltype(u1_c)::value;
     int oct_j, row0;
     unit_geom(oct_j, row0);
@@ -373,7 +382,35 @@ __global__ __launch_bounds__(512, 1) void tblock_pair_kernel(const TBlockArgs p)
     for (int it = U0; it < U1; ++it) dst[it] = __builtin_amdgcn_raw_buffer_load_b128(rs, vo + it * (16 * 256), 0, 0);
   };
   // L1 of units [U0, U1): LayerNorm1 + SiLU of x rows -> ring1 slot s3
-  auto ln1_units = [&](auto u0_c, auto u1_c, const u32x4 (&xr)[4], int s3) {
+  // chunk state: the row of frame c.t that a convolution's cache keeps (slot j = t - (T - cache_off - 2) in {0, 1})
+  auto cache_put = [&](bf16_t* cache, const Cur& c, int oct_j, int row, const u32x4& w) __attribute__((always_inline)) {
+    if constexpr (!CACHE) return;
+    const int j = c.t - (p.T - p.cache_off - 2);
+    if (cache != nullptr && (j == 0 || j == 1)) {                    // uniform
+      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(cache + ((long long)c.b * 2 + j) * p.HW * 128, 0, frame_bytes, 0x00020000);
+      __builtin_amdgcn_raw_buffer_store_b128(w, rs, (c.pt * TB_PIX + row) * 256 + oct_j * 16, 0, 0);
+    }
+  };
+  // ... and the other direction: the cached frames -2, -1 of the column at cursor c into ring slots sl2, sl1 (a group's 256
+  // threads move 2 x 64 rows of 256 B; once per column)
+  auto cache_get = [&](const bf16_t* cache, int roff, const Cur& c, int sl2, int sl1) __attribute__((always_inline)) {
+    if constexpr (!CACHE) return;
+    int oct_j, row0;
+    unit_geom(oct_j, row0);
+    u32x4 w[2][4];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(cache) + ((long long)c.b * 2 + j) * p.HW * 128, 0, frame_bytes, 0x00020000);
+#pragma unroll
+      for (int it = 0; it < 4; ++it) w[j][it] = __builtin_amdgcn_raw_buffer_load_b128(rs, (c.pt * TB_PIX + row0 + 16 * it) * 256 + oct_j * 16, 0, 0);
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int it = 0; it < 4; ++it)
+        *reinterpret_cast<u32x4*>(smem + roff + (j == 0 ? sl2 : sl1) * TB_SLOT + (row0 + 16 * it) * TB_ROWP + oct_j * 16) = w[j][it];
+  };
+  auto ln1_units = [&](auto u0_c, auto u1_c, const u32x4 (&xr)[4], int s3, const Cur& c) __attribute__((always_inline)) {
     constexpr int U0 = decltype(u0_c)::value, U1 = decltype(u1_c)::value;
     int oct_j, row0;
     unit_geom(oct_j, row0);
@@ -386,7 +423,9 @@ __global__ __launch_bounds__(512, 1) void tblock_pair_kernel(const TBlockArgs p)
       float v[8], o[8];
       t3_unpack8(xr[it], v);
       t4_row_norm_pairs<true>(v, g, b, p.eps, o);
-      *reinterpret_cast<u32x4*>(smem + wo + it * (16 * TB_ROWP)) = t3_pack8(o);
+      const u32x4 w = t3_pack8(o);
+      *reinterpret_cast<u32x4*>(smem + wo + it * (16 * TB_ROWP)) = w;
+      cache_put(p.cache1, c, oct_j, row0 + 16 * it, w);
     }
   };
 
@@ -406,10 +445,11 @@ __global__ __launch_bounds__(512, 1) void tblock_pair_kernel(const TBlockArgs p)
   __syncthreads();               // parameters are in the LDS
   if (grp == 0) {
     load_rows(std::integral_constant<int, 0>{}, std::integral_constant<int, 3>{}, sa.xn, c_0);
-    ln1_units(std::integral_constant<int, 0>{}, std::integral_constant<int, 3>{}, sa.xn, 0);
+    ln1_units(std::integral_constant<int, 0>{}, std::integral_constant<int, 3>{}, sa.xn, 0, c_0);
   } else {
     load_rows(std::integral_constant<int, 3>{}, std::integral_constant<int, 4>{}, sa.xn, c_0);
-    ln1_units(std::integral_constant<int, 3>{}, std::integral_constant<int, 4>{}, sa.xn, 0);
+    ln1_units(std::integral_constant<int, 3>{}, std::integral_constant<int, 4>{}, sa.xn, 0, c_0);
+    if (CACHE && p.replicate == 2) cache_get(p.cache1, R1, c_0, 1, 2);         // frames -2, -1 of the first column: slots (-2) % 3, (-1) % 3
   }
   cur_step(c_p1);
   c_p2 = c_p1;
@@ -452,7 +492,7 @@ __global__ __launch_bounds__(512, 1) void tblock_pair_kernel(const TBlockArgs p)
   __syncthreads();               // L1(0) is in ring1
 
   // L2 of units [U0, U1) of the step whose ring slot is sl: rows of T1 (conv1, bf16) + b1 -> LayerNorm2 + SiLU -> ring2
-  auto l2_units = [&](auto u0_c, auto u1_c, int sl) __attribute__((always_inline)) {
+  auto l2_units = [&](auto u0_c, auto u1_c, int sl, const Cur& c) __attribute__((always_inline)) {
     constexpr int U0 = decltype(u0_c)::value, U1 = decltype(u1_c)::value;
     int oct_j, row0;
     unit_geom(oct_j, row0);
@@ -472,7 +512,9 @@ __global__ __launch_bounds__(512, 1) void tblock_pair_kernel(const TBlockArgs p)
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] = v[e] + bo1[e];
       t4_row_norm<true>(v, g, b, p.eps, o);
-      *reinterpret_cast<u32x4*>(smem + wo + it * (16 * TB_ROWP)) = t3_pack8(o);
+      const u32x4 w = t3_pack8(o);
+      *reinterpret_cast<u32x4*>(smem + wo + it * (16 * TB_ROWP)) = w;
+      cache_put(p.cache2, c, oct_j, row0 + 16 * it, w);
     }
   };
   // O of unit IT of the step at cursor c: rows of T2 + b2 + x -> y, LayerNorm_next -> n
@@ -525,7 +567,10 @@ __global__ __launch_bounds__(512, 1) void tblock_pair_kernel(const TBlockArgs p)
       // ---- phase A_k: G1(k) (the result stays in the accumulators across the barrier), one unit of L2(k-1)
       if ((!GUARD || k < n) && !(PROF && (p.prof_mode & 1))) run_gemm(R1, s3, c_0.t);
       stamp(1);
-      if ((!GUARD || (k >= 1 && k - 1 < n)) && !(PROF && (p.prof_mode & 2))) l2_units(I3{}, I4{}, slot_back(1));
+      if ((!GUARD || (k >= 1 && k - 1 < n)) && !(PROF && (p.prof_mode & 2))) l2_units(I3{}, I4{}, slot_back(1), c_m1);
+      // step k-1 opened a column: conv2's cached frames -2, -1 go into ring2 slots (k-3) % 3, (k-2) % 3 -- read for the last
+      // time by G2(k-2) in phase B_{k-1}, needed by G2(k-1) in phase B_k
+      if (CACHE && p.replicate == 2 && k >= 1 && k - 1 < n && c_m1.t == 0) cache_get(p.cache2, R2, c_m1, s3, slot_back(2));
       stamp(2);
       __syncthreads();
       // ---- phase B_k: requests for B_{k+1} in front of this phase's stores, T1 <- conv1(k), my units of O(k-2) and L1(k+1)
@@ -537,10 +582,10 @@ __global__ __launch_bounds__(512, 1) void tblock_pair_kernel(const TBlockArgs p)
       const bool do_o = (!GUARD || (k >= 2 && k - 2 < n)) && !(PROF && (p.prof_mode & 2));
       const bool do_l1 = (!GUARD || k + 1 < n) && !(PROF && (p.prof_mode & 2));
       if (do_o) o_unit(I0{}, cur.xr[0], c_m2);
-      if (do_l1) ln1_units(I0{}, I1{}, cur.xn, slot_back(2));       // (k + 1) % 3 = (k - 2) % 3
+      if (do_l1) ln1_units(I0{}, I1{}, cur.xn, slot_back(2), c_p1);   // (k + 1) % 3 = (k - 2) % 3
       if (do_o) o_unit(I1{}, cur.xr[1], c_m2);
       stamp(4);
-      if (do_l1) ln1_units(I1{}, I3{}, cur.xn, slot_back(2));
+      if (do_l1) ln1_units(I1{}, I3{}, cur.xn, slot_back(2), c_p1);
       stamp(5);
       __syncthreads();
       stamp(6);
@@ -564,7 +609,7 @@ __global__ __launch_bounds__(512, 1) void tblock_pair_kernel(const TBlockArgs p)
       // ---- phase A_k: T2 <- conv2(k-2) (nobody reads T2 in an A phase), three units of L2(k-1)
       if (!GUARD || (k >= 2 && k - 2 < n)) acc_to_T2();
       stamp(1);
-      if ((!GUARD || (k >= 1 && k - 1 < n)) && !(PROF && (p.prof_mode & 2))) l2_units(I0{}, I3{}, slot_back(1));
+      if ((!GUARD || (k >= 1 && k - 1 < n)) && !(PROF && (p.prof_mode & 2))) l2_units(I0{}, I3{}, slot_back(1), c_m1);
       stamp(2);
       __syncthreads();
       // ---- phase B_k: requests for B_{k+1}; G2(k-1); my units of O(k-2) and L1(k+1)
@@ -577,8 +622,11 @@ __global__ __launch_bounds__(512, 1) void tblock_pair_kernel(const TBlockArgs p)
       const bool do_l1 = (!GUARD || k + 1 < n) && !(PROF && (p.prof_mode & 2));
       if (do_o) o_unit(I2{}, cur.xr[2], c_m2);
       stamp(4);
-      if (do_l1) ln1_units(I3{}, I4{}, cur.xn, slot_back(2));
+      if (do_l1) ln1_units(I3{}, I4{}, cur.xn, slot_back(2), c_p1);
       if (do_o) o_unit(I3{}, cur.xr[3], c_m2);
+      // step k+1 opens a column: conv1's cached frames -2, -1 go into ring1 slots (k-1) % 3, k % 3 -- read for the last time
+      // by G1(k) in phase A_k, needed by G1(k+1) in phase A_{k+1}
+      if (CACHE && p.replicate == 2 && k + 1 < n && c_p1.t == 0) cache_get(p.cache1, R1, c_p1, slot_back(1), s3);
       stamp(5);
       __syncthreads();
       stamp(6);
@@ -608,7 +656,11 @@ extern "C" int vt_temporal_block_supported(const vt_tblock_desc* d) {
   if (!d) return 0;
   if (d->dtype != VT_BF16 || d->C != 128 || d->ld != 128) return 0;
   if (d->B <= 0 || d->T <= 0 || d->HW <= 0 || d->HW % TB_PIX != 0) return 0;
-  if (d->tmode != VT_TPAD_ZERO && d->tmode != VT_TPAD_REPLICATE) return 0;
+  if (d->tmode != VT_TPAD_ZERO && d->tmode != VT_TPAD_REPLICATE && d->tmode != VT_TPAD_CACHE) return 0;
+  if (d->tmode == VT_TPAD_CACHE && (d->cache1 == nullptr || d->cache2 == nullptr)) return 0;
+  // chunk state is rewritten in place: the rows it keeps must come from frames >= 1 of this clip (frame 0's rows are written
+  // in the phase that still reads the old ones)
+  if ((d->cache1 != nullptr || d->cache2 != nullptr) && (d->cache_offset < 0 || d->T - d->cache_offset < 3)) return 0;
   if (d->ln_next_mode < 0 || d->ln_next_mode > 2) return 0;
   if (vt_opt(OPT_TBLOCK_FUSED) == 0) return 0;
   return 1;
@@ -619,8 +671,9 @@ int tblock_launch(const vt_tblock_desc* d, vt_stream stream_, unsigned long long
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
   VT_CHECK_ARG(d != nullptr, "vt_temporal_block: null descriptor");
   VT_CHECK_ARG(vt_temporal_block_supported(d),
-               "vt_temporal_block: only bf16, C = ld = 128, HW %% 64 == 0, zero / replicate time padding (got dtype %d C %d ld %d "
-               "HW %lld tmode %d)", d->dtype, d->C, d->ld, (long long)d->HW, d->tmode);
+               "vt_temporal_block: only bf16, C = ld = 128, HW %% 64 == 0; cache mode needs both caches, kept chunk state "
+               "T - cache_offset >= 3 (got dtype %d C %d ld %d HW %lld T %d tmode %d cache_offset %d)", d->dtype, d->C, d->ld,
+               (long long)d->HW, d->T, d->tmode, d->cache_offset);
   VT_CHECK_ARG(d->x && d->w1 && d->w2 && d->norm1_gamma && d->norm1_beta && d->norm2_gamma && d->norm2_beta,
                "vt_temporal_block: null tensor pointer");
   VT_CHECK_ARG(d->keep_y || d->ln_next_mode != 0, "vt_temporal_block: nothing to write (keep_y = 0 and no next norm)");
@@ -635,7 +688,9 @@ int tblock_launch(const vt_tblock_desc* d, vt_stream stream_, unsigned long long
   a.g1 = d->norm1_gamma; a.be1 = d->norm1_beta; a.g2 = d->norm2_gamma; a.be2 = d->norm2_beta;
   a.gn = d->next_gamma; a.ben = d->next_beta;
   a.B = d->B; a.T = d->T; a.HW = (int)d->HW;
-  a.replicate = d->tmode == VT_TPAD_REPLICATE ? 1 : 0;
+  a.replicate = d->tmode == VT_TPAD_REPLICATE ? 1 : (d->tmode == VT_TPAD_CACHE ? 2 : 0);
+  a.cache1 = (bf16_t*)d->cache1; a.cache2 = (bf16_t*)d->cache2; a.cache_off = d->cache_offset;
+  VT_CHECK_ARG(((reinterpret_cast<uintptr_t>(d->cache1) | reinterpret_cast<uintptr_t>(d->cache2)) & 15) == 0, "vt_temporal_block: caches must be 16-byte aligned");
   a.keep_y = d->keep_y ? 1 : 0;
   a.ln_next = d->ln_next_mode;
   a.eps = d->eps;
@@ -643,18 +698,23 @@ int tblock_launch(const vt_tblock_desc* d, vt_stream stream_, unsigned long long
   a.prof_mode = prof ? vt_opt(OPT_TBLOCK_PROF_MODE) : 0;
   VT_CHECK_ARG((long long)d->HW * 256 < (1ll << 31), "vt_temporal_block: frames of at most 2^23 pixels");
   // one instantiation per output shape: next norm none / LayerNorm / LayerNorm+SiLU, y kept or not
-  static const void* const kerns2[6] = {
-      reinterpret_cast<const void*>(&tblock_pair_kernel<0, true>), reinterpret_cast<const void*>(&tblock_pair_kernel<1, true>),
-      reinterpret_cast<const void*>(&tblock_pair_kernel<1, false>), reinterpret_cast<const void*>(&tblock_pair_kernel<2, true>),
-      reinterpret_cast<const void*>(&tblock_pair_kernel<2, false>), reinterpret_cast<const void*>(&tblock_pair_kernel<2, true, true>)};
+  static const void* const kerns2[11] = {
+      reinterpret_cast<const void*>(&tblock_pair_kernel<0, true, false>), reinterpret_cast<const void*>(&tblock_pair_kernel<1, true, false>),
+      reinterpret_cast<const void*>(&tblock_pair_kernel<1, false, false>), reinterpret_cast<const void*>(&tblock_pair_kernel<2, true, false>),
+      reinterpret_cast<const void*>(&tblock_pair_kernel<2, false, false>), reinterpret_cast<const void*>(&tblock_pair_kernel<2, true, false, true>),
+      reinterpret_cast<const void*>(&tblock_pair_kernel<0, true, true>), reinterpret_cast<const void*>(&tblock_pair_kernel<1, true, true>),
+      reinterpret_cast<const void*>(&tblock_pair_kernel<1, false, true>), reinterpret_cast<const void*>(&tblock_pair_kernel<2, true, true>),
+      reinterpret_cast<const void*>(&tblock_pair_kernel<2, false, true>)};
+  const bool cached = a.replicate == 2 || a.cache1 != nullptr || a.cache2 != nullptr;
   int ki = a.ln_next == 0 ? 0 : (a.ln_next == 1 ? (a.keep_y ? 1 : 2) : (a.keep_y ? 3 : 4));
   int lds = T4_LDS;
   const unsigned threads = 512;
   if (prof != nullptr) {                      // measurement aid: stamps [wave 0..7][step][8] of the LayerNorm+SiLU, y kept instantiation
-    VT_CHECK_ARG(a.ln_next == 2 && a.keep_y, "vt_temporal_block_profile: ln_next_mode 2 and keep_y only");
+    VT_CHECK_ARG(a.ln_next == 2 && a.keep_y && !cached, "vt_temporal_block_profile: ln_next_mode 2 and keep_y only, no chunk state");
     ki = 5;
     lds += 2048;
   }
+  if (cached) ki += 6;
   const void* kern = kerns2[ki];
   // per device, once: the dynamic-LDS attribute of every instantiation and the CU count (not a per-launch runtime call)
   static std::atomic<int> cus[kMaxDevices];
@@ -662,7 +722,7 @@ int tblock_launch(const vt_tblock_desc* d, vt_stream stream_, unsigned long long
   VT_CHECK_HIP(hipGetDevice(&dev));
   int ncu = (dev >= 0 && dev < kMaxDevices) ? cus[dev].load(std::memory_order_acquire) : 0;
   if (ncu == 0) {
-    for (int k = 0; k < 6; ++k)
+    for (int k = 0; k < 11; ++k)
       VT_CHECK_HIP(hipFuncSetAttribute(kerns2[k], hipFuncAttributeMaxDynamicSharedMemorySize, k == 5 ? T4_LDS + 2048 : T4_LDS));
     VT_CHECK_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
     if (ncu <= 0) ncu = 256;

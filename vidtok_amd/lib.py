@@ -62,7 +62,7 @@ class TBlockDesc(C.Structure):
         + [(n, C.c_int32) for n in ("dtype", "C", "ld", "B", "T")]
         + [("HW", C.c_int64)]
         + [(n, C.c_int32) for n in ("tmode", "keep_y", "ln_next_mode")]
-        + [("eps", C.c_float)]
+        + [("eps", C.c_float), ("cache_offset", C.c_int32), ("cache1", C.c_void_p), ("cache2", C.c_void_p)]
     )
 
 

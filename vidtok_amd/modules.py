@@ -497,19 +497,42 @@ class ResnetCausalBlock1D(nn.Module):
             self.conv2.conv.weight.data.zero_()
             self.conv2.conv.bias.data.zero_()
 
-    # v1.1 blocks keep chunk-to-chunk caches of their convolutions' inputs, which the fused launch never materialises:
-    # an engine that is NOT tiling sets this (AutoencodingEngineV11._set_fused_temporal); v1.0 has no caches
+    # v1.1 blocks keep chunk-to-chunk caches of their convolutions' INPUTS, which a fused launch never materialises.  An
+    # engine that is NOT tiling sets `allow_fused` (AutoencodingEngineV11._set_fused_temporal): no chunk follows, nothing
+    # to keep.  A tiling engine leaves it False and the launch keeps the chunk state itself (ops.temporal_block `caches`);
+    # v1.0 has no caches.
     allow_fused = False
 
     def _fusable(self, dt):
-        """may run as ONE launch (ops.temporal_block): LayerNorm variant, C -> C, bf16, no live v1.1 chunk state"""
+        """may run as ONE launch (ops.temporal_block): LayerNorm variant, C -> C, bf16"""
         if not _FUSE_TBLOCK or dt != torch.bfloat16 or self.in_channels != self.out_channels:
             return False
         if not (self.norm1.fusable and self.norm2.fusable) or self.norm1.norm.eps != self.norm2.norm.eps:
             return False
         if self.in_channels != 128:          # the kernel's LayerNorm statistics span exactly 128 REAL channels
             return False
-        return self.conv1.version == "v1_0" or (self.allow_fused and self.conv1.is_first_chunk)
+        if self.conv1.version == "v1_0" or (self.allow_fused and self.conv1.is_first_chunk):
+            return True
+        # a chunk of a tiled v1.1 pass: both convolutions at the same point of the chunk schedule, and -- past the first
+        # chunk -- both caches there
+        c1, c2 = self.conv1, self.conv2
+        if c1.cache_offset != c2.cache_offset or c1.is_first_chunk != c2.is_first_chunk:
+            return False
+        return c1.is_first_chunk or (c1.causal_cache is not None and c2.causal_cache is not None)
+
+    def _chunk_state(self, xp):
+        """(tmode, caches, cache_offset) of a fused launch: (zero | replicate, None, 0) where no chunk state lives, else the
+        two persistent cache buffers (allocated on the first chunk, the convolutions' `causal_cache` afterwards)"""
+        c1, c2 = self.conv1, self.conv2
+        if c1.version == "v1_0":
+            return L.VT_TPAD_ZERO, None, 0
+        if self.allow_fused and c1.is_first_chunk:
+            return L.VT_TPAD_REPLICATE, None, 0
+        shape = (xp.shape[0], 2) + tuple(xp.shape[2:])
+        if c1.is_first_chunk:
+            return L.VT_TPAD_REPLICATE, (c1._persistent(shape, xp), c2._persistent(shape, xp)), c1.cache_offset
+        ok = all(t.shape == shape and t.dtype == xp.dtype and t.is_contiguous() for t in (c1.causal_cache, c2.causal_cache))
+        return L.VT_TPAD_CACHE, ((c1.causal_cache, c2.causal_cache) if ok else None), c1.cache_offset
 
     def first_norm(self, dt=None):
         # a fused block normalises x itself: its producer must not spend a write on LayerNorm1(x)
@@ -519,8 +542,8 @@ class ResnetCausalBlock1D(nn.Module):
 
     def run(self, x, dt, next_norm=None):
         xp = plain(x)
-        tmode = L.VT_TPAD_ZERO if self.conv1.version == "v1_0" else L.VT_TPAD_REPLICATE
-        if self._fusable(dt) and ops.temporal_block_supported(xp, tmode, self.in_channels):
+        tmode, caches, off = self._chunk_state(xp) if self._fusable(dt) else (L.VT_TPAD_ZERO, None, 0)
+        if self._fusable(dt) and ops.temporal_block_supported(xp, tmode, self.in_channels, caches, off):
             c = xp.shape[-1]
             w1, b1 = self.conv1._pack.get(self.conv1.conv.weight, self.conv1.conv.bias, dt, cin_stored=c)
             w2, b2 = self.conv2._pack.get(self.conv2.conv.weight, self.conv2.conv.bias, dt, cin_stored=c)
@@ -529,7 +552,9 @@ class ResnetCausalBlock1D(nn.Module):
                 g, b = next_norm[0].affine()
                 nxt = (g, b, next_norm[1])
             out = ops.temporal_block(xp, w1, b1, w2, b2, self.norm1.affine(), self.norm2.affine(), tmode=tmode,
-                                     eps=self.norm1.norm.eps, next_ln=nxt, keep_y=True)
+                                     eps=self.norm1.norm.eps, next_ln=nxt, keep_y=True, caches=caches, cache_offset=off)
+            if caches is not None:          # the launch has rewritten the chunk state in place
+                self.conv1.causal_cache, self.conv2.causal_cache = caches
             return out if nxt is None else Normed(out[0], out[1], next_norm[0], next_norm[1])
         h = self.norm1.apply_ndhwc(x, True, dt, SITE_POS)
         x = xp

@@ -184,29 +184,38 @@ def conv(x, w, bias, geom: ConvGeom, *, cout: int, out_dtype=None, tmode=L.VT_TP
     return (y, n) if ln_keep_y else n
 
 
-def _tblock_desc(x, tmode, c=None):
+def _tblock_desc(x, tmode, c=None, caches=None, cache_offset=0):
     d = L.TBlockDesc()
     B, T, H, W, ld = x.shape
     d.dtype, d.C, d.ld, d.B, d.T, d.HW, d.tmode = _DT.get(x.dtype, -1), (ld if c is None else c), ld, B, T, H * W, tmode
+    if caches is not None:
+        for t in caches:
+            _chk(t, "tblock.cache")
+            assert tuple(t.shape) == (B, 2, H, W, ld) and t.dtype == x.dtype, (tuple(t.shape), tuple(x.shape))
+        d.cache1, d.cache2, d.cache_offset = caches[0].data_ptr(), caches[1].data_ptr(), int(cache_offset)
     return d
 
 
-def temporal_block_supported(x, tmode, c=None) -> bool:
+def temporal_block_supported(x, tmode, c=None, caches=None, cache_offset=0) -> bool:
     """True if vt_temporal_block covers a block of `c` real channels (default: the stored count) on this activation
-    (bf16, C = ld = 128 -- a block whose channels are PADDED to 128 is not covered: the statistics span C --, HW % 64 == 0,
-    zero / replicate time padding): the fused launch for ResnetCausalBlock1D (reference model_3dcausal.py:473-499)."""
+    (bf16, C = ld = 128 -- a block whose channels are PADDED to 128 is not covered: the statistics span C --, HW % 64 == 0;
+    with chunk state -- `caches`, required by tmode VT_TPAD_CACHE -- the clip must keep T - cache_offset >= 3 frames):
+    the fused launch for ResnetCausalBlock1D (reference model_3dcausal.py:473-499, v1.1 chunks model_3dcausal_v1_1.py:159-178)."""
     if not x.is_cuda or x.dtype not in _DT:
         return False
-    return bool(L.load().vt_temporal_block_supported(C.byref(_tblock_desc(x, tmode, c))))
+    return bool(L.load().vt_temporal_block_supported(C.byref(_tblock_desc(x, tmode, c, caches, cache_offset))))
 
 
-def temporal_block(x, w1, b1, w2, b2, norm1, norm2, *, tmode=L.VT_TPAD_ZERO, eps=1e-6, next_ln=None, keep_y=True, profile_out=None, c=None):
+def temporal_block(x, w1, b1, w2, b2, norm1, norm2, *, tmode=L.VT_TPAD_ZERO, eps=1e-6, next_ln=None, keep_y=True, profile_out=None, c=None,
+                   caches=None, cache_offset=0):
     """y = x + conv2(SiLU(LN2(conv1(SiLU(LN1(x)))))) with causal k=3 temporal convs, one launch (vt_temporal_block).
     norm1 / norm2 = (gamma, beta) fp32; w packed [C, 3C].  next_ln = (gamma, beta, silu) additionally returns
-    n = [SiLU](LayerNorm(y)): (y, n), or just n with keep_y=False."""
+    n = [SiLU](LayerNorm(y)): (y, n), or just n with keep_y=False.  caches = (cache1, cache2), [B, 2, H, W, C] each: the
+    chunk state of the two convolutions (their inputs at frames -2, -1), read with tmode VT_TPAD_CACHE and rewritten IN
+    PLACE with this clip's frames T - cache_offset - 2, T - cache_offset - 1."""
     lib = L.load()
     _chk(x, "tblock.x"); _chk(w1, "tblock.w1"); _chk(w2, "tblock.w2")
-    d = _tblock_desc(x, tmode, c)
+    d = _tblock_desc(x, tmode, c, caches, cache_offset)
     y = torch.empty_like(x) if keep_y else None
     n = torch.empty_like(x) if next_ln is not None else None
     d.x, d.y, d.n_out = x.data_ptr(), (y.data_ptr() if keep_y else None), (n.data_ptr() if n is not None else None)
@@ -225,7 +234,7 @@ def temporal_block(x, w1, b1, w2, b2, norm1, norm2, *, tmode=L.VT_TPAD_ZERO, eps
         return (y, n)
     L.check(lib.vt_temporal_block(C.byref(d), _stream()), "vt_temporal_block")
     if CONV_RECORD is not None:   # two K = 3C convolutions: label (pixels, C, 6C) carries their FLOPs
-        CONV_RECORD.append((d, (x, w1, b1, w2, b2, norm1, norm2, next_ln, y, n), (d.B * d.T * d.HW, d.C, 6 * d.C)))
+        CONV_RECORD.append((d, (x, w1, b1, w2, b2, norm1, norm2, next_ln, y, n, caches), (d.B * d.T * d.HW, d.C, 6 * d.C)))
     if next_ln is None:
         return y
     return (y, n) if keep_y else n
