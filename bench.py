@@ -109,7 +109,7 @@ def cpu_baseline():
                       f"{cores} host threads ({CONFIG_1GPU})"}
 
 
-MFMA_KERNELS = ("conv_igemm", "conv3x3_ws128", "conv3d_narrow", "tblock_ws128", "tblock_split")
+MFMA_KERNELS = ("conv_igemm", "conv3x3_ws2", "conv3x3_ws128", "conv3d_narrow", "tblock_pair")
 
 
 def measure_traffic(dtype, batch, config, timeout_s=200, table=None):

@@ -7,13 +7,16 @@ import sys
 from collections import defaultdict
 
 
+FAMILIES = ("conv_igemm", "conv3x3_ws2", "conv3x3_ws128", "conv3d_narrow", "tblock_pair", "layernorm_act")
+
+
 def main(root):
     out = {}
     for f in sorted(glob.glob(os.path.join(root, "*", "p_counter_collection.csv"))):
         agg = defaultdict(list)
         for r in csv.DictReader(open(f)):
             kn = r["Kernel_Name"]
-            fam = next((t for t in ("conv_igemm", "conv3x3_ws128", "conv3d_narrow", "tblock_ws128", "tblock_split") if t in kn), None)
+            fam = next((t for t in FAMILIES if t in kn), None)
             if fam is None:
                 continue
             agg[(fam, r["Counter_Name"])].append(float(r["Counter_Value"]))
@@ -21,7 +24,7 @@ def main(root):
             out[f"{k[0]}:{k[1]}"] = (sum(v) / len(v), len(v))
     kt = glob.glob(os.path.join(root, "sq1", "p_kernel_trace.csv"))
     if kt:
-        for fam in ("conv_igemm", "conv3x3_ws128", "conv3d_narrow", "tblock_ws128", "tblock_split"):
+        for fam in FAMILIES:
             d = [float(r["End_Timestamp"]) - float(r["Start_Timestamp"]) for r in csv.DictReader(open(kt[0])) if fam in r["Kernel_Name"]]
             if d:
                 out[f"{fam}:kernel_ns(avg)"] = (sum(d) / len(d), len(d))
