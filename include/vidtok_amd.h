@@ -326,6 +326,58 @@ int vt_fsq_aux_stats_avg(const float* h, const int32_t* levels_host, int32_t D, 
 int vt_entropy(const float* avg, int64_t J, float* out, vt_stream stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Model handle: AutoencodingEngine.encode / decode of the causal v1.0 tokenizers driven from C++ over the operators above
+ * (reference vidtok/models/autoencoder.py:197-229: encode = encoder -> regularization, decode = decoder, forward = both;
+ * the module tree of vidtok/modules/model_3dcausal.py:502-885 with `norm_type: layernorm`, `resamp_with_conv: true`).
+ * Same stage graph, descriptors and fusion decisions as the Python host (vidtok_amd/modules.py), hence the same bits.
+ *   vt_create(cfg, VT_BF16 | VT_F32, &h)     the fields of cfg are the constructor arguments of the reference's YAML
+ *   vt_load_weight(h, key, data, shape, n)   key = the reference state_dict key ("encoder.down.0.block.0.conv1.weight",
+ *                                            ...), data = fp32 on the HOST in the reference's parameter layout; weights
+ *                                            are re-packed when first used.  vt_weight_count / vt_weight_name list the
+ *                                            keys the graph reads.
+ *   vt_workspace_bytes(h, B, T, H, W)        device bytes vt_encode of a [B][in_channels][T][H][W] clip and vt_decode of
+ *                                            its latent need (activations; the handle owns its packed weights)
+ *   vt_latent_dims(h, T, H, W, out4)         {channels of the encoder output, T', H', W'}
+ *   vt_encode(h, x, B, T, H, W, h_out, ws, ws_bytes, stream)     x fp32 NCTHW -> h_out fp32 [B][C'][T'][H'][W'] (the
+ *                                            Gaussian moments for KL, the pre-quantisation latent for FSQ)
+ *   vt_regularize_kl(h, moments, noise | NULL, z, kl_out, B, T', H', W', stream)     = vt_kl_sample
+ *   vt_regularize_fsq(h, pre, z, indices, B, T', H', W', stream)                     = vt_fsq_quantize
+ *   vt_decode(h, z, B, T', H', W', x_out, ws, ws_bytes, stream)  z fp32 NCTHW -> x_out fp32 [B][out_ch][T][H][W]
+ *   vt_reset_cache(h)                        no state between calls in v1.0 (v1.1 chunk caches / temporal tiling and the
+ *                                            non-causal family stay with the Python host: vt_create refuses version != 0)
+ * All device pointers; every call is asynchronous on `stream`; the workspace must outlive the work queued on it.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct vt_model_config {
+  int32_t version;               /* 0 = v1.0 causal                                                             */
+  int32_t ch, num_res_blocks, in_channels, out_ch, z_channels, double_z;
+  int32_t num_resolutions;       /* len(ch_mult)                                                                */
+  int32_t ch_mult[8];
+  int32_t n_spatial_ds, spatial_ds[8], n_tempo_ds, tempo_ds[8];     /* encoder levels that end in a down-sampler */
+  int32_t n_spatial_us, spatial_us[8], n_tempo_us, tempo_us[8];     /* decoder levels that end in an up-sampler  */
+  int32_t time_downsample_factor;
+  int32_t regularizer;           /* 0 DiagonalGaussianRegularizer, 1 FSQRegularizer (dim == len(levels))        */
+  int32_t n_levels, levels[8];
+} vt_model_config;
+typedef struct vt_model vt_model;
+int vt_model_config_size(void);    /* sizeof(vt_model_config) as compiled: lets a binding verify its struct mirror */
+int vt_create(const vt_model_config* cfg, int32_t compute_dtype, vt_model** out);
+int vt_destroy(vt_model* h);
+int vt_load_weight(vt_model* h, const char* ref_key, const float* data_host, const int64_t* shape, int32_t ndim);
+int vt_weight_count(vt_model* h);
+const char* vt_weight_name(vt_model* h, int32_t i);
+int64_t vt_workspace_bytes(vt_model* h, int32_t B, int32_t T, int32_t H, int32_t W);
+int vt_latent_dims(const vt_model* h, int32_t T, int32_t H, int32_t W, int32_t* out4);
+int vt_encode(vt_model* h, const float* x, int32_t B, int32_t T, int32_t H, int32_t W, float* h_out, void* workspace,
+              int64_t workspace_bytes, vt_stream stream);
+int vt_regularize_kl(vt_model* h, const float* moments, const float* noise, float* z, float* kl_out, int32_t B, int32_t Tz,
+                     int32_t Hz, int32_t Wz, vt_stream stream);
+int vt_regularize_fsq(vt_model* h, const float* pre, float* z, int32_t* indices, int32_t B, int32_t Tz, int32_t Hz, int32_t Wz,
+                      vt_stream stream);
+int vt_decode(vt_model* h, const float* z, int32_t B, int32_t Tz, int32_t Hz, int32_t Wz, float* x_out, void* workspace,
+              int64_t workspace_bytes, vt_stream stream);
+int vt_reset_cache(vt_model* h);
+
+/* ------------------------------------------------------------------------------------------
  * Video front / back end around model(x): the device halves of scripts/inference_reconstruct.py (the codec --
  * decord / torchvision.io.write_video -- stays with the caller).  B = 1 like the reference's DataLoader.
  * vt_frames_u8_to_ncthw: decoded frames uint8 [T][H0][W0][3] -> x fp32 [3][Tdst][H][W], frames t_off .. t_off+T:

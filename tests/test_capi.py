@@ -246,3 +246,46 @@ def test_bench_committed_traffic_fallback(tmp_path, monkeypatch):
     monkeypatch.setattr(bench, "ROOT", str(tmp_path))
     assert bench.committed_traffic("bf16", 4) == (123, "profiles/r01_conv_traffic_pmc.json (committed pass)")
     assert bench.committed_traffic("fp32", 4)[0] is None
+
+
+def test_model_handle_without_gpu(built_lib):
+    """The handle-level C-ABI (csrc/model.cpp) up to the first launch: config validation, the struct mirror, the list of
+    reference state_dict keys the C++ stage graph reads (= the encoder / decoder keys of the Python model), latent
+    dimensions and workspace sizing -- all of it host-side (a dry run of the graph), no GPU needed."""
+    import vidtok_amd
+    from vidtok_amd import lib
+
+    assert built_lib.vt_model_config_size() == C.sizeof(lib.ModelConfig)
+    hdr = open(os.path.join(ROOT, "include", "vidtok_amd.h")).read()
+    body = hdr[hdr.index("typedef struct vt_model_config {") + len("typedef struct vt_model_config {"):hdr.index("} vt_model_config;")]
+    names = re.findall(r"\b([a-z_0-9]+)(?:\[8\])?\s*[,;]", re.sub(r"/\*.*?\*/", "", body, flags=re.S))
+    assert names == [f[0] for f in lib.ModelConfig._fields_], names
+    cfg = vidtok_amd.load_config(os.path.join(ROOT, "configs", "vidtok_kl_causal_488_4chn.yaml"))
+    enc = cfg["model"]["params"]["encoder_config"]["params"]
+    mc = lib.ModelConfig()
+    mc.ch, mc.num_res_blocks, mc.in_channels, mc.out_ch, mc.z_channels, mc.double_z = enc["ch"], enc["num_res_blocks"], 3, 3, enc["z_channels"], 1
+    mc.num_resolutions, mc.time_downsample_factor = 4, 4
+    for i, v in enumerate(enc["ch_mult"]):
+        mc.ch_mult[i] = v
+    for k, v in dict(spatial_ds=[0, 1, 2], tempo_ds=[2, 1], spatial_us=[1, 2, 3], tempo_us=[1, 2]).items():
+        setattr(mc, "n_" + k, len(v))
+        for i, e in enumerate(v):
+            getattr(mc, k)[i] = e
+    h = C.c_void_p()
+    mc.version = 1
+    assert built_lib.vt_create(C.byref(mc), lib.VT_BF16, C.byref(h)) != 0 and b"v1.0" in built_lib.vt_last_error()
+    mc.version = 0
+    assert built_lib.vt_create(C.byref(mc), 7, C.byref(h)) != 0 and b"dtype" in built_lib.vt_last_error()
+    assert built_lib.vt_create(C.byref(mc), lib.VT_BF16, C.byref(h)) == 0
+    try:
+        keys = [built_lib.vt_weight_name(h, i).decode() for i in range(built_lib.vt_weight_count(h))]
+        model = vidtok_amd.load_model_from_config(cfg, verbose=False)
+        assert set(keys) == set(model.state_dict().keys()) and len(keys) == len(set(keys))
+        ld = (C.c_int32 * 4)()
+        assert built_lib.vt_latent_dims(h, 17, 256, 256, ld) == 0 and list(ld) == [8, 5, 32, 32]
+        small, big = built_lib.vt_workspace_bytes(h, 1, 17, 64, 64), built_lib.vt_workspace_bytes(h, 4, 17, 256, 256)
+        assert 0 < small < big < 64 << 30          # B=4 17x256x256 bf16: two arenas of a few activations each
+        # nothing was loaded: the first use of a weight says which
+        assert built_lib.vt_encode(h, 256, 1, 17, 64, 64, 256, 256, small, None) != 0 and b"was not loaded" in built_lib.vt_last_error()
+    finally:
+        built_lib.vt_destroy(h)

@@ -438,3 +438,100 @@ def test_temporal_blocks_fused_and_unfused(name, shape, monkeypatch):
         ez, ed = rel_err(z, z2), rel_err(dec, dec2)
         print(f"{name} fused={fused}: z rel {ez:.3e} dec rel {ed:.3e}")
         assert ez < BF16_Z and ed < BF16_RECON
+
+
+# ---- the model handle of the C-ABI (vt_create / vt_load_weight / vt_encode / vt_regularize_* / vt_decode) -------------------
+def _handle_config(L, enc, reg_target, reg_params):
+    """vt_model_config from the constructor arguments of the reference's YAML (the defaults of EncoderCausal3D /
+    DecoderCausal3D for the lists the YAML leaves out, model_3dcausal.py:560-566,738-741)"""
+    c = L.ModelConfig()
+    n = len(enc["ch_mult"])
+    c.version, c.ch, c.num_res_blocks, c.in_channels, c.out_ch, c.z_channels = 0, enc["ch"], enc["num_res_blocks"], enc["in_channels"], enc["out_ch"], enc["z_channels"]
+    c.double_z, c.num_resolutions = int(enc.get("double_z", True)), n
+    lists = dict(ch_mult=enc["ch_mult"], spatial_ds=enc.get("spatial_ds") or list(range(0, n - 1)), tempo_ds=enc.get("tempo_ds") or [n - 2, n - 3],
+                 spatial_us=enc.get("spatial_us") or list(range(1, n)), tempo_us=enc.get("tempo_us") or [1, 2])
+    for k, v in lists.items():
+        for i, e in enumerate(v):
+            getattr(c, k)[i] = int(e)
+        if k != "ch_mult":
+            setattr(c, "n_" + k, len(v))
+    c.time_downsample_factor = enc.get("time_downsample_factor", 4)
+    if reg_target.endswith("FSQRegularizer"):
+        c.regularizer, c.n_levels = 1, len(reg_params["levels"])
+        for i, e in enumerate(reg_params["levels"]):
+            c.levels[i] = int(e)
+    return c
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32], ids=["bf16", "f32"])
+@pytest.mark.parametrize("name,shape", [("vidtok_kl_causal_488_4chn", (2, 3, 9, 64, 64)), ("vidtok_kl_causal_488_4chn", (1, 3, 17, 256, 256)),
+                                        ("vidtok_fsq_causal_488_32768", (1, 3, 17, 128, 128)), ("vidtok_kl_causal_41616_4chn", (1, 3, 9, 128, 128))],
+                         ids=["kl_488_small", "kl_488_full_size", "fsq_488", "kl_41616"])
+def test_model_handle_matches_engine(name, shape, dtype):
+    """the handle-level C-ABI drives the stage graph from C++ (csrc/model.cpp).  Everything below goes
+    through ctypes only -- create from the YAML's constructor arguments, load the reference state_dict key by key from
+    host memory, encode, regularize, decode into caller buffers -- and must give the bits of the Python engine."""
+    import ctypes as C
+
+    from vidtok_amd import lib as L
+    from vidtok_amd import ops
+
+    if dtype == torch.float32 and shape[-1] >= 256:
+        pytest.skip("fp32 at full size is covered by the bf16 case of the same graph and the small fp32 case")
+    model, cfg, sd = build_model(name, device=DEV, dtype=dtype)
+    prm = cfg["model"]["params"]
+    lib = L.load()
+    h = C.c_void_p()
+    mc = _handle_config(L, prm["encoder_config"]["params"], prm["regularizer_config"]["target"], prm["regularizer_config"].get("params", {}))
+    L.check(lib.vt_create(C.byref(mc), L.VT_BF16 if dtype == torch.bfloat16 else L.VT_F32, C.byref(h)), "vt_create")
+    try:
+        names = [lib.vt_weight_name(h, i).decode() for i in range(lib.vt_weight_count(h))]
+        assert set(names) == {k for k in sd if not k.startswith("regularization")}, "the handle reads exactly the encoder / decoder tensors of the reference state_dict"
+        for k in names:
+            t = sd[k].detach().float().contiguous().cpu()
+            shp = (C.c_int64 * t.dim())(*t.shape)
+            L.check(lib.vt_load_weight(h, k.encode(), t.data_ptr(), shp, t.dim()), "vt_load_weight")
+        B, _, T, H, W = shape
+        torch.manual_seed(5)
+        x = (torch.rand(shape, device=DEV) * 2 - 1).contiguous()
+        nbytes = lib.vt_workspace_bytes(h, B, T, H, W)
+        assert nbytes > 0
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=DEV)
+        ld = (C.c_int32 * 4)()
+        L.check(lib.vt_latent_dims(h, T, H, W, ld), "vt_latent_dims")
+        st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        # encoder
+        ref_h = model._run_encoder(x)
+        assert tuple(ref_h.shape) == (B, ld[0], ld[1], ld[2], ld[3])
+        got_h = torch.empty_like(ref_h)
+        L.check(lib.vt_encode(h, x.data_ptr(), B, T, H, W, got_h.data_ptr(), ws.data_ptr(), nbytes, st), "vt_encode")
+        torch.cuda.synchronize()
+        assert torch.equal(got_h, ref_h), f"encoder: {rel_err(got_h, ref_h):.3e}"
+        # regularizer (KL: the mode, no noise; FSQ: codes and indices)
+        zc = mc.z_channels
+        z = torch.empty((B, zc, ld[1], ld[2], ld[3]), dtype=torch.float32, device=DEV)
+        if mc.regularizer == 0:
+            kl = torch.zeros(1, dtype=torch.float32, device=DEV)
+            L.check(lib.vt_regularize_kl(h, got_h.data_ptr(), None, z.data_ptr(), kl.data_ptr(), B, ld[1], ld[2], ld[3], st), "vt_regularize_kl")
+            ref_z, ref_kl = ops.kl_sample(ref_h.contiguous(), None)
+            assert torch.equal(z, ref_z) and torch.equal(kl.reshape(()), ref_kl.reshape(()))
+        else:
+            idx = torch.empty((B, ld[1], ld[2], ld[3]), dtype=torch.int32, device=DEV)
+            L.check(lib.vt_regularize_fsq(h, got_h.data_ptr(), z.data_ptr(), idx.data_ptr(), B, ld[1], ld[2], ld[3], st), "vt_regularize_fsq")
+            ref_z, ref_log = model.regularization(ref_h)
+            assert torch.equal(z, ref_z) and torch.equal(idx, ref_log["indices"].to(torch.int32).reshape(idx.shape))
+        # decoder
+        ref_x = model._run_decoder(z)
+        got_x = torch.empty_like(ref_x)
+        L.check(lib.vt_decode(h, z.data_ptr(), B, ld[1], ld[2], ld[3], got_x.data_ptr(), ws.data_ptr(), nbytes, st), "vt_decode")
+        torch.cuda.synchronize()
+        assert torch.equal(got_x, ref_x), f"decoder: {rel_err(got_x, ref_x):.3e}"
+        # a second pass over the same workspace gives the same bits (nothing stale between calls)
+        L.check(lib.vt_encode(h, x.data_ptr(), B, T, H, W, got_h.data_ptr(), ws.data_ptr(), nbytes, st), "vt_encode")
+        torch.cuda.synchronize()
+        assert torch.equal(got_h, ref_h)
+        assert lib.vt_reset_cache(h) == 0
+        # a workspace that is too small is refused, not overrun
+        assert lib.vt_encode(h, x.data_ptr(), B, T, H, W, got_h.data_ptr(), ws.data_ptr(), 4096, st) != 0 and b"workspace" in lib.vt_last_error()
+    finally:
+        lib.vt_destroy(h)

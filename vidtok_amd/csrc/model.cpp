@@ -1,0 +1,889 @@
+// Handle-level C-ABI (include/vidtok_amd.h, "model handle"): the stage graph of the causal v1.0 tokenizers -- what
+// AutoencodingEngine.encode / decode run (reference vidtok/models/autoencoder.py:197-229 over EncoderCausal3DPadding /
+// DecoderCausal3DPadding, vidtok/modules/model_3dcausal.py:502-885) -- driven from C++ over the operator entry points of
+// this library, so that a host without Python runs the model:  vt_create(config) -> vt_load_weight(reference state_dict
+// key, fp32 data) x N -> vt_encode / vt_regularize_* / vt_decode.
+//
+// It is the same graph as vidtok_amd/modules.py builds (same operators, same descriptors, same fusion decisions: which
+// convolution emits which LayerNorm, the fused temporal block, the parity classes of the up-samplers), so its results
+// equal the Python engine's bit for bit (tests/test_gpu_e2e.py::test_model_handle_matches_engine drives it through ctypes
+// only).  Scope: `norm_type: layernorm`, `resamp_with_conv: true`, nearest time up-sampling -- every shipped v1.0 causal
+// config.  v1.1 chunk caches / tiling and the non-causal family stay with the Python host (vt_create refuses them).
+//
+// Memory: weights are packed on the host when first used and live in device allocations owned by the handle;
+// activations come from a caller-provided workspace, cut into two arenas that alternate between stages (a stage reads the
+// previous stage's output from one arena and builds its own output and temporaries in the other);
+// vt_workspace_bytes() runs the graph dry to size it.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string.h>
+
+#include <algorithm>
+#include <cmath>
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/vidtok_amd.h"
+
+void vt_set_error(const char* fmt, ...);
+
+namespace {
+
+struct Fail {
+  int code;
+};
+#define M_CHECK(cond, ...)        \
+  do {                            \
+    if (!(cond)) {                \
+      vt_set_error(__VA_ARGS__);  \
+      throw Fail{VT_ERR_ARG};     \
+    }                             \
+  } while (0)
+#define M_CALL(expr)                 \
+  do {                               \
+    const int rc_ = (expr);          \
+    if (rc_ != VT_OK) throw Fail{rc_}; \
+  } while (0)
+#define M_HIP(expr)                                                        \
+  do {                                                                     \
+    const hipError_t e_ = (expr);                                          \
+    if (e_ != hipSuccess) {                                                \
+      vt_set_error("%s: %s", #expr, hipGetErrorString(e_));                \
+      throw Fail{VT_ERR_HIP};                                              \
+    }                                                                      \
+  } while (0)
+
+int pad8(int c) { return (c + 7) / 8 * 8; }
+size_t esize(int dt) { return dt == VT_F32 ? 4 : 2; }
+
+// fp32 -> bf16, round to nearest even (what torch's .to(bfloat16) does)
+uint16_t bf16_rne(float f) {
+  uint32_t u;
+  memcpy(&u, &f, 4);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);   // NaN stays NaN
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+
+struct Arena {
+  char* base = nullptr;
+  size_t cap = 0, off = 0, peak = 0;
+  void reset() { off = 0; }
+  char* alloc(size_t n, bool dry) {
+    off = (off + 255) & ~(size_t)255;
+    char* p = base + off;        // dry: base = nullptr, pointers are never dereferenced
+    off += n;
+    if (off > peak) peak = off;
+    if (!dry) M_CHECK(off <= cap, "vt_model: workspace too small (%zu of %zu bytes in one arena; ask vt_workspace_bytes)", off, cap);
+    return p;
+  }
+};
+
+struct Tens {                      // NDHWC activation
+  char* p = nullptr;
+  int B = 0, T = 0, H = 0, W = 0, ld = 0, dt = VT_BF16;
+  size_t bytes() const { return (size_t)B * T * H * W * ld * esize(dt); }
+};
+
+struct Norm;
+struct Act {                       // an activation, optionally with the LayerNorm(+SiLU) its consumer starts with
+  Tens y, n;
+  const Norm* norm = nullptr;
+  bool silu = false;
+  bool has_n() const { return norm != nullptr; }
+};
+struct NormRef {
+  const Norm* norm = nullptr;
+  bool silu = false;
+};
+
+struct Param {
+  std::vector<float> data;
+  std::vector<int64_t> shape;
+};
+
+struct Model;
+struct Ctx {
+  Model* m;
+  hipStream_t stream;
+  bool dry;
+  Arena* cur;                      // arena the running stage allocates from
+  Tens alloc(int B, int T, int H, int W, int ld, int dt, int c_real) {
+    Tens t;
+    t.B = B; t.T = T; t.H = H; t.W = W; t.ld = ld; t.dt = dt;
+    t.p = cur->alloc(t.bytes(), dry);
+    if (ld != c_real && !dry) M_HIP(hipMemsetAsync(t.p, 0, t.bytes(), stream));   // keep the pad lanes defined (they meet zero weights)
+    return t;
+  }
+};
+
+struct DevBuf {
+  void* p = nullptr;
+  ~DevBuf() {
+    if (p) (void)hipFree(p);
+  }
+};
+
+struct Model {
+  vt_model_config cfg;
+  int dt;
+  std::map<std::string, Param> params;
+  std::vector<std::unique_ptr<DevBuf>> owned;
+  std::map<std::string, void*> packed;      // cache key -> device pointer
+  Arena arena[2];
+  std::vector<std::string> expected;        // state_dict keys the graph reads (filled by a dry run)
+
+  const Param& param(const std::string& key) {
+    auto it = params.find(key);
+    M_CHECK(it != params.end(), "vt_model: weight '%s' was not loaded (vt_load_weight)", key.c_str());
+    return it->second;
+  }
+  void* upload(const std::string& ckey, const void* host, size_t bytes) {
+    auto b = std::make_unique<DevBuf>();
+    M_HIP(hipMalloc(&b->p, bytes));
+    M_HIP(hipMemcpy(b->p, host, bytes, hipMemcpyHostToDevice));
+    void* p = b->p;
+    owned.push_back(std::move(b));
+    packed[ckey] = p;
+    return p;
+  }
+  // fp32 vector on the device as it is (biases, LayerNorm affines, mix factors)
+  const float* f32(const std::string& key, bool dry) {
+    if (dry) {
+      expected.push_back(key);
+      return nullptr;
+    }
+    auto it = packed.find("f32:" + key);
+    if (it != packed.end()) return (const float*)it->second;
+    const Param& p = param(key);
+    return (const float*)upload("f32:" + key, p.data.data(), p.data.size() * 4);
+  }
+  // convolution weight [Cout][Cin][k...] -> [Cout][taps * cin_p] in the arithmetic dtype (vidtok_amd/packing.py); `xf`
+  // optionally rewrites the fp32 weight first (parity classes of the up-samplers: pre-summed taps)
+  typedef std::vector<float> (*Xform)(const Param&, std::vector<int64_t>& shape, int a, int b);
+  const void* conv_w(const std::string& key, int cin_p, bool dry, Xform xf = nullptr, int xa = 0, int xb = 0) {
+    if (dry) {
+      expected.push_back(key);
+      return nullptr;
+    }
+    const std::string ckey = "w:" + key + ":" + std::to_string(cin_p) + ":" + std::to_string(dt) + ":" + std::to_string((xf ? 1 : 0) * 100 + xa * 10 + xb);
+    auto it = packed.find(ckey);
+    if (it != packed.end()) return it->second;
+    const Param& p = param(key);
+    std::vector<int64_t> shape = p.shape;
+    std::vector<float> tmp;
+    const float* src = p.data.data();
+    if (xf) {
+      tmp = xf(p, shape, xa, xb);
+      src = tmp.data();
+    }
+    M_CHECK(shape.size() >= 3, "vt_model: '%s' is not a convolution weight", key.c_str());
+    const int64_t cout = shape[0], cin = shape[1];
+    int64_t taps = 1;
+    for (size_t i = 2; i < shape.size(); ++i) taps *= shape[i];
+    M_CHECK(cin <= cin_p, "vt_model: '%s' has %lld input channels, the activation stores %d", key.c_str(), (long long)cin, cin_p);
+    std::vector<float> w((size_t)cout * taps * cin_p, 0.0f);
+    for (int64_t o = 0; o < cout; ++o)
+      for (int64_t c = 0; c < cin; ++c)
+        for (int64_t t = 0; t < taps; ++t) w[((size_t)o * taps + t) * cin_p + c] = src[((size_t)o * cin + c) * taps + t];
+    if (dt == VT_F32) return upload(ckey, w.data(), w.size() * 4);
+    std::vector<uint16_t> h(w.size());
+    for (size_t i = 0; i < w.size(); ++i) h[i] = bf16_rne(w[i]);
+    return upload(ckey, h.data(), h.size() * 2);
+  }
+};
+
+// ---- pre-summed taps of the up-samplers (vidtok_amd/packing.py) ------------------------------------------------------------
+// time: [Co][Ci][3][kh][kw] -> [Co][Ci][2][kh][kw]; early: [W0 + W1, W2], else [W0, W1 + W2]
+std::vector<float> xf_time_parity(const Param& p, std::vector<int64_t>& shape, int early, int) {
+  const int64_t co = shape[0], ci = shape[1], hw = shape[3] * shape[4];
+  std::vector<float> o((size_t)co * ci * 2 * hw);
+  for (int64_t a = 0; a < co * ci; ++a)
+    for (int64_t s = 0; s < hw; ++s) {
+      const float w0 = p.data[(a * 3 + 0) * hw + s], w1 = p.data[(a * 3 + 1) * hw + s], w2 = p.data[(a * 3 + 2) * hw + s];
+      o[(a * 2 + 0) * hw + s] = early ? w0 + w1 : w0;
+      o[(a * 2 + 1) * hw + s] = early ? w2 : w1 + w2;
+    }
+  shape[2] = 2;
+  return o;
+}
+// space: [Co][Ci][3][3] -> [Co][Ci][2][2]; rows [W0, W1+W2] for py = 0, [W0+W1, W2] for py = 1, likewise columns
+std::vector<float> xf_space_parity(const Param& p, std::vector<int64_t>& shape, int py, int px) {
+  const int64_t n = shape[0] * shape[1];
+  std::vector<float> o((size_t)n * 4);
+  for (int64_t a = 0; a < n; ++a) {
+    const float* w = &p.data[a * 9];
+    float rows[2][3];
+    for (int c = 0; c < 3; ++c) {
+      rows[0][c] = py == 0 ? w[0 * 3 + c] : w[0 * 3 + c] + w[1 * 3 + c];
+      rows[1][c] = py == 0 ? w[1 * 3 + c] + w[2 * 3 + c] : w[2 * 3 + c];
+    }
+    for (int r = 0; r < 2; ++r) {
+      o[a * 4 + r * 2 + 0] = px == 0 ? rows[r][0] : rows[r][0] + rows[r][1];
+      o[a * 4 + r * 2 + 1] = px == 0 ? rows[r][1] + rows[r][2] : rows[r][2];
+    }
+  }
+  shape[2] = 2;
+  shape[3] = 2;
+  return o;
+}
+
+// ---- operators ---------------------------------------------------------------------------------------------------------
+struct Geom {
+  int kt = 1, kh = 1, kw = 1, st = 1, sh = 1, sw = 1, pt = 0, ph = 0, pw = 0, ph_hi = 0, pw_hi = 0;
+  void out_dims(int Ti, int Hi, int Wi, int& To, int& Ho, int& Wo) const {
+    To = (Ti + pt - kt) / st + 1;
+    Ho = (Hi + ph + ph_hi - kh) / sh + 1;
+    Wo = (Wi + pw + pw_hi - kw) / sw + 1;
+  }
+};
+Geom causal3d(int kt, int kh, int kw, int st = 1, int sh = 1, int sw = 1) {
+  Geom g;
+  g.kt = kt; g.kh = kh; g.kw = kw; g.st = st; g.sh = sh; g.sw = sw;
+  g.pt = (kt - 1) + (1 - st);
+  const int hp = (kh - 1) + (1 - sh), wp = (kw - 1) + (1 - sw);
+  g.ph = hp / 2; g.pw = wp / 2; g.ph_hi = hp - hp / 2; g.pw_hi = wp - wp / 2;
+  return g;
+}
+
+struct Norm {
+  std::string key;                 // "...norm1" (the LayerNorm wrapper: parameters at key + ".norm.weight" / ".norm.bias")
+  float eps = 1e-6f;
+  // LayerNorm(+SiLU) of x, unless x already carries exactly that
+  Tens apply(Ctx& c, const Act& x, bool silu, int c_real) const {
+    if (x.has_n() && x.norm == this && x.silu == silu) return x.n;
+    const Tens& t = x.y;
+    Tens o = c.alloc(t.B, t.T, t.H, t.W, t.ld, c.m->dt, c_real);
+    const float* g = c.m->f32(key + ".norm.weight", c.dry);
+    const float* b = c.m->f32(key + ".norm.bias", c.dry);
+    if (!c.dry)
+      M_CALL(vt_layernorm_act(t.p, t.dt, t.ld, o.p, o.dt, o.ld, g, b, (int64_t)t.B * t.T * t.H * t.W, c_real, eps, silu ? 1 : 0, c.stream));
+    return o;
+  }
+};
+
+struct ConvOpts {
+  const Tens* res = nullptr;
+  int res_mode = VT_RES_NONE;
+  const float* mix = nullptr;
+  NormRef ln;                      // emit this norm of the result
+  bool keep_y = true;
+  Tens* out = nullptr;             // preallocated interleaved output (parity classes)
+  int yt_mul = 1, yt_off = 0, ys = 0, ys_oh = 0, ys_ow = 0;
+  float* ncthw = nullptr;          // write fp32 NCTHW here instead
+  int t_trim = 0;
+};
+
+// mirror of vidtok_amd/ops.py::conv
+Act conv(Ctx& c, const Tens& x, const void* w, int ldw, const float* bias, const Geom& g, int cout, const ConvOpts& o) {
+  int To, Ho, Wo;
+  g.out_dims(x.T, x.H, x.W, To, Ho, Wo);
+  M_CHECK(To > 0 && Ho > 0 && Wo > 0, "vt_model: convolution output is empty (%d x %d x %d)", To, Ho, Wo);
+  Act r;
+  vt_conv_desc d;
+  memset(&d, 0, sizeof(d));
+  int ldy;
+  if (o.out) {
+    r.y = *o.out;
+    ldy = o.out->ld;
+  } else if (o.ncthw) {
+    ldy = cout;
+  } else {
+    ldy = pad8(cout);
+    r.y = c.alloc(x.B, To, Ho, Wo, ldy, c.m->dt, cout);
+  }
+  d.x = x.p; d.w = w; d.bias = bias; d.y = o.ncthw ? (void*)o.ncthw : (void*)r.y.p;
+  d.B = x.B; d.Ti = x.T; d.Hi = x.H; d.Wi = x.W; d.Cin = x.ld;
+  d.To = To; d.Ho = Ho; d.Wo = Wo; d.Cout = cout;
+  d.ldw = ldw; d.ldy = ldy;
+  d.KT = g.kt; d.KH = g.kh; d.KW = g.kw; d.st = g.st; d.sh = g.sh; d.sw = g.sw; d.pt = g.pt; d.ph = g.ph; d.pw = g.pw;
+  d.tmode = VT_TPAD_ZERO;
+  d.res_mode = o.res_mode;
+  if (o.res_mode != VT_RES_NONE) {
+    d.res = o.res->p; d.res_tshift = 0; d.Tr = o.res->T; d.ldr = o.res->ld;
+    d.mix_factor = o.mix;
+  }
+  d.out_layout = o.ncthw ? VT_NCTHW : VT_NDHWC;
+  d.t_trim = o.t_trim;
+  d.dtype = x.dt; d.out_dtype = o.ncthw ? VT_F32 : c.m->dt;
+  d.nbatch = 1;
+  d.yt_mul = o.yt_mul; d.yt_off = o.yt_off;
+  if (o.ys) { d.ys_mul = 2; d.ys_oh = o.ys_oh; d.ys_ow = o.ys_ow; }
+  if (o.ln.norm) {
+    r.n = c.alloc(x.B, To, Ho, Wo, ldy, c.m->dt, cout);
+    d.ln_gamma = c.m->f32(o.ln.norm->key + ".norm.weight", c.dry);
+    d.ln_beta = c.m->f32(o.ln.norm->key + ".norm.bias", c.dry);
+    d.ln_out = r.n.p;
+    d.ln_mode = o.ln.silu ? 2 : 1; d.ln_keep_y = o.keep_y ? 1 : 0; d.ldn = ldy; d.ln_eps = o.ln.norm->eps;
+    r.norm = o.ln.norm; r.silu = o.ln.silu;
+  }
+  if (!c.dry) M_CALL(vt_conv(&d, c.stream));
+  return r;
+}
+
+// batched C[z] = A[z] B[z]^T on the convolution kernel (vidtok_amd/ops.py::gemm_nt)
+char* gemm_nt(Ctx& c, const void* a, bool a_batched, const void* b, int Z, int M, int N, int K, int in_dt, int out_dt, int ldo, const float* bias) {
+  const size_t bytes = (size_t)Z * M * ldo * esize(out_dt);
+  char* y = c.cur->alloc(bytes, c.dry);
+  if (ldo != N && !c.dry) M_HIP(hipMemsetAsync(y, 0, bytes, c.stream));
+  vt_conv_desc d;
+  memset(&d, 0, sizeof(d));
+  d.x = a; d.w = b; d.y = y; d.bias = bias;
+  d.B = 1; d.Ti = 1; d.Hi = 1; d.Wi = M; d.Cin = K;
+  d.To = 1; d.Ho = 1; d.Wo = M; d.Cout = N;
+  d.ldw = K; d.ldy = ldo;
+  d.KT = d.KH = d.KW = 1; d.st = d.sh = d.sw = 1;
+  d.dtype = in_dt; d.out_dtype = out_dt;
+  d.nbatch = Z;
+  d.xs_z = a_batched ? (int64_t)M * K : 0; d.ws_z = (int64_t)N * K; d.ys_z = (int64_t)M * ldo;
+  if (!c.dry) M_CALL(vt_conv(&d, c.stream));
+  return y;
+}
+
+// ---- stages ------------------------------------------------------------------------------------------------------------
+struct Stage {
+  virtual ~Stage() {}
+  virtual NormRef first_norm(Ctx&) const { return NormRef(); }      // the norm this stage wants from its producer
+  virtual Act run(Ctx& c, const Act& x, NormRef next) = 0;
+};
+
+ConvOpts emit(NormRef next) {
+  ConvOpts o;
+  o.ln = next;                     // keep_y = true
+  return o;
+}
+
+struct ConvParams {                // an nn.ConvNd parameter pair under `key` (".weight" / ".bias")
+  std::string key;
+  int cin = 0, cout = 0;
+};
+
+struct ResBlock : Stage {          // ResnetBlock (2-D per frame) or ResnetCausalBlock (3-D causal), model_3dcausal.py:276-424
+  bool causal3d_ = false;
+  int cin, cout;
+  Norm n1, n2;
+  ConvParams c1, c2, sc;
+  NormRef first_norm(Ctx&) const override { return NormRef{&n1, true}; }
+  Act run(Ctx& c, const Act& x, NormRef next) override {
+    Model* m = c.m;
+    const Geom g3 = causal3d_ ? causal3d(3, 3, 3) : causal3d(1, 3, 3), g1 = Geom();
+    const Tens h = n1.apply(c, x, true, cin);
+    ConvOpts o1;
+    o1.ln = NormRef{&n2, true};
+    o1.keep_y = false;             // conv1's result is only ever seen through norm2 + SiLU
+    const int taps = causal3d_ ? 27 : 9;
+    const Act h2 = conv(c, h, m->conv_w(c1.key + ".weight", h.ld, c.dry), taps * h.ld, m->f32(c1.key + ".bias", c.dry), g3, cout, o1);
+    Tens xs = x.y;
+    if (cin != cout) xs = conv(c, x.y, m->conv_w(sc.key + ".weight", x.y.ld, c.dry), x.y.ld, m->f32(sc.key + ".bias", c.dry), g1, cout, ConvOpts()).y;
+    ConvOpts o2 = emit(next);
+    o2.res = &xs;
+    o2.res_mode = VT_RES_ADD;
+    return conv(c, h2.n, m->conv_w(c2.key + ".weight", h2.n.ld, c.dry), taps * h2.n.ld, m->f32(c2.key + ".bias", c.dry), g3, cout, o2);
+  }
+};
+
+struct TBlock : Stage {            // ResnetCausalBlock1D, model_3dcausal.py:427-499
+  int ch;
+  Norm n1, n2;
+  ConvParams c1, c2;               // CausalConv1d: parameters at key + ".conv.weight"
+  bool fusable(const Ctx& c) const { return c.m->dt == VT_BF16 && ch == 128 && n1.eps == n2.eps; }
+  NormRef first_norm(Ctx& c) const override { return fusable(c) ? NormRef() : NormRef{&n1, true}; }
+  Act run(Ctx& c, const Act& x, NormRef next) override {
+    Model* m = c.m;
+    const Tens& xp = x.y;
+    Geom g;
+    g.kt = 3; g.pt = 2;
+    vt_tblock_desc d;
+    memset(&d, 0, sizeof(d));
+    d.dtype = xp.dt; d.C = ch; d.ld = xp.ld; d.B = xp.B; d.T = xp.T; d.HW = (int64_t)xp.H * xp.W; d.tmode = VT_TPAD_ZERO;
+    if (fusable(c) && vt_temporal_block_supported(&d)) {
+      Act r;
+      r.y = c.alloc(xp.B, xp.T, xp.H, xp.W, xp.ld, xp.dt, ch);
+      const bool nx = next.norm != nullptr && next.norm->eps == n1.eps;
+      if (nx) r.n = c.alloc(xp.B, xp.T, xp.H, xp.W, xp.ld, xp.dt, ch);
+      d.x = xp.p; d.y = r.y.p; d.n_out = nx ? r.n.p : nullptr;
+      d.w1 = m->conv_w(c1.key + ".conv.weight", xp.ld, c.dry); d.b1 = m->f32(c1.key + ".conv.bias", c.dry);
+      d.w2 = m->conv_w(c2.key + ".conv.weight", xp.ld, c.dry); d.b2 = m->f32(c2.key + ".conv.bias", c.dry);
+      d.norm1_gamma = m->f32(n1.key + ".norm.weight", c.dry); d.norm1_beta = m->f32(n1.key + ".norm.bias", c.dry);
+      d.norm2_gamma = m->f32(n2.key + ".norm.weight", c.dry); d.norm2_beta = m->f32(n2.key + ".norm.bias", c.dry);
+      if (nx) {
+        d.next_gamma = m->f32(next.norm->key + ".norm.weight", c.dry); d.next_beta = m->f32(next.norm->key + ".norm.bias", c.dry);
+        d.ln_next_mode = next.silu ? 2 : 1;
+        r.norm = next.norm; r.silu = next.silu;
+      }
+      d.keep_y = 1; d.eps = n1.eps;
+      if (!c.dry) M_CALL(vt_temporal_block(&d, c.stream));
+      return r;
+    }
+    const Tens h = n1.apply(c, x, true, ch);
+    ConvOpts o1;
+    o1.ln = NormRef{&n2, true};
+    o1.keep_y = false;
+    const Act h2 = conv(c, h, m->conv_w(c1.key + ".conv.weight", h.ld, c.dry), 3 * h.ld, m->f32(c1.key + ".conv.bias", c.dry), g, ch, o1);
+    ConvOpts o2 = emit(next);
+    o2.res = &xp;
+    o2.res_mode = VT_RES_ADD;
+    return conv(c, h2.n, m->conv_w(c2.key + ".conv.weight", h2.n.ld, c.dry), 3 * h2.n.ld, m->f32(c2.key + ".conv.bias", c.dry), g, ch, o2);
+  }
+};
+
+struct Attn : Stage {              // AttnBlockWrapper, model_3dcausal.py:83-141 ("heads" = frames)
+  int ch;
+  Norm n;
+  std::string key;                 // q / k / v / proj_out: CausalConv3d 1x1x1 at key + ".q.conv.weight" ...
+  NormRef first_norm(Ctx&) const override { return NormRef{&n, false}; }
+  Act run(Ctx& c, const Act& x, NormRef next) override {
+    Model* m = c.m;
+    const Tens hn = n.apply(c, x, false, ch);
+    const Tens& xp = x.y;
+    const int S = xp.H * xp.W, Z = xp.B * xp.T, Cc = xp.ld, Sp = pad8(S), dt = m->dt;
+    M_CHECK(Cc == ch, "vt_model: attention over %d channels stored as %d (channel counts must be multiples of 8)", ch, Cc);
+    const Geom g1;
+    const Tens q = conv(c, hn, m->conv_w(key + ".q.conv.weight", Cc, c.dry), Cc, m->f32(key + ".q.conv.bias", c.dry), g1, ch, ConvOpts()).y;
+    const Tens k = conv(c, hn, m->conv_w(key + ".k.conv.weight", Cc, c.dry), Cc, m->f32(key + ".k.conv.bias", c.dry), g1, ch, ConvOpts()).y;
+    const void* wv = m->conv_w(key + ".v.conv.weight", Cc, c.dry);
+    const float* bv = m->f32(key + ".v.conv.bias", c.dry);
+    // V^T directly: the weight is the row operand; v's bias is added after P V (rows of P sum to 1)
+    char* vT = gemm_nt(c, wv, false, hn.p, Z, Cc, S, Cc, dt, dt, Sp, nullptr);                // [Z][C][Sp]
+    char* s = gemm_nt(c, q.p, true, k.p, Z, S, S, Cc, dt, VT_F32, S, nullptr);                 // [Z][S][S] fp32
+    const size_t pbytes = (size_t)Z * S * Sp * esize(dt);
+    char* p = c.cur->alloc(pbytes, c.dry);
+    if (!c.dry) {
+      if (Sp != S) M_HIP(hipMemsetAsync(p, 0, pbytes, c.stream));
+      // scale = C^-0.5 as the Python host passes it: computed in double, rounded once to float
+      M_CALL(vt_softmax_rows((const float*)s, p, dt, (int64_t)Z * S, S, Sp, (float)std::pow((double)Cc, -0.5), c.stream));
+    }
+    Tens o = xp;
+    o.p = gemm_nt(c, p, true, vT, Z, S, Cc, Sp, dt, dt, Cc, bv);                               // [Z][S][C] = [B][T][H][W][C]
+    ConvOpts op = emit(next);
+    op.res = &xp;
+    op.res_mode = VT_RES_ADD;
+    return conv(c, o, m->conv_w(key + ".proj_out.conv.weight", Cc, c.dry), Cc, m->f32(key + ".proj_out.conv.bias", c.dry), g1, ch, op);
+  }
+};
+
+struct Down : Stage {              // Downsample: F.pad(0,1,0,1) + conv3x3 stride 2, model_3dcausal.py:215-230
+  int ch;
+  std::string key;                 // nn.Conv2d at key + ".conv.weight"
+  Act run(Ctx& c, const Act& x, NormRef next) override {
+    Geom g;
+    g.kh = 3; g.kw = 3; g.sh = 2; g.sw = 2; g.ph_hi = 1; g.pw_hi = 1;
+    return conv(c, x.y, c.m->conv_w(key + ".conv.weight", x.y.ld, c.dry), 9 * x.y.ld, c.m->f32(key + ".conv.bias", c.dry), g, ch, emit(next));
+  }
+};
+
+struct TimeDown : Stage {          // TimeDownsampleResCausal2x, model_3dcausal.py:233-252
+  int ch;
+  std::string key;                 // CausalConv3d at key + ".conv.conv.weight", key + ".mix_factor"
+  Act run(Ctx& c, const Act& x, NormRef next) override {
+    const Tens& xp = x.y;
+    Tens x1 = c.alloc(xp.B, xp.T / 2, xp.H, xp.W, xp.ld, xp.dt, xp.ld);
+    if (!c.dry) M_CALL(vt_time_avgpool3s2(xp.p, nullptr, x1.p, xp.dt, xp.B, xp.T, (int64_t)xp.H * xp.W, xp.ld, VT_TPAD_ZERO, c.stream));
+    ConvOpts o = emit(next);
+    o.res = &x1;
+    o.res_mode = VT_RES_MIX;
+    o.mix = c.m->f32(key + ".mix_factor", c.dry);
+    return conv(c, xp, c.m->conv_w(key + ".conv.conv.weight", xp.ld, c.dry), 27 * xp.ld, c.m->f32(key + ".conv.conv.bias", c.dry), causal3d(3, 3, 3, 2, 1, 1), ch, o);
+  }
+};
+
+struct Up : Stage {                // Upsample: nearest x2 + conv3x3 as four parity classes, model_3dcausal.py:200-212
+  int ch;
+  std::string key;
+  Act run(Ctx& c, const Act& x, NormRef) override {
+    const Tens& xp = x.y;
+    Act r;
+    r.y = c.alloc(xp.B, xp.T, 2 * xp.H, 2 * xp.W, pad8(ch), c.m->dt, ch);
+    for (int py = 0; py < 2; ++py)
+      for (int px = 0; px < 2; ++px) {
+        Geom g;
+        g.kh = 2; g.kw = 2; g.ph = 1 - py; g.pw = 1 - px; g.ph_hi = py; g.pw_hi = px;
+        ConvOpts o;
+        o.out = &r.y; o.ys = 1; o.ys_oh = py; o.ys_ow = px;
+        conv(c, xp, c.m->conv_w(key + ".conv.weight", xp.ld, c.dry, xf_space_parity, py, px), 4 * xp.ld, c.m->f32(key + ".conv.bias", c.dry), g, ch, o);
+      }
+    return r;
+  }
+};
+
+struct TimeUp : Stage {            // TimeUpsampleResCausal2x (nearest) as two parity classes, model_3dcausal.py:255-273
+  int ch;
+  std::string key;
+  Act run(Ctx& c, const Act& x, NormRef) override {
+    const Tens& xp = x.y;
+    Act r;
+    r.y = c.alloc(xp.B, 2 * xp.T, xp.H, xp.W, pad8(ch), c.m->dt, ch);
+    Geom g;
+    g.kt = 2; g.kh = 3; g.kw = 3; g.pt = 1; g.ph = 1; g.pw = 1; g.ph_hi = 1; g.pw_hi = 1;
+    const float* mf = c.m->f32(key + ".mix_factor", c.dry);
+    for (int par = 0; par < 2; ++par) {
+      ConvOpts o;
+      o.out = &r.y; o.yt_mul = 2; o.yt_off = par;
+      o.res = &xp; o.res_mode = VT_RES_MIX; o.mix = mf;
+      conv(c, xp, c.m->conv_w(key + ".conv.conv.weight", xp.ld, c.dry, xf_time_parity, par == 0 ? 1 : 0, 0), 18 * xp.ld, c.m->f32(key + ".conv.conv.bias", c.dry), g, ch, o);
+    }
+    return r;
+  }
+};
+
+bool in_list(const int32_t* v, int n, int x) {
+  for (int i = 0; i < n; ++i)
+    if (v[i] == x) return true;
+  return false;
+}
+
+struct Graph {
+  std::vector<std::unique_ptr<Stage>> stages;
+  std::string conv_in, conv_out;
+  Norm norm_out;
+  int c_first = 0, c_last = 0;
+};
+
+ResBlock* res_block(const std::string& key, int cin, int cout, bool causal) {
+  auto* b = new ResBlock();
+  b->causal3d_ = causal; b->cin = cin; b->cout = cout;
+  b->n1.key = key + ".norm1"; b->n2.key = key + ".norm2";
+  const std::string sfx = causal ? ".conv" : "";
+  b->c1.key = key + ".conv1" + sfx; b->c2.key = key + ".conv2" + sfx; b->sc.key = key + ".nin_shortcut" + sfx;
+  return b;
+}
+TBlock* t_block(const std::string& key, int ch) {
+  auto* b = new TBlock();
+  b->ch = ch;
+  b->n1.key = key + ".norm1"; b->n2.key = key + ".norm2";
+  b->c1.key = key + ".conv1"; b->c2.key = key + ".conv2";
+  return b;
+}
+Attn* attn(const std::string& key, int ch) {
+  auto* a = new Attn();
+  a->ch = ch; a->key = key; a->n.key = key + ".norm";
+  return a;
+}
+
+Graph build_encoder(const vt_model_config& cf) {
+  Graph g;
+  const int L = cf.num_resolutions;
+  int block_in = cf.ch;
+  for (int i = 0; i < L; ++i) {
+    block_in = cf.ch * (i == 0 ? 1 : cf.ch_mult[i - 1]);
+    const int block_out = cf.ch * cf.ch_mult[i];
+    const std::string d = "encoder.down." + std::to_string(i), dt = "encoder.down_temporal." + std::to_string(i);
+    for (int b = 0; b < cf.num_res_blocks; ++b) {
+      g.stages.emplace_back(res_block(d + ".block." + std::to_string(b), block_in, block_out, false));
+      g.stages.emplace_back(t_block(dt + ".block." + std::to_string(b), block_out));
+      block_in = block_out;
+    }
+    if (in_list(cf.spatial_ds, cf.n_spatial_ds, i)) {
+      auto* s = new Down();
+      s->ch = block_in; s->key = d + ".downsample";
+      g.stages.emplace_back(s);
+      if (in_list(cf.tempo_ds, cf.n_tempo_ds, i)) {
+        auto* t = new TimeDown();
+        t->ch = block_in; t->key = dt + ".downsample";
+        g.stages.emplace_back(t);
+      }
+    }
+  }
+  g.stages.emplace_back(res_block("encoder.mid.block_1", block_in, block_in, true));
+  g.stages.emplace_back(attn("encoder.mid.attn_1", block_in));
+  g.stages.emplace_back(res_block("encoder.mid.block_2", block_in, block_in, true));
+  g.conv_in = "encoder.conv_in.conv"; g.conv_out = "encoder.conv_out.conv";
+  g.norm_out.key = "encoder.norm_out";
+  g.c_first = cf.ch; g.c_last = block_in;
+  return g;
+}
+
+Graph build_decoder(const vt_model_config& cf) {
+  Graph g;
+  const int L = cf.num_resolutions;
+  int block_in = cf.ch * cf.ch_mult[L - 1];
+  g.c_first = block_in;
+  g.stages.emplace_back(res_block("decoder.mid.block_1", block_in, block_in, true));
+  g.stages.emplace_back(attn("decoder.mid.attn_1", block_in));
+  g.stages.emplace_back(res_block("decoder.mid.block_2", block_in, block_in, true));
+  for (int i = L - 1; i >= 0; --i) {
+    const int block_out = cf.ch * cf.ch_mult[i];
+    const std::string u = "decoder.up." + std::to_string(i), ut = "decoder.up_temporal." + std::to_string(i);
+    for (int b = 0; b < cf.num_res_blocks + 1; ++b) {
+      g.stages.emplace_back(res_block(u + ".block." + std::to_string(b), block_in, block_out, false));
+      g.stages.emplace_back(t_block(ut + ".block." + std::to_string(b), block_out));
+      block_in = block_out;
+    }
+    if (in_list(cf.spatial_us, cf.n_spatial_us, i)) {
+      auto* s = new Up();
+      s->ch = block_in; s->key = u + ".upsample";
+      g.stages.emplace_back(s);
+      if (in_list(cf.tempo_us, cf.n_tempo_us, i)) {
+        auto* t = new TimeUp();
+        t->ch = block_in; t->key = ut + ".upsample";
+        g.stages.emplace_back(t);
+      }
+    }
+  }
+  g.conv_in = "decoder.conv_in.conv"; g.conv_out = "decoder.conv_out.conv";
+  g.norm_out.key = "decoder.norm_out";
+  g.c_last = block_in;
+  return g;
+}
+
+// conv_in -> stages -> norm_out + SiLU -> conv_out (fp32 NCTHW); each stage is told which norm its consumer starts with
+void run_graph(Ctx& c, Graph& g, const Tens& x_in, int cout_final, float* out_ncthw, int t_trim) {
+  Model* m = c.m;
+  int which = 1;                   // x_in lives in arena 0
+  c.cur = &m->arena[which];
+  c.cur->reset();
+  const NormRef first = g.stages[0]->first_norm(c);
+  Act h = conv(c, x_in, m->conv_w(g.conv_in + ".weight", x_in.ld, c.dry), 27 * x_in.ld, m->f32(g.conv_in + ".bias", c.dry), causal3d(3, 3, 3), g.c_first, emit(first));
+  for (size_t i = 0; i < g.stages.size(); ++i) {
+    which ^= 1;
+    c.cur = &m->arena[which];
+    c.cur->reset();                // holds the input of the previous stage: no longer needed
+    const NormRef next = i + 1 < g.stages.size() ? g.stages[i + 1]->first_norm(c) : NormRef{&g.norm_out, true};
+    h = g.stages[i]->run(c, h, next);
+  }
+  which ^= 1;
+  c.cur = &m->arena[which];
+  c.cur->reset();
+  const Tens hn = g.norm_out.apply(c, h, true, g.c_last);
+  ConvOpts o;
+  o.ncthw = out_ncthw ? out_ncthw : (float*)16;      // dry runs pass no buffer
+  o.t_trim = t_trim;
+  conv(c, hn, m->conv_w(g.conv_out + ".weight", hn.ld, c.dry), 27 * hn.ld, m->f32(g.conv_out + ".bias", c.dry), causal3d(3, 3, 3), cout_final, o);
+}
+
+int front_pad(const vt_model_config& cf, int T) {
+  const int f = cf.time_downsample_factor;
+  return T % f == 0 ? 0 : f - 1;
+}
+
+void encode_impl(Model* m, Graph& g, const float* x, int B, int T, int H, int W, float* h_out, hipStream_t stream, bool dry) {
+  Ctx c{m, stream, dry, &m->arena[0]};
+  m->arena[0].reset();
+  const int npad = front_pad(m->cfg, T);
+  Tens xin = c.alloc(B, T + npad, H, W, pad8(m->cfg.in_channels), m->dt, pad8(m->cfg.in_channels));   // the kernel zero-fills the pad channels itself
+  if (!dry) M_CALL(vt_ncthw_to_ndhwc(x, xin.p, m->dt, B, m->cfg.in_channels, T, H, W, xin.ld, npad, stream));
+  const int cout = m->cfg.double_z ? 2 * m->cfg.z_channels : m->cfg.z_channels;
+  run_graph(c, g, xin, cout, h_out, 0);
+}
+
+void decode_impl(Model* m, Graph& g, const float* z, int B, int T, int H, int W, float* x_out, hipStream_t stream, bool dry) {
+  Ctx c{m, stream, dry, &m->arena[0]};
+  m->arena[0].reset();
+  Tens zin = c.alloc(B, T, H, W, pad8(m->cfg.z_channels), m->dt, pad8(m->cfg.z_channels));
+  if (!dry) M_CALL(vt_ncthw_to_ndhwc(z, zin.p, m->dt, B, m->cfg.z_channels, T, H, W, zin.ld, 0, stream));
+  run_graph(c, g, zin, m->cfg.out_ch, x_out, m->cfg.time_downsample_factor - 1);
+}
+
+int count(const int32_t* v, int n, int lo, int hi) {   // entries of v in [lo, hi)
+  int k = 0;
+  for (int i = 0; i < n; ++i) k += v[i] >= lo && v[i] < hi;
+  return k;
+}
+
+}  // namespace
+
+struct vt_model {
+  Model m;
+  Graph enc, dec;
+};
+
+extern "C" int vt_create(const vt_model_config* cfg, int32_t compute_dtype, vt_model** out) {
+  try {
+    M_CHECK(cfg != nullptr && out != nullptr, "vt_create: null argument");
+    M_CHECK(compute_dtype == VT_BF16 || compute_dtype == VT_F32, "vt_create: compute dtype must be VT_BF16 or VT_F32");
+    M_CHECK(cfg->version == 0, "vt_create: only the v1.0 causal family is driven from C++ (v1.1 chunk caches and the non-causal family stay with the Python host)");
+    M_CHECK(cfg->num_resolutions >= 1 && cfg->num_resolutions <= 8 && cfg->num_res_blocks >= 1 && cfg->ch > 0, "vt_create: bad level / block counts");
+    M_CHECK(cfg->n_spatial_ds <= 8 && cfg->n_tempo_ds <= 8 && cfg->n_spatial_us <= 8 && cfg->n_tempo_us <= 8 && cfg->n_levels <= 8, "vt_create: list too long");
+    M_CHECK(cfg->time_downsample_factor == 2 || cfg->time_downsample_factor == 4 || cfg->time_downsample_factor == 8, "vt_create: time_downsample_factor must be 2, 4 or 8");
+    M_CHECK(cfg->regularizer == 0 || (cfg->regularizer == 1 && cfg->n_levels == cfg->z_channels && !cfg->double_z),
+            "vt_create: regularizer 0 (KL, double_z) or 1 (FSQ with len(levels) == z_channels; projections are not covered here)");
+    for (int i = 0; i < cfg->n_tempo_ds; ++i) M_CHECK(in_list(cfg->spatial_ds, cfg->n_spatial_ds, cfg->tempo_ds[i]), "vt_create: a temporal down-sampler sits behind a spatial one (tempo_ds must be a subset of spatial_ds)");
+    for (int i = 0; i < cfg->n_tempo_us; ++i) M_CHECK(in_list(cfg->spatial_us, cfg->n_spatial_us, cfg->tempo_us[i]), "vt_create: tempo_us must be a subset of spatial_us");
+    auto* h = new vt_model();
+    h->m.cfg = *cfg;
+    h->m.dt = compute_dtype;
+    h->enc = build_encoder(*cfg);
+    h->dec = build_decoder(*cfg);
+    *out = h;
+    return VT_OK;
+  } catch (const Fail& f) {
+    return f.code;
+  } catch (const std::exception& e) {
+    vt_set_error("vt_create: %s", e.what());
+    return VT_ERR_ARG;
+  }
+}
+
+extern "C" int vt_model_config_size(void) { return (int)sizeof(vt_model_config); }
+
+extern "C" int vt_destroy(vt_model* h) {
+  delete h;
+  return VT_OK;
+}
+
+extern "C" int vt_load_weight(vt_model* h, const char* ref_key, const float* data_host, const int64_t* shape, int32_t ndim) {
+  try {
+    M_CHECK(h && ref_key && data_host && shape && ndim >= 1 && ndim <= 5, "vt_load_weight: bad argument");
+    Param p;
+    int64_t n = 1;
+    for (int i = 0; i < ndim; ++i) {
+      M_CHECK(shape[i] > 0, "vt_load_weight: '%s' has an empty dimension", ref_key);
+      p.shape.push_back(shape[i]);
+      n *= shape[i];
+    }
+    p.data.assign(data_host, data_host + n);
+    h->m.params[ref_key] = std::move(p);
+    // packed copies of an earlier version of this tensor are stale
+    for (auto it = h->m.packed.begin(); it != h->m.packed.end();) {
+      if (it->first.find(":" + std::string(ref_key)) != std::string::npos) it = h->m.packed.erase(it);
+      else ++it;
+    }
+    return VT_OK;
+  } catch (const Fail& f) {
+    return f.code;
+  } catch (const std::exception& e) {
+    vt_set_error("vt_load_weight: %s", e.what());
+    return VT_ERR_ARG;
+  }
+}
+
+extern "C" int vt_latent_dims(const vt_model* h, int32_t T, int32_t H, int32_t W, int32_t* out4) {
+  if (!h || !out4) {
+    vt_set_error("vt_latent_dims: null argument");
+    return VT_ERR_ARG;
+  }
+  const vt_model_config& cf = h->m.cfg;
+  const int Tp = T + front_pad(cf, T);
+  out4[0] = cf.double_z ? 2 * cf.z_channels : cf.z_channels;
+  out4[1] = Tp >> cf.n_tempo_ds;
+  out4[2] = H >> cf.n_spatial_ds;
+  out4[3] = W >> cf.n_spatial_ds;
+  return VT_OK;
+}
+
+extern "C" int64_t vt_workspace_bytes(vt_model* h, int32_t B, int32_t T, int32_t H, int32_t W) {
+  try {
+    M_CHECK(h && B > 0 && T > 0 && H > 0 && W > 0, "vt_workspace_bytes: bad argument");
+    Model& m = h->m;
+    Arena save[2] = {m.arena[0], m.arena[1]};
+    m.arena[0] = Arena();
+    m.arena[1] = Arena();
+    const std::vector<std::string> keep = m.expected;
+    m.expected.clear();
+    encode_impl(&m, h->enc, nullptr, B, T, H, W, nullptr, nullptr, true);
+    int32_t ld[4];
+    vt_latent_dims(h, T, H, W, ld);
+    decode_impl(&m, h->dec, nullptr, B, ld[1], ld[2], ld[3], nullptr, nullptr, true);
+    const size_t peak = std::max(m.arena[0].peak, m.arena[1].peak);
+    m.arena[0] = save[0];
+    m.arena[1] = save[1];
+    if (!keep.empty()) m.expected = keep;
+    return (int64_t)(2 * ((peak + 255) & ~(size_t)255) + 512);
+  } catch (const Fail& f) {
+    return -1;
+  } catch (const std::exception& e) {
+    vt_set_error("vt_workspace_bytes: %s", e.what());
+    return -1;
+  }
+}
+
+// the reference state_dict keys the graph reads, in first-use order (a loader can walk them): count / i-th name
+extern "C" int vt_weight_count(vt_model* h) {
+  if (!h) return 0;
+  if (h->m.expected.empty()) {
+    const int hw = 8 << h->m.cfg.n_spatial_ds;
+    (void)vt_workspace_bytes(h, 1, 1, hw, hw);                       // dry run: every parameter access records its key
+    std::vector<std::string> uniq;
+    for (const std::string& k : h->m.expected) {
+      bool seen = false;
+      for (const std::string& u : uniq) seen = seen || u == k;
+      if (!seen) uniq.push_back(k);
+    }
+    h->m.expected.swap(uniq);
+  }
+  return (int)h->m.expected.size();
+}
+extern "C" const char* vt_weight_name(vt_model* h, int32_t i) {
+  if (!h || i < 0 || i >= vt_weight_count(h)) return nullptr;
+  return h->m.expected[(size_t)i].c_str();
+}
+
+namespace {
+// every tensor the graph reads is there before anything is launched (prefix: "encoder." / "decoder.")
+void check_loaded(vt_model* h, const char* prefix) {
+  const int n = vt_weight_count(h);
+  for (int i = 0; i < n; ++i) {
+    const std::string& k = h->m.expected[(size_t)i];
+    if (k.compare(0, strlen(prefix), prefix) == 0) (void)h->m.param(k);
+  }
+}
+void bind_workspace(Model& m, void* ws, int64_t bytes) {
+  M_CHECK(ws != nullptr && bytes >= 1024 && (reinterpret_cast<uintptr_t>(ws) & 255) == 0, "vt_model: workspace must be a 256-byte aligned device buffer");
+  const size_t half = ((size_t)bytes / 2) & ~(size_t)255;
+  m.arena[0].base = (char*)ws; m.arena[0].cap = half; m.arena[0].peak = 0;
+  m.arena[1].base = (char*)ws + half; m.arena[1].cap = half; m.arena[1].peak = 0;
+}
+}  // namespace
+
+extern "C" int vt_encode(vt_model* h, const float* x, int32_t B, int32_t T, int32_t H, int32_t W, float* h_out, void* workspace,
+                         int64_t workspace_bytes, vt_stream stream) {
+  try {
+    M_CHECK(h && x && h_out && B > 0 && T > 0 && H > 0 && W > 0, "vt_encode: bad argument");
+    const int ds = 1 << h->m.cfg.n_spatial_ds;
+    M_CHECK(H % ds == 0 && W % ds == 0, "vt_encode: H and W must be multiples of %d", ds);
+    check_loaded(h, "encoder.");
+    bind_workspace(h->m, workspace, workspace_bytes);
+    encode_impl(&h->m, h->enc, x, B, T, H, W, h_out, reinterpret_cast<hipStream_t>(stream), false);
+    return VT_OK;
+  } catch (const Fail& f) {
+    return f.code;
+  } catch (const std::exception& e) {
+    vt_set_error("vt_encode: %s", e.what());
+    return VT_ERR_ARG;
+  }
+}
+
+extern "C" int vt_decode(vt_model* h, const float* z, int32_t B, int32_t Tz, int32_t Hz, int32_t Wz, float* x_out, void* workspace,
+                         int64_t workspace_bytes, vt_stream stream) {
+  try {
+    M_CHECK(h && z && x_out && B > 0 && Tz > 0 && Hz > 0 && Wz > 0, "vt_decode: bad argument");
+    M_CHECK((Tz << h->m.cfg.n_tempo_us) > h->m.cfg.time_downsample_factor - 1, "vt_decode: too few latent frames");
+    check_loaded(h, "decoder.");
+    bind_workspace(h->m, workspace, workspace_bytes);
+    decode_impl(&h->m, h->dec, z, B, Tz, Hz, Wz, x_out, reinterpret_cast<hipStream_t>(stream), false);
+    return VT_OK;
+  } catch (const Fail& f) {
+    return f.code;
+  } catch (const std::exception& e) {
+    vt_set_error("vt_decode: %s", e.what());
+    return VT_ERR_ARG;
+  }
+}
+
+extern "C" int vt_regularize_kl(vt_model* h, const float* moments, const float* noise, float* z, float* kl_out, int32_t B, int32_t Tz,
+                                int32_t Hz, int32_t Wz, vt_stream stream) {
+  if (!h || h->m.cfg.regularizer != 0) {
+    vt_set_error("vt_regularize_kl: the handle's regularizer is not the diagonal Gaussian");
+    return VT_ERR_ARG;
+  }
+  return vt_kl_sample(moments, noise, z, kl_out, B, h->m.cfg.z_channels, (int64_t)Tz * Hz * Wz, stream);
+}
+
+extern "C" int vt_regularize_fsq(vt_model* h, const float* pre, float* z, int32_t* indices, int32_t B, int32_t Tz, int32_t Hz, int32_t Wz,
+                                 vt_stream stream) {
+  if (!h || h->m.cfg.regularizer != 1) {
+    vt_set_error("vt_regularize_fsq: the handle's regularizer is not FSQ");
+    return VT_ERR_ARG;
+  }
+  return vt_fsq_quantize(pre, z, indices, h->m.cfg.levels, h->m.cfg.n_levels, B, (int64_t)Tz * Hz * Wz, stream);
+}
+
+extern "C" int vt_reset_cache(vt_model* h) {
+  if (!h) {
+    vt_set_error("vt_reset_cache: null handle");
+    return VT_ERR_ARG;
+  }
+  return VT_OK;     // the v1.0 graph keeps no state between calls (v1.1 chunk caches are not driven from here)
+}

@@ -66,6 +66,18 @@ class TBlockDesc(C.Structure):
     )
 
 
+class ModelConfig(C.Structure):
+    """Field-for-field mirror of `vt_model_config` (include/vidtok_amd.h)."""
+
+    _fields_ = (
+        [(n, C.c_int32) for n in ("version", "ch", "num_res_blocks", "in_channels", "out_ch", "z_channels", "double_z", "num_resolutions")]
+        + [("ch_mult", C.c_int32 * 8)]
+        + [("n_spatial_ds", C.c_int32), ("spatial_ds", C.c_int32 * 8), ("n_tempo_ds", C.c_int32), ("tempo_ds", C.c_int32 * 8)]
+        + [("n_spatial_us", C.c_int32), ("spatial_us", C.c_int32 * 8), ("n_tempo_us", C.c_int32), ("tempo_us", C.c_int32 * 8)]
+        + [("time_downsample_factor", C.c_int32), ("regularizer", C.c_int32), ("n_levels", C.c_int32), ("levels", C.c_int32 * 8)]
+    )
+
+
 # name -> (restype, argtypes); every symbol include/vidtok_amd.h declares
 _P, _I32, _I64, _F = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 SIGNATURES = {
@@ -77,6 +89,19 @@ SIGNATURES = {
     "vt_reset_options": (C.c_int, []),
     "vt_option_count": (C.c_int, []),
     "vt_option_name": (C.c_char_p, [_I32]),
+    "vt_model_config_size": (C.c_int, []),
+    "vt_create": (C.c_int, [C.POINTER(ModelConfig), _I32, C.POINTER(_P)]),
+    "vt_destroy": (C.c_int, [_P]),
+    "vt_load_weight": (C.c_int, [_P, C.c_char_p, _P, C.POINTER(_I64), _I32]),
+    "vt_weight_count": (C.c_int, [_P]),
+    "vt_weight_name": (C.c_char_p, [_P, _I32]),
+    "vt_workspace_bytes": (_I64, [_P, _I32, _I32, _I32, _I32]),
+    "vt_latent_dims": (C.c_int, [_P, _I32, _I32, _I32, C.POINTER(_I32)]),
+    "vt_encode": (C.c_int, [_P, _P, _I32, _I32, _I32, _I32, _P, _P, _I64, _P]),
+    "vt_regularize_kl": (C.c_int, [_P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _P]),
+    "vt_regularize_fsq": (C.c_int, [_P, _P, _P, _P, _I32, _I32, _I32, _I32, _P]),
+    "vt_decode": (C.c_int, [_P, _P, _I32, _I32, _I32, _I32, _P, _P, _I64, _P]),
+    "vt_reset_cache": (C.c_int, [_P]),
     "vt_conv": (C.c_int, [C.POINTER(ConvDesc), _P]),
     "vt_conv_desc_size": (C.c_int, []),
     "vt_conv_plan": (C.c_int, [C.POINTER(ConvDesc), C.POINTER(_I32)]),
