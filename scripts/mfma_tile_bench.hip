@@ -21,8 +21,11 @@ __device__ __forceinline__ void sfor(F&& f) {
 // BAR: barrier per K step; READS: 0 none, 1 real addressing, 2 one address for all; FD: read-ahead in MFMAs (stream form) or
 // 0 = the batch form of schedule 1 (the six reads of sub-step k+1 in front of the eight MFMAs of sub-step k); PRIO: 0 none,
 // 1 alternate s_setprio between the waves of a SIMD per sub-step (schedule 1), 2 setprio 1 always
-template <bool BAR, int READS, int FD, int PRIO>
-__global__ __launch_bounds__(512, 1) void kloop(unsigned long long* out, float* sink, int steps) {
+// DMA: 0 none; 1 the stage refill of the real kernel: 8 LDS-DMA pieces of 1 KiB per wave and step (64 KiB per workgroup) from a
+// per-workgroup region of `big`, issued behind MFMAs 1, 3, ... 15, awaited (vmcnt(0)) in front of the barrier; 2 the same
+// requests against an extent of 0 (zero fills: LDS writes, no memory traffic)
+template <bool BAR, int READS, int FD, int PRIO, int DMA = 0>
+__global__ __launch_bounds__(512, 1) void kloop(unsigned long long* out, float* sink, int steps, const char* big) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wm = wave & 1, wn = wave >> 1, wgrp = wave >> 2;
@@ -42,6 +45,24 @@ __global__ __launch_bounds__(512, 1) void kloop(unsigned long long* out, float* 
     const int slot = READS == 2 ? 0 : ((k * 2 + khalf) ^ swz) * 16;
     const char* base = (i < 2 ? a_base + i * 32 * 128 : b_base + (i - 2) * 32 * 128) + stg * 65536;
     return reinterpret_cast<const u32x4*>(READS == 2 ? lds + lane * 16 : base + slot);
+  };
+  typedef __attribute__((address_space(3))) void* lds_ptr_t;
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(big) + (size_t)blockIdx.x * (8u << 20), 0, DMA == 2 ? 0u : (8u << 20), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(big) + ((size_t)1000 << 23), 0, 8u << 20, 0x00020000);
+  auto piece = [&](int s, int stg, int q) {      // piece q of step s: wave w fills rows [32 q + 4 w ...) of the 64-KiB stage
+    if constexpr (DMA != 0) {
+      const unsigned win = DMA == 3 ? (64u << 10) : DMA == 4 ? (1u << 20) : (8u << 20);   // 3: 64 KiB per workgroup (16 MiB in all: L2 hits), 4: 1 MiB (256 MiB: the MALL)
+      unsigned off = (unsigned)((((s * 8 + q) * 8 + wave) * 1024 + lane * 16) & (win - 1));
+      if (DMA >= 5 && q >= 4) {
+        // the layer's situation: pieces 0-3 = the workgroup's own pixel rows (unique, from memory), pieces 4-7 = the weight
+        // slab (144 steps x 32 KiB = 4.5 MiB) that EVERY workgroup walks -- 5: all at the same step, 6: each at its own phase
+        const unsigned ph = DMA == 6 ? (blockIdx.x * 37u) % 144u : 0u;
+        off = ((s + ph) % 144u) * 32768u + ((q - 4) * 8 + wave) * 1024u + lane * 16;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (lds_ptr_t)(lds + stg * 65536 + (q * 8 + wave) * 1024), 16, off, 0, 0, 0);
+        return;
+      }
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)(lds + stg * 65536 + (q * 8 + wave) * 1024), 16, off, 0, 0, 0);
+    }
   };
   u32x4 fr[2][6];
 #pragma unroll
@@ -70,6 +91,7 @@ __global__ __launch_bounds__(512, 1) void kloop(unsigned long long* out, float* 
         for (int q = 0; q < 8; ++q) {
           if (k == 3 && q == 4) {
             if (BAR) {
+              if (DMA != 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
               asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
               __builtin_amdgcn_s_barrier();
               asm volatile("" ::: "memory");
@@ -80,6 +102,7 @@ __global__ __launch_bounds__(512, 1) void kloop(unsigned long long* out, float* 
             }
           }
           MFMA(acc[q >> 1][q & 1], fr[k & 1][2 + (q >> 1)], fr[k & 1][q & 1]);
+          if (DMA != 0 && k < 2 && (q & 1)) piece(s, stage ^ 1, k * 4 + (q >> 1));
         }
       }
       stage ^= 1;
@@ -94,6 +117,7 @@ __global__ __launch_bounds__(512, 1) void kloop(unsigned long long* out, float* 
         constexpr int m = decltype(mc)::value;
         constexpr int k = m >> 3, q = m & 7;
         if constexpr (k == 3 && q == 4 && BAR) {
+          if (DMA != 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
           __builtin_amdgcn_s_barrier();
           asm volatile("" ::: "memory");
@@ -104,6 +128,7 @@ __global__ __launch_bounds__(512, 1) void kloop(unsigned long long* out, float* 
           constexpr int kn = (k + 1) & 3;
           fr[(k + 1) & 1][q - 1] = *frag(k == 3 ? stage ^ 1 : stage, kn, q - 1);
         }
+        if constexpr (DMA != 0 && k < 2 && (q & 1)) piece(s, stage ^ 1, k * 4 + (q >> 1));
         __builtin_amdgcn_sched_barrier(0);
       });
       stage ^= 1;
@@ -123,14 +148,15 @@ __global__ __launch_bounds__(512, 1) void kloop(unsigned long long* out, float* 
   if (sum == 12345.678f) sink[threadIdx.x] = sum;
 }
 
-template <bool BAR, int READS, int FD, int PRIO>
+char* d_big;
+template <bool BAR, int READS, int FD, int PRIO, int DMA = 0>
 void run(const char* what, unsigned long long* d_out, float* d_sink, int waves = 8, int grid = 1) {
   const int steps = 200;
-  auto k = kloop<BAR, READS, FD, PRIO>;
+  auto k = kloop<BAR, READS, FD, PRIO, DMA>;
   hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
   unsigned long long t[16] = {0};
   for (int i = 0; i < 2; ++i) {
-    hipLaunchKernelGGL(k, dim3(grid), dim3(64 * waves), 131072, 0, d_out, d_sink, steps);
+    hipLaunchKernelGGL(k, dim3(grid), dim3(64 * waves), 131072, 0, d_out, d_sink, steps, d_big);
     hipError_t e = hipMemcpy(t, d_out, sizeof(t), hipMemcpyDeviceToHost);
     if (e != hipSuccess) { printf("%s: %s\n", what, hipGetErrorString(e)); return; }
   }
@@ -143,7 +169,7 @@ void run(const char* what, unsigned long long* d_out, float* d_sink, int waves =
 
 int main() {
   unsigned long long* d_out; float* d_sink;
-  hipMalloc(&d_out, 256); hipMalloc(&d_sink, 4096);
+  hipMalloc(&d_out, 256); hipMalloc(&d_sink, 4096); hipMalloc(&d_big, (size_t)1024 << 23); hipMemset(d_big, 0x3f, (size_t)1024 << 23);
   run<false, 0, 0, 0>("MFMAs only, 8 waves", d_out, d_sink);
   run<false, 0, 0, 0>("MFMAs only, 4 waves (one per SIMD)", d_out, d_sink, 4);
   run<true, 0, 0, 0>("MFMAs + barrier per step", d_out, d_sink);
@@ -162,5 +188,17 @@ int main() {
   run<true, 1, 0, 1>("batch reads + barrier + alternating priority (= schedule 1's skeleton)", d_out, d_sink, 8, 256);
   run<true, 1, 6, 0>("stream form + barrier", d_out, d_sink, 8, 256);
   run<true, 1, 0, 1>("batch reads + barrier + alternating priority, grid 1024", d_out, d_sink, 8, 1024);
+  printf("with the stage refill (8 LDS-DMA pieces per wave and step), grid 256:\n");
+  run<true, 1, 0, 1, 1>("batch form + barrier + pieces from memory", d_out, d_sink, 8, 256);
+  run<true, 1, 0, 1, 2>("batch form + barrier + pieces as zero fills", d_out, d_sink, 8, 256);
+  run<true, 1, 6, 0, 1>("stream form + barrier + pieces from memory", d_out, d_sink, 8, 256);
+  run<true, 1, 6, 0, 2>("stream form + barrier + pieces as zero fills", d_out, d_sink, 8, 256);
+  run<true, 1, 6, 0, 1>("stream form + barrier + pieces from memory, one workgroup", d_out, d_sink, 8, 1);
+  run<true, 0, 6, 0, 1>("MFMAs + barrier + pieces from memory (no fragment reads)", d_out, d_sink, 8, 256);
+  run<true, 1, 6, 0, 3>("stream form + barrier + pieces that hit in the L2 (64 KiB window per workgroup)", d_out, d_sink, 8, 256);
+  run<true, 1, 0, 1, 3>("batch form + barrier + pieces that hit in the L2", d_out, d_sink, 8, 256);
+  run<true, 1, 6, 0, 4>("stream form + barrier + pieces from a 1 MiB window per workgroup (256 MiB in all)", d_out, d_sink, 8, 256);
+  run<true, 1, 6, 0, 5>("stream form + barrier + own pixel rows from memory, shared weight slab walked in step", d_out, d_sink, 8, 256);
+  run<true, 1, 6, 0, 6>("stream form + barrier + own pixel rows from memory, shared weight slab at 256 different phases", d_out, d_sink, 8, 256);
   return 0;
 }
