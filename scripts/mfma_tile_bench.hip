@@ -149,6 +149,104 @@ __global__ __launch_bounds__(512, 1) void kloop(unsigned long long* out, float* 
 }
 
 char* d_big;
+// The same K loop on a 4-slot ring of HALF stages (64-B rows: 32 KiB per stage, 16 MFMAs + 12 fragment reads + 4 pieces per wave
+// and stage, one barrier per stage), the pieces of stage s + DEPTH requested during stage s: is the 2-slot loop waiting for the
+// LATENCY of its pieces (one step of cover) rather than for their bytes?  DMA modes as above (1 memory, 3 L2, 5 / 6 slab).
+template <int DEPTH, int DMA>
+__global__ __launch_bounds__(512, 1) void kloop4(unsigned long long* out, float* sink, int steps, const char* big) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = wave & 1, wn = wave >> 1;
+  for (int i = threadIdx.x; i < 131072 / 16; i += blockDim.x) ((u32x4*)lds)[i] = u32x4{0x3f803f80u, 0x3e803f80u + (unsigned)i, 0x3f803f80u, 0x3f803e80u};
+  __syncthreads();
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
+  const int row = lane & 31, khalf = lane >> 5, swz = (row >> 2) & 3;
+  const char* a_base = lds + (wm * 64) * 64 + row * 64;                 // A: 256 rows x 64 B
+  const char* b_base = lds + 16384 + (wn * 128) * 64 + row * 64;        // B: 256 rows x 64 B
+  auto frag = [&](int slot, int k, int i) -> const u32x4* {
+    const char* base = (i < 2 ? a_base + i * 32 * 64 : b_base + (i - 2) * 32 * 64) + slot * 32768;
+    return reinterpret_cast<const u32x4*>(base + ((k * 2 + khalf) ^ swz) * 16);
+  };
+  typedef __attribute__((address_space(3))) void* lds_ptr_t;
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(big) + (size_t)blockIdx.x * (8u << 20), 0, 8u << 20, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(big) + ((size_t)1000 << 23), 0, 8u << 20, 0x00020000);
+  auto piece = [&](int s, int q) {              // piece q < 4 of half-stage s: q < 2 pixel rows, q >= 2 weights
+    const int slot = s & 3;
+    unsigned off = (unsigned)((((s * 4 + q) * 8 + wave) * 1024 + lane * 16) & (DMA == 3 ? (64u << 10) - 1 : (8u << 20) - 1));
+    if (DMA >= 5 && q >= 2) {
+      const unsigned ph = DMA == 6 ? (blockIdx.x * 74u) % 288u : 0u;
+      off = ((s + ph) % 288u) * 16384u + ((q - 2) * 8 + wave) * 1024u + lane * 16;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (lds_ptr_t)(lds + slot * 32768 + (q * 8 + wave) * 1024), 16, off, 0, 0, 0);
+      return;
+    }
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)(lds + slot * 32768 + (q * 8 + wave) * 1024), 16, off, 0, 0, 0);
+  };
+  u32x4 fr[2][6];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) fr[0][i] = fr[1][i] = u32x4{0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
+  for (int s = 0; s < DEPTH; ++s)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) piece(s, q);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  for (int s = 0; s < 2 * steps; ++s) {          // half stages
+    const int slot = s & 3;
+    sfor<0, 16>([&](auto mc) {
+      constexpr int m = decltype(mc)::value;
+      constexpr int k = m >> 3, q = m & 7;
+      if constexpr (k == 1 && q == 4) {
+        // pieces of stage s + 1 (requested DEPTH stages ago) have landed when at most the younger (DEPTH - 1) x 4 are out
+        if constexpr (DEPTH == 3) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+        else if constexpr (DEPTH == 2) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+      }
+      MFMA(acc[q >> 1][q & 1], fr[k & 1][2 + (q >> 1)], fr[k & 1][q & 1]);
+      if constexpr (q >= 1 && q <= 6) fr[(k + 1) & 1][q - 1] = *frag(k == 1 ? (slot + 1) & 3 : slot, (k + 1) & 1, q - 1);
+      // the slot read DEPTH ... stages ago is free again behind the barrier of the previous stage: refill it for stage s + DEPTH
+      if constexpr (k == 0 && (q & 1)) piece(s + DEPTH, q >> 1);
+      __builtin_amdgcn_sched_barrier(0);
+    });
+  }
+  asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+  const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+  const unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  float sum = 0.f;
+#pragma unroll
+  for (int a = 0; a < 4; ++a) sum += acc[a][0][0] + acc[a][1][3];
+  if (lane == 0 && blockIdx.x == 0) {
+    out[wave] = t1 - t0;
+    out[8 + wave] = r1 - r0;
+  }
+  if (sum == 12345.678f) sink[threadIdx.x] = sum;
+}
+template <int DEPTH, int DMA>
+void run4(const char* what, unsigned long long* d_out, float* d_sink, char* big, int grid) {
+  const int steps = 200;
+  auto k = kloop4<DEPTH, DMA>;
+  hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+  unsigned long long t[16] = {0};
+  for (int i = 0; i < 2; ++i) {
+    hipLaunchKernelGGL(k, dim3(grid), dim3(512), 131072, 0, d_out, d_sink, steps, big);
+    hipError_t e = hipMemcpy(t, d_out, sizeof(t), hipMemcpyDeviceToHost);
+    if (e != hipSuccess) { printf("%s: %s\n", what, hipGetErrorString(e)); return; }
+  }
+  double lo = 1e30, hi = 0;
+  for (int w = 0; w < 8; ++w) { lo = t[w] < lo ? t[w] : lo; hi = t[w] > hi ? t[w] : hi; }
+  printf("%-100s %7.0f .. %7.0f s_memtime ticks per K step of 64 (matrix work: 2048); %.1f ns\n", what, lo / steps, hi / steps, (double)t[8] * 10.0 / steps);
+  fflush(stdout);
+}
+
 template <bool BAR, int READS, int FD, int PRIO, int DMA = 0>
 void run(const char* what, unsigned long long* d_out, float* d_sink, int waves = 8, int grid = 1) {
   const int steps = 200;
@@ -200,5 +298,14 @@ int main() {
   run<true, 1, 6, 0, 4>("stream form + barrier + pieces from a 1 MiB window per workgroup (256 MiB in all)", d_out, d_sink, 8, 256);
   run<true, 1, 6, 0, 5>("stream form + barrier + own pixel rows from memory, shared weight slab walked in step", d_out, d_sink, 8, 256);
   run<true, 1, 6, 0, 6>("stream form + barrier + own pixel rows from memory, shared weight slab at 256 different phases", d_out, d_sink, 8, 256);
+  printf("4-slot ring of half stages (64-B rows), grid 256:\n");
+  run4<1, 3>("depth 1, pieces hit in the L2", d_out, d_sink, d_big, 256);
+  run4<3, 3>("depth 3, pieces hit in the L2", d_out, d_sink, d_big, 256);
+  run4<1, 1>("depth 1, pieces from memory", d_out, d_sink, d_big, 256);
+  run4<2, 1>("depth 2, pieces from memory", d_out, d_sink, d_big, 256);
+  run4<3, 1>("depth 3, pieces from memory", d_out, d_sink, d_big, 256);
+  run4<1, 5>("depth 1, own pixel rows from memory + shared weight slab in step", d_out, d_sink, d_big, 256);
+  run4<3, 5>("depth 3, own pixel rows from memory + shared weight slab in step", d_out, d_sink, d_big, 256);
+  run4<3, 6>("depth 3, own pixel rows from memory + shared weight slab at different phases", d_out, d_sink, d_big, 256);
   return 0;
 }
