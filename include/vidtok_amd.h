@@ -333,8 +333,8 @@ int vt_entropy(const float* avg, int64_t J, float* out, vt_stream stream);
  *   vt_create(cfg, VT_BF16 | VT_F32, &h)     the fields of cfg are the constructor arguments of the reference's YAML
  *   vt_load_weight(h, key, data, shape, n)   key = the reference state_dict key ("encoder.down.0.block.0.conv1.weight",
  *                                            ...), data = fp32 on the HOST in the reference's parameter layout; weights
- *                                            are re-packed when first used.  vt_weight_count / vt_weight_name list the
- *                                            keys the graph reads.
+ *                                            are re-packed when first used.  vt_weight_count / vt_weight_name /
+ *                                            vt_weight_shape list the parameters; unknown keys and wrong shapes are refused.
  *   vt_workspace_bytes(h, B, T, H, W)        device bytes vt_encode of a [B][in_channels][T][H][W] clip and vt_decode of
  *                                            its latent need (activations; the handle owns its packed weights)
  *   vt_latent_dims(h, T, H, W, out4)         {channels of the encoder output, T', H', W'}
@@ -365,6 +365,7 @@ int vt_destroy(vt_model* h);
 int vt_load_weight(vt_model* h, const char* ref_key, const float* data_host, const int64_t* shape, int32_t ndim);
 int vt_weight_count(vt_model* h);
 const char* vt_weight_name(vt_model* h, int32_t i);
+int vt_weight_shape(vt_model* h, int32_t i, int64_t* shape5, int32_t* ndim);   /* the shape vt_load_weight expects for key i */
 int64_t vt_workspace_bytes(vt_model* h, int32_t B, int32_t T, int32_t H, int32_t W);
 int vt_latent_dims(const vt_model* h, int32_t T, int32_t H, int32_t W, int32_t* out4);
 int vt_encode(vt_model* h, const float* x, int32_t B, int32_t T, int32_t H, int32_t W, float* h_out, void* workspace,

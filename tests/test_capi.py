@@ -280,7 +280,16 @@ def test_model_handle_without_gpu(built_lib):
     try:
         keys = [built_lib.vt_weight_name(h, i).decode() for i in range(built_lib.vt_weight_count(h))]
         model = vidtok_amd.load_model_from_config(cfg, verbose=False)
-        assert set(keys) == set(model.state_dict().keys()) and len(keys) == len(set(keys))
+        sd = model.state_dict()
+        assert set(keys) == set(sd.keys()) and len(keys) == len(set(keys))
+        for i, k in enumerate(keys):           # ... with the reference's parameter shapes
+            shp, nd = (C.c_int64 * 5)(), C.c_int32()
+            assert built_lib.vt_weight_shape(h, i, shp, C.byref(nd)) == 0 and tuple(shp[:nd.value]) == tuple(sd[k].shape), k
+        import torch
+        w = torch.zeros(sd[keys[0]].shape)
+        bad = (C.c_int64 * 1)(3)
+        assert built_lib.vt_load_weight(h, keys[0].encode(), w.data_ptr(), bad, 1) != 0 and b"wrong shape" in built_lib.vt_last_error()
+        assert built_lib.vt_load_weight(h, b"loss.logvar", w.data_ptr(), bad, 1) != 0 and b"not a parameter" in built_lib.vt_last_error()
         ld = (C.c_int32 * 4)()
         assert built_lib.vt_latent_dims(h, 17, 256, 256, ld) == 0 and list(ld) == [8, 5, 32, 32]
         small, big = built_lib.vt_workspace_bytes(h, 1, 17, 64, 64), built_lib.vt_workspace_bytes(h, 4, 17, 256, 256)
@@ -289,3 +298,35 @@ def test_model_handle_without_gpu(built_lib):
         assert built_lib.vt_encode(h, 256, 1, 17, 64, 64, 256, 256, small, None) != 0 and b"was not loaded" in built_lib.vt_last_error()
     finally:
         built_lib.vt_destroy(h)
+
+
+def _build_c_example(tmp_path):
+    """examples/roundtrip.c with the system C compiler (not hipcc): the boundary is C"""
+    import shutil
+    import subprocess
+
+    cc = shutil.which("cc") or shutil.which("gcc")
+    assert cc, "no C compiler"
+    exe = os.path.join(str(tmp_path), "roundtrip")
+    libdir = os.path.join(ROOT, "vidtok_amd")
+    cmd = [cc, "-O2", "-Wall", "-Werror", "-D__HIP_PLATFORM_AMD__", "-I", os.path.join(ROOT, "include"), "-I", "/opt/rocm/include",
+           os.path.join(ROOT, "examples", "roundtrip.c"), "-o", exe, "-L", libdir, "-lvidtok_amd", "-L", "/opt/rocm/lib", "-lamdhip64", "-lm",
+           f"-Wl,-rpath,{libdir}", "-Wl,-rpath,/opt/rocm/lib"]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    return exe
+
+
+def test_c_example_builds(built_lib, tmp_path):
+    assert os.path.exists(_build_c_example(tmp_path))
+
+
+@pytest.mark.gpu
+def test_c_example_runs(built_lib, tmp_path):
+    """the plain-C host of examples/roundtrip.c: create, load 416 tensors by reference key, encode -> KL mode -> decode, twice
+    on one workspace; exit code 0 = finite reconstruction"""
+    import subprocess
+
+    exe = _build_c_example(tmp_path)
+    r = subprocess.run([exe, "9", "64", "64"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "finite 1" in r.stdout, (r.stdout, r.stderr)

@@ -534,6 +534,18 @@ bool in_list(const int32_t* v, int n, int x) {
   return false;
 }
 
+typedef std::map<std::string, std::vector<int64_t>> Shapes;     // reference state_dict key -> parameter shape
+void sh_conv(Shapes& sh, const std::string& key, int cout, int cin, std::vector<int64_t> k) {
+  std::vector<int64_t> w = {cout, cin};
+  w.insert(w.end(), k.begin(), k.end());
+  sh[key + ".weight"] = w;
+  sh[key + ".bias"] = {cout};
+}
+void sh_norm(Shapes& sh, const std::string& key, int c) {
+  sh[key + ".norm.weight"] = {c};
+  sh[key + ".norm.bias"] = {c};
+}
+
 struct Graph {
   std::vector<std::unique_ptr<Stage>> stages;
   std::string conv_in, conv_out;
@@ -541,7 +553,15 @@ struct Graph {
   int c_first = 0, c_last = 0;
 };
 
-ResBlock* res_block(const std::string& key, int cin, int cout, bool causal) {
+ResBlock* res_block(Shapes& sh, const std::string& key, int cin, int cout, bool causal) {
+  const std::string sfx0 = causal ? ".conv" : "";
+  const std::vector<int64_t> k3 = causal ? std::vector<int64_t>{3, 3, 3} : std::vector<int64_t>{3, 3};
+  const std::vector<int64_t> k1 = causal ? std::vector<int64_t>{1, 1, 1} : std::vector<int64_t>{1, 1};
+  sh_norm(sh, key + ".norm1", cin);
+  sh_norm(sh, key + ".norm2", cout);
+  sh_conv(sh, key + ".conv1" + sfx0, cout, cin, k3);
+  sh_conv(sh, key + ".conv2" + sfx0, cout, cout, k3);
+  if (cin != cout) sh_conv(sh, key + ".nin_shortcut" + sfx0, cout, cin, k1);
   auto* b = new ResBlock();
   b->causal3d_ = causal; b->cin = cin; b->cout = cout;
   b->n1.key = key + ".norm1"; b->n2.key = key + ".norm2";
@@ -549,20 +569,26 @@ ResBlock* res_block(const std::string& key, int cin, int cout, bool causal) {
   b->c1.key = key + ".conv1" + sfx; b->c2.key = key + ".conv2" + sfx; b->sc.key = key + ".nin_shortcut" + sfx;
   return b;
 }
-TBlock* t_block(const std::string& key, int ch) {
+TBlock* t_block(Shapes& sh, const std::string& key, int ch) {
+  sh_norm(sh, key + ".norm1", ch);
+  sh_norm(sh, key + ".norm2", ch);
+  sh_conv(sh, key + ".conv1.conv", ch, ch, {3});
+  sh_conv(sh, key + ".conv2.conv", ch, ch, {3});
   auto* b = new TBlock();
   b->ch = ch;
   b->n1.key = key + ".norm1"; b->n2.key = key + ".norm2";
   b->c1.key = key + ".conv1"; b->c2.key = key + ".conv2";
   return b;
 }
-Attn* attn(const std::string& key, int ch) {
+Attn* attn(Shapes& sh, const std::string& key, int ch) {
+  sh_norm(sh, key + ".norm", ch);
+  for (const char* n : {".q", ".k", ".v", ".proj_out"}) sh_conv(sh, key + n + ".conv", ch, ch, {1, 1, 1});
   auto* a = new Attn();
   a->ch = ch; a->key = key; a->n.key = key + ".norm";
   return a;
 }
 
-Graph build_encoder(const vt_model_config& cf) {
+Graph build_encoder(const vt_model_config& cf, Shapes& sh) {
   Graph g;
   const int L = cf.num_resolutions;
   int block_in = cf.ch;
@@ -571,53 +597,62 @@ Graph build_encoder(const vt_model_config& cf) {
     const int block_out = cf.ch * cf.ch_mult[i];
     const std::string d = "encoder.down." + std::to_string(i), dt = "encoder.down_temporal." + std::to_string(i);
     for (int b = 0; b < cf.num_res_blocks; ++b) {
-      g.stages.emplace_back(res_block(d + ".block." + std::to_string(b), block_in, block_out, false));
-      g.stages.emplace_back(t_block(dt + ".block." + std::to_string(b), block_out));
+      g.stages.emplace_back(res_block(sh, d + ".block." + std::to_string(b), block_in, block_out, false));
+      g.stages.emplace_back(t_block(sh, dt + ".block." + std::to_string(b), block_out));
       block_in = block_out;
     }
     if (in_list(cf.spatial_ds, cf.n_spatial_ds, i)) {
       auto* s = new Down();
       s->ch = block_in; s->key = d + ".downsample";
+      sh_conv(sh, d + ".downsample.conv", block_in, block_in, {3, 3});
       g.stages.emplace_back(s);
       if (in_list(cf.tempo_ds, cf.n_tempo_ds, i)) {
         auto* t = new TimeDown();
         t->ch = block_in; t->key = dt + ".downsample";
+        sh_conv(sh, dt + ".downsample.conv.conv", block_in, block_in, {3, 3, 3});
+        sh[dt + ".downsample.mix_factor"] = {1};
         g.stages.emplace_back(t);
       }
     }
   }
-  g.stages.emplace_back(res_block("encoder.mid.block_1", block_in, block_in, true));
-  g.stages.emplace_back(attn("encoder.mid.attn_1", block_in));
-  g.stages.emplace_back(res_block("encoder.mid.block_2", block_in, block_in, true));
+  g.stages.emplace_back(res_block(sh, "encoder.mid.block_1", block_in, block_in, true));
+  g.stages.emplace_back(attn(sh, "encoder.mid.attn_1", block_in));
+  g.stages.emplace_back(res_block(sh, "encoder.mid.block_2", block_in, block_in, true));
   g.conv_in = "encoder.conv_in.conv"; g.conv_out = "encoder.conv_out.conv";
   g.norm_out.key = "encoder.norm_out";
   g.c_first = cf.ch; g.c_last = block_in;
+  sh_conv(sh, g.conv_in, cf.ch, cf.in_channels, {3, 3, 3});
+  sh_conv(sh, g.conv_out, cf.double_z ? 2 * cf.z_channels : cf.z_channels, block_in, {3, 3, 3});
+  sh_norm(sh, g.norm_out.key, block_in);
   return g;
 }
 
-Graph build_decoder(const vt_model_config& cf) {
+Graph build_decoder(const vt_model_config& cf, Shapes& sh) {
   Graph g;
   const int L = cf.num_resolutions;
   int block_in = cf.ch * cf.ch_mult[L - 1];
   g.c_first = block_in;
-  g.stages.emplace_back(res_block("decoder.mid.block_1", block_in, block_in, true));
-  g.stages.emplace_back(attn("decoder.mid.attn_1", block_in));
-  g.stages.emplace_back(res_block("decoder.mid.block_2", block_in, block_in, true));
+  g.stages.emplace_back(res_block(sh, "decoder.mid.block_1", block_in, block_in, true));
+  g.stages.emplace_back(attn(sh, "decoder.mid.attn_1", block_in));
+  g.stages.emplace_back(res_block(sh, "decoder.mid.block_2", block_in, block_in, true));
   for (int i = L - 1; i >= 0; --i) {
     const int block_out = cf.ch * cf.ch_mult[i];
     const std::string u = "decoder.up." + std::to_string(i), ut = "decoder.up_temporal." + std::to_string(i);
     for (int b = 0; b < cf.num_res_blocks + 1; ++b) {
-      g.stages.emplace_back(res_block(u + ".block." + std::to_string(b), block_in, block_out, false));
-      g.stages.emplace_back(t_block(ut + ".block." + std::to_string(b), block_out));
+      g.stages.emplace_back(res_block(sh, u + ".block." + std::to_string(b), block_in, block_out, false));
+      g.stages.emplace_back(t_block(sh, ut + ".block." + std::to_string(b), block_out));
       block_in = block_out;
     }
     if (in_list(cf.spatial_us, cf.n_spatial_us, i)) {
       auto* s = new Up();
       s->ch = block_in; s->key = u + ".upsample";
+      sh_conv(sh, u + ".upsample.conv", block_in, block_in, {3, 3});
       g.stages.emplace_back(s);
       if (in_list(cf.tempo_us, cf.n_tempo_us, i)) {
         auto* t = new TimeUp();
         t->ch = block_in; t->key = ut + ".upsample";
+        sh_conv(sh, ut + ".upsample.conv.conv", block_in, block_in, {3, 3, 3});
+        sh[ut + ".upsample.mix_factor"] = {1};
         g.stages.emplace_back(t);
       }
     }
@@ -625,6 +660,9 @@ Graph build_decoder(const vt_model_config& cf) {
   g.conv_in = "decoder.conv_in.conv"; g.conv_out = "decoder.conv_out.conv";
   g.norm_out.key = "decoder.norm_out";
   g.c_last = block_in;
+  sh_conv(sh, g.conv_in, g.c_first, cf.z_channels, {3, 3, 3});
+  sh_conv(sh, g.conv_out, cf.out_ch, block_in, {3, 3, 3});
+  sh_norm(sh, g.norm_out.key, block_in);
   return g;
 }
 
@@ -687,6 +725,8 @@ int count(const int32_t* v, int n, int lo, int hi) {   // entries of v in [lo, h
 struct vt_model {
   Model m;
   Graph enc, dec;
+  Shapes shapes;                  // every parameter of the graph: the keys vt_weight_name lists, with their shapes
+  std::vector<std::string> names;
 };
 
 extern "C" int vt_create(const vt_model_config* cfg, int32_t compute_dtype, vt_model** out) {
@@ -704,8 +744,9 @@ extern "C" int vt_create(const vt_model_config* cfg, int32_t compute_dtype, vt_m
     auto* h = new vt_model();
     h->m.cfg = *cfg;
     h->m.dt = compute_dtype;
-    h->enc = build_encoder(*cfg);
-    h->dec = build_decoder(*cfg);
+    h->enc = build_encoder(*cfg, h->shapes);
+    h->dec = build_decoder(*cfg, h->shapes);
+    for (const auto& kv : h->shapes) h->names.push_back(kv.first);
     *out = h;
     return VT_OK;
   } catch (const Fail& f) {
@@ -726,6 +767,12 @@ extern "C" int vt_destroy(vt_model* h) {
 extern "C" int vt_load_weight(vt_model* h, const char* ref_key, const float* data_host, const int64_t* shape, int32_t ndim) {
   try {
     M_CHECK(h && ref_key && data_host && shape && ndim >= 1 && ndim <= 5, "vt_load_weight: bad argument");
+    const auto want = h->shapes.find(ref_key);
+    M_CHECK(want != h->shapes.end(), "vt_load_weight: '%s' is not a parameter of this model (vt_weight_name lists them)", ref_key);
+    bool same = (int)want->second.size() == ndim;
+    for (int i = 0; same && i < ndim; ++i) same = want->second[(size_t)i] == shape[i];
+    M_CHECK(same, "vt_load_weight: '%s' has the wrong shape (%d dims, first %lld; expected %zu dims, first %lld)", ref_key, ndim,
+            (long long)shape[0], want->second.size(), (long long)want->second[0]);
     Param p;
     int64_t n = 1;
     for (int i = 0; i < ndim; ++i) {
@@ -770,7 +817,6 @@ extern "C" int64_t vt_workspace_bytes(vt_model* h, int32_t B, int32_t T, int32_t
     Arena save[2] = {m.arena[0], m.arena[1]};
     m.arena[0] = Arena();
     m.arena[1] = Arena();
-    const std::vector<std::string> keep = m.expected;
     m.expected.clear();
     encode_impl(&m, h->enc, nullptr, B, T, H, W, nullptr, nullptr, true);
     int32_t ld[4];
@@ -779,7 +825,6 @@ extern "C" int64_t vt_workspace_bytes(vt_model* h, int32_t B, int32_t T, int32_t
     const size_t peak = std::max(m.arena[0].peak, m.arena[1].peak);
     m.arena[0] = save[0];
     m.arena[1] = save[1];
-    if (!keep.empty()) m.expected = keep;
     return (int64_t)(2 * ((peak + 255) & ~(size_t)255) + 512);
   } catch (const Fail& f) {
     return -1;
@@ -789,35 +834,28 @@ extern "C" int64_t vt_workspace_bytes(vt_model* h, int32_t B, int32_t T, int32_t
   }
 }
 
-// the reference state_dict keys the graph reads, in first-use order (a loader can walk them): count / i-th name
-extern "C" int vt_weight_count(vt_model* h) {
-  if (!h) return 0;
-  if (h->m.expected.empty()) {
-    const int hw = 8 << h->m.cfg.n_spatial_ds;
-    (void)vt_workspace_bytes(h, 1, 1, hw, hw);                       // dry run: every parameter access records its key
-    std::vector<std::string> uniq;
-    for (const std::string& k : h->m.expected) {
-      bool seen = false;
-      for (const std::string& u : uniq) seen = seen || u == k;
-      if (!seen) uniq.push_back(k);
-    }
-    h->m.expected.swap(uniq);
-  }
-  return (int)h->m.expected.size();
-}
+// the reference state_dict keys of the model's parameters (sorted) with their shapes: a loader walks them
+extern "C" int vt_weight_count(vt_model* h) { return h ? (int)h->names.size() : 0; }
 extern "C" const char* vt_weight_name(vt_model* h, int32_t i) {
-  if (!h || i < 0 || i >= vt_weight_count(h)) return nullptr;
-  return h->m.expected[(size_t)i].c_str();
+  if (!h || i < 0 || i >= (int)h->names.size()) return nullptr;
+  return h->names[(size_t)i].c_str();
+}
+extern "C" int vt_weight_shape(vt_model* h, int32_t i, int64_t* shape5, int32_t* ndim) {
+  if (!h || !shape5 || !ndim || i < 0 || i >= (int)h->names.size()) {
+    vt_set_error("vt_weight_shape: bad argument");
+    return VT_ERR_ARG;
+  }
+  const std::vector<int64_t>& sh = h->shapes[h->names[(size_t)i]];
+  *ndim = (int32_t)sh.size();
+  for (size_t k = 0; k < sh.size(); ++k) shape5[k] = sh[k];
+  return VT_OK;
 }
 
 namespace {
 // every tensor the graph reads is there before anything is launched (prefix: "encoder." / "decoder.")
 void check_loaded(vt_model* h, const char* prefix) {
-  const int n = vt_weight_count(h);
-  for (int i = 0; i < n; ++i) {
-    const std::string& k = h->m.expected[(size_t)i];
+  for (const std::string& k : h->names)
     if (k.compare(0, strlen(prefix), prefix) == 0) (void)h->m.param(k);
-  }
 }
 void bind_workspace(Model& m, void* ws, int64_t bytes) {
   M_CHECK(ws != nullptr && bytes >= 1024 && (reinterpret_cast<uintptr_t>(ws) & 255) == 0, "vt_model: workspace must be a 256-byte aligned device buffer");

@@ -95,6 +95,7 @@ SIGNATURES = {
     "vt_load_weight": (C.c_int, [_P, C.c_char_p, _P, C.POINTER(_I64), _I32]),
     "vt_weight_count": (C.c_int, [_P]),
     "vt_weight_name": (C.c_char_p, [_P, _I32]),
+    "vt_weight_shape": (C.c_int, [_P, _I32, C.POINTER(_I64), C.POINTER(_I32)]),
     "vt_workspace_bytes": (_I64, [_P, _I32, _I32, _I32, _I32]),
     "vt_latent_dims": (C.c_int, [_P, _I32, _I32, _I32, C.POINTER(_I32)]),
     "vt_encode": (C.c_int, [_P, _P, _I32, _I32, _I32, _I32, _P, _P, _I64, _P]),
