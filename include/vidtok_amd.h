@@ -172,7 +172,8 @@ int vt_conv(const vt_conv_desc* d, vt_stream stream);
 /* What vt_conv(d) would do, without launching (no GPU needed): out8 = {pixel tile, channel tile, waves per
  * workgroup, workgroups (tiles for the persistent kernel), 1 if LayerNorm comes from the conv epilogue, kernel
  * launches of the call, kernel (0 = tile-per-workgroup implicit GEMM, 1 = weight-stationary persistent 3x3 for
- * Cin = Cout = 128 bf16), 0}.  Validates `d` exactly like vt_conv.  Test / measurement aid: which kernel and
+ * Cin = Cout = 128 bf16), 1 if the 8-wave tile's epilogue goes through the LDS (coalesced rows; always with a fused LayerNorm,
+ * without one for bf16 full tiles)}.  Validates `d` exactly like vt_conv.  Test / measurement aid: which kernel and
  * instantiation does a parity case exercise. */
 int vt_conv_plan(const vt_conv_desc* d, int32_t* out8);
 /* Measurement aid (scripts/conv_profile.py): vt_conv(d) on the bf16 8-wave 256 x 256 tile (no LayerNorm) with shader-clock

@@ -366,6 +366,20 @@ def test_conv_8wave_schedules(case, sched, vt_opts):
     assert plan["tile"] == ((256, 256) if case[3] % 256 == 0 else (128, 128))
 
 
+@pytest.mark.parametrize("coalesced", [True, False], ids=["lds_epilogue", "vector_epilogue"])
+@pytest.mark.parametrize("case", [c for c in CONV_CASES_LARGE if c[3] % 256 == 0], ids=[c[0] for c in CONV_CASES_LARGE if c[3] % 256 == 0])
+def test_conv_8wave_plain_epilogues(case, coalesced, vt_opts):
+    """8-wave tile without LayerNorm: the LDS-transposed epilogue (bf16 full tiles; + residual / alpha-mix / interleaved
+    output frames) and the MFMA-layout vector epilogue it replaces, both against the reference"""
+    vt_opts(conv_ln256_v=(1 if coalesced else 0))
+    plan = _check_conv(case, torch.bfloat16)
+    if plan["tile"] == (256, 256) and not plan["ln_fused"]:
+        name, (B, T, H, W), cin, cout, kdims, geom, ex = case
+        To, Ho, Wo = geom.out_dims(T, H, W)
+        full = (B * To * Ho * Wo) % 256 == 0 and "ncthw" not in ex and ex.get("res") != "mix_up"
+        assert plan["lds_epilogue"] == (coalesced and full), (name, plan)
+
+
 LN256_CASES = [c for c in CONV_CASES if c[0] in ("conv2d_ln256_only", "conv2d_ln256_res_keep", "temporal_ln256_only")] + \
               [c for c in CONV_CASES_LARGE if c[0] in ("L_conv2d_256_256_ln", "L_temporal_k3_256_ln_only")]
 

@@ -405,7 +405,7 @@ __device__ __forceinline__ void conv_epilogue_lds256(const ConvArgs& p, f32x16 (
 // w*64 + b*32 + l.  A lane's two chunks (2j, 2j+1) make its ds_read_b128 pair 2-way bank-conflicted (16 lanes of a service
 // group hit 8 bank quads); the LDS is idle here, the 16-B global accesses are what counts.
 template <typename TOut>
-__device__ __forceinline__ void conv_epilogue_lds256_v1(const ConvArgs& p, f32x16 (&acc)[4][2], int m_blk, int wm, int wn, int lane,
+__device__ __forceinline__ void conv_epilogue_lds256_v1(const ConvArgs& p, f32x16 (&acc)[4][2], int m_blk, int n_blk, int wm, int wn, int lane,
                                                         int tid, char* smem, long long z) {
 #pragma clang fp contract(off)
   static_assert(std::is_same<TOut, bf16_t>::value, "bf16 storage");
@@ -415,10 +415,16 @@ __device__ __forceinline__ void conv_epilogue_lds256_v1(const ConvArgs& p, f32x1
   const TOut* __restrict__ rg = reinterpret_cast<const TOut*>(p.res) + z * p.rs_z;
   TOut* __restrict__ ng = reinterpret_cast<TOut*>(p.ln_out);
   float* T = reinterpret_cast<float*>(smem);
-  const bool has_res = p.res_mode == VT_RES_ADD;
+  // Also the epilogue of launches WITHOUT a LayerNorm (ln_mode 0; any Cout % 256 == 0: n_blk = the tile's first channel): the
+  // transposition alone turns the 8-byte pieces of the MFMA layout into 16-byte accesses covering whole lines, for the
+  // stores and for the residual / alpha-mix operand (the vector epilogue's wave store is 64 separate 8-B transactions).
+  const bool has_res = p.res_mode != VT_RES_NONE;
+  const bool has_ln = p.ln_mode != 0;                    // uniform
+  float alpha = 0.0f;
+  if (p.res_mode == VT_RES_MIX) alpha = 1.0f / (1.0f + __expf(-p.mix_factor[0]));
   const int j = tid & 31, rsub = tid >> 5;              // lane j: channels [8j, 8j+8) of T rows rsub + 16 it
   f32x2 lg[4], lb[4];
-  {
+  if (has_ln) {
     const f32x4 g0 = *reinterpret_cast<const f32x4*>(p.ln_gamma + 8 * j), g1 = *reinterpret_cast<const f32x4*>(p.ln_gamma + 8 * j + 4);
     const f32x4 b0 = *reinterpret_cast<const f32x4*>(p.ln_beta + 8 * j), b1 = *reinterpret_cast<const f32x4*>(p.ln_beta + 8 * j + 4);
     lg[0] = f32x2{g0[0], g0[1]}; lg[1] = f32x2{g0[2], g0[3]}; lg[2] = f32x2{g1[0], g1[1]}; lg[3] = f32x2{g1[2], g1[3]};
@@ -435,7 +441,7 @@ __device__ __forceinline__ void conv_epilogue_lds256_v1(const ConvArgs& p, f32x1
 #pragma unroll
       for (int it = 0; it < 8; ++it) {
         const long long m = (long long)m_blk + (it >> 1) * 64 + PZ * 32 + rsub + 16 * (it & 1);
-        rq[it] = *reinterpret_cast<const u32x4*>(rg + m * p.ldr + 8 * j);
+        rq[it] = *reinterpret_cast<const u32x4*>(rg + m * p.ldr + n_blk + 8 * j);
       }
     }
     __syncthreads();                                    // K loop / previous half: everybody is done with this LDS
@@ -447,7 +453,7 @@ __device__ __forceinline__ void conv_epilogue_lds256_v1(const ConvArgs& p, f32x1
         for (int g = 0; g < 4; ++g) {
           const int c = wn * 128 + 32 * a + 8 * g + 4 * h;
           f32x4 bq;
-          if (p.bias) bq = *reinterpret_cast<const f32x4*>(p.bias + c);
+          if (p.bias) bq = *reinterpret_cast<const f32x4*>(p.bias + n_blk + c);
           else bq[0] = bq[1] = bq[2] = bq[3] = 0.0f;
           f32x4 v;
 #pragma unroll
@@ -464,16 +470,20 @@ __device__ __forceinline__ void conv_epilogue_lds256_v1(const ConvArgs& p, f32x1
       const f32x4 t0 = *reinterpret_cast<const f32x4*>(T + r * 256 + (((2 * j) ^ (r & 63)) << 2));
       const f32x4 t1 = *reinterpret_cast<const f32x4*>(T + r * 256 + (((2 * j + 1) ^ (r & 63)) << 2));
       f32x2 v[4] = {f32x2{t0[0], t0[1]}, f32x2{t0[2], t0[3]}, f32x2{t1[0], t1[1]}, f32x2{t1[2], t1[3]}};
-      if (has_res) {
+      if (p.res_mode == VT_RES_ADD) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) v[q] = unpack2(rq[it][q]) + v[q];
+      } else if (p.res_mode == VT_RES_MIX) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = unpack2(rq[it][q]) * alpha + v[q] * (1.0f - alpha);
       }
-      if (p.ln_keep_y) {
+      if (p.ln_keep_y || !has_ln) {
         u32x4 w;
 #pragma unroll
         for (int q = 0; q < 4; ++q) w[q] = pack2(v[q]);
-        *reinterpret_cast<u32x4*>(yg + orow * p.ldy + 8 * j) = w;
+        *reinterpret_cast<u32x4*>(yg + orow * p.ldy + n_blk + 8 * j) = w;
       }
+      if (!has_ln) continue;
       const f32x2 s = (v[0] + v[1]) + (v[2] + v[3]);
       const float mean = group_sum_dpp<32>(s[0] + s[1]) * (1.0f / 256.0f);
       f32x2 d[4], qq = {0.f, 0.f};
@@ -1139,7 +1149,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_igemm_glds_ker
   if constexpr (LN256 != 0) {
     static_assert(WAVES_M == 4 && WAVES_N == 2 && TM == 2 && TN == 4 && std::is_same<MT, TOut>::value, "LN256: the 8-wave 256 x 256 tile");
     if constexpr (!BUF) wait_vmcnt<0>();
-    if constexpr (LN256 == 2) conv_epilogue_lds256_v1<TOut>(p, acc, m_blk, wm, wn, lane, tid, smem, z);
+    if constexpr (LN256 == 2) conv_epilogue_lds256_v1<TOut>(p, acc, m_blk, n_blk, wm, wn, lane, tid, smem, z);
     else conv_epilogue_lds256<TOut>(p, acc, m_blk, wm, wn, lane, tid, smem, z);
     return;
   }
@@ -1296,6 +1306,14 @@ inline TileKind select_tile(const ConvArgs& a, int nbatch) {
   return TILE_128x128;
 }
 
+// 8-wave tile, no LayerNorm, but everything the LDS-transposed epilogue needs (conv_epilogue_lds256_v1 with ln_mode = 0):
+// bf16, full tiles, plain NDHWC rows, a residual / mix operand indexed like the output
+inline bool lds256_plain_eligible(const ConvArgs& a, int nbatch, bool bf16_io) {
+  return bf16_io && a.ln_mode == 0 && a.prof == nullptr && vt_opt(OPT_CONV_LDSEPI) != 0 && vt_opt(OPT_CONV_LN256_V) != 0 &&
+         a.M % 256 == 0 && a.Cout % 256 == 0 && nbatch == 1 && a.Cin % (kRowBytes / 2) == 0 && a.out_layout == VT_NDHWC &&
+         (a.ldy & 7) == 0 && (a.res_mode == VT_RES_NONE || ((a.ldr & 7) == 0 && a.Tr == a.To && a.res_tshift == 0));
+}
+
 template <typename MT, typename TOut>
 int dispatch_tile(const ConvArgs& a, int nbatch, hipStream_t stream) {
   switch (select_tile(a, nbatch)) {
@@ -1308,6 +1326,11 @@ int dispatch_tile(const ConvArgs& a, int nbatch, hipStream_t stream) {
             if (vt_opt(OPT_CONV_LN256_V) != 0) return launch_variant<MT, TOut, 4, 2, 2, 4, true, 2>(a, nbatch, stream);
           }
           return launch_variant<MT, TOut, 4, 2, 2, 4, true, 1>(a, nbatch, stream);
+        }
+        // the same instantiation with ln_mode = 0: coalesced stores and residual reads (-8 % on the time up-sampler's
+        // parity convolutions, -10 % on the K = 1 024 / 1 536 layers)
+        if constexpr (std::is_same<TOut, bf16_t>::value) {
+          if (lds256_plain_eligible(a, nbatch, true)) return launch_variant<MT, TOut, 4, 2, 2, 4, true, 2>(a, nbatch, stream);
         }
       }
       return launch_fast_or_general<MT, TOut, 4, 2, 2, 4>(a, nbatch, stream);
@@ -1460,6 +1483,8 @@ extern "C" int vt_conv_plan(const vt_conv_desc* d, int32_t* out8) {
   out8[3] = (int32_t)((long long)((a.M + dims[k][0] - 1) / dims[k][0]) * ((a.Cout + dims[k][1] - 1) / dims[k][1]) * nbatch);
   out8[4] = ln_fused ? 1 : 0;
   out8[5] = (d->ln_mode != 0 && !ln_fused) ? 2 : 1;
+  // epilogue through the LDS (rows of 16-byte accesses) instead of the MFMA-layout vector epilogue
+  if (k == TILE_256x256) out8[7] = (ln_fused || lds256_plain_eligible(a, nbatch, d->dtype == VT_BF16 && d->out_dtype == VT_BF16)) ? 1 : 0;
   return VT_OK;
 }
 

@@ -35,7 +35,7 @@ def conv_plan(d):
     out = (C.c_int32 * 8)()
     L.check(L.load().vt_conv_plan(C.byref(d), out), "vt_conv_plan")
     return dict(tile=(out[0], out[1]), waves=out[2], workgroups=out[3], ln_fused=bool(out[4]), launches=out[5],
-                kernel={1: "ws128", 2: "narrow"}.get(out[6], "igemm"))
+                kernel={1: "ws128", 2: "narrow"}.get(out[6], "igemm"), lds_epilogue=bool(out[7]))
 
 
 def replay_convs(record, conv_kernel_only=True):
