@@ -343,6 +343,7 @@ int vt_entropy(const float* avg, int64_t J, float* out, vt_stream stream);
  *                                            Gaussian moments for KL, the pre-quantisation latent for FSQ)
  *   vt_regularize_kl(h, moments, noise | NULL, z, kl_out, B, T', H', W', stream)     = vt_kl_sample
  *   vt_regularize_fsq(h, pre, z, indices, B, T', H', W', stream)                     = vt_fsq_quantize
+ *   vt_indices_to_latent(h, indices, z, B, T', H', W', stream)                       = vt_fsq_indices_to_codes
  *   vt_decode(h, z, B, T', H', W', x_out, ws, ws_bytes, stream)  z fp32 NCTHW -> x_out fp32 [B][out_ch][T][H][W]
  *   vt_reset_cache(h)                        no state between calls in v1.0 (v1.1 chunk caches / temporal tiling and the
  *                                            non-causal family stay with the Python host: vt_create refuses version != 0)
@@ -375,6 +376,8 @@ int vt_regularize_kl(vt_model* h, const float* moments, const float* noise, floa
                      int32_t Hz, int32_t Wz, vt_stream stream);
 int vt_regularize_fsq(vt_model* h, const float* pre, float* z, int32_t* indices, int32_t B, int32_t Tz, int32_t Hz, int32_t Wz,
                       vt_stream stream);
+int vt_indices_to_latent(vt_model* h, const int32_t* indices, float* z, int32_t B, int32_t Tz, int32_t Hz, int32_t Wz,
+                         vt_stream stream);    /* FSQ: decode(indices, decode_from_indices=True) = this, then vt_decode */
 int vt_decode(vt_model* h, const float* z, int32_t B, int32_t Tz, int32_t Hz, int32_t Wz, float* x_out, void* workspace,
               int64_t workspace_bytes, vt_stream stream);
 int vt_reset_cache(vt_model* h);

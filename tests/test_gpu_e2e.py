@@ -520,6 +520,9 @@ def test_model_handle_matches_engine(name, shape, dtype):
             L.check(lib.vt_regularize_fsq(h, got_h.data_ptr(), z.data_ptr(), idx.data_ptr(), B, ld[1], ld[2], ld[3], st), "vt_regularize_fsq")
             ref_z, ref_log = model.regularization(ref_h)
             assert torch.equal(z, ref_z) and torch.equal(idx, ref_log["indices"].to(torch.int32).reshape(idx.shape))
+            z2 = torch.empty_like(z)          # decode(indices, decode_from_indices=True) starts here
+            L.check(lib.vt_indices_to_latent(h, idx.data_ptr(), z2.data_ptr(), B, ld[1], ld[2], ld[3], st), "vt_indices_to_latent")
+            assert torch.equal(z2, model.indices_to_latent(ref_log["indices"])) and torch.equal(z2, z)
         # decoder
         ref_x = model._run_decoder(z)
         got_x = torch.empty_like(ref_x)

@@ -918,6 +918,16 @@ extern "C" int vt_regularize_fsq(vt_model* h, const float* pre, float* z, int32_
   return vt_fsq_quantize(pre, z, indices, h->m.cfg.levels, h->m.cfg.n_levels, B, (int64_t)Tz * Hz * Wz, stream);
 }
 
+// FSQ: token indices -> latent codes (AutoencodingEngine.indices_to_latent / decode(..., decode_from_indices=True),
+// reference autoencoder.py:205-229): z then goes to vt_decode
+extern "C" int vt_indices_to_latent(vt_model* h, const int32_t* indices, float* z, int32_t B, int32_t Tz, int32_t Hz, int32_t Wz, vt_stream stream) {
+  if (!h || h->m.cfg.regularizer != 1) {
+    vt_set_error("vt_indices_to_latent: the handle's regularizer is not FSQ");
+    return VT_ERR_ARG;
+  }
+  return vt_fsq_indices_to_codes(indices, z, h->m.cfg.levels, h->m.cfg.n_levels, B, (int64_t)Tz * Hz * Wz, stream);
+}
+
 extern "C" int vt_reset_cache(vt_model* h) {
   if (!h) {
     vt_set_error("vt_reset_cache: null handle");

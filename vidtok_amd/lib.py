@@ -101,6 +101,7 @@ SIGNATURES = {
     "vt_encode": (C.c_int, [_P, _P, _I32, _I32, _I32, _I32, _P, _P, _I64, _P]),
     "vt_regularize_kl": (C.c_int, [_P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _P]),
     "vt_regularize_fsq": (C.c_int, [_P, _P, _P, _P, _I32, _I32, _I32, _I32, _P]),
+    "vt_indices_to_latent": (C.c_int, [_P, _P, _P, _I32, _I32, _I32, _I32, _P]),
     "vt_decode": (C.c_int, [_P, _P, _I32, _I32, _I32, _I32, _P, _P, _I64, _P]),
     "vt_reset_cache": (C.c_int, [_P]),
     "vt_conv": (C.c_int, [C.POINTER(ConvDesc), _P]),
