@@ -327,7 +327,7 @@ int vt_fsq_aux_stats_avg(const float* h, const int32_t* levels_host, int32_t D, 
 int vt_entropy(const float* avg, int64_t J, float* out, vt_stream stream);
 
 /* ------------------------------------------------------------------------------------------
- * Model handle: AutoencodingEngine.encode / decode of the causal v1.0 tokenizers driven from C++ over the operators above
+ * Model handle: AutoencodingEngine.encode / decode of the causal tokenizers (v1.0 and v1.1) driven from C++ over the operators above
  * (reference vidtok/models/autoencoder.py:197-229: encode = encoder -> regularization, decode = decoder, forward = both;
  * the module tree of vidtok/modules/model_3dcausal.py:502-885 with `norm_type: layernorm`, `resamp_with_conv: true`).
  * Same stage graph, descriptors and fusion decisions as the Python host (vidtok_amd/modules.py), hence the same bits.
@@ -345,12 +345,15 @@ int vt_entropy(const float* avg, int64_t J, float* out, vt_stream stream);
  *   vt_regularize_fsq(h, pre, z, indices, B, T', H', W', stream)                     = vt_fsq_quantize
  *   vt_indices_to_latent(h, indices, z, B, T', H', W', stream)                       = vt_fsq_indices_to_codes
  *   vt_decode(h, z, B, T', H', W', x_out, ws, ws_bytes, stream)  z fp32 NCTHW -> x_out fp32 [B][out_ch][T][H][W]
- *   vt_reset_cache(h)                        no state between calls in v1.0 (v1.1 chunk caches / temporal tiling and the
- *                                            non-causal family stay with the Python host: vt_create refuses version != 0)
+ *   vt_reset_cache(h)                        nothing to reset: a call is one pass over the clip.  v1.1 (version 1): the
+ *                                            encoder pads T up to a multiple of time_downsample_factor in front and
+ *                                            vt_decode returns all T' * factor frames -- the caller keeps the last T, as
+ *                                            AutoencodingEngine.forward does (autoencoder_v1_1.py:339-341); the temporal
+ *                                            TILING of v1.1 (chunk caches) and the non-causal family stay with the Python host
  * All device pointers; every call is asynchronous on `stream`; the workspace must outlive the work queued on it.
  * ---------------------------------------------------------------------------------------- */
 typedef struct vt_model_config {
-  int32_t version;               /* 0 = v1.0 causal                                                             */
+  int32_t version;               /* 0 = v1.0 causal, 1 = v1.1 causal (replicate padding; one pass per clip)      */
   int32_t ch, num_res_blocks, in_channels, out_ch, z_channels, double_z;
   int32_t num_resolutions;       /* len(ch_mult)                                                                */
   int32_t ch_mult[8];
@@ -359,6 +362,7 @@ typedef struct vt_model_config {
   int32_t time_downsample_factor;
   int32_t regularizer;           /* 0 DiagonalGaussianRegularizer, 1 FSQRegularizer (dim == len(levels))        */
   int32_t n_levels, levels[8];
+  int32_t interpolation_mode;    /* v1.1 time up-samplers: 0 nearest, 1 trilinear                                 */
 } vt_model_config;
 typedef struct vt_model vt_model;
 int vt_model_config_size(void);    /* sizeof(vt_model_config) as compiled: lets a binding verify its struct mirror */

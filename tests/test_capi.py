@@ -272,9 +272,25 @@ def test_model_handle_without_gpu(built_lib):
         for i, e in enumerate(v):
             getattr(mc, k)[i] = e
     h = C.c_void_p()
+    mc.version = 2
+    assert built_lib.vt_create(C.byref(mc), lib.VT_BF16, C.byref(h)) != 0 and b"version" in built_lib.vt_last_error()
+    mc.version, mc.interpolation_mode = 0, 1
+    assert built_lib.vt_create(C.byref(mc), lib.VT_BF16, C.byref(h)) != 0 and b"interpolation_mode" in built_lib.vt_last_error()
+    # v1.1: same parameters, a front pad up to a multiple of 4 instead of 3 frames, one pass per clip
     mc.version = 1
-    assert built_lib.vt_create(C.byref(mc), lib.VT_BF16, C.byref(h)) != 0 and b"v1.0" in built_lib.vt_last_error()
-    mc.version = 0
+    assert built_lib.vt_create(C.byref(mc), lib.VT_BF16, C.byref(h)) == 0
+    try:
+        cfg11 = vidtok_amd.load_config(os.path.join(ROOT, "configs", "vidtok_v1_1", "vidtok_kl_causal_488_4chn_v1_1.yaml"))
+        sd11 = vidtok_amd.load_model_from_config(cfg11, verbose=False).state_dict()
+        assert {built_lib.vt_weight_name(h, i).decode() for i in range(built_lib.vt_weight_count(h))} == set(sd11.keys())
+        ld = (C.c_int32 * 4)()
+        assert built_lib.vt_latent_dims(h, 17, 256, 256, ld) == 0 and list(ld) == [8, 5, 32, 32]      # 17 + 3
+        assert built_lib.vt_latent_dims(h, 18, 256, 256, ld) == 0 and list(ld) == [8, 5, 32, 32]      # 18 + 2 (v1.0: 18 + 3 -> 5 too)
+        assert built_lib.vt_latent_dims(h, 21, 256, 256, ld) == 0 and list(ld) == [8, 6, 32, 32]
+        assert built_lib.vt_workspace_bytes(h, 1, 18, 64, 64) > 0
+    finally:
+        built_lib.vt_destroy(h)
+    mc.version, mc.interpolation_mode = 0, 0
     assert built_lib.vt_create(C.byref(mc), 7, C.byref(h)) != 0 and b"dtype" in built_lib.vt_last_error()
     assert built_lib.vt_create(C.byref(mc), lib.VT_BF16, C.byref(h)) == 0
     try:

@@ -441,12 +441,14 @@ def test_temporal_blocks_fused_and_unfused(name, shape, monkeypatch):
 
 
 # ---- the model handle of the C-ABI (vt_create / vt_load_weight / vt_encode / vt_regularize_* / vt_decode) -------------------
-def _handle_config(L, enc, reg_target, reg_params):
+def _handle_config(L, enc, reg_target, reg_params, enc_target=""):
     """vt_model_config from the constructor arguments of the reference's YAML (the defaults of EncoderCausal3D /
     DecoderCausal3D for the lists the YAML leaves out, model_3dcausal.py:560-566,738-741)"""
     c = L.ModelConfig()
     n = len(enc["ch_mult"])
-    c.version, c.ch, c.num_res_blocks, c.in_channels, c.out_ch, c.z_channels = 0, enc["ch"], enc["num_res_blocks"], enc["in_channels"], enc["out_ch"], enc["z_channels"]
+    c.version = 1 if enc_target.endswith("V11") else 0
+    c.interpolation_mode = {"nearest": 0, "trilinear": 1}[enc.get("interpolation_mode", "nearest")] if c.version else 0
+    c.ch, c.num_res_blocks, c.in_channels, c.out_ch, c.z_channels = enc["ch"], enc["num_res_blocks"], enc["in_channels"], enc["out_ch"], enc["z_channels"]
     c.double_z, c.num_resolutions = int(enc.get("double_z", True)), n
     lists = dict(ch_mult=enc["ch_mult"], spatial_ds=enc.get("spatial_ds") or list(range(0, n - 1)), tempo_ds=enc.get("tempo_ds") or [n - 2, n - 3],
                  spatial_us=enc.get("spatial_us") or list(range(1, n)), tempo_us=enc.get("tempo_us") or [1, 2])
@@ -465,8 +467,12 @@ def _handle_config(L, enc, reg_target, reg_params):
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32], ids=["bf16", "f32"])
 @pytest.mark.parametrize("name,shape", [("vidtok_kl_causal_488_4chn", (2, 3, 9, 64, 64)), ("vidtok_kl_causal_488_4chn", (1, 3, 17, 256, 256)),
-                                        ("vidtok_fsq_causal_488_32768", (1, 3, 17, 128, 128)), ("vidtok_kl_causal_41616_4chn", (1, 3, 9, 128, 128))],
-                         ids=["kl_488_small", "kl_488_full_size", "fsq_488", "kl_41616"])
+                                        ("vidtok_fsq_causal_488_32768", (1, 3, 17, 128, 128)), ("vidtok_kl_causal_41616_4chn", (1, 3, 9, 128, 128)),
+                                        ("vidtok_v1_1/vidtok_kl_causal_488_4chn_v1_1", (2, 3, 18, 64, 64)),      # front pad 2, trilinear
+                                        ("vidtok_v1_1/vidtok_fsq_causal_888_32768_v1_1", (1, 3, 16, 128, 128)),  # three time up-samplers
+                                        ("vidtok_v1_1/vidtok_kl_causal_288_8chn_v1_1", (1, 3, 33, 64, 64)),
+                                        ("vidtok_v1_1/vidtok_kl_causal_488_4chn_v1_1:nearest", (1, 3, 12, 64, 64))],
+                         ids=["kl_488_small", "kl_488_full_size", "fsq_488", "kl_41616", "v11_kl_488", "v11_fsq_888", "v11_kl_288", "v11_nearest"])
 def test_model_handle_matches_engine(name, shape, dtype):
     """the handle-level C-ABI drives the stage graph from C++ (csrc/model.cpp).  Everything below goes
     through ctypes only -- create from the YAML's constructor arguments, load the reference state_dict key by key from
@@ -478,11 +484,21 @@ def test_model_handle_matches_engine(name, shape, dtype):
 
     if dtype == torch.float32 and shape[-1] >= 256:
         pytest.skip("fp32 at full size is covered by the bf16 case of the same graph and the small fp32 case")
-    model, cfg, sd = build_model(name, device=DEV, dtype=dtype)
+    name, _, interp = name.partition(":")
+    model, cfg, sd = build_model(name, device=DEV, dtype=dtype, overrides={"interpolation_mode": interp} if interp else None)
     prm = cfg["model"]["params"]
     lib = L.load()
     h = C.c_void_p()
-    mc = _handle_config(L, prm["encoder_config"]["params"], prm["regularizer_config"]["target"], prm["regularizer_config"].get("params", {}))
+    mc = _handle_config(L, prm["encoder_config"]["params"], prm["regularizer_config"]["target"], prm["regularizer_config"].get("params", {}),
+                        prm["encoder_config"]["target"])
+    v11 = mc.version == 1
+    if v11:
+        # one pass per clip: what AutoencodingEngineV11.encode / decode set up before running un-tiled
+        assert not model.use_tiling
+        for part in (model.encoder, model.decoder):
+            model._empty_causal_cached(part)
+        model._set_first_chunk(True)
+        model._set_fused_temporal()
     L.check(lib.vt_create(C.byref(mc), L.VT_BF16 if dtype == torch.bfloat16 else L.VT_F32, C.byref(h)), "vt_create")
     try:
         names = [lib.vt_weight_name(h, i).decode() for i in range(lib.vt_weight_count(h))]

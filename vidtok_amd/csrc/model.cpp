@@ -7,8 +7,10 @@
 // It is the same graph as vidtok_amd/modules.py builds (same operators, same descriptors, same fusion decisions: which
 // convolution emits which LayerNorm, the fused temporal block, the parity classes of the up-samplers), so its results
 // equal the Python engine's bit for bit (tests/test_gpu_e2e.py::test_model_handle_matches_engine drives it through ctypes
-// only).  Scope: `norm_type: layernorm`, `resamp_with_conv: true`, nearest time up-sampling -- every shipped v1.0 causal
-// config.  v1.1 chunk caches / tiling and the non-causal family stay with the Python host (vt_create refuses them).
+// only).  Scope: `norm_type: layernorm`, `resamp_with_conv: true` -- every shipped causal config, v1.0 and v1.1 (first-frame
+// replicate padding, nearest or trilinear time up-sampling, model_3dcausal_v1_1.py) as ONE pass over the clip.  The temporal
+// tiling of v1.1 (chunk caches, AutoencodingEngine.tile_encode / tile_decode) and the non-causal family stay with the
+// Python host.
 //
 // Memory: weights are packed on the host when first used and live in device allocations owned by the handle;
 // activations come from a caller-provided workspace, cut into two arenas that alternate between stages (a stage reads the
@@ -129,6 +131,9 @@ struct DevBuf {
 struct Model {
   vt_model_config cfg;
   int dt;
+  bool v11() const { return cfg.version == 1; }
+  // time padding of a convolution with taps before the clip: zeros (v1.0) or the first frame repeated (v1.1, one pass)
+  int tpad() const { return v11() ? VT_TPAD_REPLICATE : VT_TPAD_ZERO; }
   std::map<std::string, Param> params;
   std::vector<std::unique_ptr<DevBuf>> owned;
   std::map<std::string, void*> packed;      // cache key -> device pointer
@@ -274,6 +279,7 @@ struct ConvOpts {
   int yt_mul = 1, yt_off = 0, ys = 0, ys_oh = 0, ys_ow = 0;
   float* ncthw = nullptr;          // write fp32 NCTHW here instead
   int t_trim = 0;
+  int tmode = VT_TPAD_ZERO;
 };
 
 // mirror of vidtok_amd/ops.py::conv
@@ -299,7 +305,7 @@ Act conv(Ctx& c, const Tens& x, const void* w, int ldw, const float* bias, const
   d.To = To; d.Ho = Ho; d.Wo = Wo; d.Cout = cout;
   d.ldw = ldw; d.ldy = ldy;
   d.KT = g.kt; d.KH = g.kh; d.KW = g.kw; d.st = g.st; d.sh = g.sh; d.sw = g.sw; d.pt = g.pt; d.ph = g.ph; d.pw = g.pw;
-  d.tmode = VT_TPAD_ZERO;
+  d.tmode = g.pt > 0 ? o.tmode : VT_TPAD_ZERO;
   d.res_mode = o.res_mode;
   if (o.res_mode != VT_RES_NONE) {
     d.res = o.res->p; d.res_tshift = 0; d.Tr = o.res->T; d.ldr = o.res->ld;
@@ -349,9 +355,10 @@ struct Stage {
   virtual Act run(Ctx& c, const Act& x, NormRef next) = 0;
 };
 
-ConvOpts emit(NormRef next) {
+ConvOpts emit(NormRef next, int tmode = VT_TPAD_ZERO) {
   ConvOpts o;
   o.ln = next;                     // keep_y = true
+  o.tmode = tmode;
   return o;
 }
 
@@ -373,11 +380,12 @@ struct ResBlock : Stage {          // ResnetBlock (2-D per frame) or ResnetCausa
     ConvOpts o1;
     o1.ln = NormRef{&n2, true};
     o1.keep_y = false;             // conv1's result is only ever seen through norm2 + SiLU
+    o1.tmode = m->tpad();
     const int taps = causal3d_ ? 27 : 9;
     const Act h2 = conv(c, h, m->conv_w(c1.key + ".weight", h.ld, c.dry), taps * h.ld, m->f32(c1.key + ".bias", c.dry), g3, cout, o1);
     Tens xs = x.y;
     if (cin != cout) xs = conv(c, x.y, m->conv_w(sc.key + ".weight", x.y.ld, c.dry), x.y.ld, m->f32(sc.key + ".bias", c.dry), g1, cout, ConvOpts()).y;
-    ConvOpts o2 = emit(next);
+    ConvOpts o2 = emit(next, m->tpad());
     o2.res = &xs;
     o2.res_mode = VT_RES_ADD;
     return conv(c, h2.n, m->conv_w(c2.key + ".weight", h2.n.ld, c.dry), taps * h2.n.ld, m->f32(c2.key + ".bias", c.dry), g3, cout, o2);
@@ -397,7 +405,7 @@ struct TBlock : Stage {            // ResnetCausalBlock1D, model_3dcausal.py:427
     g.kt = 3; g.pt = 2;
     vt_tblock_desc d;
     memset(&d, 0, sizeof(d));
-    d.dtype = xp.dt; d.C = ch; d.ld = xp.ld; d.B = xp.B; d.T = xp.T; d.HW = (int64_t)xp.H * xp.W; d.tmode = VT_TPAD_ZERO;
+    d.dtype = xp.dt; d.C = ch; d.ld = xp.ld; d.B = xp.B; d.T = xp.T; d.HW = (int64_t)xp.H * xp.W; d.tmode = m->tpad();
     if (fusable(c) && vt_temporal_block_supported(&d)) {
       Act r;
       r.y = c.alloc(xp.B, xp.T, xp.H, xp.W, xp.ld, xp.dt, ch);
@@ -421,8 +429,9 @@ struct TBlock : Stage {            // ResnetCausalBlock1D, model_3dcausal.py:427
     ConvOpts o1;
     o1.ln = NormRef{&n2, true};
     o1.keep_y = false;
+    o1.tmode = m->tpad();
     const Act h2 = conv(c, h, m->conv_w(c1.key + ".conv.weight", h.ld, c.dry), 3 * h.ld, m->f32(c1.key + ".conv.bias", c.dry), g, ch, o1);
-    ConvOpts o2 = emit(next);
+    ConvOpts o2 = emit(next, m->tpad());
     o2.res = &xp;
     o2.res_mode = VT_RES_ADD;
     return conv(c, h2.n, m->conv_w(c2.key + ".conv.weight", h2.n.ld, c.dry), 3 * h2.n.ld, m->f32(c2.key + ".conv.bias", c.dry), g, ch, o2);
@@ -480,8 +489,8 @@ struct TimeDown : Stage {          // TimeDownsampleResCausal2x, model_3dcausal.
   Act run(Ctx& c, const Act& x, NormRef next) override {
     const Tens& xp = x.y;
     Tens x1 = c.alloc(xp.B, xp.T / 2, xp.H, xp.W, xp.ld, xp.dt, xp.ld);
-    if (!c.dry) M_CALL(vt_time_avgpool3s2(xp.p, nullptr, x1.p, xp.dt, xp.B, xp.T, (int64_t)xp.H * xp.W, xp.ld, VT_TPAD_ZERO, c.stream));
-    ConvOpts o = emit(next);
+    if (!c.dry) M_CALL(vt_time_avgpool3s2(xp.p, nullptr, x1.p, xp.dt, xp.B, xp.T, (int64_t)xp.H * xp.W, xp.ld, c.m->tpad(), c.stream));
+    ConvOpts o = emit(next, c.m->tpad());
     o.res = &x1;
     o.res_mode = VT_RES_MIX;
     o.mix = c.m->f32(key + ".mix_factor", c.dry);
@@ -508,10 +517,49 @@ struct Up : Stage {                // Upsample: nearest x2 + conv3x3 as four par
   }
 };
 
-struct TimeUp : Stage {            // TimeUpsampleResCausal2x (nearest) as two parity classes, model_3dcausal.py:255-273
-  int ch;
+struct TimeUp : Stage {            // TimeUpsampleResCausal2x: v1.0 nearest as two parity classes (model_3dcausal.py:255-273);
+  int ch;                          // v1.1 nearest / trilinear up-sampling, then the 27-tap convolution (model_3dcausal_v1_1.py:305-343)
+  int n_up = 1;                    // num_temp_upsample: 1, 2, 4 ... along the decoder (how many frames the trilinear head covers)
   std::string key;
-  Act run(Ctx& c, const Act& x, NormRef) override {
+  Act run_v11(Ctx& c, const Act& x, NormRef next) {
+    const Tens& xp = x.y;
+    const int T = xp.T;
+    const int64_t fr = (int64_t)xp.H * xp.W * xp.ld;
+    Tens up = c.alloc(xp.B, 2 * T, xp.H, xp.W, xp.ld, xp.dt, xp.ld);
+    if (c.m->cfg.interpolation_mode == 0) {                            // nearest: up[t] = x[t / 2]
+      for (int j0 = 0; j0 < 2 * T; j0 += 128) {
+        int32_t idx[128];
+        const int n = std::min(128, 2 * T - j0);
+        for (int j = 0; j < n; ++j) idx[j] = (j0 + j) / 2;
+        if (!c.dry) M_CALL(vt_gather_frames(xp.p, up.p + (size_t)j0 * fr * esize(xp.dt), (int)esize(xp.dt), xp.B, fr, (int64_t)T * fr, (int64_t)2 * T * fr, idx, n, c.stream));
+      }
+    } else {
+      // trilinear, first chunk (the only one here): the first n_up frames are interpolated on their own, the rest likewise
+      // (F.interpolate on x[:, :n] and x[:, n:] separately, model_3dcausal_v1_1.py:327-341); one launch per clip and part
+      const int hn = std::min(n_up, T);
+      auto lerp_part = [&](int t0, int n, int out_t0) {
+        Tens part = c.alloc(xp.B, n, xp.H, xp.W, xp.ld, xp.dt, xp.ld);
+        for (int j0 = 0; j0 < n; j0 += 128) {
+          int32_t idx[128];
+          const int m = std::min(128, n - j0);
+          for (int j = 0; j < m; ++j) idx[j] = t0 + j0 + j;
+          if (!c.dry) M_CALL(vt_gather_frames(xp.p, part.p + (size_t)j0 * fr * esize(xp.dt), (int)esize(xp.dt), xp.B, fr, (int64_t)T * fr, (int64_t)n * fr, idx, m, c.stream));
+        }
+        for (int b = 0; b < xp.B; ++b)
+          if (!c.dry)
+            M_CALL(vt_time_lerp2x(part.p + (size_t)b * n * fr * esize(xp.dt), up.p + ((size_t)b * 2 * T + out_t0) * fr * esize(xp.dt), xp.dt, 1, n, fr, c.stream));
+      };
+      lerp_part(0, hn, 0);
+      if (T > n_up) lerp_part(n_up, T - n_up, 2 * hn);
+    }
+    ConvOpts o = emit(next, VT_TPAD_REPLICATE);
+    o.res = &up;
+    o.res_mode = VT_RES_MIX;
+    o.mix = c.m->f32(key + ".mix_factor", c.dry);
+    return conv(c, up, c.m->conv_w(key + ".conv.conv.weight", up.ld, c.dry), 27 * up.ld, c.m->f32(key + ".conv.conv.bias", c.dry), causal3d(3, 3, 3), ch, o);
+  }
+  Act run(Ctx& c, const Act& x, NormRef next) override {
+    if (c.m->v11()) return run_v11(c, x, next);
     const Tens& xp = x.y;
     Act r;
     r.y = c.alloc(xp.B, 2 * xp.T, xp.H, xp.W, pad8(ch), c.m->dt, ch);
@@ -631,6 +679,7 @@ Graph build_decoder(const vt_model_config& cf, Shapes& sh) {
   Graph g;
   const int L = cf.num_resolutions;
   int block_in = cf.ch * cf.ch_mult[L - 1];
+  int n_up = 1;
   g.c_first = block_in;
   g.stages.emplace_back(res_block(sh, "decoder.mid.block_1", block_in, block_in, true));
   g.stages.emplace_back(attn(sh, "decoder.mid.attn_1", block_in));
@@ -651,6 +700,8 @@ Graph build_decoder(const vt_model_config& cf, Shapes& sh) {
       if (in_list(cf.tempo_us, cf.n_tempo_us, i)) {
         auto* t = new TimeUp();
         t->ch = block_in; t->key = ut + ".upsample";
+        t->n_up = n_up;
+        n_up *= 2;
         sh_conv(sh, ut + ".upsample.conv.conv", block_in, block_in, {3, 3, 3});
         sh[ut + ".upsample.mix_factor"] = {1};
         g.stages.emplace_back(t);
@@ -673,7 +724,7 @@ void run_graph(Ctx& c, Graph& g, const Tens& x_in, int cout_final, float* out_nc
   c.cur = &m->arena[which];
   c.cur->reset();
   const NormRef first = g.stages[0]->first_norm(c);
-  Act h = conv(c, x_in, m->conv_w(g.conv_in + ".weight", x_in.ld, c.dry), 27 * x_in.ld, m->f32(g.conv_in + ".bias", c.dry), causal3d(3, 3, 3), g.c_first, emit(first));
+  Act h = conv(c, x_in, m->conv_w(g.conv_in + ".weight", x_in.ld, c.dry), 27 * x_in.ld, m->f32(g.conv_in + ".bias", c.dry), causal3d(3, 3, 3), g.c_first, emit(first, m->tpad()));
   for (size_t i = 0; i < g.stages.size(); ++i) {
     which ^= 1;
     c.cur = &m->arena[which];
@@ -688,12 +739,14 @@ void run_graph(Ctx& c, Graph& g, const Tens& x_in, int cout_final, float* out_nc
   ConvOpts o;
   o.ncthw = out_ncthw ? out_ncthw : (float*)16;      // dry runs pass no buffer
   o.t_trim = t_trim;
+  o.tmode = m->tpad();
   conv(c, hn, m->conv_w(g.conv_out + ".weight", hn.ld, c.dry), 27 * hn.ld, m->f32(g.conv_out + ".bias", c.dry), causal3d(3, 3, 3), cout_final, o);
 }
 
-int front_pad(const vt_model_config& cf, int T) {
+int front_pad(const vt_model_config& cf, int T) {      // EncoderCausal3DPadding.forward: v1.0 pads f - 1 frames, v1.1 up to a multiple of f
   const int f = cf.time_downsample_factor;
-  return T % f == 0 ? 0 : f - 1;
+  if (T % f == 0) return 0;
+  return cf.version == 1 ? f - T % f : f - 1;
 }
 
 void encode_impl(Model* m, Graph& g, const float* x, int B, int T, int H, int W, float* h_out, hipStream_t stream, bool dry) {
@@ -711,7 +764,7 @@ void decode_impl(Model* m, Graph& g, const float* z, int B, int T, int H, int W,
   m->arena[0].reset();
   Tens zin = c.alloc(B, T, H, W, pad8(m->cfg.z_channels), m->dt, pad8(m->cfg.z_channels));
   if (!dry) M_CALL(vt_ncthw_to_ndhwc(z, zin.p, m->dt, B, m->cfg.z_channels, T, H, W, zin.ld, 0, stream));
-  run_graph(c, g, zin, m->cfg.out_ch, x_out, m->cfg.time_downsample_factor - 1);
+  run_graph(c, g, zin, m->cfg.out_ch, x_out, m->v11() ? 0 : m->cfg.time_downsample_factor - 1);   // v1.1 keeps every frame (the caller drops the padding's)
 }
 
 int count(const int32_t* v, int n, int lo, int hi) {   // entries of v in [lo, hi)
@@ -733,7 +786,8 @@ extern "C" int vt_create(const vt_model_config* cfg, int32_t compute_dtype, vt_m
   try {
     M_CHECK(cfg != nullptr && out != nullptr, "vt_create: null argument");
     M_CHECK(compute_dtype == VT_BF16 || compute_dtype == VT_F32, "vt_create: compute dtype must be VT_BF16 or VT_F32");
-    M_CHECK(cfg->version == 0, "vt_create: only the v1.0 causal family is driven from C++ (v1.1 chunk caches and the non-causal family stay with the Python host)");
+    M_CHECK(cfg->version == 0 || cfg->version == 1, "vt_create: version 0 (v1.0 causal) or 1 (v1.1 causal, one pass per clip); the non-causal family stays with the Python host");
+    M_CHECK(cfg->interpolation_mode == 0 || (cfg->interpolation_mode == 1 && cfg->version == 1), "vt_create: interpolation_mode 0 (nearest) or, for v1.1, 1 (trilinear)");
     M_CHECK(cfg->num_resolutions >= 1 && cfg->num_resolutions <= 8 && cfg->num_res_blocks >= 1 && cfg->ch > 0, "vt_create: bad level / block counts");
     M_CHECK(cfg->n_spatial_ds <= 8 && cfg->n_tempo_ds <= 8 && cfg->n_spatial_us <= 8 && cfg->n_tempo_us <= 8 && cfg->n_levels <= 8, "vt_create: list too long");
     M_CHECK(cfg->time_downsample_factor == 2 || cfg->time_downsample_factor == 4 || cfg->time_downsample_factor == 8, "vt_create: time_downsample_factor must be 2, 4 or 8");
@@ -887,7 +941,7 @@ extern "C" int vt_decode(vt_model* h, const float* z, int32_t B, int32_t Tz, int
                          int64_t workspace_bytes, vt_stream stream) {
   try {
     M_CHECK(h && z && x_out && B > 0 && Tz > 0 && Hz > 0 && Wz > 0, "vt_decode: bad argument");
-    M_CHECK((Tz << h->m.cfg.n_tempo_us) > h->m.cfg.time_downsample_factor - 1, "vt_decode: too few latent frames");
+    M_CHECK(h->m.v11() || (Tz << h->m.cfg.n_tempo_us) > h->m.cfg.time_downsample_factor - 1, "vt_decode: too few latent frames");
     check_loaded(h, "decoder.");
     bind_workspace(h->m, workspace, workspace_bytes);
     decode_impl(&h->m, h->dec, z, B, Tz, Hz, Wz, x_out, reinterpret_cast<hipStream_t>(stream), false);
@@ -933,5 +987,5 @@ extern "C" int vt_reset_cache(vt_model* h) {
     vt_set_error("vt_reset_cache: null handle");
     return VT_ERR_ARG;
   }
-  return VT_OK;     // the v1.0 graph keeps no state between calls (v1.1 chunk caches are not driven from here)
+  return VT_OK;     // one pass per clip keeps no state between calls (the chunk caches of v1.1 tiling are not driven from here)
 }

@@ -74,7 +74,8 @@ class ModelConfig(C.Structure):
         + [("ch_mult", C.c_int32 * 8)]
         + [("n_spatial_ds", C.c_int32), ("spatial_ds", C.c_int32 * 8), ("n_tempo_ds", C.c_int32), ("tempo_ds", C.c_int32 * 8)]
         + [("n_spatial_us", C.c_int32), ("spatial_us", C.c_int32 * 8), ("n_tempo_us", C.c_int32), ("tempo_us", C.c_int32 * 8)]
-        + [("time_downsample_factor", C.c_int32), ("regularizer", C.c_int32), ("n_levels", C.c_int32), ("levels", C.c_int32 * 8)]
+        + [("time_downsample_factor", C.c_int32), ("regularizer", C.c_int32), ("n_levels", C.c_int32), ("levels", C.c_int32 * 8),
+           ("interpolation_mode", C.c_int32)]
     )
 
 
