@@ -72,7 +72,7 @@ int vt_conv_max_lds_bytes(void);
  * through vt_set_option; vt_reset_options() re-reads the environment defaults.  Every option selects between
  * implementations of the SAME operator contract (the parity tests run both sides of each switch), so none of them
  * is part of the reference's interface.  Names (default):
- *   conv_buf (1)        gather through buffer descriptors; 0 = 64-bit pointers (always used for > 4 GiB tensors / cache mode)
+ *   conv_buf (1)        gather through buffer descriptors; 0 = 64-bit pointers (always used for > 4 GiB tensors, and in cache mode when a tile spans frames)
  *   conv_tinner (1)     temporal convolutions walk their tiles frames-innermost (L2 reuse of the kt taps)
  *   conv_ldsepi (1)     128 x 128 tile: epilogue transposed through the LDS (whole-line stores, carries the fused LayerNorm)
  *   conv_sched (2)      K-step schedule of the 8-wave 256 x 256 tile: 0 plain loop, 1 schedule 1, 2 two-group ping-pong (bf16)

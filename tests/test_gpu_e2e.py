@@ -440,6 +440,39 @@ def test_temporal_blocks_fused_and_unfused(name, shape, monkeypatch):
         assert ez < BF16_Z and ed < BF16_RECON
 
 
+def test_encoder_tail_precision():
+    """set_compute_dtype(bf16, encoder_tail=fp32, tail_level=k): the deep encoder levels, mid and conv_out in fp32 on a
+    bf16 pass.  tail_level 0 = everything after conv_in in fp32; the latent gets closer to the fp32 kernels' as the tail
+    grows, a tail in the pass's own type is the plain pass bit for bit, and the decoder is untouched."""
+    name, shape = "vidtok_fsq_causal_488_32768", (1, 3, 9, 128, 128)
+    model, cfg, sd = build_model(name, device=DEV, dtype=torch.float32)
+    torch.manual_seed(11)
+    x = torch.rand(shape, device=DEV) * 2 - 1
+    ref = model._run_encoder(x)
+    model.set_compute_dtype(torch.bfloat16)
+    plain_bf16 = model._run_encoder(x)
+    err = [rel_err(plain_bf16, ref)]
+    n = model.encoder.num_resolutions
+    for level in (n, n - 1, 0):
+        model.set_compute_dtype(torch.bfloat16, encoder_tail=torch.float32, tail_level=level)
+        assert model.decoder.compute_dtype == torch.bfloat16 and model.encoder.tail_level == level
+        err.append(rel_err(model._run_encoder(x), ref))
+    assert err[3] < err[2] < err[0] and err[1] < err[0], err
+    model.set_compute_dtype(torch.bfloat16, encoder_tail=torch.bfloat16)
+    assert torch.equal(model._run_encoder(x), plain_bf16)
+    model.set_compute_dtype(torch.float32, encoder_tail=torch.bfloat16, tail_level=n)        # the other direction runs too
+    assert rel_err(model._run_encoder(x), ref) < err[0]
+    model.set_compute_dtype(torch.bfloat16)
+    assert model.encoder.tail_dtype is None and torch.equal(model._run_encoder(x), plain_bf16)
+    model.enable_graphs()
+    model.set_compute_dtype(torch.bfloat16, encoder_tail=torch.float32)
+    eager = None
+    for _ in range(3):                                    # eager, captured, replayed
+        got = model._run_encoder(x)
+        eager = got if eager is None else eager
+        assert torch.equal(got, eager)
+
+
 # ---- the model handle of the C-ABI (vt_create / vt_load_weight / vt_encode / vt_regularize_* / vt_decode) -------------------
 def _handle_config(L, enc, reg_target, reg_params, enc_target=""):
     """vt_model_config from the constructor arguments of the reference's YAML (the defaults of EncoderCausal3D /

@@ -366,6 +366,32 @@ def test_conv_8wave_schedules(case, sched, vt_opts):
     assert plan["tile"] == ((256, 256) if case[3] % 256 == 0 else (128, 128))
 
 
+# Cache mode (v1.1 chunks after the first) gathers through buffer descriptors when a tile lies inside one output frame
+# (Ho * Wo % tile rows == 0: a time tap then reads the cache or x for the whole tile and the kernel switches the descriptor
+# per tap), through pointers otherwise.  Two clips (the cache's own batch stride), caches longer than the padding, a time
+# stride of 2 (the down-sampler's convolution), frames of exactly one 256-row tile, LayerNorm emitted; both gather forms.
+CACHE_BUF_CASES = [
+    ("cb_3d_256_b2", (2, 5, 32, 32), 256, 256, (3, 3, 3), ConvGeom(**G333), dict(tmode="cache", res="add")),
+    ("cb_3d_s2_256", (2, 6, 32, 32), 256, 256, (3, 3, 3),
+     ConvGeom(kt=3, kh=3, kw=3, st=2, pt=1, ph=1, pw=1, ph_hi=1, pw_hi=1), dict(tmode="cache")),
+    ("cb_1d_512_b2", (2, 4, 16, 16), 512, 512, (3,), ConvGeom(kt=3, pt=2), dict(tmode="cache", res="add")),
+    ("cb_1d_256_ln", (2, 4, 16, 16), 256, 256, (3,), ConvGeom(kt=3, pt=2), dict(tmode="cache", res="add", ln="keep")),
+    ("cb_3d_128_b2", (2, 3, 16, 16), 128, 128, (3, 3, 3), ConvGeom(**G333), dict(tmode="cache", ln="keep")),
+    ("cb_3d_128_to_3", (1, 3, 16, 16), 128, 8, (3, 3, 3), ConvGeom(**G333), dict(tmode="cache")),
+]
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+@pytest.mark.parametrize("gather", ["descriptors", "descriptors_plain_loop", "pointers"])
+@pytest.mark.parametrize("case", CACHE_BUF_CASES, ids=[c[0] for c in CACHE_BUF_CASES])
+def test_conv_cache_mode_gather_forms(case, gather, dtype, vt_opts):
+    vt_opts(conv_buf=(0 if gather == "pointers" else 1), conv_sched=(0 if gather == "descriptors_plain_loop" else 2))
+    if case[3] % 256 == 0:
+        vt_opts(conv_tile=256)
+    plan = _check_conv(case, dtype)
+    assert plan["tile"][0] in (128, 256)
+
+
 @pytest.mark.parametrize("coalesced", [True, False], ids=["lds_epilogue", "vector_epilogue"])
 @pytest.mark.parametrize("case", [c for c in CONV_CASES_LARGE if c[3] % 256 == 0], ids=[c[0] for c in CONV_CASES_LARGE if c[3] % 256 == 0])
 def test_conv_8wave_plain_epilogues(case, coalesced, vt_opts):

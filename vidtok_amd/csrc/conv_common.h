@@ -66,6 +66,7 @@ struct ConvArgs {
   int lds_epi;                 // 128 x 128 tile: epilogue transposed through the LDS (coalesced rows)
   int hw_tiles;                // > 0: pixel tiles per frame, tile order (b, hw tile, t) -- see launch_variant
   unsigned x_bytes, w_bytes;   // BUF path: descriptor extents (0 = tensors too large, use pointers)
+  unsigned c_bytes;            // BUF path in cache mode: extent of the cache tensor [B][ncache][Hi][Wi][Cin]
   long long xs_z, ws_z, ys_z, rs_z;
   unsigned long long* prof;    // PROF instantiation only (vt_conv_profile): cycle stamps of workgroup 0
   int prof_mode;               // PROF instantiation of conv_ws2.hip only: option ws_prof_mode

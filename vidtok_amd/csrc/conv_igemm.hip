@@ -594,6 +594,9 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_igemm_glds_ker
   // against extent 0 (every lane out of range: zeros into a slot nobody reads again, no memory traffic), so
   // the K loop has no branch around any piece and ONE straight-line body
   unsigned ext_x = BUF ? p.x_bytes : 0u, ext_w = BUF ? p.w_bytes : 0u;
+  // BUF in cache mode (v1.1 chunks after the first): a tile lies in ONE output frame (launch_variant checks), so a time tap
+  // reads either the cache or x for all of its rows -- the descriptor of the activation pieces is switched per tap
+  const MT* x_cur = xg;
   if constexpr (PROF) {            // measurement (option ws_prof_mode): bit 0 / bit 1 = activation / weight pieces become zero fills (no memory traffic)
     if (p.prof_mode & 1) ext_x = 0u;
     if (p.prof_mode & 2) ext_w = 0u;
@@ -732,13 +735,31 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_igemm_glds_ker
       if (q_cc == 0) {               // uniform branch: new tap -> new gather addresses
         if constexpr (BUF) {
           if ((q_kh | q_kw) == 0) {  // new kt (rare): time part of the offsets, time-padding bit
+            bool from_cache = false;
+            if constexpr (!PROF) {
+              if (p.tmode == VT_TPAD_CACHE) {            // uniform
+                const int tv_u = __builtin_amdgcn_readfirstlane(a_t0[0]) + q_kt;     // the tile's frame: the same for every row
+                from_cache = tv_u < 0;
+                x_cur = from_cache ? cg : xg;
+                ext_x = from_cache ? p.c_bytes : p.x_bytes;
+              }
+            }
+            if (from_cache) {                            // frame ncache + tv of the cache [B][ncache][Hi][Wi][Cin] (ncache >= pt: vt_conv checks)
 #pragma unroll
-            for (int i = 0; i < A_VECS; ++i) {
-              const int tv = a_t0[i] + q_kt;
-              const bool ok = (tv < Tv) & ((tv >= 0) | replicate);
-              const unsigned ti = (unsigned)(max(tv, 0) >> p.ups_t);
-              a_tb[i] = (((unsigned)a_bt[i] + ti) * HiWi + (unsigned)a_hw[i]) * pix_bytes + chunk_bytes;
-              a_mask[i] = (a_mask[i] & ~(1u << 16)) | (ok ? (1u << 16) : 0u);
+              for (int i = 0; i < A_VECS; ++i) {
+                const unsigned ti = (unsigned)(p.ncache + a_t0[i] + q_kt);
+                a_tb[i] = (((unsigned)(a_b[i] * p.ncache) + ti) * HiWi + (unsigned)a_hw[i]) * pix_bytes + chunk_bytes;
+                a_mask[i] |= 1u << 16;
+              }
+            } else {
+#pragma unroll
+              for (int i = 0; i < A_VECS; ++i) {
+                const int tv = a_t0[i] + q_kt;
+                const bool ok = (tv < Tv) & ((tv >= 0) | replicate);
+                const unsigned ti = (unsigned)(max(tv, 0) >> p.ups_t);
+                a_tb[i] = (((unsigned)a_bt[i] + ti) * HiWi + (unsigned)a_hw[i]) * pix_bytes + chunk_bytes;
+                a_mask[i] = (a_mask[i] & ~(1u << 16)) | (ok ? (1u << 16) : 0u);
+              }
             }
           }
           const unsigned tm = (1u << q_kh) | (1u << (8 + q_kw)) | (1u << 16);
@@ -804,7 +825,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_igemm_glds_ker
     char* As = smem + stage * STAGE_BYTES + lds_row_off;
     if (q < A_VECS) {
       if constexpr (BUF) {
-        const __amdgpu_buffer_rsrc_t rsrc_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<MT*>(xg), 0, ext_x, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rsrc_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<MT*>(x_cur), 0, ext_x, 0x00020000);
         // (a non-temporal hint on these gathers -- "let the L2 drop x first, keep the weight slab" -- was measured and lost:
         // 833 -> 778-793 frames/s, profiles/r03_traffic_by_layer_group.txt; and a run-time switch in front of every piece is a
         // branch in the K loop)
@@ -1196,10 +1217,15 @@ int launch_variant(const ConvArgs& a_in, int nbatch, hipStream_t stream) {
                (a.res_mode == VT_RES_NONE || a.ldr % kOctAlign == 0) && (a.ln_mode == 0 || a.ldn % kOctAlign == 0)) ? 1 : 0;
   a.hw_tiles = 0;
   if (conv_tinner() && a.KT > 1 && a.To > 1 && ((long long)a.Ho * a.Wo) % BM == 0) a.hw_tiles = (int)(((long long)a.Ho * a.Wo) / BM);
-  // descriptor gather needs both tensors under 4 GiB (minus the out-of-range marker) and no cache-mode padding
+  // descriptor gather needs the tensors under 4 GiB (minus the out-of-range marker)
   const unsigned long long xb = (unsigned long long)a.B * a.Ti * a.Hi * a.Wi * a.Cin * sizeof(MT);
   const unsigned long long wb = (unsigned long long)a.Cout * a.ldw * sizeof(MT);
-  const bool buf = conv_buf() && xb < 0xFFFF0000ull && wb < 0xFFFF0000ull && a.tmode != VT_TPAD_CACHE &&
+  // cache mode (v1.1 chunks after the first): descriptors only where a tile lies in one output frame, so that a time tap reads
+  // the cache or x for the whole tile (the kernel switches the descriptor per tap); other shapes gather through pointers
+  const unsigned long long cb = a.tmode == VT_TPAD_CACHE ? (unsigned long long)a.B * a.ncache * a.Hi * a.Wi * a.Cin * sizeof(MT) : 0ull;
+  const bool cache_ok = a.tmode != VT_TPAD_CACHE ||
+                        (FAST && nbatch == 1 && a.prof == nullptr && cb < 0xFFFF0000ull && ((long long)a.Ho * a.Wo) % BM == 0 && a.ups_t == 0);
+  const bool buf = conv_buf() && xb < 0xFFFF0000ull && wb < 0xFFFF0000ull && cache_ok &&
                    a.KH <= 8 && a.KW <= 8;   // the per-row padding mask of the FAST form holds 8 bits per axis
   const void* kern;
   // option conv_sched: 0 = the plain K-step loop of the 8-wave tile, 1 = schedule 1, 2 (default) = ping-pong; see the kernel
@@ -1211,6 +1237,7 @@ int launch_variant(const ConvArgs& a_in, int nbatch, hipStream_t stream) {
   if (buf) {
     a.x_bytes = (unsigned)xb;
     a.w_bytes = (unsigned)wb;
+    a.c_bytes = (unsigned)cb;
     kern = reinterpret_cast<const void*>(&conv_igemm_glds_kernel<MT, TOut, WAVES_M, WAVES_N, TM, TN, FAST, ROWB, STAGES, true, LN256>);
     if constexpr (HAS_S1) {
       if (s1) kern = reinterpret_cast<const void*>(&conv_igemm_glds_kernel<MT, TOut, WAVES_M, WAVES_N, TM, TN, FAST, ROWB, STAGES, true, LN256, false, 1>);

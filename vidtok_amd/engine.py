@@ -7,7 +7,7 @@ alias (BASELINE.json names it that way).  Training (`training_step`, optimizers,
 of scope: `loss_config` is accepted and ignored.
 """
 import re
-from typing import Any, Dict, Tuple, Union
+from typing import Any, Dict, Optional, Tuple, Union
 
 import torch
 import torch.nn as nn
@@ -64,12 +64,22 @@ class AutoencodingEngine(nn.Module):
             self.init_from_ckpt(ckpt_path, ignore_keys=ignore_keys, verbose=verbose)
 
     # ---- numeric mode ---------------------------------------------------------------------------
-    def set_compute_dtype(self, dtype: torch.dtype):
+    def set_compute_dtype(self, dtype: torch.dtype, encoder_tail: Optional[torch.dtype] = None, tail_level: Optional[int] = None):
         """torch.float32: fp32 storage + fp32-input MFMA (parity mode); torch.bfloat16: bf16 storage +
-        bf16 MFMA with fp32 accumulation (throughput mode, the reference's autocast analogue)."""
-        assert dtype in (torch.float32, torch.bfloat16)
+        bf16 MFMA with fp32 accumulation (throughput mode, the reference's autocast analogue).
+        `encoder_tail` (causal encoders): the encoder levels from `tail_level` on (default: the last level), its mid section
+        and conv_out run in that type instead -- the small deep layers, whose rounding decides most of the FSQ code flips
+        of a bf16 pass, in fp32 while the wide levels stay on the bf16 kernels."""
+        assert dtype in (torch.float32, torch.bfloat16) and encoder_tail in (None, torch.float32, torch.bfloat16)
         self.encoder.compute_dtype = dtype
         self.decoder.compute_dtype = dtype
+        if hasattr(self.encoder, "tail_dtype"):
+            n = self.encoder.num_resolutions
+            self.encoder.tail_dtype = encoder_tail
+            self.encoder.tail_level = (n - 1 if tail_level is None else int(tail_level)) if encoder_tail is not None else None
+            assert encoder_tail is None or 0 <= self.encoder.tail_level <= n
+        else:
+            assert encoder_tail is None, "encoder_tail: causal encoders only"
         self.invalidate_graphs()
         return self
 

@@ -607,14 +607,23 @@ def first_norm_of(stage, dt=None):
     return stage.first_norm()
 
 
-def run_stages(stages, h, dt, last_norm=None, first=None):
+def run_stages(stages, h, dt, last_norm=None, first=None, switch=None):
     """Run the blocks in order; every block is told which norm its consumer starts with, so the conv that writes the
-    activation can emit that norm as well (ops.conv `ln=`).  `h` may already come with stages[0]'s norm (`first`)."""
+    activation can emit that norm as well (ops.conv `ln=`).  `h` may already come with stages[0]'s norm (`first`).
+    `switch` = (i, dtype): stages[i:] (and `last_norm`) run in that storage / arithmetic type -- the activation is
+    converted once, un-normalised, in front of stages[i] (i == len(stages): in front of `last_norm`'s consumer)."""
     if first is not None and not isinstance(h, Normed):
         h = _wrap(h, first)
     for i, stage in enumerate(stages):
-        nxt = first_norm_of(stages[i + 1], dt) if i + 1 < len(stages) else last_norm
+        if switch is not None and i == switch[0]:
+            h, dt = plain(h).to(switch[1]), switch[1]
+        if switch is not None and i + 1 == switch[0]:
+            nxt = None                               # the consumer works in another type: it runs its own norm
+        else:
+            nxt = first_norm_of(stages[i + 1], dt) if i + 1 < len(stages) else last_norm
         h = stage.run(h, dt, next_norm=nxt)
+    if switch is not None and switch[0] == len(stages):
+        h = plain(h).to(switch[1])
     return h
 
 
@@ -650,6 +659,9 @@ class EncoderCausal3DPadding(nn.Module):
         self.time_padding = self.time_downsample_factor - 1
         self.out_channels = 2 * z_channels if double_z else z_channels
         self.compute_dtype = torch.float32
+        # mixed precision (AutoencodingEngine.set_compute_dtype(..., encoder_tail=)): the levels from `tail_level` on, the
+        # mid section and conv_out run in `tail_dtype`; tail_level == num_resolutions: mid + conv_out only
+        self.tail_dtype, self.tail_level = None, None
 
         self.conv_in = CausalConv3d(in_channels, ch, 3, version=v)
         in_ch_mult = (1,) + tuple(ch_mult)
@@ -704,17 +716,24 @@ class EncoderCausal3DPadding(nn.Module):
             h = ops.ncthw_to_ndhwc(xp, dt, tpad=0)
         else:
             h = ops.ncthw_to_ndhwc(x.contiguous().float(), dt, tpad=npad)
-        stages = []
+        stages, level_start = [], []
         for i_level in range(self.num_resolutions):
+            level_start.append(len(stages))
             for i_block in range(self.num_res_blocks):
                 stages += [self.down[i_level].block[i_block], self.down_temporal[i_level].block[i_block]]
             if i_level in self.spatial_ds:
                 stages.append(self.down[i_level].downsample)
                 if i_level in self.tempo_ds:
                     stages.append(self.down_temporal[i_level].downsample)
+        level_start.append(len(stages))
         stages += [self.mid.block_1, self.mid.attn_1, self.mid.block_2]
+        switch = None
+        if self.tail_dtype is not None and self.tail_dtype != dt:
+            switch = (level_start[self.tail_level], self.tail_dtype)
         h = run_stages(stages, self.conv_in.run(h, dt, **_emit(first_norm_of(stages[0], dt))), dt,
-                       last_norm=(self.norm_out, True), first=first_norm_of(stages[0], dt))
+                       last_norm=(self.norm_out, True), first=first_norm_of(stages[0], dt), switch=switch)
+        if switch is not None:
+            dt = switch[1]
         h = self.norm_out.apply_ndhwc(h, True, dt, SITE_FRAME)
         return self.conv_out.run(h, dt, out_layout=L.VT_NCTHW)
 
