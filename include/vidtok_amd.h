@@ -286,11 +286,17 @@ int vt_ndhwc_to_ncthw(const void* x, int in_dtype, float* y, int32_t B, int32_t 
  *   last frame, as avg_pool3d does), same dtype.
  * vt_time_lerp2x: F.interpolate(scale (2,1,1), "trilinear", align_corners=False) along T of a
  *   sequence of Ti frames -> 2*Ti frames (model_3dcausal_v1_1.py:327-341); fp32 arithmetic.
+ * vt_time_lerp2x_cat: the same of the sequence [head (nh frames, [B][nh][HWC]) | x ([B][Tx][HWC])] per clip without
+ *   assembling it, leaving out the first `skip` output frames: y [B][2 (nh + Tx) - skip][HWC].  The chunks after the
+ *   first of a v1.1 tiled pass: head = the frames cached from the previous chunk, skip = 2 * num_temp_upsample
+ *   (torch.cat + interpolate + slice, model_3dcausal_v1_1.py:331-341).  nh = 0, skip = 0 is vt_time_lerp2x.
  * ---------------------------------------------------------------------------------------- */
 int vt_time_avgpool3s2(const void* x, const void* cache, void* y, int dtype, int32_t B, int32_t Ti,
                        int64_t HW, int32_t C, int32_t tmode, vt_stream stream);
 int vt_time_lerp2x(const void* x, void* y, int dtype, int32_t B, int32_t Ti, int64_t HWC,
                    vt_stream stream);
+int vt_time_lerp2x_cat(const void* head, int32_t nh, const void* x, void* y, int dtype, int32_t B, int32_t Tx, int32_t skip,
+                       int64_t HWC, vt_stream stream);
 
 /* ------------------------------------------------------------------------------------------
  * regularizers; all tensors NCTHW fp32 as in the reference API

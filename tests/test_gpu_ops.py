@@ -608,6 +608,19 @@ def test_time_lerp2x(dtype, Ti):
     assert torch.equal(out[:, 2:2 + 2 * Ti], y) and float(out[:, :2].float().abs().max()) == 0
 
 
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+@pytest.mark.parametrize("nh,T,skip", [(1, 4, 2), (2, 5, 4), (4, 8, 8), (2, 1, 0), (1, 3, 7)])
+def test_time_lerp2x_cat(dtype, nh, T, skip):
+    """interpolation of [head | x] without assembling it, minus the first `skip` frames (v1.1 chunks after the first:
+    torch.cat + F.interpolate + slice, reference model_3dcausal_v1_1.py:331-341) = the bits of the assembled form"""
+    head, x = _act(2, nh, 4, 4, 128, dtype, 1), _act(2, T, 4, 4, 128, dtype, 2)
+    y = ops.time_lerp2x_cat(head, x, skip)
+    full = ops.time_lerp2x(torch.cat([head, x], dim=1).contiguous())
+    assert y.shape[1] == 2 * (nh + T) - skip and torch.equal(y, full[:, skip:])
+    yr = R.time_lerp2x(torch.cat([head, x], dim=1).cpu())[:, skip:]
+    assert rel_err(y, yr) < (1e-6 if dtype == torch.float32 else 8e-3)
+
+
 def test_gather_frames():
     x = _act(2, 5, 4, 4, 128, torch.bfloat16, 1)
     idx = [4, 0, 0, 3, 2, 2]

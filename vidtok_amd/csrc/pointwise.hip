@@ -274,15 +274,19 @@ __global__ __launch_bounds__(kBlock) void time_avgpool3s2_kernel(const T* __rest
   }
 }
 
+// The sequence that is interpolated is [h (nh frames) | x (Tx frames)] per clip -- nh = 0: x alone -- and the first `skip`
+// of its 2 (nh + Tx) output frames are not produced (v1.1 chunks after the first: h = the cached frames of the previous
+// chunk, whose part of the output the previous chunk already delivered; model_3dcausal_v1_1.py:327-341).
 template <typename T>
-__global__ __launch_bounds__(kBlock) void time_lerp2x_kernel(const T* __restrict__ x, T* __restrict__ y, int B,
-                                                             int Ti, long long F4) {
-  const int To = 2 * Ti;
+__global__ __launch_bounds__(kBlock) void time_lerp2x_kernel(const T* __restrict__ h, int nh, const T* __restrict__ x, T* __restrict__ y,
+                                                             int B, int Tx, int skip, long long F4) {
+  const int Ti = nh + Tx;
+  const int To = 2 * Ti - skip;
   const long long n = (long long)B * To * F4;
   for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < n; i += (long long)gridDim.x * kBlock) {
     const long long f = i % F4;
     long long r = i / F4;
-    const int j = (int)(r % To);
+    const int j = (int)(r % To) + skip;
     const int b = (int)(r / To);
     // align_corners=False source coordinate, scale 1/2:  src = (j + 0.5) * 0.5 - 0.5, clamped at 0
     float src = ((float)j + 0.5f) * 0.5f - 0.5f;
@@ -292,9 +296,10 @@ __global__ __launch_bounds__(kBlock) void time_lerp2x_kernel(const T* __restrict
     const float l1 = src - (float)t0;
     const float l0 = 1.0f - l1;
     float a[4], c[4], o[4];
-    const T* xb = x + ((long long)b * Ti) * F4 * 4 + f * 4;
-    load4<T>(xb + (long long)t0 * F4 * 4, a);
-    load4<T>(xb + (long long)t1 * F4 * 4, c);
+    const T* p0 = t0 < nh ? h + ((long long)b * nh + t0) * F4 * 4 : x + ((long long)b * Tx + (t0 - nh)) * F4 * 4;
+    const T* p1 = t1 < nh ? h + ((long long)b * nh + t1) * F4 * 4 : x + ((long long)b * Tx + (t1 - nh)) * F4 * 4;
+    load4<T>(p0 + f * 4, a);
+    load4<T>(p1 + f * 4, c);
 #pragma unroll
     for (int e = 0; e < 4; ++e) o[e] = l0 * a[e] + l1 * c[e];
     store4<T>(y + i * 4, o);
@@ -443,22 +448,28 @@ extern "C" int vt_time_avgpool3s2(const void* x, const void* cache, void* y, int
   return VT_OK;
 }
 
-extern "C" int vt_time_lerp2x(const void* x, void* y, int dtype, int32_t B, int32_t Ti, int64_t HWC,
-                              vt_stream stream_) {
+extern "C" int vt_time_lerp2x_cat(const void* head, int32_t nh, const void* x, void* y, int dtype, int32_t B, int32_t Tx, int32_t skip,
+                                  int64_t HWC, vt_stream stream_) {
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
-  VT_CHECK_ARG(x && y && B > 0 && Ti > 0 && HWC > 0 && HWC % 4 == 0, "vt_time_lerp2x: bad dims");
+  VT_CHECK_ARG(x && y && B > 0 && Tx > 0 && HWC > 0 && HWC % 4 == 0, "vt_time_lerp2x: bad dims");
+  VT_CHECK_ARG(nh >= 0 && (nh == 0 || head != nullptr) && skip >= 0 && skip < 2 * (nh + Tx), "vt_time_lerp2x_cat: head frames %d, skip %d of %d", nh, skip, 2 * (nh + Tx));
   const long long F4 = HWC / 4;
-  const long long n = (long long)B * 2 * Ti * F4;
+  const long long n = (long long)B * (2 * (nh + Tx) - skip) * F4;
   if (dtype == VT_F32)
-    hipLaunchKernelGGL(time_lerp2x_kernel<float>, dim3(grid_for(n)), dim3(kBlock), 0, stream, (const float*)x,
-                       (float*)y, B, Ti, F4);
+    hipLaunchKernelGGL(time_lerp2x_kernel<float>, dim3(grid_for(n)), dim3(kBlock), 0, stream, (const float*)head, nh, (const float*)x,
+                       (float*)y, B, Tx, skip, F4);
   else if (dtype == VT_BF16)
-    hipLaunchKernelGGL(time_lerp2x_kernel<bf16_t>, dim3(grid_for(n)), dim3(kBlock), 0, stream, (const bf16_t*)x,
-                       (bf16_t*)y, B, Ti, F4);
+    hipLaunchKernelGGL(time_lerp2x_kernel<bf16_t>, dim3(grid_for(n)), dim3(kBlock), 0, stream, (const bf16_t*)head, nh, (const bf16_t*)x,
+                       (bf16_t*)y, B, Tx, skip, F4);
   else
     VT_CHECK_ARG(false, "vt_time_lerp2x: dtype %d", dtype);
   VT_CHECK_LAUNCH();
   return VT_OK;
+}
+
+extern "C" int vt_time_lerp2x(const void* x, void* y, int dtype, int32_t B, int32_t Ti, int64_t HWC,
+                              vt_stream stream_) {
+  return vt_time_lerp2x_cat(nullptr, 0, x, y, dtype, B, Ti, 0, HWC, stream_);
 }
 
 extern "C" int vt_gather_frames(const void* src, void* dst, int32_t esize, int32_t B, int64_t frame_elems,

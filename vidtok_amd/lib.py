@@ -124,6 +124,7 @@ SIGNATURES = {
     "vt_ndhwc_to_ncthw": (C.c_int, [_P, C.c_int, _P, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _P]),
     "vt_time_avgpool3s2": (C.c_int, [_P, _P, _P, C.c_int, _I32, _I32, _I64, _I32, _I32, _P]),
     "vt_time_lerp2x": (C.c_int, [_P, _P, C.c_int, _I32, _I32, _I64, _P]),
+    "vt_time_lerp2x_cat": (C.c_int, [_P, _I32, _P, _P, C.c_int, _I32, _I32, _I32, _I64, _P]),
     "vt_fsq_consts": (C.c_int, [C.POINTER(_I32), _I32, C.POINTER(_F)]),
     "vt_kl_sample": (C.c_int, [_P, _P, _P, _P, _I32, _I32, _I64, _P]),
     "vt_fsq_quantize": (C.c_int, [_P, _P, _P, C.POINTER(_I32), _I32, _I32, _I64, _P]),

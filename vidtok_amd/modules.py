@@ -379,6 +379,13 @@ class TimeUpsampleResCausal2x(nn.Module):
         if not self.is_first_chunk:
             nc = self.causal_cache.shape[1]
             Tc = nc + T
+            if Tc - 2 * n >= nc:
+                # the frames to keep all lie in x: [cache | x] is never assembled -- the interpolation reads both parts in
+                # place and leaves out the frames the previous chunk delivered; then the cache buffer is rewritten
+                up = ops.time_lerp2x_cat(self.causal_cache, x, 2 * n)
+                keep = list(range(Tc - 2 * n - nc, Tc - n - nc))
+                self.causal_cache = ops.gather_frames(x, keep, out=_persistent_cache(self, (x.shape[0], len(keep)) + tuple(x.shape[2:]), x))
+                return up
             xc = torch.empty((x.shape[0], Tc) + tuple(x.shape[2:]), dtype=x.dtype, device=x.device)   # [cache | x]
             ops.gather_frames(self.causal_cache, list(range(nc)), out=xc, out_t0=0)
             ops.gather_frames(x, list(range(T)), out=xc, out_t0=nc)

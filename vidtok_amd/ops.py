@@ -444,6 +444,20 @@ def time_lerp2x(x, out=None, out_t0=0):
     return out
 
 
+def time_lerp2x_cat(head, x, skip):
+    """time_lerp2x of [head | x] along T (head [B, nh, H, W, C], x [B, T, H, W, C]) without its first `skip` frames -- the
+    sequence is never assembled: [B, 2 (nh + T) - skip, H, W, C]"""
+    lib = L.load()
+    _chk(x, "lerp.x")
+    _chk(head, "lerp.head")
+    B, T, H, W, Cc = x.shape
+    nh = head.shape[1]
+    assert head.dtype == x.dtype and head.shape[0] == B and tuple(head.shape[2:]) == (H, W, Cc) and 0 <= skip < 2 * (nh + T)
+    y = torch.empty((B, 2 * (nh + T) - skip, H, W, Cc), dtype=x.dtype, device=x.device)
+    L.check(lib.vt_time_lerp2x_cat(_ptr(head), nh, _ptr(x), _ptr(y), _DT[x.dtype], B, T, skip, H * W * Cc, _stream()), "vt_time_lerp2x_cat")
+    return y
+
+
 def gather_frames(src, idx, out=None, out_t0=0):
     """dst[:, out_t0 + j] = src[:, idx[j]] along dim 1 of an NDHWC tensor (or any [B, T, ...] tensor: frames are copied
     as bytes).  v1.1 cache maintenance and chunk assembly; `out` [B, Td, ...] is filled in place."""
