@@ -767,12 +767,6 @@ void decode_impl(Model* m, Graph& g, const float* z, int B, int T, int H, int W,
   run_graph(c, g, zin, m->cfg.out_ch, x_out, m->v11() ? 0 : m->cfg.time_downsample_factor - 1);   // v1.1 keeps every frame (the caller drops the padding's)
 }
 
-int count(const int32_t* v, int n, int lo, int hi) {   // entries of v in [lo, hi)
-  int k = 0;
-  for (int i = 0; i < n; ++i) k += v[i] >= lo && v[i] < hi;
-  return k;
-}
-
 }  // namespace
 
 struct vt_model {
