@@ -176,6 +176,11 @@ def time_lerp2x(x, out=None, out_t0=0):
     return out
 
 
+def time_lerp2x_cat(head, x, skip):
+    """torch.cat + F.interpolate + slice (reference model_3dcausal_v1_1.py:331-341)"""
+    return time_lerp2x(torch.cat([head, x], dim=1))[:, skip:].contiguous()
+
+
 def gather_frames(src, idx, out=None, out_t0=0):
     g = src[:, list(idx)].contiguous()
     if out is None:
@@ -311,7 +316,7 @@ def ncthw_copy_frames(src, dst, ts0, td0, n, clamp=False):
 
 
 ALL = ["conv", "gemm_nt", "layernorm_act", "softmax_rows", "ncthw_to_ndhwc", "ndhwc_to_ncthw", "time_avgpool3s2",
-       "time_lerp2x", "gather_frames", "kl_sample", "fsq_quantize", "fsq_indices_to_codes", "fsq_aux_stats", "entropy", "tanh_", "temporal_block", "temporal_block_supported", "frames_u8_to_ncthw", "ncthw_to_frames_u8", "ncthw_copy_frames",
+       "time_lerp2x", "time_lerp2x_cat", "gather_frames", "kl_sample", "fsq_quantize", "fsq_indices_to_codes", "fsq_aux_stats", "entropy", "tanh_", "temporal_block", "temporal_block_supported", "frames_u8_to_ncthw", "ncthw_to_frames_u8", "ncthw_copy_frames",
        "eval_psnr_ssim", "channel_linear", "groupnorm_act"]
 
 
