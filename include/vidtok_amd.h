@@ -83,6 +83,7 @@ int vt_conv_max_lds_bytes(void);
  *   conv_tile_min (128) fewest 256 x 256 tiles for which the 8-wave tile is chosen
  *   conv_fuse_ln (1), conv_fuse_ln256 (1)   LayerNorm of the result inside the epilogue for Cout = 128 / 256
  *   conv_ln256_v (1)    form of the Cout = 256 LayerNorm epilogue (0: round-2 form)
+ *   conv_deep (1)       128 x 128 tile on a 4-slot ring (three K steps of DMA in flight) for launches with no more tiles than CUs
  *   ws_acc (0), tblock_prof_mode (0), ws_prof_mode (0)   measurement aids
  *   tblock_fused (1)   0: vt_temporal_block_supported answers no (blocks stay on the unfused operators)
  * Returns VT_ERR_ARG for an unknown name.
@@ -173,7 +174,8 @@ int vt_conv(const vt_conv_desc* d, vt_stream stream);
  * workgroup, workgroups (tiles for the persistent kernel), 1 if LayerNorm comes from the conv epilogue, kernel
  * launches of the call, kernel (0 = tile-per-workgroup implicit GEMM, 1 = weight-stationary persistent 3x3 for
  * Cin = Cout = 128 bf16), 1 if the 8-wave tile's epilogue goes through the LDS (coalesced rows; always with a fused LayerNorm,
- * without one for bf16 full tiles)}.  Validates `d` exactly like vt_conv.  Test / measurement aid: which kernel and
+ * without one for bf16 full tiles) or 2 if the 128 x 128 tile runs on its 4-slot ring (option conv_deep: launches with no
+ * more tiles than the device has CUs)}.  Validates `d` exactly like vt_conv.  Test / measurement aid: which kernel and
  * instantiation does a parity case exercise. */
 int vt_conv_plan(const vt_conv_desc* d, int32_t* out8);
 /* Measurement aid (scripts/conv_profile.py): vt_conv(d) on the bf16 8-wave 256 x 256 tile (no LayerNorm) with shader-clock

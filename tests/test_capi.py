@@ -151,7 +151,12 @@ def test_conv_plan_tile_selection(built_lib, monkeypatch):
     L.load().vt_reset_options()
     big = ops.conv_plan(desc((1280, 1024), 256, 256))            # the 256-channel level of the benchmark (B=4: 20 frames)
     assert big["tile"] == (256, 256) and big["waves"] == 8 and big["workgroups"] == 5120
-    assert ops.conv_plan(desc((64, 64), 256, 256))["tile"] == (128, 128)
+    small = ops.conv_plan(desc((64, 64), 256, 256))
+    assert small["tile"] == (128, 128) and small["deep_ring"] and not small["lds_epilogue"]      # 64 tiles <= CUs: 4-slot ring
+    with L.options(conv_deep=0):
+        assert not ops.conv_plan(desc((64, 64), 256, 256))["deep_ring"]
+    with L.options(conv_tile=128):
+        assert not ops.conv_plan(desc((1280, 1024), 256, 256))["deep_ring"]                      # 20 480 tiles: two workgroups per CU
     assert ops.conv_plan(desc((64, 64), 128, 8))["tile"] == (256, 32)
     assert ops.conv_plan(desc((64, 64), 128, 64))["tile"] == (256, 64)
     with L.options(conv_tile=256):

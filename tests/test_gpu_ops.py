@@ -392,6 +392,32 @@ def test_conv_cache_mode_gather_forms(case, gather, dtype, vt_opts):
     assert plan["tile"][0] in (128, 256)
 
 
+# The 128 x 128 tile has two rings: two slots (two workgroups per CU cover each other's DMA latency) and, for launches with
+# no more tiles than CUs -- every workgroup alone on its CU -- four slots with three K steps in flight (option conv_deep).
+# Both instantiations on the shapes that pick the deep one by themselves: the deep 512-channel layers of a v1.1 chunk,
+# cache mode in both gather forms, fused LayerNorm, ragged pixel / channel tiles, exactly 8 K steps (the shortest it takes).
+DEEP_CASES = [
+    ("deep_3d_512", (1, 3, 16, 16), 512, 512, (3, 3, 3), ConvGeom(**G333), dict(res="add")),
+    ("deep_cache_1d_256", (2, 4, 16, 16), 256, 256, (3,), ConvGeom(kt=3, pt=2), dict(tmode="cache", res="add")),
+    ("deep_cache_3d_ragged", (1, 3, 10, 10), 128, 128, (3, 3, 3), ConvGeom(**G333), dict(tmode="cache")),
+    ("deep_ln128", (1, 2, 16, 16), 128, 128, (3, 3), ConvGeom(**G3), dict(res="add", ln="keep")),
+    ("deep_ragged_192", (1, 3, 10, 10), 256, 192, (3, 3, 3), ConvGeom(**G333), dict(res="mix")),
+    ("deep_1x1_512_8steps", (1, 2, 16, 16), 512, 256, (1, 1), ConvGeom(), {}),
+    ("deep_replicate_s2", (1, 6, 16, 16), 256, 256, (3, 3, 3),
+     ConvGeom(kt=3, kh=3, kw=3, st=2, pt=1, ph=1, pw=1, ph_hi=1, pw_hi=1), dict(tmode="replicate")),
+]
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+@pytest.mark.parametrize("ring", ["deep", "deep_pointers", "two_slots"])
+@pytest.mark.parametrize("case", DEEP_CASES, ids=[c[0] for c in DEEP_CASES])
+def test_conv_128_tile_rings(case, ring, dtype, vt_opts):
+    vt_opts(conv_tile=128, conv_ws=0, conv_deep=(0 if ring == "two_slots" else 1), conv_buf=(0 if ring == "deep_pointers" else 1))
+    plan = _check_conv(case, dtype)
+    steps = math.prod(case[4]) * case[2] // (64 if dtype == torch.bfloat16 else 32)
+    assert plan["tile"] == (128, 128) and plan["deep_ring"] == (ring != "two_slots" and steps >= 8), (plan, steps)
+
+
 @pytest.mark.parametrize("coalesced", [True, False], ids=["lds_epilogue", "vector_epilogue"])
 @pytest.mark.parametrize("case", [c for c in CONV_CASES_LARGE if c[3] % 256 == 0], ids=[c[0] for c in CONV_CASES_LARGE if c[3] % 256 == 0])
 def test_conv_8wave_plain_epilogues(case, coalesced, vt_opts):

@@ -1195,9 +1195,9 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_igemm_glds_ker
 inline bool conv_buf() { return vt_opt(OPT_CONV_BUF) != 0; }
 inline bool conv_tinner() { return vt_opt(OPT_CONV_TINNER) != 0; }
 
-template <typename MT, typename TOut, int WAVES_M, int WAVES_N, int TM, int TN, bool FAST, int LN256 = 0>
+template <typename MT, typename TOut, int WAVES_M, int WAVES_N, int TM, int TN, bool FAST, int LN256 = 0, int STAGES = 2>
 int launch_variant(const ConvArgs& a_in, int nbatch, hipStream_t stream) {
-  constexpr int ROWB = kRowBytes, STAGES = 2;
+  constexpr int ROWB = kRowBytes;
   constexpr int BM = WAVES_M * TM * 32;
   constexpr int BN = WAVES_N * TN * 32;
   constexpr int BK = ROWB / (int)sizeof(MT);
@@ -1284,6 +1284,38 @@ int launch_fast_or_general(const ConvArgs& a, int nbatch, hipStream_t stream) {
                            : launch_variant<MT, TOut, WAVES_M, WAVES_N, TM, TN, false>(a, nbatch, stream);
 }
 
+// CUs of the current device (cached per device; 256 when it cannot be asked, e.g. vt_conv_plan on a host without a GPU)
+inline int device_cus() {
+  static std::atomic<int> cus[kMaxDevices];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) {
+    (void)hipGetLastError();
+    return 256;
+  }
+  const bool dev_ok = dev >= 0 && dev < kMaxDevices;
+  int n = dev_ok ? cus[dev].load(std::memory_order_acquire) : 0;
+  if (n == 0) {
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) {
+      (void)hipGetLastError();
+      n = 256;
+    }
+    if (dev_ok) cus[dev].store(n, std::memory_order_release);
+  }
+  return n;
+}
+
+// 128 x 128 tile on a 4-slot ring (128 KB of LDS, three K steps of DMA in flight instead of one).  Two workgroups per CU
+// cover each other's DMA latency; a launch with no more tiles than CUs leaves every workgroup alone on its CU, and with
+// one step of look-ahead its K step then lasts one fabric round trip (the deep layers of a v1.1 chunk, M = 4 096 / 5 120
+// at 512 channels and K = 13 824: ~1 600 cycles per step against 512 of MFMA work).  Alone on the CU it can have the LDS.
+inline bool deep_ring_eligible(const ConvArgs& a, int nbatch, int elem_bytes) {
+  if (vt_opt(OPT_CONV_DEEP) == 0 || a.prof != nullptr) return false;
+  const int bk = kRowBytes / elem_bytes;
+  if (a.Cin % bk != 0 || a.ntaps * (a.Cin / bk) < 8) return false;              // descriptor-walk form only; a K worth the ring
+  const long long tiles = (long long)((a.M + 127) / 128) * ((a.Cout + 127) / 128) * nbatch;
+  return tiles <= device_cus();
+}
+
 // Tile selection.  Bytes staged per FLOP fall with the tile area (128x128: 15.6 KB/MFLOP bf16, 256x256: 7.8),
 // so Cout % 256 == 0 layers with enough pixels take the 8-wave 256x256 tile (measured 988 vs 814 TFLOP/s on
 // the 27-tap 256->256 conv when introduced); everything else keeps 128x128 with two independent workgroups
@@ -1361,7 +1393,9 @@ int dispatch_tile(const ConvArgs& a, int nbatch, hipStream_t stream) {
         }
       }
       return launch_fast_or_general<MT, TOut, 4, 2, 2, 4>(a, nbatch, stream);
-    default: return launch_fast_or_general<MT, TOut, 2, 2, 2, 2>(a, nbatch, stream);
+    default:
+      if (deep_ring_eligible(a, nbatch, (int)sizeof(MT))) return launch_variant<MT, TOut, 2, 2, 2, 2, true, 0, 4>(a, nbatch, stream);
+      return launch_fast_or_general<MT, TOut, 2, 2, 2, 2>(a, nbatch, stream);
   }
 }
 
@@ -1481,7 +1515,7 @@ int conv_prepare(const vt_conv_desc* d, ConvArgs& a, bool& ln_fused, int& nbatch
 // What vt_conv(d) will do, without launching: out[0..1] = pixel x channel tile, out[2] = waves per workgroup,
 // out[3] = workgroups (tiles for the persistent kernel), out[4] = 1 when LayerNorm is produced by the conv kernel's
 // epilogue (0: second launch of vt_layernorm_act, or no LayerNorm requested), out[5] = kernel launches the call
-// performs, out[6] = kernel: 0 = conv_igemm_glds_kernel, 1 = conv3x3_ws128_kernel (weight-stationary), 2 = conv3d_narrow_kernel, out[7] = 0.  Lets tests assert which
+// performs, out[6] = kernel: 0 = conv_igemm_glds_kernel, 1 = conv3x3_ws128_kernel (weight-stationary), 2 = conv3d_narrow_kernel, out[7] = epilogue / ring form (see the header).  Lets tests assert which
 // instantiation a parity case exercises and lets bench.py separate conv kernel time from LayerNorm passes.
 extern "C" int vt_conv_plan(const vt_conv_desc* d, int32_t* out8) {
   VT_CHECK_ARG(out8 != nullptr, "vt_conv_plan: null output");
@@ -1512,6 +1546,7 @@ extern "C" int vt_conv_plan(const vt_conv_desc* d, int32_t* out8) {
   out8[5] = (d->ln_mode != 0 && !ln_fused) ? 2 : 1;
   // epilogue through the LDS (rows of 16-byte accesses) instead of the MFMA-layout vector epilogue
   if (k == TILE_256x256) out8[7] = (ln_fused || lds256_plain_eligible(a, nbatch, d->dtype == VT_BF16 && d->out_dtype == VT_BF16)) ? 1 : 0;
+  if (k == TILE_128x128 && deep_ring_eligible(a, nbatch, d->dtype == VT_F32 ? 4 : 2)) out8[7] = 2;   // 4-slot ring
   return VT_OK;
 }
 

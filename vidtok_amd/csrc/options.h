@@ -19,6 +19,7 @@ enum VtOpt {
   OPT_WS_ACC,              // ws128: accumulator placement (measurement aid)
   OPT_TBLOCK_FUSED,        // 0: vt_temporal_block_supported answers no (the host keeps the blocks on the unfused operators)
   OPT_TBLOCK_PROF_MODE,    // vt_temporal_block_profile: bit 0 GEMMs skipped, bit 1 row units skipped, bit 4 no stores (wrong results)
+  OPT_CONV_DEEP,           // 1: 128 x 128 tile on a 4-slot ring (three K steps in flight) when a launch has no more tiles than the device has CUs
   OPT_WS_PROF_MODE,        // vt_conv_profile on conv_ws2.hip: bit 0 = row slots skipped, bit 1 = LDS-DMA requests skipped (wrong results)
   OPT_COUNT
 };
