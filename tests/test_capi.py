@@ -321,6 +321,51 @@ def test_model_handle_without_gpu(built_lib):
         built_lib.vt_destroy(h)
 
 
+def _causal_configs():
+    import glob
+
+    paths = sorted(glob.glob(os.path.join(ROOT, "configs", "*.yaml")) + glob.glob(os.path.join(ROOT, "configs", "vidtok_v1_1", "*.yaml")))
+    return [os.path.relpath(q, os.path.join(ROOT, "configs"))[:-5] for q in paths if "noncausal" not in q]
+
+
+@pytest.mark.parametrize("name", _causal_configs())
+def test_model_handle_graph_of_every_causal_config(built_lib, name):
+    """The C++ stage graph (csrc/model.cpp) for every shipped causal YAML, v1.0 and v1.1 -- every compression schedule
+    (4x8x8, 4x16x16, 2x8x8, 4x4x4, 8x8x8), every latent width, both regularizers: the handle lists exactly the encoder /
+    decoder parameters of the Python model with the reference's shapes, its latent dimensions follow the schedule, and
+    the dry run of both graphs sizes a workspace.  Host-side only."""
+    import vidtok_amd
+    from util import handle_config
+    from vidtok_amd import lib
+
+    cfg = vidtok_amd.load_config(os.path.join(ROOT, "configs", name + ".yaml"))
+    prm = cfg["model"]["params"]
+    enc = prm["encoder_config"]["params"]
+    reg = prm["regularizer_config"]
+    mc = handle_config(lib, enc, reg["target"], reg.get("params", {}), prm["encoder_config"]["target"])
+    assert mc.version == (1 if "v1_1" in name else 0)
+    h = C.c_void_p()
+    assert built_lib.vt_create(C.byref(mc), lib.VT_BF16, C.byref(h)) == 0, built_lib.vt_last_error()
+    try:
+        sd = {k: v for k, v in vidtok_amd.load_model_from_config(cfg, verbose=False).state_dict().items() if not k.startswith("regularization")}
+        n = built_lib.vt_weight_count(h)
+        keys = [built_lib.vt_weight_name(h, i).decode() for i in range(n)]
+        assert set(keys) == set(sd) and len(keys) == len(sd)
+        for i, k in enumerate(keys):
+            shp, nd = (C.c_int64 * 5)(), C.c_int32()
+            assert built_lib.vt_weight_shape(h, i, shp, C.byref(nd)) == 0 and tuple(shp[:nd.value]) == tuple(sd[k].shape), k
+        f = enc.get("time_downsample_factor", 4)
+        sds = len(enc.get("spatial_ds") or range(len(enc["ch_mult"]) - 1))
+        for T in (1, f, f + 1, 2 * f + 1, 3 * f):
+            pad = 0 if T % f == 0 else (f - T % f if mc.version == 1 else f - 1)
+            ld = (C.c_int32 * 4)()
+            assert built_lib.vt_latent_dims(h, T, 64, 64, ld) == 0
+            assert list(ld) == [enc["z_channels"] * (2 if enc.get("double_z", True) else 1), (T + pad) // f, 64 >> sds, 64 >> sds], (T, list(ld))
+        assert built_lib.vt_workspace_bytes(h, 1, f + 1, 64, 64) > 0, built_lib.vt_last_error()
+    finally:
+        built_lib.vt_destroy(h)
+
+
 def _build_c_example(tmp_path):
     """examples/roundtrip.c with the system C compiler (not hipcc): the boundary is C"""
     import shutil

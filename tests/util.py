@@ -66,3 +66,27 @@ def build_oracle(cfg: dict, sd: dict):
     from oracle.vidtok_oracle import OracleEngine
 
     return OracleEngine(cfg["model"]["params"], sd)
+
+
+def handle_config(L, enc, reg_target, reg_params, enc_target=""):
+    """vt_model_config from the constructor arguments of the reference's YAML (the defaults of EncoderCausal3D /
+    DecoderCausal3D for the lists the YAML leaves out, model_3dcausal.py:560-566,738-741)"""
+    c = L.ModelConfig()
+    n = len(enc["ch_mult"])
+    c.version = 1 if enc_target.endswith("V11") else 0
+    c.interpolation_mode = {"nearest": 0, "trilinear": 1}[enc.get("interpolation_mode", "nearest")] if c.version else 0
+    c.ch, c.num_res_blocks, c.in_channels, c.out_ch, c.z_channels = enc["ch"], enc["num_res_blocks"], enc["in_channels"], enc["out_ch"], enc["z_channels"]
+    c.double_z, c.num_resolutions = int(enc.get("double_z", True)), n
+    lists = dict(ch_mult=enc["ch_mult"], spatial_ds=enc.get("spatial_ds") or list(range(0, n - 1)), tempo_ds=enc.get("tempo_ds") or [n - 2, n - 3],
+                 spatial_us=enc.get("spatial_us") or list(range(1, n)), tempo_us=enc.get("tempo_us") or [1, 2])
+    for k, v in lists.items():
+        for i, e in enumerate(v):
+            getattr(c, k)[i] = int(e)
+        if k != "ch_mult":
+            setattr(c, "n_" + k, len(v))
+    c.time_downsample_factor = enc.get("time_downsample_factor", 4)
+    if reg_target.endswith("FSQRegularizer"):
+        c.regularizer, c.n_levels = 1, len(reg_params["levels"])
+        for i, e in enumerate(reg_params["levels"]):
+            c.levels[i] = int(e)
+    return c
