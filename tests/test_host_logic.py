@@ -36,6 +36,39 @@ def test_host_graph_matches_reference_golden(case, emulated_ops):
         assert abs(float(log["kl_loss"]) - float(gold["kl_loss"])) < 1e-4 * abs(float(gold["kl_loss"]))
 
 
+def test_encoder_tail_precision_plumbing(emulated_ops):
+    """set_compute_dtype(bf16, encoder_tail=fp32, tail_level=k) (host logic with the torch stand-ins for the operators): the
+    stages from level k on run in fp32 -- their inputs arrive converted, un-normalised, and every one of them is handed
+    fp32; with the whole encoder behind conv_in in the tail the latent is much closer to the fp32 pass's; tail = the pass's own
+    type is the plain pass."""
+    import vidtok_amd.ops as ops
+
+    model, cfg, sd = build_model("vidtok_kl_causal_488_4chn", seed=4)
+    x = torch.rand(1, 3, 5, 32, 32) * 2 - 1
+    ref = model.encoder(x)
+    model.set_compute_dtype(torch.bfloat16)
+    plain = model.encoder(x)
+    seen = []
+    conv = ops.conv
+    ops.conv = lambda xx, *a, **k: (seen.append(xx.dtype), conv(xx, *a, **k))[1]      # (monkeypatched module attribute: restored below)
+    try:
+        n = model.encoder.num_resolutions
+        errs = []
+        for level in (n, 2, 0):
+            seen.clear()
+            model.set_compute_dtype(torch.bfloat16, encoder_tail=torch.float32, tail_level=level)
+            errs.append(rel_err(model.encoder(x), ref))
+            first32 = seen.index(torch.float32)
+            assert seen[0] == torch.bfloat16 and all(d == torch.float32 for d in seen[first32:]) and all(d == torch.bfloat16 for d in seen[:first32])
+        assert errs[2] < 0.5 * rel_err(plain, ref), errs          # everything after conv_in in fp32 (a short tail on a 4-frame clip is within the noise)
+    finally:
+        ops.conv = conv
+    model.set_compute_dtype(torch.bfloat16, encoder_tail=torch.bfloat16)
+    assert torch.equal(model.encoder(x), plain)
+    model.set_compute_dtype(torch.bfloat16)
+    assert model.encoder.tail_dtype is None and model.encoder.tail_level is None
+
+
 @pytest.mark.parametrize("name,shape", [
     ("vidtok_kl_causal_288_8chn", (1, 3, 5, 32, 32)),
     ("vidtok_kl_causal_444_4chn", (1, 3, 5, 16, 16)),
