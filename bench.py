@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """bench.py -- encode+decode frames/s of the MI355X VidTok path (BASELINE.json metric).
 
-    python bench.py --gpus N --steps K --warmup W [--dtype bf16|fp32] [--batch B] [--no-graph]
+    python bench.py --gpus N --steps K --warmup W [--dtype bf16|fp32|bf16x3] [--batch B] [--no-graph]
 
 One "step" = one pass of the hot path, `model(x)` = encode -> KL regularizer -> decode
 (reference AutoencodingEngine.forward, vidtok/models/autoencoder.py:221-229), over one batch of
@@ -47,7 +47,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 FLOP_PER_PADDED_FRAME_256 = 1.0345e12     # SURVEY.md section 8(d), conv + attention MACs x 2
-PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}   # MI355X_MICROARCH.md: dense MFMA peaks
+# MI355X_MICROARCH.md: dense MFMA peaks.  bf16x3 (split-bf16: fp32 storage, three bf16 MFMAs per product) is priced per
+# ALGORITHMIC FLOP like the others: a third of the bf16 peak
+PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3, "bf16x3": 2500.0 / 3}
 PEAK_HBM_GBS = 8000.0                           # MI355X_MICROARCH.md: HBM3E 8 TB/s (6.3 TB/s achievable by a copy)
 T_REAL, T_PADDED, RES = 17, 20, 256
 CONFIG_1GPU = "vidtok_kl_causal_488_4chn"       # BASELINE.json configs[1]
@@ -213,7 +215,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--dtype", choices=["bf16", "fp32"], default="bf16")
+    ap.add_argument("--dtype", choices=["bf16", "fp32", "bf16x3"], default="bf16",
+                    help="bf16: bf16 storage + MFMA (throughput mode); fp32: fp32 storage + fp32 MFMA; bf16x3: fp32 storage, every "
+                         "convolution as three bf16 MFMAs per product (the fast mode inside the reference's fp32 tolerance)")
     ap.add_argument("--batch", type=int, default=4, help="clips per GPU")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -268,7 +272,7 @@ def main():
     import vidtok_amd
     from vidtok_amd import ops
 
-    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    dtype = {"bf16": torch.bfloat16, "fp32": torch.float32, "bf16x3": "bf16x3"}[args.dtype]
     config = args.config or (CONFIG_1GPU if world == 1 else CONFIG_NGPU)
     model = vidtok_amd.load_model_from_config(os.path.join(ROOT, "configs", config + ".yaml"), verbose=False)
     randomize_weights(model, 0)

@@ -19,7 +19,17 @@
  *   - `dtype` selects the arithmetic: VT_F32 = fp32 storage + fp32-input MFMA
  *     (v_mfma_f32_32x32x2_f32, bit-wise an fmaf chain), VT_BF16 = bf16 storage + bf16 MFMA
  *     (v_mfma_f32_32x32x16_bf16) with fp32 accumulation.  Statistics, softmax, the regularizers
- *     and all epilogue arithmetic are fp32 in both modes.
+ *     and all epilogue arithmetic are fp32 in both modes.  vt_conv additionally takes
+ *     VT_BF16X3 ("split-bf16"): fp32 storage (x, cache, y, res, ln_out exactly as for VT_F32,
+ *     out_dtype = VT_F32) with the products taken on the bf16 matrix cores from bf16 hi / lo
+ *     planes of both operands (x_hi w_hi + x_hi w_lo + x_lo w_hi, fp32 accumulation: ~2^-17
+ *     relative per product against 2^-9 for VT_BF16, at 3/16 of the matrix-pipe time of
+ *     VT_F32).  Activations are split inside the kernel; the WEIGHTS are handed over already
+ *     split: row n of `w` holds, per group of 16 consecutive k, 16 bf16 hi values followed by
+ *     16 bf16 lo values (hi = bf16_rne(w), lo = bf16_rne(w - hi)) -- 64 bytes, the size of the
+ *     16 fp32 values they replace, so ldw (in 4-byte units) = K rounded up to 16
+ *     (vidtok_amd/packing.py::pack_split3).  Every other operator of a split-bf16 pass is the
+ *     VT_F32 one.
  */
 #ifndef VIDTOK_AMD_H
 #define VIDTOK_AMD_H
@@ -40,7 +50,7 @@ typedef enum vt_status {
   VT_ERR_UNSUPPORTED = -3
 } vt_status;
 
-typedef enum vt_dtype { VT_F32 = 0, VT_BF16 = 1, VT_I32 = 2 } vt_dtype;
+typedef enum vt_dtype { VT_F32 = 0, VT_BF16 = 1, VT_I32 = 2, VT_BF16X3 = 3 /* vt_conv arithmetic only, see below */ } vt_dtype;
 
 /* time-axis treatment of taps that fall before the first frame of the input */
 typedef enum vt_tmode {

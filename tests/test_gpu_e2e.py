@@ -24,6 +24,9 @@ DEV = "cuda"
 # accuracy in a kernel turns these red.  test_bf16_vs_autocast_oracle additionally pins the bf16 path to the
 # oracle run under torch.autocast(bfloat16) on the same GPU (the reference's own bf16 mode).
 BF16_RECON, BF16_Z, BF16_CODE_RATE = 5e-2, 2e-2, 0.9
+# split-bf16 mode ("bf16x3": fp32 storage, every convolution as three bf16 MFMAs per product, vt_conv VT_BF16X3): the fast
+# mode that has to stay inside the reference's fp32 tolerance -- gated like the fp32 kernels (1e-3; measured 1e-5 .. 4e-5)
+X3 = "bf16x3"
 
 
 @pytest.mark.parametrize("case", CASES, ids=[c["name"] for c in CASES])
@@ -40,7 +43,7 @@ def test_fp32_matches_reference_golden(case):
     if "indices" in gold:
         rate = (log["indices"].cpu() == gold["indices"]).float().mean().item()
         print(f"{case['name']}: FSQ code match rate {rate:.6f}")
-        assert log["indices"].dtype == torch.int32 and rate >= 0.999
+        assert log["indices"].dtype == torch.int32 and rate == 1.0
         dec2 = model.decode(log["indices"], decode_from_indices=True)
         assert torch.equal(dec2[:, :, -dec.shape[2]:], dec)       # decode(indices) == decode(z), bit for bit
         assert abs(float(log["aux_loss"]) - float(gold["aux_loss"])) < 1e-3
@@ -65,6 +68,13 @@ def _decode_err_on_oracle_codes(model, log2, dec2):
     # the other compression schedules of the reference's config set on the GPU --
     # 4x16x16 (ch_mult [1,2,4,4,4]), 2x8x8 (tempo_ds [1]), 4x4x4 (spatial_ds [1,2]), 8x8x8 v1.1 (tempo_ds [0,1,2]),
     # the other FSQ codebooks, the v1.1 variants un-tiled (reference configs/*.yaml:19-23)
+    ("vidtok_kl_causal_488_4chn", (2, 3, 17, 64, 64), X3, 1e-3),
+    ("vidtok_fsq_causal_488_32768", (1, 3, 17, 64, 64), X3, 1e-3),
+    ("vidtok_kl_causal_488_16chn", (1, 3, 9, 40, 24), X3, 1e-3),
+    ("vidtok_kl_noncausal_488_4chn", (1, 3, 16, 64, 64), X3, 1e-3),
+    ("vidtok_fsq_noncausal_41616_262144", (1, 3, 8, 64, 64), X3, 1e-3),
+    ("vidtok_v1_1/vidtok_fsq_causal_888_32768_v1_1", (1, 3, 17, 64, 64), X3, 1e-3),
+    ("vidtok_v1_1/vidtok_kl_causal_41616_16chn_v1_1", (1, 3, 9, 64, 64), X3, 1e-3),
     ("vidtok_kl_causal_41616_4chn", (1, 3, 9, 64, 64), torch.float32, 1e-3),
     ("vidtok_kl_causal_41616_4chn", (1, 3, 9, 64, 64), torch.bfloat16, BF16_RECON),
     ("vidtok_kl_causal_288_8chn", (2, 3, 9, 64, 48), torch.float32, 1e-3),
@@ -106,17 +116,19 @@ def test_matches_cpu_oracle(name, shape, dtype, tol):
         assert ed_codes < tol
     else:
         assert ed < tol
-    if "indices" not in log2 or dtype == torch.float32:
+    if "indices" not in log2 or dtype != torch.bfloat16:
         # (bf16 FSQ latents are code values: compared through the match rate below)
-        assert ez < (tol if dtype == torch.float32 else BF16_Z)
+        assert ez < (tol if dtype != torch.bfloat16 else BF16_Z)
     if "indices" in log2:
         rate = (log["indices"].cpu() == log2["indices"]).float().mean().item()
         print(f"{name} {dtype}: FSQ code match rate {rate:.5f} over {log2['indices'].numel()} tokens")
-        assert rate >= (0.999 if dtype == torch.float32 else BF16_CODE_RATE)
+        # fp32 kernels: every code (measured everywhere; north_star: bit-exact); split-bf16: these clips measure 1.0 too, the
+        # gate leaves room for one boundary case per thousand tokens
+        assert rate == 1.0 if dtype == torch.float32 else rate >= (0.999 if dtype == X3 else BF16_CODE_RATE)
         # the quantiser itself is exact: feeding the oracle's own pre-quantisation h gives its codes
         h = ora.pre_quant(x)
         _, qlog = model.regularization(h.to(DEV))
-        assert (qlog["indices"].cpu() != log2["indices"]).sum() <= 1
+        assert (qlog["indices"].cpu() != log2["indices"]).sum() == 0
 
 
 @pytest.mark.parametrize("name,shape", [("vidtok_kl_causal_488_4chn", (1, 3, 9, 32, 32)),
@@ -181,7 +193,7 @@ def test_v11_long_video_tiled_matches_oracle():
     assert dec.shape == x.shape and rel_err(z, z2) < 1e-3 and rel_err(dec, dec2) < 1e-3
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, X3], ids=["f32", "bf16", "bf16x3"])
 def test_full_size_properties(dtype):
     """BASELINE.json size (17x256x256): properties that need no oracle."""
     model, cfg, sd = build_model("vidtok_fsq_causal_488_32768", seed=23, device=DEV, dtype=dtype)
@@ -249,7 +261,7 @@ FULL = [("vidtok_kl_causal_488_4chn", (2, 3, 17, 256, 256)), ("vidtok_fsq_causal
         ("vidtok_kl_causal_488_16chn", (2, 3, 17, 256, 256))]
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, X3], ids=["f32", "bf16", "bf16x3"])
 @pytest.mark.parametrize("name,shape", FULL, ids=["kl_4chn_B2", "fsq_B1", "kl_16chn_B2"])
 def test_full_size_matches_cpu_oracle(name, shape, dtype):
     cfg, sd, x, (z2, dec2, log2) = _oracle_full(name, shape, 33)
@@ -259,7 +271,7 @@ def test_full_size_matches_cpu_oracle(name, shape, dtype):
     ez, ed = rel_err(z, z2), rel_err(dec, dec2)
     print(f"FULL {name} {shape} {dtype}: z rel {ez:.3e} dec rel {ed:.3e}")
     assert dec.shape == dec2.shape
-    if dtype == torch.float32:
+    if dtype != torch.bfloat16:
         assert ez < 1e-3 and ed < 1e-3
     elif "indices" in log2:
         ed_codes = _decode_err_on_oracle_codes(model, log2, dec2)   # see test_matches_cpu_oracle: gate on equal codes
@@ -272,11 +284,13 @@ def test_full_size_matches_cpu_oracle(name, shape, dtype):
         print(f"FULL {name} {dtype}: {n_bad} of {log2['indices'].numel()} FSQ codes differ")
         if dtype == torch.float32:
             assert n_bad == 0                      # bit-exact at the benchmarked size
+        elif dtype == X3:
+            assert n_bad <= 5                      # split-bf16: >= 99.9 % of the 5 120 codes (measured: 0 differ)
         else:
             assert n_bad <= (1 - BF16_CODE_RATE) * log2["indices"].numel()
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, X3], ids=["f32", "bf16", "bf16x3"])
 def test_full_size_v11_tiled_matches_cpu_oracle(dtype):
     """BASELINE.json configs[4] geometry (256x256 frames, t_chunk_enc=16, decoder look-ahead) on a 33-frame clip:
     cache-mode (pointer form) gathers, chunk caches and the trilinear up-sampler at full frame size vs the oracle --
@@ -290,7 +304,7 @@ def test_full_size_v11_tiled_matches_cpu_oracle(dtype):
     ez, ed = rel_err(z, z2), rel_err(dec, dec2)
     print(f"FULL v1.1 tiled T=33 256x256 {dtype}: z rel {ez:.3e} dec rel {ed:.3e}")
     assert dec.shape == x.shape
-    assert (ez < 1e-3 and ed < 1e-3) if dtype == torch.float32 else (ez < BF16_Z and ed < BF16_RECON)
+    assert (ez < 1e-3 and ed < 1e-3) if dtype != torch.bfloat16 else (ez < BF16_Z and ed < BF16_RECON)
 
 
 @pytest.mark.parametrize("name,shape", [("vidtok_kl_causal_488_4chn", (1, 3, 17, 128, 128)),
@@ -408,7 +422,7 @@ def test_rare_constructor_options_match_oracle(ov, T, dtype):
     ez, ed = rel_err(z, z2), rel_err(dec, dec2)
     print(f"{ov} {dtype}: z rel {ez:.2e} dec rel {ed:.2e}")
     assert dec.shape == dec2.shape
-    assert (ez < 1e-3 and ed < 1e-3) if dtype == torch.float32 else (ez < BF16_Z and ed < BF16_RECON)
+    assert (ez < 1e-3 and ed < 1e-3) if dtype != torch.bfloat16 else (ez < BF16_Z and ed < BF16_RECON)
 
 
 @pytest.mark.parametrize("name,shape", [("vidtok_kl_causal_488_4chn", (1, 3, 9, 64, 64)),

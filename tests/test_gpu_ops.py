@@ -11,12 +11,17 @@ from util import rel_err
 from vidtok_amd import lib as L
 from vidtok_amd import ops
 from vidtok_amd.ops import ConvGeom
-from vidtok_amd.packing import pack_conv_weight
+from vidtok_amd.packing import pack_conv_weight, pack_split3
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
-TOL = {torch.float32: 2e-5, torch.bfloat16: 1.2e-2}
+# "x3" = vt_conv's split-bf16 arithmetic (VT_BF16X3): fp32 tensors, weights as bf16 hi / lo planes, three bf16 MFMAs per
+# product -- checked against the same fp32 statement as the fp32 kernels (measured 2e-6 .. 6e-6 of the output's max norm)
+X3 = "x3"
+TOL = {torch.float32: 2e-5, torch.bfloat16: 1.2e-2, X3: 4e-5}
 DTYPES = [torch.float32, torch.bfloat16]
+DTYPES3 = DTYPES + [X3]
+IDS3 = ["f32", "bf16", "x3"]
 
 
 def _rand(shape, dtype, seed, scale=1.0):
@@ -94,7 +99,7 @@ CONV_CASES = [
 ]
 
 
-@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+@pytest.mark.parametrize("dtype", DTYPES3, ids=IDS3)
 @pytest.mark.parametrize("case", CONV_CASES, ids=[c[0] for c in CONV_CASES])
 def test_conv(case, dtype):
     _check_conv(case, dtype)
@@ -119,7 +124,7 @@ CONV_CASES_LARGE = [
 ]
 
 
-@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+@pytest.mark.parametrize("dtype", DTYPES3, ids=IDS3)
 @pytest.mark.parametrize("case", BIG256, ids=[c[0] for c in BIG256])
 def test_conv_forced_256_tile(case, dtype, vt_opts):
     vt_opts(conv_tile=256)
@@ -130,7 +135,7 @@ def test_conv_forced_256_tile(case, dtype, vt_opts):
         assert plan["ln_fused"] and plan["launches"] == 1       # conv_epilogue_lds256
 
 
-@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+@pytest.mark.parametrize("dtype", DTYPES3, ids=IDS3)
 @pytest.mark.parametrize("case", CONV_CASES_LARGE, ids=[c[0] for c in CONV_CASES_LARGE])
 def test_conv_large(case, dtype):
     plan = _check_conv(case, dtype)
@@ -335,7 +340,7 @@ POINTER_CASES = [c for c in CONV_CASES if c[0] in ("conv2d_3x3_256_128_res", "co
 
 
 @pytest.mark.parametrize("tile", ["", "256"])
-@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+@pytest.mark.parametrize("dtype", DTYPES3, ids=IDS3)
 @pytest.mark.parametrize("case", POINTER_CASES, ids=[c[0] for c in POINTER_CASES])
 def test_conv_pointer_gather(case, dtype, tile, vt_opts):
     """conv_buf = 0: the 64-bit pointer form of the gather (what tensors >= 4 GiB and v1.1 cache mode use)"""
@@ -366,6 +371,18 @@ def test_conv_8wave_schedules(case, sched, vt_opts):
     assert plan["tile"] == ((256, 256) if case[3] % 256 == 0 else (128, 128))
 
 
+@pytest.mark.parametrize("sched", [0, 2], ids=["plain_loop", "two_groups"])
+@pytest.mark.parametrize("case", SCHED_CASES + CONV_CASES_LARGE, ids=[c[0] for c in SCHED_CASES + CONV_CASES_LARGE])
+def test_conv_8wave_schedules_split_bf16(case, sched, vt_opts):
+    """split-bf16 arithmetic on the 8-wave tile (64-byte rows, 4-slot ring): schedule 3 (LOAD / COMPUTE phases, two wave
+    groups one barrier apart) and the plain K loop of the same instantiation"""
+    vt_opts(conv_sched=sched)
+    if case in SCHED_CASES:
+        vt_opts(conv_tile=256)
+    plan = _check_conv(case, X3)
+    assert plan["tile"] == ((256, 256) if case[3] % 256 == 0 else (128, 128))
+
+
 # Cache mode (v1.1 chunks after the first) gathers through buffer descriptors when a tile lies inside one output frame
 # (Ho * Wo % tile rows == 0: a time tap then reads the cache or x for the whole tile and the kernel switches the descriptor
 # per tap), through pointers otherwise.  Two clips (the cache's own batch stride), caches longer than the padding, a time
@@ -381,7 +398,7 @@ CACHE_BUF_CASES = [
 ]
 
 
-@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+@pytest.mark.parametrize("dtype", DTYPES3, ids=IDS3)
 @pytest.mark.parametrize("gather", ["descriptors", "descriptors_plain_loop", "pointers"])
 @pytest.mark.parametrize("case", CACHE_BUF_CASES, ids=[c[0] for c in CACHE_BUF_CASES])
 def test_conv_cache_mode_gather_forms(case, gather, dtype, vt_opts):
@@ -408,7 +425,7 @@ DEEP_CASES = [
 ]
 
 
-@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+@pytest.mark.parametrize("dtype", DTYPES3, ids=IDS3)
 @pytest.mark.parametrize("ring", ["deep", "deep_pointers", "two_slots"])
 @pytest.mark.parametrize("case", DEEP_CASES, ids=[c[0] for c in DEEP_CASES])
 def test_conv_128_tile_rings(case, ring, dtype, vt_opts):
@@ -436,7 +453,7 @@ LN256_CASES = [c for c in CONV_CASES if c[0] in ("conv2d_ln256_only", "conv2d_ln
               [c for c in CONV_CASES_LARGE if c[0] in ("L_conv2d_256_256_ln", "L_temporal_k3_256_ln_only")]
 
 
-@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+@pytest.mark.parametrize("dtype", DTYPES3, ids=IDS3)
 @pytest.mark.parametrize("mode", ["unfused", "fused_v0", "fused_v1"])
 @pytest.mark.parametrize("case", LN256_CASES, ids=[c[0] for c in LN256_CASES])
 def test_conv_ln256_variants(case, mode, dtype, vt_opts):
@@ -449,7 +466,7 @@ LDSEPI_CASES = [c for c in CONV_CASES if c[0] in ("conv2d_3x3_128_128", "conv2d_
                                                   "conv2d_ln_fused_res_keep", "temporal_ln_fused")]
 
 
-@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+@pytest.mark.parametrize("dtype", DTYPES3, ids=IDS3)
 @pytest.mark.parametrize("case", LDSEPI_CASES, ids=[c[0] for c in LDSEPI_CASES])
 def test_conv_without_lds_epilogue(case, dtype, vt_opts):
     vt_opts(conv_ldsepi=0, conv_ws=0)
@@ -459,11 +476,13 @@ def test_conv_without_lds_epilogue(case, dtype, vt_opts):
 
 def _check_conv(case, dtype):
     name, (B, T, H, W), cin, cout, kdims, geom, ex = case
+    mode, dtype = dtype, (torch.float32 if dtype == X3 else dtype)      # x3: fp32 tensors, split weight planes
     x = _act(B, T, H, W, cin, dtype, 1)
     g = torch.Generator().manual_seed(2)
     fan = cin * math.prod(kdims)
     wt = torch.randn((cout, cin) + tuple(kdims), generator=g) / math.sqrt(fan)
-    w = pack_conv_weight(wt, dtype, cin_stored=x.shape[-1]).to(DEV)
+    w_rows = pack_conv_weight(wt, dtype, cin_stored=x.shape[-1]).to(DEV)
+    w = pack_split3(w_rows) if mode == X3 else w_rows
     bias = None if ex.get("nobias") else _rand((cout,), torch.float32, 3, 0.1)
     kw = {}
     To, Ho, Wo = geom.out_dims(T, H, W)
@@ -489,25 +508,25 @@ def _check_conv(case, dtype):
         out = ops.conv(x, w, bias, geom, cout=cout, ln=(gam, bet, 1e-6, True), ln_keep_y=keep, **kw)
         rec, ops.CONV_RECORD = ops.CONV_RECORD, None
         torch.cuda.synchronize()
-        ref = R.conv(x.cpu(), w.cpu(), None if bias is None else bias.cpu(), geom, cout=cout, ln=(gam.cpu(), bet.cpu(), 1e-6, True),
+        ref = R.conv(x.cpu(), w_rows.cpu(), None if bias is None else bias.cpu(), geom, cout=cout, ln=(gam.cpu(), bet.cpu(), 1e-6, True),
                      ln_keep_y=keep, **_cpu(kw))
         outs, refs = (out if keep else (out,)), (ref if keep else (ref,))
         for o, r in zip(outs, refs):
             assert o.shape == r.shape and o.dtype == r.dtype and torch.isfinite(o.float()).all()
             e = rel_err(o, r)
             # the normalised output amplifies the bf16 rounding of y when the library normalises the stored y
-            assert e < 2 * TOL[dtype], f"{name} {dtype}: rel_err={e}"
+            assert e < 2 * TOL[mode], f"{name} {mode}: rel_err={e}"
         return ops.conv_plan(rec[0][0])
     ops.CONV_RECORD = []
     y = ops.conv(x, w, bias, geom, cout=cout, **kw)
     rec, ops.CONV_RECORD = ops.CONV_RECORD, None
     torch.cuda.synchronize()
-    yr = R.conv(x.cpu(), w.cpu(), None if bias is None else bias.cpu(), geom, cout=cout, **_cpu(kw))   # reference on the host
+    yr = R.conv(x.cpu(), w_rows.cpu(), None if bias is None else bias.cpu(), geom, cout=cout, **_cpu(kw))   # reference on the host
     assert y.shape == yr.shape and y.dtype == yr.dtype
     assert torch.isfinite(y.float()).all()
     e = rel_err(y, yr)
-    print(f"{name} {dtype}: rel_err={e:.3e}")
-    assert e < TOL[dtype], f"{name} {dtype}: rel_err={e}"
+    print(f"{name} {mode}: rel_err={e:.3e}")
+    assert e < TOL[mode], f"{name} {mode}: rel_err={e}"
     return ops.conv_plan(rec[0][0])
 
 

@@ -91,6 +91,44 @@ def test_other_causal_configs_match_oracle(name, shape, emulated_ops):
     assert rel_err(z, z2) < 2e-5 and rel_err(dec, dec2) < 5e-5
 
 
+def test_split_bf16_weight_planes_and_mode_plumbing(emulated_ops):
+    """"bf16x3": pack_split3's plane layout ([hi 16 | lo 16] bf16 per 16 k, K padded to 16, hi + lo within 2^-16 of w), and
+    set_compute_dtype("bf16x3") reaching every convolution's PackedCache (not the attention's W_v row operand) with fp32
+    storage -- the host graph in that mode stays within the fp32 tolerance of the oracle; switching back restores fp32 rows"""
+    from vidtok_amd.packing import PackedCache, pack_split3
+
+    w = torch.randn(5, 40)
+    p = pack_split3(w)
+    assert p.dtype == torch.float32 and p.shape == (5, 48) and p.vt_arith == "bf16x3"
+    planes = p.view(torch.bfloat16).reshape(5, 3, 2, 16)
+    hi, lo = planes[:, :, 0].reshape(5, 48).float(), planes[:, :, 1].reshape(5, 48).float()
+    assert torch.equal(hi[:, :40], w.to(torch.bfloat16).float()) and torch.equal(lo[:, :40], (w - hi[:, :40]).to(torch.bfloat16).float())
+    assert hi[:, 40:].abs().sum() == 0 and lo[:, 40:].abs().sum() == 0
+    assert ((hi + lo)[:, :40] - w).abs().max() <= w.abs().max() * 2.0 ** -16
+
+    for name, shape in (("vidtok_fsq_causal_488_32768", (1, 3, 5, 32, 32)), ("vidtok_kl_noncausal_488_4chn", (1, 3, 8, 32, 32)),
+                        ("vidtok_v1_1/vidtok_kl_causal_488_16chn_v1_1", (1, 3, 9, 32, 32))):
+        model, cfg, sd = build_model(name, seed=3, dtype="bf16x3")
+        assert model.arith == "bf16x3" and model.encoder.compute_dtype == torch.float32
+        caches = [v for m in model.modules() for v in m.__dict__.values() if isinstance(v, PackedCache)]
+        assert caches and all((c.arith == "bf16x3") != c.pin_native for c in caches) and any(c.pin_native for c in caches)
+        ora = build_oracle(cfg, sd)
+        x = torch.rand(*shape) * 2 - 1
+        torch.manual_seed(1)
+        z, dec, log = model(x)
+        torch.manual_seed(1)
+        z2, dec2, log2 = ora(x)
+        ez, ed = rel_err(z, z2), rel_err(dec, dec2)
+        assert ez < 1e-3 and ed < 1e-3 and (ez > 0 or "indices" in log2), (name, ez, ed)      # not bit-equal to fp32: the planes were used
+        if "indices" in log2:
+            assert torch.equal(log["indices"], log2["indices"])
+        model.set_compute_dtype(torch.float32)
+        assert all(c.arith is None for c in caches) and model.arith == "fp32"
+        torch.manual_seed(1)
+        z3, dec3, _ = model(x)
+        assert rel_err(dec3, dec2) < 5e-5
+
+
 @pytest.mark.parametrize("name,shape", [
     ("vidtok_kl_causal_488_4chn", (1, 3, 5, 32, 32)),
     ("vidtok_v1_1/vidtok_kl_causal_488_16chn_v1_1", (1, 3, 9, 32, 32)),

@@ -19,6 +19,29 @@ def _round_like(t, dtype):
     return t.to(dtype)
 
 
+def _conv_rows(x, w, bias, geom, cout, tmode, cache):
+    """the convolution proper on plain fp32 rows: padded NCTHW input, one F.conv3d"""
+    Cin = x.shape[-1]
+    xp = x.float().permute(0, 4, 1, 2, 3)  # NCTHW
+    if geom.ups_t:
+        xp = xp.repeat_interleave(2, dim=2)
+    if geom.ups_s:
+        xp = xp.repeat_interleave(2, dim=3).repeat_interleave(2, dim=4)
+    if geom.pt > 0:
+        if tmode == L.VT_TPAD_ZERO:
+            front = torch.zeros_like(xp[:, :, :1]).repeat(1, 1, geom.pt, 1, 1)
+        elif tmode == L.VT_TPAD_REPLICATE:
+            front = xp[:, :, :1].repeat(1, 1, geom.pt, 1, 1)
+        else:
+            assert not geom.ups_t and not geom.ups_s
+            front = cache.float().permute(0, 4, 1, 2, 3)[:, :, -geom.pt:]
+        xp = torch.cat([front, xp], dim=2)
+    xp = F.pad(xp, (geom.pw, geom.pw_hi, geom.ph, geom.ph_hi, 0, geom.pt_hi))
+    w5 = w.float().reshape(cout, geom.kt, geom.kh, geom.kw, Cin).permute(0, 4, 1, 2, 3)
+    y = F.conv3d(xp, w5, None if bias is None else bias.float()[:cout], stride=(geom.st, geom.sh, geom.sw))
+    return y
+
+
 def conv(x, w, bias, geom, *, cout, out_dtype=None, tmode=L.VT_TPAD_ZERO, cache=None, res=None,
          res_mode=L.VT_RES_NONE, res_tshift=0, mix_factor=None, out_layout=L.VT_NDHWC, t_trim=0, ldy=None,
          ln=None, ln_keep_y=True, out=None, ln_out=None, out_t=None, out_s=None):
@@ -39,23 +62,24 @@ def conv(x, w, bias, geom, *, cout, out_dtype=None, tmode=L.VT_TPAD_ZERO, cache=
         return (out, ln_out) if ln_keep_y else ln_out
     B, Ti, Hi, Wi, Cin = x.shape
     out_dtype = out_dtype or x.dtype
-    xp = x.float().permute(0, 4, 1, 2, 3)  # NCTHW
-    if geom.ups_t:
-        xp = xp.repeat_interleave(2, dim=2)
-    if geom.ups_s:
-        xp = xp.repeat_interleave(2, dim=3).repeat_interleave(2, dim=4)
-    if geom.pt > 0:
-        if tmode == L.VT_TPAD_ZERO:
-            front = torch.zeros_like(xp[:, :, :1]).repeat(1, 1, geom.pt, 1, 1)
-        elif tmode == L.VT_TPAD_REPLICATE:
-            front = xp[:, :, :1].repeat(1, 1, geom.pt, 1, 1)
-        else:
-            assert not geom.ups_t and not geom.ups_s
-            front = cache.float().permute(0, 4, 1, 2, 3)[:, :, -geom.pt:]
-        xp = torch.cat([front, xp], dim=2)
-    xp = F.pad(xp, (geom.pw, geom.pw_hi, geom.ph, geom.ph_hi, 0, geom.pt_hi))
-    w5 = w.float().reshape(cout, geom.kt, geom.kh, geom.kw, Cin).permute(0, 4, 1, 2, 3)
-    y = F.conv3d(xp, w5, None if bias is None else bias.float()[:cout], stride=(geom.st, geom.sh, geom.sw))
+    if getattr(w, "vt_arith", None) == "bf16x3":
+        # VT_BF16X3 (include/vidtok_amd.h): rows of [hi 16 x bf16 | lo 16 x bf16] per 16 k; in fp32 terms the contract is
+        # conv(x_lo, w_hi) + conv(x_hi, w_lo) + conv(x_hi, w_hi) with x_hi = bf16(x), x_lo = bf16(x - x_hi)
+        K = geom.kt * geom.kh * geom.kw * Cin
+        planes = w.contiguous().view(torch.bfloat16).reshape(cout, -1, 2, 16).float()
+        w_hi, w_lo = planes[:, :, 0].reshape(cout, -1)[:, :K], planes[:, :, 1].reshape(cout, -1)[:, :K]
+
+        def split(t):
+            if t is None:
+                return None, None
+            hi = t.to(torch.bfloat16).float()
+            return hi, (t.float() - hi).to(torch.bfloat16).float()
+
+        (x_hi, x_lo), (c_hi, c_lo) = split(x), split(cache)
+        y = _conv_rows(x_lo, w_hi, None, geom, cout, tmode, c_lo) + _conv_rows(x_hi, w_lo, None, geom, cout, tmode, c_hi)
+        y = y + _conv_rows(x_hi, w_hi, bias, geom, cout, tmode, c_hi)
+    else:
+        y = _conv_rows(x, w, bias, geom, cout, tmode, cache)
     To = y.shape[2]
     if res_mode != L.VT_RES_NONE:
         r = res.float().permute(0, 4, 1, 2, 3)[:, :cout]

@@ -72,6 +72,51 @@ struct ConvArgs {
   int prof_mode;               // PROF instantiation of conv_ws2.hip only: option ws_prof_mode
 };
 
+// Split-bf16 arithmetic (vt_dtype VT_BF16X3, "bf16x3"): fp32 STORAGE on both sides of the convolution, bf16 MATRIX cores
+// inside it.  An fp32 value v is carried as two bf16 planes, hi = bf16(v) (round to nearest even) and lo = bf16(v - hi):
+// hi + lo holds 16-17 significant bits of v, and a product x * w is taken as x_lo * w_hi + x_hi * w_lo + x_hi * w_hi on
+// v_mfma_f32_32x32x16_bf16 with fp32 accumulation (the x_lo * w_lo term, ~2^-18 relative, is dropped): three bf16 MFMAs
+// per 16 k-values = 96 matrix-pipe cycles against 512 for the eight v_mfma_f32_32x32x2_f32 of the fp32 mode.  The weights
+// are split once on the host (vidtok_amd/packing.py::pack_split3) and stored per row as blocks of 16 k-values,
+// [hi 16 x bf16 | lo 16 x bf16] = 64 bytes = the bytes of 16 fp32 values, so the staging code (element size 4, K step =
+// ROWB bytes of both operands) is the fp32 one; activations are split in registers right behind their fragment read.
+struct split3_t {
+  float v;
+};
+template <typename MT>
+struct is_split3 {
+  [[maybe_unused]] static constexpr bool value = false;
+};
+template <>
+struct is_split3<split3_t> {
+  [[maybe_unused]] static constexpr bool value = true;
+};
+// element type an MT tensor is stored in
+template <typename MT>
+struct storage_of {
+  typedef MT type;
+};
+template <>
+struct storage_of<split3_t> {
+  typedef float type;
+};
+
+// 8 consecutive fp32 k-values (two 16-byte fragment reads) -> their bf16 hi / lo fragments (element j in bits 16 (j & 1)
+// of word j >> 1: the order of the packed weight planes)
+__device__ __forceinline__ void split3_x(const u32x4& r0, const u32x4& r1, u32x4& hi, u32x4& lo) {
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const float f0 = __uint_as_float(e < 2 ? r0[2 * e] : r1[2 * e - 4]);
+    const float f1 = __uint_as_float(e < 2 ? r0[2 * e + 1] : r1[2 * e - 3]);
+    const uint32_t h = pack_bf16x2(f0, f1);
+    hi[e] = h;
+    lo[e] = pack_bf16x2(f0 - __uint_as_float(h << 16), f1 - __uint_as_float(h & 0xffff0000u));
+  }
+}
+__device__ __forceinline__ void mma_bf16(const u32x4& wfrag, const u32x4& xfrag, f32x16& acc) {
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wfrag), __builtin_bit_cast(bf16x8, xfrag), acc, 0, 0, 0);
+}
+
 template <typename MT>
 __device__ __forceinline__ void mma_step(const u32x4& wfrag, const u32x4& xfrag, f32x16& acc);
 

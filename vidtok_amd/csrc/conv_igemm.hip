@@ -557,6 +557,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_igemm_glds_ker
   constexpr int A_BYTES = BM * ROWB;
   constexpr int STAGE_BYTES = (BM + BN) * ROWB;
   constexpr int D = STAGES - 1;                     // prefetch distance
+  constexpr bool X3 = is_split3<MT>::value;         // split-bf16 arithmetic on fp32 storage (conv_common.h)
   static_assert(ROWB == 128 || ROWB == 64, "row bytes");
   static_assert(A_VECS >= 1 && B_VECS >= 1 && BM % RSTEP == 0 && BN % RSTEP == 0, "tile / workgroup mismatch");
   static_assert(D >= 1 && D <= 3 && (D - 1) * IPS <= 63, "pipeline depth");
@@ -884,6 +885,45 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_igemm_glds_ker
     constexpr bool FIRE = decltype(fire_tag)::value;
     const char* As = smem + stage * STAGE_BYTES + (wm * TM * 32) * ROWB + frag_row;
     const char* Bs = smem + stage * STAGE_BYTES + A_BYTES + (wn * TN * 32) * ROWB + frag_row;
+    if constexpr (X3) {
+      // a row holds ROWB / 64 groups of 16 k-values: x as 16 fp32 (chunks 4 kg .. 4 kg + 3; a lane's 8 values = chunks
+      // 4 kg + 2 khalf, + 1), w as [hi 16 x bf16 | lo 16 x bf16] (a lane's hi fragment = chunk 4 kg + khalf, lo = + 2)
+      constexpr int KG = ROWB / 64;
+      constexpr int NMX = KG * 3 * TM * TN;
+      constexpr int MPPX = (NMX + IPS - 1) / IPS;
+#pragma unroll
+      for (int kg = 0; kg < KG; ++kg) {
+        u32x4 whi[TN], wlo[TN], xhi[TM], xlo[TM];
+        const int sh = ((4 * kg + khalf) ^ swz) * 16, sl = ((4 * kg + 2 + khalf) ^ swz) * 16;
+        const int s0 = ((4 * kg + 2 * khalf) ^ swz) * 16, s1 = ((4 * kg + 2 * khalf + 1) ^ swz) * 16;
+#pragma unroll
+        for (int a = 0; a < TN; ++a) {
+          whi[a] = *reinterpret_cast<const u32x4*>(Bs + a * 32 * ROWB + sh);
+          wlo[a] = *reinterpret_cast<const u32x4*>(Bs + a * 32 * ROWB + sl);
+        }
+#pragma unroll
+        for (int b = 0; b < TM; ++b) {
+          const u32x4 r0 = *reinterpret_cast<const u32x4*>(As + b * 32 * ROWB + s0);
+          const u32x4 r1 = *reinterpret_cast<const u32x4*>(As + b * 32 * ROWB + s1);
+          split3_x(r0, r1, xhi[b], xlo[b]);
+        }
+#pragma unroll
+        for (int qq = 0; qq < 3 * TM * TN; ++qq) {       // small terms first: x_lo w_hi, x_hi w_lo, x_hi w_hi
+          const int pr = qq / (TM * TN), a = (qq / TM) % TN, b = qq % TM;
+          mma_bf16(pr == 1 ? wlo[a] : whi[a], pr == 0 ? xlo[b] : xhi[b], acc[a][b]);
+          const int q = kg * 3 * TM * TN + qq;
+          if (FIRE && (q + 1) % MPPX == 0) {
+            const int piece = q / MPPX;
+            if (piece < IPS && fire_rt) fire_piece(piece, dst);
+          }
+        }
+      }
+      if (FIRE && fire_rt) {
+#pragma unroll
+        for (int piece = NMX / MPPX; piece < IPS; ++piece) fire_piece(piece, dst);
+      }
+      return;
+    } else {
 #pragma unroll
     for (int k0 = 0; k0 < KS; k0 += KSB) {
       u32x4 wf[KSB][TN], xf[KSB][TM];
@@ -910,9 +950,12 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_igemm_glds_ker
 #pragma unroll
       for (int piece = FIRE_SPAN / MPP; piece < IPS; ++piece) fire_piece(piece, dst);
     }
+    }
   };
 
-  if constexpr (!S2) {
+  // SCHED 3: the two-group schedule of the split-bf16 arithmetic on the 8-wave tile (below)
+  constexpr bool S3 = SCHED == 3 && X3 && (WAVES_M * WAVES_N == 8) && FAST && BUF;
+  if constexpr (!S2 && !S3) {
 #pragma unroll
     for (int d = 0; d < D; ++d)
       if (d < p.nsteps) {
@@ -938,7 +981,84 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_igemm_glds_ker
       }
     }
   };
-  if constexpr (S2) {
+  if constexpr (S3) {
+    // Schedule 3: split-bf16 arithmetic (X3) on the 8-wave 256 x 256 tile.  A K step is ONE group of 16 k-values (rows of
+    // 64 bytes: 16 fp32 of a pixel / [hi | lo] bf16 planes of a weight row), the ring has four slots, and a wave alternates
+    //   LOAD(s)     12 fragment reads (x: 2 pixel sub-tiles x 2 chunks of fp32; w: 4 channel sub-tiles x (hi, lo)), the
+    //               addresses and the 4 DMA pieces of step s + 3, the split of the 32 fp32 values into bf16 hi / lo
+    //               fragments (~100 VALU) -- no MFMA
+    //   COMPUTE(s)  24 MFMAs (x_lo w_hi, x_hi w_lo, x_hi w_hi for the 8 accumulator tiles) = 768 matrix-pipe cycles
+    // with one barrier after each; waves 4-7 (the second wave of every SIMD) run one barrier behind waves 0-3, so a SIMD
+    // always has one wave feeding the matrix pipe while the other owns the remaining issue slots (the structure of
+    // schedule 2; with three MFMAs per fragment pair instead of one the LOAD phase fits under the partner's COMPUTE phase).
+    // Slot s & 3 is read in LOAD(s) by both groups (the later one before barrier 2 s + 2, reads retired by lgkmcnt(0) in
+    // front of it), so the pieces of step s + 3 = slot (s - 1) & 3 may go out in LOAD(s); a wave's pieces are issued
+    // 4 per step in step order, so "all but the youngest 8" = vmcnt(8) at the end of LOAD(s) says its pieces of step
+    // s + 1 have landed -- one barrier before anyone reads them, two steps after they were requested.
+    static_assert(ROWB == 64 && STAGES == 4 && TM == 2 && TN == 4 && A_VECS == 2 && B_VECS == 2, "schedule 3: 8-wave tile, 64-byte rows, 4 slots");
+    const int grp = __builtin_amdgcn_readfirstlane((int)(tid >> 8));     // 0: waves 0-3, 1: waves 4-7 (one barrier behind)
+    const char* a_base = smem + (wm * TM * 32) * ROWB + frag_row;
+    const char* b_base = smem + A_BYTES + (wn * TN * 32) * ROWB + frag_row;
+    const int sh = (khalf ^ swz) * 16, sl = ((2 + khalf) ^ swz) * 16;
+    const int s0 = ((2 * khalf) ^ swz) * 16, s1 = ((2 * khalf + 1) ^ swz) * 16;
+    u32x4 whi[TN], wlo[TN], xhi[TM], xlo[TM];
+    // prologue: steps 0, 1, 2 -- 12 pieces whatever nsteps is (pieces of steps that do not exist go out against extent 0)
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      if (d < p.nsteps) prep_step(d);
+      else ext_x = ext_w = 0u;
+#pragma unroll
+      for (int q = 0; q < IPS; ++q) fire_piece(q, d);
+    }
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    if (grp == 1) {
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    for (int s = 0; s < p.nsteps; ++s) {
+      const int stg = s & 3;
+      // ---- LOAD(s)
+      {
+        const char* As = a_base + stg * STAGE_BYTES;
+        const char* Bs = b_base + stg * STAGE_BYTES;
+        u32x4 r[TM][2];
+#pragma unroll
+        for (int b = 0; b < TM; ++b) {
+          r[b][0] = *reinterpret_cast<const u32x4*>(As + b * 32 * ROWB + s0);
+          r[b][1] = *reinterpret_cast<const u32x4*>(As + b * 32 * ROWB + s1);
+        }
+#pragma unroll
+        for (int a = 0; a < TN; ++a) {
+          whi[a] = *reinterpret_cast<const u32x4*>(Bs + a * 32 * ROWB + sh);
+          wlo[a] = *reinterpret_cast<const u32x4*>(Bs + a * 32 * ROWB + sl);
+        }
+        if (s + 3 < p.nsteps) prep_step(s + 3);
+        else ext_x = ext_w = 0u;                     // past the last step: the pieces below turn into zero fills
+#pragma unroll
+        for (int q = 0; q < IPS; ++q) fire_piece(q, (s + 3) & 3);
+#pragma unroll
+        for (int b = 0; b < TM; ++b) split3_x(r[b][0], r[b][1], xhi[b], xlo[b]);
+      }
+      asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      // ---- COMPUTE(s): 24 MFMAs, nothing else
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int qq = 0; qq < 3 * TM * TN; ++qq) {
+        const int pr = qq / (TM * TN), a = (qq / TM) % TN, b = qq % TM;
+        mma_bf16(pr == 1 ? wlo[a] : whi[a], pr == 0 ? xlo[b] : xhi[b], acc[a][b]);
+      }
+      __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (!(grp == 1 && s + 1 == p.nsteps)) {      // waves 4-7 entered one barrier late: they leave without the last one
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  } else if constexpr (S2) {
     // Schedule 2, "ping-pong" (the structure of the guide's 256 x 256 template, adapted to the gather).
     // What the stamps of schedule 1 show (profiles/r02_igemm_step_cycles_sched1.txt): the two waves of a SIMD run the same
     // mixed stream of fragment reads, DMA pieces and MFMAs side by side, the older one wins every arbitration, finishes
@@ -1168,7 +1288,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_igemm_glds_ker
     }
   }
   if constexpr (LN256 != 0) {
-    static_assert(WAVES_M == 4 && WAVES_N == 2 && TM == 2 && TN == 4 && std::is_same<MT, TOut>::value, "LN256: the 8-wave 256 x 256 tile");
+    static_assert(WAVES_M == 4 && WAVES_N == 2 && TM == 2 && TN == 4 && std::is_same<typename storage_of<MT>::type, TOut>::value, "LN256: the 8-wave 256 x 256 tile");
     if constexpr (!BUF) wait_vmcnt<0>();
     if constexpr (LN256 == 2) conv_epilogue_lds256_v1<TOut>(p, acc, m_blk, n_blk, wm, wn, lane, tid, smem, z);
     else conv_epilogue_lds256<TOut>(p, acc, m_blk, wm, wn, lane, tid, smem, z);
@@ -1195,9 +1315,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_igemm_glds_ker
 inline bool conv_buf() { return vt_opt(OPT_CONV_BUF) != 0; }
 inline bool conv_tinner() { return vt_opt(OPT_CONV_TINNER) != 0; }
 
-template <typename MT, typename TOut, int WAVES_M, int WAVES_N, int TM, int TN, bool FAST, int LN256 = 0, int STAGES = 2>
+template <typename MT, typename TOut, int WAVES_M, int WAVES_N, int TM, int TN, bool FAST, int LN256 = 0, int STAGES = 2, int ROWB = kRowBytes>
 int launch_variant(const ConvArgs& a_in, int nbatch, hipStream_t stream) {
-  constexpr int ROWB = kRowBytes;
   constexpr int BM = WAVES_M * TM * 32;
   constexpr int BN = WAVES_N * TN * 32;
   constexpr int BK = ROWB / (int)sizeof(MT);
@@ -1229,11 +1348,13 @@ int launch_variant(const ConvArgs& a_in, int nbatch, hipStream_t stream) {
                    a.KH <= 8 && a.KW <= 8;   // the per-row padding mask of the FAST form holds 8 bits per axis
   const void* kern;
   // option conv_sched: 0 = the plain K-step loop of the 8-wave tile, 1 = schedule 1, 2 (default) = ping-pong; see the kernel
-  constexpr bool HAS_S1 = WAVES_M * WAVES_N == 8 && FAST;
+  constexpr bool HAS_S1 = WAVES_M * WAVES_N == 8 && FAST && !is_split3<MT>::value && ROWB == kRowBytes && STAGES == 2;
   constexpr bool HAS_S2 = HAS_S1 && std::is_same<MT, bf16_t>::value;    // schedule 2 (ping-pong): bf16 operands only
+  constexpr bool HAS_S3 = WAVES_M * WAVES_N == 8 && FAST && is_split3<MT>::value && ROWB == 64 && STAGES == 4;   // schedule 3: split-bf16
   const int sched_opt = vt_opt(OPT_CONV_SCHED);
   const bool s2 = HAS_S2 && buf && sched_opt >= 2;
   const bool s1 = HAS_S1 && buf && sched_opt != 0 && !s2;
+  const bool s3 = HAS_S3 && buf && sched_opt != 0;
   if (buf) {
     a.x_bytes = (unsigned)xb;
     a.w_bytes = (unsigned)wb;
@@ -1244,6 +1365,9 @@ int launch_variant(const ConvArgs& a_in, int nbatch, hipStream_t stream) {
     }
     if constexpr (HAS_S2) {
       if (s2) kern = reinterpret_cast<const void*>(&conv_igemm_glds_kernel<MT, TOut, WAVES_M, WAVES_N, TM, TN, FAST, ROWB, STAGES, true, LN256, false, 2>);
+    }
+    if constexpr (HAS_S3) {
+      if (s3) kern = reinterpret_cast<const void*>(&conv_igemm_glds_kernel<MT, TOut, WAVES_M, WAVES_N, TM, TN, FAST, ROWB, STAGES, true, LN256, false, 3>);
     }
   } else {
     kern = reinterpret_cast<const void*>(&conv_igemm_glds_kernel<MT, TOut, WAVES_M, WAVES_N, TM, TN, FAST, ROWB, STAGES, false, LN256>);
@@ -1263,7 +1387,7 @@ int launch_variant(const ConvArgs& a_in, int nbatch, hipStream_t stream) {
   }
   // the attribute is per device: one flag per (instantiation, gather form, device), set race-free
   static std::atomic<bool> attr_done[4][kMaxDevices];
-  const int ki = buf ? (s2 ? 3 : (s1 ? 2 : 1)) : 0;
+  const int ki = buf ? ((s2 || s3) ? 3 : (s1 ? 2 : 1)) : 0;
   int dev = 0;
   VT_CHECK_HIP(hipGetDevice(&dev));
   if (dev < 0 || dev >= kMaxDevices || !attr_done[ki][dev].load(std::memory_order_acquire)) {
@@ -1379,7 +1503,14 @@ int dispatch_tile(const ConvArgs& a, int nbatch, hipStream_t stream) {
     case TILE_256x32: return launch_fast_or_general<MT, TOut, 4, 1, 2, 1>(a, nbatch, stream);
     case TILE_256x64: return launch_fast_or_general<MT, TOut, 4, 1, 2, 2>(a, nbatch, stream);
     case TILE_256x256:                                                                           // 8 waves
-      if constexpr (std::is_same<MT, TOut>::value) {
+      if constexpr (is_split3<MT>::value) {
+        // split-bf16: 64-byte rows (one group of 16 k-values per K step) on a 4-slot ring, schedule 3
+        if (a.Cin % 16 == 0) {
+          if (a.ln_mode != 0) return launch_variant<MT, TOut, 4, 2, 2, 4, true, 1, 4, 64>(a, nbatch, stream);
+          return launch_variant<MT, TOut, 4, 2, 2, 4, true, 0, 4, 64>(a, nbatch, stream);
+        }
+        return launch_variant<MT, TOut, 4, 2, 2, 4, false>(a, nbatch, stream);
+      } else if constexpr (std::is_same<MT, TOut>::value) {
         if (a.ln_mode != 0) {                                                                     // conv_prepare checked Cin % BK
           if constexpr (std::is_same<TOut, bf16_t>::value) {
             if (vt_opt(OPT_CONV_LN256_V) != 0) return launch_variant<MT, TOut, 4, 2, 2, 4, true, 2>(a, nbatch, stream);
@@ -1413,10 +1544,13 @@ namespace {
 int conv_prepare(const vt_conv_desc* d, ConvArgs& a, bool& ln_fused, int& nbatch_out, bool& use_ws) {
   VT_CHECK_ARG(d != nullptr, "vt_conv: null descriptor");
   VT_CHECK_ARG(d->x && d->w && d->y, "vt_conv: null tensor pointer");
-  VT_CHECK_ARG(d->dtype == VT_F32 || d->dtype == VT_BF16, "vt_conv: dtype %d", d->dtype);
-  VT_CHECK_ARG(d->out_dtype == d->dtype || d->out_dtype == VT_F32, "vt_conv: out_dtype %d with dtype %d",
+  VT_CHECK_ARG(d->dtype == VT_F32 || d->dtype == VT_BF16 || d->dtype == VT_BF16X3, "vt_conv: dtype %d", d->dtype);
+  VT_CHECK_ARG((d->out_dtype == d->dtype && d->dtype != VT_BF16X3) || d->out_dtype == VT_F32, "vt_conv: out_dtype %d with dtype %d",
                d->out_dtype, d->dtype);
-  const int vec = d->dtype == VT_F32 ? 4 : 8;
+  const int vec = d->dtype == VT_BF16 ? 8 : 4;
+  if (d->dtype == VT_BF16X3)    // split weight planes: [hi 16 x bf16 | lo 16 x bf16] per 16 k-values, K padded to the block
+    VT_CHECK_ARG(d->ldw % 16 == 0 && d->ldw >= (d->KT * d->KH * d->KW * d->Cin + 15) / 16 * 16 && d->nbatch <= 1,
+                 "vt_conv: VT_BF16X3 needs ldw = K rounded up to 16 (got %d) and nbatch 1", d->ldw);
   VT_CHECK_ARG(d->B > 0 && d->Ti > 0 && d->Hi > 0 && d->Wi > 0 && d->Cin > 0, "vt_conv: bad input dims");
   VT_CHECK_ARG(d->To > 0 && d->Ho > 0 && d->Wo > 0 && d->Cout > 0, "vt_conv: bad output dims");
   VT_CHECK_ARG(d->Cin % vec == 0, "vt_conv: Cin=%d must be a multiple of %d (pad the channel dim)", d->Cin, vec);
@@ -1495,8 +1629,8 @@ int conv_prepare(const vt_conv_desc* d, ConvArgs& a, bool& ln_fused, int& nbatch
                         (d->res_mode == VT_RES_NONE || (d->ldr & 7) == 0) && vt_opt(OPT_CONV_LDSEPI) != 0 &&
                         vt_opt(OPT_CONV_FUSE_LN) != 0));
   // ... or inside the 8-wave 256 x 256 tile's epilogue for Cout = 256 (conv_epilogue_lds256): full tiles, plain rows
-  if (d->ln_mode != 0 && !ln_fused && d->Cout == 256 && M % 256 == 0 && d->dtype == d->out_dtype && nbatch == 1 &&
-      d->Cin % (kRowBytes / (d->dtype == VT_F32 ? 4 : 2)) == 0 && (d->ldy & 3) == 0 && (d->ldn & 3) == 0 &&
+  if (d->ln_mode != 0 && !ln_fused && d->Cout == 256 && M % 256 == 0 && (d->dtype == VT_BF16X3 ? VT_F32 : d->dtype) == d->out_dtype && nbatch == 1 &&
+      d->Cin % (kRowBytes / (d->dtype == VT_BF16 ? 2 : 4)) == 0 && (d->ldy & 3) == 0 && (d->ldn & 3) == 0 &&
       (d->res_mode == VT_RES_NONE || (d->res_mode == VT_RES_ADD && (d->ldr & 3) == 0 && d->Tr == d->To && d->res_tshift == 0)) &&
       vt_opt(OPT_CONV_FUSE_LN256) != 0 && select_tile(a, nbatch) == TILE_256x256)
     ln_fused = true;
@@ -1546,7 +1680,7 @@ extern "C" int vt_conv_plan(const vt_conv_desc* d, int32_t* out8) {
   out8[5] = (d->ln_mode != 0 && !ln_fused) ? 2 : 1;
   // epilogue through the LDS (rows of 16-byte accesses) instead of the MFMA-layout vector epilogue
   if (k == TILE_256x256) out8[7] = (ln_fused || lds256_plain_eligible(a, nbatch, d->dtype == VT_BF16 && d->out_dtype == VT_BF16)) ? 1 : 0;
-  if (k == TILE_128x128 && deep_ring_eligible(a, nbatch, d->dtype == VT_F32 ? 4 : 2)) out8[7] = 2;   // 4-slot ring
+  if (k == TILE_128x128 && deep_ring_eligible(a, nbatch, d->dtype == VT_BF16 ? 2 : 4)) out8[7] = 2;   // 4-slot ring
   return VT_OK;
 }
 
@@ -1579,6 +1713,7 @@ extern "C" int vt_conv(const vt_conv_desc* d, vt_stream stream_) {
   if (narrow_eligible(a, nbatch, d->dtype, d->out_dtype, d->ln_mode)) return vt_conv_narrow_launch(&a, stream_);
   const long long M = a.M;
   if (d->dtype == VT_F32) rc = dispatch_tile<float, float>(a, nbatch, stream);
+  else if (d->dtype == VT_BF16X3) rc = dispatch_tile<split3_t, float>(a, nbatch, stream);
   else if (d->out_dtype == VT_F32) rc = dispatch_tile<bf16_t, float>(a, nbatch, stream);
   else rc = dispatch_tile<bf16_t, bf16_t>(a, nbatch, stream);
   if (rc != VT_OK || d->ln_mode == 0 || ln_fused) return rc;

@@ -12,7 +12,7 @@ from typing import Any, Dict, Optional, Tuple, Union
 import torch
 import torch.nn as nn
 
-from . import ops
+from . import ops, packing
 from .config import instantiate_from_config
 from .graphs import GraphedCall
 
@@ -64,13 +64,21 @@ class AutoencodingEngine(nn.Module):
             self.init_from_ckpt(ckpt_path, ignore_keys=ignore_keys, verbose=verbose)
 
     # ---- numeric mode ---------------------------------------------------------------------------
-    def set_compute_dtype(self, dtype: torch.dtype, encoder_tail: Optional[torch.dtype] = None, tail_level: Optional[int] = None):
+    def set_compute_dtype(self, dtype, encoder_tail: Optional[torch.dtype] = None, tail_level: Optional[int] = None):
         """torch.float32: fp32 storage + fp32-input MFMA (parity mode); torch.bfloat16: bf16 storage +
-        bf16 MFMA with fp32 accumulation (throughput mode, the reference's autocast analogue).
+        bf16 MFMA with fp32 accumulation (throughput mode, the reference's autocast analogue); "bf16x3": fp32 storage,
+        every convolution on the bf16 matrix cores from bf16 hi / lo planes of both operands (vt_conv VT_BF16X3: three
+        MFMAs per product, ~2^-17 relative per product) -- the fast mode that stays inside the reference's fp32 tolerance;
+        `self.arith` says which ("fp32" | "bf16" | "bf16x3").
         `encoder_tail` (causal encoders): the encoder levels from `tail_level` on (default: the last level), its mid section
         and conv_out run in that type instead -- the small deep layers, whose rounding decides most of the FSQ code flips
         of a bf16 pass, in fp32 while the wide levels stay on the bf16 kernels."""
+        split3 = dtype == packing.ARITH_SPLIT3
+        if split3:
+            dtype = torch.float32
         assert dtype in (torch.float32, torch.bfloat16) and encoder_tail in (None, torch.float32, torch.bfloat16)
+        packing.set_arith(self, packing.ARITH_SPLIT3 if split3 else None)
+        self.arith = packing.ARITH_SPLIT3 if split3 else ("fp32" if dtype == torch.float32 else "bf16")
         self.encoder.compute_dtype = dtype
         self.decoder.compute_dtype = dtype
         if hasattr(self.encoder, "tail_dtype"):
@@ -135,10 +143,11 @@ class AutoencodingEngine(nn.Module):
             m.causal_cache = c
 
     def _run_encoder(self, x):
-        return self._genc(x, (self.encoder.compute_dtype,)) if self.use_graphs else self.encoder(x)
+        key = (self.encoder.compute_dtype, getattr(self, "arith", None), getattr(self.encoder, "tail_dtype", None), getattr(self.encoder, "tail_level", None))
+        return self._genc(x, key) if self.use_graphs else self.encoder(x)
 
     def _run_decoder(self, z):
-        return self._gdec(z, (self.decoder.compute_dtype,)) if self.use_graphs else self.decoder(z)
+        return self._gdec(z, (self.decoder.compute_dtype, getattr(self, "arith", None))) if self.use_graphs else self.decoder(z)
 
     # ---- checkpoints (autoencoder.py:146-176) ---------------------------------------------------
     def init_from_ckpt(self, path: str, ignore_keys=tuple(), verbose: bool = True) -> None:
@@ -277,7 +286,8 @@ class AutoencodingEngineV11(AutoencodingEngine):
         if not (self.use_graphs and x.is_cuda):
             return module(self._chunk_of(x, start, end))
         sig = tuple(0 if c is None else c.shape[1] for _, c in self._chunk_state(module))
-        key = (module.compute_dtype, "chunk", bool(first), bool(self.use_overlap), sig)
+        key = (module.compute_dtype, getattr(self, "arith", None), getattr(module, "tail_dtype", None), getattr(module, "tail_level", None),
+               "chunk", bool(first), bool(self.use_overlap), sig)
         return graphed(x, key, stateful=True, frames=(start, end), borrow=True)
 
     def tile_encode(self, x: Any) -> Any:

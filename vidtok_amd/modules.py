@@ -585,6 +585,7 @@ class AttnBlockWrapper(nn.Module):
         self.k = CausalConv3d(in_channels, in_channels, 1, version=version)
         self.v = CausalConv3d(in_channels, in_channels, 1, version=version)
         self.proj_out = CausalConv3d(in_channels, in_channels, 1, version=version)
+        self._v_rows = PackedCache(pin_native=True)     # W_v as the ROW operand of a GEMM against activations: plain rows in every mode
 
     def first_norm(self):
         return (self.norm, False)
@@ -596,7 +597,7 @@ class AttnBlockWrapper(nn.Module):
         S, Z = H * W, B * T
         q = self.q.run(hn, dt).view(Z, S, Cc)
         k = self.k.run(hn, dt).view(Z, S, Cc)
-        wv, bv = self.v._pack.get(self.v.conv.weight, self.v.conv.bias, dt, cin_stored=Cc)
+        wv, bv = self._v_rows.get(self.v.conv.weight, self.v.conv.bias, dt, cin_stored=Cc)
         Sp = ops.pad_channels(S)        # K-contiguous operands need 16-byte rows: pad S with zero columns
         vT = ops.gemm_nt(wv.view(1, Cc, Cc), hn.view(Z, S, Cc), ld_out=Sp)                     # [Z, C, Sp]
         s = ops.gemm_nt(q, k, out_dtype=torch.float32)                                         # [Z, S, S]

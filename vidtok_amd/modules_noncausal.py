@@ -153,7 +153,7 @@ class AttnBlockWrapper(nn.Module):
         self.k = nn.Conv3d(in_channels, in_channels, kernel_size=1, stride=1, padding=0)
         self.v = nn.Conv3d(in_channels, in_channels, kernel_size=1, stride=1, padding=0)
         self.proj_out = nn.Conv3d(in_channels, in_channels, kernel_size=1, stride=1, padding=0)
-        self._pq, self._pk, self._pv, self._po = PackedCache(), PackedCache(), PackedCache(), PackedCache()
+        self._pq, self._pk, self._pv, self._po = PackedCache(), PackedCache(), PackedCache(pin_native=True), PackedCache()
 
     def first_norm(self):
         return (self.norm, False)

@@ -142,6 +142,8 @@ def conv(x, w, bias, geom: ConvGeom, *, cout: int, out_dtype=None, tmode=L.VT_TP
     d.B, d.Ti, d.Hi, d.Wi, d.Cin = B, Ti, Hi, Wi, Cin
     d.To, d.Ho, d.Wo, d.Cout = To, Ho, Wo, cout
     d.ldw, d.ldy = w.shape[1], ldy
+    x3 = getattr(w, "vt_arith", None) == "bf16x3"       # split-bf16 weight planes (packing.pack_split3): fp32 storage, bf16 MFMA
+    assert not x3 or (x.dtype == torch.float32 and out_dtype == torch.float32)
     d.KT, d.KH, d.KW = geom.kt, geom.kh, geom.kw
     d.st, d.sh, d.sw = geom.st, geom.sh, geom.sw
     d.pt, d.ph, d.pw = geom.pt, geom.ph, geom.pw
@@ -161,7 +163,7 @@ def conv(x, w, bias, geom: ConvGeom, *, cout: int, out_dtype=None, tmode=L.VT_TP
             assert mix_factor is not None and mix_factor.dtype == torch.float32 and mix_factor.is_cuda
             d.mix_factor = mix_factor.data_ptr()
     d.out_layout, d.t_trim = out_layout, t_trim
-    d.dtype, d.out_dtype = _DT[x.dtype], _DT[out_dtype]
+    d.dtype, d.out_dtype = (L.VT_BF16X3 if x3 else _DT[x.dtype]), _DT[out_dtype]
     d.nbatch = 1
     d.yt_mul, d.yt_off = mul, off
     if out_s is not None:
@@ -309,7 +311,7 @@ def launch_bytes(d):
         es = 2
         px = d.B * d.T * d.HW
         return px * d.ld * es * (1 + (1 if d.keep_y else 0) + (1 if d.ln_next_mode else 0)) + 2 * d.C * 3 * d.C * es
-    es = 4 if d.dtype == L.VT_F32 else 2
+    es = 2 if d.dtype == L.VT_BF16 else 4
     eo = 4 if d.out_dtype == L.VT_F32 else 2
     nb = max(1, d.nbatch)
     M = d.B * d.To * d.Ho * d.Wo * nb

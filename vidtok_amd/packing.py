@@ -25,6 +25,47 @@ def pack_conv_weight(weight: torch.Tensor, dtype: torch.dtype, cin_stored: int =
     return w.reshape(cout, -1).to(dtype).contiguous()
 
 
+ARITH_SPLIT3 = "bf16x3"
+
+
+def pack_split3(w2d: torch.Tensor) -> torch.Tensor:
+    """Packed fp32 rows [Cout, K] -> the operand of vt_conv's VT_BF16X3 arithmetic (include/vidtok_amd.h): every value as
+    two bf16 planes, hi = bf16(w) (round to nearest even) and lo = bf16(w - hi), stored per group of 16 k as
+    [hi 16 x bf16 | lo 16 x bf16] (64 bytes, the size of the 16 fp32 values they replace), K zero-padded to the group.
+    Returned as a float32-typed container [Cout, K16] (ldw = K16) tagged `vt_arith`; data movement + two roundings."""
+    cout, K = w2d.shape
+    Kp = (K + 15) // 16 * 16
+    w = w2d.detach().to(torch.float32)
+    if Kp != K:
+        w = torch.nn.functional.pad(w, (0, Kp - K))
+    hi = w.to(torch.bfloat16)
+    lo = (w - hi.to(torch.float32)).to(torch.bfloat16)
+    planes = torch.stack([hi.view(cout, Kp // 16, 16), lo.view(cout, Kp // 16, 16)], dim=2).contiguous()   # [Cout, K/16, 2, 16]
+    out = planes.view(torch.float32).reshape(cout, Kp)
+    out.vt_arith = ARITH_SPLIT3
+    return out
+
+
+def set_arith(root: torch.nn.Module, arith):
+    """Select the weight arithmetic of every convolution under `root` for fp32 storage: None = fp32 rows (fp32 MFMA),
+    ARITH_SPLIT3 = split-bf16 planes (three bf16 MFMAs per product).  Visits the PackedCache objects the modules hold
+    (directly or inside tuples / lists); caches created with pin_native=True (operands of an activation x activation GEMM)
+    keep fp32 rows."""
+    assert arith in (None, ARITH_SPLIT3)
+
+    def visit(v):
+        if isinstance(v, PackedCache):
+            if not v.pin_native:
+                v.arith = arith
+        elif isinstance(v, (tuple, list)):
+            for e in v:
+                visit(e)
+
+    for m in root.modules():
+        for v in m.__dict__.values():
+            visit(v)
+
+
 def time_upsample_parity_weights(weight: torch.Tensor, early: bool):
     """A k=3 temporal conv over a nearest-x2 frame-repeated input u[t] = x[t >> 1] touches only two input frames per
     output frame, so it equals a k=2 conv over x with pre-summed taps (fp32 sums, rounded once when packed):
@@ -54,16 +95,21 @@ class PackedCache:
     """Caches the packed weight / fp32 bias of one conv-like parameter holder.  `transform` (optional) maps the
     parameter tensor to the tensor that is packed (e.g. the parity weights of a time up-sampler)."""
 
-    def __init__(self, transform=None):
+    def __init__(self, transform=None, pin_native=False):
         self._key = None
         self._val = None
         self._transform = transform
+        self.arith = None            # set_arith(): ARITH_SPLIT3 = fp32 requests are answered with split-bf16 planes
+        self.pin_native = pin_native
 
     def get(self, weight: torch.nn.Parameter, bias, dtype, cin_stored=None):
+        arith = self.arith if dtype == torch.float32 else None
         key = (dtype, weight.device, weight._version, None if bias is None else bias._version, cin_stored,
-               weight.data_ptr())
+               weight.data_ptr(), arith)
         if key != self._key:
             w = pack_conv_weight(weight if self._transform is None else self._transform(weight), dtype, cin_stored)
+            if arith == ARITH_SPLIT3:
+                w = pack_split3(w)
             b = None if bias is None else bias.detach().to(torch.float32).contiguous()
             self._key, self._val = key, (w, b)
         return self._val
