@@ -27,7 +27,8 @@
  *     VT_F32).  Activations are split inside the kernel; the WEIGHTS are handed over already
  *     split: row n of `w` holds, per group of 16 consecutive k, 16 bf16 hi values followed by
  *     16 bf16 lo values (hi = bf16_rne(w), lo = bf16_rne(w - hi)) -- 64 bytes, the size of the
- *     16 fp32 values they replace, so ldw (in 4-byte units) = K rounded up to 16
+ *     16 fp32 values they replace; rows are zero-padded to whole 128-byte K steps, so ldw (in
+ *     4-byte units) = K rounded up to 32
  *     (vidtok_amd/packing.py::pack_split3).  Every other operator of a split-bf16 pass is the
  *     VT_F32 one.
  */
@@ -94,6 +95,9 @@ int vt_conv_max_lds_bytes(void);
  *   conv_fuse_ln (1), conv_fuse_ln256 (1)   LayerNorm of the result inside the epilogue for Cout = 128 / 256
  *   conv_ln256_v (1)    form of the Cout = 256 LayerNorm epilogue (0: round-2 form)
  *   conv_deep (1)       128 x 128 tile on a 4-slot ring (three K steps of DMA in flight) for launches with no more tiles than CUs
+ *   conv_sched_x3 (3)   K-step schedule of the 8-wave tile under VT_BF16X3 (64-byte rows, 4-slot ring): 0 plain loop, 1 / 2 / 3 two
+ *                       wave groups alternating LOAD and COMPUTE phases with the DMA pieces of a step issued in the LOAD phase /
+ *                       between the MFMAs of the COMPUTE phase / half and half
  *   ws_acc (0), tblock_prof_mode (0), ws_prof_mode (0)   measurement aids
  *   tblock_fused (1)   0: vt_temporal_block_supported answers no (blocks stay on the unfused operators)
  * Returns VT_ERR_ARG for an unknown name.

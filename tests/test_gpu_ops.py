@@ -371,12 +371,12 @@ def test_conv_8wave_schedules(case, sched, vt_opts):
     assert plan["tile"] == ((256, 256) if case[3] % 256 == 0 else (128, 128))
 
 
-@pytest.mark.parametrize("sched", [0, 2], ids=["plain_loop", "two_groups"])
+@pytest.mark.parametrize("sched", [0, 1, 2, 3], ids=["plain_loop", "two_groups_dma_in_load", "two_groups_dma_in_compute", "two_groups_dma_split"])
 @pytest.mark.parametrize("case", SCHED_CASES + CONV_CASES_LARGE, ids=[c[0] for c in SCHED_CASES + CONV_CASES_LARGE])
 def test_conv_8wave_schedules_split_bf16(case, sched, vt_opts):
     """split-bf16 arithmetic on the 8-wave tile (64-byte rows, 4-slot ring): schedule 3 (LOAD / COMPUTE phases, two wave
     groups one barrier apart) and the plain K loop of the same instantiation"""
-    vt_opts(conv_sched=sched)
+    vt_opts(conv_sched_x3=sched)
     if case in SCHED_CASES:
         vt_opts(conv_tile=256)
     plan = _check_conv(case, X3)
@@ -403,6 +403,8 @@ CACHE_BUF_CASES = [
 @pytest.mark.parametrize("case", CACHE_BUF_CASES, ids=[c[0] for c in CACHE_BUF_CASES])
 def test_conv_cache_mode_gather_forms(case, gather, dtype, vt_opts):
     vt_opts(conv_buf=(0 if gather == "pointers" else 1), conv_sched=(0 if gather == "descriptors_plain_loop" else 2))
+    if gather == "descriptors_plain_loop":
+        vt_opts(conv_sched_x3=0)
     if case[3] % 256 == 0:
         vt_opts(conv_tile=256)
     plan = _check_conv(case, dtype)

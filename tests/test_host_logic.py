@@ -92,16 +92,16 @@ def test_other_causal_configs_match_oracle(name, shape, emulated_ops):
 
 
 def test_split_bf16_weight_planes_and_mode_plumbing(emulated_ops):
-    """"bf16x3": pack_split3's plane layout ([hi 16 | lo 16] bf16 per 16 k, K padded to 16, hi + lo within 2^-16 of w), and
+    """"bf16x3": pack_split3's plane layout ([hi 16 | lo 16] bf16 per 16 k, K padded to 32, hi + lo within 2^-16 of w), and
     set_compute_dtype("bf16x3") reaching every convolution's PackedCache (not the attention's W_v row operand) with fp32
     storage -- the host graph in that mode stays within the fp32 tolerance of the oracle; switching back restores fp32 rows"""
     from vidtok_amd.packing import PackedCache, pack_split3
 
     w = torch.randn(5, 40)
     p = pack_split3(w)
-    assert p.dtype == torch.float32 and p.shape == (5, 48) and p.vt_arith == "bf16x3"
-    planes = p.view(torch.bfloat16).reshape(5, 3, 2, 16)
-    hi, lo = planes[:, :, 0].reshape(5, 48).float(), planes[:, :, 1].reshape(5, 48).float()
+    assert p.dtype == torch.float32 and p.shape == (5, 64) and p.vt_arith == "bf16x3"
+    planes = p.view(torch.bfloat16).reshape(5, 4, 2, 16)
+    hi, lo = planes[:, :, 0].reshape(5, 64).float(), planes[:, :, 1].reshape(5, 64).float()
     assert torch.equal(hi[:, :40], w.to(torch.bfloat16).float()) and torch.equal(lo[:, :40], (w - hi[:, :40]).to(torch.bfloat16).float())
     assert hi[:, 40:].abs().sum() == 0 and lo[:, 40:].abs().sum() == 0
     assert ((hi + lo)[:, :40] - w).abs().max() <= w.abs().max() * 2.0 ** -16

@@ -110,7 +110,12 @@ __device__ __forceinline__ void split3_x(const u32x4& r0, const u32x4& r1, u32x4
     const float f1 = __uint_as_float(e < 2 ? r0[2 * e + 1] : r1[2 * e - 3]);
     const uint32_t h = pack_bf16x2(f0, f1);
     hi[e] = h;
-    lo[e] = pack_bf16x2(f0 - __uint_as_float(h << 16), f1 - __uint_as_float(h & 0xffff0000u));
+    // the two subtractions as scalar v_sub_f32: left to the compiler they become one v_pk_add_f32, and a packed-fp32
+    // instruction stalls the matrix pipe of its SIMD (profiles/r02_mfma_issue_microbench.txt) -- this runs beside MFMAs
+    float d0, d1;
+    asm("v_sub_f32_e32 %0, %1, %2" : "=v"(d0) : "v"(f0), "v"(h << 16));
+    asm("v_sub_f32_e32 %0, %1, %2" : "=v"(d1) : "v"(f1), "v"(h & 0xffff0000u));
+    lo[e] = pack_bf16x2(d0, d1);
   }
 }
 __device__ __forceinline__ void mma_bf16(const u32x4& wfrag, const u32x4& xfrag, f32x16& acc) {

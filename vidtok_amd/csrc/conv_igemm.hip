@@ -840,11 +840,13 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_igemm_glds_ker
       if constexpr (BUF) {
         // FAST: lane offset is fixed for the tile (row + chunk), the step advances through soffset;
         // general: the lane's k offset is folded in here
-        const unsigned off = FAST ? b_off[j] : (kvalid ? b_off[j] + (unsigned)koff * (unsigned)sizeof(MT) : kOob);
+        // (split-bf16 weight rows are zero-padded to whole K steps and their 16-byte chunks hold other k than the x chunk at
+        // the same offset: no per-chunk validity on the weight side)
+        const unsigned off = FAST ? b_off[j] : ((kvalid || X3) ? b_off[j] + (unsigned)koff * (unsigned)sizeof(MT) : kOob);
         const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<MT*>(wg), 0, ext_w, 0x00020000);
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (lds_ptr_t)(As + A_BYTES + (RSTEP * j) * ROWB), 16, off, s_b, 0, 0);
       } else {
-        const MT* src = (b_row[j] && kvalid) ? b_row[j] + koff : zero;
+        const MT* src = (b_row[j] && (kvalid || X3)) ? b_row[j] + koff : zero;
         __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)(As + A_BYTES + (RSTEP * j) * ROWB), 16, 0, 0);
       }
     }
@@ -954,7 +956,9 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_igemm_glds_ker
   };
 
   // SCHED 3: the two-group schedule of the split-bf16 arithmetic on the 8-wave tile (below)
-  constexpr bool S3 = SCHED == 3 && X3 && (WAVES_M * WAVES_N == 8) && FAST && BUF;
+  constexpr bool S3 = (SCHED >= 3 && SCHED <= 5) && X3 && (WAVES_M * WAVES_N == 8) && FAST && BUF;
+  // how many of the 4 DMA pieces of step s + 3 go out in LOAD(s); the others between the MFMAs of COMPUTE(s)
+  constexpr int S3_NL = SCHED == 3 ? 4 : (SCHED == 4 ? 0 : 2);
   if constexpr (!S2 && !S3) {
 #pragma unroll
     for (int d = 0; d < D; ++d)
@@ -1017,8 +1021,12 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_igemm_glds_ker
       __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
     }
+    // PROF stamps per step: 0 LOAD start, 1 reads / pieces issued + x split, 2 COMPUTE start (waits + barrier over), 3 COMPUTE end,
+    // 4 trailing barrier over
     for (int s = 0; s < p.nsteps; ++s) {
       const int stg = s & 3;
+      s_cur = s;
+      stamp(0);
       // ---- LOAD(s)
       {
         const char* As = a_base + stg * STAGE_BYTES;
@@ -1037,26 +1045,48 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_igemm_glds_ker
         if (s + 3 < p.nsteps) prep_step(s + 3);
         else ext_x = ext_w = 0u;                     // past the last step: the pieces below turn into zero fills
 #pragma unroll
-        for (int q = 0; q < IPS; ++q) fire_piece(q, (s + 3) & 3);
+        for (int q = 0; q < S3_NL; ++q) fire_piece(q, (s + 3) & 3);
+        bool do_split = true;
+        if constexpr (PROF) do_split = !(p.prof_mode & 16);       // measurement: no split (the fragments keep stale values)
+        if (do_split) {
 #pragma unroll
-        for (int b = 0; b < TM; ++b) split3_x(r[b][0], r[b][1], xhi[b], xlo[b]);
+          for (int b = 0; b < TM; ++b) split3_x(r[b][0], r[b][1], xhi[b], xlo[b]);
+        }
       }
-      asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);             // the split stays in the LOAD phase (left alone, half of it sinks behind the barrier)
+      stamp(1);
+      // my pieces of step s + 1 have landed: all but the youngest 8 (steps s + 2, s + 3), or 4 where step s + 3 is still to be requested
+      asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(4 + S3_NL) : "memory");
       __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
+      stamp(2);
       // ---- COMPUTE(s): 24 MFMAs, nothing else
-      __builtin_amdgcn_s_setprio(1);
+      bool do_mma = true;
+      if constexpr (PROF) do_mma = !(p.prof_mode & 32);           // measurement: no MFMAs
+      if (do_mma) {
+        __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-      for (int qq = 0; qq < 3 * TM * TN; ++qq) {
-        const int pr = qq / (TM * TN), a = (qq / TM) % TN, b = qq % TM;
-        mma_bf16(pr == 1 ? wlo[a] : whi[a], pr == 0 ? xlo[b] : xhi[b], acc[a][b]);
+        for (int qq = 0; qq < 3 * TM * TN; ++qq) {
+          const int pr = qq / (TM * TN), a = (qq / TM) % TN, b = qq % TM;
+          mma_bf16(pr == 1 ? wlo[a] : whi[a], pr == 0 ? xlo[b] : xhi[b], acc[a][b]);
+          if constexpr (S3_NL < 4) {
+            constexpr int GAP = 24 / (4 - S3_NL);    // one piece behind MFMAs 1, 1 + GAP, ...
+            if (qq % GAP == 1) {
+              __builtin_amdgcn_sched_barrier(0);
+              fire_piece(S3_NL + qq / GAP, (s + 3) & 3);
+              __builtin_amdgcn_sched_barrier(0);
+            }
+          }
+        }
+        __builtin_amdgcn_s_setprio(0);
       }
-      __builtin_amdgcn_s_setprio(0);
       __builtin_amdgcn_sched_barrier(0);
+      stamp(3);
       if (!(grp == 1 && s + 1 == p.nsteps)) {      // waves 4-7 entered one barrier late: they leave without the last one
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
       }
+      stamp(4);
     }
   } else if constexpr (S2) {
     // Schedule 2, "ping-pong" (the structure of the guide's 256 x 256 template, adapted to the gather).
@@ -1354,7 +1384,10 @@ int launch_variant(const ConvArgs& a_in, int nbatch, hipStream_t stream) {
   const int sched_opt = vt_opt(OPT_CONV_SCHED);
   const bool s2 = HAS_S2 && buf && sched_opt >= 2;
   const bool s1 = HAS_S1 && buf && sched_opt != 0 && !s2;
-  const bool s3 = HAS_S3 && buf && sched_opt != 0;
+  const int sched_x3 = vt_opt(OPT_CONV_SCHED_X3);
+  const bool s3 = HAS_S3 && buf && sched_x3 != 0;
+  const bool s3b = s3 && sched_x3 == 2;      // conv_sched_x3 1: DMA pieces in the LOAD phases, 2: between the MFMAs of the COMPUTE phases,
+  const bool s3c = s3 && sched_x3 >= 3;      // 3: half and half
   if (buf) {
     a.x_bytes = (unsigned)xb;
     a.w_bytes = (unsigned)wb;
@@ -1367,7 +1400,9 @@ int launch_variant(const ConvArgs& a_in, int nbatch, hipStream_t stream) {
       if (s2) kern = reinterpret_cast<const void*>(&conv_igemm_glds_kernel<MT, TOut, WAVES_M, WAVES_N, TM, TN, FAST, ROWB, STAGES, true, LN256, false, 2>);
     }
     if constexpr (HAS_S3) {
-      if (s3) kern = reinterpret_cast<const void*>(&conv_igemm_glds_kernel<MT, TOut, WAVES_M, WAVES_N, TM, TN, FAST, ROWB, STAGES, true, LN256, false, 3>);
+      if (s3) kern = s3c ? reinterpret_cast<const void*>(&conv_igemm_glds_kernel<MT, TOut, WAVES_M, WAVES_N, TM, TN, FAST, ROWB, STAGES, true, LN256, false, 5>)
+                   : s3b ? reinterpret_cast<const void*>(&conv_igemm_glds_kernel<MT, TOut, WAVES_M, WAVES_N, TM, TN, FAST, ROWB, STAGES, true, LN256, false, 4>)
+                         : reinterpret_cast<const void*>(&conv_igemm_glds_kernel<MT, TOut, WAVES_M, WAVES_N, TM, TN, FAST, ROWB, STAGES, true, LN256, false, 3>);
     }
   } else {
     kern = reinterpret_cast<const void*>(&conv_igemm_glds_kernel<MT, TOut, WAVES_M, WAVES_N, TM, TN, FAST, ROWB, STAGES, false, LN256>);
@@ -1381,13 +1416,21 @@ int launch_variant(const ConvArgs& a_in, int nbatch, hipStream_t stream) {
                 : reinterpret_cast<const void*>(&conv_igemm_glds_kernel<MT, TOut, WAVES_M, WAVES_N, TM, TN, FAST, ROWB, STAGES, true, 0, true, 0>);
       lds_bytes = LDS + 4096;
       VT_CHECK_HIP(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+    } else if constexpr (HAS_S3 && LN256 == 0) {           // split-bf16 on the 8-wave tile: schedule 3 / the plain loop of its ring
+      VT_CHECK_ARG(buf, "vt_conv_profile: descriptor gather only");
+      kern = s3c ? reinterpret_cast<const void*>(&conv_igemm_glds_kernel<MT, TOut, WAVES_M, WAVES_N, TM, TN, FAST, ROWB, STAGES, true, 0, true, 5>)
+           : s3b ? reinterpret_cast<const void*>(&conv_igemm_glds_kernel<MT, TOut, WAVES_M, WAVES_N, TM, TN, FAST, ROWB, STAGES, true, 0, true, 4>)
+           : s3 ? reinterpret_cast<const void*>(&conv_igemm_glds_kernel<MT, TOut, WAVES_M, WAVES_N, TM, TN, FAST, ROWB, STAGES, true, 0, true, 3>)
+                : reinterpret_cast<const void*>(&conv_igemm_glds_kernel<MT, TOut, WAVES_M, WAVES_N, TM, TN, FAST, ROWB, STAGES, true, 0, true, 0>);
+      lds_bytes = LDS + 4096;
+      VT_CHECK_HIP(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
     } else {
-      VT_CHECK_ARG(false, "vt_conv_profile: only the bf16 8-wave 256 x 256 tile without fused LayerNorm is instrumented");
+      VT_CHECK_ARG(false, "vt_conv_profile: only the bf16 / split-bf16 8-wave 256 x 256 tile without fused LayerNorm is instrumented");
     }
   }
   // the attribute is per device: one flag per (instantiation, gather form, device), set race-free
-  static std::atomic<bool> attr_done[4][kMaxDevices];
-  const int ki = buf ? ((s2 || s3) ? 3 : (s1 ? 2 : 1)) : 0;
+  static std::atomic<bool> attr_done[6][kMaxDevices];
+  const int ki = buf ? (s3c ? 5 : (s3b ? 4 : ((s2 || s3) ? 3 : (s1 ? 2 : 1)))) : 0;
   int dev = 0;
   VT_CHECK_HIP(hipGetDevice(&dev));
   if (dev < 0 || dev >= kMaxDevices || !attr_done[ki][dev].load(std::memory_order_acquire)) {
@@ -1549,8 +1592,8 @@ int conv_prepare(const vt_conv_desc* d, ConvArgs& a, bool& ln_fused, int& nbatch
                d->out_dtype, d->dtype);
   const int vec = d->dtype == VT_BF16 ? 8 : 4;
   if (d->dtype == VT_BF16X3)    // split weight planes: [hi 16 x bf16 | lo 16 x bf16] per 16 k-values, K padded to the block
-    VT_CHECK_ARG(d->ldw % 16 == 0 && d->ldw >= (d->KT * d->KH * d->KW * d->Cin + 15) / 16 * 16 && d->nbatch <= 1,
-                 "vt_conv: VT_BF16X3 needs ldw = K rounded up to 16 (got %d) and nbatch 1", d->ldw);
+    VT_CHECK_ARG(d->ldw % 32 == 0 && d->ldw >= (d->KT * d->KH * d->KW * d->Cin + 31) / 32 * 32 && d->nbatch <= 1,
+                 "vt_conv: VT_BF16X3 needs ldw = K rounded up to 32 (got %d) and nbatch 1", d->ldw);
   VT_CHECK_ARG(d->B > 0 && d->Ti > 0 && d->Hi > 0 && d->Wi > 0 && d->Cin > 0, "vt_conv: bad input dims");
   VT_CHECK_ARG(d->To > 0 && d->Ho > 0 && d->Wo > 0 && d->Cout > 0, "vt_conv: bad output dims");
   VT_CHECK_ARG(d->Cin % vec == 0, "vt_conv: Cin=%d must be a multiple of %d (pad the channel dim)", d->Cin, vec);
@@ -1697,8 +1740,9 @@ extern "C" int vt_conv_profile(const vt_conv_desc* d, uint64_t* stamps_out, vt_s
   a.prof_mode = vt_opt(OPT_WS_PROF_MODE);
   if (use_ws)                                          // stamps [wave][16]: conv_ws128.hip workgroup 0's fourth tile (4 waves), conv_ws2.hip iterations 8, 9 (8 waves)
     return vt_opt(OPT_CONV_WS) == 2 ? vt_ws2_launch(&a, stream_) : vt_ws128_launch(&a, stream_);
-  VT_CHECK_ARG(d->dtype == VT_BF16 && d->out_dtype == VT_BF16 && d->ln_mode == 0 && select_tile(a, nbatch) == TILE_256x256,
-               "vt_conv_profile: bf16 launches on the 256 x 256 tile without LayerNorm, or on the weight-stationary kernel");
+  VT_CHECK_ARG(((d->dtype == VT_BF16 && d->out_dtype == VT_BF16) || d->dtype == VT_BF16X3) && d->ln_mode == 0 && select_tile(a, nbatch) == TILE_256x256,
+               "vt_conv_profile: bf16 / split-bf16 launches on the 256 x 256 tile without LayerNorm, or on the weight-stationary kernel");
+  if (d->dtype == VT_BF16X3) return dispatch_tile<split3_t, float>(a, nbatch, reinterpret_cast<hipStream_t>(stream_));
   return dispatch_tile<bf16_t, bf16_t>(a, nbatch, reinterpret_cast<hipStream_t>(stream_));
 }
 

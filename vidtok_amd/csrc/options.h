@@ -21,6 +21,7 @@ enum VtOpt {
   OPT_TBLOCK_PROF_MODE,    // vt_temporal_block_profile: bit 0 GEMMs skipped, bit 1 row units skipped, bit 4 no stores (wrong results)
   OPT_CONV_DEEP,           // 1: 128 x 128 tile on a 4-slot ring (three K steps in flight) when a launch has no more tiles than the device has CUs
   OPT_WS_PROF_MODE,        // vt_conv_profile on conv_ws2.hip: bit 0 = row slots skipped, bit 1 = LDS-DMA requests skipped (wrong results)
+  OPT_CONV_SCHED_X3,       // split-bf16 arithmetic on the 8-wave tile: 0 plain loop, two-group schedule 3 with the DMA pieces of a step issued 1 in the LOAD phase / 2 between the MFMAs of the COMPUTE phase / 3 half and half
   OPT_COUNT
 };
 

@@ -31,10 +31,11 @@ ARITH_SPLIT3 = "bf16x3"
 def pack_split3(w2d: torch.Tensor) -> torch.Tensor:
     """Packed fp32 rows [Cout, K] -> the operand of vt_conv's VT_BF16X3 arithmetic (include/vidtok_amd.h): every value as
     two bf16 planes, hi = bf16(w) (round to nearest even) and lo = bf16(w - hi), stored per group of 16 k as
-    [hi 16 x bf16 | lo 16 x bf16] (64 bytes, the size of the 16 fp32 values they replace), K zero-padded to the group.
-    Returned as a float32-typed container [Cout, K16] (ldw = K16) tagged `vt_arith`; data movement + two roundings."""
+    [hi 16 x bf16 | lo 16 x bf16] (64 bytes, the size of the 16 fp32 values they replace), K zero-padded to 32 (a whole
+    128-byte K step of the kernel).  Returned as a float32-typed container [Cout, K32] (ldw = K32) tagged `vt_arith`;
+    data movement + two roundings."""
     cout, K = w2d.shape
-    Kp = (K + 15) // 16 * 16
+    Kp = (K + 31) // 32 * 32
     w = w2d.detach().to(torch.float32)
     if Kp != K:
         w = torch.nn.functional.pad(w, (0, Kp - K))
