@@ -30,6 +30,10 @@ Launch: `python bench.py --gpus N` spawns its N ranks itself (re-executes under 
               roofline.hbm: the HBM-shaped kernel classes (LayerNorm passes, conv_in, 1x1 convolutions, conv_out, the
               temporal k3 convolutions and the fused temporal block: FLOP per byte below the 312 FLOP/B ridge), each
               replayed alone the same way: algorithmic bytes (every operand / result once) / time, against 8 TB/s
+  parity_mode / modes / other_configs   (N = 1) the same workload in the other arithmetic modes -- fp32 (fp32 MFMA) and bf16x3
+              (split-bf16: fp32 storage, three bf16 MFMAs per product; the fast mode inside the reference's fp32 tolerance) --
+              with each mode's distance from the CPU oracle on clip 0 of the batch, and the frames/s of BASELINE.json
+              configs[2] (FSQ, with the integer-code agreement) and configs[4] (129-frame clip, temporal tiling)
   cpu_baseline  the CPU oracle (port of the reference, oracle/vidtok_oracle.py) timed on this host's
               cores on a bounded sample of the same workload; a baseline, not a target.  At N > 1 rank 0 runs it (and
               the traffic passes) after the process group is gone, so the line of a scaling run carries both too
@@ -73,7 +77,7 @@ def randomize_weights(model, seed=0):
                 p.copy_(torch.randn(p.shape, generator=g) / math.sqrt(p[0].numel()))
 
 
-def cpu_baseline():
+def cpu_baseline(config=None, clip=None, seed=77):
     """Time the CPU oracle (a port: the reference is Python and cannot travel to the GPU box) on ONE unscaled
     17x256x256 clip of the bench workload -- about 30 s of CPU work.  The thread count is the best of 16 / 32 / 64
     (capped by the host) on a 17x64x64 probe: torch's CPU convolutions collapse when given all 256 hardware threads
@@ -82,8 +86,9 @@ def cpu_baseline():
     import vidtok_amd
     from oracle.vidtok_oracle import OracleEngine
 
+    config = config or CONFIG_1GPU
     cores = os.cpu_count() or 1
-    cfg = vidtok_amd.load_config(os.path.join(ROOT, "configs", CONFIG_1GPU + ".yaml"))
+    cfg = vidtok_amd.load_config(os.path.join(ROOT, "configs", config + ".yaml"))
     model = vidtok_amd.load_model_from_config(cfg, verbose=False)
     randomize_weights(model, 0)
     ora = OracleEngine(cfg["model"]["params"], model.state_dict())
@@ -105,10 +110,102 @@ def cpu_baseline():
         if t > 10.0:
             break
     torch.set_num_threads(threads)
-    t = run(RES)
+    if clip is None:
+        clip = torch.rand(1, 3, T_REAL, RES, RES) * 2 - 1
+    torch.manual_seed(seed)          # the KL noise stream: the engine's host-noise pass of the same clip draws the same numbers
+    t0 = time.perf_counter()
+    z, dec, _ = ora(clip)
+    t = time.perf_counter() - t0
     return {"value": round(T_REAL / t, 4), "unit": "frames/s", "cores": threads, "kind": "port",
             "sample": f"oracle/vidtok_oracle.py forward, fp32, 1 unscaled clip 17x{RES}x{RES} in {t:.2f}s on {threads} of "
-                      f"{cores} host threads ({CONFIG_1GPU})"}
+                      f"{cores} host threads ({config})"}, (z, dec)
+
+
+def rel_err(a, b):
+    """max |a - b| / max |b|: the parity metric of SURVEY.md section 8(d)"""
+    a, b = a.detach().float().cpu(), b.detach().float().cpu()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+
+def time_steps(fn, steps, warmup=3):
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / steps, out
+
+
+MODES = {"bf16": torch.bfloat16, "fp32": torch.float32, "bf16x3": "bf16x3"}
+
+
+def mode_measurements(model, x, main_mode, seed=77):
+    """rank 0, N = 1: the bench workload in the OTHER arithmetic modes (frames/s, graph-replayed like the main line) and, in
+    every mode, the engine's output for clip 0 with the reference's host-side noise stream -- compared by the caller with the
+    CPU oracle's output for that clip (the run cpu_baseline times anyway)."""
+    B = x.shape[0]
+    res = {}
+    for name, dt in MODES.items():
+        model.set_compute_dtype(dt)
+        model.enable_graphs(False)
+        model.regularization.noise_source = "host"
+        torch.manual_seed(seed)
+        z, dec, _ = model(x[:1].contiguous())
+        res[name] = {"z": z.cpu(), "dec": dec.cpu()}
+        if name != main_mode:
+            model.regularization.noise_source = "device"
+            model.enable_graphs(True)
+            dt_s, _ = time_steps(lambda: model(x), 3 if name == "fp32" else 5)
+            res[name].update(value=round(B * T_REAL / dt_s, 2), ms_per_step=round(dt_s * 1e3, 3))
+    return res
+
+
+def other_config_measurements(dev, x):
+    """rank 0, N = 1: the BASELINE.json configurations that are not the bench line -- configs[2] (vidtok_fsq_causal_488_32768,
+    B=4 17x256x256: frames/s in bf16 and bf16x3, FSQ integer codes of those modes against the fp32 kernels', which
+    reproduce the CPU oracle's codes exactly in the GPU tests and in smoke()) and configs[4] (vidtok_kl_causal_488_16chn_v1_1,
+    one clip of 129x256x256, t_chunk_enc = 16 tiling with decoder look-ahead, bf16; chunks replayed from the graph cache)."""
+    import vidtok_amd
+
+    out = {}
+    B = x.shape[0]
+    name = "vidtok_fsq_causal_488_32768"
+    m = vidtok_amd.load_model_from_config(os.path.join(ROOT, "configs", name + ".yaml"), verbose=False)
+    randomize_weights(m, 0)
+    m = m.to(dev).eval()
+    codes, e = {}, {}
+    for mode in ("fp32", "bf16x3", "bf16"):
+        m.set_compute_dtype(MODES[mode])
+        m.enable_graphs(False)
+        codes[mode] = m(x)[2]["indices"]
+        if mode != "fp32":
+            m.enable_graphs(True)
+            dt_s, _ = time_steps(lambda: m(x), 5)
+            e[mode] = {"value": round(B * T_REAL / dt_s, 2), "ms_per_step": round(dt_s * 1e3, 3),
+                       "code_rate_vs_fp32_kernels": round(float((codes[mode] == codes["fp32"]).float().mean()), 6)}
+    out["configs[2]"] = {"workload": f"{name} forward (encode+FSQ+decode), B={B} clips, 17x256x256", "unit": "frames/s",
+                         "codes_compared": int(codes["fp32"].numel()), **e}
+    del m, codes
+    torch.cuda.empty_cache()
+    name = "vidtok_v1_1/vidtok_kl_causal_488_16chn_v1_1"
+    m = vidtok_amd.load_model_from_config(os.path.join(ROOT, "configs", name + ".yaml"), verbose=False)
+    randomize_weights(m, 0)
+    m = m.to(dev).eval().set_compute_dtype(torch.bfloat16)
+    m.regularization.noise_source = "device"
+    xl = (torch.rand((1, 3, 129, RES, RES), generator=torch.Generator().manual_seed(2)) * 2 - 1).to(dev)
+    e = {}
+    for tiled in (True, False):
+        m.use_tiling, m.t_chunk_enc, m.use_overlap = tiled, 16, True
+        m.enable_graphs(True)
+        dt_s, o = time_steps(lambda: m(xl), 3, warmup=2)
+        e["tiled" if tiled else "untiled"] = {"value": round(129 / dt_s, 2), "ms_per_clip": round(dt_s * 1e3, 2),
+                                               "output_finite": bool(torch.isfinite(o[1]).all())}
+    out["configs[4]"] = {"workload": f"{name} forward, bf16, 1 clip 129x256x256; tiled = t_chunk_enc 16 + decoder look-ahead",
+                         "unit": "frames/s", **e}
+    return out
+
 
 
 MFMA_KERNELS = ("conv_igemm", "conv3x3_ws2", "conv3x3_ws128", "conv3d_narrow", "tblock_pair")
@@ -229,6 +326,8 @@ def main():
     ap.add_argument("--selftest-spawn", action="store_true",
                     help="CPU/gloo check of the N-rank launch path only (no GPU work): prints the world size reached")
     ap.add_argument("--config", default=None, help="override the workload's YAML (default: BASELINE configs[1] / [3])")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the N = 1 extras of the line: the other arithmetic modes (parity_mode, modes) and BASELINE configs[2] / [4]")
     args = ap.parse_args()
 
     if not torch.cuda.is_available() and not args.selftest_spawn:
@@ -280,7 +379,10 @@ def main():
     model.regularization.noise_source = "device"   # reparameterisation noise drawn on the GPU (capturable)
     B = args.batch
     g = torch.Generator().manual_seed(1234 + rank)
-    x = (torch.rand((B, 3, T_REAL, RES, RES), generator=g) * 2 - 1).to(dev)
+    x_host = torch.rand((B, 3, T_REAL, RES, RES), generator=g) * 2 - 1
+    x = x_host.to(dev)
+    clip0 = x_host[:1].clone()
+    del x_host
 
     def step():
         return model(x)
@@ -408,6 +510,11 @@ def main():
     # HBM-side bytes per launch: PMC counters cannot be read inside an un-profiled process, so two rocprofv3 passes over
     # a child run of this command measure them now; the committed pass of profiles/ is the fallback (and what
     # --traffic profile quotes)
+    extras_on = world == 1 and not args.no_extras
+    modes = others = None
+    if extras_on:
+        modes = mode_measurements(model, x, args.dtype)
+        others = other_config_measurements(dev, x)
     if args.traffic == "pmc":
         del model, out, z, dec
         torch.cuda.empty_cache()
@@ -431,7 +538,23 @@ def main():
             roof["traffic"] = tb
             roof["traffic_source"] = src + ("" if args.traffic == "profile" else f"; {roof['traffic_source']}")
 
-    cpu = None if args.no_cpu_baseline else cpu_baseline()
+    cpu, ref = (None, None) if args.no_cpu_baseline else cpu_baseline(config, clip0)
+    parity_mode = mode_table = None
+    if modes is not None:
+        # every arithmetic mode on the bench workload: frames/s, and the distance of its output for clip 0 from the CPU
+        # oracle's (z: the latent, recon: the reconstruction; max-norm relative).  parity_mode = the fastest mode inside the
+        # reference's fp32 tolerance (north_star: 1e-3 relative, FSQ codes bit-exact): bf16x3
+        mode_table = {}
+        for name, r in modes.items():
+            e = {"value": r.get("value", round(total_frames / elapsed, 2)), "ms_per_step": r.get("ms_per_step", round(elapsed / args.steps * 1e3, 3))}
+            if ref is not None:
+                e["z_rel"], e["recon_rel"] = float(f"{rel_err(r['z'], ref[0]):.3e}"), float(f"{rel_err(r['dec'], ref[1]):.3e}")
+            mode_table[name] = e
+        parity_mode = {"dtype": "bf16x3", **mode_table["bf16x3"],
+                       "code_rate": (others or {}).get("configs[2]", {}).get("bf16x3", {}).get("code_rate_vs_fp32_kernels"),
+                       "code_rate_basis": "FSQ integer codes of configs[2] (B=4, 20 480 tokens) against the fp32 kernels' codes; fp32 kernels vs "
+                                          "the CPU oracle: all codes equal (tests/test_gpu_e2e.py, smoke())",
+                       "tolerance": "recon / z <= 1e-3 relative to the fp32 oracle (SURVEY.md section 8d)"}
 
     ms = elapsed / args.steps * 1e3
     value = total_frames / elapsed
@@ -445,6 +568,8 @@ def main():
                    "launch": "hipGraph replay (engine graph cache)" if graph is not None else "eager"},
         "output_finite": ok, "roofline": roof, "cpu_baseline": cpu,
     }
+    if parity_mode is not None:
+        line["parity_mode"], line["modes"], line["other_configs"] = parity_mode, mode_table, others
     print(json.dumps(line), flush=True)
 
 
