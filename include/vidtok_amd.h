@@ -353,7 +353,8 @@ int vt_entropy(const float* avg, int64_t J, float* out, vt_stream stream);
  * (reference vidtok/models/autoencoder.py:197-229: encode = encoder -> regularization, decode = decoder, forward = both;
  * the module tree of vidtok/modules/model_3dcausal.py:502-885 with `norm_type: layernorm`, `resamp_with_conv: true`).
  * Same stage graph, descriptors and fusion decisions as the Python host (vidtok_amd/modules.py), hence the same bits.
- *   vt_create(cfg, VT_BF16 | VT_F32, &h)     the fields of cfg are the constructor arguments of the reference's YAML
+ *   vt_create(cfg, VT_BF16 | VT_F32 | VT_BF16X3, &h)   the fields of cfg are the constructor arguments of the reference's YAML;
+ *                                            VT_BF16X3 = fp32 storage with every convolution in split-bf16 arithmetic
  *   vt_load_weight(h, key, data, shape, n)   key = the reference state_dict key ("encoder.down.0.block.0.conv1.weight",
  *                                            ...), data = fp32 on the HOST in the reference's parameter layout; weights
  *                                            are re-packed when first used.  vt_weight_count / vt_weight_name /

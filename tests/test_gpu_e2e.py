@@ -307,6 +307,23 @@ def test_full_size_v11_tiled_matches_cpu_oracle(dtype):
     assert (ez < 1e-3 and ed < 1e-3) if dtype != torch.bfloat16 else (ez < BF16_Z and ed < BF16_RECON)
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, X3, torch.float32], ids=["bf16", "bf16x3", "f32"])
+def test_configs4_long_video_tiled_matches_cpu_oracle(dtype):
+    """BASELINE.json configs[4] AT ITS STATED LENGTH: vidtok_kl_causal_488_16chn_v1_1, one clip of 129x256x256, t_chunk_enc = 16
+    temporal tiling with decoder look-ahead, against the CPU oracle running the same tiled protocol (one ~4-minute host run,
+    cached for the session and shared by the three arithmetic modes; bf16 is the dtype BASELINE.json names)."""
+    name = "vidtok_v1_1/vidtok_kl_causal_488_16chn_v1_1"
+    cfg, sd, x, (z2, dec2, log2) = _oracle_full(name, (1, 3, 129, 256, 256), 35, tiling=(16, True))
+    model, _, _ = build_model(name, seed=35, device=DEV, dtype=dtype)
+    model.use_tiling, model.t_chunk_enc, model.t_chunk_dec, model.use_overlap = True, 16, 4, True
+    torch.manual_seed(8)
+    z, dec, log = model(x.to(DEV))
+    ez, ed = rel_err(z, z2), rel_err(dec, dec2)
+    print(f"configs[4] tiled T=129 256x256 {dtype}: z rel {ez:.3e} dec rel {ed:.3e}")
+    assert dec.shape == x.shape and z.shape == (1, 16, 33, 32, 32)
+    assert (ez < 1e-3 and ed < 1e-3) if dtype != torch.bfloat16 else (ez < BF16_Z and ed < BF16_RECON)
+
+
 @pytest.mark.parametrize("name,shape", [("vidtok_kl_causal_488_4chn", (1, 3, 17, 128, 128)),
                                         ("vidtok_fsq_causal_488_32768", (1, 3, 17, 64, 64)),
                                         ("vidtok_kl_causal_488_4chn", (1, 3, 17, 256, 256))], ids=["kl_128", "fsq_64", "kl_256_benchmarked_size"])
@@ -488,7 +505,7 @@ def test_encoder_tail_precision():
 
 
 # ---- the model handle of the C-ABI (vt_create / vt_load_weight / vt_encode / vt_regularize_* / vt_decode) -------------------
-@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32], ids=["bf16", "f32"])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32, X3], ids=["bf16", "f32", "bf16x3"])
 @pytest.mark.parametrize("name,shape", [("vidtok_kl_causal_488_4chn", (2, 3, 9, 64, 64)), ("vidtok_kl_causal_488_4chn", (1, 3, 17, 256, 256)),
                                         ("vidtok_fsq_causal_488_32768", (1, 3, 17, 128, 128)), ("vidtok_kl_causal_41616_4chn", (1, 3, 9, 128, 128)),
                                         ("vidtok_v1_1/vidtok_kl_causal_488_4chn_v1_1", (2, 3, 18, 64, 64)),      # front pad 2, trilinear
@@ -522,7 +539,7 @@ def test_model_handle_matches_engine(name, shape, dtype):
             model._empty_causal_cached(part)
         model._set_first_chunk(True)
         model._set_fused_temporal()
-    L.check(lib.vt_create(C.byref(mc), L.VT_BF16 if dtype == torch.bfloat16 else L.VT_F32, C.byref(h)), "vt_create")
+    L.check(lib.vt_create(C.byref(mc), {torch.bfloat16: L.VT_BF16, torch.float32: L.VT_F32, X3: L.VT_BF16X3}[dtype], C.byref(h)), "vt_create")
     try:
         names = [lib.vt_weight_name(h, i).decode() for i in range(lib.vt_weight_count(h))]
         assert set(names) == {k for k in sd if not k.startswith("regularization")}, "the handle reads exactly the encoder / decoder tensors of the reference state_dict"

@@ -371,7 +371,7 @@ def test_conv_8wave_schedules(case, sched, vt_opts):
     assert plan["tile"] == ((256, 256) if case[3] % 256 == 0 else (128, 128))
 
 
-@pytest.mark.parametrize("sched", [0, 1, 2, 3], ids=["plain_loop", "two_groups_dma_in_load", "two_groups_dma_in_compute", "two_groups_dma_split"])
+@pytest.mark.parametrize("sched", [0, 1, 2, 3, 4], ids=["plain_loop", "two_groups_dma_in_load", "two_groups_dma_in_compute", "two_groups_dma_split", "stream"])
 @pytest.mark.parametrize("case", SCHED_CASES + CONV_CASES_LARGE, ids=[c[0] for c in SCHED_CASES + CONV_CASES_LARGE])
 def test_conv_8wave_schedules_split_bf16(case, sched, vt_opts):
     """split-bf16 arithmetic on the 8-wave tile (64-byte rows, 4-slot ring): schedule 3 (LOAD / COMPUTE phases, two wave

@@ -956,10 +956,12 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_igemm_glds_ker
   };
 
   // SCHED 3: the two-group schedule of the split-bf16 arithmetic on the 8-wave tile (below)
+  // SCHED 6: the "stream" schedule of the split-bf16 arithmetic on the 8-wave tile (below, S5)
+  constexpr bool S5 = SCHED == 6 && X3 && (WAVES_M * WAVES_N == 8) && FAST && BUF;
   constexpr bool S3 = (SCHED >= 3 && SCHED <= 5) && X3 && (WAVES_M * WAVES_N == 8) && FAST && BUF;
   // how many of the 4 DMA pieces of step s + 3 go out in LOAD(s); the others between the MFMAs of COMPUTE(s)
   constexpr int S3_NL = SCHED == 3 ? 4 : (SCHED == 4 ? 0 : 2);
-  if constexpr (!S2 && !S3) {
+  if constexpr (!S2 && !S3 && !S5) {
 #pragma unroll
     for (int d = 0; d < D; ++d)
       if (d < p.nsteps) {
@@ -985,7 +987,90 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_igemm_glds_ker
       }
     }
   };
-  if constexpr (S3) {
+  if constexpr (S5) {
+    // Stream schedule of the split-bf16 arithmetic (X3) on the 8-wave 256 x 256 tile: K steps of 16 k-values (64-byte rows),
+    // 4-slot ring, ONE barrier per step, all eight waves in the same phase -- each wave's 24 MFMAs of step s carry, in their
+    // shadows, everything else: the fragment reads of step s + 1 (w hi planes, x as fp32) and the w lo planes of step s, the
+    // split of the x values of step s + 1 into bf16 hi / lo fragments, the address set-up and the 4 DMA pieces of step s + 3.
+    // Why not two groups one phase apart (schedule 3): there only one wave of a SIMD feeds the matrix pipe at a time, and a
+    // wave that stands at a full VMEM queue with a DMA piece feeds nothing (launch time by mode, scripts/conv_profile.py: the
+    // zero-fill pieces alone cost schedule 3 0.24-0.38 us of a 1.3-1.4 us step wherever they were issued; with both waves
+    // streaming MFMAs the sibling covers such a stall, scripts/mfma_tile_bench.hip: +66 cycles per step for the same pieces).
+    //   step s:  wait my pieces of step s + 1 (vmcnt(4): all but step s + 2's) -> barrier (everyone's have landed; everyone
+    //            has finished reading slot (s - 1) & 3, which the pieces of step s + 3 refill) -> reads, MFMAs, split, pieces
+    // Register sets alternate between steps (the loop body exists twice), nothing is copied.
+    static_assert(ROWB == 64 && STAGES == 4 && TM == 2 && TN == 4 && A_VECS == 2 && B_VECS == 2, "stream schedule: 8-wave tile, 64-byte rows, 4 slots");
+    const char* a_base = smem + (wm * TM * 32) * ROWB + frag_row;
+    const char* b_base = smem + A_BYTES + (wn * TN * 32) * ROWB + frag_row;
+    const int sh = (khalf ^ swz) * 16, sl = ((2 + khalf) ^ swz) * 16;
+    const int s0 = ((2 * khalf) ^ swz) * 16, s1 = ((2 * khalf + 1) ^ swz) * 16;
+    u32x4 whi[2][TN], wlo[TN], xh[2][TM], xl[2][TM];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      if (d < p.nsteps) prep_step(d);
+      else ext_x = ext_w = 0u;
+#pragma unroll
+      for (int q = 0; q < IPS; ++q) fire_piece(q, d);
+    }
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    {                                               // fragments of step 0 (set 0)
+#pragma unroll
+      for (int a = 0; a < TN; ++a) whi[0][a] = *reinterpret_cast<const u32x4*>(b_base + a * 32 * ROWB + sh);
+#pragma unroll
+      for (int b = 0; b < TM; ++b) {
+        const u32x4 r0 = *reinterpret_cast<const u32x4*>(a_base + b * 32 * ROWB + s0);
+        const u32x4 r1 = *reinterpret_cast<const u32x4*>(a_base + b * 32 * ROWB + s1);
+        split3_x(r0, r1, xh[0][b], xl[0][b]);
+      }
+    }
+    auto body = [&](auto set_c, int s) __attribute__((always_inline)) {
+      constexpr int C = decltype(set_c)::value, N = C ^ 1;
+      const char* As_n = a_base + ((s + 1) & 3) * STAGE_BYTES;
+      const char* Bs_c = b_base + (s & 3) * STAGE_BYTES;
+      const char* Bs_n = b_base + ((s + 1) & 3) * STAGE_BYTES;
+      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int a = 0; a < TN; ++a) wlo[a] = *reinterpret_cast<const u32x4*>(Bs_c + a * 32 * ROWB + sl);
+#pragma unroll
+      for (int a = 0; a < TN; ++a) whi[N][a] = *reinterpret_cast<const u32x4*>(Bs_n + a * 32 * ROWB + sh);
+      u32x4 r[TM][2];
+#pragma unroll
+      for (int b = 0; b < TM; ++b) {
+        r[b][0] = *reinterpret_cast<const u32x4*>(As_n + b * 32 * ROWB + s0);
+        r[b][1] = *reinterpret_cast<const u32x4*>(As_n + b * 32 * ROWB + s1);
+      }
+      // x_hi w_hi first: it needs nothing read in this step, and its 8 MFMAs run while the wave works out the addresses of
+      // step s + 3 (left alone the compiler puts the address arithmetic and all four pieces in front of the first MFMA)
+#pragma unroll
+      for (int qq = 0; qq < TM * TN; ++qq) mma_bf16(whi[C][qq / TM], xh[C][qq % TM], acc[qq / TM][qq % TM]);
+      __builtin_amdgcn_sched_barrier(0);
+      if (s + 3 < p.nsteps) prep_step(s + 3);
+      else ext_x = ext_w = 0u;                     // past the last step: the pieces below turn into zero fills
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int qq = TM * TN; qq < 3 * TM * TN; ++qq) {    // x_hi w_lo, x_lo w_hi; a piece behind MFMAs 9, 13, 17, 21
+        const int pr = qq / (TM * TN), a = (qq / TM) % TN, b = qq % TM;
+        mma_bf16(pr == 1 ? wlo[a] : whi[C][a], pr == 2 ? xl[C][b] : xh[C][b], acc[a][b]);
+        if (qq % 4 == 1) {
+          __builtin_amdgcn_sched_barrier(0);
+          fire_piece((qq - 9) / 4, (s + 3) & 3);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        if (qq == 10 || qq == 14) split3_x(r[(qq - 10) / 4][0], r[(qq - 10) / 4][1], xh[N][(qq - 10) / 4], xl[N][(qq - 10) / 4]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    int s = 0;
+    for (; s + 1 < p.nsteps; s += 2) {
+      body(std::integral_constant<int, 0>{}, s);
+      body(std::integral_constant<int, 1>{}, s + 1);
+    }
+    if (s < p.nsteps) body(std::integral_constant<int, 0>{}, s);
+  } else if constexpr (S3) {
     // Schedule 3: split-bf16 arithmetic (X3) on the 8-wave 256 x 256 tile.  A K step is ONE group of 16 k-values (rows of
     // 64 bytes: 16 fp32 of a pixel / [hi | lo] bf16 planes of a weight row), the ring has four slots, and a wave alternates
     //   LOAD(s)     12 fragment reads (x: 2 pixel sub-tiles x 2 chunks of fp32; w: 4 channel sub-tiles x (hi, lo)), the
@@ -1387,7 +1472,8 @@ int launch_variant(const ConvArgs& a_in, int nbatch, hipStream_t stream) {
   const int sched_x3 = vt_opt(OPT_CONV_SCHED_X3);
   const bool s3 = HAS_S3 && buf && sched_x3 != 0;
   const bool s3b = s3 && sched_x3 == 2;      // conv_sched_x3 1: DMA pieces in the LOAD phases, 2: between the MFMAs of the COMPUTE phases,
-  const bool s3c = s3 && sched_x3 >= 3;      // 3: half and half
+  const bool s3c = s3 && sched_x3 == 3;      // 3: half and half
+  const bool s5 = s3 && sched_x3 >= 4;       // 4: the stream schedule (one barrier per step, everything in the MFMA shadows)
   if (buf) {
     a.x_bytes = (unsigned)xb;
     a.w_bytes = (unsigned)wb;
@@ -1400,7 +1486,8 @@ int launch_variant(const ConvArgs& a_in, int nbatch, hipStream_t stream) {
       if (s2) kern = reinterpret_cast<const void*>(&conv_igemm_glds_kernel<MT, TOut, WAVES_M, WAVES_N, TM, TN, FAST, ROWB, STAGES, true, LN256, false, 2>);
     }
     if constexpr (HAS_S3) {
-      if (s3) kern = s3c ? reinterpret_cast<const void*>(&conv_igemm_glds_kernel<MT, TOut, WAVES_M, WAVES_N, TM, TN, FAST, ROWB, STAGES, true, LN256, false, 5>)
+      if (s3) kern = s5 ? reinterpret_cast<const void*>(&conv_igemm_glds_kernel<MT, TOut, WAVES_M, WAVES_N, TM, TN, FAST, ROWB, STAGES, true, LN256, false, 6>)
+                   : s3c ? reinterpret_cast<const void*>(&conv_igemm_glds_kernel<MT, TOut, WAVES_M, WAVES_N, TM, TN, FAST, ROWB, STAGES, true, LN256, false, 5>)
                    : s3b ? reinterpret_cast<const void*>(&conv_igemm_glds_kernel<MT, TOut, WAVES_M, WAVES_N, TM, TN, FAST, ROWB, STAGES, true, LN256, false, 4>)
                          : reinterpret_cast<const void*>(&conv_igemm_glds_kernel<MT, TOut, WAVES_M, WAVES_N, TM, TN, FAST, ROWB, STAGES, true, LN256, false, 3>);
     }
@@ -1429,8 +1516,8 @@ int launch_variant(const ConvArgs& a_in, int nbatch, hipStream_t stream) {
     }
   }
   // the attribute is per device: one flag per (instantiation, gather form, device), set race-free
-  static std::atomic<bool> attr_done[6][kMaxDevices];
-  const int ki = buf ? (s3c ? 5 : (s3b ? 4 : ((s2 || s3) ? 3 : (s1 ? 2 : 1)))) : 0;
+  static std::atomic<bool> attr_done[7][kMaxDevices];
+  const int ki = buf ? (s5 ? 6 : s3c ? 5 : (s3b ? 4 : ((s2 || s3) ? 3 : (s1 ? 2 : 1)))) : 0;
   int dev = 0;
   VT_CHECK_HIP(hipGetDevice(&dev));
   if (dev < 0 || dev >= kMaxDevices || !attr_done[ki][dev].load(std::memory_order_acquire)) {

@@ -130,7 +130,8 @@ struct DevBuf {
 
 struct Model {
   vt_model_config cfg;
-  int dt;
+  int dt;                          // storage type of the activations (VT_BF16 | VT_F32)
+  bool x3 = false;                 // VT_BF16X3: fp32 storage, convolutions on split-bf16 weight planes (three bf16 MFMAs per product)
   bool v11() const { return cfg.version == 1; }
   // time padding of a convolution with taps before the clip: zeros (v1.0) or the first frame repeated (v1.1, one pass)
   int tpad() const { return v11() ? VT_TPAD_REPLICATE : VT_TPAD_ZERO; }
@@ -168,12 +169,14 @@ struct Model {
   // convolution weight [Cout][Cin][k...] -> [Cout][taps * cin_p] in the arithmetic dtype (vidtok_amd/packing.py); `xf`
   // optionally rewrites the fp32 weight first (parity classes of the up-samplers: pre-summed taps)
   typedef std::vector<float> (*Xform)(const Param&, std::vector<int64_t>& shape, int a, int b);
-  const void* conv_w(const std::string& key, int cin_p, bool dry, Xform xf = nullptr, int xa = 0, int xb = 0) {
+  // `rows` = plain rows in the storage type even under VT_BF16X3 (the row operand of a GEMM against activations)
+  const void* conv_w(const std::string& key, int cin_p, bool dry, Xform xf = nullptr, int xa = 0, int xb = 0, bool rows = false) {
     if (dry) {
       expected.push_back(key);
       return nullptr;
     }
-    const std::string ckey = "w:" + key + ":" + std::to_string(cin_p) + ":" + std::to_string(dt) + ":" + std::to_string((xf ? 1 : 0) * 100 + xa * 10 + xb);
+    const bool split = x3 && !rows;
+    const std::string ckey = "w:" + key + ":" + std::to_string(cin_p) + ":" + std::to_string(dt) + (split ? "x3" : "") + ":" + std::to_string((xf ? 1 : 0) * 100 + xa * 10 + xb);
     auto it = packed.find(ckey);
     if (it != packed.end()) return it->second;
     const Param& p = param(key);
@@ -193,6 +196,24 @@ struct Model {
     for (int64_t o = 0; o < cout; ++o)
       for (int64_t c = 0; c < cin; ++c)
         for (int64_t t = 0; t < taps; ++t) w[((size_t)o * taps + t) * cin_p + c] = src[((size_t)o * cin + c) * taps + t];
+    if (split) {
+      // vidtok_amd/packing.py::pack_split3: per group of 16 k, [hi 16 x bf16 | lo 16 x bf16], hi = bf16(w), lo = bf16(w - hi);
+      // rows zero-padded to whole 128-byte K steps (ldw = K rounded up to 32, in 4-byte units)
+      const size_t K = (size_t)taps * cin_p, Kp = (K + 31) / 32 * 32;
+      std::vector<uint16_t> pl((size_t)cout * Kp * 2, 0);
+      for (int64_t o = 0; o < cout; ++o)
+        for (size_t k = 0; k < K; ++k) {
+          const float v = w[(size_t)o * K + k];
+          const uint16_t hi = bf16_rne(v);
+          uint32_t hb = (uint32_t)hi << 16;
+          float hf;
+          memcpy(&hf, &hb, 4);
+          uint16_t* blk = &pl[((size_t)o * Kp + (k / 16) * 16) * 2];
+          blk[k % 16] = hi;
+          blk[16 + k % 16] = bf16_rne(v - hf);
+        }
+      return upload(ckey, pl.data(), pl.size() * 2);
+    }
     if (dt == VT_F32) return upload(ckey, w.data(), w.size() * 4);
     std::vector<uint16_t> h(w.size());
     for (size_t i = 0; i < w.size(); ++i) h[i] = bf16_rne(w[i]);
@@ -303,7 +324,7 @@ Act conv(Ctx& c, const Tens& x, const void* w, int ldw, const float* bias, const
   d.x = x.p; d.w = w; d.bias = bias; d.y = o.ncthw ? (void*)o.ncthw : (void*)r.y.p;
   d.B = x.B; d.Ti = x.T; d.Hi = x.H; d.Wi = x.W; d.Cin = x.ld;
   d.To = To; d.Ho = Ho; d.Wo = Wo; d.Cout = cout;
-  d.ldw = ldw; d.ldy = ldy;
+  d.ldw = c.m->x3 ? (ldw + 31) / 32 * 32 : ldw; d.ldy = ldy;
   d.KT = g.kt; d.KH = g.kh; d.KW = g.kw; d.st = g.st; d.sh = g.sh; d.sw = g.sw; d.pt = g.pt; d.ph = g.ph; d.pw = g.pw;
   d.tmode = g.pt > 0 ? o.tmode : VT_TPAD_ZERO;
   d.res_mode = o.res_mode;
@@ -313,7 +334,7 @@ Act conv(Ctx& c, const Tens& x, const void* w, int ldw, const float* bias, const
   }
   d.out_layout = o.ncthw ? VT_NCTHW : VT_NDHWC;
   d.t_trim = o.t_trim;
-  d.dtype = x.dt; d.out_dtype = o.ncthw ? VT_F32 : c.m->dt;
+  d.dtype = c.m->x3 ? VT_BF16X3 : x.dt; d.out_dtype = o.ncthw ? VT_F32 : c.m->dt;
   d.nbatch = 1;
   d.yt_mul = o.yt_mul; d.yt_off = o.yt_off;
   if (o.ys) { d.ys_mul = 2; d.ys_oh = o.ys_oh; d.ys_ow = o.ys_ow; }
@@ -452,7 +473,7 @@ struct Attn : Stage {              // AttnBlockWrapper, model_3dcausal.py:83-141
     const Geom g1;
     const Tens q = conv(c, hn, m->conv_w(key + ".q.conv.weight", Cc, c.dry), Cc, m->f32(key + ".q.conv.bias", c.dry), g1, ch, ConvOpts()).y;
     const Tens k = conv(c, hn, m->conv_w(key + ".k.conv.weight", Cc, c.dry), Cc, m->f32(key + ".k.conv.bias", c.dry), g1, ch, ConvOpts()).y;
-    const void* wv = m->conv_w(key + ".v.conv.weight", Cc, c.dry);
+    const void* wv = m->conv_w(key + ".v.conv.weight", Cc, c.dry, nullptr, 0, 0, true);
     const float* bv = m->f32(key + ".v.conv.bias", c.dry);
     // V^T directly: the weight is the row operand; v's bias is added after P V (rows of P sum to 1)
     char* vT = gemm_nt(c, wv, false, hn.p, Z, Cc, S, Cc, dt, dt, Sp, nullptr);                // [Z][C][Sp]
@@ -779,7 +800,7 @@ struct vt_model {
 extern "C" int vt_create(const vt_model_config* cfg, int32_t compute_dtype, vt_model** out) {
   try {
     M_CHECK(cfg != nullptr && out != nullptr, "vt_create: null argument");
-    M_CHECK(compute_dtype == VT_BF16 || compute_dtype == VT_F32, "vt_create: compute dtype must be VT_BF16 or VT_F32");
+    M_CHECK(compute_dtype == VT_BF16 || compute_dtype == VT_F32 || compute_dtype == VT_BF16X3, "vt_create: compute dtype must be VT_BF16, VT_F32 or VT_BF16X3");
     M_CHECK(cfg->version == 0 || cfg->version == 1, "vt_create: version 0 (v1.0 causal) or 1 (v1.1 causal, one pass per clip); the non-causal family stays with the Python host");
     M_CHECK(cfg->interpolation_mode == 0 || (cfg->interpolation_mode == 1 && cfg->version == 1), "vt_create: interpolation_mode 0 (nearest) or, for v1.1, 1 (trilinear)");
     M_CHECK(cfg->num_resolutions >= 1 && cfg->num_resolutions <= 8 && cfg->num_res_blocks >= 1 && cfg->ch > 0, "vt_create: bad level / block counts");
@@ -791,7 +812,8 @@ extern "C" int vt_create(const vt_model_config* cfg, int32_t compute_dtype, vt_m
     for (int i = 0; i < cfg->n_tempo_us; ++i) M_CHECK(in_list(cfg->spatial_us, cfg->n_spatial_us, cfg->tempo_us[i]), "vt_create: tempo_us must be a subset of spatial_us");
     auto* h = new vt_model();
     h->m.cfg = *cfg;
-    h->m.dt = compute_dtype;
+    h->m.x3 = compute_dtype == VT_BF16X3;              // fp32 storage, split-bf16 convolutions (set_compute_dtype("bf16x3") of the Python host)
+    h->m.dt = h->m.x3 ? VT_F32 : compute_dtype;
     h->enc = build_encoder(*cfg, h->shapes);
     h->dec = build_decoder(*cfg, h->shapes);
     for (const auto& kv : h->shapes) h->names.push_back(kv.first);
