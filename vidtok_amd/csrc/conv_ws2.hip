@@ -128,7 +128,10 @@ __global__ __launch_bounds__(512, 1) void conv3x3_ws2_kernel(const ConvArgs p) {
     if (tid < 128) v = LN != 0 ? p.ln_gamma[tid] : 1.0f;
     else if (tid < 256) v = LN != 0 ? p.ln_beta[tid - 128] : 0.0f;
     else v = p.bias ? p.bias[tid - 256] : 0.0f;
-    prm[tid] = v;
+    // channel c = 8 oct + 4 half + e of an array at [half][oct][e]: the 16 lanes of a row read 256 contiguous bytes (in channel
+    // order lanes oct and oct + 8 of a ds_read_b128 group share their banks: every parameter read 2-way conflicted)
+    const int c = tid & 127;
+    prm[(tid & ~127) + ((c >> 2) & 1) * 64 + (c >> 3) * 4 + (c & 3)] = v;
   }
 
   // Tile cursor: (frame, h0, w0) of a tile, stepped through the workgroup's run of tiles by additions -- a wave issues one
@@ -261,16 +264,16 @@ __global__ __launch_bounds__(512, 1) void conv3x3_ws2_kernel(const ConvArgs p) {
     __amdgpu_buffer_rsrc_t yrs, nrs;
     if constexpr (KEEP) yrs = __builtin_amdgcn_make_buffer_rsrc(yg + (long long)tc.f * H * W * 128, 0, frame_bytes, 0x00020000);
     if constexpr (LN != 0) nrs = __builtin_amdgcn_make_buffer_rsrc(ng + (long long)tc.f * H * W * 128, 0, frame_bytes, 0x00020000);
-    const float* pl = prm + 8 * oct_j;                         // gamma of channels [8 oct_j, +8); beta + 128, bias + 256
+    const float* pl = prm + 4 * oct_j;                         // gamma of channels [8 oct_j, +4) and, 64 floats on, [8 oct_j + 4, +4); beta + 128, bias + 256
     f32x4 g0, g1, b0, b1;
     if constexpr (LN != 0) {
       g0 = *reinterpret_cast<const f32x4*>(pl);
-      g1 = *reinterpret_cast<const f32x4*>(pl + 4);
+      g1 = *reinterpret_cast<const f32x4*>(pl + 64);
       b0 = *reinterpret_cast<const f32x4*>(pl + 128);
-      b1 = *reinterpret_cast<const f32x4*>(pl + 132);
+      b1 = *reinterpret_cast<const f32x4*>(pl + 192);
     }
     const f32x4 o0 = *reinterpret_cast<const f32x4*>(pl + 256);
-    const f32x4 o1 = *reinterpret_cast<const f32x4*>(pl + 260);
+    const f32x4 o1 = *reinterpret_cast<const f32x4*>(pl + 320);
     // lane slot `it`: row m = row_l + 16 it of the sub-tile; subtile_pixel(m + 16) = (1 - rsel(m), col(m) + 8)
     int rsel0, col0;
     subtile_pixel(row_l, rsel0, col0);

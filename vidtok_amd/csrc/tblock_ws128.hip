@@ -83,10 +83,13 @@ __device__ __forceinline__ uint32_t tb_pack2(f32x2 v) {              // round-to
 // LDS: two rings of three 64-row slots (bf16 rows of 272 B: 256 + 16 pad), T1 (conv1 rounded to bf16, 272-B rows; b1 is
 // added by the rows that read it), T2 (conv2 in fp32, 16-B chunks XOR-swizzled by row), the LayerNorm affines and biases.
 // ---------------------------------------------------------------------------------------------------------------------
-[[maybe_unused]] constexpr int T3_T1P = 272;                              // bytes per T1 row: 128 bf16 + 16 pad (16-B aligned rows)
+// T1 rows: 128 bf16 = 256 B, the sixteen 16-B chunks of a row XOR-swizzled by row % 16 (a row read = 16 lanes x 16 B is then a
+// permutation of one 256-B bank line, and the two rows a ds_read_b128 lane group spans -- lanes {0-3, 12-15} of row 4 w, {20-27} of
+// row 4 w + 1 -- land in complementary bank quads; with 272-B padded rows one quad of every group was hit twice)
+[[maybe_unused]] constexpr int T3_T1P = 256;
 [[maybe_unused]] constexpr int T3_OFF_T1 = 2 * TB_RING;
 [[maybe_unused]] constexpr int T3_OFF_T2 = 2 * TB_RING + TB_PIX * T3_T1P;
-[[maybe_unused]] constexpr int T3_LDS = T3_OFF_T2 + TB_T;                 // 154 624
+[[maybe_unused]] constexpr int T3_LDS = T3_OFF_T2 + TB_T;                 // 153 600
 __device__ __forceinline__ void t3_unpack8(const u32x4& w, float (&v)[8]) {
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
@@ -120,10 +123,10 @@ __device__ __forceinline__ u32x4 t3_pack8(const float (&o)[8]) {
 // all addressing is 32-bit through buffer descriptors rebased to the frame, the (column, frame) of a virtual step is
 // carried by additions.  Row arithmetic: plain fp32, element order of the two-role kernel (L1 sums the even and the odd
 // channels separately, as its packed form did): the two arrangements agreed to the bit when both existed.
-// LDS: 154 624 + 4 096 = 158 720 B.
+// LDS: 153 600 + 4 096 = 157 696 B.
 // ---------------------------------------------------------------------------------------------------------------------
 [[maybe_unused]] constexpr int T4_OFF_PRM = T3_LDS;                       // g1 | be1 | g2 | be2 | gn | ben | b1 | b2, 128 fp32 each
-[[maybe_unused]] constexpr int T4_LDS = T4_OFF_PRM + 8 * 128 * 4;         // 158 720
+[[maybe_unused]] constexpr int T4_LDS = T4_OFF_PRM + 8 * 128 * 4;         // 157 696
 [[maybe_unused]] constexpr int T4_FD = 3;                                 // fragment prefetch distance of a GEMM, in MFMAs
 
 template <bool FIRST>
@@ -214,14 +217,18 @@ __global__ __launch_bounds__(512, 1) void tblock_pair_kernel(const TBlockArgs p)
   float* prm = reinterpret_cast<float*>(smem + T4_OFF_PRM);
   {
     const int c = tid & 127, a = tid >> 7;                           // arrays a and a + 4
+    // channel c = 8 oct + 4 half + e of an array sits at [half][oct][e]: the 16 lanes of a row read their first (second) four
+    // values as 256 contiguous bytes.  In channel order (32 B per lane) lanes oct and oct + 8 of a ds_read_b128 group met in
+    // the same banks -- every parameter read 2-way conflicted, 23 % of the kernel's LDS cycles (profiles/r03_bench_bf16_sq_pmc.txt)
+    const int pc = ((c >> 2) & 1) * 64 + (c >> 3) * 4 + (c & 3);
     const float* src0 = a == 0 ? p.g1 : (a == 1 ? p.be1 : (a == 2 ? p.g2 : p.be2));
-    prm[a * 128 + c] = src0[c];
+    prm[a * 128 + pc] = src0[c];
     float v;
     if (a == 0) v = LNN ? p.gn[c] : 1.0f;
     else if (a == 1) v = LNN ? p.ben[c] : 0.0f;
     else if (a == 2) v = p.b1 ? p.b1[c] : 0.0f;
     else v = p.b2 ? p.b2[c] : 0.0f;
-    prm[(a + 4) * 128 + c] = v;
+    prm[(a + 4) * 128 + pc] = v;
   }
 
   // ---- virtual step -> (batch, pixel tile, frame), carried by additions
@@ -327,7 +334,8 @@ __global__ __launch_bounds__(512, 1) void tblock_pair_kernel(const TBlockArgs p)
   auto acc_to_T1 = [&]() __attribute__((always_inline)) {                                           // rounded to bf16 (8 B per quad); b1 is added by the rows
     int lo = lane;
     asm volatile("" : "+v"(lo));
-    const int base = T3_OFF_T1 + (lo & 31) * T3_T1P + (cw * 32 + 4 * (lo >> 5)) * 2;
+    const int l31 = lo & 31;
+    const int base = T3_OFF_T1 + l31 * T3_T1P + 8 * (lo >> 5);       // chunk 4 cw + g of the row, half lane / 32, at slot chunk ^ (row % 16)
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -335,7 +343,7 @@ __global__ __launch_bounds__(512, 1) void tblock_pair_kernel(const TBlockArgs p)
         u32x2 w;
         w[0] = tb_pack2(f32x2{acc[j][4 * g], acc[j][4 * g + 1]});
         w[1] = tb_pack2(f32x2{acc[j][4 * g + 2], acc[j][4 * g + 3]});
-        *reinterpret_cast<u32x2*>(smem + base + j * (32 * T3_T1P) + g * 16) = w;
+        *reinterpret_cast<u32x2*>(smem + base + j * (32 * T3_T1P) + (((4 * cw + g) ^ (l31 & 15)) << 4)) = w;
       }
   };
   auto acc_to_T2 = [&]() __attribute__((always_inline)) {                                           // fp32, 16-B chunk (8 cw + 2 g + h) ^ (row % 32) of row 32 j + lane % 32
@@ -363,8 +371,8 @@ __global__ __launch_bounds__(512, 1) void tblock_pair_kernel(const TBlockArgs p)
     row0 = vt >> 4;
   };
   auto ld_prm = [&](int arr, int oct_j, float (&o)[8]) __attribute__((always_inline)) {
-    const f32x4 a = *reinterpret_cast<const f32x4*>(prm + arr * 128 + 8 * oct_j);
-    const f32x4 b = *reinterpret_cast<const f32x4*>(prm + arr * 128 + 8 * oct_j + 4);
+    const f32x4 a = *reinterpret_cast<const f32x4*>(prm + arr * 128 + 4 * oct_j);
+    const f32x4 b = *reinterpret_cast<const f32x4*>(prm + arr * 128 + 64 + 4 * oct_j);
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       o[e] = a[e];
@@ -500,7 +508,7 @@ __global__ __launch_bounds__(512, 1) void tblock_pair_kernel(const TBlockArgs p)
     ld_prm(6, oct_j, bo1);
     ld_prm(2, oct_j, g);
     ld_prm(3, oct_j, b);
-    const int ro = T3_OFF_T1 + row0 * T3_T1P + oct_j * 16;
+    const int ro = T3_OFF_T1 + row0 * T3_T1P + ((oct_j ^ row0) << 4);    // rows row0 + 16 it: swizzle key row % 16 = row0
     const int wo = R2 + sl * TB_SLOT + row0 * TB_ROWP + oct_j * 16;
     u32x4 tw[4];
 #pragma unroll
