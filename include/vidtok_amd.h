@@ -368,15 +368,31 @@ int vt_entropy(const float* avg, int64_t J, float* out, vt_stream stream);
  *   vt_regularize_fsq(h, pre, z, indices, B, T', H', W', stream)                     = vt_fsq_quantize
  *   vt_indices_to_latent(h, indices, z, B, T', H', W', stream)                       = vt_fsq_indices_to_codes
  *   vt_decode(h, z, B, T', H', W', x_out, ws, ws_bytes, stream)  z fp32 NCTHW -> x_out fp32 [B][out_ch][T][H][W]
- *   vt_reset_cache(h)                        nothing to reset: a call is one pass over the clip.  v1.1 (version 1): the
- *                                            encoder pads T up to a multiple of time_downsample_factor in front and
- *                                            vt_decode returns all T' * factor frames -- the caller keeps the last T, as
- *                                            AutoencodingEngine.forward does (autoencoder_v1_1.py:339-341); the temporal
- *                                            TILING of v1.1 (chunk caches) and the non-causal family stay with the Python host
- * All device pointers; every call is asynchronous on `stream`; the workspace must outlive the work queued on it.
+ *   vt_regularize_fsq_aux(h, pre, B, T', H', W', inv_temperature, work, out3, stream)   the three statistics of FSQ's auxiliary
+ *                                            loss = vt_fsq_aux_stats with the handle's levels
+ *   v1.1 (version 1): the encoder pads T up to a multiple of time_downsample_factor in front and vt_decode returns all
+ *   T' * factor frames -- the caller keeps the last T, as AutoencodingEngine.forward does (autoencoder_v1_1.py:339-341).
+ * Temporal tiling of the v1.1 models (AutoencodingEngine.tile_encode / tile_decode, autoencoder_v1_1.py:218-331): the clip
+ * runs as chunks [0,1), [1,1+c), [1+c,1+2c) ... through the same graph, every causal convolution and time resampler
+ * keeping its last frames in device buffers owned by the handle (the reference's `causal_cache` attributes):
+ *   vt_tile_latent_frames(h, T, t_chunk_enc)      T' of a tiled encode = sum over the chunks of ceil(frames / factor)
+ *   vt_tile_workspace_bytes(h, B, T, H, W, t_chunk_enc, use_overlap)   workspace of vt_tile_encode + vt_tile_decode
+ *   vt_tile_encode(h, x, B, T, H, W, t_chunk_enc, h_out, ws, ws_bytes, stream)     h_out fp32 [B][C'][T'][H'][W']; the
+ *                                            regularizer then runs on the whole latent (it is per position)
+ *   vt_tile_decode(h, z, B, T', H', W', t_chunk_dec, use_overlap, x_out, ws, ws_bytes, stream)   t_chunk_dec = t_chunk_enc /
+ *                                            factor; use_overlap = one look-ahead latent frame per chunk whose output frames
+ *                                            are dropped, with the doubling cache offsets of the reference (:307-320);
+ *                                            x_out fp32 [B][out_ch][T' * factor][H][W]
+ *   vt_reset_cache(h)                        drops the chunk state and frees its buffers (synchronises the device); the
+ *                                            tiled calls reset the state themselves at the start of a clip
+ * The non-causal family stays with the Python host.
+ * All device pointers; the calls are asynchronous on `stream` except that (a) the FIRST use of a weight packs it on the host
+ * and uploads it with a blocking copy and (b) a chunk cache is hipMalloc'ed the first time a chunk kind needs it -- run one
+ * warm-up call before capturing a stream.  A handle keeps per-call state (arenas, caches): one call at a time per handle.
+ * The workspace must outlive the work queued on it.
  * ---------------------------------------------------------------------------------------- */
 typedef struct vt_model_config {
-  int32_t version;               /* 0 = v1.0 causal, 1 = v1.1 causal (replicate padding; one pass per clip)      */
+  int32_t version;               /* 0 = v1.0 causal, 1 = v1.1 causal (replicate padding; one pass or temporal tiling) */
   int32_t ch, num_res_blocks, in_channels, out_ch, z_channels, double_z;
   int32_t num_resolutions;       /* len(ch_mult)                                                                */
   int32_t ch_mult[8];
@@ -408,6 +424,14 @@ int vt_indices_to_latent(vt_model* h, const int32_t* indices, float* z, int32_t 
 int vt_decode(vt_model* h, const float* z, int32_t B, int32_t Tz, int32_t Hz, int32_t Wz, float* x_out, void* workspace,
               int64_t workspace_bytes, vt_stream stream);
 int vt_reset_cache(vt_model* h);
+int vt_regularize_fsq_aux(vt_model* h, const float* pre, int32_t B, int32_t Tz, int32_t Hz, int32_t Wz, float inv_temperature,
+                          float* work, float* out3, vt_stream stream);
+int32_t vt_tile_latent_frames(const vt_model* h, int32_t T, int32_t t_chunk_enc);
+int64_t vt_tile_workspace_bytes(vt_model* h, int32_t B, int32_t T, int32_t H, int32_t W, int32_t t_chunk_enc, int32_t use_overlap);
+int vt_tile_encode(vt_model* h, const float* x, int32_t B, int32_t T, int32_t H, int32_t W, int32_t t_chunk_enc, float* h_out,
+                   void* workspace, int64_t workspace_bytes, vt_stream stream);
+int vt_tile_decode(vt_model* h, const float* z, int32_t B, int32_t Tz, int32_t Hz, int32_t Wz, int32_t t_chunk_dec, int32_t use_overlap,
+                   float* x_out, void* workspace, int64_t workspace_bytes, vt_stream stream);
 
 /* ------------------------------------------------------------------------------------------
  * Video front / back end around model(x): the device halves of scripts/inference_reconstruct.py (the codec --

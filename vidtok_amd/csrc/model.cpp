@@ -8,9 +8,10 @@
 // convolution emits which LayerNorm, the fused temporal block, the parity classes of the up-samplers), so its results
 // equal the Python engine's bit for bit (tests/test_gpu_e2e.py::test_model_handle_matches_engine drives it through ctypes
 // only).  Scope: `norm_type: layernorm`, `resamp_with_conv: true` -- every shipped causal config, v1.0 and v1.1 (first-frame
-// replicate padding, nearest or trilinear time up-sampling, model_3dcausal_v1_1.py) as ONE pass over the clip.  The temporal
-// tiling of v1.1 (chunk caches, AutoencodingEngine.tile_encode / tile_decode) and the non-causal family stay with the
-// Python host.
+// replicate padding, nearest or trilinear time up-sampling, model_3dcausal_v1_1.py) as ONE pass over the clip, and the
+// temporal TILING of v1.1 (vt_tile_encode / vt_tile_decode: the chunk schedule, the per-module causal caches, the decoder's
+// look-ahead frame with its cache offsets -- AutoencodingEngine.tile_encode / tile_decode, autoencoder_v1_1.py:202-331).  The
+// non-causal family stays with the Python host.
 //
 // Memory: weights are packed on the host when first used and live in device allocations owned by the handle;
 // activations come from a caller-provided workspace, cut into two arenas that alternate between stages (a stage reads the
@@ -128,8 +129,37 @@ struct DevBuf {
   }
 };
 
+// Chunk-to-chunk state of one module of a v1.1 tiled pass: the last frames of a causal convolution's input
+// (CausalConv*.causal_cache, model_3dcausal_v1_1.py:155-178) or the frames a time resampler keeps (:286-300, 323-343).  The
+// buffer is owned by the handle and rewritten in place; `offset` = the module's cache_offset of an overlapped decode.
+struct CState {
+  std::unique_ptr<DevBuf> buf;
+  size_t cap = 0;
+  int frames = 0;                  // frames held (0 = nothing cached yet)
+  int offset = 0;
+};
+
 struct Model {
   vt_model_config cfg;
+  bool tiled = false;              // a chunk of a tiled pass is running: causal convolutions read / leave caches
+  bool first_chunk = true;
+  std::vector<CState*> states;     // every CState of both graphs (vt_reset_cache)
+  std::vector<std::unique_ptr<DevBuf>> retired;   // outgrown cache buffers: work queued on them may still run; freed at reset / destroy
+  // the cache buffer of `st` with room for `bytes` (grown by a synchronous hipMalloc the first time a chunk kind needs it)
+  char* persistent(CState& st, size_t bytes, bool dry) {
+    if (dry) return nullptr;
+    if (st.cap < bytes) {
+      auto b = std::make_unique<DevBuf>();
+      if (hipMalloc(&b->p, bytes) != hipSuccess) {
+        vt_set_error("vt_model: hipMalloc of a %zu-byte chunk cache failed", bytes);
+        throw Fail{VT_ERR_HIP};
+      }
+      if (st.buf) retired.push_back(std::move(st.buf));
+      st.buf = std::move(b);
+      st.cap = bytes;
+    }
+    return (char*)st.buf->p;
+  }
   int dt;                          // storage type of the activations (VT_BF16 | VT_F32)
   bool x3 = false;                 // VT_BF16X3: fp32 storage, convolutions on split-bf16 weight planes (three bf16 MFMAs per product)
   bool v11() const { return cfg.version == 1; }
@@ -301,6 +331,8 @@ struct ConvOpts {
   float* ncthw = nullptr;          // write fp32 NCTHW here instead
   int t_trim = 0;
   int tmode = VT_TPAD_ZERO;
+  const void* cache = nullptr;     // tmode VT_TPAD_CACHE: [B][ncache][H][W][ld]
+  int ncache = 0;
 };
 
 // mirror of vidtok_amd/ops.py::conv
@@ -327,6 +359,7 @@ Act conv(Ctx& c, const Tens& x, const void* w, int ldw, const float* bias, const
   d.ldw = c.m->x3 ? (ldw + 31) / 32 * 32 : ldw; d.ldy = ldy;
   d.KT = g.kt; d.KH = g.kh; d.KW = g.kw; d.st = g.st; d.sh = g.sh; d.sw = g.sw; d.pt = g.pt; d.ph = g.ph; d.pw = g.pw;
   d.tmode = g.pt > 0 ? o.tmode : VT_TPAD_ZERO;
+  if (d.tmode == VT_TPAD_CACHE) { d.cache = o.cache; d.ncache = o.ncache; }
   d.res_mode = o.res_mode;
   if (o.res_mode != VT_RES_NONE) {
     d.res = o.res->p; d.res_tshift = 0; d.Tr = o.res->T; d.ldr = o.res->ld;
@@ -347,6 +380,68 @@ Act conv(Ctx& c, const Tens& x, const void* w, int ldw, const float* bias, const
     r.norm = o.ln.norm; r.silu = o.ln.silu;
   }
   if (!c.dry) M_CALL(vt_conv(&d, c.stream));
+  return r;
+}
+
+// frames idx[0..n) of src [B][Ts][frame] -> dst frames [t0, t0 + n) of [B][Td][frame] (vidtok_amd/ops.py::gather_frames)
+void gather(Ctx& c, const char* src, int Ts, char* dst, int Td, int t0, const std::vector<int>& idx, int B, int64_t frame_elems, int es) {
+  for (size_t j0 = 0; j0 < idx.size(); j0 += 128) {
+    int32_t part[128];
+    const int n = (int)std::min<size_t>(128, idx.size() - j0);
+    for (int j = 0; j < n; ++j) part[j] = idx[j0 + j];
+    if (!c.dry)
+      M_CALL(vt_gather_frames(src, dst + (size_t)(t0 + (int)j0) * frame_elems * es, es, B, frame_elems, (int64_t)Ts * frame_elems, (int64_t)Td * frame_elems, part, n, c.stream));
+  }
+}
+
+// _CausalState._update_cache (vidtok_amd/modules.py; reference model_3dcausal_v1_1.py:172-176): keep the last P frames of
+// padded[: len - offset], padded = [P pad frames (x[0] repeated on the first chunk | the previous cache), x]
+void update_cache(Ctx& c, CState& st, const Tens& x, int P) {
+  if (P == 0) return;
+  Model* m = c.m;
+  const int T = x.T, off = st.offset, es = (int)esize(x.dt);
+  const int64_t fr = (int64_t)x.H * x.W * x.ld;
+  std::vector<int> sx, sc;
+  int jx = -1, jc = -1;
+  for (int j = 0; j < P; ++j) {
+    const int q = T - off + j;                      // index into the padded sequence
+    M_CHECK(q >= 0, "vt_model: chunk of %d frames is shorter than its cache offset %d", T, off);
+    if (q >= P) { if (jx < 0) jx = j; sx.push_back(q - P); }
+    else if (m->first_chunk) { if (jx < 0) jx = j; sx.push_back(0); }
+    else { if (jc < 0) jc = j; sc.push_back(q); }
+  }
+  // frames kept from the old cache move inside the buffer they are read from: through a temporary (stream order)
+  char* kept = nullptr;
+  if (!sc.empty()) {
+    M_CHECK(c.dry || st.frames >= P, "vt_model: causal cache missing (the first chunk must come first)");
+    kept = c.cur->alloc((size_t)x.B * sc.size() * fr * es, c.dry);
+    gather(c, c.dry ? nullptr : (const char*)st.buf->p, P, kept, (int)sc.size(), 0, sc, x.B, fr, es);
+  }
+  char* buf = m->persistent(st, (size_t)x.B * P * fr * es, c.dry);
+  if (kept) {
+    std::vector<int> id(sc.size());
+    for (size_t i = 0; i < id.size(); ++i) id[i] = (int)i;
+    gather(c, kept, (int)sc.size(), buf, P, jc, id, x.B, fr, es);
+  }
+  if (!sx.empty()) gather(c, x.p, T, buf, P, jx, sx, x.B, fr, es);
+  if (!c.dry) st.frames = P;
+}
+
+// a causal convolution with chunk state: CausalConv3d.run / CausalConv1d.run of vidtok_amd/modules.py
+Act conv_causal(Ctx& c, CState& st, const Tens& x, const void* w, int ldw, const float* bias, const Geom& g, int cout, ConvOpts o) {
+  Model* m = c.m;
+  const int P = g.pt;
+  if (m->tiled && P > 0) {
+    if (m->first_chunk) o.tmode = VT_TPAD_REPLICATE;
+    else {
+      M_CHECK(c.dry || st.frames >= P, "vt_model: causal cache missing (the first chunk must come first)");
+      o.tmode = VT_TPAD_CACHE;
+      o.cache = c.dry ? (const void*)16 : st.buf->p;
+      o.ncache = c.dry ? P : st.frames;
+    }
+  }
+  const Act r = conv(c, x, w, ldw, bias, g, cout, o);
+  if (m->tiled) update_cache(c, st, x, P);
   return r;
 }
 
@@ -374,6 +469,8 @@ struct Stage {
   virtual ~Stage() {}
   virtual NormRef first_norm(Ctx&) const { return NormRef(); }      // the norm this stage wants from its producer
   virtual Act run(Ctx& c, const Act& x, NormRef next) = 0;
+  virtual void states(std::vector<CState*>&) {}                     // the chunk state this stage keeps in a tiled pass
+  virtual bool time_up() const { return false; }                    // a temporal up-sampler: cache offsets double from here on
 };
 
 ConvOpts emit(NormRef next, int tmode = VT_TPAD_ZERO) {
@@ -393,6 +490,10 @@ struct ResBlock : Stage {          // ResnetBlock (2-D per frame) or ResnetCausa
   int cin, cout;
   Norm n1, n2;
   ConvParams c1, c2, sc;
+  CState s1, s2;                   // the 3-D causal block's convolutions keep two frames each in a tiled pass
+  void states(std::vector<CState*>& v) override {
+    if (causal3d_) { v.push_back(&s1); v.push_back(&s2); }
+  }
   NormRef first_norm(Ctx&) const override { return NormRef{&n1, true}; }
   Act run(Ctx& c, const Act& x, NormRef next) override {
     Model* m = c.m;
@@ -403,13 +504,13 @@ struct ResBlock : Stage {          // ResnetBlock (2-D per frame) or ResnetCausa
     o1.keep_y = false;             // conv1's result is only ever seen through norm2 + SiLU
     o1.tmode = m->tpad();
     const int taps = causal3d_ ? 27 : 9;
-    const Act h2 = conv(c, h, m->conv_w(c1.key + ".weight", h.ld, c.dry), taps * h.ld, m->f32(c1.key + ".bias", c.dry), g3, cout, o1);
+    const Act h2 = conv_causal(c, s1, h, m->conv_w(c1.key + ".weight", h.ld, c.dry), taps * h.ld, m->f32(c1.key + ".bias", c.dry), g3, cout, o1);
     Tens xs = x.y;
     if (cin != cout) xs = conv(c, x.y, m->conv_w(sc.key + ".weight", x.y.ld, c.dry), x.y.ld, m->f32(sc.key + ".bias", c.dry), g1, cout, ConvOpts()).y;
     ConvOpts o2 = emit(next, m->tpad());
     o2.res = &xs;
     o2.res_mode = VT_RES_ADD;
-    return conv(c, h2.n, m->conv_w(c2.key + ".weight", h2.n.ld, c.dry), taps * h2.n.ld, m->f32(c2.key + ".bias", c.dry), g3, cout, o2);
+    return conv_causal(c, s2, h2.n, m->conv_w(c2.key + ".weight", h2.n.ld, c.dry), taps * h2.n.ld, m->f32(c2.key + ".bias", c.dry), g3, cout, o2);
   }
 };
 
@@ -417,7 +518,16 @@ struct TBlock : Stage {            // ResnetCausalBlock1D, model_3dcausal.py:427
   int ch;
   Norm n1, n2;
   ConvParams c1, c2;               // CausalConv1d: parameters at key + ".conv.weight"
-  bool fusable(const Ctx& c) const { return c.m->dt == VT_BF16 && ch == 128 && n1.eps == n2.eps; }
+  CState s1, s2;                   // chunk state of the two convolutions: [B][2][H][W][C] each
+  void states(std::vector<CState*>& v) override { v.push_back(&s1); v.push_back(&s2); }
+  // ResnetCausalBlock1D._fusable (vidtok_amd/modules.py): one launch for bf16, C = 128; in a tiled pass both convolutions must
+  // stand at the same point of the chunk schedule and, past the first chunk, both caches must be there
+  bool fusable(const Ctx& c) const {
+    if (!(c.m->dt == VT_BF16 && ch == 128 && n1.eps == n2.eps)) return false;
+    if (!c.m->tiled) return true;
+    if (s1.offset != s2.offset) return false;
+    return c.m->first_chunk || c.dry || (s1.frames >= 2 && s2.frames >= 2);
+  }
   NormRef first_norm(Ctx& c) const override { return fusable(c) ? NormRef() : NormRef{&n1, true}; }
   Act run(Ctx& c, const Act& x, NormRef next) override {
     Model* m = c.m;
@@ -427,7 +537,17 @@ struct TBlock : Stage {            // ResnetCausalBlock1D, model_3dcausal.py:427
     vt_tblock_desc d;
     memset(&d, 0, sizeof(d));
     d.dtype = xp.dt; d.C = ch; d.ld = xp.ld; d.B = xp.B; d.T = xp.T; d.HW = (int64_t)xp.H * xp.W; d.tmode = m->tpad();
-    if (fusable(c) && vt_temporal_block_supported(&d)) {
+    const bool fus = fusable(c);
+    if (fus && m->tiled) {           // the launch keeps the chunk state itself: both caches rewritten in place
+      const size_t cb = (size_t)xp.B * 2 * xp.H * xp.W * xp.ld * esize(xp.dt);
+      d.tmode = m->first_chunk ? VT_TPAD_REPLICATE : VT_TPAD_CACHE;
+      d.cache1 = m->persistent(s1, cb, c.dry);
+      d.cache2 = m->persistent(s2, cb, c.dry);
+      if (c.dry) d.cache1 = d.cache2 = (void*)16;
+      d.cache_offset = s1.offset;
+    }
+    if (fus && vt_temporal_block_supported(&d)) {
+      if (m->tiled && !c.dry) s1.frames = s2.frames = 2;
       Act r;
       r.y = c.alloc(xp.B, xp.T, xp.H, xp.W, xp.ld, xp.dt, ch);
       const bool nx = next.norm != nullptr && next.norm->eps == n1.eps;
@@ -451,11 +571,11 @@ struct TBlock : Stage {            // ResnetCausalBlock1D, model_3dcausal.py:427
     o1.ln = NormRef{&n2, true};
     o1.keep_y = false;
     o1.tmode = m->tpad();
-    const Act h2 = conv(c, h, m->conv_w(c1.key + ".conv.weight", h.ld, c.dry), 3 * h.ld, m->f32(c1.key + ".conv.bias", c.dry), g, ch, o1);
+    const Act h2 = conv_causal(c, s1, h, m->conv_w(c1.key + ".conv.weight", h.ld, c.dry), 3 * h.ld, m->f32(c1.key + ".conv.bias", c.dry), g, ch, o1);
     ConvOpts o2 = emit(next, m->tpad());
     o2.res = &xp;
     o2.res_mode = VT_RES_ADD;
-    return conv(c, h2.n, m->conv_w(c2.key + ".conv.weight", h2.n.ld, c.dry), 3 * h2.n.ld, m->f32(c2.key + ".conv.bias", c.dry), g, ch, o2);
+    return conv_causal(c, s2, h2.n, m->conv_w(c2.key + ".conv.weight", h2.n.ld, c.dry), 3 * h2.n.ld, m->f32(c2.key + ".conv.bias", c.dry), g, ch, o2);
   }
 };
 
@@ -507,15 +627,33 @@ struct Down : Stage {              // Downsample: F.pad(0,1,0,1) + conv3x3 strid
 struct TimeDown : Stage {          // TimeDownsampleResCausal2x, model_3dcausal.py:233-252
   int ch;
   std::string key;                 // CausalConv3d at key + ".conv.conv.weight", key + ".mix_factor"
+  CState sc, sp;                   // the convolution's cache (one frame) and the pooling branch's (the chunk's last frame)
+  void states(std::vector<CState*>& v) override { v.push_back(&sc); v.push_back(&sp); }
   Act run(Ctx& c, const Act& x, NormRef next) override {
+    Model* m = c.m;
     const Tens& xp = x.y;
     Tens x1 = c.alloc(xp.B, xp.T / 2, xp.H, xp.W, xp.ld, xp.dt, xp.ld);
-    if (!c.dry) M_CALL(vt_time_avgpool3s2(xp.p, nullptr, x1.p, xp.dt, xp.B, xp.T, (int64_t)xp.H * xp.W, xp.ld, c.m->tpad(), c.stream));
-    ConvOpts o = emit(next, c.m->tpad());
+    int tm = m->tpad();
+    const void* pc = nullptr;
+    if (m->tiled) {                // TimeDownsampleResCausal2x.run of the Python host (model_3dcausal_v1_1.py:286-300)
+      tm = m->first_chunk ? VT_TPAD_REPLICATE : VT_TPAD_CACHE;
+      if (!m->first_chunk) {
+        M_CHECK(c.dry || sp.frames >= 1, "vt_model: time down-sampler cache missing (the first chunk must come first)");
+        pc = c.dry ? nullptr : sp.buf->p;
+      }
+    }
+    if (!c.dry) M_CALL(vt_time_avgpool3s2(xp.p, pc, x1.p, xp.dt, xp.B, xp.T, (int64_t)xp.H * xp.W, xp.ld, tm, c.stream));
+    if (m->tiled) {
+      const int64_t fr = (int64_t)xp.H * xp.W * xp.ld;
+      char* buf = m->persistent(sp, (size_t)xp.B * fr * esize(xp.dt), c.dry);
+      gather(c, xp.p, xp.T, buf, 1, 0, std::vector<int>{xp.T - 1}, xp.B, fr, (int)esize(xp.dt));
+      if (!c.dry) sp.frames = 1;
+    }
+    ConvOpts o = emit(next, m->tpad());
     o.res = &x1;
     o.res_mode = VT_RES_MIX;
-    o.mix = c.m->f32(key + ".mix_factor", c.dry);
-    return conv(c, xp, c.m->conv_w(key + ".conv.conv.weight", xp.ld, c.dry), 27 * xp.ld, c.m->f32(key + ".conv.conv.bias", c.dry), causal3d(3, 3, 3, 2, 1, 1), ch, o);
+    o.mix = m->f32(key + ".mix_factor", c.dry);
+    return conv_causal(c, sc, xp, m->conv_w(key + ".conv.conv.weight", xp.ld, c.dry), 27 * xp.ld, m->f32(key + ".conv.conv.bias", c.dry), causal3d(3, 3, 3, 2, 1, 1), ch, o);
   }
 };
 
@@ -542,10 +680,61 @@ struct TimeUp : Stage {            // TimeUpsampleResCausal2x: v1.0 nearest as t
   int ch;                          // v1.1 nearest / trilinear up-sampling, then the 27-tap convolution (model_3dcausal_v1_1.py:305-343)
   int n_up = 1;                    // num_temp_upsample: 1, 2, 4 ... along the decoder (how many frames the trilinear head covers)
   std::string key;
+  CState sc, su;                   // the convolution's cache (two frames) and the trilinear interpolation's (num_temp_upsample frames)
+  void states(std::vector<CState*>& v) override { v.push_back(&sc); v.push_back(&su); }
+  bool time_up() const override { return true; }
+  // later chunks of a tiled pass with trilinear up-sampling: [cache | x] interpolated, the frames the previous chunk already
+  // delivered left out (TimeUpsampleResCausal2x._interp_v11 of the Python host; model_3dcausal_v1_1.py:325-343)
+  Tens interp_cached(Ctx& c, const Tens& xp) {
+    Model* m = c.m;
+    const int n = n_up, T = xp.T, es = (int)esize(xp.dt);
+    const int64_t fr = (int64_t)xp.H * xp.W * xp.ld;
+    const int nc = c.dry ? n : su.frames;
+    M_CHECK(nc >= 1, "vt_model: time up-sampler cache missing (the first chunk must come first)");
+    const int Tc = nc + T;
+    const char* head = c.dry ? nullptr : (const char*)su.buf->p;
+    if (Tc - 2 * n >= nc) {
+      Tens up = c.alloc(xp.B, 2 * Tc - 2 * n, xp.H, xp.W, xp.ld, xp.dt, xp.ld);
+      if (!c.dry) M_CALL(vt_time_lerp2x_cat(head, nc, xp.p, up.p, xp.dt, xp.B, T, 2 * n, fr, c.stream));
+      std::vector<int> keep;
+      for (int t = Tc - 2 * n - nc; t < Tc - n - nc; ++t) keep.push_back(t);
+      char* buf = m->persistent(su, (size_t)xp.B * keep.size() * fr * es, c.dry);
+      gather(c, xp.p, T, buf, (int)keep.size(), 0, keep, xp.B, fr, es);
+      if (!c.dry) su.frames = (int)keep.size();
+      return up;
+    }
+    Tens xc = c.alloc(xp.B, Tc, xp.H, xp.W, xp.ld, xp.dt, xp.ld);     // [cache | x]
+    std::vector<int> all;
+    for (int t = 0; t < nc; ++t) all.push_back(t);
+    gather(c, head, nc, xc.p, Tc, 0, all, xp.B, fr, es);
+    all.clear();
+    for (int t = 0; t < T; ++t) all.push_back(t);
+    gather(c, xp.p, T, xc.p, Tc, nc, all, xp.B, fr, es);
+    std::vector<int> keep;
+    for (int t = std::max(0, Tc - 2 * n); t < Tc - n; ++t) keep.push_back(t);
+    char* buf = m->persistent(su, (size_t)xp.B * keep.size() * fr * es, c.dry);   // (xc is a copy: the cache buffer is free to be rewritten)
+    gather(c, xc.p, Tc, buf, (int)keep.size(), 0, keep, xp.B, fr, es);
+    if (!c.dry) su.frames = (int)keep.size();
+    Tens full = c.alloc(xp.B, 2 * Tc, xp.H, xp.W, xp.ld, xp.dt, xp.ld);
+    if (!c.dry) M_CALL(vt_time_lerp2x(xc.p, full.p, xp.dt, xp.B, Tc, fr, c.stream));
+    Tens up = c.alloc(xp.B, 2 * Tc - 2 * n, xp.H, xp.W, xp.ld, xp.dt, xp.ld);
+    all.clear();
+    for (int t = 2 * n; t < 2 * Tc; ++t) all.push_back(t);
+    gather(c, full.p, 2 * Tc, up.p, 2 * Tc - 2 * n, 0, all, xp.B, fr, es);
+    return up;
+  }
+  Act conv_of(Ctx& c, const Tens& up, NormRef next) {
+    ConvOpts o = emit(next, VT_TPAD_REPLICATE);
+    o.res = &up;
+    o.res_mode = VT_RES_MIX;
+    o.mix = c.m->f32(key + ".mix_factor", c.dry);
+    return conv_causal(c, sc, up, c.m->conv_w(key + ".conv.conv.weight", up.ld, c.dry), 27 * up.ld, c.m->f32(key + ".conv.conv.bias", c.dry), causal3d(3, 3, 3), ch, o);
+  }
   Act run_v11(Ctx& c, const Act& x, NormRef next) {
     const Tens& xp = x.y;
     const int T = xp.T;
     const int64_t fr = (int64_t)xp.H * xp.W * xp.ld;
+    if (c.m->tiled && !c.m->first_chunk && c.m->cfg.interpolation_mode == 1) return conv_of(c, interp_cached(c, xp), next);
     Tens up = c.alloc(xp.B, 2 * T, xp.H, xp.W, xp.ld, xp.dt, xp.ld);
     if (c.m->cfg.interpolation_mode == 0) {                            // nearest: up[t] = x[t / 2]
       for (int j0 = 0; j0 < 2 * T; j0 += 128) {
@@ -570,14 +759,17 @@ struct TimeUp : Stage {            // TimeUpsampleResCausal2x: v1.0 nearest as t
           if (!c.dry)
             M_CALL(vt_time_lerp2x(part.p + (size_t)b * n * fr * esize(xp.dt), up.p + ((size_t)b * 2 * T + out_t0) * fr * esize(xp.dt), xp.dt, 1, n, fr, c.stream));
       };
+      if (c.m->tiled) {            // first chunk of a tiled pass: keep the last n_up frames for the next chunk's interpolation
+        std::vector<int> keep;
+        for (int t = std::max(0, T - n_up); t < T; ++t) keep.push_back(t);
+        char* buf = c.m->persistent(su, (size_t)xp.B * keep.size() * fr * esize(xp.dt), c.dry);
+        gather(c, xp.p, T, buf, (int)keep.size(), 0, keep, xp.B, fr, (int)esize(xp.dt));
+        if (!c.dry) su.frames = (int)keep.size();
+      }
       lerp_part(0, hn, 0);
       if (T > n_up) lerp_part(n_up, T - n_up, 2 * hn);
     }
-    ConvOpts o = emit(next, VT_TPAD_REPLICATE);
-    o.res = &up;
-    o.res_mode = VT_RES_MIX;
-    o.mix = c.m->f32(key + ".mix_factor", c.dry);
-    return conv(c, up, c.m->conv_w(key + ".conv.conv.weight", up.ld, c.dry), 27 * up.ld, c.m->f32(key + ".conv.conv.bias", c.dry), causal3d(3, 3, 3), ch, o);
+    return conv_of(c, up, next);
   }
   Act run(Ctx& c, const Act& x, NormRef next) override {
     if (c.m->v11()) return run_v11(c, x, next);
@@ -620,6 +812,25 @@ struct Graph {
   std::string conv_in, conv_out;
   Norm norm_out;
   int c_first = 0, c_last = 0;
+  CState st_in, st_out;            // chunk state of conv_in / conv_out (two frames each)
+  void states(std::vector<CState*>& v) {
+    v.push_back(&st_in);
+    for (auto& st : stages) st->states(v);
+    v.push_back(&st_out);
+  }
+  // cache offsets of an overlapped decode (AutoencodingEngineV11._overlap_offsets, autoencoder_v1_1.py:307-320): 1 at latent
+  // rate, doubling at each temporal up-sampler (the up-sampler itself already works at the doubled rate); 0 = no look-ahead
+  void set_offsets(bool overlap) {
+    int off = overlap ? 1 : 0;
+    st_in.offset = off;
+    for (auto& st : stages) {
+      if (st->time_up()) off *= 2;
+      std::vector<CState*> v;
+      st->states(v);
+      for (CState* s : v) s->offset = off;
+    }
+    st_out.offset = off;
+  }
 };
 
 ResBlock* res_block(Shapes& sh, const std::string& key, int cin, int cout, bool causal) {
@@ -745,7 +956,7 @@ void run_graph(Ctx& c, Graph& g, const Tens& x_in, int cout_final, float* out_nc
   c.cur = &m->arena[which];
   c.cur->reset();
   const NormRef first = g.stages[0]->first_norm(c);
-  Act h = conv(c, x_in, m->conv_w(g.conv_in + ".weight", x_in.ld, c.dry), 27 * x_in.ld, m->f32(g.conv_in + ".bias", c.dry), causal3d(3, 3, 3), g.c_first, emit(first, m->tpad()));
+  Act h = conv_causal(c, g.st_in, x_in, m->conv_w(g.conv_in + ".weight", x_in.ld, c.dry), 27 * x_in.ld, m->f32(g.conv_in + ".bias", c.dry), causal3d(3, 3, 3), g.c_first, emit(first, m->tpad()));
   for (size_t i = 0; i < g.stages.size(); ++i) {
     which ^= 1;
     c.cur = &m->arena[which];
@@ -761,7 +972,7 @@ void run_graph(Ctx& c, Graph& g, const Tens& x_in, int cout_final, float* out_nc
   o.ncthw = out_ncthw ? out_ncthw : (float*)16;      // dry runs pass no buffer
   o.t_trim = t_trim;
   o.tmode = m->tpad();
-  conv(c, hn, m->conv_w(g.conv_out + ".weight", hn.ld, c.dry), 27 * hn.ld, m->f32(g.conv_out + ".bias", c.dry), causal3d(3, 3, 3), cout_final, o);
+  conv_causal(c, g.st_out, hn, m->conv_w(g.conv_out + ".weight", hn.ld, c.dry), 27 * hn.ld, m->f32(g.conv_out + ".bias", c.dry), causal3d(3, 3, 3), cout_final, o);
 }
 
 int front_pad(const vt_model_config& cf, int T) {      // EncoderCausal3DPadding.forward: v1.0 pads f - 1 frames, v1.1 up to a multiple of f
@@ -786,6 +997,95 @@ void decode_impl(Model* m, Graph& g, const float* z, int B, int T, int H, int W,
   Tens zin = c.alloc(B, T, H, W, pad8(m->cfg.z_channels), m->dt, pad8(m->cfg.z_channels));
   if (!dry) M_CALL(vt_ncthw_to_ndhwc(z, zin.p, m->dt, B, m->cfg.z_channels, T, H, W, zin.ld, 0, stream));
   run_graph(c, g, zin, m->cfg.out_ch, x_out, m->v11() ? 0 : m->cfg.time_downsample_factor - 1);   // v1.1 keeps every frame (the caller drops the padding's)
+}
+
+// ---- temporal tiling of the v1.1 tokenizers (AutoencodingEngineV11.tile_encode / tile_decode, autoencoder_v1_1.py:218-331) -----------
+// [[0, 1], [1, 1 + c], [1 + c, 1 + 2 c], ...]: the first chunk is the single leading frame (build_chunk_start_end, :218-228)
+std::vector<std::pair<int, int>> chunk_list(int t, int step) {
+  std::vector<std::pair<int, int>> v{{0, 1}};
+  for (int start = 1; start < t;) {
+    const int end = std::min(t, start + step);
+    v.emplace_back(start, end);
+    start = end;
+  }
+  return v;
+}
+int ceil_div(int a, int b) { return (a + b - 1) / b; }
+
+struct ChunkBufs {                 // staging of one chunk in front of the arenas: its input frames and its result, contiguous NCTHW
+  float* in = nullptr;
+  float* out = nullptr;
+  size_t bytes = 0;
+};
+ChunkBufs chunk_bufs(void* ws, size_t in_elems, size_t out_elems) {
+  ChunkBufs b;
+  const size_t ib = (in_elems * 4 + 255) & ~(size_t)255, ob = (out_elems * 4 + 255) & ~(size_t)255;
+  b.in = (float*)ws;
+  b.out = (float*)((char*)ws + ib);
+  b.bytes = ib + ob;
+  return b;
+}
+void reset_states(Model& m) {
+  for (CState* st : m.states) st->frames = 0;
+}
+
+// every chunk through the encoder in order (the module caches carry the causal state); a chunk of n frames is front-padded
+// to a multiple of f by the encoder and yields ceil(n / f) latent frames, written to h_out at their place
+void tile_encode_impl(Model* m, Graph& g, const float* x, int B, int T, int H, int W, int t_chunk, float* h_out, char* ws, hipStream_t stream, bool dry) {
+  const vt_model_config& cf = m->cfg;
+  const int f = cf.time_downsample_factor, cin = cf.in_channels, cz = cf.double_z ? 2 * cf.z_channels : cf.z_channels;
+  const int Hz = H >> cf.n_spatial_ds, Wz = W >> cf.n_spatial_ds;
+  const auto chunks = chunk_list(T, t_chunk);
+  int tz = 0, nmax = 1;
+  for (auto& ch : chunks) {
+    tz += ceil_div(ch.second - ch.first, f);
+    nmax = std::max(nmax, ch.second - ch.first);
+  }
+  const ChunkBufs cb = chunk_bufs(ws, (size_t)B * cin * nmax * H * W, (size_t)B * cz * ceil_div(nmax, f) * Hz * Wz);
+  g.set_offsets(false);
+  if (!dry) reset_states(*m);
+  m->tiled = true;
+  int done = 0;
+  for (size_t i = 0; i < chunks.size(); ++i) {
+    const int n = chunks[i].second - chunks[i].first, nz = ceil_div(n, f);
+    if (dry && !(i == 0 || n == nmax)) continue;          // sizing: the first chunk and one of the largest kind
+    m->first_chunk = i == 0;
+    if (!dry) M_CALL(vt_ncthw_copy_frames(x, cb.in, B * cin, T, n, chunks[i].first, 0, n, (int64_t)H * W, 0, stream));
+    encode_impl(m, g, cb.in, B, n, H, W, cb.out, stream, dry);
+    if (!dry) M_CALL(vt_ncthw_copy_frames(cb.out, h_out, B * cz, nz, tz, 0, done, nz, (int64_t)Hz * Wz, 0, stream));
+    done += nz;
+  }
+  m->tiled = false;
+  m->first_chunk = true;
+}
+
+// chunks of t_chunk_dec latent frames decoded in order, each with one look-ahead latent frame when `overlap` (its f trailing
+// output frames are dropped, the module caches stop `cache_offset` frames early); f * Tz output frames in all
+void tile_decode_impl(Model* m, Graph& g, const float* z, int B, int Tz, int Hz, int Wz, int t_chunk_dec, bool overlap, float* x_out, char* ws, hipStream_t stream, bool dry) {
+  const vt_model_config& cf = m->cfg;
+  const int f = cf.time_downsample_factor, zc = cf.z_channels, oc = cf.out_ch;
+  const int H = Hz << cf.n_spatial_us, W = Wz << cf.n_spatial_us;
+  const auto chunks = chunk_list(Tz, t_chunk_dec);
+  int nmax = 1;
+  for (auto& ch : chunks) nmax = std::max(nmax, ch.second - ch.first + ((overlap && ch.second + 1 <= Tz) ? 1 : 0));
+  const ChunkBufs cb = chunk_bufs(ws, (size_t)B * zc * nmax * Hz * Wz, (size_t)B * oc * nmax * f * H * W);
+  g.set_offsets(overlap);
+  if (!dry) reset_states(*m);
+  m->tiled = true;
+  int done = 0;
+  for (size_t i = 0; i < chunks.size(); ++i) {
+    const bool look = overlap && chunks[i].second + 1 <= Tz;
+    const int nl = chunks[i].second - chunks[i].first + (look ? 1 : 0), n = nl * f - (look ? f : 0);
+    if (dry && !(i == 0 || nl == nmax)) continue;
+    m->first_chunk = i == 0;
+    if (!dry) M_CALL(vt_ncthw_copy_frames(z, cb.in, B * zc, Tz, nl, chunks[i].first, 0, nl, (int64_t)Hz * Wz, 0, stream));
+    decode_impl(m, g, cb.in, B, nl, Hz, Wz, cb.out, stream, dry);
+    if (!dry) M_CALL(vt_ncthw_copy_frames(cb.out, x_out, B * oc, nl * f, Tz * f, 0, done, n, (int64_t)H * W, 0, stream));
+    done += n;
+  }
+  m->tiled = false;
+  m->first_chunk = true;
+  g.set_offsets(false);
 }
 
 }  // namespace
@@ -816,6 +1116,8 @@ extern "C" int vt_create(const vt_model_config* cfg, int32_t compute_dtype, vt_m
     h->m.dt = h->m.x3 ? VT_F32 : compute_dtype;
     h->enc = build_encoder(*cfg, h->shapes);
     h->dec = build_decoder(*cfg, h->shapes);
+    h->enc.states(h->m.states);
+    h->dec.states(h->m.states);
     for (const auto& kv : h->shapes) h->names.push_back(kv.first);
     *out = h;
     return VT_OK;
@@ -927,11 +1229,23 @@ void check_loaded(vt_model* h, const char* prefix) {
   for (const std::string& k : h->names)
     if (k.compare(0, strlen(prefix), prefix) == 0) (void)h->m.param(k);
 }
-void bind_workspace(Model& m, void* ws, int64_t bytes) {
+void bind_workspace(Model& m, void* ws, int64_t bytes, size_t skip = 0) {
   M_CHECK(ws != nullptr && bytes >= 1024 && (reinterpret_cast<uintptr_t>(ws) & 255) == 0, "vt_model: workspace must be a 256-byte aligned device buffer");
-  const size_t half = ((size_t)bytes / 2) & ~(size_t)255;
-  m.arena[0].base = (char*)ws; m.arena[0].cap = half; m.arena[0].peak = 0;
-  m.arena[1].base = (char*)ws + half; m.arena[1].cap = half; m.arena[1].peak = 0;
+  M_CHECK((size_t)bytes > skip + 1024, "vt_model: workspace too small (%lld bytes; ask vt_workspace_bytes / vt_tile_workspace_bytes)", (long long)bytes);
+  const size_t half = (((size_t)bytes - skip) / 2) & ~(size_t)255;
+  m.arena[0].base = (char*)ws + skip; m.arena[0].cap = half; m.arena[0].peak = 0;
+  m.arena[1].base = (char*)ws + skip + half; m.arena[1].cap = half; m.arena[1].peak = 0;
+}
+// bytes the chunk staging buffers of a tiled pass take at the front of the workspace
+// (sized for the largest chunk the schedule can hold, whatever the clip length: t_chunk_enc frames in, t_chunk_dec + 1 latent frames)
+size_t tile_staging_bytes(const vt_model_config& cf, int B, int H, int W, int t_chunk_enc) {
+  const int f = cf.time_downsample_factor, cz = cf.double_z ? 2 * cf.z_channels : cf.z_channels;
+  const int Hz = H >> cf.n_spatial_ds, Wz = W >> cf.n_spatial_ds;
+  const int ne = std::max(1, t_chunk_enc);
+  const size_t enc = chunk_bufs(nullptr, (size_t)B * cf.in_channels * ne * H * W, (size_t)B * cz * ceil_div(ne, f) * Hz * Wz).bytes;
+  const int nd = std::max(1, t_chunk_enc / f) + 1;
+  const size_t dec = chunk_bufs(nullptr, (size_t)B * cf.z_channels * nd * Hz * Wz, (size_t)B * cf.out_ch * nd * f * H * W).bytes;
+  return std::max(enc, dec);
 }
 }  // namespace
 
@@ -998,10 +1312,112 @@ extern "C" int vt_indices_to_latent(vt_model* h, const int32_t* indices, float* 
   return vt_fsq_indices_to_codes(indices, z, h->m.cfg.levels, h->m.cfg.n_levels, B, (int64_t)Tz * Hz * Wz, stream);
 }
 
+// forget the chunk state of a tiled pass (vt_tile_encode / vt_tile_decode do it themselves at the start of a clip) and give the
+// cache buffers back: SYNCHRONISES the device first -- work queued on them may still be running
 extern "C" int vt_reset_cache(vt_model* h) {
   if (!h) {
     vt_set_error("vt_reset_cache: null handle");
     return VT_ERR_ARG;
   }
-  return VT_OK;     // one pass per clip keeps no state between calls (the chunk caches of v1.1 tiling are not driven from here)
+  if (hipDeviceSynchronize() != hipSuccess) {
+    vt_set_error("vt_reset_cache: hipDeviceSynchronize failed");
+    return VT_ERR_HIP;
+  }
+  for (CState* st : h->m.states) {
+    st->frames = 0;
+    st->cap = 0;
+    st->buf.reset();
+  }
+  h->m.retired.clear();
+  return VT_OK;
+}
+
+extern "C" int32_t vt_tile_latent_frames(const vt_model* h, int32_t T, int32_t t_chunk_enc) {
+  if (!h || T <= 0 || t_chunk_enc <= 0) return -1;
+  int tz = 0;
+  for (auto& ch : chunk_list(T, t_chunk_enc)) tz += ceil_div(ch.second - ch.first, h->m.cfg.time_downsample_factor);
+  return tz;
+}
+
+extern "C" int64_t vt_tile_workspace_bytes(vt_model* h, int32_t B, int32_t T, int32_t H, int32_t W, int32_t t_chunk_enc, int32_t use_overlap) {
+  try {
+    M_CHECK(h && B > 0 && T > 0 && H > 0 && W > 0 && t_chunk_enc > 0, "vt_tile_workspace_bytes: bad argument");
+    M_CHECK(h->m.v11(), "vt_tile_workspace_bytes: temporal tiling exists only in the v1.1 models (version 1)");
+    Model& m = h->m;
+    const int f = m.cfg.time_downsample_factor;
+    M_CHECK(t_chunk_enc >= f, "vt_tile_workspace_bytes: t_chunk_enc must be at least the temporal factor %d", f);
+    Arena save[2] = {m.arena[0], m.arena[1]};
+    m.arena[0] = Arena();
+    m.arena[1] = Arena();
+    const int Hz = H >> m.cfg.n_spatial_ds, Wz = W >> m.cfg.n_spatial_ds;
+    const int tz = vt_tile_latent_frames(h, T, t_chunk_enc);
+    tile_encode_impl(&m, h->enc, nullptr, B, T, H, W, t_chunk_enc, nullptr, nullptr, nullptr, true);
+    tile_decode_impl(&m, h->dec, nullptr, B, tz, Hz, Wz, t_chunk_enc / f, use_overlap != 0, nullptr, nullptr, nullptr, true);
+    const size_t peak = std::max(m.arena[0].peak, m.arena[1].peak);
+    m.arena[0] = save[0];
+    m.arena[1] = save[1];
+    return (int64_t)(tile_staging_bytes(m.cfg, B, H, W, t_chunk_enc) + 2 * ((peak + 255) & ~(size_t)255) + 1024);
+  } catch (const Fail& f) {
+    return -1;
+  } catch (const std::exception& e) {
+    vt_set_error("vt_tile_workspace_bytes: %s", e.what());
+    return -1;
+  }
+}
+
+extern "C" int vt_tile_encode(vt_model* h, const float* x, int32_t B, int32_t T, int32_t H, int32_t W, int32_t t_chunk_enc, float* h_out,
+                              void* workspace, int64_t workspace_bytes, vt_stream stream) {
+  try {
+    M_CHECK(h && x && h_out && B > 0 && T > 0 && H > 0 && W > 0, "vt_tile_encode: bad argument");
+    M_CHECK(h->m.v11(), "vt_tile_encode: temporal tiling exists only in the v1.1 models (version 1)");
+    M_CHECK(t_chunk_enc >= h->m.cfg.time_downsample_factor, "vt_tile_encode: t_chunk_enc must be at least the temporal factor");
+    const int ds = 1 << h->m.cfg.n_spatial_ds;
+    M_CHECK(H % ds == 0 && W % ds == 0, "vt_tile_encode: H and W must be multiples of %d", ds);
+    check_loaded(h, "encoder.");
+    const size_t skip = tile_staging_bytes(h->m.cfg, B, H, W, t_chunk_enc);
+    bind_workspace(h->m, workspace, workspace_bytes, skip);
+    tile_encode_impl(&h->m, h->enc, x, B, T, H, W, t_chunk_enc, h_out, (char*)workspace, reinterpret_cast<hipStream_t>(stream), false);
+    return VT_OK;
+  } catch (const Fail& f) {
+    h->m.tiled = false;
+    return f.code;
+  } catch (const std::exception& e) {
+    h->m.tiled = false;
+    vt_set_error("vt_tile_encode: %s", e.what());
+    return VT_ERR_ARG;
+  }
+}
+
+extern "C" int vt_tile_decode(vt_model* h, const float* z, int32_t B, int32_t Tz, int32_t Hz, int32_t Wz, int32_t t_chunk_dec, int32_t use_overlap,
+                              float* x_out, void* workspace, int64_t workspace_bytes, vt_stream stream) {
+  try {
+    M_CHECK(h && z && x_out && B > 0 && Tz > 0 && Hz > 0 && Wz > 0 && t_chunk_dec > 0, "vt_tile_decode: bad argument");
+    M_CHECK(h->m.v11(), "vt_tile_decode: temporal tiling exists only in the v1.1 models (version 1)");
+    check_loaded(h, "decoder.");
+    const vt_model_config& cf = h->m.cfg;
+    const int f = cf.time_downsample_factor;
+    const size_t skip = tile_staging_bytes(cf, B, Hz << cf.n_spatial_us, Wz << cf.n_spatial_us, t_chunk_dec * f);
+    bind_workspace(h->m, workspace, workspace_bytes, skip);
+    tile_decode_impl(&h->m, h->dec, z, B, Tz, Hz, Wz, t_chunk_dec, use_overlap != 0, x_out, (char*)workspace, reinterpret_cast<hipStream_t>(stream), false);
+    return VT_OK;
+  } catch (const Fail& f) {
+    h->m.tiled = false;
+    return f.code;
+  } catch (const std::exception& e) {
+    h->m.tiled = false;
+    vt_set_error("vt_tile_decode: %s", e.what());
+    return VT_ERR_ARG;
+  }
+}
+
+// FSQ: the three statistics of the auxiliary loss on the pre-quantisation latent (FSQRegularizer.forward, regularizers.py:229-262):
+// out3 = {per-sample entropy, codebook entropy, commitment}; the caller forms (out3[0] - diversity_gamma * out3[1]) *
+// entropy_loss_weight + out3[2] * commitment_loss_weight with its YAML's weights.  work: vt_fsq_aux_work_floats(levels, D, B, S) floats
+extern "C" int vt_regularize_fsq_aux(vt_model* h, const float* pre, int32_t B, int32_t Tz, int32_t Hz, int32_t Wz, float inv_temperature,
+                                     float* work, float* out3, vt_stream stream) {
+  if (!h || h->m.cfg.regularizer != 1) {
+    vt_set_error("vt_regularize_fsq_aux: the handle's regularizer is not FSQ");
+    return VT_ERR_ARG;
+  }
+  return vt_fsq_aux_stats_avg(pre, h->m.cfg.levels, h->m.cfg.n_levels, B, (int64_t)Tz * Hz * Wz, inv_temperature, work, out3, nullptr, stream);
 }
