@@ -186,8 +186,9 @@ typedef struct vt_conv_desc {
 int vt_conv(const vt_conv_desc* d, vt_stream stream);
 /* What vt_conv(d) would do, without launching (no GPU needed): out8 = {pixel tile, channel tile, waves per
  * workgroup, workgroups (tiles for the persistent kernel), 1 if LayerNorm comes from the conv epilogue, kernel
- * launches of the call, kernel (0 = tile-per-workgroup implicit GEMM, 1 = weight-stationary persistent 3x3 for
- * Cin = Cout = 128 bf16), 1 if the 8-wave tile's epilogue goes through the LDS (coalesced rows; always with a fused LayerNorm,
+ * launches of the call, kernel (0 = tile-per-workgroup implicit GEMM; weight-stationary persistent 3x3 for
+ * Cin = Cout = 128 bf16: 1 = conv_ws128.hip, 8 x 16-pixel tiles on 4 waves, 3 = conv_ws2.hip, 4 x 16-pixel tiles on 8 waves; 2 = the
+ * narrow-output kernel), 1 if the 8-wave tile's epilogue goes through the LDS (coalesced rows; always with a fused LayerNorm,
  * without one for bf16 full tiles) or 2 if the 128 x 128 tile runs on its 4-slot ring (option conv_deep: launches with no
  * more tiles than the device has CUs)}.  Validates `d` exactly like vt_conv.  Test / measurement aid: which kernel and
  * instantiation does a parity case exercise. */
@@ -386,8 +387,9 @@ int vt_entropy(const float* avg, int64_t J, float* out, vt_stream stream);
  *   vt_reset_cache(h)                        drops the chunk state and frees its buffers (synchronises the device); the
  *                                            tiled calls reset the state themselves at the start of a clip
  * The non-causal family stays with the Python host.
+ *   vt_prepare(h)                            packs and uploads every weight now instead of at its first use
  * All device pointers; the calls are asynchronous on `stream` except that (a) the FIRST use of a weight packs it on the host
- * and uploads it with a blocking copy and (b) a chunk cache is hipMalloc'ed the first time a chunk kind needs it -- run one
+ * and uploads it with a blocking copy (vt_prepare does all of them up front) and (b) a chunk cache is hipMalloc'ed the first time a chunk kind needs it -- run one
  * warm-up call before capturing a stream.  A handle keeps per-call state (arenas, caches): one call at a time per handle.
  * The workspace must outlive the work queued on it.
  * ---------------------------------------------------------------------------------------- */
@@ -424,6 +426,7 @@ int vt_indices_to_latent(vt_model* h, const int32_t* indices, float* z, int32_t 
 int vt_decode(vt_model* h, const float* z, int32_t B, int32_t Tz, int32_t Hz, int32_t Wz, float* x_out, void* workspace,
               int64_t workspace_bytes, vt_stream stream);
 int vt_reset_cache(vt_model* h);
+int vt_prepare(vt_model* h);       /* pack + upload every weight now (blocking) instead of at first use */
 int vt_regularize_fsq_aux(vt_model* h, const float* pre, int32_t B, int32_t Tz, int32_t Hz, int32_t Wz, float inv_temperature,
                           float* work, float* out3, vt_stream stream);
 int32_t vt_tile_latent_frames(const vt_model* h, int32_t T, int32_t t_chunk_enc);

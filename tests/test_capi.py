@@ -173,7 +173,10 @@ def test_conv_plan_tile_selection(built_lib, monkeypatch):
     assert not p["ln_fused"] and p["launches"] == 2
     # the weight-stationary persistent kernel: bf16, 3x3, Cin = Cout = 128, frames tiling by 8 x 16
     p = ops.conv_plan(desc((256, 256), 128, 128))
-    assert p["kernel"] == "ws128" and p["workgroups"] == 32 * 16
+    assert p["kernel"] == "ws2" and p["tile"] == (64, 128) and p["waves"] == 8 and p["workgroups"] == 64 * 16      # conv_ws2.hip: 4 x 16-pixel tiles
+    with L.options(conv_ws=1):
+        p = ops.conv_plan(desc((256, 256), 128, 128))
+        assert p["kernel"] == "ws128" and p["tile"] == (128, 128) and p["waves"] == 4 and p["workgroups"] == 32 * 16  # conv_ws128.hip: 8 x 16
     assert ops.conv_plan(desc((256, 256), 128, 128, **dict(ln, ldn=128)))["ln_fused"]
     assert ops.conv_plan(desc((256, 250), 128, 128))["kernel"] == "igemm"
     assert ops.conv_plan(desc((256, 256), 128, 128, dtype=L.VT_F32, out_dtype=L.VT_F32))["kernel"] == "igemm"
@@ -396,3 +399,7 @@ def test_c_example_runs(built_lib, tmp_path):
     exe = _build_c_example(tmp_path)
     r = subprocess.run([exe, "9", "64", "64"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "finite 1" in r.stdout, (r.stdout, r.stderr)
+    # ... and the v1.1 model with temporal tiling from C (chunks of 16 frames, decoder look-ahead: BASELINE.json configs[4]'s
+    # protocol on a short clip), next to the one-pass result of the same clip
+    r = subprocess.run([exe, "41", "64", "64", "16"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "finite 1" in r.stdout and "tiled (t_chunk_enc 16" in r.stdout, (r.stdout, r.stderr)

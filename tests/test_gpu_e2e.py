@@ -609,6 +609,7 @@ def _make_handle(L, lib, cfg, sd, dtype):
         k = lib.vt_weight_name(h, i).decode()
         t = sd[k].detach().float().contiguous().cpu()
         L.check(lib.vt_load_weight(h, k.encode(), t.data_ptr(), (C.c_int64 * t.dim())(*t.shape), t.dim()), "vt_load_weight")
+    L.check(lib.vt_prepare(h), "vt_prepare")             # every weight packed + uploaded now: the calls below never block on one
     return h, mc
 
 

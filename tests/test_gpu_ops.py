@@ -166,7 +166,7 @@ WS_CASES = [
 def test_conv_weight_stationary(case, ws, vt_opts):
     vt_opts(conv_ws=ws)
     plan = _check_conv(case, torch.bfloat16)
-    assert plan["kernel"] == ("igemm" if ws == "0" else "ws128")
+    assert plan["kernel"] == {"0": "igemm", "1": "ws128", "2": "ws2"}[ws]
     if "ln" in case[6]:
         assert plan["ln_fused"]
 

@@ -1779,7 +1779,7 @@ int conv_prepare(const vt_conv_desc* d, ConvArgs& a, bool& ln_fused, int& nbatch
 // What vt_conv(d) will do, without launching: out[0..1] = pixel x channel tile, out[2] = waves per workgroup,
 // out[3] = workgroups (tiles for the persistent kernel), out[4] = 1 when LayerNorm is produced by the conv kernel's
 // epilogue (0: second launch of vt_layernorm_act, or no LayerNorm requested), out[5] = kernel launches the call
-// performs, out[6] = kernel: 0 = conv_igemm_glds_kernel, 1 = conv3x3_ws128_kernel (weight-stationary), 2 = conv3d_narrow_kernel, out[7] = epilogue / ring form (see the header).  Lets tests assert which
+// performs, out[6] = kernel: 0 = conv_igemm_glds_kernel, 1 = conv3x3_ws128_kernel (weight-stationary), 2 = conv3d_narrow_kernel, 3 = conv3x3_ws2_kernel, out[7] = epilogue / ring form (see the header).  Lets tests assert which
 // instantiation a parity case exercises and lets bench.py separate conv kernel time from LayerNorm passes.
 extern "C" int vt_conv_plan(const vt_conv_desc* d, int32_t* out8) {
   VT_CHECK_ARG(out8 != nullptr, "vt_conv_plan: null output");
@@ -1795,11 +1795,13 @@ extern "C" int vt_conv_plan(const vt_conv_desc* d, int32_t* out8) {
     out8[4] = 0; out8[5] = 1; out8[6] = 2;
     return VT_OK;
   }
-  if (use_ws) {   // persistent: 8 x 16-pixel tiles x all 128 channels, at most one workgroup per CU
-    out8[0] = 128; out8[1] = 128; out8[2] = 4;
-    out8[3] = (a.Wo / 16) * (a.Ho / 8) * a.B * a.To;
+  if (use_ws) {   // persistent, at most one workgroup per CU, all 128 channels per tile: conv_ws128.hip walks 8 x 16-pixel tiles on 4 waves,
+    const bool ws2 = vt_opt(OPT_CONV_WS) == 2;   // conv_ws2.hip (option conv_ws = 2, the default) 4 x 16-pixel tiles on 8 waves
+    out8[0] = ws2 ? 64 : 128; out8[1] = 128; out8[2] = ws2 ? 8 : 4;
+    out8[3] = (a.Wo / 16) * (a.Ho / (ws2 ? 4 : 8)) * a.B * a.To;
     out8[4] = d->ln_mode != 0 ? 1 : 0;
     out8[5] = 1;
+    out8[6] = ws2 ? 3 : 1;
     return VT_OK;
   }
   static const int dims[4][3] = {{256, 32, 4}, {256, 64, 4}, {256, 256, 8}, {128, 128, 4}};

@@ -166,8 +166,8 @@ struct Model {
   // time padding of a convolution with taps before the clip: zeros (v1.0) or the first frame repeated (v1.1, one pass)
   int tpad() const { return v11() ? VT_TPAD_REPLICATE : VT_TPAD_ZERO; }
   std::map<std::string, Param> params;
-  std::vector<std::unique_ptr<DevBuf>> owned;
-  std::map<std::string, void*> packed;      // cache key -> device pointer
+  std::map<std::string, std::unique_ptr<DevBuf>> packed;      // cache key -> the packed tensor on the device (owned)
+  bool prepare = false;            // vt_prepare: a dry walk of the graphs that packs and uploads every weight it meets
   Arena arena[2];
   std::vector<std::string> expected;        // state_dict keys the graph reads (filled by a dry run)
 
@@ -181,18 +181,17 @@ struct Model {
     M_HIP(hipMalloc(&b->p, bytes));
     M_HIP(hipMemcpy(b->p, host, bytes, hipMemcpyHostToDevice));
     void* p = b->p;
-    owned.push_back(std::move(b));
-    packed[ckey] = p;
+    packed[ckey] = std::move(b);
     return p;
   }
   // fp32 vector on the device as it is (biases, LayerNorm affines, mix factors)
   const float* f32(const std::string& key, bool dry) {
-    if (dry) {
+    if (dry && !prepare) {
       expected.push_back(key);
       return nullptr;
     }
     auto it = packed.find("f32:" + key);
-    if (it != packed.end()) return (const float*)it->second;
+    if (it != packed.end()) return (const float*)it->second->p;
     const Param& p = param(key);
     return (const float*)upload("f32:" + key, p.data.data(), p.data.size() * 4);
   }
@@ -201,14 +200,14 @@ struct Model {
   typedef std::vector<float> (*Xform)(const Param&, std::vector<int64_t>& shape, int a, int b);
   // `rows` = plain rows in the storage type even under VT_BF16X3 (the row operand of a GEMM against activations)
   const void* conv_w(const std::string& key, int cin_p, bool dry, Xform xf = nullptr, int xa = 0, int xb = 0, bool rows = false) {
-    if (dry) {
+    if (dry && !prepare) {
       expected.push_back(key);
       return nullptr;
     }
     const bool split = x3 && !rows;
     const std::string ckey = "w:" + key + ":" + std::to_string(cin_p) + ":" + std::to_string(dt) + (split ? "x3" : "") + ":" + std::to_string((xf ? 1 : 0) * 100 + xa * 10 + xb);
     auto it = packed.find(ckey);
-    if (it != packed.end()) return it->second;
+    if (it != packed.end()) return it->second->p;
     const Param& p = param(key);
     std::vector<int64_t> shape = p.shape;
     std::vector<float> tmp;
@@ -1154,10 +1153,20 @@ extern "C" int vt_load_weight(vt_model* h, const char* ref_key, const float* dat
     }
     p.data.assign(data_host, data_host + n);
     h->m.params[ref_key] = std::move(p);
-    // packed copies of an earlier version of this tensor are stale
+    // packed copies of an earlier version of THIS tensor are stale ("f32:<key>", "w:<key>:..."): freed here, after the
+    // device has finished whatever was queued on them
+    const std::string fk = "f32:" + std::string(ref_key), wk = "w:" + std::string(ref_key) + ":";
+    bool synced = false;
     for (auto it = h->m.packed.begin(); it != h->m.packed.end();) {
-      if (it->first.find(":" + std::string(ref_key)) != std::string::npos) it = h->m.packed.erase(it);
-      else ++it;
+      if (it->first == fk || it->first.compare(0, wk.size(), wk) == 0) {
+        if (!synced) {
+          M_HIP(hipDeviceSynchronize());
+          synced = true;
+        }
+        it = h->m.packed.erase(it);
+      } else {
+        ++it;
+      }
     }
     return VT_OK;
   } catch (const Fail& f) {
@@ -1167,6 +1176,12 @@ extern "C" int vt_load_weight(vt_model* h, const char* ref_key, const float* dat
     return VT_ERR_ARG;
   }
 }
+
+namespace {
+void check_loaded_all(vt_model* h) {
+  for (const std::string& k : h->names) (void)h->m.param(k);
+}
+}  // namespace
 
 extern "C" int vt_latent_dims(const vt_model* h, int32_t T, int32_t H, int32_t W, int32_t* out4) {
   if (!h || !out4) {
@@ -1203,6 +1218,41 @@ extern "C" int64_t vt_workspace_bytes(vt_model* h, int32_t B, int32_t T, int32_t
   } catch (const std::exception& e) {
     vt_set_error("vt_workspace_bytes: %s", e.what());
     return -1;
+  }
+}
+
+// Pack and upload every weight now (host-side repacking + blocking copies), so that the first vt_encode / vt_decode is as
+// asynchronous as the later ones -- e.g. before capturing a stream.  Walks both graphs dry on a minimal clip.
+extern "C" int vt_prepare(vt_model* h) {
+  try {
+    M_CHECK(h != nullptr, "vt_prepare: null handle");
+    check_loaded_all(h);
+    Model& m = h->m;
+    Arena save[2] = {m.arena[0], m.arena[1]};
+    m.arena[0] = Arena();
+    m.arena[1] = Arena();
+    m.prepare = true;
+    const int s = 1 << m.cfg.n_spatial_ds, T = m.cfg.time_downsample_factor;
+    int32_t ld[4];
+    vt_latent_dims(h, T, 8 * s, 8 * s, ld);
+    try {
+      encode_impl(&m, h->enc, nullptr, 1, T, 8 * s, 8 * s, nullptr, nullptr, true);
+      decode_impl(&m, h->dec, nullptr, 1, ld[1], ld[2], ld[3], nullptr, nullptr, true);
+    } catch (...) {
+      m.prepare = false;
+      m.arena[0] = save[0];
+      m.arena[1] = save[1];
+      throw;
+    }
+    m.prepare = false;
+    m.arena[0] = save[0];
+    m.arena[1] = save[1];
+    return VT_OK;
+  } catch (const Fail& f) {
+    return f.code;
+  } catch (const std::exception& e) {
+    vt_set_error("vt_prepare: %s", e.what());
+    return VT_ERR_ARG;
   }
 }
 

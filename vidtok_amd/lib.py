@@ -105,6 +105,7 @@ SIGNATURES = {
     "vt_indices_to_latent": (C.c_int, [_P, _P, _P, _I32, _I32, _I32, _I32, _P]),
     "vt_decode": (C.c_int, [_P, _P, _I32, _I32, _I32, _I32, _P, _P, _I64, _P]),
     "vt_reset_cache": (C.c_int, [_P]),
+    "vt_prepare": (C.c_int, [_P]),
     "vt_regularize_fsq_aux": (C.c_int, [_P, _P, _I32, _I32, _I32, _I32, _F, _P, _P, _P]),
     "vt_tile_latent_frames": (_I32, [_P, _I32, _I32]),
     "vt_tile_workspace_bytes": (_I64, [_P, _I32, _I32, _I32, _I32, _I32, _I32]),
