@@ -350,7 +350,7 @@ int vt_fsq_aux_stats_avg(const float* h, const int32_t* levels_host, int32_t D, 
 int vt_entropy(const float* avg, int64_t J, float* out, vt_stream stream);
 
 /* ------------------------------------------------------------------------------------------
- * Model handle: AutoencodingEngine.encode / decode of the causal tokenizers (v1.0 and v1.1) driven from C++ over the operators above
+ * Model handle: AutoencodingEngine.encode / decode of the causal (v1.0, v1.1) and non-causal tokenizers driven from C++ over the operators above
  * (reference vidtok/models/autoencoder.py:197-229: encode = encoder -> regularization, decode = decoder, forward = both;
  * the module tree of vidtok/modules/model_3dcausal.py:502-885 with `norm_type: layernorm`, `resamp_with_conv: true`).
  * Same stage graph, descriptors and fusion decisions as the Python host (vidtok_amd/modules.py), hence the same bits.
@@ -394,7 +394,7 @@ int vt_entropy(const float* avg, int64_t J, float* out, vt_stream stream);
  * The workspace must outlive the work queued on it.
  * ---------------------------------------------------------------------------------------- */
 typedef struct vt_model_config {
-  int32_t version;               /* 0 = v1.0 causal, 1 = v1.1 causal (replicate padding; one pass or temporal tiling) */
+  int32_t version;               /* 0 = v1.0 causal, 1 = v1.1 causal (replicate padding; one pass or temporal tiling), 2 = non-causal */
   int32_t ch, num_res_blocks, in_channels, out_ch, z_channels, double_z;
   int32_t num_resolutions;       /* len(ch_mult)                                                                */
   int32_t ch_mult[8];

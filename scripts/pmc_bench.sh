@@ -7,5 +7,5 @@ OUT="$1"; DT="${2:-bf16}"; mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout 900 rocprofv3 --kernel-trace --pmc $c --output-format csv -d "$OUT/$c" -o p -- \
-    python /root/repo/bench.py --dtype $DT --steps 2 --warmup 1 --no-cpu-baseline --no-graph --traffic none > "$OUT/$c.log" 2>&1
+    python /root/repo/bench.py --dtype $DT --steps 2 --warmup 1 --no-cpu-baseline --no-graph --traffic none --no-extras > "$OUT/$c.log" 2>&1
 done

@@ -280,7 +280,7 @@ def test_model_handle_without_gpu(built_lib):
         for i, e in enumerate(v):
             getattr(mc, k)[i] = e
     h = C.c_void_p()
-    mc.version = 2
+    mc.version = 3
     assert built_lib.vt_create(C.byref(mc), lib.VT_BF16, C.byref(h)) != 0 and b"version" in built_lib.vt_last_error()
     mc.version, mc.interpolation_mode = 0, 1
     assert built_lib.vt_create(C.byref(mc), lib.VT_BF16, C.byref(h)) != 0 and b"interpolation_mode" in built_lib.vt_last_error()
@@ -328,12 +328,12 @@ def _causal_configs():
     import glob
 
     paths = sorted(glob.glob(os.path.join(ROOT, "configs", "*.yaml")) + glob.glob(os.path.join(ROOT, "configs", "vidtok_v1_1", "*.yaml")))
-    return [os.path.relpath(q, os.path.join(ROOT, "configs"))[:-5] for q in paths if "noncausal" not in q]
+    return [os.path.relpath(q, os.path.join(ROOT, "configs"))[:-5] for q in paths]
 
 
 @pytest.mark.parametrize("name", _causal_configs())
 def test_model_handle_graph_of_every_causal_config(built_lib, name):
-    """The C++ stage graph (csrc/model.cpp) for every shipped causal YAML, v1.0 and v1.1 -- every compression schedule
+    """The C++ stage graph (csrc/model.cpp) for every shipped YAML, causal v1.0 / v1.1 and non-causal -- every compression schedule
     (4x8x8, 4x16x16, 2x8x8, 4x4x4, 8x8x8), every latent width, both regularizers: the handle lists exactly the encoder /
     decoder parameters of the Python model with the reference's shapes, its latent dimensions follow the schedule, and
     the dry run of both graphs sizes a workspace.  Host-side only."""
@@ -346,7 +346,7 @@ def test_model_handle_graph_of_every_causal_config(built_lib, name):
     enc = prm["encoder_config"]["params"]
     reg = prm["regularizer_config"]
     mc = handle_config(lib, enc, reg["target"], reg.get("params", {}), prm["encoder_config"]["target"])
-    assert mc.version == (1 if "v1_1" in name else 0)
+    assert mc.version == (1 if "v1_1" in name else (2 if "noncausal" in name else 0))
     h = C.c_void_p()
     assert built_lib.vt_create(C.byref(mc), lib.VT_BF16, C.byref(h)) == 0, built_lib.vt_last_error()
     try:
@@ -359,7 +359,7 @@ def test_model_handle_graph_of_every_causal_config(built_lib, name):
             assert built_lib.vt_weight_shape(h, i, shp, C.byref(nd)) == 0 and tuple(shp[:nd.value]) == tuple(sd[k].shape), k
         f = enc.get("time_downsample_factor", 4)
         sds = len(enc.get("spatial_ds") or range(len(enc["ch_mult"]) - 1))
-        for T in (1, f, f + 1, 2 * f + 1, 3 * f):
+        for T in ((f, 2 * f, 3 * f) if mc.version == 2 else (1, f, f + 1, 2 * f + 1, 3 * f)):
             pad = 0 if T % f == 0 else (f - T % f if mc.version == 1 else f - 1)
             ld = (C.c_int32 * 4)()
             assert built_lib.vt_latent_dims(h, T, 64, 64, ld) == 0

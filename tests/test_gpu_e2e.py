@@ -511,8 +511,11 @@ def test_encoder_tail_precision():
                                         ("vidtok_v1_1/vidtok_kl_causal_488_4chn_v1_1", (2, 3, 18, 64, 64)),      # front pad 2, trilinear
                                         ("vidtok_v1_1/vidtok_fsq_causal_888_32768_v1_1", (1, 3, 16, 128, 128)),  # three time up-samplers
                                         ("vidtok_v1_1/vidtok_kl_causal_288_8chn_v1_1", (1, 3, 33, 64, 64)),
-                                        ("vidtok_v1_1/vidtok_kl_causal_488_4chn_v1_1:nearest", (1, 3, 12, 64, 64))],
-                         ids=["kl_488_small", "kl_488_full_size", "fsq_488", "kl_41616", "v11_kl_488", "v11_fsq_888", "v11_kl_288", "v11_nearest"])
+                                        ("vidtok_v1_1/vidtok_kl_causal_488_4chn_v1_1:nearest", (1, 3, 12, 64, 64)),
+                                        ("vidtok_kl_noncausal_488_4chn", (2, 3, 16, 64, 64)),                     # the non-causal family: centred windows
+                                        ("vidtok_fsq_noncausal_41616_262144", (1, 3, 8, 128, 128))],
+                         ids=["kl_488_small", "kl_488_full_size", "fsq_488", "kl_41616", "v11_kl_488", "v11_fsq_888", "v11_kl_288", "v11_nearest",
+                              "noncausal_kl_488", "noncausal_fsq_41616"])
 def test_model_handle_matches_engine(name, shape, dtype):
     """the handle-level C-ABI drives the stage graph from C++ (csrc/model.cpp).  Everything below goes
     through ctypes only -- create from the YAML's constructor arguments, load the reference state_dict key by key from

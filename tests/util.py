@@ -73,7 +73,7 @@ def handle_config(L, enc, reg_target, reg_params, enc_target=""):
     DecoderCausal3D for the lists the YAML leaves out, model_3dcausal.py:560-566,738-741)"""
     c = L.ModelConfig()
     n = len(enc["ch_mult"])
-    c.version = 1 if enc_target.endswith("V11") else 0
+    c.version = 1 if enc_target.endswith("V11") else (2 if "noncausal" in enc_target else 0)
     c.interpolation_mode = {"nearest": 0, "trilinear": 1}[enc.get("interpolation_mode", "nearest")] if c.version else 0
     c.ch, c.num_res_blocks, c.in_channels, c.out_ch, c.z_channels = enc["ch"], enc["num_res_blocks"], enc["in_channels"], enc["out_ch"], enc["z_channels"]
     c.double_z, c.num_resolutions = int(enc.get("double_z", True)), n

@@ -10,8 +10,9 @@
 // only).  Scope: `norm_type: layernorm`, `resamp_with_conv: true` -- every shipped causal config, v1.0 and v1.1 (first-frame
 // replicate padding, nearest or trilinear time up-sampling, model_3dcausal_v1_1.py) as ONE pass over the clip, and the
 // temporal TILING of v1.1 (vt_tile_encode / vt_tile_decode: the chunk schedule, the per-module causal caches, the decoder's
-// look-ahead frame with its cache offsets -- AutoencodingEngine.tile_encode / tile_decode, autoencoder_v1_1.py:202-331).  The
-// non-causal family stays with the Python host.
+// look-ahead frame with its cache offsets -- AutoencodingEngine.tile_encode / tile_decode, autoencoder_v1_1.py:202-331); and
+// (version 2) the non-causal family, Encoder3D / Decoder3D of model_3dnoncausal.py:314-651: the same stages with centred temporal
+// windows and plain nn.Conv parameter keys.
 //
 // Memory: weights are packed on the host when first used and live in device allocations owned by the handle;
 // activations come from a caller-provided workspace, cut into two arenas that alternate between stages (a stage reads the
@@ -163,6 +164,9 @@ struct Model {
   int dt;                          // storage type of the activations (VT_BF16 | VT_F32)
   bool x3 = false;                 // VT_BF16X3: fp32 storage, convolutions on split-bf16 weight planes (three bf16 MFMAs per product)
   bool v11() const { return cfg.version == 1; }
+  bool noncausal() const { return cfg.version == 2; }          // Encoder3D / Decoder3D of model_3dnoncausal.py: centred temporal windows
+  // the parameter level a Causal* wrapper adds in front of its nn.Conv ("...conv1.conv.weight"); plain nn.Conv3d / Conv1d have none
+  std::string cv() const { return noncausal() ? "" : ".conv"; }
   // time padding of a convolution with taps before the clip: zeros (v1.0) or the first frame repeated (v1.1, one pass)
   int tpad() const { return v11() ? VT_TPAD_REPLICATE : VT_TPAD_ZERO; }
   std::map<std::string, Param> params;
@@ -288,8 +292,9 @@ std::vector<float> xf_space_parity(const Param& p, std::vector<int64_t>& shape, 
 // ---- operators ---------------------------------------------------------------------------------------------------------
 struct Geom {
   int kt = 1, kh = 1, kw = 1, st = 1, sh = 1, sw = 1, pt = 0, ph = 0, pw = 0, ph_hi = 0, pw_hi = 0;
+  int pt_hi = 0;                   // zero frames after the clip (non-causal windows; the kernel reads 0 beyond the end)
   void out_dims(int Ti, int Hi, int Wi, int& To, int& Ho, int& Wo) const {
-    To = (Ti + pt - kt) / st + 1;
+    To = (Ti + pt + pt_hi - kt) / st + 1;
     Ho = (Hi + ph + ph_hi - kh) / sh + 1;
     Wo = (Wi + pw + pw_hi - kw) / sw + 1;
   }
@@ -300,6 +305,13 @@ Geom causal3d(int kt, int kh, int kw, int st = 1, int sh = 1, int sw = 1) {
   g.pt = (kt - 1) + (1 - st);
   const int hp = (kh - 1) + (1 - sh), wp = (kw - 1) + (1 - sw);
   g.ph = hp / 2; g.pw = wp / 2; g.ph_hi = hp - hp / 2; g.pw_hi = wp - wp / 2;
+  return g;
+}
+// the same window centred in time (nn.Conv3d / Conv1d with padding k / 2 of the non-causal family): `before` frames in front,
+// the rest of the k - 1 behind
+Geom centred(Geom g, int before) {
+  g.pt_hi = g.pt - before;
+  g.pt = before;
   return g;
 }
 
@@ -496,7 +508,9 @@ struct ResBlock : Stage {          // ResnetBlock (2-D per frame) or ResnetCausa
   NormRef first_norm(Ctx&) const override { return NormRef{&n1, true}; }
   Act run(Ctx& c, const Act& x, NormRef next) override {
     Model* m = c.m;
-    const Geom g3 = causal3d_ ? causal3d(3, 3, 3) : causal3d(1, 3, 3), g1 = Geom();
+    Geom g3 = causal3d_ ? causal3d(3, 3, 3) : causal3d(1, 3, 3);
+    const Geom g1 = Geom();
+    if (causal3d_ && m->noncausal()) g3 = centred(g3, 1);           // ResnetNoncausalBlock: Conv3d padding 1
     const Tens h = n1.apply(c, x, true, cin);
     ConvOpts o1;
     o1.ln = NormRef{&n2, true};
@@ -522,6 +536,7 @@ struct TBlock : Stage {            // ResnetCausalBlock1D, model_3dcausal.py:427
   // ResnetCausalBlock1D._fusable (vidtok_amd/modules.py): one launch for bf16, C = 128; in a tiled pass both convolutions must
   // stand at the same point of the chunk schedule and, past the first chunk, both caches must be there
   bool fusable(const Ctx& c) const {
+    if (c.m->noncausal()) return false;                // the fused launch is the causal block
     if (!(c.m->dt == VT_BF16 && ch == 128 && n1.eps == n2.eps)) return false;
     if (!c.m->tiled) return true;
     if (s1.offset != s2.offset) return false;
@@ -533,6 +548,8 @@ struct TBlock : Stage {            // ResnetCausalBlock1D, model_3dcausal.py:427
     const Tens& xp = x.y;
     Geom g;
     g.kt = 3; g.pt = 2;
+    if (m->noncausal()) g = centred(g, 1);             // ResnetBlock1D: Conv1d padding 1
+    const std::string cv = m->cv();
     vt_tblock_desc d;
     memset(&d, 0, sizeof(d));
     d.dtype = xp.dt; d.C = ch; d.ld = xp.ld; d.B = xp.B; d.T = xp.T; d.HW = (int64_t)xp.H * xp.W; d.tmode = m->tpad();
@@ -570,11 +587,11 @@ struct TBlock : Stage {            // ResnetCausalBlock1D, model_3dcausal.py:427
     o1.ln = NormRef{&n2, true};
     o1.keep_y = false;
     o1.tmode = m->tpad();
-    const Act h2 = conv_causal(c, s1, h, m->conv_w(c1.key + ".conv.weight", h.ld, c.dry), 3 * h.ld, m->f32(c1.key + ".conv.bias", c.dry), g, ch, o1);
+    const Act h2 = conv_causal(c, s1, h, m->conv_w(c1.key + cv + ".weight", h.ld, c.dry), 3 * h.ld, m->f32(c1.key + cv + ".bias", c.dry), g, ch, o1);
     ConvOpts o2 = emit(next, m->tpad());
     o2.res = &xp;
     o2.res_mode = VT_RES_ADD;
-    return conv_causal(c, s2, h2.n, m->conv_w(c2.key + ".conv.weight", h2.n.ld, c.dry), 3 * h2.n.ld, m->f32(c2.key + ".conv.bias", c.dry), g, ch, o2);
+    return conv_causal(c, s2, h2.n, m->conv_w(c2.key + cv + ".weight", h2.n.ld, c.dry), 3 * h2.n.ld, m->f32(c2.key + cv + ".bias", c.dry), g, ch, o2);
   }
 };
 
@@ -590,10 +607,11 @@ struct Attn : Stage {              // AttnBlockWrapper, model_3dcausal.py:83-141
     const int S = xp.H * xp.W, Z = xp.B * xp.T, Cc = xp.ld, Sp = pad8(S), dt = m->dt;
     M_CHECK(Cc == ch, "vt_model: attention over %d channels stored as %d (channel counts must be multiples of 8)", ch, Cc);
     const Geom g1;
-    const Tens q = conv(c, hn, m->conv_w(key + ".q.conv.weight", Cc, c.dry), Cc, m->f32(key + ".q.conv.bias", c.dry), g1, ch, ConvOpts()).y;
-    const Tens k = conv(c, hn, m->conv_w(key + ".k.conv.weight", Cc, c.dry), Cc, m->f32(key + ".k.conv.bias", c.dry), g1, ch, ConvOpts()).y;
-    const void* wv = m->conv_w(key + ".v.conv.weight", Cc, c.dry, nullptr, 0, 0, true);
-    const float* bv = m->f32(key + ".v.conv.bias", c.dry);
+    const std::string cv = m->cv();
+    const Tens q = conv(c, hn, m->conv_w(key + ".q" + cv + ".weight", Cc, c.dry), Cc, m->f32(key + ".q" + cv + ".bias", c.dry), g1, ch, ConvOpts()).y;
+    const Tens k = conv(c, hn, m->conv_w(key + ".k" + cv + ".weight", Cc, c.dry), Cc, m->f32(key + ".k" + cv + ".bias", c.dry), g1, ch, ConvOpts()).y;
+    const void* wv = m->conv_w(key + ".v" + cv + ".weight", Cc, c.dry, nullptr, 0, 0, true);
+    const float* bv = m->f32(key + ".v" + cv + ".bias", c.dry);
     // V^T directly: the weight is the row operand; v's bias is added after P V (rows of P sum to 1)
     char* vT = gemm_nt(c, wv, false, hn.p, Z, Cc, S, Cc, dt, dt, Sp, nullptr);                // [Z][C][Sp]
     char* s = gemm_nt(c, q.p, true, k.p, Z, S, S, Cc, dt, VT_F32, S, nullptr);                 // [Z][S][S] fp32
@@ -609,7 +627,7 @@ struct Attn : Stage {              // AttnBlockWrapper, model_3dcausal.py:83-141
     ConvOpts op = emit(next);
     op.res = &xp;
     op.res_mode = VT_RES_ADD;
-    return conv(c, o, m->conv_w(key + ".proj_out.conv.weight", Cc, c.dry), Cc, m->f32(key + ".proj_out.conv.bias", c.dry), g1, ch, op);
+    return conv(c, o, m->conv_w(key + ".proj_out" + cv + ".weight", Cc, c.dry), Cc, m->f32(key + ".proj_out" + cv + ".bias", c.dry), g1, ch, op);
   }
 };
 
@@ -632,7 +650,7 @@ struct TimeDown : Stage {          // TimeDownsampleResCausal2x, model_3dcausal.
     Model* m = c.m;
     const Tens& xp = x.y;
     Tens x1 = c.alloc(xp.B, xp.T / 2, xp.H, xp.W, xp.ld, xp.dt, xp.ld);
-    int tm = m->tpad();
+    int tm = m->noncausal() ? VT_TPAD_ZERO_BACK : m->tpad();        // non-causal: both branches see [x, 0] (model_3dnoncausal.py:86-89)
     const void* pc = nullptr;
     if (m->tiled) {                // TimeDownsampleResCausal2x.run of the Python host (model_3dcausal_v1_1.py:286-300)
       tm = m->first_chunk ? VT_TPAD_REPLICATE : VT_TPAD_CACHE;
@@ -652,7 +670,10 @@ struct TimeDown : Stage {          // TimeDownsampleResCausal2x, model_3dcausal.
     o.res = &x1;
     o.res_mode = VT_RES_MIX;
     o.mix = m->f32(key + ".mix_factor", c.dry);
-    return conv_causal(c, sc, xp, m->conv_w(key + ".conv.conv.weight", xp.ld, c.dry), 27 * xp.ld, m->f32(key + ".conv.conv.bias", c.dry), causal3d(3, 3, 3, 2, 1, 1), ch, o);
+    Geom g = causal3d(3, 3, 3, 2, 1, 1);
+    if (m->noncausal()) g = centred(g, 0);                            // stride-2 Conv3d with padding (0,1,1) over [x, 0]
+    const std::string ck = key + ".conv" + m->cv();
+    return conv_causal(c, sc, xp, m->conv_w(ck + ".weight", xp.ld, c.dry), 27 * xp.ld, m->f32(ck + ".bias", c.dry), g, ch, o);
   }
 };
 
@@ -778,11 +799,18 @@ struct TimeUp : Stage {            // TimeUpsampleResCausal2x: v1.0 nearest as t
     Geom g;
     g.kt = 2; g.kh = 3; g.kw = 3; g.pt = 1; g.ph = 1; g.pw = 1; g.ph_hi = 1; g.pw_hi = 1;
     const float* mf = c.m->f32(key + ".mix_factor", c.dry);
+    const bool nc = c.m->noncausal();
+    const std::string ck = key + ".conv" + c.m->cv();
     for (int par = 0; par < 2; ++par) {
       ConvOpts o;
       o.out = &r.y; o.yt_mul = 2; o.yt_off = par;
       o.res = &xp; o.res_mode = VT_RES_MIX; o.mix = mf;
-      conv(c, xp, c.m->conv_w(key + ".conv.conv.weight", xp.ld, c.dry, xf_time_parity, par == 0 ? 1 : 0, 0), 18 * xp.ld, c.m->f32(key + ".conv.conv.bias", c.dry), g, ch, o);
+      // causal (window ends at the output frame):  o[2j] = (W0+W1) x[j-1] + W2 x[j],  o[2j+1] = W0 x[j-1] + (W1+W2) x[j]
+      // centred (TimeUpsampleRes2x, model_3dnoncausal.py:93-115):  o[2j] = W0 x[j-1] + (W1+W2) x[j],  o[2j+1] = (W0+W1) x[j] + W2 x[j+1]
+      const int early = nc ? par : (par == 0 ? 1 : 0);
+      Geom gp = g;
+      if (nc) gp = centred(g, par == 0 ? 1 : 0);
+      conv(c, xp, c.m->conv_w(ck + ".weight", xp.ld, c.dry, xf_time_parity, early, 0), 18 * xp.ld, c.m->f32(ck + ".bias", c.dry), gp, ch, o);
     }
     return r;
   }
@@ -832,8 +860,9 @@ struct Graph {
   }
 };
 
-ResBlock* res_block(Shapes& sh, const std::string& key, int cin, int cout, bool causal) {
-  const std::string sfx0 = causal ? ".conv" : "";
+// `wrap`: the 3-D / 1-D convolutions sit under a Causal* wrapper (a ".conv" level in their keys); false for the non-causal family
+ResBlock* res_block(Shapes& sh, const std::string& key, int cin, int cout, bool causal, bool wrap = true) {
+  const std::string sfx0 = (causal && wrap) ? ".conv" : "";
   const std::vector<int64_t> k3 = causal ? std::vector<int64_t>{3, 3, 3} : std::vector<int64_t>{3, 3};
   const std::vector<int64_t> k1 = causal ? std::vector<int64_t>{1, 1, 1} : std::vector<int64_t>{1, 1};
   sh_norm(sh, key + ".norm1", cin);
@@ -844,24 +873,24 @@ ResBlock* res_block(Shapes& sh, const std::string& key, int cin, int cout, bool 
   auto* b = new ResBlock();
   b->causal3d_ = causal; b->cin = cin; b->cout = cout;
   b->n1.key = key + ".norm1"; b->n2.key = key + ".norm2";
-  const std::string sfx = causal ? ".conv" : "";
+  const std::string sfx = sfx0;
   b->c1.key = key + ".conv1" + sfx; b->c2.key = key + ".conv2" + sfx; b->sc.key = key + ".nin_shortcut" + sfx;
   return b;
 }
-TBlock* t_block(Shapes& sh, const std::string& key, int ch) {
+TBlock* t_block(Shapes& sh, const std::string& key, int ch, bool wrap = true) {
   sh_norm(sh, key + ".norm1", ch);
   sh_norm(sh, key + ".norm2", ch);
-  sh_conv(sh, key + ".conv1.conv", ch, ch, {3});
-  sh_conv(sh, key + ".conv2.conv", ch, ch, {3});
+  sh_conv(sh, key + ".conv1" + (wrap ? ".conv" : ""), ch, ch, {3});
+  sh_conv(sh, key + ".conv2" + (wrap ? ".conv" : ""), ch, ch, {3});
   auto* b = new TBlock();
   b->ch = ch;
   b->n1.key = key + ".norm1"; b->n2.key = key + ".norm2";
   b->c1.key = key + ".conv1"; b->c2.key = key + ".conv2";
   return b;
 }
-Attn* attn(Shapes& sh, const std::string& key, int ch) {
+Attn* attn(Shapes& sh, const std::string& key, int ch, bool wrap = true) {
   sh_norm(sh, key + ".norm", ch);
-  for (const char* n : {".q", ".k", ".v", ".proj_out"}) sh_conv(sh, key + n + ".conv", ch, ch, {1, 1, 1});
+  for (const char* n : {".q", ".k", ".v", ".proj_out"}) sh_conv(sh, key + n + (wrap ? ".conv" : ""), ch, ch, {1, 1, 1});
   auto* a = new Attn();
   a->ch = ch; a->key = key; a->n.key = key + ".norm";
   return a;
@@ -870,6 +899,8 @@ Attn* attn(Shapes& sh, const std::string& key, int ch) {
 Graph build_encoder(const vt_model_config& cf, Shapes& sh) {
   Graph g;
   const int L = cf.num_resolutions;
+  const bool wrap = cf.version != 2;
+  const std::string cv = wrap ? ".conv" : "";
   int block_in = cf.ch;
   for (int i = 0; i < L; ++i) {
     block_in = cf.ch * (i == 0 ? 1 : cf.ch_mult[i - 1]);
@@ -877,7 +908,7 @@ Graph build_encoder(const vt_model_config& cf, Shapes& sh) {
     const std::string d = "encoder.down." + std::to_string(i), dt = "encoder.down_temporal." + std::to_string(i);
     for (int b = 0; b < cf.num_res_blocks; ++b) {
       g.stages.emplace_back(res_block(sh, d + ".block." + std::to_string(b), block_in, block_out, false));
-      g.stages.emplace_back(t_block(sh, dt + ".block." + std::to_string(b), block_out));
+      g.stages.emplace_back(t_block(sh, dt + ".block." + std::to_string(b), block_out, wrap));
       block_in = block_out;
     }
     if (in_list(cf.spatial_ds, cf.n_spatial_ds, i)) {
@@ -888,16 +919,16 @@ Graph build_encoder(const vt_model_config& cf, Shapes& sh) {
       if (in_list(cf.tempo_ds, cf.n_tempo_ds, i)) {
         auto* t = new TimeDown();
         t->ch = block_in; t->key = dt + ".downsample";
-        sh_conv(sh, dt + ".downsample.conv.conv", block_in, block_in, {3, 3, 3});
+        sh_conv(sh, dt + ".downsample.conv" + cv, block_in, block_in, {3, 3, 3});
         sh[dt + ".downsample.mix_factor"] = {1};
         g.stages.emplace_back(t);
       }
     }
   }
-  g.stages.emplace_back(res_block(sh, "encoder.mid.block_1", block_in, block_in, true));
-  g.stages.emplace_back(attn(sh, "encoder.mid.attn_1", block_in));
-  g.stages.emplace_back(res_block(sh, "encoder.mid.block_2", block_in, block_in, true));
-  g.conv_in = "encoder.conv_in.conv"; g.conv_out = "encoder.conv_out.conv";
+  g.stages.emplace_back(res_block(sh, "encoder.mid.block_1", block_in, block_in, true, wrap));
+  g.stages.emplace_back(attn(sh, "encoder.mid.attn_1", block_in, wrap));
+  g.stages.emplace_back(res_block(sh, "encoder.mid.block_2", block_in, block_in, true, wrap));
+  g.conv_in = "encoder.conv_in" + cv; g.conv_out = "encoder.conv_out" + cv;
   g.norm_out.key = "encoder.norm_out";
   g.c_first = cf.ch; g.c_last = block_in;
   sh_conv(sh, g.conv_in, cf.ch, cf.in_channels, {3, 3, 3});
@@ -909,18 +940,20 @@ Graph build_encoder(const vt_model_config& cf, Shapes& sh) {
 Graph build_decoder(const vt_model_config& cf, Shapes& sh) {
   Graph g;
   const int L = cf.num_resolutions;
+  const bool wrap = cf.version != 2;
+  const std::string cv = wrap ? ".conv" : "";
   int block_in = cf.ch * cf.ch_mult[L - 1];
   int n_up = 1;
   g.c_first = block_in;
-  g.stages.emplace_back(res_block(sh, "decoder.mid.block_1", block_in, block_in, true));
-  g.stages.emplace_back(attn(sh, "decoder.mid.attn_1", block_in));
-  g.stages.emplace_back(res_block(sh, "decoder.mid.block_2", block_in, block_in, true));
+  g.stages.emplace_back(res_block(sh, "decoder.mid.block_1", block_in, block_in, true, wrap));
+  g.stages.emplace_back(attn(sh, "decoder.mid.attn_1", block_in, wrap));
+  g.stages.emplace_back(res_block(sh, "decoder.mid.block_2", block_in, block_in, true, wrap));
   for (int i = L - 1; i >= 0; --i) {
     const int block_out = cf.ch * cf.ch_mult[i];
     const std::string u = "decoder.up." + std::to_string(i), ut = "decoder.up_temporal." + std::to_string(i);
     for (int b = 0; b < cf.num_res_blocks + 1; ++b) {
       g.stages.emplace_back(res_block(sh, u + ".block." + std::to_string(b), block_in, block_out, false));
-      g.stages.emplace_back(t_block(sh, ut + ".block." + std::to_string(b), block_out));
+      g.stages.emplace_back(t_block(sh, ut + ".block." + std::to_string(b), block_out, wrap));
       block_in = block_out;
     }
     if (in_list(cf.spatial_us, cf.n_spatial_us, i)) {
@@ -933,13 +966,13 @@ Graph build_decoder(const vt_model_config& cf, Shapes& sh) {
         t->ch = block_in; t->key = ut + ".upsample";
         t->n_up = n_up;
         n_up *= 2;
-        sh_conv(sh, ut + ".upsample.conv.conv", block_in, block_in, {3, 3, 3});
+        sh_conv(sh, ut + ".upsample.conv" + cv, block_in, block_in, {3, 3, 3});
         sh[ut + ".upsample.mix_factor"] = {1};
         g.stages.emplace_back(t);
       }
     }
   }
-  g.conv_in = "decoder.conv_in.conv"; g.conv_out = "decoder.conv_out.conv";
+  g.conv_in = "decoder.conv_in" + cv; g.conv_out = "decoder.conv_out" + cv;
   g.norm_out.key = "decoder.norm_out";
   g.c_last = block_in;
   sh_conv(sh, g.conv_in, g.c_first, cf.z_channels, {3, 3, 3});
@@ -955,7 +988,8 @@ void run_graph(Ctx& c, Graph& g, const Tens& x_in, int cout_final, float* out_nc
   c.cur = &m->arena[which];
   c.cur->reset();
   const NormRef first = g.stages[0]->first_norm(c);
-  Act h = conv_causal(c, g.st_in, x_in, m->conv_w(g.conv_in + ".weight", x_in.ld, c.dry), 27 * x_in.ld, m->f32(g.conv_in + ".bias", c.dry), causal3d(3, 3, 3), g.c_first, emit(first, m->tpad()));
+  const Geom g333 = m->noncausal() ? centred(causal3d(3, 3, 3), 1) : causal3d(3, 3, 3);       // conv_in / conv_out: causal, or Conv3d padding 1
+  Act h = conv_causal(c, g.st_in, x_in, m->conv_w(g.conv_in + ".weight", x_in.ld, c.dry), 27 * x_in.ld, m->f32(g.conv_in + ".bias", c.dry), g333, g.c_first, emit(first, m->tpad()));
   for (size_t i = 0; i < g.stages.size(); ++i) {
     which ^= 1;
     c.cur = &m->arena[which];
@@ -971,12 +1005,12 @@ void run_graph(Ctx& c, Graph& g, const Tens& x_in, int cout_final, float* out_nc
   o.ncthw = out_ncthw ? out_ncthw : (float*)16;      // dry runs pass no buffer
   o.t_trim = t_trim;
   o.tmode = m->tpad();
-  conv_causal(c, g.st_out, hn, m->conv_w(g.conv_out + ".weight", hn.ld, c.dry), 27 * hn.ld, m->f32(g.conv_out + ".bias", c.dry), causal3d(3, 3, 3), cout_final, o);
+  conv_causal(c, g.st_out, hn, m->conv_w(g.conv_out + ".weight", hn.ld, c.dry), 27 * hn.ld, m->f32(g.conv_out + ".bias", c.dry), g333, cout_final, o);
 }
 
 int front_pad(const vt_model_config& cf, int T) {      // EncoderCausal3DPadding.forward: v1.0 pads f - 1 frames, v1.1 up to a multiple of f
   const int f = cf.time_downsample_factor;
-  if (T % f == 0) return 0;
+  if (T % f == 0 || cf.version == 2) return 0;         // Encoder3D pads nothing (T must be a multiple of f: vt_encode checks)
   return cf.version == 1 ? f - T % f : f - 1;
 }
 
@@ -995,7 +1029,7 @@ void decode_impl(Model* m, Graph& g, const float* z, int B, int T, int H, int W,
   m->arena[0].reset();
   Tens zin = c.alloc(B, T, H, W, pad8(m->cfg.z_channels), m->dt, pad8(m->cfg.z_channels));
   if (!dry) M_CALL(vt_ncthw_to_ndhwc(z, zin.p, m->dt, B, m->cfg.z_channels, T, H, W, zin.ld, 0, stream));
-  run_graph(c, g, zin, m->cfg.out_ch, x_out, m->v11() ? 0 : m->cfg.time_downsample_factor - 1);   // v1.1 keeps every frame (the caller drops the padding's)
+  run_graph(c, g, zin, m->cfg.out_ch, x_out, m->cfg.version != 0 ? 0 : m->cfg.time_downsample_factor - 1);   // v1.1 keeps every frame (the caller drops the padding's), the non-causal decoder drops nothing
 }
 
 // ---- temporal tiling of the v1.1 tokenizers (AutoencodingEngineV11.tile_encode / tile_decode, autoencoder_v1_1.py:218-331) -----------
@@ -1100,7 +1134,7 @@ extern "C" int vt_create(const vt_model_config* cfg, int32_t compute_dtype, vt_m
   try {
     M_CHECK(cfg != nullptr && out != nullptr, "vt_create: null argument");
     M_CHECK(compute_dtype == VT_BF16 || compute_dtype == VT_F32 || compute_dtype == VT_BF16X3, "vt_create: compute dtype must be VT_BF16, VT_F32 or VT_BF16X3");
-    M_CHECK(cfg->version == 0 || cfg->version == 1, "vt_create: version 0 (v1.0 causal) or 1 (v1.1 causal, one pass per clip); the non-causal family stays with the Python host");
+    M_CHECK(cfg->version >= 0 && cfg->version <= 2, "vt_create: version 0 (v1.0 causal), 1 (v1.1 causal) or 2 (non-causal Encoder3D / Decoder3D)");
     M_CHECK(cfg->interpolation_mode == 0 || (cfg->interpolation_mode == 1 && cfg->version == 1), "vt_create: interpolation_mode 0 (nearest) or, for v1.1, 1 (trilinear)");
     M_CHECK(cfg->num_resolutions >= 1 && cfg->num_resolutions <= 8 && cfg->num_res_blocks >= 1 && cfg->ch > 0, "vt_create: bad level / block counts");
     M_CHECK(cfg->n_spatial_ds <= 8 && cfg->n_tempo_ds <= 8 && cfg->n_spatial_us <= 8 && cfg->n_tempo_us <= 8 && cfg->n_levels <= 8, "vt_create: list too long");
@@ -1305,6 +1339,8 @@ extern "C" int vt_encode(vt_model* h, const float* x, int32_t B, int32_t T, int3
     M_CHECK(h && x && h_out && B > 0 && T > 0 && H > 0 && W > 0, "vt_encode: bad argument");
     const int ds = 1 << h->m.cfg.n_spatial_ds;
     M_CHECK(H % ds == 0 && W % ds == 0, "vt_encode: H and W must be multiples of %d", ds);
+    M_CHECK(!h->m.noncausal() || T % h->m.cfg.time_downsample_factor == 0, "vt_encode: the non-causal encoder takes clips whose length is a multiple of %d",
+            h->m.cfg.time_downsample_factor);
     check_loaded(h, "encoder.");
     bind_workspace(h->m, workspace, workspace_bytes);
     encode_impl(&h->m, h->enc, x, B, T, H, W, h_out, reinterpret_cast<hipStream_t>(stream), false);
@@ -1321,7 +1357,7 @@ extern "C" int vt_decode(vt_model* h, const float* z, int32_t B, int32_t Tz, int
                          int64_t workspace_bytes, vt_stream stream) {
   try {
     M_CHECK(h && z && x_out && B > 0 && Tz > 0 && Hz > 0 && Wz > 0, "vt_decode: bad argument");
-    M_CHECK(h->m.v11() || (Tz << h->m.cfg.n_tempo_us) > h->m.cfg.time_downsample_factor - 1, "vt_decode: too few latent frames");
+    M_CHECK(h->m.cfg.version != 0 || (Tz << h->m.cfg.n_tempo_us) > h->m.cfg.time_downsample_factor - 1, "vt_decode: too few latent frames");
     check_loaded(h, "decoder.");
     bind_workspace(h->m, workspace, workspace_bytes);
     decode_impl(&h->m, h->dec, z, B, Tz, Hz, Wz, x_out, reinterpret_cast<hipStream_t>(stream), false);
