@@ -275,11 +275,13 @@ def committed_traffic(dtype, batch):
     different rounds name the figure differently; both spellings are read.  Returns (bytes | None, source)."""
     if batch != 4:
         return None, "committed passes are for B=4"
+    import re
+
     sfx = "" if dtype == "bf16" else "_" + dtype
-    for rnd in ("r03", "r02", "r01"):
-        tpath = os.path.join(ROOT, "profiles", f"{rnd}_conv_traffic_pmc{sfx}.json")
-        if not os.path.exists(tpath):
-            continue
+    pdir = os.path.join(ROOT, "profiles")
+    names = sorted((f for f in (os.listdir(pdir) if os.path.isdir(pdir) else []) if re.fullmatch(rf"r\d+_conv_traffic_pmc{sfx}\.json", f)), reverse=True)
+    for name in names:
+        tpath = os.path.join(pdir, name)
         try:
             rec = json.load(open(tpath))
         except (OSError, ValueError):

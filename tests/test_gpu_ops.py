@@ -188,12 +188,15 @@ NARROW_CASES = [   # conv3d_narrow_kernel: bf16 -> fp32 NCTHW, Cin 128, Cout <= 
 ]
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, X3], ids=["bf16", "x3"])
 @pytest.mark.parametrize("nw", ["1", "0"], ids=["narrow", "igemm"])
 @pytest.mark.parametrize("case", NARROW_CASES, ids=[c[0] for c in NARROW_CASES])
-def test_conv_narrow_output(case, nw, vt_opts):
+def test_conv_narrow_output(case, nw, dtype, vt_opts):
+    """bf16, and the split-bf16 form (fp32 x, weight planes): two passes of the same kernel, hi plane -> y, lo plane onto y"""
     vt_opts(conv_narrow=nw)
-    plan = _check_conv(case, torch.bfloat16)
+    plan = _check_conv(case, dtype)
     assert plan["kernel"] == ("narrow" if nw == "1" else "igemm")
+    assert plan["launches"] == (2 if (nw == "1" and dtype == X3) else 1)
 
 
 def test_conv_narrow_is_tiling_independent():

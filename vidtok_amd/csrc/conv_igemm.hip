@@ -1595,13 +1595,14 @@ inline bool ws128_eligible(const ConvArgs& a, int nbatch, bool bf16_io) {
 // Narrow-output 3x3x3 convolution (conv_narrow.hip): bf16 in, fp32 NCTHW out, Cin = 128, Cout <= 4 -- the decoder's
 // conv_out (reference model_3dcausal.py:862-870).  VT_CONV_NARROW=0 keeps it on the 256 x 32 implicit-GEMM tile.
 inline bool narrow_eligible(const ConvArgs& a, int nbatch, int dtype, int out_dtype, int ln_mode) {
-  if (dtype != VT_BF16 || out_dtype != VT_F32 || a.out_layout != VT_NCTHW || vt_opt(OPT_CONV_NARROW) == 0) return false;
+  if ((dtype != VT_BF16 && dtype != VT_BF16X3) || out_dtype != VT_F32 || a.out_layout != VT_NCTHW || vt_opt(OPT_CONV_NARROW) == 0) return false;
   if (a.Cin != 128 || a.Cout > 4 || a.KT != 3 || a.KH != 3 || a.KW != 3) return false;
   if (a.st != 1 || a.sh != 1 || a.sw != 1 || a.ph != 1 || a.pw != 1 || a.pt < 1 || a.pt > 2) return false;
   if (a.ups_t || a.ups_s || a.Ho != a.Hi || a.Wo != a.Wi || a.To != a.Ti) return false;
   if (a.res_mode != VT_RES_NONE || ln_mode != 0 || nbatch != 1 || a.yt_mul != 1 || a.ys_mul == 2) return false;
   if ((long long)a.Ho * a.Wo * 256 > (1ll << 30)) return false;
   if (a.tmode == VT_TPAD_CACHE && a.ncache < a.pt) return false;
+  if (dtype == VT_BF16X3 && a.ldw != 27 * 128) return false;      // the planes are addressed as [K / 16][hi 16 | lo 16], K = 3 456
   return true;
 }
 
@@ -1664,7 +1665,7 @@ int dispatch_tile(const ConvArgs& a, int nbatch, hipStream_t stream) {
 
 extern "C" int vt_ws128_launch(const void* conv_args, void* stream);   // conv_ws128.hip
 extern "C" int vt_ws2_launch(const void* conv_args, void* stream);     // conv_ws2.hip (option conv_ws = 2)
-extern "C" int vt_conv_narrow_launch(const void* conv_args, void* stream);   // conv_narrow.hip
+extern "C" int vt_conv_narrow_launch(const void* conv_args, void* stream, int x3);   // conv_narrow.hip (x3: fp32 x, split weight planes, two passes)
 extern "C" void vt_conv_narrow_plan(const void* conv_args, int32_t* plan4);
 
 extern "C" int vt_conv_max_lds_bytes(void) { return 163840; }   // conv3x3_ws128_kernel: two patches + T = all of a CU's LDS
@@ -1792,7 +1793,7 @@ extern "C" int vt_conv_plan(const vt_conv_desc* d, int32_t* out8) {
   out8[7] = 0;
   if (narrow_eligible(a, nbatch, d->dtype, d->out_dtype, d->ln_mode)) {   // independent waves: 8 x 14 output pixels x all frames of a time segment
     vt_conv_narrow_plan(&a, out8);
-    out8[4] = 0; out8[5] = 1; out8[6] = 2;
+    out8[4] = 0; out8[5] = d->dtype == VT_BF16X3 ? 2 : 1; out8[6] = 2;      // split-bf16: two passes (hi / lo weight plane)
     return VT_OK;
   }
   if (use_ws) {   // persistent, at most one workgroup per CU, all 128 channels per tile: conv_ws128.hip walks 8 x 16-pixel tiles on 4 waves,
@@ -1843,7 +1844,7 @@ extern "C" int vt_conv(const vt_conv_desc* d, vt_stream stream_) {
   int rc = conv_prepare(d, a, ln_fused, nbatch, use_ws);
   if (rc != VT_OK) return rc;
   if (use_ws) return vt_opt(OPT_CONV_WS) == 2 ? vt_ws2_launch(&a, stream_) : vt_ws128_launch(&a, stream_);
-  if (narrow_eligible(a, nbatch, d->dtype, d->out_dtype, d->ln_mode)) return vt_conv_narrow_launch(&a, stream_);
+  if (narrow_eligible(a, nbatch, d->dtype, d->out_dtype, d->ln_mode)) return vt_conv_narrow_launch(&a, stream_, d->dtype == VT_BF16X3 ? 1 : 0);
   const long long M = a.M;
   if (d->dtype == VT_F32) rc = dispatch_tile<float, float>(a, nbatch, stream);
   else if (d->dtype == VT_BF16X3) rc = dispatch_tile<split3_t, float>(a, nbatch, stream);

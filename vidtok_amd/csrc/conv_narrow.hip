@@ -32,10 +32,15 @@ namespace {
 [[maybe_unused]] constexpr int NW_TH = 8;                 // output rows of a wave tile
 [[maybe_unused]] constexpr int NW_PH = NW_TH + 2;         // input rows
 [[maybe_unused]] constexpr int NW_OW = 14;                // output columns of a wave tile (16 input columns)
-[[maybe_unused]] constexpr int NW_ROWB = 4096;            // one input row of the window in LDS: 4 fragments of 1 KiB
-[[maybe_unused]] constexpr int NW_RING = 8;               // ring of rows per wave
-[[maybe_unused]] constexpr int NW_DEPTH = 5;              // rows in flight ahead of the one being multiplied
-[[maybe_unused]] constexpr int NW_LDS = 4 * NW_RING * NW_ROWB;   // 131 072 B per workgroup (4 waves)
+// per arithmetic: bytes of one input row of the window in LDS (bf16: 4 fragments of 1 KiB; fp32 for the split-bf16 form: 8),
+// ring of rows per wave, rows in flight ahead of the one being multiplied -- 128 KiB per workgroup (4 waves) either way
+template <int MODE> struct NwCfg {
+  [[maybe_unused]] static constexpr int NDMA = MODE == 0 ? 4 : 8;
+  [[maybe_unused]] static constexpr int ROWB = NDMA * 1024;
+  [[maybe_unused]] static constexpr int RING = MODE == 0 ? 8 : 4;
+  [[maybe_unused]] static constexpr int DEPTH = MODE == 0 ? 5 : 2;
+};
+[[maybe_unused]] constexpr int NW_LDS = 4 * 8 * 4096;     // 131 072 B
 
 struct NarrowArgs {
   const char* x;        // [B][Ti][H][W][128] bf16
@@ -57,8 +62,15 @@ __device__ __forceinline__ void nw_static_for(F&& f) {
   }
 }
 
+// MODE 0: bf16 tensors.  MODE 1 / 2: the split-bf16 arithmetic (VT_BF16X3: x fp32, w = [hi 16 | lo 16] bf16 planes per 16 k) as
+// TWO passes over x, each with 36 stationary fragments like the bf16 kernel (both planes at once would be 288 registers of
+// weights): pass 1 keeps the hi plane and takes W_hi x_lo + W_hi x_hi (+ bias) -> y, pass 2 keeps the lo plane and adds
+// W_lo x_hi to y.  The activations are split in registers behind their fragment read (split3_x, conv_common.h).
+template <int MODE>
 __global__ __launch_bounds__(256, 1) void conv3d_narrow_kernel(const NarrowArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int NW_ROWB = NwCfg<MODE>::ROWB, NW_RING = NwCfg<MODE>::RING, NW_DEPTH = NwCfg<MODE>::DEPTH, NDMA = NwCfg<MODE>::NDMA;
+  constexpr int PIXB = MODE == 0 ? 256 : 512;          // bytes of a pixel's 128 channels
   extern __shared__ __attribute__((aligned(16))) char smem[];
   typedef __attribute__((address_space(3))) void* lds_ptr_t;
   const int lane = threadIdx.x & 63;
@@ -83,21 +95,34 @@ __global__ __launch_bounds__(256, 1) void conv3d_narrow_kernel(const NarrowArgs 
   {
     const int m = lane & 15, co = m >> 2, kw = m & 3;
     const bool ok = co < p.Cout && kw < 3;
-    const bf16_t* row = reinterpret_cast<const bf16_t*>(p.w) + (long long)(ok ? co : 0) * p.ldw + (ok ? kw : 0) * 128 + (lane >> 4) * 8;
+    if constexpr (MODE == 0) {
+      const bf16_t* row = reinterpret_cast<const bf16_t*>(p.w) + (long long)(ok ? co : 0) * p.ldw + (ok ? kw : 0) * 128 + (lane >> 4) * 8;
 #pragma unroll
-    for (int f = 0; f < 36; ++f) {                   // f = (kt*3 + kh)*4 + ks
-      u32x4 v = *reinterpret_cast<const u32x4*>(row + (f >> 2) * 3 * 128 + (f & 3) * 32);
-      if (!ok) v = u32x4{0u, 0u, 0u, 0u};
-      wf[f] = v;
+      for (int f = 0; f < 36; ++f) {                 // f = (kt*3 + kh)*4 + ks
+        u32x4 v = *reinterpret_cast<const u32x4*>(row + (f >> 2) * 3 * 128 + (f & 3) * 32);
+        if (!ok) v = u32x4{0u, 0u, 0u, 0u};
+        wf[f] = v;
+      }
+    } else {
+      // k = tap * 128 + 32 ks + 8 (lane >> 4): group of 16 = k / 16 at byte (k / 16) * 64 of the row, plane 32 B apart, 8 values = 16 B
+      const char* row = p.w + (long long)(ok ? co : 0) * p.ldw * 4 + (MODE == 2 ? 32 : 0);
+#pragma unroll
+      for (int f = 0; f < 36; ++f) {
+        const int k0 = ((f >> 2) * 3 + (ok ? kw : 0)) * 128 + (f & 3) * 32 + (lane >> 4) * 8;
+        u32x4 v = *reinterpret_cast<const u32x4*>(row + (k0 >> 4) * 64 + (k0 & 15) * 2);
+        if (!ok) v = u32x4{0u, 0u, 0u, 0u};
+        wf[f] = v;
+      }
     }
   }
 
   // ---- DMA lane constants: lane l fetches 16 B: pixel l >> 2 of the window, unit 4 ks + (l & 3) of its 16 ----------------
   constexpr unsigned kOob = 0xFFFF0000u;
-  const unsigned frame_bytes = (unsigned)H * (unsigned)W * 256u;   // <= 2^30 (launcher)
+  const unsigned frame_bytes = (unsigned)H * (unsigned)W * (unsigned)PIXB;   // <= 2^31 (launcher)
   const int dcol = c0 - 1 + (lane >> 2);
   const bool dcol_ok = dcol >= 0 && dcol < W;
-  const unsigned dlane = (unsigned)(dcol * 256 + (lane & 3) * 16);
+  // bf16: unit 4 ks + (l & 3) = 16 B; fp32: the 8 values of (ks, l & 3) are 32 B, fetched as two 16-B halves
+  const unsigned dlane = (unsigned)(dcol * PIXB + (lane & 3) * (MODE == 0 ? 16 : 32));
   char* ring = smem + wave * (NW_RING * NW_ROWB);
   // B fragment lane (g = lane >> 4, n = lane & 15): pixel n, unit 4 ks + g -> byte (4 n + g) * 16 of fragment ks
   const int rd = ((lane & 15) * 4 + (lane >> 4)) * 16;
@@ -118,13 +143,13 @@ __global__ __launch_bounds__(256, 1) void conv3d_narrow_kernel(const NarrowArgs 
     __amdgpu_buffer_rsrc_t rsrc = frame_rsrc(j, live);
     const int hi = h0 - 1 + r;
     const bool ok = hi >= 0 && hi < H;
-    const unsigned off = (ok && dcol_ok) ? (unsigned)(hi * W) * 256u + dlane : kOob;
+    const unsigned off = (ok && dcol_ok) ? (unsigned)(hi * W) * (unsigned)PIXB + dlane : kOob;
     char* dst = ring + rs * NW_ROWB;
-    // k-step ks = +64 B in memory through the scalar offset (an instruction offset would move the LDS side as well)
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)(dst), 16, off, 0, 0, 0);
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)(dst + 1024), 16, off, 64, 0, 0);
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)(dst + 2048), 16, off, 128, 0, 0);
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)(dst + 3072), 16, off, 192, 0, 0);
+    // k-step ks = +64 B (bf16) / +128 B (fp32; second half of a lane's 8 values + 16 B) in memory through the scalar offset (an
+    // instruction offset would move the LDS side as well)
+#pragma unroll
+    for (int i = 0; i < NDMA; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)(dst + i * 1024), 16, off, MODE == 0 ? i * 64 : (i >> 1) * 128 + (i & 1) * 16, 0, 0);
   };
 
   // ---- accumulators: [slot = output frame mod 3][output row] -----------------------------------------------------------------
@@ -157,16 +182,16 @@ __global__ __launch_bounds__(256, 1) void conv3d_narrow_kernel(const NarrowArgs 
 
   // B fragments of two rows: the row being multiplied and the next one, read from the ring one row ahead of its use
   // (with one wave per SIMD nobody else covers an LDS round trip in front of the MFMAs)
-  u32x4 bf[2][4];
+  u32x4 bf[2][NDMA];                                  // bf16: fragment ks; fp32: the two halves of fragment ks at 2 ks, 2 ks + 1
   int crs = 0;                                        // ring row to read next
   auto read_row = [&](auto parc) {
     constexpr int par = decltype(parc)::value;
     const char* src = ring + crs * NW_ROWB + rd;
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) bf[par][ks] = *reinterpret_cast<const u32x4*>(src + ks * 1024);
+    for (int i = 0; i < NDMA; ++i) bf[par][i] = *reinterpret_cast<const u32x4*>(src + i * 1024);
     crs = crs + 1 == NW_RING ? 0 : crs + 1;
   };
-  wait_vmcnt<4 * (NW_DEPTH - 1)>();
+  wait_vmcnt<NDMA * (NW_DEPTH - 1)>();
   read_row(std::integral_constant<int, 0>{});
 
   // one step = one input frame: 10 rows x 4 fragments x 9 MFMAs, then the frame that got its last tap is stored
@@ -175,19 +200,26 @@ __global__ __launch_bounds__(256, 1) void conv3d_narrow_kernel(const NarrowArgs 
     nw_static_for<0, NW_PH>([&](auto rc) {
       constexpr int r = decltype(rc)::value;          // (NW_PH is even: the parity of a row is the parity of r)
       issue_next();
-      wait_vmcnt<4 * (NW_DEPTH - 1)>();               // the next row has landed; later ones may still fly (stores only add)
+      wait_vmcnt<NDMA * (NW_DEPTH - 1)>();            // the next row has landed; later ones may still fly (stores only add)
       read_row(std::integral_constant<int, (r + 1) & 1>{});
       nw_static_for<0, 4>([&](auto ksc) {
         constexpr int ks = decltype(ksc)::value;
+        u32x4 xhi, xlo;
+        if constexpr (MODE == 0) xhi = bf[r & 1][ks];
+        else split3_x(bf[r & 1][2 * ks], bf[r & 1][2 * ks + 1], xhi, xlo);
         nw_static_for<0, 3>([&](auto ktc) {
           constexpr int kt = decltype(ktc)::value;
           constexpr int s = (jp - kt + 3) % 3;        // output frame j - kt
           nw_static_for<0, 3>([&](auto khc) {
             constexpr int kh = decltype(khc)::value;
             constexpr int orow = r - kh;              // input row h0 - 1 + r is tap kh of output row h0 + r - kh
-            if constexpr (orow >= 0 && orow < NW_TH)
+            if constexpr (orow >= 0 && orow < NW_TH) {
+              if constexpr (MODE == 1)                // small term first: W_hi x_lo
+                acc[s][orow] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[(kt * 3 + kh) * 4 + ks]),
+                                                                       __builtin_bit_cast(bf16x8, xlo), acc[s][orow], 0, 0, 0);
               acc[s][orow] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[(kt * 3 + kh) * 4 + ks]),
-                                                                     __builtin_bit_cast(bf16x8, bf[r & 1][ks]), acc[s][orow], 0, 0, 0);
+                                                                     __builtin_bit_cast(bf16x8, xhi), acc[s][orow], 0, 0, 0);
+            }
           });
         });
       });
@@ -202,8 +234,12 @@ __global__ __launch_bounds__(256, 1) void conv3d_narrow_kernel(const NarrowArgs 
       const f32x4 v = acc[fs][r];
       const float left = __shfl_up(v[0], 1, 16);      // Q[kw=0] of column - 1
       const float right = __shfl_down(v[2], 1, 16);   // Q[kw=2] of column + 1
-      const float o = __fadd_rn(__fadd_rn(__fadd_rn(left, v[1]), right), bias);
-      if (st_frame && st_lane && (h0 + r) < H) yf[(long long)(h0 + r) * W] = o;
+      float o = __fadd_rn(__fadd_rn(left, v[1]), right);
+      if constexpr (MODE != 2) o = __fadd_rn(o, bias);
+      if (st_frame && st_lane && (h0 + r) < H) {
+        if constexpr (MODE == 2) o = __fadd_rn(yf[(long long)(h0 + r) * W], o);     // second pass: onto the first one's result
+        yf[(long long)(h0 + r) * W] = o;
+      }
       acc[fs][r] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
   };
@@ -248,21 +284,28 @@ extern "C" __attribute__((visibility("hidden"))) void vt_conv_narrow_plan(const 
 }
 
 // conv_igemm.hip's dispatcher hands over launches that qualify; `args` is its ConvArgs
-extern "C" __attribute__((visibility("hidden"))) int vt_conv_narrow_launch(const void* args, void* stream_) {
+extern "C" __attribute__((visibility("hidden"))) int vt_conv_narrow_launch(const void* args, void* stream_, int x3) {
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
   NarrowArgs n;
   const long long grid = narrow_geometry(*reinterpret_cast<const ConvArgs*>(args), n);
   VT_CHECK_ARG(grid > 0 && grid < (1ll << 31), "vt_conv (narrow): grid");
-  const void* kern = reinterpret_cast<const void*>(&conv3d_narrow_kernel);
+  const void* kerns[3] = {reinterpret_cast<const void*>(&conv3d_narrow_kernel<0>), reinterpret_cast<const void*>(&conv3d_narrow_kernel<1>),
+                          reinterpret_cast<const void*>(&conv3d_narrow_kernel<2>)};
   static std::atomic<bool> attr_done[kMaxDevices];
   int dev = 0;
   VT_CHECK_HIP(hipGetDevice(&dev));
   const bool dev_ok = dev >= 0 && dev < kMaxDevices;
   if (!dev_ok || !attr_done[dev].load(std::memory_order_acquire)) {
-    VT_CHECK_HIP(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, NW_LDS));
+    for (const void* k : kerns) VT_CHECK_HIP(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, NW_LDS));
     if (dev_ok) attr_done[dev].store(true, std::memory_order_release);
   }
   void* kargs[] = {&n};
-  VT_CHECK_HIP(hipLaunchKernel(kern, dim3((unsigned)grid), dim3(256), kargs, NW_LDS, stream));
+  if (!x3) {
+    VT_CHECK_HIP(hipLaunchKernel(kerns[0], dim3((unsigned)grid), dim3(256), kargs, NW_LDS, stream));
+    return VT_OK;
+  }
+  // split-bf16: two passes over x (hi weight plane -> y, lo weight plane onto y), stream-ordered
+  VT_CHECK_HIP(hipLaunchKernel(kerns[1], dim3((unsigned)grid), dim3(256), kargs, NW_LDS, stream));
+  VT_CHECK_HIP(hipLaunchKernel(kerns[2], dim3((unsigned)grid), dim3(256), kargs, NW_LDS, stream));
   return VT_OK;
 }
