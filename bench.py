@@ -208,7 +208,7 @@ def other_config_measurements(dev, x):
 
 
 
-MFMA_KERNELS = ("conv_igemm", "conv3x3_ws2", "conv3x3_ws128", "conv3d_narrow", "tblock_pair")
+MFMA_KERNELS = ("conv_igemm", "conv3x3_ws2", "conv3x3_ws128", "conv3d_narrow", "tblock_pair", "flash_attn")
 
 
 def measure_traffic(dtype, batch, config, timeout_s=200, table=None):
@@ -491,7 +491,7 @@ def main():
         # unit over kernel time -- is an effective rate; the executed rate is reported next to it
         executed = sum(2.0 * M * N * K for (M, N, K) in tl)
         peak = PEAK_TFLOPS[args.dtype]
-        roof = {"bound": "mfma", "kernel": "conv_igemm_glds_kernel + conv3x3_ws2_kernel + conv3d_narrow_kernel + tblock_pair_kernel", "achieved": round(achieved, 2), "peak": peak,
+        roof = {"bound": "mfma", "kernel": "conv_igemm_glds_kernel + conv3x3_ws2_kernel + conv3d_narrow_kernel + tblock_pair_kernel + flash_attn_kernel", "achieved": round(achieved, 2), "peak": peak,
                 "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": None, "traffic_source": "not measured",
                 "launches_per_step": len(tl), "kernel_ms_per_step": round(conv_ms, 3),
                 "avg_launch_ms": round(conv_ms / max(1, len(tl)), 4), "algorithmic_tflop_per_step": round(flops / 1e12, 3),

@@ -98,6 +98,7 @@ int vt_conv_max_lds_bytes(void);
  *   conv_sched_x3 (3)   K-step schedule of the 8-wave tile under VT_BF16X3 (64-byte rows, 4-slot ring): 0 plain loop, 1 / 2 / 3 two
  *                       wave groups alternating LOAD and COMPUTE phases with the DMA pieces of a step issued in the LOAD phase /
  *                       between the MFMAs of the COMPUTE phase / half and half
+ *   attn_flash (1)      the attention block as one vt_flash_attention launch where it applies; 0: GEMM -> softmax -> GEMM operators
  *   ws_acc (0), tblock_prof_mode (0), ws_prof_mode (0)   measurement aids
  *   tblock_fused (1)   0: vt_temporal_block_supported answers no (blocks stay on the unfused operators)
  * Returns VT_ERR_ARG for an unknown name.
@@ -271,6 +272,17 @@ int64_t vt_groupnorm_work_bytes(int32_t B, int32_t T, int32_t groups, int32_t sc
 int vt_groupnorm_act(const void* x, int in_dtype, int64_t ldx, void* y, int out_dtype, int64_t ldy,
                      const float* gamma, const float* beta, int32_t B, int32_t T, int64_t HW, int32_t C,
                      int32_t groups, int32_t scope, float eps, int32_t silu, void* work, vt_stream stream);
+
+/* Single-head self-attention of the pixels of a frame in ONE launch, nothing S x S in memory (F.scaled_dot_product_attention
+ * of AttnBlock, model_3dcausal.py:129-141): o[z][q][:] = sum_k softmax_k(scale * q[z][q] . k[z][k]) v[z][k][:] + bias_v.
+ * q, k, o: [Z][S][C]; vt: V TRANSPOSED, [Z][C][ldv] with the keys contiguous (the v projection with its operands swapped, as the
+ * hosts already compute it; its bias goes in as bias_v, fp32 [C] or NULL).  bf16, C = 512, S a multiple of 64
+ * (vt_flash_attention_supported says whether a shape is covered and option attn_flash is on; otherwise the same contract is
+ * vt_conv as batched GEMM -> vt_softmax_rows -> vt_conv).  Online softmax in fp32; P is rounded to bf16 before the second
+ * product, un-normalised, and the division by the row sum comes last. */
+int vt_flash_attention_supported(int32_t dtype, int32_t S, int32_t C, int32_t ldv);
+int vt_flash_attention(const void* q, const void* k, const void* vt, const float* bias_v, void* o, int32_t dtype, int32_t Z, int32_t S,
+                       int32_t C, int32_t ldv, float scale, vt_stream stream);
 
 /* row softmax(scale * s) over the last dim; s fp32 [rows][cols] -> p (out_dtype) [rows][ldp].
  * The softmax inside F.scaled_dot_product_attention (model_3dcausal.py:140), scale = C^-0.5. */

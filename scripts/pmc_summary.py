@@ -7,7 +7,7 @@ import sys
 from collections import defaultdict
 
 
-FAMILIES = ("conv_igemm", "conv3x3_ws2", "conv3x3_ws128", "conv3d_narrow", "tblock_pair", "layernorm_act")
+FAMILIES = ("conv_igemm", "conv3x3_ws2", "conv3x3_ws128", "conv3d_narrow", "tblock_pair", "flash_attn", "layernorm_act")
 
 
 def main(root):

@@ -131,6 +131,28 @@ def test_matches_cpu_oracle(name, shape, dtype, tol):
         assert (qlog["indices"].cpu() != log2["indices"]).sum() == 0
 
 
+@pytest.mark.parametrize("name,shape", [("vidtok_kl_causal_488_4chn", (1, 3, 9, 128, 128)), ("vidtok_kl_noncausal_488_4chn", (1, 3, 8, 64, 64))])
+def test_attention_flash_and_operator_paths(name, shape, vt_opts):
+    """the attention block as ONE launch (vt_flash_attention, default where it applies: bf16, S % 64 == 0) and as the operator sequence
+    GEMM -> softmax -> GEMM (option attn_flash = 0): both inside the bf16 gates against the fp32 oracle, and close to each other"""
+    model, cfg, sd = build_model(name, seed=12, device=DEV, dtype=torch.bfloat16)
+    model.regularization.sample = False
+    ora = build_oracle(cfg, sd)
+    ora.sample = False
+    x = torch.rand(shape, generator=torch.Generator().manual_seed(5)) * 2 - 1
+    z2, dec2, _ = ora(x)
+    outs = {}
+    for flash in (1, 0):
+        vt_opts(attn_flash=flash)
+        z, dec, _ = model(x.to(DEV))
+        ez, ed = rel_err(z, z2), rel_err(dec, dec2)
+        print(f"{name} attn_flash={flash}: z rel {ez:.3e} dec rel {ed:.3e}")
+        assert ez < BF16_Z and ed < BF16_RECON
+        outs[flash] = (z, dec)
+    assert not torch.equal(outs[0][1], outs[1][1])                      # two different kernels did run
+    assert rel_err(outs[1][0], outs[0][0]) < BF16_Z and rel_err(outs[1][1], outs[0][1]) < BF16_RECON
+
+
 @pytest.mark.parametrize("name,shape", [("vidtok_kl_causal_488_4chn", (1, 3, 9, 32, 32)),
                                         ("vidtok_kl_noncausal_488_4chn", (1, 3, 8, 32, 32))])
 def test_groupnorm_variant_matches_oracle(name, shape):

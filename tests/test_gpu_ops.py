@@ -598,6 +598,47 @@ def test_gemm_nt(Z, M, N, K, bcast, use_bias, dtype):
         assert y.shape == (Z, M, N) and e < TOL[dtype], f"gemm {Z,M,N,K} {dtype}->{od}: {e}"
 
 
+@pytest.mark.parametrize("Z,S,ld,use_bias", [(2, 64, 64, True), (3, 256, 256, False), (2, 1024, 1024, True), (1, 4096, 4096, True), (2, 128, 136, True)],
+                         ids=["one_q_tile", "s256", "s1024_benchmark_size", "s4096_512x512_input", "padded_vT"])
+def test_flash_attention(Z, S, ld, use_bias):
+    """vt_flash_attention (one launch, online softmax, nothing S x S in memory) against the fp32 statement of the attention and against
+    the operator sequence it replaces (batched GEMM -> row softmax -> batched GEMM) on the same tensors: S = 1 024 is the attention of
+    a 256 x 256 input, S = 4 096 of a 512 x 512 one"""
+    C_ = 512
+    dt = torch.bfloat16
+    q, k = _rand((Z, S, C_), dt, 1), _rand((Z, S, C_), dt, 2)
+    v = _rand((Z, S, C_), dt, 3)
+    vT = torch.zeros((Z, C_, ld), dtype=dt, device=DEV)
+    vT[:, :, :S] = v.transpose(1, 2)
+    bias = _rand((C_,), torch.float32, 4, 0.3) if use_bias else None
+    scale = C_ ** -0.5
+    assert ops.flash_attention_supported(q, vT)
+    o = ops.flash_attention(q, k, vT, bias, scale)
+    torch.cuda.synchronize()
+    ref = R.flash_attention(q.cpu(), k.cpu(), vT.cpu(), None if bias is None else bias.cpu(), scale)
+    e = rel_err(o, ref)
+    assert o.shape == (Z, S, C_) and torch.isfinite(o.float()).all() and e < TOL[dt], f"flash attention Z={Z} S={S}: {e}"
+    # the operator path on the same tensors (P normalised and rounded to bf16 before the second product: the two differ by roundings only)
+    s_ = ops.gemm_nt(q, k, out_dtype=torch.float32)
+    p_ = ops.softmax_rows(s_, scale, dt, ld_out=ld)
+    o2 = ops.gemm_nt(p_, vT, bias=bias)
+    e2 = rel_err(o, o2)
+    print(f"flash attention Z={Z} S={S}: vs fp32 statement {e:.3e}, vs operator path {e2:.3e}")
+    assert e2 < TOL[dt]
+
+
+def test_flash_attention_declines_other_shapes(vt_opts):
+    q = _rand((1, 96, 512), torch.bfloat16, 1)
+    assert not ops.flash_attention_supported(q, torch.zeros((1, 512, 96), dtype=torch.bfloat16, device=DEV))          # S % 64
+    q = _rand((1, 64, 256), torch.bfloat16, 1)
+    assert not ops.flash_attention_supported(q, torch.zeros((1, 256, 64), dtype=torch.bfloat16, device=DEV))          # C != 512
+    q = _rand((1, 64, 512), torch.float32, 1)
+    assert not ops.flash_attention_supported(q, torch.zeros((1, 512, 64), dtype=torch.float32, device=DEV))           # fp32 storage
+    q = _rand((1, 64, 512), torch.bfloat16, 1)
+    vt_opts(attn_flash=0)
+    assert not ops.flash_attention_supported(q, torch.zeros((1, 512, 64), dtype=torch.bfloat16, device=DEV))          # switched off
+
+
 @pytest.mark.parametrize("C", [32, 64, 128, 256, 512, 1024])
 @pytest.mark.parametrize("din,dout", [(torch.float32, torch.float32), (torch.bfloat16, torch.bfloat16),
                                       (torch.float32, torch.bfloat16), (torch.bfloat16, torch.float32)])

@@ -152,6 +152,20 @@ def groupnorm_act(x, gamma, beta, *, scope, silu, eps=1e-6, out_dtype=None, c=No
     return out
 
 
+def flash_attention_supported(q, vT):
+    return False          # the CPU statement of the attention block is the operator sequence (gemm_nt -> softmax_rows -> gemm_nt)
+
+
+def flash_attention(q, k, vT, bias_v, scale):
+    """softmax(scale * q k^T) v + bias_v, fp32 arithmetic on the stored values; q, k [Z, S, C], vT [Z, C, ld] (keys contiguous)"""
+    S = q.shape[1]
+    p = torch.softmax(torch.matmul(q.float(), k.float().transpose(1, 2)) * scale, dim=-1)
+    o = torch.matmul(p, vT.float()[:, :, :S].transpose(1, 2))
+    if bias_v is not None:
+        o = o + bias_v.float()[: o.shape[-1]]
+    return o.to(q.dtype)
+
+
 def softmax_rows(s, scale, out_dtype, ld_out=None):
     p = torch.softmax(s.float() * scale, dim=-1).to(out_dtype)
     if ld_out and ld_out > p.shape[-1]:

@@ -614,16 +614,23 @@ struct Attn : Stage {              // AttnBlockWrapper, model_3dcausal.py:83-141
     const float* bv = m->f32(key + ".v" + cv + ".bias", c.dry);
     // V^T directly: the weight is the row operand; v's bias is added after P V (rows of P sum to 1)
     char* vT = gemm_nt(c, wv, false, hn.p, Z, Cc, S, Cc, dt, dt, Sp, nullptr);                // [Z][C][Sp]
-    char* s = gemm_nt(c, q.p, true, k.p, Z, S, S, Cc, dt, VT_F32, S, nullptr);                 // [Z][S][S] fp32
-    const size_t pbytes = (size_t)Z * S * Sp * esize(dt);
-    char* p = c.cur->alloc(pbytes, c.dry);
-    if (!c.dry) {
-      if (Sp != S) M_HIP(hipMemsetAsync(p, 0, pbytes, c.stream));
-      // scale = C^-0.5 as the Python host passes it: computed in double, rounded once to float
-      M_CALL(vt_softmax_rows((const float*)s, p, dt, (int64_t)Z * S, S, Sp, (float)std::pow((double)Cc, -0.5), c.stream));
-    }
+    // scale = C^-0.5 as the Python host passes it: computed in double, rounded once to float
+    const float scale = (float)std::pow((double)Cc, -0.5);
     Tens o = xp;
-    o.p = gemm_nt(c, p, true, vT, Z, S, Cc, Sp, dt, dt, Cc, bv);                               // [Z][S][C] = [B][T][H][W][C]
+    if (vt_flash_attention_supported(dt, S, Cc, Sp)) {
+      // one launch with the online softmax: no [Z][S][S] scores in memory (vidtok_amd/modules.py takes the same decision)
+      o.p = c.cur->alloc((size_t)Z * S * Cc * esize(dt), c.dry);
+      if (!c.dry) M_CALL(vt_flash_attention(q.p, k.p, vT, bv, o.p, dt, Z, S, Cc, Sp, scale, c.stream));
+    } else {
+      char* s = gemm_nt(c, q.p, true, k.p, Z, S, S, Cc, dt, VT_F32, S, nullptr);               // [Z][S][S] fp32
+      const size_t pbytes = (size_t)Z * S * Sp * esize(dt);
+      char* p = c.cur->alloc(pbytes, c.dry);
+      if (!c.dry) {
+        if (Sp != S) M_HIP(hipMemsetAsync(p, 0, pbytes, c.stream));
+        M_CALL(vt_softmax_rows((const float*)s, p, dt, (int64_t)Z * S, S, Sp, scale, c.stream));
+      }
+      o.p = gemm_nt(c, p, true, vT, Z, S, Cc, Sp, dt, dt, Cc, bv);                             // [Z][S][C] = [B][T][H][W][C]
+    }
     ConvOpts op = emit(next);
     op.res = &xp;
     op.res_mode = VT_RES_ADD;

@@ -123,6 +123,8 @@ SIGNATURES = {
     "vt_temporal_block_supported": (C.c_int, [C.POINTER(TBlockDesc)]),
     "vt_temporal_block": (C.c_int, [C.POINTER(TBlockDesc), _P]),
     "vt_temporal_block_profile": (C.c_int, [C.POINTER(TBlockDesc), _P, _P]),
+    "vt_flash_attention_supported": (C.c_int, [_I32, _I32, _I32, _I32]),
+    "vt_flash_attention": (C.c_int, [_P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _F, _P]),
     "vt_layernorm_act": (C.c_int, [_P, C.c_int, _I64, _P, C.c_int, _I64, _P, _P, _I64, _I32, _F, _I32, _P]),
     "vt_tanh_inplace": (C.c_int, [_P, _I64, _P]),
     "vt_softmax_rows": (C.c_int, [_P, _P, C.c_int, _I64, _I32, _I64, _F, _P]),

@@ -600,9 +600,13 @@ class AttnBlockWrapper(nn.Module):
         wv, bv = self._v_rows.get(self.v.conv.weight, self.v.conv.bias, dt, cin_stored=Cc)
         Sp = ops.pad_channels(S)        # K-contiguous operands need 16-byte rows: pad S with zero columns
         vT = ops.gemm_nt(wv.view(1, Cc, Cc), hn.view(Z, S, Cc), ld_out=Sp)                     # [Z, C, Sp]
-        s = ops.gemm_nt(q, k, out_dtype=torch.float32)                                         # [Z, S, S]
-        p = ops.softmax_rows(s, float(Cc) ** -0.5, dt, ld_out=Sp)                              # [Z, S, Sp]
-        o = ops.gemm_nt(p, vT, bias=bv).view(B, T, H, W, Cc)
+        if ops.flash_attention_supported(q, vT):
+            # one launch, online softmax: no [Z, S, S] scores in memory (1 GiB per latent frame at 1024 x 1024 input)
+            o = ops.flash_attention(q, k, vT, bv, float(Cc) ** -0.5).view(B, T, H, W, Cc)
+        else:
+            s = ops.gemm_nt(q, k, out_dtype=torch.float32)                                     # [Z, S, S]
+            p = ops.softmax_rows(s, float(Cc) ** -0.5, dt, ld_out=Sp)                          # [Z, S, Sp]
+            o = ops.gemm_nt(p, vT, bias=bv).view(B, T, H, W, Cc)
         return _wrap(self.proj_out.run(o, dt, res=x, res_mode=L.VT_RES_ADD, **_emit(next_norm)), next_norm)
 
 

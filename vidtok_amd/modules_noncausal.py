@@ -168,9 +168,12 @@ class AttnBlockWrapper(nn.Module):
         wv, bv = self._pv.get(self.v.weight, self.v.bias, dt, cin_stored=Cc)
         Sp = ops.pad_channels(S)
         vT = ops.gemm_nt(wv.view(1, Cc, Cc), hn.view(Z, S, Cc), ld_out=Sp)
-        s = ops.gemm_nt(q, k, out_dtype=torch.float32)
-        p = ops.softmax_rows(s, float(Cc) ** -0.5, dt, ld_out=Sp)
-        o = ops.gemm_nt(p, vT, bias=bv).view(B, T, H, W, Cc)
+        if ops.flash_attention_supported(q, vT):
+            o = ops.flash_attention(q, k, vT, bv, float(Cc) ** -0.5).view(B, T, H, W, Cc)
+        else:
+            s = ops.gemm_nt(q, k, out_dtype=torch.float32)
+            p = ops.softmax_rows(s, float(Cc) ** -0.5, dt, ld_out=Sp)
+            o = ops.gemm_nt(p, vT, bias=bv).view(B, T, H, W, Cc)
         return _wrap(_Conv3dSym.run(self.proj_out, self._po, o, dt, res=x, res_mode=L.VT_RES_ADD, **_emit(next_norm)),
                      next_norm)
 

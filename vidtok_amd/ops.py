@@ -48,6 +48,11 @@ def replay_convs(record, conv_kernel_only=True):
         if isinstance(d, L.TBlockDesc):
             L.check(lib.vt_temporal_block(C.byref(d), _stream()), "vt_temporal_block(replay)")
             continue
+        if isinstance(d, tuple):                 # ("flash", q, k, vT, bias, o, scale): vt_flash_attention
+            _, q, k, vT, bias, o, scale = d
+            L.check(lib.vt_flash_attention(_ptr(q), _ptr(k), _ptr(vT), _ptr(bias), _ptr(o), _DT[q.dtype], q.shape[0], q.shape[1], q.shape[2],
+                                           vT.shape[2], scale, _stream()), "vt_flash_attention(replay)")
+            continue
         if conv_kernel_only and d.ln_mode != 0 and not conv_plan(d)["ln_fused"]:
             d2 = L.ConvDesc()
             C.memmove(C.byref(d2), C.byref(d), C.sizeof(d))
@@ -272,6 +277,30 @@ def gemm_nt(a, b, *, out_dtype=None, bias=None, ld_out=None):
     return y
 
 
+def flash_attention_supported(q, vT) -> bool:
+    """q [Z, S, C], vT [Z, C, ld]: does vt_flash_attention cover this attention (bf16, C = 512, S % 64 == 0; option attn_flash)"""
+    if not q.is_cuda or q.dtype not in _DT:
+        return False
+    return bool(L.load().vt_flash_attention_supported(_DT[q.dtype], q.shape[1], q.shape[2], vT.shape[2]))
+
+
+def flash_attention(q, k, vT, bias_v, scale: float):
+    """o[z] = softmax(scale * q[z] k[z]^T) v[z] + bias_v in one launch, nothing S x S in memory (vt_flash_attention);
+    q, k [Z, S, C], vT = V transposed [Z, C, ld] (keys contiguous) -> o [Z, S, C]"""
+    lib = L.load()
+    _chk(q, "attn.q"); _chk(k, "attn.k"); _chk(vT, "attn.vT")
+    Z, S, Cc = q.shape
+    assert k.shape == q.shape and k.dtype == q.dtype == vT.dtype and vT.shape[:2] == (Z, Cc)
+    o = torch.empty_like(q)
+    if bias_v is not None:
+        assert bias_v.dtype == torch.float32 and bias_v.numel() >= Cc and bias_v.is_cuda
+    L.check(lib.vt_flash_attention(_ptr(q), _ptr(k), _ptr(vT), _ptr(bias_v), _ptr(o), _DT[q.dtype], Z, S, Cc, vT.shape[2], float(scale), _stream()),
+            "vt_flash_attention")
+    if CONV_RECORD is not None:   # both products of the attention: label (rows, keys, 2 C) carries their FLOPs
+        CONV_RECORD.append((("flash", q, k, vT, bias_v, o, float(scale)), (), (Z * S, S, 2 * Cc)))
+    return o
+
+
 # Optional record of the vt_layernorm_act launches of a step (bench.py's per-class HBM roofline): tuples
 # (x, y, gamma, beta, M, c, eps, silu) with the tensors kept alive; None in normal use.
 LN_RECORD = None
@@ -307,6 +336,9 @@ def replay_layernorms(record):
 def launch_bytes(d):
     """Algorithmic HBM bytes of one recorded MFMA-kernel launch: the input once, the weights once, the result(s) once,
     the residual once (what a perfectly cached launch would move)."""
+    if isinstance(d, tuple):                     # vt_flash_attention: q, k, V^T in, o out
+        _, q, k, vT, _b, o, _s = d
+        return (q.numel() + k.numel() + vT.numel() + o.numel()) * q.element_size()
     if isinstance(d, L.TBlockDesc):
         es = 2
         px = d.B * d.T * d.HW
@@ -330,6 +362,8 @@ def launch_class(d):
     """(class name, algorithmic HBM bytes) of a recorded MFMA-kernel launch whose FLOP per byte sits below the chip's
     ridge (2.5 PFLOP/s over 8 TB/s = 312): the launches bench.py prices against the HBM roofline.  None for the
     matrix-bound ones."""
+    if isinstance(d, tuple):
+        return None                              # attention: 0.1 % of the FLOPs, matrix-shaped
     if isinstance(d, L.TBlockDesc):
         return "temporal block fused (C=128)", launch_bytes(d)
     taps = d.KT * d.KH * d.KW
