@@ -514,9 +514,14 @@ def main():
     # --traffic profile quotes)
     extras_on = world == 1 and not args.no_extras
     modes = others = None
+    extras_error = None
     if extras_on:
-        modes = mode_measurements(model, x, args.dtype)
-        others = other_config_measurements(dev, x)
+        try:        # an extra must never cost the line
+            modes = mode_measurements(model, x, args.dtype)
+            others = other_config_measurements(dev, x)
+        except Exception as e:  # noqa: BLE001
+            extras_error = f"{type(e).__name__}: {e}"
+            print(f"[bench] extras failed: {extras_error}", file=sys.stderr)
     if args.traffic == "pmc":
         del model, out, z, dec
         torch.cuda.empty_cache()
@@ -572,6 +577,8 @@ def main():
     }
     if parity_mode is not None:
         line["parity_mode"], line["modes"], line["other_configs"] = parity_mode, mode_table, others
+    if extras_error is not None:
+        line["extras_error"] = extras_error
     print(json.dumps(line), flush=True)
 
 

@@ -98,6 +98,7 @@ int vt_conv_max_lds_bytes(void);
  *   conv_sched_x3 (3)   K-step schedule of the 8-wave tile under VT_BF16X3 (64-byte rows, 4-slot ring): 0 plain loop, 1 / 2 / 3 two
  *                       wave groups alternating LOAD and COMPUTE phases with the DMA pieces of a step issued in the LOAD phase /
  *                       between the MFMAs of the COMPUTE phase / half and half
+ *   conv_splitk (1)     split-K over the time taps for small-M launches when the caller provides scratch (vt_conv_work_bytes)
  *   attn_flash (1)      the attention block as one vt_flash_attention launch where it applies; 0: GEMM -> softmax -> GEMM operators
  *   ws_acc (0), tblock_prof_mode (0), ws_prof_mode (0)   measurement aids
  *   tblock_fused (1)   0: vt_temporal_block_supported answers no (blocks stay on the unfused operators)
@@ -182,9 +183,19 @@ typedef struct vt_conv_desc {
                                a y whose frames are 2Ho x 2Wo (spatial parity classes, see below); 0/1 = off     */
   float ln_eps;
   int64_t xs_z, ws_z, ys_z, rs_z;   /* element strides between problems                       */
+  void* work;                  /* optional scratch for split-K launches (see vt_conv_work_bytes); NULL = never split */
+  int64_t work_bytes;
 } vt_conv_desc;
 
 int vt_conv(const vt_conv_desc* d, vt_stream stream);
+/* Split-K over tap planes (the three time taps; the three rows of a 3 x 3 without time taps).  A long-K convolution on few pixels (the 512-channel 3x3x3 layers on a chunk of a v1.1 tiled
+ * pass: M = 4 096 pixels x N = 512 x K = 13 824 = 128 tiles of 128 x 128 with 216 K steps each on 256 CUs) is latency-bound: one tile per
+ * CU walking a long K.  Given scratch, vt_conv runs it as three launches-in-one (grid.z = tap plane: each workgroup walks the KH x KW x Cin
+ * -- or KW x Cin -- of ONE plane into an fp32 partial) and a reduction that owns bias / residual / rounding: 3 x the workgroups, a third of the steps.
+ * vt_conv_work_bytes(d) = the scratch vt_conv(d) would use (0: this call does not split; decided from the descriptor and option
+ * conv_splitk, ignoring d->work); with d->work = NULL or d->work_bytes too small the call runs unsplit.  The fp32 sum of an output
+ * is then taken in another order (per tap, then over the taps): results differ from the unsplit launch by fp32 rounding. */
+int64_t vt_conv_work_bytes(const vt_conv_desc* d);
 /* What vt_conv(d) would do, without launching (no GPU needed): out8 = {pixel tile, channel tile, waves per
  * workgroup, workgroups (tiles for the persistent kernel), 1 if LayerNorm comes from the conv epilogue, kernel
  * launches of the call, kernel (0 = tile-per-workgroup implicit GEMM; weight-stationary persistent 3x3 for

@@ -440,6 +440,56 @@ def test_conv_128_tile_rings(case, ring, dtype, vt_opts):
     assert plan["tile"] == (128, 128) and plan["deep_ring"] == (ring != "two_slots" and steps >= 8), (plan, steps)
 
 
+# Split-K over the time taps (vt_conv_work_bytes): 3x3x3 convolutions on few pixels -- no more tiles than CUs -- run as three tap-plane
+# launches-in-one into fp32 partials + a reduction that owns bias / residual / rounding.  The 512-channel mid blocks of a v1.1 chunk
+# (M = 4 096), cache mode, a residual, the 8-wave tile (M = 20 480: the mid blocks of the benchmark batch), Cin = 256.
+SPLITK_CASES = [
+    ("sk_3d_512_m4096", (1, 4, 32, 32), 512, 512, (3, 3, 3), ConvGeom(**G333), dict(tmode="replicate")),
+    ("sk_3d_512_cache_res", (1, 4, 32, 32), 512, 512, (3, 3, 3), ConvGeom(**G333), dict(tmode="cache", res="add")),
+    ("sk_3d_512_m20480_8wave", (4, 5, 32, 32), 512, 512, (3, 3, 3), ConvGeom(**G333), dict(res="add")),
+    ("sk_3d_256_m1024", (1, 4, 16, 16), 256, 256, (3, 3, 3), ConvGeom(**G333), {}),
+    ("sk_3d_512_ln_after", (1, 5, 32, 32), 512, 512, (3, 3, 3), ConvGeom(**G333), dict(ln="only")),
+    ("sk_2d_512_rows", (1, 4, 32, 32), 512, 512, (3, 3), ConvGeom(**G3), dict(res="add")),                  # no time taps: planes = the rows of the 3 x 3
+    ("sk_2d_512_m5120", (1, 5, 32, 32), 512, 512, (3, 3), ConvGeom(**G3), {}),
+]
+
+
+@pytest.mark.parametrize("split", [1, 0], ids=["split", "whole"])
+@pytest.mark.parametrize("case", SPLITK_CASES, ids=[c[0] for c in SPLITK_CASES])
+def test_conv_split_k(case, split, vt_opts):
+    vt_opts(conv_splitk=split)
+    plan = _check_conv(case, torch.bfloat16)
+    extra = 1 if "ln" in case[6] else 0                      # Cout = 512: the LayerNorm is its own launch either way
+    assert plan["launches"] == (2 if split else 1) + extra, plan
+
+
+def test_conv_split_k_needs_scratch_and_small_m(vt_opts):
+    """no scratch in the descriptor -> the call runs whole; many pixels (more tiles than CUs) -> no split is asked for"""
+    import ctypes as C
+
+    lib = L.load()
+    x = _act(1, 4, 32, 32, 512, torch.bfloat16, 1)
+    wt = torch.randn((512, 512, 3, 3, 3), generator=torch.Generator().manual_seed(2)) / math.sqrt(512 * 27)
+    w = pack_conv_weight(wt, torch.bfloat16, cin_stored=512).to(DEV)
+    ops.CONV_RECORD = []
+    y = ops.conv(x, w, None, ConvGeom(**G333), cout=512)
+    rec, ops.CONV_RECORD = ops.CONV_RECORD, None
+    d = rec[0][0]
+    assert d.work and lib.vt_conv_work_bytes(C.byref(d)) == 3 * 4096 * 512 * 4 == d.work_bytes
+    d2 = L.ConvDesc()
+    C.memmove(C.byref(d2), C.byref(d), C.sizeof(d))
+    y2 = torch.empty_like(y)
+    d2.y, d2.work, d2.work_bytes = y2.data_ptr(), None, 0
+    L.check(lib.vt_conv(C.byref(d2), None), "vt_conv")
+    torch.cuda.synchronize()
+    assert ops.conv_plan(d2)["launches"] == 1 and rel_err(y2, y) < 1e-2 and not torch.equal(y2, y)      # another summation order
+    big = _act(4, 20, 64, 64, 512, torch.bfloat16, 1)                                                     # 327 680 pixels: 2 560 tiles
+    ops.CONV_RECORD = []
+    ops.conv(big, w, None, ConvGeom(**G333), cout=512)
+    rec, ops.CONV_RECORD = ops.CONV_RECORD, None
+    assert not rec[0][0].work and lib.vt_conv_work_bytes(C.byref(rec[0][0])) == 0
+
+
 @pytest.mark.parametrize("coalesced", [True, False], ids=["lds_epilogue", "vector_epilogue"])
 @pytest.mark.parametrize("case", [c for c in CONV_CASES_LARGE if c[3] % 256 == 0], ids=[c[0] for c in CONV_CASES_LARGE if c[3] % 256 == 0])
 def test_conv_8wave_plain_epilogues(case, coalesced, vt_opts):

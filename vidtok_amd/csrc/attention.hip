@@ -140,6 +140,14 @@ __global__ __launch_bounds__(256, 1) void flash_attn_kernel(const FlashArgs p) {
     pf[3] = pack_bf16x2(pv[6], pv[7]);
     // ---- O^T = alpha O^T + V^T P^T: 32 tiles of 16 dims; A fragment of dims row d = 16 mt + n: keys 4 g .. + 3 (logical chunk g / 2,
     // half g % 2) and 16 + 4 g .. + 3 (logical chunk 2 + g / 2)
+    // (once the running maxima have settled alpha is exactly 1 for every row of the wave: the 128 multiplications are skipped --
+    // by 1.0f they would change nothing)
+    if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0ull) {
+#pragma unroll
+      for (int mt = 0; mt < 32; ++mt)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[mt][i] *= alpha;
+    }
 #pragma unroll
     for (int mt = 0; mt < 32; ++mt) {
       const int d = 16 * mt + n;
@@ -148,10 +156,7 @@ __global__ __launch_bounds__(256, 1) void flash_attn_kernel(const FlashArgs p) {
       const u32x2 lo = *reinterpret_cast<const u32x2*>(row + (((g >> 1) ^ sw) * 16));
       const u32x2 hi = *reinterpret_cast<const u32x2*>(row + (((2 + (g >> 1)) ^ sw) * 16));
       const u32x4 a = u32x4{lo[0], lo[1], hi[0], hi[1]};
-      f32x4 c = acc[mt];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) c[i] *= alpha;
-      acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, pf), c, 0, 0, 0);
+      acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, pf), acc[mt], 0, 0, 0);
     }
   }
   // ---- O[q][dims] = O^T / l + bias_v: a lane owns 4 consecutive dims of its row per tile (8-byte stores)

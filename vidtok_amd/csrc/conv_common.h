@@ -68,6 +68,8 @@ struct ConvArgs {
   unsigned x_bytes, w_bytes;   // BUF path: descriptor extents (0 = tensors too large, use pointers)
   unsigned c_bytes;            // BUF path in cache mode: extent of the cache tensor [B][ncache][Hi][Wi][Cin]
   long long xs_z, ws_z, ys_z, rs_z;
+  int ksplit;                  // split-K: blockIdx.z = tap plane, the walk covers that plane only; 1: planes = kt, 2: planes = kh (KT = 1)
+  unsigned plane_bytes;        //      bytes of one tap plane in a weight row (KH * KW * Cin, or KW * Cin, elements)
   unsigned long long* prof;    // PROF instantiation only (vt_conv_profile): cycle stamps of workgroup 0
   int prof_mode;               // PROF instantiation of conv_ws2.hip only: option ws_prof_mode
 };

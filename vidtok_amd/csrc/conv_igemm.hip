@@ -585,7 +585,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_igemm_glds_ker
   const int m_blk = mt * BM;
   const int n_blk = nt * BN;
 
-  const long long z = blockIdx.z;
+  const long long z = blockIdx.z;                  // problem of a batched launch, or (ksplit) the time-tap plane: y advances, x / w do not
   const MT* __restrict__ xg = reinterpret_cast<const MT*>(p.x) + z * p.xs_z;
   const MT* __restrict__ wg = reinterpret_cast<const MT*>(p.w) + z * p.ws_z;
   const MT* __restrict__ cg = reinterpret_cast<const MT*>(p.cache);
@@ -644,6 +644,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_igemm_glds_ker
     const int n = n_blk + (S2 ? ((lr >> 6) & 1) * 128 + ((((lr >> 7) & 1) << 1) | ((lr >> 5) & 1)) * 32 + (lr & 31) : lr);
     b_row[j] = (n < p.Cout) ? wg + (long long)n * p.ldw : nullptr;
     b_off[j] = (n < p.Cout) ? (unsigned)n * (unsigned)p.ldw * (unsigned)sizeof(MT) + (FAST ? (unsigned)chunk * 16u : 0u) : kOob;
+    if (p.ksplit && n < p.Cout) b_off[j] += (unsigned)blockIdx.z * p.plane_bytes;       // my tap plane of the row (descriptor form only)
   }
 
   // Gather address of input row i for tap (kt,kh,kw).  Straight-line integer arithmetic (unsigned compares
@@ -722,7 +723,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_igemm_glds_ker
   // FAST path: pipeline steps are prepared strictly in order, so the position in the K walk (tap-major, channel
   // chunks innermost) advances as scalar counters instead of being recovered from the step index with three
   // integer divisions per step.
-  int q_step = 0, q_cc = 0, q_kt = 0, q_kh = 0, q_kw = 0;
+  // (split-K: the walk starts at my tap plane -- kt = z, or kh = z for a convolution without time taps -- and nsteps ends it there)
+  int q_step = 0, q_cc = 0, q_kt = p.ksplit == 1 ? (int)blockIdx.z : 0, q_kh = p.ksplit == 2 ? (int)blockIdx.z : 0, q_kw = 0;
   unsigned s_a = 0, s_b = 0;   // BUF: wave-uniform byte offsets (soffset operand): chunk-in-tap for x, k offset for w
   const unsigned chunk_bytes = (unsigned)chunk * 16u;
   const unsigned HiWi = (unsigned)p.Hi * (unsigned)p.Wi;
@@ -735,7 +737,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_igemm_glds_ker
     if (FAST) {
       if (q_cc == 0) {               // uniform branch: new tap -> new gather addresses
         if constexpr (BUF) {
-          if ((q_kh | q_kw) == 0) {  // new kt (rare): time part of the offsets, time-padding bit
+          if ((q_kh | q_kw) == 0 || q_step == 0) {  // new kt (rare; or the first step of a walk that starts inside a plane): time part of the offsets, time-padding bit
             bool from_cache = false;
             if constexpr (!PROF) {
               if (p.tmode == VT_TPAD_CACHE) {            // uniform
@@ -1441,6 +1443,10 @@ int launch_variant(const ConvArgs& a_in, int nbatch, hipStream_t stream) {
   a.m_tiles = (a.M + BM - 1) / BM;
   a.n_tiles = (a.Cout + BN - 1) / BN;
   a.nsteps = FAST ? a.ntaps * (a.Cin / BK) : (a.K + BK - 1) / BK;
+  if (a.ksplit) {
+    VT_CHECK_ARG(FAST, "vt_conv: split-K needs the tap-walk form");
+    a.nsteps = (a.ksplit == 1 ? a.KH * a.KW : a.KW) * (a.Cin / BK);
+  }
   // Temporal taps: in pixel order (b,t,h,w) the frames t-1, t-2 a tile reads were last touched one whole frame of
   // tiles earlier -- far beyond the 4 MiB L2 of its XCD -- so every kt tap came from the fabric again (the k3
   // temporal conv of the widest level moved 3x its input).  Walking the tiles as (b, hw tile, t) puts the
@@ -1458,9 +1464,10 @@ int launch_variant(const ConvArgs& a_in, int nbatch, hipStream_t stream) {
   // the cache or x for the whole tile (the kernel switches the descriptor per tap); other shapes gather through pointers
   const unsigned long long cb = a.tmode == VT_TPAD_CACHE ? (unsigned long long)a.B * a.ncache * a.Hi * a.Wi * a.Cin * sizeof(MT) : 0ull;
   const bool cache_ok = a.tmode != VT_TPAD_CACHE ||
-                        (FAST && nbatch == 1 && a.prof == nullptr && cb < 0xFFFF0000ull && ((long long)a.Ho * a.Wo) % BM == 0 && a.ups_t == 0);
+                        (FAST && (nbatch == 1 || a.ksplit) && a.prof == nullptr && cb < 0xFFFF0000ull && ((long long)a.Ho * a.Wo) % BM == 0 && a.ups_t == 0);
   const bool buf = conv_buf() && xb < 0xFFFF0000ull && wb < 0xFFFF0000ull && cache_ok &&
                    a.KH <= 8 && a.KW <= 8;   // the per-row padding mask of the FAST form holds 8 bits per axis
+  VT_CHECK_ARG(!a.ksplit || buf, "vt_conv: split-K needs the descriptor gather");
   const void* kern;
   // option conv_sched: 0 = the plain K-step loop of the 8-wave tile, 1 = schedule 1, 2 (default) = ping-pong; see the kernel
   constexpr bool HAS_S1 = WAVES_M * WAVES_N == 8 && FAST && !is_split3<MT>::value && ROWB == kRowBytes && STAGES == 2;
@@ -1661,6 +1668,80 @@ int dispatch_tile(const ConvArgs& a, int nbatch, hipStream_t stream) {
   }
 }
 
+// ---- split-K over the time taps (include/vidtok_amd.h, vt_conv_work_bytes) ------------------------------------------------------------
+// y[m][n] = bf16(((p0 + p1) + p2) + bias[n]  [+ res[m][n]]) from the KT fp32 partials [KT][M][Cout]; a thread = 8 channels of a pixel
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ part, int planes, long long M, int Cout, const float* __restrict__ bias,
+                                                            const bf16_t* __restrict__ res, bf16_t* __restrict__ y) {
+  const long long n8 = M * (Cout / 8);
+  const long long plane = M * (long long)Cout;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long long)gridDim.x * blockDim.x) {
+    const long long e = i * 8;
+    const int c = (int)(e % Cout);
+    float v[8];
+    {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(part + e), b = *reinterpret_cast<const f32x4*>(part + e + 4);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { v[k] = a[k]; v[4 + k] = b[k]; }
+    }
+    for (int pz = 1; pz < planes; ++pz) {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(part + pz * plane + e), b = *reinterpret_cast<const f32x4*>(part + pz * plane + e + 4);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { v[k] += a[k]; v[4 + k] += b[k]; }
+    }
+    if (bias) {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(bias + c), b = *reinterpret_cast<const f32x4*>(bias + c + 4);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { v[k] += a[k]; v[4 + k] += b[k]; }
+    }
+    if (res) {
+      Oct<bf16_t> r;
+      r.load(res + e);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v[k] = r.get(k) + v[k];
+    }
+    Oct<bf16_t>::store(y + e, v);
+  }
+}
+
+// how many tap planes vt_conv would split `a` into (0 = no split): bf16, 3 taps in time at stride 1, K long, few pixels -- no more
+// tiles than CUs, so every workgroup would walk the whole K alone on its CU --, plain NDHWC rows, residual add at most
+inline int splitk_planes(const vt_conv_desc* d, const ConvArgs& a, int nbatch, bool ln_fused, bool use_ws) {
+  if (vt_opt(OPT_CONV_SPLITK) == 0 || !conv_buf()) return 0;
+  if (d->dtype != VT_BF16 || d->out_dtype != VT_BF16 || nbatch != 1 || use_ws || ln_fused || a.prof != nullptr) return 0;
+  const bool by_kt = a.KT == 3 && a.st == 1, by_kh = a.KT == 1 && a.KH == 3;      // three planes: the time taps, or the rows of a 3 x 3
+  if (!(by_kt || by_kh) || a.ups_t || a.ups_s || a.out_layout != VT_NDHWC || a.yt_mul != 1 || a.ys_mul == 2) return 0;
+  if (a.Cin % 64 != 0 || a.Cout % 128 != 0 || a.ldy != a.Cout || a.KT * a.KH * a.KW * a.Cin < 4608) return 0;
+  if (a.res_mode == VT_RES_MIX || (a.res_mode == VT_RES_ADD && (a.ldr != a.Cout || a.Tr != a.To || a.res_tshift != 0))) return 0;
+  if (a.tmode == VT_TPAD_CACHE && ((long long)a.Ho * a.Wo) % 256 != 0) return 0;     // the descriptor form of the cache gather: a tile inside one frame
+  const unsigned long long xb = (unsigned long long)a.B * a.Ti * a.Hi * a.Wi * a.Cin * 2, wb = (unsigned long long)a.Cout * a.ldw * 2;
+  if (xb >= 0xFFFF0000ull || wb >= 0xFFFF0000ull) return 0;
+  const TileKind tk = select_tile(a, 1);
+  const int bm = tk == TILE_256x256 ? 256 : 128;
+  if (tk != TILE_256x256 && tk != TILE_128x128) return 0;
+  const long long tiles = (long long)((a.M + bm - 1) / bm) * ((a.Cout + bm - 1) / bm);
+  return tiles <= device_cus() ? 3 : 0;
+}
+
+int launch_splitk(const vt_conv_desc* d, const ConvArgs& a_in, int planes, hipStream_t stream) {
+  ConvArgs a = a_in;
+  a.ksplit = a.KT == 3 ? 1 : 2;
+  a.plane_bytes = (unsigned)((a.KT == 3 ? a.KH * a.KW : a.KW) * a.Cin * 2);
+  a.y = reinterpret_cast<char*>(d->work);
+  a.bias = nullptr;
+  a.res = nullptr; a.res_mode = VT_RES_NONE;
+  a.ln_mode = 0;
+  a.xs_z = 0; a.ws_z = 0; a.rs_z = 0;
+  a.ys_z = (long long)a.M * a.ldy;
+  int rc = dispatch_tile<bf16_t, float>(a, planes, stream);
+  if (rc != VT_OK) return rc;
+  const long long n8 = (long long)a.M * (a.Cout / 8);
+  const unsigned grid = (unsigned)std::min<long long>((n8 + 255) / 256, 4096);
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3(grid), dim3(256), 0, stream, reinterpret_cast<const float*>(d->work), planes, (long long)a.M, a.Cout, a_in.bias,
+                     a_in.res_mode == VT_RES_ADD ? reinterpret_cast<const bf16_t*>(a_in.res) : nullptr, reinterpret_cast<bf16_t*>(a_in.y));
+  VT_CHECK_LAUNCH();
+  return VT_OK;
+}
+
 }  // namespace
 
 extern "C" int vt_ws128_launch(const void* conv_args, void* stream);   // conv_ws128.hip
@@ -1811,6 +1892,7 @@ extern "C" int vt_conv_plan(const vt_conv_desc* d, int32_t* out8) {
   out8[3] = (int32_t)((long long)((a.M + dims[k][0] - 1) / dims[k][0]) * ((a.Cout + dims[k][1] - 1) / dims[k][1]) * nbatch);
   out8[4] = ln_fused ? 1 : 0;
   out8[5] = (d->ln_mode != 0 && !ln_fused) ? 2 : 1;
+  if (d->work != nullptr && splitk_planes(d, a, nbatch, ln_fused, use_ws) > 0) out8[5] += 1;       // partial launch + reduction
   // epilogue through the LDS (rows of 16-byte accesses) instead of the MFMA-layout vector epilogue
   if (k == TILE_256x256) out8[7] = (ln_fused || lds256_plain_eligible(a, nbatch, d->dtype == VT_BF16 && d->out_dtype == VT_BF16)) ? 1 : 0;
   if (k == TILE_128x128 && deep_ring_eligible(a, nbatch, d->dtype == VT_BF16 ? 2 : 4)) out8[7] = 2;   // 4-slot ring
@@ -1836,6 +1918,16 @@ extern "C" int vt_conv_profile(const vt_conv_desc* d, uint64_t* stamps_out, vt_s
   return dispatch_tile<bf16_t, bf16_t>(a, nbatch, reinterpret_cast<hipStream_t>(stream_));
 }
 
+extern "C" int64_t vt_conv_work_bytes(const vt_conv_desc* d) {
+  ConvArgs a;
+  bool ln_fused = false, use_ws = false;
+  int nbatch = 1;
+  if (conv_prepare(d, a, ln_fused, nbatch, use_ws) != VT_OK) return 0;
+  if (narrow_eligible(a, nbatch, d->dtype, d->out_dtype, d->ln_mode)) return 0;
+  const int planes = splitk_planes(d, a, nbatch, ln_fused, use_ws);
+  return (int64_t)planes * a.M * a.Cout * 4;
+}
+
 extern "C" int vt_conv(const vt_conv_desc* d, vt_stream stream_) {
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
   ConvArgs a;
@@ -1846,7 +1938,10 @@ extern "C" int vt_conv(const vt_conv_desc* d, vt_stream stream_) {
   if (use_ws) return vt_opt(OPT_CONV_WS) == 2 ? vt_ws2_launch(&a, stream_) : vt_ws128_launch(&a, stream_);
   if (narrow_eligible(a, nbatch, d->dtype, d->out_dtype, d->ln_mode)) return vt_conv_narrow_launch(&a, stream_, d->dtype == VT_BF16X3 ? 1 : 0);
   const long long M = a.M;
-  if (d->dtype == VT_F32) rc = dispatch_tile<float, float>(a, nbatch, stream);
+  const int planes = d->work != nullptr ? splitk_planes(d, a, nbatch, ln_fused, use_ws) : 0;
+  if (planes > 0 && d->work_bytes >= (int64_t)planes * M * a.Cout * 4 && (reinterpret_cast<uintptr_t>(d->work) & 15) == 0)
+    rc = launch_splitk(d, a, planes, stream);
+  else if (d->dtype == VT_F32) rc = dispatch_tile<float, float>(a, nbatch, stream);
   else if (d->dtype == VT_BF16X3) rc = dispatch_tile<split3_t, float>(a, nbatch, stream);
   else if (d->out_dtype == VT_F32) rc = dispatch_tile<bf16_t, float>(a, nbatch, stream);
   else rc = dispatch_tile<bf16_t, bf16_t>(a, nbatch, stream);

@@ -390,6 +390,23 @@ Act conv(Ctx& c, const Tens& x, const void* w, int ldw, const float* bias, const
     d.ln_mode = o.ln.silu ? 2 : 1; d.ln_keep_y = o.keep_y ? 1 : 0; d.ldn = ldy; d.ln_eps = o.ln.norm->eps;
     r.norm = o.ln.norm; r.silu = o.ln.silu;
   }
+  // split-K over the time taps (small-M launches): the library says how much scratch; it comes from the stage's arena.  (A dry run
+  // has no pointers to validate: it asks with stand-ins, the decision depends on the geometry only.)
+  {
+    vt_conv_desc q = d;
+    if (c.dry) {
+      q.x = q.w = q.y = (void*)16;
+      if (q.res_mode != VT_RES_NONE) q.res = (void*)16;
+      if (q.res_mode == VT_RES_MIX) q.mix_factor = (const float*)16;
+      if (q.tmode == VT_TPAD_CACHE) q.cache = (void*)16;
+      if (q.ln_mode != 0) { q.ln_gamma = q.ln_beta = (const float*)16; q.ln_out = (void*)16; }
+    }
+    const int64_t wb = (x.dt == VT_BF16 && (g.kt == 3 || g.kh == 3)) ? vt_conv_work_bytes(&q) : 0;
+    if (wb > 0) {
+      d.work = c.cur->alloc((size_t)wb, c.dry);
+      d.work_bytes = wb;
+    }
+  }
   if (!c.dry) M_CALL(vt_conv(&d, c.stream));
   return r;
 }

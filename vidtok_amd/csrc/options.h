@@ -23,6 +23,7 @@ enum VtOpt {
   OPT_WS_PROF_MODE,        // vt_conv_profile on conv_ws2.hip: bit 0 = row slots skipped, bit 1 = LDS-DMA requests skipped (wrong results)
   OPT_CONV_SCHED_X3,       // split-bf16 arithmetic on the 8-wave tile: 0 plain loop, two-group schedule 3 with the DMA pieces of a step issued 1 in the LOAD phase / 2 between the MFMAs of the COMPUTE phase / 3 half and half
   OPT_ATTN_FLASH,          // 1: vt_flash_attention_supported answers yes where the kernel applies (0: the hosts keep the GEMM -> softmax -> GEMM operators)
+  OPT_CONV_SPLITK,         // 1: 3-tap-in-time convolutions on few pixels run split over the time taps when the caller gives scratch
   OPT_COUNT
 };
 

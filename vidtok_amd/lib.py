@@ -50,6 +50,7 @@ class ConvDesc(C.Structure):
         )]
         + [("ln_eps", C.c_float)]
         + [(n, C.c_int64) for n in ("xs_z", "ws_z", "ys_z", "rs_z")]
+        + [("work", C.c_void_p), ("work_bytes", C.c_int64)]
     )
 
 
@@ -113,6 +114,7 @@ SIGNATURES = {
     "vt_tile_decode": (C.c_int, [_P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _P, _P, _I64, _P]),
     "vt_conv": (C.c_int, [C.POINTER(ConvDesc), _P]),
     "vt_conv_desc_size": (C.c_int, []),
+    "vt_conv_work_bytes": (_I64, [C.POINTER(ConvDesc)]),
     "vt_conv_plan": (C.c_int, [C.POINTER(ConvDesc), C.POINTER(_I32)]),
     "vt_conv_profile": (C.c_int, [C.POINTER(ConvDesc), _P, _P]),
     "vt_frames_work_floats": (_I64, [_I32, _I32, _I32]),

@@ -186,7 +186,13 @@ def conv(x, w, bias, geom: ConvGeom, *, cout: int, out_dtype=None, tmode=L.VT_TP
             n = (torch.zeros if ldy != cout else torch.empty)(y.shape, dtype=out_dtype, device=x.device)
         d.ln_gamma, d.ln_beta, d.ln_out = gamma.data_ptr(), beta.data_ptr(), n.data_ptr()
         d.ln_mode, d.ln_keep_y, d.ldn, d.ln_eps = (2 if silu else 1), int(bool(ln_keep_y)), ldy, float(eps)
-    _conv_launch(lib, d, "vt_conv", (x, w, bias, y, res, cache, mix_factor, n, ln))
+    work = None
+    if x.dtype == torch.bfloat16 and (geom.kt == 3 or geom.kh == 3):      # split-K over tap planes (small-M launches): the library says how much scratch
+        nb = lib.vt_conv_work_bytes(C.byref(d))
+        if nb > 0:
+            work = torch.empty((nb,), dtype=torch.uint8, device=x.device)
+            d.work, d.work_bytes = work.data_ptr(), nb
+    _conv_launch(lib, d, "vt_conv", (x, w, bias, y, res, cache, mix_factor, n, ln, work))
     if ln is None:
         return y
     return (y, n) if ln_keep_y else n
