@@ -99,6 +99,9 @@ int vt_conv_max_lds_bytes(void);
  *                       wave groups alternating LOAD and COMPUTE phases with the DMA pieces of a step issued in the LOAD phase /
  *                       between the MFMAs of the COMPUTE phase / half and half
  *   conv_splitk (1)     split-K over the time taps for small-M launches when the caller provides scratch (vt_conv_work_bytes)
+ *   conv_half256 (0)    K bound (0 = off; measured slower than the 8-wave tile on every layer of the benchmark): bf16 Cout % 256 == 0 launches whose epilogue goes through the LDS and whose K is at most
+ *                       the bound run as 128 x 256 half tiles on 4 waves, two workgroups per CU (one in its K loop while the other
+ *                       is in its epilogue); results equal the 8-wave tile's bit for bit
  *   attn_flash (1)      the attention block as one vt_flash_attention launch where it applies; 0: GEMM -> softmax -> GEMM operators
  *   ws_acc (0), tblock_prof_mode (0), ws_prof_mode (0)   measurement aids
  *   tblock_fused (1)   0: vt_temporal_block_supported answers no (blocks stay on the unfused operators)
@@ -201,8 +204,9 @@ int64_t vt_conv_work_bytes(const vt_conv_desc* d);
  * launches of the call, kernel (0 = tile-per-workgroup implicit GEMM; weight-stationary persistent 3x3 for
  * Cin = Cout = 128 bf16: 1 = conv_ws128.hip, 8 x 16-pixel tiles on 4 waves, 3 = conv_ws2.hip, 4 x 16-pixel tiles on 8 waves; 2 = the
  * narrow-output kernel), 1 if the 8-wave tile's epilogue goes through the LDS (coalesced rows; always with a fused LayerNorm,
- * without one for bf16 full tiles) or 2 if the 128 x 128 tile runs on its 4-slot ring (option conv_deep: launches with no
- * more tiles than the device has CUs)}.  Validates `d` exactly like vt_conv.  Test / measurement aid: which kernel and
+ * without one for bf16 full tiles), 2 if the 128 x 128 tile runs on its 4-slot ring (option conv_deep: launches with no
+ * more tiles than the device has CUs), 3 if such an LDS-epilogue launch runs as 128 x 256 half tiles on 4 waves, two workgroups
+ * per CU (option conv_half256)}.  Validates `d` exactly like vt_conv.  Test / measurement aid: which kernel and
  * instantiation does a parity case exercise. */
 int vt_conv_plan(const vt_conv_desc* d, int32_t* out8);
 /* Measurement aid (scripts/conv_profile.py): vt_conv(d) on the bf16 8-wave 256 x 256 tile (no LayerNorm) with shader-clock

@@ -127,7 +127,7 @@ CONV_CASES_LARGE = [
 @pytest.mark.parametrize("dtype", DTYPES3, ids=IDS3)
 @pytest.mark.parametrize("case", BIG256, ids=[c[0] for c in BIG256])
 def test_conv_forced_256_tile(case, dtype, vt_opts):
-    vt_opts(conv_tile=256)
+    vt_opts(conv_tile=256, conv_half256=0)
     plan = _check_conv(case, dtype)
     assert plan["tile"] == (256, 256)
     (B, T, H, W), cout = case[1], case[3]
@@ -139,7 +139,8 @@ def test_conv_forced_256_tile(case, dtype, vt_opts):
 @pytest.mark.parametrize("case", CONV_CASES_LARGE, ids=[c[0] for c in CONV_CASES_LARGE])
 def test_conv_large(case, dtype):
     plan = _check_conv(case, dtype)
-    assert plan["tile"] == ((256, 256) if case[3] % 256 == 0 else (128, 128)) and plan["workgroups"] >= 384
+    small = (64, 128) if plan["kernel"] == "ws2" else (128, 128)        # conv_ws2.hip walks 4 x 16-pixel tiles
+    assert plan["tile"] == ((256, 256) if case[3] % 256 == 0 else small) and plan["workgroups"] >= 384
     if "ln" in case[6]:
         assert plan["ln_fused"]
 
@@ -367,7 +368,7 @@ SCHED_CASES = [c for c in BIG256 if c[0] in ("nin_1x1_128_256", "nin_1x1_64_256_
 @pytest.mark.parametrize("sched", [0, 1, 2])
 @pytest.mark.parametrize("case", SCHED_CASES + CONV_CASES_LARGE, ids=[c[0] for c in SCHED_CASES + CONV_CASES_LARGE])
 def test_conv_8wave_schedules(case, sched, vt_opts):
-    vt_opts(conv_sched=sched)
+    vt_opts(conv_sched=sched, conv_half256=0)
     if case in SCHED_CASES:
         vt_opts(conv_tile=256)
     plan = _check_conv(case, torch.bfloat16)
@@ -495,7 +496,7 @@ def test_conv_split_k_needs_scratch_and_small_m(vt_opts):
 def test_conv_8wave_plain_epilogues(case, coalesced, vt_opts):
     """8-wave tile without LayerNorm: the LDS-transposed epilogue (bf16 full tiles; + residual / alpha-mix / interleaved
     output frames) and the MFMA-layout vector epilogue it replaces, both against the reference"""
-    vt_opts(conv_ln256_v=(1 if coalesced else 0))
+    vt_opts(conv_ln256_v=(1 if coalesced else 0), conv_half256=0)
     plan = _check_conv(case, torch.bfloat16)
     if plan["tile"] == (256, 256) and not plan["ln_fused"]:
         name, (B, T, H, W), cin, cout, kdims, geom, ex = case
@@ -512,9 +513,44 @@ LN256_CASES = [c for c in CONV_CASES if c[0] in ("conv2d_ln256_only", "conv2d_ln
 @pytest.mark.parametrize("mode", ["unfused", "fused_v0", "fused_v1"])
 @pytest.mark.parametrize("case", LN256_CASES, ids=[c[0] for c in LN256_CASES])
 def test_conv_ln256_variants(case, mode, dtype, vt_opts):
-    vt_opts(conv_tile=256, conv_fuse_ln256=(mode != "unfused"), conv_ln256_v=(1 if mode == "fused_v1" else 0))
+    vt_opts(conv_tile=256, conv_fuse_ln256=(mode != "unfused"), conv_ln256_v=(1 if mode == "fused_v1" else 0), conv_half256=0)
     plan = _check_conv(case, dtype)
     assert plan["tile"] == (256, 256) and plan["ln_fused"] == (mode != "unfused") and plan["launches"] == (2 if mode == "unfused" else 1)
+
+
+# Half tiles (option conv_half256 = K bound): the bf16 launches of the 8-wave tile whose epilogue goes through the LDS -- with or
+# without a fused LayerNorm, residual added or alpha-mixed, interleaved output frames, cache-mode gather, frames-innermost tile
+# order, Cout = 512 (two channel tiles) -- run as 128 x 256 tiles on 4 waves, two workgroups per CU.  Same K order and the same
+# epilogue arithmetic per element: the results must equal the 8-wave tile's bit for bit.
+HALF_CASES = [c for c in CONV_CASES_LARGE if c[3] % 256 == 0]
+
+
+@pytest.mark.parametrize("case", HALF_CASES, ids=[c[0] for c in HALF_CASES])
+def test_conv_half_tile(case, vt_opts):
+    vt_opts(conv_half256=1 << 20)
+    half = []
+    plan = _check_conv(case, torch.bfloat16, keep_outputs=half)
+    assert plan["half_tile"] and plan["tile"] == (128, 256) and plan["waves"] == 4 and plan["lds_epilogue"] and plan["launches"] == 1, plan
+    vt_opts(conv_half256=0)
+    full = []
+    plan8 = _check_conv(case, torch.bfloat16, keep_outputs=full)
+    assert not plan8["half_tile"] and plan8["tile"] == (256, 256) and plan8["waves"] == 8 and plan8["workgroups"] * 2 == plan["workgroups"]
+    assert len(half) == len(full) and all(torch.equal(a, b) for a, b in zip(half, full))
+
+
+def test_conv_half_tile_bounds(vt_opts):
+    """the K bound, and not on launches too small to give both workgroup slots of every CU a tile / other arithmetic / ragged M"""
+    case = next(c for c in CONV_CASES_LARGE if c[0] == "L_conv2d_3x3_256_256")           # K = 2 304, 98 304 pixels
+    assert not _check_conv(case, torch.bfloat16)["half_tile"]                            # off by default (measured slower, DESIGN section 6)
+    vt_opts(conv_half256=2304)
+    assert _check_conv(case, torch.bfloat16)["half_tile"]
+    vt_opts(conv_half256=2303)
+    assert not _check_conv(case, torch.bfloat16)["half_tile"]
+    vt_opts(conv_half256=1 << 20)
+    assert not _check_conv(case, torch.float32)["half_tile"] and not _check_conv(case, X3)["half_tile"]
+    small = next(c for c in BIG256 if c[0] == "conv2d_ln256_only")
+    vt_opts(conv_tile=256)
+    assert not _check_conv(small, torch.bfloat16)["half_tile"]
 
 
 LDSEPI_CASES = [c for c in CONV_CASES if c[0] in ("conv2d_3x3_128_128", "conv2d_3x3_256_128_res", "temporal_k3_tinner", "conv2d_ln_fused",
@@ -529,7 +565,8 @@ def test_conv_without_lds_epilogue(case, dtype, vt_opts):
     assert plan["tile"] == (128, 128) and not plan["ln_fused"]
 
 
-def _check_conv(case, dtype):
+def _check_conv(case, dtype, keep_outputs=None):
+    """one case against the host reference; returns vt_conv_plan of the launch (keep_outputs: a list that receives the device results)"""
     name, (B, T, H, W), cin, cout, kdims, geom, ex = case
     mode, dtype = dtype, (torch.float32 if dtype == X3 else dtype)      # x3: fp32 tensors, split weight planes
     x = _act(B, T, H, W, cin, dtype, 1)
@@ -566,6 +603,8 @@ def _check_conv(case, dtype):
         ref = R.conv(x.cpu(), w_rows.cpu(), None if bias is None else bias.cpu(), geom, cout=cout, ln=(gam.cpu(), bet.cpu(), 1e-6, True),
                      ln_keep_y=keep, **_cpu(kw))
         outs, refs = (out if keep else (out,)), (ref if keep else (ref,))
+        if keep_outputs is not None:
+            keep_outputs.extend(outs)
         for o, r in zip(outs, refs):
             assert o.shape == r.shape and o.dtype == r.dtype and torch.isfinite(o.float()).all()
             e = rel_err(o, r)
@@ -579,6 +618,8 @@ def _check_conv(case, dtype):
     yr = R.conv(x.cpu(), w_rows.cpu(), None if bias is None else bias.cpu(), geom, cout=cout, **_cpu(kw))   # reference on the host
     assert y.shape == yr.shape and y.dtype == yr.dtype
     assert torch.isfinite(y.float()).all()
+    if keep_outputs is not None:
+        keep_outputs.append(y)
     e = rel_err(y, yr)
     print(f"{name} {mode}: rel_err={e:.3e}")
     assert e < TOL[mode], f"{name} {mode}: rel_err={e}"

@@ -404,7 +404,9 @@ __device__ __forceinline__ void conv_epilogue_lds256(const ConvArgs& p, f32x16 (
 // LDS layout: T[128 rows][64 chunks of 4 floats], chunk index XOR (row & 63); row w*32 + l of half b = tile pixel
 // w*64 + b*32 + l.  A lane's two chunks (2j, 2j+1) make its ds_read_b128 pair 2-way bank-conflicted (16 lanes of a service
 // group hit 8 bank quads); the LDS is idle here, the 16-B global accesses are what counts.
-template <typename TOut>
+// WM = waves along the pixels: 4 (the 8-wave 256 x 256 tile: T holds 128 rows, 128 KiB) or 2 (the 4-wave 128 x 256 half tile, two
+// workgroups per CU: 64 rows, 64 KiB); a sweep of the block covers 4 WM rows, eight sweeps per half either way.
+template <typename TOut, int WM = 4>
 __device__ __forceinline__ void conv_epilogue_lds256_v1(const ConvArgs& p, f32x16 (&acc)[4][2], int m_blk, int n_blk, int wm, int wn, int lane,
                                                         int tid, char* smem, long long z) {
 #pragma clang fp contract(off)
@@ -422,7 +424,8 @@ __device__ __forceinline__ void conv_epilogue_lds256_v1(const ConvArgs& p, f32x1
   const bool has_ln = p.ln_mode != 0;                    // uniform
   float alpha = 0.0f;
   if (p.res_mode == VT_RES_MIX) alpha = 1.0f / (1.0f + __expf(-p.mix_factor[0]));
-  const int j = tid & 31, rsub = tid >> 5;              // lane j: channels [8j, 8j+8) of T rows rsub + 16 it
+  constexpr int RS = 4 * WM;                            // T rows per sweep of the block (32 lanes per row)
+  const int j = tid & 31, rsub = tid >> 5;              // lane j: channels [8j, 8j+8) of T rows rsub + RS it
   f32x2 lg[4], lb[4];
   if (has_ln) {
     const f32x4 g0 = *reinterpret_cast<const f32x4*>(p.ln_gamma + 8 * j), g1 = *reinterpret_cast<const f32x4*>(p.ln_gamma + 8 * j + 4);
@@ -435,12 +438,12 @@ __device__ __forceinline__ void conv_epilogue_lds256_v1(const ConvArgs& p, f32x1
   const int h = lane >> 5;
   auto half = [&](auto pz_c) {
     constexpr int PZ = decltype(pz_c)::value;            // compile-time: acc[.][PZ] must not become a dynamic register index
-    // tile pixel of T row r = rsub + 16 it:  (r >> 5) * 64 + PZ * 32 + (r & 31),  r >> 5 = it >> 1 (rsub < 16)
+    // tile pixel of T row r = rsub + RS it:  (r >> 5) * 64 + PZ * 32 + (r & 31)   (rsub < RS, RS divides 32: r >> 5 = it RS >> 5)
     u32x4 rq[8];
     if (has_res) {
 #pragma unroll
       for (int it = 0; it < 8; ++it) {
-        const long long m = (long long)m_blk + (it >> 1) * 64 + PZ * 32 + rsub + 16 * (it & 1);
+        const long long m = (long long)m_blk + ((RS * it) >> 5) * 64 + PZ * 32 + rsub + ((RS * it) & 31);
         rq[it] = *reinterpret_cast<const u32x4*>(rg + m * p.ldr + n_blk + 8 * j);
       }
     }
@@ -464,8 +467,8 @@ __device__ __forceinline__ void conv_epilogue_lds256_v1(const ConvArgs& p, f32x1
     __syncthreads();
 #pragma unroll
     for (int it = 0; it < 8; ++it) {
-      const int r = rsub + 16 * it;
-      const int m = m_blk + (it >> 1) * 64 + PZ * 32 + rsub + 16 * (it & 1);
+      const int r = rsub + RS * it;
+      const int m = m_blk + ((RS * it) >> 5) * 64 + PZ * 32 + rsub + ((RS * it) & 31);
       const long long orow = out_row(p, m);
       const f32x4 t0 = *reinterpret_cast<const f32x4*>(T + r * 256 + (((2 * j) ^ (r & 63)) << 2));
       const f32x4 t1 = *reinterpret_cast<const f32x4*>(T + r * 256 + (((2 * j + 1) ^ (r & 63)) << 2));
@@ -1405,9 +1408,11 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_igemm_glds_ker
     }
   }
   if constexpr (LN256 != 0) {
-    static_assert(WAVES_M == 4 && WAVES_N == 2 && TM == 2 && TN == 4 && std::is_same<typename storage_of<MT>::type, TOut>::value, "LN256: the 8-wave 256 x 256 tile");
+    static_assert((WAVES_M == 4 || (WAVES_M == 2 && LN256 == 2)) && WAVES_N == 2 && TM == 2 && TN == 4 && std::is_same<typename storage_of<MT>::type, TOut>::value,
+                  "LN256: the 8-wave 256 x 256 tile, or (second form) the 4-wave 128 x 256 half tile");
+    static_assert(STAGES * STAGE_BYTES >= 32 * WAVES_M * 256 * 4, "LN256: the transposition tile must fit the ring");
     if constexpr (!BUF) wait_vmcnt<0>();
-    if constexpr (LN256 == 2) conv_epilogue_lds256_v1<TOut>(p, acc, m_blk, n_blk, wm, wn, lane, tid, smem, z);
+    if constexpr (LN256 == 2) conv_epilogue_lds256_v1<TOut, WAVES_M>(p, acc, m_blk, n_blk, wm, wn, lane, tid, smem, z);
     else conv_epilogue_lds256<TOut>(p, acc, m_blk, wm, wn, lane, tid, smem, z);
     return;
   }
@@ -1635,6 +1640,25 @@ inline bool lds256_plain_eligible(const ConvArgs& a, int nbatch, bool bf16_io) {
          (a.ldy & 7) == 0 && (a.res_mode == VT_RES_NONE || ((a.ldr & 7) == 0 && a.Tr == a.To && a.res_tshift == 0));
 }
 
+// Half tile of the 8-wave layers (option conv_half256 = K bound, 0 = off): 128 pixels x 256 channels on 4 waves, 64-byte rows on a
+// 3-slot ring (72 KiB) so that TWO workgroups share a CU.  The 8-wave tile runs its K loop and its epilogue one after the other
+// with the whole CU in the same phase: on the short-K layers of the 256-channel level (K = 768: 12 K steps against an epilogue
+// that reads a residual, normalises and writes one or two tensors) the matrix pipe idles half of the time.  Two independent
+// workgroups drift apart -- one in its K loop while the other transposes / normalises / stores -- the way the 128 x 128 tiles
+// cover each other; the price is 1.5x the operand bytes staged per FLOP, which long K loops (whose epilogue is a small share
+// anyway) do not pay back: hence the bound.  Same epilogue code (conv_epilogue_lds256_v1<., 2>), same arithmetic per element, results
+// bit-equal to the 8-wave tile's (tests/test_gpu_ops.py::test_conv_half_tile).
+// MEASURED (profiles/r04_half_tile_ab.txt, per-group A/B inside the bench step): slower on every layer -- K = 768, Cout = 256: 2.97 ->
+// 3.23 ms (695 -> 638 TFLOP/s); K = 2 304: 4.57 -> 5.42 ms; K = 1 536, Cout = 512: 1.01 -> 1.26 ms.  The K loop of a 4-wave tile (one
+// barrier per 16 MFMAs of a wave, no ping-pong between the two waves of a SIMD, 1.5x the DMA pieces per FLOP) loses more than the
+// overlap of the epilogues returns.  The option therefore defaults to 0 (off); the instantiation stays as the A/B it is.
+inline bool half256_eligible(const ConvArgs& a, int nbatch, bool ln_or_plain) {
+  const int kmax = vt_opt(OPT_CONV_HALF256);
+  if (kmax <= 0 || !ln_or_plain || a.prof != nullptr || nbatch != 1 || a.ksplit) return false;
+  if (a.K > kmax || a.Cin % 32 != 0 || a.M % 256 != 0) return false;
+  return (long long)(a.M / 128) * (a.Cout / 256) >= 2ll * device_cus();       // both workgroup slots of every CU get tiles
+}
+
 template <typename MT, typename TOut>
 int dispatch_tile(const ConvArgs& a, int nbatch, hipStream_t stream) {
   switch (select_tile(a, nbatch)) {
@@ -1651,14 +1675,20 @@ int dispatch_tile(const ConvArgs& a, int nbatch, hipStream_t stream) {
       } else if constexpr (std::is_same<MT, TOut>::value) {
         if (a.ln_mode != 0) {                                                                     // conv_prepare checked Cin % BK
           if constexpr (std::is_same<TOut, bf16_t>::value) {
-            if (vt_opt(OPT_CONV_LN256_V) != 0) return launch_variant<MT, TOut, 4, 2, 2, 4, true, 2>(a, nbatch, stream);
+            if (vt_opt(OPT_CONV_LN256_V) != 0) {
+              if (half256_eligible(a, nbatch, true)) return launch_variant<MT, TOut, 2, 2, 2, 4, true, 2, 3, 64>(a, nbatch, stream);
+              return launch_variant<MT, TOut, 4, 2, 2, 4, true, 2>(a, nbatch, stream);
+            }
           }
           return launch_variant<MT, TOut, 4, 2, 2, 4, true, 1>(a, nbatch, stream);
         }
         // the same instantiation with ln_mode = 0: coalesced stores and residual reads (-8 % on the time up-sampler's
         // parity convolutions, -10 % on the K = 1 024 / 1 536 layers)
         if constexpr (std::is_same<TOut, bf16_t>::value) {
-          if (lds256_plain_eligible(a, nbatch, true)) return launch_variant<MT, TOut, 4, 2, 2, 4, true, 2>(a, nbatch, stream);
+          if (lds256_plain_eligible(a, nbatch, true)) {
+            if (half256_eligible(a, nbatch, true)) return launch_variant<MT, TOut, 2, 2, 2, 4, true, 2, 3, 64>(a, nbatch, stream);
+            return launch_variant<MT, TOut, 4, 2, 2, 4, true, 2>(a, nbatch, stream);
+          }
         }
       }
       return launch_fast_or_general<MT, TOut, 4, 2, 2, 4>(a, nbatch, stream);
@@ -1892,9 +1922,17 @@ extern "C" int vt_conv_plan(const vt_conv_desc* d, int32_t* out8) {
   out8[3] = (int32_t)((long long)((a.M + dims[k][0] - 1) / dims[k][0]) * ((a.Cout + dims[k][1] - 1) / dims[k][1]) * nbatch);
   out8[4] = ln_fused ? 1 : 0;
   out8[5] = (d->ln_mode != 0 && !ln_fused) ? 2 : 1;
-  if (d->work != nullptr && splitk_planes(d, a, nbatch, ln_fused, use_ws) > 0) out8[5] += 1;       // partial launch + reduction
+  const bool split_k = d->work != nullptr && splitk_planes(d, a, nbatch, ln_fused, use_ws) > 0;
+  if (split_k) out8[5] += 1;                                                                      // partial launch + reduction
   // epilogue through the LDS (rows of 16-byte accesses) instead of the MFMA-layout vector epilogue
-  if (k == TILE_256x256) out8[7] = (ln_fused || lds256_plain_eligible(a, nbatch, d->dtype == VT_BF16 && d->out_dtype == VT_BF16)) ? 1 : 0;
+  if (k == TILE_256x256) {
+    const bool bf16_io = d->dtype == VT_BF16 && d->out_dtype == VT_BF16;
+    const bool v1 = bf16_io && ((ln_fused && vt_opt(OPT_CONV_LN256_V) != 0) || lds256_plain_eligible(a, nbatch, true));
+    out8[7] = (ln_fused || lds256_plain_eligible(a, nbatch, bf16_io)) ? 1 : 0;
+    if (v1 && !split_k && half256_eligible(a, nbatch, true)) {
+      out8[0] = 128; out8[2] = 4; out8[3] *= 2; out8[7] = 3;                                                     // 128 x 256 half tiles, two workgroups per CU
+    }
+  }
   if (k == TILE_128x128 && deep_ring_eligible(a, nbatch, d->dtype == VT_BF16 ? 2 : 4)) out8[7] = 2;   // 4-slot ring
   return VT_OK;
 }

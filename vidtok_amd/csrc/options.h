@@ -24,6 +24,7 @@ enum VtOpt {
   OPT_CONV_SCHED_X3,       // split-bf16 arithmetic on the 8-wave tile: 0 plain loop, two-group schedule 3 with the DMA pieces of a step issued 1 in the LOAD phase / 2 between the MFMAs of the COMPUTE phase / 3 half and half
   OPT_ATTN_FLASH,          // 1: vt_flash_attention_supported answers yes where the kernel applies (0: the hosts keep the GEMM -> softmax -> GEMM operators)
   OPT_CONV_SPLITK,         // 1: 3-tap-in-time convolutions on few pixels run split over the time taps when the caller gives scratch
+  OPT_CONV_HALF256,        // K bound (0 = off): bf16 Cout % 256 == 0 launches with the LDS-transposed epilogue and K <= the bound run 128 x 256 half tiles, two workgroups per CU
   OPT_COUNT
 };
 
