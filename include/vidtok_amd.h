@@ -102,6 +102,9 @@ int vt_conv_max_lds_bytes(void);
  *   conv_half256 (0)    K bound (0 = off; measured slower than the 8-wave tile on every layer of the benchmark): bf16 Cout % 256 == 0 launches whose epilogue goes through the LDS and whose K is at most
  *                       the bound run as 128 x 256 half tiles on 4 waves, two workgroups per CU (one in its K loop while the other
  *                       is in its epilogue); results equal the 8-wave tile's bit for bit
+ *   conv_half_plain (0) half tiles also for launches without a fused LayerNorm (their epilogue is stores, nothing to overlap: slower)
+ *   conv_half_stagger (900) half tiles: the second workgroup slot of every CU starts late by this many shader cycles per K step
+ *                       (+ 6 000), so that the two workgroups of a CU run in anti-phase; 0 = start together
  *   attn_flash (1)      the attention block as one vt_flash_attention launch where it applies; 0: GEMM -> softmax -> GEMM operators
  *   ws_acc (0), tblock_prof_mode (0), ws_prof_mode (0)   measurement aids
  *   tblock_fused (1)   0: vt_temporal_block_supported answers no (blocks stay on the unfused operators)

@@ -151,7 +151,7 @@ def test_conv_plan_tile_selection(built_lib, monkeypatch):
     L.load().vt_reset_options()
     big = ops.conv_plan(desc((1280, 1024), 256, 256))            # the 256-channel level of the benchmark (B=4: 20 frames), K = 2 304
     assert big["tile"] == (256, 256) and big["waves"] == 8 and big["workgroups"] == 5120 and not big["half_tile"] and big["lds_epilogue"]
-    with L.options(conv_half256=2304):                           # option conv_half256 = K bound: 128 x 256 half tiles, two workgroups per CU
+    with L.options(conv_half256=2304, conv_half_plain=1):       # option conv_half256 = K bound: 128 x 256 half tiles, two workgroups per CU
         big = ops.conv_plan(desc((1280, 1024), 256, 256))
         assert big["tile"] == (128, 256) and big["waves"] == 4 and big["workgroups"] == 10240 and big["half_tile"] and big["lds_epilogue"]
         long_k = ops.conv_plan(desc((1280, 1024), 512, 256, ldw=9 * 512))                 # K = 4 608: the 8-wave tile

@@ -525,9 +525,10 @@ def test_conv_ln256_variants(case, mode, dtype, vt_opts):
 HALF_CASES = [c for c in CONV_CASES_LARGE if c[3] % 256 == 0]
 
 
+@pytest.mark.parametrize("sched", [0, 2], ids=["plain_loop", "schedule_1_two_stages_in_flight"])
 @pytest.mark.parametrize("case", HALF_CASES, ids=[c[0] for c in HALF_CASES])
-def test_conv_half_tile(case, vt_opts):
-    vt_opts(conv_half256=1 << 20)
+def test_conv_half_tile(case, sched, vt_opts):
+    vt_opts(conv_half256=1 << 20, conv_half_plain=1, conv_sched=sched)
     half = []
     plan = _check_conv(case, torch.bfloat16, keep_outputs=half)
     assert plan["half_tile"] and plan["tile"] == (128, 256) and plan["waves"] == 4 and plan["lds_epilogue"] and plan["launches"] == 1, plan
@@ -543,6 +544,8 @@ def test_conv_half_tile_bounds(vt_opts):
     case = next(c for c in CONV_CASES_LARGE if c[0] == "L_conv2d_3x3_256_256")           # K = 2 304, 98 304 pixels
     assert not _check_conv(case, torch.bfloat16)["half_tile"]                            # off by default (measured slower)
     vt_opts(conv_half256=2304)
+    assert not _check_conv(case, torch.bfloat16)["half_tile"]                            # no LayerNorm in this launch: conv_half_plain
+    vt_opts(conv_half_plain=1)
     assert _check_conv(case, torch.bfloat16)["half_tile"]
     vt_opts(conv_half256=2303)
     assert not _check_conv(case, torch.bfloat16)["half_tile"]

@@ -72,6 +72,8 @@ struct ConvArgs {
   unsigned plane_bytes;        //      bytes of one tap plane in a weight row (KH * KW * Cin, or KW * Cin, elements)
   unsigned long long* prof;    // PROF instantiation only (vt_conv_profile): cycle stamps of workgroup 0
   int prof_mode;               // PROF instantiation of conv_ws2.hip only: option ws_prof_mode
+  int stagger_cycles;          // half tiles (option conv_half256): the second workgroup slot of every CU starts this many shader cycles late
+  int stagger_cus;             //      = CUs of the device: workgroups [cus, 2 cus) of the launch are taken to be those second slots
 };
 
 // Split-bf16 arithmetic (vt_dtype VT_BF16X3, "bf16x3"): fp32 STORAGE on both sides of the convolution, bf16 MATRIX cores

@@ -575,6 +575,16 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_igemm_glds_ker
   const int wm = wave % WAVES_M;
   const int wn = wave / WAVES_M;
 
+  if constexpr (WAVES_M == 2 && LN256 == 2) {
+    // Half tiles: the two workgroups of a CU start together and do the same work, so left alone they stay in phase -- both in
+    // their K loops (sharing the matrix pipe), then both in their epilogues (sharing the VALU and the store path) -- and nothing
+    // overlaps.  The workgroups that fill the second slot of each CU in the first round wait half a tile time once; their
+    // successors inherit the offset (a workgroup starts when its predecessor in the slot ends).
+    if (p.stagger_cycles > 0 && (int)blockIdx.x >= p.stagger_cus && (int)blockIdx.x < 2 * p.stagger_cus) {
+      const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+      while ((long long)(__builtin_amdgcn_s_memtime() - t0) < (long long)p.stagger_cycles) __builtin_amdgcn_s_sleep(32);
+    }
+  }
   const int tile = xcd_remap(blockIdx.x, p.m_tiles * p.n_tiles);
   const int nt = tile / p.m_tiles;
   int mt = tile - nt * p.m_tiles;
@@ -878,7 +888,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_igemm_glds_ker
   // address set-up of the next step.  So: all pieces go out in the FIRST half of the stage (they have the second half
   // to land), the address set-up of the step after next runs in the middle of the stage (VALU in the other wave's MFMA
   // shadow), and the two waves of a SIMD swap issue priority at half time.
-  constexpr bool S1 = SCHED == 1 && EIGHT_WAVES;
+  constexpr bool HALF_TILE = WAVES_M == 2 && WAVES_N == 2 && TM == 2 && TN == 4;      // 128 x 256 on 4 waves (option conv_half256)
+  constexpr bool S1 = SCHED == 1 && (EIGHT_WAVES || (HALF_TILE && BUF));
   constexpr int FIRE_SPAN = S1 ? NM / 2 : NM;         // MFMA groups over which the DMA pieces of the next stage are spread
   constexpr int MPP = (FIRE_SPAN + IPS - 1) / IPS;    // ... per DMA piece
   const int wgrp = __builtin_amdgcn_readfirstlane((int)(tid >> 8));   // 8 waves: 0 = first wave of its SIMD, 1 = second (uniform: a scalar branch, not an exec mask)
@@ -1301,8 +1312,14 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_igemm_glds_ker
     // pieces of the next stage have had most of a stage to land (measured: in front of the last EIGHT groups they had
     // not -- 400 cycles of vmcnt wait); after the barrier the first fragments of the next stage are requested and the
     // remaining MFMAs cover their latency: no MFMA waits for an LDS round trip.
-    static_assert(STAGES == 2 && D == 1 && KS % 2 == 0, "schedule 1: two-slot ring, one stage in flight");
+    // Half tile (4 waves, 64-byte rows, 3-slot ring, descriptor gather only): a wave is alone on its SIMD while the other workgroup
+    // of the CU is in its epilogue and a 32-k step is only 512 cycles of MFMA, so TWO stages are in flight (the pieces of step
+    // s + 2 go out during step s, the wait in front of the barrier leaves them outstanding; past the last prefetch they are zero
+    // fills, so the count stays uniform) and one piece follows every MFMA group of the first half.
+    static_assert(((STAGES == 2 && D == 1) || (HALF_TILE && BUF && STAGES == 3 && D == 2)) && KS % 2 == 0, "schedule 1: one stage in flight on two slots, or two on three");
     constexpr int BAR_AT = TM * TN - 4;      // MFMA groups of the last sub-step issued before the barrier
+    constexpr int MPP1 = (NM / 2) / IPS >= 1 ? (NM / 2) / IPS : 1;       // MFMA groups per DMA piece: every piece is out before prep_step at half time
+    static_assert(IPS * MPP1 <= NM / 2, "schedule 1: the pieces of a stage must fit its first half");
     const char* a_base = smem + (wm * TM * 32) * ROWB + frag_row;
     const char* b_base = smem + A_BYTES + (wn * TN * 32) * ROWB + frag_row;
     u32x4 wf[2][TN], xf[2][TM];
@@ -1325,7 +1342,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_igemm_glds_ker
       const bool fire = s < n_fire;
       if (!fire && BUF) ext_x = ext_w = 0u;    // past the last prefetch: the pieces below turn into zero fills
       const bool fire_rt = BUF || fire;
-      const int dst = stage ^ 1;
+      const int dst = (stage + D) % STAGES;
+      const int nxt = (stage + 1 == STAGES) ? 0 : stage + 1;
 #pragma unroll
       for (int k = 0; k < KS; ++k) {
         // issue priority alternates between the two waves of a SIMD every sub-step (left alone the older wave wins
@@ -1342,16 +1360,16 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_igemm_glds_ker
             // fragments read behind it come from a slot nobody writes any more and are never used
             stamp(1);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // my last fragments of this slot are in registers
-            wait_vmcnt<0>();                                      // my pieces of the next stage have landed
+            wait_vmcnt<(D - 1) * IPS>();                          // my pieces of the next stage have landed (those of the one after may be in flight)
             stamp(2);
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
             stamp(3);
-            read_frags(stage ^ 1, 0, 0);
+            read_frags(nxt, 0, 0);
           }
           mma_step<MT>(wf[k & 1][a], xf[k & 1][b], acc[a][b]);
-          if ((q + 1) % MPP == 0) {
-            const int piece = q / MPP;
+          if ((q + 1) % MPP1 == 0) {
+            const int piece = q / MPP1;
             if (piece < IPS && fire_rt) fire_piece(piece, dst);
           }
           if (q + 1 == NM / 2) {
@@ -1359,7 +1377,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_igemm_glds_ker
           }
         }
       }
-      stage ^= 1;
+      stage = nxt;
       stamp(4);
     }
     __builtin_amdgcn_s_setprio(0);
@@ -1437,6 +1455,26 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_igemm_glds_ker
 inline bool conv_buf() { return vt_opt(OPT_CONV_BUF) != 0; }
 inline bool conv_tinner() { return vt_opt(OPT_CONV_TINNER) != 0; }
 
+// CUs of the current device (cached per device; 256 when it cannot be asked, e.g. vt_conv_plan on a host without a GPU)
+inline int device_cus() {
+  static std::atomic<int> cus[kMaxDevices];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) {
+    (void)hipGetLastError();
+    return 256;
+  }
+  const bool dev_ok = dev >= 0 && dev < kMaxDevices;
+  int n = dev_ok ? cus[dev].load(std::memory_order_acquire) : 0;
+  if (n == 0) {
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) {
+      (void)hipGetLastError();
+      n = 256;
+    }
+    if (dev_ok) cus[dev].store(n, std::memory_order_release);
+  }
+  return n;
+}
+
 template <typename MT, typename TOut, int WAVES_M, int WAVES_N, int TM, int TN, bool FAST, int LN256 = 0, int STAGES = 2, int ROWB = kRowBytes>
 int launch_variant(const ConvArgs& a_in, int nbatch, hipStream_t stream) {
   constexpr int BM = WAVES_M * TM * 32;
@@ -1460,6 +1498,11 @@ int launch_variant(const ConvArgs& a_in, int nbatch, hipStream_t stream) {
   constexpr int kOctAlign = 16 / (int)sizeof(TOut) > 4 ? 8 : 4;   // elements per 16 bytes, at least a quad
   a.lds_epi = (vt_opt(OPT_CONV_LDSEPI) != 0 && a.out_layout == VT_NDHWC && a.ldy % kOctAlign == 0 &&
                (a.res_mode == VT_RES_NONE || a.ldr % kOctAlign == 0) && (a.ln_mode == 0 || a.ldn % kOctAlign == 0)) ? 1 : 0;
+  if constexpr (WAVES_M == 2 && LN256 == 2) {      // half tiles: option conv_half_stagger = cycles per K step, + half an epilogue
+    const int per_step = vt_opt(OPT_CONV_HALF_STAGGER);
+    a.stagger_cycles = per_step > 0 ? per_step * a.nsteps + 6000 : 0;
+    a.stagger_cus = device_cus();
+  }
   a.hw_tiles = 0;
   if (conv_tinner() && a.KT > 1 && a.To > 1 && ((long long)a.Ho * a.Wo) % BM == 0) a.hw_tiles = (int)(((long long)a.Ho * a.Wo) / BM);
   // descriptor gather needs the tensors under 4 GiB (minus the out-of-range marker)
@@ -1475,8 +1518,9 @@ int launch_variant(const ConvArgs& a_in, int nbatch, hipStream_t stream) {
   VT_CHECK_ARG(!a.ksplit || buf, "vt_conv: split-K needs the descriptor gather");
   const void* kern;
   // option conv_sched: 0 = the plain K-step loop of the 8-wave tile, 1 = schedule 1, 2 (default) = ping-pong; see the kernel
-  constexpr bool HAS_S1 = WAVES_M * WAVES_N == 8 && FAST && !is_split3<MT>::value && ROWB == kRowBytes && STAGES == 2;
-  constexpr bool HAS_S2 = HAS_S1 && std::is_same<MT, bf16_t>::value;    // schedule 2 (ping-pong): bf16 operands only
+  constexpr bool HALF_S1 = WAVES_M == 2 && WAVES_N == 2 && TM == 2 && TN == 4 && FAST && LN256 == 2 && ROWB == 64 && STAGES == 3;   // half tile: schedule 1 on its 3-slot ring
+  constexpr bool HAS_S1 = (WAVES_M * WAVES_N == 8 && FAST && !is_split3<MT>::value && ROWB == kRowBytes && STAGES == 2) || HALF_S1;
+  constexpr bool HAS_S2 = HAS_S1 && !HALF_S1 && std::is_same<MT, bf16_t>::value;    // schedule 2 (ping-pong): bf16 operands only, 8 waves
   constexpr bool HAS_S3 = WAVES_M * WAVES_N == 8 && FAST && is_split3<MT>::value && ROWB == 64 && STAGES == 4;   // schedule 3: split-bf16
   const int sched_opt = vt_opt(OPT_CONV_SCHED);
   const bool s2 = HAS_S2 && buf && sched_opt >= 2;
@@ -1548,26 +1592,6 @@ int launch_fast_or_general(const ConvArgs& a, int nbatch, hipStream_t stream) {
   constexpr int BK = kRowBytes / (int)sizeof(MT);
   return (a.Cin % BK) == 0 ? launch_variant<MT, TOut, WAVES_M, WAVES_N, TM, TN, true>(a, nbatch, stream)
                            : launch_variant<MT, TOut, WAVES_M, WAVES_N, TM, TN, false>(a, nbatch, stream);
-}
-
-// CUs of the current device (cached per device; 256 when it cannot be asked, e.g. vt_conv_plan on a host without a GPU)
-inline int device_cus() {
-  static std::atomic<int> cus[kMaxDevices];
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess) {
-    (void)hipGetLastError();
-    return 256;
-  }
-  const bool dev_ok = dev >= 0 && dev < kMaxDevices;
-  int n = dev_ok ? cus[dev].load(std::memory_order_acquire) : 0;
-  if (n == 0) {
-    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) {
-      (void)hipGetLastError();
-      n = 256;
-    }
-    if (dev_ok) cus[dev].store(n, std::memory_order_release);
-  }
-  return n;
 }
 
 // 128 x 128 tile on a 4-slot ring (128 KB of LDS, three K steps of DMA in flight instead of one).  Two workgroups per CU
@@ -1651,10 +1675,14 @@ inline bool lds256_plain_eligible(const ConvArgs& a, int nbatch, bool bf16_io) {
 // MEASURED (profiles/r04_half_tile_ab.txt, per-group A/B inside the bench step): slower on every layer -- K = 768, Cout = 256: 2.97 ->
 // 3.23 ms (695 -> 638 TFLOP/s); K = 2 304: 4.57 -> 5.42 ms; K = 1 536, Cout = 512: 1.01 -> 1.26 ms.  The K loop of a 4-wave tile (one
 // barrier per 16 MFMAs of a wave, no ping-pong between the two waves of a SIMD, 1.5x the DMA pieces per FLOP) loses more than the
-// overlap of the epilogues returns.  The option therefore defaults to 0 (off); the instantiation stays as the A/B it is.
+// overlap of the epilogues returns.  With the start offset of the second workgroup slot (conv_half_stagger: the two workgroups of a CU
+// otherwise stay in phase) and schedule 1 with two stages in flight: - 8 % on LayerNorm-only launches, + 12 % on launches that also read a
+// residual and keep y (profiles/r04_half_tile_bench.txt) -- no net gain.  The option therefore defaults to 0 (off); the instantiation
+// stays as the A/B it is.
 inline bool half256_eligible(const ConvArgs& a, int nbatch, bool ln_or_plain) {
   const int kmax = vt_opt(OPT_CONV_HALF256);
   if (kmax <= 0 || !ln_or_plain || a.prof != nullptr || nbatch != 1 || a.ksplit) return false;
+  if (a.ln_mode == 0 && vt_opt(OPT_CONV_HALF_PLAIN) == 0) return false;        // without a LayerNorm the epilogue is stores, not VALU: nothing to overlap (measured)
   if (a.K > kmax || a.Cin % 32 != 0 || a.M % 256 != 0) return false;
   return (long long)(a.M / 128) * (a.Cout / 256) >= 2ll * device_cus();       // both workgroup slots of every CU get tiles
 }
