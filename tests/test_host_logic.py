@@ -334,29 +334,3 @@ def test_graph_cache_bookkeeping_and_engine_copies():
         assert other._genc.fn.__self__ is other and other._gdec.fn.__self__ is other
         assert other._genc.state_get.__self__ is other and other._genc.fn.__func__ is type(model)._encoder_fn
         assert torch.equal(other.state_dict()["encoder.conv_in.conv.weight"], model.state_dict()["encoder.conv_in.conv.weight"])
-
-
-def test_temporal_block_first_norm_follows_the_fused_decision(emulated_ops):
-    """whether a C = 128 bf16 temporal block runs as ONE launch also depends on the activation
-    (vt_temporal_block_supported), which its producer's caller does not have when it asks first_norm(): the block
-    remembers what run() decided for this kind of chunk, so a producer stops withholding LayerNorm1 from a block that
-    then runs unfused (the stand-in operators never fuse) -- and the result does not depend on the guess."""
-    from vidtok_amd.modules import Normed, ResnetCausalBlock1D, first_norm_of
-
-    torch.manual_seed(0)
-    blk = ResnetCausalBlock1D(in_channels=128, out_channels=128)
-    for p in blk.parameters():
-        torch.nn.init.normal_(p, std=0.05)
-    dt = torch.bfloat16
-    x = torch.randn(1, 5, 4, 4, 128).to(dt)
-    assert first_norm_of(blk, dt) is None                       # nothing known yet: expect the fused launch
-    assert first_norm_of(blk, torch.float32) == (blk.norm1, True)
-    y0 = blk.run(x, dt)                                         # ... which the stand-ins decline: unfused, own LayerNorm pass
-    nrm = first_norm_of(blk, dt)
-    assert nrm == (blk.norm1, True)                             # remembered: the producer emits LayerNorm1 from now on
-    h = blk.norm1.apply_ndhwc(x, True, dt, 0)
-    y1 = blk.run(Normed(x, h, blk.norm1, True), dt)
-    assert torch.equal(y0, y1)
-    blk.conv1.cache_offset = 2                                  # another kind of chunk: its own memory
-    blk.conv2.cache_offset = 2
-    assert first_norm_of(blk, dt) is None or blk.conv1.version == "v1_0"

@@ -503,7 +503,6 @@ class ResnetCausalBlock1D(nn.Module):
         if zero_init:
             self.conv2.conv.weight.data.zero_()
             self.conv2.conv.bias.data.zero_()
-        self._fused_memo = {}       # chunk kind -> did run() take the fused launch (first_norm)
 
     # v1.1 blocks keep chunk-to-chunk caches of their convolutions' INPUTS, which a fused launch never materialises.  An
     # engine that is NOT tiling sets `allow_fused` (AutoencodingEngineV11._set_fused_temporal): no chunk follows, nothing
@@ -542,26 +541,16 @@ class ResnetCausalBlock1D(nn.Module):
         ok = all(t.shape == shape and t.dtype == xp.dtype and t.is_contiguous() for t in (c1.causal_cache, c2.causal_cache))
         return L.VT_TPAD_CACHE, ((c1.causal_cache, c2.causal_cache) if ok else None), c1.cache_offset
 
-    def _chunk_kind(self):
-        return (self.conv1.version, self.allow_fused, self.conv1.is_first_chunk, self.conv1.cache_offset)
-
     def first_norm(self, dt=None):
-        # a fused block normalises x itself: its producer must not spend a write on LayerNorm1(x).  Whether the block fuses
-        # also depends on the activation (frames past the cache offset, pixels per frame: vt_temporal_block_supported), which
-        # the producer's caller does not have yet: the decision run() took for this kind of chunk last time is remembered --
-        # a wrong guess costs one LayerNorm pass or one unused write, never a different result.
-        if dt is not None and self._fusable(dt) and self._fused_memo.get(self._chunk_kind(), True):
+        # a fused block normalises x itself: its producer must not spend a write on LayerNorm1(x)
+        if dt is not None and self._fusable(dt):
             return None
         return (self.norm1, True)
 
     def run(self, x, dt, next_norm=None):
         xp = plain(x)
-        fusable = self._fusable(dt)
-        tmode, caches, off = self._chunk_state(xp) if fusable else (L.VT_TPAD_ZERO, None, 0)
-        fused = fusable and ops.temporal_block_supported(xp, tmode, self.in_channels, caches, off)
-        if fusable:
-            self._fused_memo[self._chunk_kind()] = fused
-        if fused:
+        tmode, caches, off = self._chunk_state(xp) if self._fusable(dt) else (L.VT_TPAD_ZERO, None, 0)
+        if self._fusable(dt) and ops.temporal_block_supported(xp, tmode, self.in_channels, caches, off):
             c = xp.shape[-1]
             w1, b1 = self.conv1._pack.get(self.conv1.conv.weight, self.conv1.conv.bias, dt, cin_stored=c)
             w2, b2 = self.conv2._pack.get(self.conv2.conv.weight, self.conv2.conv.bias, dt, cin_stored=c)
