@@ -542,15 +542,20 @@ class ResnetCausalBlock1D(nn.Module):
         return L.VT_TPAD_CACHE, ((c1.causal_cache, c2.causal_cache) if ok else None), c1.cache_offset
 
     def first_norm(self, dt=None):
-        # a fused block normalises x itself: its producer must not spend a write on LayerNorm1(x)
+        # a fused block normalises x itself: its producer must not spend a write on LayerNorm1(x).  Whether the block then
+        # really fuses also depends on the activation (vt_temporal_block_supported: frames past the cache offset, pixels per
+        # frame), which the producer's caller does not have; where it does not, run() spends its own LayerNorm pass.  Remembering
+        # run()'s decision here was tried and taken back: a producer's epilogue normalises the fp32 accumulators, a
+        # separate pass the stored bf16 rows, so the first pass of a shape would differ in bits from every later one.
         if dt is not None and self._fusable(dt):
             return None
         return (self.norm1, True)
 
     def run(self, x, dt, next_norm=None):
         xp = plain(x)
-        tmode, caches, off = self._chunk_state(xp) if self._fusable(dt) else (L.VT_TPAD_ZERO, None, 0)
-        if self._fusable(dt) and ops.temporal_block_supported(xp, tmode, self.in_channels, caches, off):
+        fusable = self._fusable(dt)
+        tmode, caches, off = self._chunk_state(xp) if fusable else (L.VT_TPAD_ZERO, None, 0)
+        if fusable and ops.temporal_block_supported(xp, tmode, self.in_channels, caches, off):
             c = xp.shape[-1]
             w1, b1 = self.conv1._pack.get(self.conv1.conv.weight, self.conv1.conv.bias, dt, cin_stored=c)
             w2, b2 = self.conv2._pack.get(self.conv2.conv.weight, self.conv2.conv.bias, dt, cin_stored=c)
