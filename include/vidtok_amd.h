@@ -98,7 +98,9 @@ int vt_conv_max_lds_bytes(void);
  *   conv_sched_x3 (3)   K-step schedule of the 8-wave tile under VT_BF16X3 (64-byte rows, 4-slot ring): 0 plain loop, 1 / 2 / 3 two
  *                       wave groups alternating LOAD and COMPUTE phases with the DMA pieces of a step issued in the LOAD phase /
  *                       between the MFMAs of the COMPUTE phase / half and half
- *   conv_splitk (1)     split-K over the time taps for small-M launches when the caller provides scratch (vt_conv_work_bytes)
+ *   conv_splitk (0)     1: split-K over the tap planes for small-M launches when the caller provides scratch (vt_conv_work_bytes).
+ *                       Opt-in: a split launch sums in another order, and whether a launch splits depends on the pixel count -- with
+ *                       it a clip's bits depend on the batch it was part of (+ 1 % on a v1.1 tiled pass is what it buys)
  *   conv_half256 (0)    K bound (0 = off; measured slower than the 8-wave tile on every layer of the benchmark): bf16 Cout % 256 == 0 launches whose epilogue goes through the LDS and whose K is at most
  *                       the bound run as 128 x 256 half tiles on 4 waves, two workgroups per CU (one in its K loop while the other
  *                       is in its epilogue); results equal the 8-wave tile's bit for bit
