@@ -186,6 +186,7 @@ extern "C" int vt_flash_attention(const void* q, const void* k, const void* vt, 
                                   int32_t C, int32_t ldv, float scale, vt_stream stream_) {
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
   VT_CHECK_ARG(q && k && vt && o && Z > 0, "vt_flash_attention: null tensor or empty batch");
+  VT_CHECK_ARG(Z <= 65535, "vt_flash_attention: Z = %d exceeds the grid's y extent (65 535 frames per call)", Z);
   VT_CHECK_ARG(vt_flash_attention_supported(dtype, S, C, ldv), "vt_flash_attention: bf16, C = 512, S %% 64 == 0, ldv >= S and %% 8 == 0 only (got dtype %d S %d C %d ldv %d)",
                dtype, S, C, ldv);
   const uintptr_t al = reinterpret_cast<uintptr_t>(q) | reinterpret_cast<uintptr_t>(k) | reinterpret_cast<uintptr_t>(vt) | reinterpret_cast<uintptr_t>(o) |
