@@ -1446,12 +1446,11 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_igemm_glds_ker
 #endif
 }
 
-// Test / A-B switches, read from the environment at every call (a getenv per launch is noise next to the launch
-// itself, and nothing is cached in unsynchronised statics):
-//   VT_CONV_BUF=0     gather through 64-bit pointers (global_load_lds) instead of buffer descriptors
-//   VT_CONV_TINNER=0  plain pixel order for temporal convs
-//   VT_CONV_TILE=256  force the 8-wave 256x256 tile wherever it is legal (Cout % 256 == 0, vector epilogue), however
-//                     few tiles that gives; =128 forbids it -- lets small parity cases reach either instantiation
+// Test / A-B switches of the option table (options.h; vt_set_option, seeded once from VT_<NAME> -- no launch path reads the environment):
+//   conv_buf = 0      gather through 64-bit pointers (global_load_lds) instead of buffer descriptors
+//   conv_tinner = 0   plain pixel order for temporal convs
+//   conv_tile = 256   force the 8-wave 256x256 tile wherever it is legal (Cout % 256 == 0, vector epilogue), however
+//                     few tiles that gives; = 128 forbids it -- lets small parity cases reach either instantiation
 inline bool conv_buf() { return vt_opt(OPT_CONV_BUF) != 0; }
 inline bool conv_tinner() { return vt_opt(OPT_CONV_TINNER) != 0; }
 
