@@ -200,6 +200,17 @@ def test_conv_plan_tile_selection(built_lib, monkeypatch):
         assert ops.conv_plan(desc((256, 256), 128, 3, **co))["kernel"] == "igemm"
     with pytest.raises(L.VtError):
         ops.conv_plan(desc((64, 64), 100, 128))                  # same validation as vt_conv
+    # split-K over the tap planes (vt_conv_work_bytes; no GPU: 256 CUs assumed): an opt-in -- which launches split depends on the
+    # pixel count, so with it a clip's bits would depend on its batch (tests/test_gpu_e2e.py::test_full_size_properties)
+    import ctypes as C
+    lib = L.load()
+    deep = desc((64, 64), 512, 512, work=4096)                  # 4 096 pixels, K = 4 608: 128 tiles of 128 x 128 -- every workgroup alone on its CU
+    assert L.get_option("conv_splitk") == 0 and lib.vt_conv_work_bytes(C.byref(deep)) == 0 and ops.conv_plan(deep)["launches"] == 1
+    with L.options(conv_splitk=1):
+        assert lib.vt_conv_work_bytes(C.byref(deep)) == 3 * 4096 * 512 * 4 and ops.conv_plan(deep)["launches"] == 2     # the three rows of the 3 x 3 + the reduction
+        assert lib.vt_conv_work_bytes(C.byref(desc((256, 256), 512, 512))) == 0                                        # 65 536 pixels: enough tiles
+        assert lib.vt_conv_work_bytes(C.byref(desc((64, 64), 512, 512, dtype=L.VT_F32, out_dtype=L.VT_F32))) == 0      # bf16 only
+        assert lib.vt_conv_work_bytes(C.byref(desc((64, 64), 128, 512, ldw=9 * 128))) == 0                              # K = 1 152: too short to pay
 
 
 def test_options_table(built_lib, monkeypatch):
