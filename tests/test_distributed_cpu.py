@@ -142,3 +142,24 @@ def test_bench_gpus_flag_spawns_ranks():
     bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--selftest-spawn"], env=env2,
                          capture_output=True, text=True, timeout=120)
     assert bad.returncode != 0 and "WORLD_SIZE=1" in (bad.stderr + bad.stdout)
+
+
+def test_eight_rank_host_loop_stays_small():
+    """8-GPU readiness without an 8-GPU box: eight ranks at once run the bench's real per-step host loop --
+    AutoencodingEngine.forward in graph-replay mode through the real GraphedCall bookkeeping and the real KL regularizer with
+    the reference's host-side noise draw (torch.randn of the CPU generator, distributions.py:16-18), each on its share of the
+    host threads -- with every device operation stubbed (bench.py::selftest_host_loop).  The slowest rank's host time per
+    step must stay under 4 ms (a step is ~75 ms of GPU time: the host then cannot pace a rank, and 8 ranks fit one box)."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--selftest-spawn", "--selftest-steps", "40"], env=env,
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    print(line)
+    assert line["n_gpus"] == 8 and line["clips"] == 32.0 and line["steps"] == 40
+    assert 0.0 < line["host_ms_per_step"] < 4.0, line

@@ -99,7 +99,7 @@ def test_split_bf16_weight_planes_and_mode_plumbing(emulated_ops):
 
     w = torch.randn(5, 40)
     p = pack_split3(w)
-    assert p.dtype == torch.float32 and p.shape == (5, 64) and p.vt_arith == "bf16x3"
+    assert p.dtype == torch.int32 and p.shape == (5, 64) and p[1:3].contiguous().dtype == torch.int32     # the tag survives views
     planes = p.view(torch.bfloat16).reshape(5, 4, 2, 16)
     hi, lo = planes[:, :, 0].reshape(5, 64).float(), planes[:, :, 1].reshape(5, 64).float()
     assert torch.equal(hi[:, :40], w.to(torch.bfloat16).float()) and torch.equal(lo[:, :40], (w - hi[:, :40]).to(torch.bfloat16).float())

@@ -62,7 +62,7 @@ def conv(x, w, bias, geom, *, cout, out_dtype=None, tmode=L.VT_TPAD_ZERO, cache=
         return (out, ln_out) if ln_keep_y else ln_out
     B, Ti, Hi, Wi, Cin = x.shape
     out_dtype = out_dtype or x.dtype
-    if getattr(w, "vt_arith", None) == "bf16x3":
+    if w.dtype == torch.int32:        # packing.SPLIT3_DTYPE
         # VT_BF16X3 (include/vidtok_amd.h): rows of [hi 16 x bf16 | lo 16 x bf16] per 16 k; in fp32 terms the contract is
         # conv(x_lo, w_hi) + conv(x_hi, w_lo) + conv(x_hi, w_hi) with x_hi = bf16(x), x_lo = bf16(x - x_hi)
         K = geom.kt * geom.kh * geom.kw * Cin

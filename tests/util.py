@@ -90,3 +90,37 @@ def handle_config(L, enc, reg_target, reg_params, enc_target=""):
         for i, e in enumerate(reg_params["levels"]):
             c.levels[i] = int(e)
     return c
+
+
+def fsq_mismatch_report(levels, h, h_ref, idx, idx_ref, limit=16):
+    """Forensics of FSQ code mismatches ("report count of mismatches and their distance to a rounding
+    boundary").  h / h_ref: pre-quantisation encoder outputs [B, D, T, H, W] (ours / the checker's), idx / idx_ref: integer
+    codes [B, T, H, W].  For every token whose code differs, and every channel of it whose digit differs: the bounded value
+    b = tanh(h + shift) * half_l - offset the digit is rounded from (reference regularizers.py:153-163), its distance to the
+    nearest rounding boundary k + 1/2 in fp32 ulps of b, and |h - h_ref| in fp32 ulps of h_ref.  A digit can only flip where
+    the checker's own value sits within the two paths' distance of a boundary; the report shows exactly that."""
+    import numpy as np
+
+    lv = torch.tensor([int(v) for v in levels], dtype=torch.float64)
+    half_l = (lv - 1) * (1 + 1e-3) / 2
+    offset = torch.where(lv % 2 == 0, 0.5, 0.0).double()
+    shift = (offset / half_l).atanh()
+    idx, idx_ref = idx.cpu().long(), idx_ref.cpu().long()
+    bad = (idx != idx_ref).nonzero()
+    out = {"mismatches": int(bad.shape[0]), "tokens": int(idx_ref.numel()), "detail": []}
+    basis = torch.cumprod(torch.tensor([1] + [int(v) for v in levels[:-1]]), 0)
+    for b, t, y, x in bad.tolist()[:limit]:
+        hv, hr = h[b, :, t, y, x].double().cpu(), h_ref[b, :, t, y, x].double().cpu()
+        d_ours = (idx[b, t, y, x] // basis) % lv.long()
+        d_ref = (idx_ref[b, t, y, x] // basis) % lv.long()
+        for c in (d_ours != d_ref).nonzero().flatten().tolist():
+            bo, br = (float(torch.tanh(v[c] + shift[c]) * half_l[c] - offset[c]) for v in (hv, hr))
+            edge = np.floor(br) + 0.5
+            ulp_b = float(np.spacing(np.float32(abs(br))))
+            ulp_h = float(np.spacing(np.float32(abs(float(hr[c])))))
+            out["detail"].append({"token": [b, t, y, x], "channel": c, "digit": int(d_ours[c]), "digit_ref": int(d_ref[c]),
+                                  "bounded_ref": round(br, 9), "bounded": round(bo, 9),
+                                  "ref_to_boundary_ulps": round(float(abs(br - edge) / ulp_b), 2),
+                                  "ours_to_boundary_ulps": round(float(abs(bo - edge) / ulp_b), 2),
+                                  "h_diff_ulps": round(float(abs(float(hv[c]) - float(hr[c])) / ulp_h), 2)})
+    return out

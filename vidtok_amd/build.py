@@ -31,17 +31,25 @@ def _hipcc():
     raise RuntimeError("hipcc not found (set HIPCC)")
 
 
-def _digest():
+def _src_digest(src):
+    """digest of one translation unit: its source, every header (any of them may be included), its flags"""
     h = hashlib.sha256()
-    for f in SOURCES + HEADERS:
+    for f in [src] + HEADERS:
         with open(os.path.join(CSRC, f), "rb") as fh:
             h.update(fh.read())
-    h.update(" ".join(FLAGS).encode())
-    h.update(repr(sorted(EXTRA_FLAGS.items())).encode())
+    h.update(" ".join(FLAGS + EXTRA_FLAGS.get(src, [])).encode())
+    return h.hexdigest()
+
+
+def _digest():
+    h = hashlib.sha256()
+    for src in SOURCES:
+        h.update(_src_digest(src).encode())
     return h.hexdigest()
 
 
 def build(force: bool = False, verbose: bool = True) -> str:
+    """Compile what changed (per-object stamps under build/), link, stamp the library.  `force` recompiles everything."""
     stamp = LIB + ".stamp"
     dig = _digest()
     if not force and os.path.exists(LIB) and os.path.exists(stamp) and open(stamp).read() == dig:
@@ -53,14 +61,25 @@ def build(force: bool = False, verbose: bool = True) -> str:
     procs = []
     for src in SOURCES:
         obj = os.path.join(objdir, os.path.splitext(src)[0] + ".o")
+        objs.append(obj)
+        ostamp, odig = obj + ".stamp", _src_digest(src)
+        if not force and os.path.exists(obj) and os.path.exists(ostamp) and open(ostamp).read() == odig:
+            continue
+        if os.path.exists(ostamp):
+            os.remove(ostamp)
         cmd = [hipcc, *FLAGS, *EXTRA_FLAGS.get(src, []), "-x", "hip", "-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print("[vidtok_amd.build]", " ".join(cmd), flush=True)
-        procs.append((src, subprocess.Popen(cmd)))
-        objs.append(obj)
-    for src, p in procs:
+        procs.append((src, subprocess.Popen(cmd), ostamp, odig))
+    failed = []
+    for src, p, ostamp, odig in procs:
         if p.wait() != 0:
-            raise RuntimeError(f"hipcc failed on {src}")
+            failed.append(src)
+        else:
+            with open(ostamp, "w") as f:
+                f.write(odig)
+    if failed:
+        raise RuntimeError(f"hipcc failed on {', '.join(failed)}")
     cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", LIB]
     if verbose:
         print("[vidtok_amd.build]", " ".join(cmd), flush=True)

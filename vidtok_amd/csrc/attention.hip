@@ -186,7 +186,7 @@ extern "C" int vt_flash_attention(const void* q, const void* k, const void* vt, 
                                   int32_t C, int32_t ldv, float scale, vt_stream stream_) {
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
   VT_CHECK_ARG(q && k && vt && o && Z > 0, "vt_flash_attention: null tensor or empty batch");
-  VT_CHECK_ARG(Z <= 65535, "vt_flash_attention: Z = %d exceeds the grid's y extent (65 535 frames per call)", Z);
+  VT_CHECK_ARG(vt_opt(OPT_ATTN_FLASH) != 0, "vt_flash_attention: switched off (option attn_flash = 0)");
   VT_CHECK_ARG(vt_flash_attention_supported(dtype, S, C, ldv), "vt_flash_attention: bf16, C = 512, S %% 64 == 0, ldv >= S and %% 8 == 0 only (got dtype %d S %d C %d ldv %d)",
                dtype, S, C, ldv);
   const uintptr_t al = reinterpret_cast<uintptr_t>(q) | reinterpret_cast<uintptr_t>(k) | reinterpret_cast<uintptr_t>(vt) | reinterpret_cast<uintptr_t>(o) |
@@ -205,7 +205,14 @@ extern "C" int vt_flash_attention(const void* q, const void* k, const void* vt, 
     VT_CHECK_HIP(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, FA_LDS));
     if (dev_ok) attr_done[dev].store(true, std::memory_order_release);
   }
-  void* kargs[] = {&a};
-  VT_CHECK_HIP(hipLaunchKernel(kern, dim3((unsigned)(S / FA_BQ), (unsigned)Z), dim3(256), kargs, FA_LDS, stream));
+  // the frame index rides in grid.y (65 535 at most): more frames than that go out as slices of the batch
+  for (int z0 = 0; z0 < Z; z0 += 65535) {
+    const int zn = Z - z0 < 65535 ? Z - z0 : 65535;
+    FlashArgs s = a;
+    s.q = a.q + (long long)z0 * S * FA_D; s.k = a.k + (long long)z0 * S * FA_D; s.o = a.o + (long long)z0 * S * FA_D;
+    s.vt = a.vt + (long long)z0 * FA_D * ldv;
+    void* kargs[] = {&s};
+    VT_CHECK_HIP(hipLaunchKernel(kern, dim3((unsigned)(S / FA_BQ), (unsigned)zn), dim3(256), kargs, FA_LDS, stream));
+  }
   return VT_OK;
 }

@@ -26,6 +26,7 @@
 #include <cmath>
 #include <map>
 #include <memory>
+#include <set>
 #include <string>
 #include <vector>
 
@@ -1086,6 +1087,42 @@ void reset_states(Model& m) {
   for (CState* st : m.states) st->frames = 0;
 }
 
+// The handle's tiled-pass state (tiled / first_chunk flags, the decoder's doubling cache offsets), restored on EVERY exit path of a
+// tiled walk -- a walk that throws half way (an M_CHECK in Attn, update_cache, interp_cached, a workspace that is too small) must
+// not leave a handle on which the next plain vt_encode / vt_decode runs as "a chunk" (extra allocations, cache reads, "causal cache
+// missing")
+struct TileScope {
+  Model* m;
+  Graph* g;
+  TileScope(Model* m_, Graph& g_, bool overlap) : m(m_), g(&g_) {
+    g->set_offsets(overlap);
+    m->tiled = true;
+  }
+  ~TileScope() {
+    m->tiled = false;
+    m->first_chunk = true;
+    g->set_offsets(false);
+  }
+  TileScope(const TileScope&) = delete;
+  TileScope& operator=(const TileScope&) = delete;
+};
+
+// dry walks (workspace sizing, vt_prepare) run on empty arenas: the caller's arenas come back on every exit path
+struct ArenaScope {
+  Model* m;
+  Arena save[2];
+  explicit ArenaScope(Model* m_) : m(m_), save{m_->arena[0], m_->arena[1]} {
+    m->arena[0] = Arena();
+    m->arena[1] = Arena();
+  }
+  ~ArenaScope() {
+    m->arena[0] = save[0];
+    m->arena[1] = save[1];
+  }
+  ArenaScope(const ArenaScope&) = delete;
+  ArenaScope& operator=(const ArenaScope&) = delete;
+};
+
 // every chunk through the encoder in order (the module caches carry the causal state); a chunk of n frames is front-padded
 // to a multiple of f by the encoder and yields ceil(n / f) latent frames, written to h_out at their place
 void tile_encode_impl(Model* m, Graph& g, const float* x, int B, int T, int H, int W, int t_chunk, float* h_out, char* ws, hipStream_t stream, bool dry) {
@@ -1099,21 +1136,19 @@ void tile_encode_impl(Model* m, Graph& g, const float* x, int B, int T, int H, i
     nmax = std::max(nmax, ch.second - ch.first);
   }
   const ChunkBufs cb = chunk_bufs(ws, (size_t)B * cin * nmax * H * W, (size_t)B * cz * ceil_div(nmax, f) * Hz * Wz);
-  g.set_offsets(false);
+  TileScope scope(m, g, false);
   if (!dry) reset_states(*m);
-  m->tiled = true;
   int done = 0;
-  for (size_t i = 0; i < chunks.size(); ++i) {
+  std::set<int> sized;                                     // sizing: the first chunk and one chunk of every other length (a short trailing
+  for (size_t i = 0; i < chunks.size(); ++i) {             // chunk takes branches the largest one never sees)
     const int n = chunks[i].second - chunks[i].first, nz = ceil_div(n, f);
-    if (dry && !(i == 0 || n == nmax)) continue;          // sizing: the first chunk and one of the largest kind
+    if (dry && i != 0 && !sized.insert(n).second) continue;
     m->first_chunk = i == 0;
     if (!dry) M_CALL(vt_ncthw_copy_frames(x, cb.in, B * cin, T, n, chunks[i].first, 0, n, (int64_t)H * W, 0, stream));
     encode_impl(m, g, cb.in, B, n, H, W, cb.out, stream, dry);
     if (!dry) M_CALL(vt_ncthw_copy_frames(cb.out, h_out, B * cz, nz, tz, 0, done, nz, (int64_t)Hz * Wz, 0, stream));
     done += nz;
   }
-  m->tiled = false;
-  m->first_chunk = true;
 }
 
 // chunks of t_chunk_dec latent frames decoded in order, each with one look-ahead latent frame when `overlap` (its f trailing
@@ -1126,23 +1161,20 @@ void tile_decode_impl(Model* m, Graph& g, const float* z, int B, int Tz, int Hz,
   int nmax = 1;
   for (auto& ch : chunks) nmax = std::max(nmax, ch.second - ch.first + ((overlap && ch.second + 1 <= Tz) ? 1 : 0));
   const ChunkBufs cb = chunk_bufs(ws, (size_t)B * zc * nmax * Hz * Wz, (size_t)B * oc * nmax * f * H * W);
-  g.set_offsets(overlap);
+  TileScope scope(m, g, overlap);
   if (!dry) reset_states(*m);
-  m->tiled = true;
   int done = 0;
+  std::set<int> sized;                                     // as in tile_encode_impl: every distinct chunk length is walked once
   for (size_t i = 0; i < chunks.size(); ++i) {
     const bool look = overlap && chunks[i].second + 1 <= Tz;
     const int nl = chunks[i].second - chunks[i].first + (look ? 1 : 0), n = nl * f - (look ? f : 0);
-    if (dry && !(i == 0 || nl == nmax)) continue;
+    if (dry && i != 0 && !sized.insert(nl).second) continue;
     m->first_chunk = i == 0;
     if (!dry) M_CALL(vt_ncthw_copy_frames(z, cb.in, B * zc, Tz, nl, chunks[i].first, 0, nl, (int64_t)Hz * Wz, 0, stream));
     decode_impl(m, g, cb.in, B, nl, Hz, Wz, cb.out, stream, dry);
     if (!dry) M_CALL(vt_ncthw_copy_frames(cb.out, x_out, B * oc, nl * f, Tz * f, 0, done, n, (int64_t)H * W, 0, stream));
     done += n;
   }
-  m->tiled = false;
-  m->first_chunk = true;
-  g.set_offsets(false);
 }
 
 }  // namespace
@@ -1259,17 +1291,13 @@ extern "C" int64_t vt_workspace_bytes(vt_model* h, int32_t B, int32_t T, int32_t
   try {
     M_CHECK(h && B > 0 && T > 0 && H > 0 && W > 0, "vt_workspace_bytes: bad argument");
     Model& m = h->m;
-    Arena save[2] = {m.arena[0], m.arena[1]};
-    m.arena[0] = Arena();
-    m.arena[1] = Arena();
+    ArenaScope arenas(&m);
     m.expected.clear();
     encode_impl(&m, h->enc, nullptr, B, T, H, W, nullptr, nullptr, true);
     int32_t ld[4];
     vt_latent_dims(h, T, H, W, ld);
     decode_impl(&m, h->dec, nullptr, B, ld[1], ld[2], ld[3], nullptr, nullptr, true);
     const size_t peak = std::max(m.arena[0].peak, m.arena[1].peak);
-    m.arena[0] = save[0];
-    m.arena[1] = save[1];
     return (int64_t)(2 * ((peak + 255) & ~(size_t)255) + 512);
   } catch (const Fail& f) {
     return -1;
@@ -1456,16 +1484,12 @@ extern "C" int64_t vt_tile_workspace_bytes(vt_model* h, int32_t B, int32_t T, in
     Model& m = h->m;
     const int f = m.cfg.time_downsample_factor;
     M_CHECK(t_chunk_enc >= f, "vt_tile_workspace_bytes: t_chunk_enc must be at least the temporal factor %d", f);
-    Arena save[2] = {m.arena[0], m.arena[1]};
-    m.arena[0] = Arena();
-    m.arena[1] = Arena();
+    ArenaScope arenas(&m);
     const int Hz = H >> m.cfg.n_spatial_ds, Wz = W >> m.cfg.n_spatial_ds;
     const int tz = vt_tile_latent_frames(h, T, t_chunk_enc);
     tile_encode_impl(&m, h->enc, nullptr, B, T, H, W, t_chunk_enc, nullptr, nullptr, nullptr, true);
     tile_decode_impl(&m, h->dec, nullptr, B, tz, Hz, Wz, t_chunk_enc / f, use_overlap != 0, nullptr, nullptr, nullptr, true);
     const size_t peak = std::max(m.arena[0].peak, m.arena[1].peak);
-    m.arena[0] = save[0];
-    m.arena[1] = save[1];
     return (int64_t)(tile_staging_bytes(m.cfg, B, H, W, t_chunk_enc) + 2 * ((peak + 255) & ~(size_t)255) + 1024);
   } catch (const Fail& f) {
     return -1;
@@ -1489,10 +1513,8 @@ extern "C" int vt_tile_encode(vt_model* h, const float* x, int32_t B, int32_t T,
     tile_encode_impl(&h->m, h->enc, x, B, T, H, W, t_chunk_enc, h_out, (char*)workspace, reinterpret_cast<hipStream_t>(stream), false);
     return VT_OK;
   } catch (const Fail& f) {
-    h->m.tiled = false;
-    return f.code;
+    return f.code;                                  // TileScope has put the handle's tiled-pass state back
   } catch (const std::exception& e) {
-    h->m.tiled = false;
     vt_set_error("vt_tile_encode: %s", e.what());
     return VT_ERR_ARG;
   }
@@ -1511,10 +1533,8 @@ extern "C" int vt_tile_decode(vt_model* h, const float* z, int32_t B, int32_t Tz
     tile_decode_impl(&h->m, h->dec, z, B, Tz, Hz, Wz, t_chunk_dec, use_overlap != 0, x_out, (char*)workspace, reinterpret_cast<hipStream_t>(stream), false);
     return VT_OK;
   } catch (const Fail& f) {
-    h->m.tiled = false;
     return f.code;
   } catch (const std::exception& e) {
-    h->m.tiled = false;
     vt_set_error("vt_tile_decode: %s", e.what());
     return VT_ERR_ARG;
   }

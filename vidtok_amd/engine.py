@@ -30,6 +30,7 @@ def _print0(msg):
 
 class AutoencodingEngine(nn.Module):
     version = "v1_0"
+    arith = "fp32"          # set_compute_dtype(): "fp32" | "bf16" | "bf16x3"
 
     def __init__(self, *args, encoder_config: Dict, decoder_config: Dict, loss_config: Dict = None,
                  regularizer_config: Dict, optimizer_config: Union[Dict, None] = None, lr_g_factor: float = 1.0,
@@ -73,6 +74,12 @@ class AutoencodingEngine(nn.Module):
         `encoder_tail` (causal encoders): the encoder levels from `tail_level` on (default: the last level), its mid section
         and conv_out run in that type instead -- the small deep layers, whose rounding decides most of the FSQ code flips
         of a bf16 pass, in fp32 while the wide levels stay on the bf16 kernels."""
+        self._chosen = (dtype, encoder_tail, tail_level)         # what to return to when an autocast region ends
+        self._autocast_active = None
+        self._apply_compute_dtype(dtype, encoder_tail, tail_level)
+        return self
+
+    def _apply_compute_dtype(self, dtype, encoder_tail=None, tail_level=None):
         split3 = dtype == packing.ARITH_SPLIT3
         if split3:
             dtype = torch.float32
@@ -89,7 +96,61 @@ class AutoencodingEngine(nn.Module):
         else:
             assert encoder_tail is None, "encoder_tail: causal encoders only"
         self.invalidate_graphs()
+
+    # ---- the caller's torch.autocast region (reference README.md:336-340,375-385: `with torch.autocast(device_type="cuda",
+    # dtype=...): model(x)`) ---------------------------------------------------------------------------------------------
+    # The reference has no precision switch of its own: the ambient autocast context decides what its convolutions and
+    # matmuls compute in.  Here the kernels are chosen by `set_compute_dtype`, so the engine reads the context at every
+    # entry point: autocast(bfloat16) -> the bf16 kernels for this call (whatever was set; the chosen mode returns when
+    # the region ends), autocast(float16) -> per `autocast_policy["float16"]`: "error" (default: there are no fp16
+    # kernels, and running another precision silently is not what the caller asked for), or "bf16" / "bf16x3" to map it.
+    autocast_policy = {"bfloat16": "bf16", "float16": "error"}
+
+    def set_autocast_policy(self, **kw):
+        """e.g. set_autocast_policy(float16="bf16"): run autocast(float16) regions on the bf16 kernels (fp32 accumulation,
+        8 significant bits of storage instead of fp16's 11); "bf16x3" = the split-bf16 mode (inside fp32 tolerance); "error";
+        "ignore" = keep the mode chosen by set_compute_dtype"""
+        pol = dict(self.autocast_policy)
+        for k, v in kw.items():
+            assert k in ("bfloat16", "float16") and v in ("bf16", "bf16x3", "error", "ignore"), (k, v)
+            pol[k] = v
+        self.autocast_policy = pol
         return self
+
+    _MODE_DTYPE = {"bf16": torch.bfloat16, "bf16x3": packing.ARITH_SPLIT3}
+
+    def _sync_autocast(self, x):
+        """make the arithmetic mode follow the caller's autocast context (device of `x`)"""
+        dev = x.device.type if isinstance(x, torch.Tensor) else "cuda"
+        try:
+            on = torch.is_autocast_enabled(dev)
+            adt = torch.get_autocast_dtype(dev) if on else None
+        except (TypeError, AttributeError, RuntimeError):      # older torch: the CUDA-only spellings
+            on = torch.is_autocast_enabled()
+            adt = torch.get_autocast_gpu_dtype() if on else None
+        want = None
+        if on:
+            pol = self.autocast_policy.get({torch.bfloat16: "bfloat16", torch.float16: "float16"}.get(adt, ""), "error")
+            if pol == "error":
+                raise NotImplementedError(
+                    f"vidtok_amd: called under torch.autocast(dtype={adt}); the MI355X kernels compute in bf16 (autocast(bfloat16) "
+                    f"selects them), split-bf16 or fp32 -- there is no {adt} arithmetic.  Use torch.autocast(dtype=torch.bfloat16), "
+                    f"or model.set_autocast_policy(float16='bf16' | 'bf16x3' | 'ignore') to choose what such a region runs")
+            if pol != "ignore":
+                want = self._MODE_DTYPE[pol]
+        active = getattr(self, "_autocast_active", None)
+        if want is not None:
+            name = "bf16" if want == torch.bfloat16 else want
+            if active is None and self.arith == name and getattr(self.encoder, "tail_dtype", None) is None:
+                return                                          # already the mode the region asks for: nothing to switch, nothing to restore
+            if active != want:
+                if getattr(self, "_chosen", None) is None:      # never set: the construction default
+                    self._chosen = (self.encoder.compute_dtype, None, None)
+                self._apply_compute_dtype(want)
+                self._autocast_active = want
+        elif active is not None:
+            self._autocast_active = None
+            self._apply_compute_dtype(*self._chosen)
 
     # ---- launch mode: per-shape hipGraphs of the encoder / decoder launch sequences (vidtok_amd/graphs.py) ----
     def enable_graphs(self, on: bool = True):
@@ -181,6 +242,7 @@ class AutoencodingEngine(nn.Module):
     # ---- encode / decode ------------------------------------------------------------------------
     @torch.no_grad()
     def encode(self, x: Any, return_reg_log: bool = False) -> Any:
+        self._sync_autocast(x)
         z = self._run_encoder(x)
         z, reg_log = self.regularization(z, n_steps=self.global_step // 2)
         if return_reg_log:
@@ -194,6 +256,7 @@ class AutoencodingEngine(nn.Module):
 
     @torch.no_grad()
     def decode(self, z: Any, decode_from_indices: bool = False) -> torch.Tensor:
+        self._sync_autocast(z)
         if decode_from_indices:
             z = self.indices_to_latent(z)
         return self._run_decoder(z)
@@ -258,6 +321,7 @@ class AutoencodingEngineV11(AutoencodingEngine):
 
     @torch.no_grad()
     def encode(self, x: Any, return_reg_log: bool = False) -> Any:
+        self._sync_autocast(x)
         self._empty_causal_cached(self.encoder)
         self._set_first_chunk(True)
         self._set_fused_temporal()
@@ -329,6 +393,7 @@ class AutoencodingEngineV11(AutoencodingEngine):
 
     @torch.no_grad()
     def decode(self, z: Any, decode_from_indices: bool = False) -> torch.Tensor:
+        self._sync_autocast(z)
         if decode_from_indices:
             z = self.tile_indices_to_latent(z) if self.use_tiling else self.indices_to_latent(z)
         self._empty_causal_cached(self.decoder)

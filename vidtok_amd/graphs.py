@@ -73,23 +73,37 @@ class GraphedCall:
             if old != key and not self._is_stateful(self.entries[old]):
                 del self.entries[old]
 
+    # the device side of a call, as four small methods: bench.py's host-loop self-test (--selftest-steps) runs the REAL
+    # __call__ below -- key construction, cache lookup, LRU bookkeeping, state hand-over -- with these stubbed out
+    def _on_device(self, x):
+        return x.is_cuda
+
+    def _fill(self, dst, x, frames):
+        if frames is None:
+            return dst.copy_(x)
+        from . import ops
+
+        return ops.ncthw_copy_frames(x, dst, frames[0], 0, frames[1] - frames[0])
+
+    def _replay(self, g):
+        g.replay()
+
+    def _result(self, sy, borrow):
+        return sy if borrow else sy.clone()
+
     def __call__(self, x, key_extra=(), stateful=False, frames=None, borrow=False):
-        if not x.is_cuda:
+        if not self._on_device(x):
             return self.fn(x if frames is None else x[:, :, frames[0]:frames[1]].contiguous())
         x = x.contiguous()
         if frames is not None:
-            from . import ops
-
             x = x.float()
             shape = tuple(x.shape[:2]) + (frames[1] - frames[0],) + tuple(x.shape[3:])
-
-            def fill(dst):
-                return ops.ncthw_copy_frames(x, dst, frames[0], 0, frames[1] - frames[0])
         else:
             shape = tuple(x.shape)
 
-            def fill(dst):
-                return dst.copy_(x)
+        def fill(dst):
+            return self._fill(dst, x, frames)
+
         key = (shape, x.dtype, x.device, key_extra)
         e = self.entries.get(key)
         if e is None:                       # first sight of this shape: eager (packs weights, sizes the allocator)
@@ -115,7 +129,7 @@ class GraphedCall:
         self._touch(key)
         g, sx, sy, state = e
         fill(sx)
-        g.replay()
+        self._replay(g)
         if state is not None:
             self.state_set(state)
-        return sy if borrow else sy.clone()
+        return self._result(sy, borrow)

@@ -119,7 +119,8 @@ def conv(x, w, bias, geom: ConvGeom, *, cout: int, out_dtype=None, tmode=L.VT_TP
     lib = L.load()
     _chk(x, "conv.x"); _chk(w, "conv.w")
     B, Ti, Hi, Wi, Cin = x.shape
-    assert w.dtype == x.dtype and x.dtype in _DT, (w.dtype, x.dtype)
+    x3 = w.dtype == torch.int32       # split-bf16 weight planes (packing.pack_split3 / SPLIT3_DTYPE): fp32 storage, bf16 MFMA
+    assert (w.dtype == x.dtype or (x3 and x.dtype == torch.float32)) and x.dtype in _DT, (w.dtype, x.dtype)
     out_dtype = out_dtype or x.dtype
     To, Ho, Wo = geom.out_dims(Ti, Hi, Wi)
     assert To > 0 and Ho > 0 and Wo > 0, (To, Ho, Wo)
@@ -147,8 +148,7 @@ def conv(x, w, bias, geom: ConvGeom, *, cout: int, out_dtype=None, tmode=L.VT_TP
     d.B, d.Ti, d.Hi, d.Wi, d.Cin = B, Ti, Hi, Wi, Cin
     d.To, d.Ho, d.Wo, d.Cout = To, Ho, Wo, cout
     d.ldw, d.ldy = w.shape[1], ldy
-    x3 = getattr(w, "vt_arith", None) == "bf16x3"       # split-bf16 weight planes (packing.pack_split3): fp32 storage, bf16 MFMA
-    assert not x3 or (x.dtype == torch.float32 and out_dtype == torch.float32)
+    assert not x3 or out_dtype == torch.float32
     d.KT, d.KH, d.KW = geom.kt, geom.kh, geom.kw
     d.st, d.sh, d.sw = geom.st, geom.sh, geom.sw
     d.pt, d.ph, d.pw = geom.pt, geom.ph, geom.pw

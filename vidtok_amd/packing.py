@@ -26,14 +26,16 @@ def pack_conv_weight(weight: torch.Tensor, dtype: torch.dtype, cin_stored: int =
 
 
 ARITH_SPLIT3 = "bf16x3"
+SPLIT3_DTYPE = torch.int32        # element type of a split-bf16 weight container (4 bytes per k, like the fp32 row it replaces)
 
 
 def pack_split3(w2d: torch.Tensor) -> torch.Tensor:
     """Packed fp32 rows [Cout, K] -> the operand of vt_conv's VT_BF16X3 arithmetic (include/vidtok_amd.h): every value as
     two bf16 planes, hi = bf16(w) (round to nearest even) and lo = bf16(w - hi), stored per group of 16 k as
     [hi 16 x bf16 | lo 16 x bf16] (64 bytes, the size of the 16 fp32 values they replace), K zero-padded to 32 (a whole
-    128-byte K step of the kernel).  Returned as a float32-typed container [Cout, K32] (ldw = K32) tagged `vt_arith`;
-    data movement + two roundings."""
+    128-byte K step of the kernel).  Returned as an INT32-typed container [Cout, K32] (ldw = K32): the element type is the
+    tag ops.conv reads (`SPLIT3_DTYPE`) -- unlike a Python attribute it survives .view / .contiguous / slicing, and a
+    split container can never be taken for fp32 rows.  Data movement + two roundings."""
     cout, K = w2d.shape
     Kp = (K + 31) // 32 * 32
     w = w2d.detach().to(torch.float32)
@@ -42,9 +44,7 @@ def pack_split3(w2d: torch.Tensor) -> torch.Tensor:
     hi = w.to(torch.bfloat16)
     lo = (w - hi.to(torch.float32)).to(torch.bfloat16)
     planes = torch.stack([hi.view(cout, Kp // 16, 16), lo.view(cout, Kp // 16, 16)], dim=2).contiguous()   # [Cout, K/16, 2, 16]
-    out = planes.view(torch.float32).reshape(cout, Kp)
-    out.vt_arith = ARITH_SPLIT3
-    return out
+    return planes.view(SPLIT3_DTYPE).reshape(cout, Kp)
 
 
 def set_arith(root: torch.nn.Module, arith):
