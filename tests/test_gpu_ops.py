@@ -914,3 +914,58 @@ def test_library_is_the_hip_extension():
     assert lib.vt_version() >= 100 and L.LIB_PATH.endswith("libvidtok_amd.so")
     with pytest.raises(L.VtError):
         ops.layernorm_act(torch.zeros(4, 128), torch.ones(128), torch.zeros(128), silu=True)  # CPU tensor
+
+
+# Zero-padded time taps skipped per tile (option conv_tskip, default on): causal convolutions of the v1.0 models (tmode ZERO) whose
+# tiles lie inside one output frame start their K walk behind the tap planes that read only the zero frames in front of the clip.
+# The skipped products are exact zeros, so the result must be the SAME BITS as the full walk -- in every arithmetic, on both tiles,
+# with stride 2 in time (one plane skipped for frame 0) and for the k = 2 parity convolutions of a time up-sampler.
+TSKIP_CASES = [
+    ("ts_temporal_k3_256", (2, 5, 16, 16), 256, 256, (3,), ConvGeom(kt=3, pt=2), dict(res="add")),
+    ("ts_temporal_k3_512_ln", (1, 5, 16, 16), 256, 256, (3,), ConvGeom(kt=3, pt=2), dict(ln="keep")),
+    ("ts_conv3d_333_512", (1, 5, 16, 16), 512, 512, (3, 3, 3), ConvGeom(**G333), dict(res="add")),
+    ("ts_conv3d_333_128", (1, 4, 16, 16), 128, 128, (3, 3, 3), ConvGeom(**G333), {}),
+    ("ts_timedown_s2_mix", (1, 6, 16, 16), 128, 128, (3, 3, 3),
+     ConvGeom(kt=3, kh=3, kw=3, st=2, pt=1, ph=1, pw=1, ph_hi=1, pw_hi=1), dict(res="mix")),
+    ("ts_parity_kt2_256", (1, 4, 32, 32), 256, 256, (2, 3, 3), ConvGeom(kt=2, kh=3, kw=3, pt=1, ph=1, pw=1, ph_hi=1, pw_hi=1), dict(res="mix")),
+    ("ts_noncausal_sym", (1, 4, 16, 16), 128, 128, (3, 3, 3), ConvGeom(kt=3, kh=3, kw=3, pt=1, pt_hi=1, ph=1, pw=1, ph_hi=1, pw_hi=1), {}),
+]
+
+
+@pytest.mark.parametrize("tile", [0, 256], ids=["auto_tile", "tile256"])
+@pytest.mark.parametrize("dtype", DTYPES3, ids=IDS3)
+@pytest.mark.parametrize("case", TSKIP_CASES, ids=[c[0] for c in TSKIP_CASES])
+def test_conv_time_tap_skip_is_bit_exact(case, dtype, tile, vt_opts):
+    if tile == 256 and case[3] % 256 != 0:
+        pytest.skip("256 tile needs Cout % 256")
+    outs = {}
+    for skip in (1, 0):
+        vt_opts(conv_tskip=skip, conv_tile=tile, conv_ws=0)
+        keep = []
+        _check_conv(case, dtype, keep_outputs=keep)
+        outs[skip] = keep
+    assert len(outs[1]) == len(outs[0]) >= 1
+    for a, b in zip(outs[1], outs[0]):
+        assert torch.equal(a, b), f"{case[0]}: the skipped walk differs from the full one"
+
+
+def test_conv_split_k_does_not_depend_on_the_batch(vt_opts):
+    """Split-K is decided from ONE clip's geometry (To, Ho, Wo, Cout, K), never from B: a clip's result is the same bits
+    whether it is convolved alone or inside a batch of four (the round-4 rule looked at the launch's pixel
+    count and tied a clip's bits to its batch)."""
+    import ctypes as C
+
+    lib = L.load()
+    vt_opts(conv_splitk=1)
+    wt = torch.randn((512, 512, 3, 3, 3), generator=torch.Generator().manual_seed(2)) / math.sqrt(512 * 27)
+    w = pack_conv_weight(wt, torch.bfloat16, cin_stored=512).to(DEV)
+    xb = _act(4, 5, 32, 32, 512, torch.bfloat16, 1)                      # the mid block of the benchmark batch: 4 x 5 120 pixels
+    ys = {}
+    for name, x in (("batch", xb), ("alone", xb[2:3].contiguous())):
+        ops.CONV_RECORD = []
+        ys[name] = ops.conv(x, w, None, ConvGeom(**G333), cout=512)
+        rec, ops.CONV_RECORD = ops.CONV_RECORD, None
+        assert rec[0][0].work and ops.conv_plan(rec[0][0])["launches"] == 2, name     # both split: 160 tiles per clip <= 256 CUs
+        assert lib.vt_conv_work_bytes(C.byref(rec[0][0])) == 3 * x.shape[0] * 5120 * 512 * 4
+    torch.cuda.synchronize()
+    assert torch.equal(ys["batch"][2:3], ys["alone"])

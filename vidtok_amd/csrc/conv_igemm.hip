@@ -738,6 +738,21 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_igemm_glds_ker
   // integer divisions per step.
   // (split-K: the walk starts at my tap plane -- kt = z, or kh = z for a convolution without time taps -- and nsteps ends it there)
   int q_step = 0, q_cc = 0, q_kt = p.ksplit == 1 ? (int)blockIdx.z : 0, q_kh = p.ksplit == 2 ? (int)blockIdx.z : 0, q_kw = 0;
+  // Causal zero padding (tmode ZERO, the v1.0 models): the time taps in front of the clip multiply zeros.  Where a tile lies
+  // inside ONE output frame (p.tskip: launch_variant checks) those taps are the same for all of its rows, so its K walk simply
+  // starts at the first tap plane that reads a frame of the clip -- kt0 = -(to * st - pt) for the first frames, 0 elsewhere --
+  // and is that many planes shorter: a third / two thirds of the K steps of frames 1 / 0 of a 3-tap convolution, 3 of the 3 T
+  // tap planes of a clip (20 % at the T = 5 levels).  The fp32 sum of an output is unchanged (the skipped products are exact
+  // zeros added to a partial sum that starts at +0).
+  int nsteps = p.nsteps;
+  if constexpr (FAST && BUF) {
+    if (p.tskip) {
+      const int kt0 = min(max(-__builtin_amdgcn_readfirstlane(a_t0[0]), 0), p.KT - 1);
+      q_kt = kt0;
+      q_step = kt0 * khw * cpb;                      // the weight rows are walked from that plane on (s_b = q_step * ROWB)
+      nsteps -= q_step;
+    }
+  }
   unsigned s_a = 0, s_b = 0;   // BUF: wave-uniform byte offsets (soffset operand): chunk-in-tap for x, k offset for w
   const unsigned chunk_bytes = (unsigned)chunk * 16u;
   const unsigned HiWi = (unsigned)p.Hi * (unsigned)p.Wi;
@@ -980,17 +995,17 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_igemm_glds_ker
   if constexpr (!S2 && !S3 && !S5) {
 #pragma unroll
     for (int d = 0; d < D; ++d)
-      if (d < p.nsteps) {
+      if (d < nsteps) {
         prep_step(d);
 #pragma unroll
         for (int q = 0; q < IPS; ++q) fire_piece(q, d);
       }
   }
   if constexpr (S1) {                        // the addresses of a step are ready one stage before its pieces are fired
-    if (D < p.nsteps) prep_step(D);
+    if (D < nsteps) prep_step(D);
   }
   int stage = 0;
-  const int n_fire = p.nsteps - D;          // steps that still have a successor to prefetch
+  const int n_fire = nsteps - D;          // steps that still have a successor to prefetch
   // PROF (vt_conv_profile): s_memtime at the phase boundaries of K steps [8, 12) of workgroup 0, parked in the LDS
   // behind the ring and copied out after the loop
   unsigned long long* stamps = reinterpret_cast<unsigned long long*>(smem + STAGES * STAGE_BYTES);
@@ -1023,7 +1038,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_igemm_glds_ker
     u32x4 whi[2][TN], wlo[TN], xh[2][TM], xl[2][TM];
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
-      if (d < p.nsteps) prep_step(d);
+      if (d < nsteps) prep_step(d);
       else ext_x = ext_w = 0u;
 #pragma unroll
       for (int q = 0; q < IPS; ++q) fire_piece(q, d);
@@ -1064,7 +1079,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_igemm_glds_ker
 #pragma unroll
       for (int qq = 0; qq < TM * TN; ++qq) mma_bf16(whi[C][qq / TM], xh[C][qq % TM], acc[qq / TM][qq % TM]);
       __builtin_amdgcn_sched_barrier(0);
-      if (s + 3 < p.nsteps) prep_step(s + 3);
+      if (s + 3 < nsteps) prep_step(s + 3);
       else ext_x = ext_w = 0u;                     // past the last step: the pieces below turn into zero fills
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -1081,11 +1096,11 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_igemm_glds_ker
       __builtin_amdgcn_sched_barrier(0);
     };
     int s = 0;
-    for (; s + 1 < p.nsteps; s += 2) {
+    for (; s + 1 < nsteps; s += 2) {
       body(std::integral_constant<int, 0>{}, s);
       body(std::integral_constant<int, 1>{}, s + 1);
     }
-    if (s < p.nsteps) body(std::integral_constant<int, 0>{}, s);
+    if (s < nsteps) body(std::integral_constant<int, 0>{}, s);
   } else if constexpr (S3) {
     // Schedule 3: split-bf16 arithmetic (X3) on the 8-wave 256 x 256 tile.  A K step is ONE group of 16 k-values (rows of
     // 64 bytes: 16 fp32 of a pixel / [hi | lo] bf16 planes of a weight row), the ring has four slots, and a wave alternates
@@ -1110,7 +1125,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_igemm_glds_ker
     // prologue: steps 0, 1, 2 -- 12 pieces whatever nsteps is (pieces of steps that do not exist go out against extent 0)
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
-      if (d < p.nsteps) prep_step(d);
+      if (d < nsteps) prep_step(d);
       else ext_x = ext_w = 0u;
 #pragma unroll
       for (int q = 0; q < IPS; ++q) fire_piece(q, d);
@@ -1124,7 +1139,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_igemm_glds_ker
     }
     // PROF stamps per step: 0 LOAD start, 1 reads / pieces issued + x split, 2 COMPUTE start (waits + barrier over), 3 COMPUTE end,
     // 4 trailing barrier over
-    for (int s = 0; s < p.nsteps; ++s) {
+    for (int s = 0; s < nsteps; ++s) {
       const int stg = s & 3;
       s_cur = s;
       stamp(0);
@@ -1143,7 +1158,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_igemm_glds_ker
           whi[a] = *reinterpret_cast<const u32x4*>(Bs + a * 32 * ROWB + sh);
           wlo[a] = *reinterpret_cast<const u32x4*>(Bs + a * 32 * ROWB + sl);
         }
-        if (s + 3 < p.nsteps) prep_step(s + 3);
+        if (s + 3 < nsteps) prep_step(s + 3);
         else ext_x = ext_w = 0u;                     // past the last step: the pieces below turn into zero fills
 #pragma unroll
         for (int q = 0; q < S3_NL; ++q) fire_piece(q, (s + 3) & 3);
@@ -1183,7 +1198,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_igemm_glds_ker
       }
       __builtin_amdgcn_sched_barrier(0);
       stamp(3);
-      if (!(grp == 1 && s + 1 == p.nsteps)) {      // waves 4-7 entered one barrier late: they leave without the last one
+      if (!(grp == 1 && s + 1 == nsteps)) {      // waves 4-7 entered one barrier late: they leave without the last one
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -1258,7 +1273,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_igemm_glds_ker
     prep_step(0);
 #pragma unroll
     for (int q = 0; q < IPS; ++q) fire_piece(q, 0);
-    if (1 < p.nsteps) prep_step(1);
+    if (1 < nsteps) prep_step(1);
     else ext_x = ext_w = 0u;
 #pragma unroll
     for (int q = 0; q < A_VECS + 2; ++q) fire_piece(q, 1);
@@ -1271,7 +1286,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_igemm_glds_ker
     }
     // PROF stamps per step: 0 L(2s) start, 1 reads / pieces issued, 2 C(2s) start (wait + barrier over), 3 C(2s) end,
     // 4 L(2s+1) start (barrier over), 5 issued, 6 C(2s+1) start, 7 C(2s+1) end
-    for (int s = 0; s < p.nsteps; ++s) {
+    for (int s = 0; s < nsteps; ++s) {
       const int stg = s & 1;
       s_cur = s;
       stamp(0);
@@ -1290,7 +1305,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_igemm_glds_ker
       stamp(4);
       // ---- phase 2s+1
       read_w(stg, 1);
-      if (s + 2 < p.nsteps) prep_step(s + 2);
+      if (s + 2 < nsteps) prep_step(s + 2);
       else ext_x = ext_w = 0u;                     // past the last step: the pieces below turn into zero fills
       // XX(s+2), W0(s+2) into the regions read for the last time in phase 2s
 #pragma unroll
@@ -1300,7 +1315,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_igemm_glds_ker
       stamp(6);
       compute(I1{});
       stamp(7);
-      if (!(grp == 1 && s + 1 == p.nsteps)) {      // waves 4-7 entered one barrier late: they leave without the last one
+      if (!(grp == 1 && s + 1 == nsteps)) {      // waves 4-7 entered one barrier late: they leave without the last one
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -1336,7 +1351,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_igemm_glds_ker
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     read_frags(0, 0, 0);
-    for (int s = 0; s < p.nsteps; ++s) {
+    for (int s = 0; s < nsteps; ++s) {
       s_cur = s;
       stamp(0);
       const bool fire = s < n_fire;
@@ -1382,11 +1397,11 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_igemm_glds_ker
     }
     __builtin_amdgcn_s_setprio(0);
   } else {
-  for (int s = 0; s < p.nsteps; ++s) {
+  for (int s = 0; s < nsteps; ++s) {
     s_cur = s;
     stamp(0);
     // my DMA pieces of step s have landed once at most `newer` younger steps are still outstanding
-    const int newer = min(D - 1, p.nsteps - 1 - s);
+    const int newer = min(D - 1, nsteps - 1 - s);
     if (D >= 3 && newer >= 2) wait_vmcnt<2 * IPS>();
     else if (D >= 2 && newer >= 1) wait_vmcnt<IPS>();
     else wait_vmcnt<0>();
@@ -1515,6 +1530,9 @@ int launch_variant(const ConvArgs& a_in, int nbatch, hipStream_t stream) {
   const bool buf = conv_buf() && xb < 0xFFFF0000ull && wb < 0xFFFF0000ull && cache_ok &&
                    a.KH <= 8 && a.KW <= 8;   // the per-row padding mask of the FAST form holds 8 bits per axis
   VT_CHECK_ARG(!a.ksplit || buf, "vt_conv: split-K needs the descriptor gather");
+  // zero-padded time taps skipped per tile: the tap-walk form on descriptors, a tile inside one output frame
+  a.tskip = (FAST && buf && vt_opt(OPT_CONV_TSKIP) != 0 && a.tmode == VT_TPAD_ZERO && a.KT > 1 && a.pt > 0 && a.ups_t == 0 && !a.ksplit &&
+             nbatch == 1 && a.prof == nullptr && ((long long)a.Ho * a.Wo) % BM == 0) ? 1 : 0;
   const void* kern;
   // option conv_sched: 0 = the plain K-step loop of the 8-wave tile, 1 = schedule 1, 2 (default) = ping-pong; see the kernel
   constexpr bool HALF_S1 = WAVES_M == 2 && WAVES_N == 2 && TM == 2 && TN == 4 && FAST && LN256 == 2 && ROWB == 64 && STAGES == 3;   // half tile: schedule 1 on its 3-slot ring
@@ -1760,8 +1778,8 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
   }
 }
 
-// how many tap planes vt_conv would split `a` into (0 = no split): bf16, 3 taps in time at stride 1, K long, few pixels -- no more
-// tiles than CUs, so every workgroup would walk the whole K alone on its CU --, plain NDHWC rows, residual add at most
+// how many tap planes vt_conv would split `a` into (0 = no split): bf16, 3 taps in time at stride 1, K long, few pixels PER CLIP,
+// plain NDHWC rows, residual add at most
 inline int splitk_planes(const vt_conv_desc* d, const ConvArgs& a, int nbatch, bool ln_fused, bool use_ws) {
   if (vt_opt(OPT_CONV_SPLITK) == 0 || !conv_buf()) return 0;
   if (d->dtype != VT_BF16 || d->out_dtype != VT_BF16 || nbatch != 1 || use_ws || ln_fused || a.prof != nullptr) return 0;
@@ -1773,10 +1791,13 @@ inline int splitk_planes(const vt_conv_desc* d, const ConvArgs& a, int nbatch, b
   const unsigned long long xb = (unsigned long long)a.B * a.Ti * a.Hi * a.Wi * a.Cin * 2, wb = (unsigned long long)a.Cout * a.ldw * 2;
   if (xb >= 0xFFFF0000ull || wb >= 0xFFFF0000ull) return 0;
   const TileKind tk = select_tile(a, 1);
-  const int bm = tk == TILE_256x256 ? 256 : 128;
   if (tk != TILE_256x256 && tk != TILE_128x128) return 0;
-  const long long tiles = (long long)((a.M + bm - 1) / bm) * ((a.Cout + bm - 1) / bm);
-  return tiles <= device_cus() ? 3 : 0;
+  // The decision is a function of ONE CLIP's geometry (To, Ho, Wo, Cout, K) and never of B: a split launch sums its tap planes in
+  // another order than a whole one, so a rule that looked at the launch's pixel count (round 4: "no more tiles than CUs") tied a
+  // clip's bits to the batch it was part of.  A clip whose pixels make no more 128 x 128 tiles than the device has CUs splits --
+  // alone it would leave every workgroup by itself on a CU walking the whole K -- whatever the batch around it.
+  const long long clip_tiles = (((long long)a.To * a.Ho * a.Wo + 127) / 128) * ((a.Cout + 127) / 128);
+  return clip_tiles <= device_cus() ? 3 : 0;
 }
 
 int launch_splitk(const vt_conv_desc* d, const ConvArgs& a_in, int planes, hipStream_t stream) {

@@ -27,6 +27,7 @@ enum VtOpt {
   OPT_CONV_HALF256,        // K bound (0 = off): bf16 Cout % 256 == 0 launches with the LDS-transposed epilogue and K <= the bound run 128 x 256 half tiles, two workgroups per CU
   OPT_CONV_HALF_STAGGER,   // half tiles: start offset of the second workgroup slot of every CU, shader cycles per K step (+ 6 000); 0 = none
   OPT_CONV_HALF_PLAIN,     // half tiles also for launches without a fused LayerNorm (measured slower: A/B and tests only)
+  OPT_CONV_TSKIP,          // 1: a tile whose leading time taps read only the zero frames in front of the clip (causal padding, tmode ZERO) starts its K walk behind them
   OPT_COUNT
 };
 
