@@ -97,10 +97,12 @@ int vt_conv_max_lds_bytes(void);
  *   conv_deep (1)       128 x 128 tile on a 4-slot ring (three K steps of DMA in flight) for launches with no more tiles than CUs
  *   conv_sched_x3 (3)   K-step schedule of the 8-wave tile under VT_BF16X3 (64-byte rows, 4-slot ring): 0 plain loop, 1 / 2 / 3 two
  *                       wave groups alternating LOAD and COMPUTE phases with the DMA pieces of a step issued in the LOAD phase /
- *                       between the MFMAs of the COMPUTE phase / half and half
- *   conv_splitk (0)     1: split-K over the tap planes for small-M launches when the caller provides scratch (vt_conv_work_bytes).
- *                       Opt-in: a split launch sums in another order, and whether a launch splits depends on the pixel count -- with
- *                       it a clip's bits depend on the batch it was part of (+ 1 % on a v1.1 tiled pass is what it buys)
+ *                       between the MFMAs of the COMPUTE phase / half and half, 4 = "stream": one barrier per step, all eight waves
+ *                       in phase, reads / split / addresses / DMA pieces in the shadows of the step's 24 MFMAs
+ *   conv_splitk (1)     split-K over the tap planes for launches with few pixels PER CLIP when the caller provides scratch
+ *                       (vt_conv_work_bytes).  A split launch sums in another order than a whole one, so the decision is a function
+ *                       of one clip's geometry (To, Ho, Wo, Cout, K) and never of B: a clip's bits do not depend on its batch.
+ *                       + 2-3 % on a v1.1 tiled pass, neutral on the B = 4 benchmark step (profiles/r05_tskip_splitk_ab.txt)
  *   conv_tskip (1)      causal zero padding in time (tmode VT_TPAD_ZERO): a tile that lies inside one output frame starts its K walk
  *                       behind the tap planes that read only the zero frames in front of the clip (frames 0 / 1 of a 3-tap convolution
  *                       run a third / two thirds of the K steps); the skipped products are exact zeros: same bits as the full walk
@@ -377,6 +379,13 @@ int vt_fsq_quantize(const float* h, float* z, int32_t* indices, const int32_t* l
                     int32_t D, int32_t B, int64_t S, vt_stream stream);
 int vt_fsq_indices_to_codes(const int32_t* indices, float* z, const int32_t* levels_host,
                             int32_t D, int32_t B, int64_t S, vt_stream stream);
+/* The same with `ncb` codebooks (FSQRegularizer num_codebooks, "b n (c d) -> b n c d", regularizers.py:131-133,227): h, z
+ * [B][ncb * D][S] -- the D channels of codebook c of a clip are contiguous --, each codebook quantised on its own, and the
+ * codebook axis LAST on the indices as the reference keeps it: indices [B][S][ncb].  ncb = 1 is the plain form. */
+int vt_fsq_quantize_cb(const float* h, float* z, int32_t* indices, const int32_t* levels_host,
+                       int32_t D, int32_t B, int32_t ncb, int64_t S, vt_stream stream);
+int vt_fsq_indices_to_codes_cb(const int32_t* indices, float* z, const int32_t* levels_host,
+                               int32_t D, int32_t B, int32_t ncb, int64_t S, vt_stream stream);
 int64_t vt_fsq_aux_work_floats(const int32_t* levels_host, int32_t D, int32_t B, int64_t S);
 int vt_fsq_aux_stats(const float* h, const int32_t* levels_host, int32_t D, int32_t B, int64_t S,
                      float inv_temperature, float* work, float* out3, vt_stream stream);
@@ -401,8 +410,10 @@ int vt_entropy(const float* avg, int64_t J, float* out, vt_stream stream);
  *   vt_encode(h, x, B, T, H, W, h_out, ws, ws_bytes, stream)     x fp32 NCTHW -> h_out fp32 [B][C'][T'][H'][W'] (the
  *                                            Gaussian moments for KL, the pre-quantisation latent for FSQ)
  *   vt_regularize_kl(h, moments, noise | NULL, z, kl_out, B, T', H', W', stream)     = vt_kl_sample
- *   vt_regularize_fsq(h, pre, z, indices, B, T', H', W', stream)                     = vt_fsq_quantize
- *   vt_indices_to_latent(h, indices, z, B, T', H', W', stream)                       = vt_fsq_indices_to_codes
+ *   vt_regularize_fsq(h, pre, z, indices, B, T', H', W', stream)                     = [project_in ->] vt_fsq_quantize_cb [-> project_out]
+ *   vt_indices_to_latent(h, indices, z, B, T', H', W', stream)                       = vt_fsq_indices_to_codes_cb [-> project_out]
+ *                                            (indices int32 [B][T'][H'][W'], with fsq_num_codebooks = c > 1: [B][T'][H'][W'][c]; with
+ *                                            projections the handle keeps a scratch of the projected latent, grown on first use)
  *   vt_decode(h, z, B, T', H', W', x_out, ws, ws_bytes, stream)  z fp32 NCTHW -> x_out fp32 [B][out_ch][T][H][W]
  *   vt_regularize_fsq_aux(h, pre, B, T', H', W', inv_temperature, work, out3, stream)   the three statistics of FSQ's auxiliary
  *                                            loss = vt_fsq_aux_stats with the handle's levels
@@ -421,7 +432,6 @@ int vt_entropy(const float* avg, int64_t J, float* out, vt_stream stream);
  *                                            x_out fp32 [B][out_ch][T' * factor][H][W]
  *   vt_reset_cache(h)                        drops the chunk state and frees its buffers (synchronises the device); the
  *                                            tiled calls reset the state themselves at the start of a clip
- * The non-causal family stays with the Python host.
  *   vt_prepare(h)                            packs and uploads every weight now instead of at its first use
  * All device pointers; the calls are asynchronous on `stream` except that (a) the FIRST use of a weight packs it on the host
  * and uploads it with a blocking copy (vt_prepare does all of them up front) and (b) a chunk cache is hipMalloc'ed the first time a chunk kind needs it -- run one
@@ -436,9 +446,18 @@ typedef struct vt_model_config {
   int32_t n_spatial_ds, spatial_ds[8], n_tempo_ds, tempo_ds[8];     /* encoder levels that end in a down-sampler */
   int32_t n_spatial_us, spatial_us[8], n_tempo_us, tempo_us[8];     /* decoder levels that end in an up-sampler  */
   int32_t time_downsample_factor;
-  int32_t regularizer;           /* 0 DiagonalGaussianRegularizer, 1 FSQRegularizer (dim == len(levels))        */
+  int32_t regularizer;           /* 0 DiagonalGaussianRegularizer, 1 FSQRegularizer                              */
   int32_t n_levels, levels[8];
   int32_t interpolation_mode;    /* v1.1 time up-samplers: 0 nearest, 1 trilinear                                 */
+  /* the constructor arguments no shipped YAML sets (zero = the reference's default):                             */
+  int32_t norm_type;             /* 0 "layernorm", 1 "groupnorm": torch.nn.GroupNorm(32, C, eps=1e-6) at every norm site, its
+                                    statistics over the view the reference's call site passes (model_3dcausal.py:30-34;
+                                    parameters at "<norm>.weight" / ".bias", no ".norm" level); never fused into an epilogue */
+  int32_t fsq_num_codebooks;     /* FSQRegularizer num_codebooks (0 or 1 = one): indices carry the codebook axis last,
+                                    [B][T'][H'][W'][c] (regularizers.py:131-133)                                  */
+  int32_t fsq_dim;               /* FSQRegularizer dim (0 = len(levels) * num_codebooks): when it differs, z_channels = dim and the
+                                    quantiser sits between project_in / project_out (nn.Linear along the channel axis,
+                                    "regularization.project_in.weight" ..., regularizers.py:137-139,225,255)       */
 } vt_model_config;
 typedef struct vt_model vt_model;
 int vt_model_config_size(void);    /* sizeof(vt_model_config) as compiled: lets a binding verify its struct mirror */

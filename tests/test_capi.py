@@ -200,17 +200,20 @@ def test_conv_plan_tile_selection(built_lib, monkeypatch):
         assert ops.conv_plan(desc((256, 256), 128, 3, **co))["kernel"] == "igemm"
     with pytest.raises(L.VtError):
         ops.conv_plan(desc((64, 64), 100, 128))                  # same validation as vt_conv
-    # split-K over the tap planes (vt_conv_work_bytes; no GPU: 256 CUs assumed): an opt-in -- which launches split depends on the
-    # pixel count, so with it a clip's bits would depend on its batch (tests/test_gpu_e2e.py::test_full_size_properties)
+    # split-K over the tap planes (vt_conv_work_bytes; no GPU: 256 CUs assumed): on by default since round 5 -- the decision looks at
+    # ONE clip's pixels (To * Ho * Wo), never at B, so a clip's bits do not depend on its batch (tests/test_gpu_ops.py::
+    # test_conv_split_k_does_not_depend_on_the_batch, tests/test_gpu_e2e.py::test_full_size_properties)
     import ctypes as C
     lib = L.load()
-    deep = desc((64, 64), 512, 512, work=4096)                  # 4 096 pixels, K = 4 608: 128 tiles of 128 x 128 -- every workgroup alone on its CU
-    assert L.get_option("conv_splitk") == 0 and lib.vt_conv_work_bytes(C.byref(deep)) == 0 and ops.conv_plan(deep)["launches"] == 1
-    with L.options(conv_splitk=1):
-        assert lib.vt_conv_work_bytes(C.byref(deep)) == 3 * 4096 * 512 * 4 and ops.conv_plan(deep)["launches"] == 2     # the three rows of the 3 x 3 + the reduction
-        assert lib.vt_conv_work_bytes(C.byref(desc((256, 256), 512, 512))) == 0                                        # 65 536 pixels: enough tiles
-        assert lib.vt_conv_work_bytes(C.byref(desc((64, 64), 512, 512, dtype=L.VT_F32, out_dtype=L.VT_F32))) == 0      # bf16 only
-        assert lib.vt_conv_work_bytes(C.byref(desc((64, 64), 128, 512, ldw=9 * 128))) == 0                              # K = 1 152: too short to pay
+    deep = desc((64, 64), 512, 512, work=4096)                  # 4 096 pixels per clip, K = 4 608: 128 tiles of 128 x 128 -- every workgroup alone on its CU
+    assert L.get_option("conv_splitk") == 1
+    assert lib.vt_conv_work_bytes(C.byref(deep)) == 3 * 4096 * 512 * 4 and ops.conv_plan(deep)["launches"] == 2     # the three rows of the 3 x 3 + the reduction
+    assert lib.vt_conv_work_bytes(C.byref(desc((64, 64), 512, 512, B=8))) == 8 * 3 * 4096 * 512 * 4                # a batch of such clips splits too
+    assert lib.vt_conv_work_bytes(C.byref(desc((256, 256), 512, 512))) == 0                                        # 65 536 pixels per clip: enough tiles
+    assert lib.vt_conv_work_bytes(C.byref(desc((64, 64), 512, 512, dtype=L.VT_F32, out_dtype=L.VT_F32))) == 0      # bf16 only
+    assert lib.vt_conv_work_bytes(C.byref(desc((64, 64), 128, 512, ldw=9 * 128))) == 0                              # K = 1 152: too short to pay
+    with L.options(conv_splitk=0):
+        assert lib.vt_conv_work_bytes(C.byref(deep)) == 0 and ops.conv_plan(deep)["launches"] == 1
 
 
 def test_options_table(built_lib, monkeypatch):
@@ -385,6 +388,49 @@ def test_model_handle_graph_of_every_causal_config(built_lib, name):
         assert built_lib.vt_workspace_bytes(h, 1, f + 1, 64, 64) > 0, built_lib.vt_last_error()
     finally:
         built_lib.vt_destroy(h)
+
+
+@pytest.mark.parametrize("name,ov,reg", [
+    ("vidtok_kl_causal_488_4chn", dict(norm_type="groupnorm"), None),
+    ("vidtok_v1_1/vidtok_fsq_causal_888_32768_v1_1", dict(norm_type="groupnorm"), None),
+    ("vidtok_kl_noncausal_488_4chn", dict(norm_type="groupnorm"), None),
+    ("vidtok_fsq_causal_488_32768", dict(z_channels=6), dict(levels=[8, 5, 5], num_codebooks=2)),
+    ("vidtok_fsq_causal_488_32768", dict(z_channels=8), dict(levels=[8, 5, 5], num_codebooks=2, dim=8)),
+    ("vidtok_fsq_causal_488_32768", dict(z_channels=7), dict(levels=[8, 5, 5], dim=7)),
+], ids=["groupnorm_v10", "groupnorm_v11", "groupnorm_noncausal", "fsq_two_codebooks", "fsq_two_codebooks_projected", "fsq_projected"])
+def test_model_handle_constructor_variants_without_gpu(built_lib, name, ov, reg):
+    """vt_model_config.norm_type / fsq_num_codebooks / fsq_dim: vt_create drives the constructor arguments no shipped
+    YAML sets -- GroupNorm parameter keys without the ".norm" level (model_3dcausal.py:30-34), FSQ's project_in / project_out
+    (regularizers.py:137-139) -- and lists exactly the tensors of the Python model built with the same overrides; inconsistent
+    FSQ widths are refused.  Host-side only (bit-equality with the engine: tests/test_gpu_e2e.py::test_model_handle_constructor_variants)."""
+    import sys
+
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from util import build_model, handle_config
+    from vidtok_amd import lib
+
+    model, cfg, sd = build_model(name, overrides=ov, reg_overrides=reg)
+    prm = cfg["model"]["params"]
+    mc = handle_config(lib, prm["encoder_config"]["params"], prm["regularizer_config"]["target"], prm["regularizer_config"].get("params", {}),
+                       prm["encoder_config"]["target"])
+    assert mc.norm_type == (1 if "norm_type" in ov else 0)
+    h = C.c_void_p()
+    assert built_lib.vt_create(C.byref(mc), lib.VT_F32, C.byref(h)) == 0, built_lib.vt_last_error()
+    try:
+        keys = [built_lib.vt_weight_name(h, i).decode() for i in range(built_lib.vt_weight_count(h))]
+        want = {k: v for k, v in sd.items() if not k.startswith("regularization") or ".project_" in k}
+        assert set(keys) == set(want) and len(keys) == len(want)
+        for i, k in enumerate(keys):
+            shp, nd = (C.c_int64 * 5)(), C.c_int32()
+            assert built_lib.vt_weight_shape(h, i, shp, C.byref(nd)) == 0 and tuple(shp[:nd.value]) == tuple(want[k].shape), k
+        if "norm_type" in ov:
+            assert any(k.endswith("norm1.weight") for k in keys) and not any("norm1.norm." in k or ".norm.norm." in k for k in keys)
+        assert built_lib.vt_workspace_bytes(h, 1, 8, 64, 64) > 0, built_lib.vt_last_error()
+    finally:
+        built_lib.vt_destroy(h)
+    if reg is not None:
+        mc.z_channels += 1                          # z_channels must be FSQ's dim
+        assert built_lib.vt_create(C.byref(mc), lib.VT_F32, C.byref(h)) != 0 and b"z_channels" in built_lib.vt_last_error()
 
 
 def _build_c_example(tmp_path):

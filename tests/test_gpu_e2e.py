@@ -571,6 +571,34 @@ def test_model_handle_matches_engine(name, shape, dtype):
         pytest.skip("fp32 at full size is covered by the bf16 case of the same graph and the small fp32 case")
     name, _, interp = name.partition(":")
     model, cfg, sd = build_model(name, device=DEV, dtype=dtype, overrides={"interpolation_mode": interp} if interp else None)
+    _handle_vs_engine(model, cfg, sd, shape, dtype)
+
+
+# the constructor arguments no shipped YAML sets: `norm_type: groupnorm` (model_3dcausal.py:30-34) in each family,
+# FSQ with several codebooks and with project_in / project_out (regularizers.py:95-146) -- vt_model_config carries them
+# (norm_type, fsq_num_codebooks, fsq_dim), and the handle must give the Python engine's bits for them as for the shipped YAMLs
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32], ids=["bf16", "f32"])
+@pytest.mark.parametrize("name,shape,ov,reg", [
+    ("vidtok_kl_causal_488_4chn", (1, 3, 9, 64, 64), dict(norm_type="groupnorm"), None),
+    ("vidtok_v1_1/vidtok_kl_causal_488_4chn_v1_1", (1, 3, 10, 64, 64), dict(norm_type="groupnorm"), None),
+    ("vidtok_kl_noncausal_488_4chn", (1, 3, 8, 64, 64), dict(norm_type="groupnorm"), None),
+    ("vidtok_fsq_causal_488_32768", (1, 3, 9, 64, 64), dict(z_channels=6), dict(levels=[8, 5, 5], num_codebooks=2)),
+    ("vidtok_fsq_causal_488_32768", (2, 3, 5, 64, 64), dict(z_channels=8), dict(levels=[8, 5, 5], num_codebooks=2, dim=8)),
+    ("vidtok_fsq_causal_488_32768", (1, 3, 9, 64, 64), dict(z_channels=7), dict(levels=[8, 5, 5], dim=7)),
+], ids=["groupnorm_v10", "groupnorm_v11", "groupnorm_noncausal", "fsq_two_codebooks", "fsq_two_codebooks_projected", "fsq_projected"])
+def test_model_handle_constructor_variants(name, shape, ov, reg, dtype):
+    if reg is not None:
+        reg = dict(reg, entropy_loss_weight=0.0, commitment_loss_weight=0.0)
+    model, cfg, sd = build_model(name, seed=17, device=DEV, dtype=dtype, overrides=ov, reg_overrides=reg)
+    _handle_vs_engine(model, cfg, sd, shape, dtype)
+
+
+def _handle_vs_engine(model, cfg, sd, shape, dtype):
+    import ctypes as C
+
+    from vidtok_amd import lib as L
+    from vidtok_amd import ops
+
     prm = cfg["model"]["params"]
     lib = L.load()
     h = C.c_void_p()
@@ -587,7 +615,8 @@ def test_model_handle_matches_engine(name, shape, dtype):
     L.check(lib.vt_create(C.byref(mc), {torch.bfloat16: L.VT_BF16, torch.float32: L.VT_F32, X3: L.VT_BF16X3}[dtype], C.byref(h)), "vt_create")
     try:
         names = [lib.vt_weight_name(h, i).decode() for i in range(lib.vt_weight_count(h))]
-        assert set(names) == {k for k in sd if not k.startswith("regularization")}, "the handle reads exactly the encoder / decoder tensors of the reference state_dict"
+        assert set(names) == {k for k in sd if not k.startswith("regularization") or ".project_" in k}, \
+            "the handle reads exactly the encoder / decoder tensors of the reference state_dict (+ FSQ's projections)"
         for k in names:
             t = sd[k].detach().float().contiguous().cpu()
             shp = (C.c_int64 * t.dim())(*t.shape)
@@ -617,9 +646,11 @@ def test_model_handle_matches_engine(name, shape, dtype):
             ref_z, ref_kl = ops.kl_sample(ref_h.contiguous(), None)
             assert torch.equal(z, ref_z) and torch.equal(kl.reshape(()), ref_kl.reshape(()))
         else:
-            idx = torch.empty((B, ld[1], ld[2], ld[3]), dtype=torch.int32, device=DEV)
+            ncb = max(1, mc.fsq_num_codebooks)
+            idx = torch.empty((B, ld[1], ld[2], ld[3]) + ((ncb,) if ncb > 1 else ()), dtype=torch.int32, device=DEV)
             L.check(lib.vt_regularize_fsq(h, got_h.data_ptr(), z.data_ptr(), idx.data_ptr(), B, ld[1], ld[2], ld[3], st), "vt_regularize_fsq")
             ref_z, ref_log = model.regularization(ref_h)
+            assert ref_log["indices"].numel() == idx.numel()
             assert torch.equal(z, ref_z) and torch.equal(idx, ref_log["indices"].to(torch.int32).reshape(idx.shape))
             z2 = torch.empty_like(z)          # decode(indices, decode_from_indices=True) starts here
             L.check(lib.vt_indices_to_latent(h, idx.data_ptr(), z2.data_ptr(), B, ld[1], ld[2], ld[3], st), "vt_indices_to_latent")

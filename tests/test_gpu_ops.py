@@ -466,13 +466,12 @@ def test_conv_split_k(case, split, vt_opts):
 
 
 def test_conv_split_k_needs_scratch_and_small_m(vt_opts):
-    """no scratch in the descriptor -> the call runs whole; many pixels (more tiles than CUs) -> no split is asked for"""
+    """no scratch in the descriptor -> the call runs whole; many pixels per clip (more tiles than CUs) -> no split is asked for"""
     import ctypes as C
 
     lib = L.load()
     x = _act(1, 4, 32, 32, 512, torch.bfloat16, 1)
-    assert L.get_option("conv_splitk") == 0          # opt-in: a split launch sums in another order, and whether a launch splits depends on the batch size
-    vt_opts(conv_splitk=1)
+    assert L.get_option("conv_splitk") == 1          # on by default: the decision is per clip, never per batch
     wt = torch.randn((512, 512, 3, 3, 3), generator=torch.Generator().manual_seed(2)) / math.sqrt(512 * 27)
     w = pack_conv_weight(wt, torch.bfloat16, cin_stored=512).to(DEV)
     ops.CONV_RECORD = []

@@ -244,17 +244,24 @@ def _fsq_consts(levels):
     return lv, half_l, offset, shift, lv // 2, basis
 
 
-def fsq_quantize(h, levels):
+def fsq_quantize(h, levels, num_codebooks=1):
     lv, half_l, offset, shift, half_w, basis = (t.to(h.device) for t in _fsq_consts(levels))
+    c, d = int(num_codebooks), len(levels)
     zf = h.float().movedim(1, -1)
+    zf = zf.reshape(zf.shape[:-1] + (c, d))                      # "b n (c d) -> b n c d" (regularizers.py:227)
     codes = ((zf + shift).tanh() * half_l - offset).round() / half_w
-    idx = ((codes * half_w + half_w) * basis).sum(-1).to(torch.int32)
-    return codes.movedim(-1, 1).contiguous(), idx
+    idx = ((codes * half_w + half_w) * basis).sum(-1).to(torch.int32)         # [b, ..., c]
+    codes = codes.reshape(codes.shape[:-2] + (c * d,))
+    return codes.movedim(-1, 1).contiguous(), (idx if c > 1 else idx[..., 0])
 
 
-def fsq_indices_to_codes(idx, levels):
+def fsq_indices_to_codes(idx, levels, num_codebooks=1):
     lv, _, _, _, half_w, basis = (t.to(idx.device) for t in _fsq_consts(levels))
-    codes = ((idx[..., None] // basis) % lv - half_w) / half_w
+    c = int(num_codebooks)
+    if c == 1:
+        idx = idx[..., None]
+    codes = ((idx[..., None] // basis) % lv - half_w) / half_w                # [b, ..., c, d]
+    codes = codes.reshape(codes.shape[:-2] + (c * len(levels),))
     return codes.movedim(-1, 1).contiguous().float()
 
 

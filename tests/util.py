@@ -85,10 +85,13 @@ def handle_config(L, enc, reg_target, reg_params, enc_target=""):
         if k != "ch_mult":
             setattr(c, "n_" + k, len(v))
     c.time_downsample_factor = enc.get("time_downsample_factor", 4)
+    c.norm_type = {"layernorm": 0, "groupnorm": 1}[enc.get("norm_type", "layernorm")]
     if reg_target.endswith("FSQRegularizer"):
         c.regularizer, c.n_levels = 1, len(reg_params["levels"])
         for i, e in enumerate(reg_params["levels"]):
             c.levels[i] = int(e)
+        c.fsq_num_codebooks = int(reg_params.get("num_codebooks", 1))
+        c.fsq_dim = int(reg_params.get("dim") or 0)
     return c
 
 

@@ -172,6 +172,24 @@ struct Model {
   int tpad() const { return v11() ? VT_TPAD_REPLICATE : VT_TPAD_ZERO; }
   std::map<std::string, Param> params;
   std::map<std::string, std::unique_ptr<DevBuf>> packed;      // cache key -> the packed tensor on the device (owned)
+  std::unique_ptr<DevBuf> reg_buf; // FSQ with projections: the projected latent and its codes (grown on first use, like the chunk caches)
+  size_t reg_cap = 0;
+  float* reg_scratch(size_t floats) {
+    if (reg_cap < floats * 4) {
+      auto b = std::make_unique<DevBuf>();
+      if (hipMalloc(&b->p, floats * 4) != hipSuccess) {
+        vt_set_error("vt_model: hipMalloc of the %zu-byte FSQ projection scratch failed", floats * 4);
+        throw Fail{VT_ERR_HIP};
+      }
+      if (reg_buf) retired.push_back(std::move(reg_buf));
+      reg_buf = std::move(b);
+      reg_cap = floats * 4;
+    }
+    return (float*)reg_buf->p;
+  }
+  int fsq_ncb() const { return cfg.fsq_num_codebooks > 1 ? cfg.fsq_num_codebooks : 1; }
+  int fsq_eff() const { return cfg.n_levels * fsq_ncb(); }                     // effective_codebook_dim
+  bool fsq_proj() const { return cfg.regularizer == 1 && cfg.fsq_dim > 0 && cfg.fsq_dim != fsq_eff(); }
   bool prepare = false;            // vt_prepare: a dry walk of the graphs that packs and uploads every weight it meets
   Arena arena[2];
   std::vector<std::string> expected;        // state_dict keys the graph reads (filled by a dry run)
@@ -317,19 +335,39 @@ Geom centred(Geom g, int before) {
 }
 
 struct Norm {
-  std::string key;                 // "...norm1" (the LayerNorm wrapper: parameters at key + ".norm.weight" / ".norm.bias")
+  std::string key;                 // "...norm1": LayerNorm wrapper, parameters at key + ".norm.weight" / ".norm.bias"; GroupNorm: key + ".weight" / ".bias"
   float eps = 1e-6f;
+  bool group = false;              // norm_type "groupnorm": torch.nn.GroupNorm(32, C, eps 1e-6) (model_3dcausal.py:30-32)
+  int site = VT_GN_FRAME;          // GroupNorm only: the view the reference's call site normalises; -1 = single positions (the causal temporal blocks)
+  std::string wkey() const { return key + (group ? ".weight" : ".norm.weight"); }
+  std::string bkey() const { return key + (group ? ".bias" : ".norm.bias"); }
+  // the norm of a plain tensor (LayerNorm: vt_layernorm_act; GroupNorm: vt_groupnorm_act over the site's domain, as
+  // vidtok_amd/ops.py::groupnorm_act drives it)
+  Tens of(Ctx& c, const Tens& t, bool silu, int c_real) const {
+    Tens o = c.alloc(t.B, t.T, t.H, t.W, t.ld, c.m->dt, c_real);
+    const float* g = c.m->f32(wkey(), c.dry);
+    const float* b = c.m->f32(bkey(), c.dry);
+    if (!group) {
+      if (!c.dry)
+        M_CALL(vt_layernorm_act(t.p, t.dt, t.ld, o.p, o.dt, o.ld, g, b, (int64_t)t.B * t.T * t.H * t.W, c_real, eps, silu ? 1 : 0, c.stream));
+      return o;
+    }
+    // single positions ("(b t) c s" with s = 1, model_3dcausal.py:476-487) = the PIXEL domain of a one-frame view of all positions
+    const int scope = site < 0 ? VT_GN_PIXEL : site;
+    const int B = site < 0 ? 1 : t.B, T = site < 0 ? 1 : t.T;
+    const int64_t HW = site < 0 ? (int64_t)t.B * t.T * t.H * t.W : (int64_t)t.H * t.W;
+    const int64_t wb = std::max<int64_t>(vt_groupnorm_work_bytes(B, T, 32, scope), 8);
+    void* work = c.cur->alloc((size_t)wb, c.dry);
+    if (!c.dry) M_CALL(vt_groupnorm_act(t.p, t.dt, t.ld, o.p, o.dt, o.ld, g, b, B, T, HW, c_real, 32, scope, eps, silu ? 1 : 0, work, c.stream));
+    return o;
+  }
   // LayerNorm(+SiLU) of x, unless x already carries exactly that
   Tens apply(Ctx& c, const Act& x, bool silu, int c_real) const {
     if (x.has_n() && x.norm == this && x.silu == silu) return x.n;
-    const Tens& t = x.y;
-    Tens o = c.alloc(t.B, t.T, t.H, t.W, t.ld, c.m->dt, c_real);
-    const float* g = c.m->f32(key + ".norm.weight", c.dry);
-    const float* b = c.m->f32(key + ".norm.bias", c.dry);
-    if (!c.dry)
-      M_CALL(vt_layernorm_act(t.p, t.dt, t.ld, o.p, o.dt, o.ld, g, b, (int64_t)t.B * t.T * t.H * t.W, c_real, eps, silu ? 1 : 0, c.stream));
-    return o;
+    return of(c, x.y, silu, c_real);
   }
+  // what a stage asks its producer to emit: nothing for GroupNorm (its statistics span more than a position: never fused)
+  NormRef ref(bool silu) const { return group ? NormRef() : NormRef{this, silu}; }
 };
 
 struct ConvOpts {
@@ -383,10 +421,11 @@ Act conv(Ctx& c, const Tens& x, const void* w, int ldw, const float* bias, const
   d.nbatch = 1;
   d.yt_mul = o.yt_mul; d.yt_off = o.yt_off;
   if (o.ys) { d.ys_mul = 2; d.ys_oh = o.ys_oh; d.ys_ow = o.ys_ow; }
-  if (o.ln.norm) {
+  const bool ln_after = o.ln.norm && o.ln.norm->group;      // GroupNorm of the result: its own pass behind the convolution (GroupNorm32.after)
+  if (o.ln.norm && !ln_after) {
     r.n = c.alloc(x.B, To, Ho, Wo, ldy, c.m->dt, cout);
-    d.ln_gamma = c.m->f32(o.ln.norm->key + ".norm.weight", c.dry);
-    d.ln_beta = c.m->f32(o.ln.norm->key + ".norm.bias", c.dry);
+    d.ln_gamma = c.m->f32(o.ln.norm->wkey(), c.dry);
+    d.ln_beta = c.m->f32(o.ln.norm->bkey(), c.dry);
     d.ln_out = r.n.p;
     d.ln_mode = o.ln.silu ? 2 : 1; d.ln_keep_y = o.keep_y ? 1 : 0; d.ldn = ldy; d.ln_eps = o.ln.norm->eps;
     r.norm = o.ln.norm; r.silu = o.ln.silu;
@@ -409,6 +448,11 @@ Act conv(Ctx& c, const Tens& x, const void* w, int ldw, const float* bias, const
     }
   }
   if (!c.dry) M_CALL(vt_conv(&d, c.stream));
+  if (ln_after) {
+    M_CHECK(!o.out && !o.ncthw, "vt_model: GroupNorm of an interleaved / NCTHW result");
+    r.n = o.ln.norm->of(c, r.y, o.ln.silu, cout);
+    r.norm = o.ln.norm; r.silu = o.ln.silu;
+  }
   return r;
 }
 
@@ -523,7 +567,7 @@ struct ResBlock : Stage {          // ResnetBlock (2-D per frame) or ResnetCausa
   void states(std::vector<CState*>& v) override {
     if (causal3d_) { v.push_back(&s1); v.push_back(&s2); }
   }
-  NormRef first_norm(Ctx&) const override { return NormRef{&n1, true}; }
+  NormRef first_norm(Ctx&) const override { return n1.ref(true); }
   Act run(Ctx& c, const Act& x, NormRef next) override {
     Model* m = c.m;
     Geom g3 = causal3d_ ? causal3d(3, 3, 3) : causal3d(1, 3, 3);
@@ -555,12 +599,12 @@ struct TBlock : Stage {            // ResnetCausalBlock1D, model_3dcausal.py:427
   // stand at the same point of the chunk schedule and, past the first chunk, both caches must be there
   bool fusable(const Ctx& c) const {
     if (c.m->noncausal()) return false;                // the fused launch is the causal block
-    if (!(c.m->dt == VT_BF16 && ch == 128 && n1.eps == n2.eps)) return false;
+    if (!(c.m->dt == VT_BF16 && ch == 128 && n1.eps == n2.eps) || n1.group) return false;
     if (!c.m->tiled) return true;
     if (s1.offset != s2.offset) return false;
     return c.m->first_chunk || c.dry || (s1.frames >= 2 && s2.frames >= 2);
   }
-  NormRef first_norm(Ctx& c) const override { return fusable(c) ? NormRef() : NormRef{&n1, true}; }
+  NormRef first_norm(Ctx& c) const override { return fusable(c) ? NormRef() : n1.ref(true); }
   Act run(Ctx& c, const Act& x, NormRef next) override {
     Model* m = c.m;
     const Tens& xp = x.y;
@@ -617,7 +661,7 @@ struct Attn : Stage {              // AttnBlockWrapper, model_3dcausal.py:83-141
   int ch;
   Norm n;
   std::string key;                 // q / k / v / proj_out: CausalConv3d 1x1x1 at key + ".q.conv.weight" ...
-  NormRef first_norm(Ctx&) const override { return NormRef{&n, false}; }
+  NormRef first_norm(Ctx&) const override { return n.ref(false); }
   Act run(Ctx& c, const Act& x, NormRef next) override {
     Model* m = c.m;
     const Tens hn = n.apply(c, x, false, ch);
@@ -854,9 +898,16 @@ void sh_conv(Shapes& sh, const std::string& key, int cout, int cin, std::vector<
   sh[key + ".weight"] = w;
   sh[key + ".bias"] = {cout};
 }
+bool g_group_norm = false;         // set by the builders from vt_model_config.norm_type while a graph is being built (single-threaded: vt_create)
 void sh_norm(Shapes& sh, const std::string& key, int c) {
-  sh[key + ".norm.weight"] = {c};
-  sh[key + ".norm.bias"] = {c};
+  sh[key + (g_group_norm ? ".weight" : ".norm.weight")] = {c};
+  sh[key + (g_group_norm ? ".bias" : ".norm.bias")] = {c};
+}
+// a norm of the graph under `key`; `site` = the view its call site hands to GroupNorm (vidtok_amd/modules.py SITE_*)
+void set_norm(Norm& n, const std::string& key, int site) {
+  n.key = key;
+  n.group = g_group_norm;
+  n.site = site;
 }
 
 struct Graph {
@@ -886,7 +937,7 @@ struct Graph {
 };
 
 // `wrap`: the 3-D / 1-D convolutions sit under a Causal* wrapper (a ".conv" level in their keys); false for the non-causal family
-ResBlock* res_block(Shapes& sh, const std::string& key, int cin, int cout, bool causal, bool wrap = true) {
+ResBlock* res_block(Shapes& sh, const std::string& key, int cin, int cout, bool causal, bool wrap = true, int site = VT_GN_FRAME) {
   const std::string sfx0 = (causal && wrap) ? ".conv" : "";
   const std::vector<int64_t> k3 = causal ? std::vector<int64_t>{3, 3, 3} : std::vector<int64_t>{3, 3};
   const std::vector<int64_t> k1 = causal ? std::vector<int64_t>{1, 1, 1} : std::vector<int64_t>{1, 1};
@@ -897,7 +948,7 @@ ResBlock* res_block(Shapes& sh, const std::string& key, int cin, int cout, bool 
   if (cin != cout) sh_conv(sh, key + ".nin_shortcut" + sfx0, cout, cin, k1);
   auto* b = new ResBlock();
   b->causal3d_ = causal; b->cin = cin; b->cout = cout;
-  b->n1.key = key + ".norm1"; b->n2.key = key + ".norm2";
+  set_norm(b->n1, key + ".norm1", site); set_norm(b->n2, key + ".norm2", site);
   const std::string sfx = sfx0;
   b->c1.key = key + ".conv1" + sfx; b->c2.key = key + ".conv2" + sfx; b->sc.key = key + ".nin_shortcut" + sfx;
   return b;
@@ -909,7 +960,8 @@ TBlock* t_block(Shapes& sh, const std::string& key, int ch, bool wrap = true) {
   sh_conv(sh, key + ".conv2" + (wrap ? ".conv" : ""), ch, ch, {3});
   auto* b = new TBlock();
   b->ch = ch;
-  b->n1.key = key + ".norm1"; b->n2.key = key + ".norm2";
+  // causal temporal blocks normalise single positions (model_3dcausal.py:476-487), the non-causal ones pixels over time (model_3dnoncausal.py:228-236)
+  set_norm(b->n1, key + ".norm1", wrap ? -1 : VT_GN_PIXEL); set_norm(b->n2, key + ".norm2", wrap ? -1 : VT_GN_PIXEL);
   b->c1.key = key + ".conv1"; b->c2.key = key + ".conv2";
   return b;
 }
@@ -917,12 +969,14 @@ Attn* attn(Shapes& sh, const std::string& key, int ch, bool wrap = true) {
   sh_norm(sh, key + ".norm", ch);
   for (const char* n : {".q", ".k", ".v", ".proj_out"}) sh_conv(sh, key + n + (wrap ? ".conv" : ""), ch, ch, {1, 1, 1});
   auto* a = new Attn();
-  a->ch = ch; a->key = key; a->n.key = key + ".norm";
+  a->ch = ch; a->key = key;
+  set_norm(a->n, key + ".norm", wrap ? VT_GN_FRAME : VT_GN_CLIP);
   return a;
 }
 
 Graph build_encoder(const vt_model_config& cf, Shapes& sh) {
   Graph g;
+  g_group_norm = cf.norm_type == 1;
   const int L = cf.num_resolutions;
   const bool wrap = cf.version != 2;
   const std::string cv = wrap ? ".conv" : "";
@@ -950,11 +1004,11 @@ Graph build_encoder(const vt_model_config& cf, Shapes& sh) {
       }
     }
   }
-  g.stages.emplace_back(res_block(sh, "encoder.mid.block_1", block_in, block_in, true, wrap));
+  g.stages.emplace_back(res_block(sh, "encoder.mid.block_1", block_in, block_in, true, wrap, wrap ? VT_GN_FRAME : VT_GN_CLIP));
   g.stages.emplace_back(attn(sh, "encoder.mid.attn_1", block_in, wrap));
-  g.stages.emplace_back(res_block(sh, "encoder.mid.block_2", block_in, block_in, true, wrap));
+  g.stages.emplace_back(res_block(sh, "encoder.mid.block_2", block_in, block_in, true, wrap, wrap ? VT_GN_FRAME : VT_GN_CLIP));
   g.conv_in = "encoder.conv_in" + cv; g.conv_out = "encoder.conv_out" + cv;
-  g.norm_out.key = "encoder.norm_out";
+  set_norm(g.norm_out, "encoder.norm_out", wrap ? VT_GN_FRAME : VT_GN_CLIP);
   g.c_first = cf.ch; g.c_last = block_in;
   sh_conv(sh, g.conv_in, cf.ch, cf.in_channels, {3, 3, 3});
   sh_conv(sh, g.conv_out, cf.double_z ? 2 * cf.z_channels : cf.z_channels, block_in, {3, 3, 3});
@@ -964,15 +1018,16 @@ Graph build_encoder(const vt_model_config& cf, Shapes& sh) {
 
 Graph build_decoder(const vt_model_config& cf, Shapes& sh) {
   Graph g;
+  g_group_norm = cf.norm_type == 1;
   const int L = cf.num_resolutions;
   const bool wrap = cf.version != 2;
   const std::string cv = wrap ? ".conv" : "";
   int block_in = cf.ch * cf.ch_mult[L - 1];
   int n_up = 1;
   g.c_first = block_in;
-  g.stages.emplace_back(res_block(sh, "decoder.mid.block_1", block_in, block_in, true, wrap));
+  g.stages.emplace_back(res_block(sh, "decoder.mid.block_1", block_in, block_in, true, wrap, wrap ? VT_GN_FRAME : VT_GN_CLIP));
   g.stages.emplace_back(attn(sh, "decoder.mid.attn_1", block_in, wrap));
-  g.stages.emplace_back(res_block(sh, "decoder.mid.block_2", block_in, block_in, true, wrap));
+  g.stages.emplace_back(res_block(sh, "decoder.mid.block_2", block_in, block_in, true, wrap, wrap ? VT_GN_FRAME : VT_GN_CLIP));
   for (int i = L - 1; i >= 0; --i) {
     const int block_out = cf.ch * cf.ch_mult[i];
     const std::string u = "decoder.up." + std::to_string(i), ut = "decoder.up_temporal." + std::to_string(i);
@@ -998,7 +1053,7 @@ Graph build_decoder(const vt_model_config& cf, Shapes& sh) {
     }
   }
   g.conv_in = "decoder.conv_in" + cv; g.conv_out = "decoder.conv_out" + cv;
-  g.norm_out.key = "decoder.norm_out";
+  set_norm(g.norm_out, "decoder.norm_out", wrap ? VT_GN_FRAME : VT_GN_CLIP);
   g.c_last = block_in;
   sh_conv(sh, g.conv_in, g.c_first, cf.z_channels, {3, 3, 3});
   sh_conv(sh, g.conv_out, cf.out_ch, block_in, {3, 3, 3});
@@ -1019,7 +1074,7 @@ void run_graph(Ctx& c, Graph& g, const Tens& x_in, int cout_final, float* out_nc
     which ^= 1;
     c.cur = &m->arena[which];
     c.cur->reset();                // holds the input of the previous stage: no longer needed
-    const NormRef next = i + 1 < g.stages.size() ? g.stages[i + 1]->first_norm(c) : NormRef{&g.norm_out, true};
+    const NormRef next = i + 1 < g.stages.size() ? g.stages[i + 1]->first_norm(c) : g.norm_out.ref(true);
     h = g.stages[i]->run(c, h, next);
   }
   which ^= 1;
@@ -1195,8 +1250,14 @@ extern "C" int vt_create(const vt_model_config* cfg, int32_t compute_dtype, vt_m
     M_CHECK(cfg->num_resolutions >= 1 && cfg->num_resolutions <= 8 && cfg->num_res_blocks >= 1 && cfg->ch > 0, "vt_create: bad level / block counts");
     M_CHECK(cfg->n_spatial_ds <= 8 && cfg->n_tempo_ds <= 8 && cfg->n_spatial_us <= 8 && cfg->n_tempo_us <= 8 && cfg->n_levels <= 8, "vt_create: list too long");
     M_CHECK(cfg->time_downsample_factor == 2 || cfg->time_downsample_factor == 4 || cfg->time_downsample_factor == 8, "vt_create: time_downsample_factor must be 2, 4 or 8");
-    M_CHECK(cfg->regularizer == 0 || (cfg->regularizer == 1 && cfg->n_levels == cfg->z_channels && !cfg->double_z),
-            "vt_create: regularizer 0 (KL, double_z) or 1 (FSQ with len(levels) == z_channels; projections are not covered here)");
+    M_CHECK(cfg->norm_type == 0 || cfg->norm_type == 1, "vt_create: norm_type 0 (layernorm) or 1 (groupnorm)");
+    M_CHECK(cfg->regularizer == 0 || cfg->regularizer == 1, "vt_create: regularizer 0 (KL) or 1 (FSQ)");
+    if (cfg->regularizer == 1) {
+      const int ncb = cfg->fsq_num_codebooks > 1 ? cfg->fsq_num_codebooks : 1, eff = cfg->n_levels * ncb;
+      const int dim = cfg->fsq_dim > 0 ? cfg->fsq_dim : eff;
+      M_CHECK(cfg->n_levels >= 1 && !cfg->double_z && cfg->z_channels == dim && cfg->fsq_num_codebooks >= 0 && cfg->fsq_dim >= 0 && eff <= 1024 && dim <= 1024,
+              "vt_create: FSQ needs double_z = 0 and z_channels = dim (%d; len(levels) * num_codebooks = %d unless fsq_dim says otherwise)", dim, eff);
+    }
     for (int i = 0; i < cfg->n_tempo_ds; ++i) M_CHECK(in_list(cfg->spatial_ds, cfg->n_spatial_ds, cfg->tempo_ds[i]), "vt_create: a temporal down-sampler sits behind a spatial one (tempo_ds must be a subset of spatial_ds)");
     for (int i = 0; i < cfg->n_tempo_us; ++i) M_CHECK(in_list(cfg->spatial_us, cfg->n_spatial_us, cfg->tempo_us[i]), "vt_create: tempo_us must be a subset of spatial_us");
     auto* h = new vt_model();
@@ -1207,6 +1268,13 @@ extern "C" int vt_create(const vt_model_config* cfg, int32_t compute_dtype, vt_m
     h->dec = build_decoder(*cfg, h->shapes);
     h->enc.states(h->m.states);
     h->dec.states(h->m.states);
+    if (h->m.fsq_proj()) {         // nn.Linear(dim, effective_codebook_dim) / back (regularizers.py:137-139)
+      const int64_t eff = h->m.fsq_eff(), dim = cfg->fsq_dim;
+      h->shapes["regularization.project_in.weight"] = {eff, dim};
+      h->shapes["regularization.project_in.bias"] = {eff};
+      h->shapes["regularization.project_out.weight"] = {dim, eff};
+      h->shapes["regularization.project_out.bias"] = {dim};
+    }
     for (const auto& kv : h->shapes) h->names.push_back(kv.first);
     *out = h;
     return VT_OK;
@@ -1333,6 +1401,9 @@ extern "C" int vt_prepare(vt_model* h) {
     m.prepare = false;
     m.arena[0] = save[0];
     m.arena[1] = save[1];
+    if (m.fsq_proj())              // FSQ projections: uploaded with the rest
+      for (const char* k : {"regularization.project_in.weight", "regularization.project_in.bias", "regularization.project_out.weight", "regularization.project_out.bias"})
+        (void)m.f32(k, false);
     return VT_OK;
   } catch (const Fail& f) {
     return f.code;
@@ -1431,23 +1502,57 @@ extern "C" int vt_regularize_kl(vt_model* h, const float* moments, const float* 
   return vt_kl_sample(moments, noise, z, kl_out, B, h->m.cfg.z_channels, (int64_t)Tz * Hz * Wz, stream);
 }
 
+// FSQRegularizer.forward without the auxiliary loss (regularizers.py:206-230,247-268): [project_in ->] bound / round / pack per
+// codebook [-> project_out]; indices [B][T'][H'][W'] (num_codebooks c > 1: [B][T'][H'][W'][c])
 extern "C" int vt_regularize_fsq(vt_model* h, const float* pre, float* z, int32_t* indices, int32_t B, int32_t Tz, int32_t Hz, int32_t Wz,
                                  vt_stream stream) {
   if (!h || h->m.cfg.regularizer != 1) {
     vt_set_error("vt_regularize_fsq: the handle's regularizer is not FSQ");
     return VT_ERR_ARG;
   }
-  return vt_fsq_quantize(pre, z, indices, h->m.cfg.levels, h->m.cfg.n_levels, B, (int64_t)Tz * Hz * Wz, stream);
+  try {
+    Model& m = h->m;
+    const int64_t S = (int64_t)Tz * Hz * Wz;
+    const int ncb = m.fsq_ncb();
+    if (!m.fsq_proj()) return vt_fsq_quantize_cb(pre, z, indices, m.cfg.levels, m.cfg.n_levels, B, ncb, S, stream);
+    const int eff = m.fsq_eff(), dim = m.cfg.fsq_dim;
+    float* hp = m.reg_scratch((size_t)2 * B * eff * S);
+    float* codes = hp + (size_t)B * eff * S;
+    M_CALL(vt_channel_linear(pre, m.f32("regularization.project_in.weight", false), m.f32("regularization.project_in.bias", false), hp, B, dim, eff, S, stream));
+    M_CALL(vt_fsq_quantize_cb(hp, codes, indices, m.cfg.levels, m.cfg.n_levels, B, ncb, S, stream));
+    M_CALL(vt_channel_linear(codes, m.f32("regularization.project_out.weight", false), m.f32("regularization.project_out.bias", false), z, B, eff, dim, S, stream));
+    return VT_OK;
+  } catch (const Fail& f) {
+    return f.code;
+  } catch (const std::exception& e) {
+    vt_set_error("vt_regularize_fsq: %s", e.what());
+    return VT_ERR_ARG;
+  }
 }
 
 // FSQ: token indices -> latent codes (AutoencodingEngine.indices_to_latent / decode(..., decode_from_indices=True),
-// reference autoencoder.py:205-229): z then goes to vt_decode
+// reference autoencoder.py:205-229; FSQRegularizer.indices_to_codes with project_out, regularizers.py:180-198): z then goes to vt_decode
 extern "C" int vt_indices_to_latent(vt_model* h, const int32_t* indices, float* z, int32_t B, int32_t Tz, int32_t Hz, int32_t Wz, vt_stream stream) {
   if (!h || h->m.cfg.regularizer != 1) {
     vt_set_error("vt_indices_to_latent: the handle's regularizer is not FSQ");
     return VT_ERR_ARG;
   }
-  return vt_fsq_indices_to_codes(indices, z, h->m.cfg.levels, h->m.cfg.n_levels, B, (int64_t)Tz * Hz * Wz, stream);
+  try {
+    Model& m = h->m;
+    const int64_t S = (int64_t)Tz * Hz * Wz;
+    const int ncb = m.fsq_ncb();
+    if (!m.fsq_proj()) return vt_fsq_indices_to_codes_cb(indices, z, m.cfg.levels, m.cfg.n_levels, B, ncb, S, stream);
+    const int eff = m.fsq_eff(), dim = m.cfg.fsq_dim;
+    float* codes = m.reg_scratch((size_t)2 * B * eff * S);
+    M_CALL(vt_fsq_indices_to_codes_cb(indices, codes, m.cfg.levels, m.cfg.n_levels, B, ncb, S, stream));
+    M_CALL(vt_channel_linear(codes, m.f32("regularization.project_out.weight", false), m.f32("regularization.project_out.bias", false), z, B, eff, dim, S, stream));
+    return VT_OK;
+  } catch (const Fail& f) {
+    return f.code;
+  } catch (const std::exception& e) {
+    vt_set_error("vt_indices_to_latent: %s", e.what());
+    return VT_ERR_ARG;
+  }
 }
 
 // forget the chunk state of a tiled pass (vt_tile_encode / vt_tile_decode do it themselves at the start of a clip) and give the
@@ -1549,5 +1654,23 @@ extern "C" int vt_regularize_fsq_aux(vt_model* h, const float* pre, int32_t B, i
     vt_set_error("vt_regularize_fsq_aux: the handle's regularizer is not FSQ");
     return VT_ERR_ARG;
   }
-  return vt_fsq_aux_stats_avg(pre, h->m.cfg.levels, h->m.cfg.n_levels, B, (int64_t)Tz * Hz * Wz, inv_temperature, work, out3, nullptr, stream);
+  try {
+    Model& m = h->m;
+    const int64_t S = (int64_t)Tz * Hz * Wz;
+    // with the codebook axis kept the reference's own forward raises (its implicit codebook is one-dimensional, regularizers.py:143-146,234)
+    M_CHECK(m.fsq_ncb() == 1, "vt_regularize_fsq_aux: the reference cannot compute the FSQ auxiliary loss with num_codebooks > 1 either");
+    const float* hq = pre;
+    if (m.fsq_proj()) {            // the statistics are those of the PROJECTED latent (regularizers.py:225-246)
+      const int eff = m.fsq_eff();
+      float* hp = m.reg_scratch((size_t)2 * B * eff * S);
+      M_CALL(vt_channel_linear(pre, m.f32("regularization.project_in.weight", false), m.f32("regularization.project_in.bias", false), hp, B, m.cfg.fsq_dim, eff, S, stream));
+      hq = hp;
+    }
+    return vt_fsq_aux_stats_avg(hq, m.cfg.levels, m.cfg.n_levels, B, S, inv_temperature, work, out3, nullptr, stream);
+  } catch (const Fail& f) {
+    return f.code;
+  } catch (const std::exception& e) {
+    vt_set_error("vt_regularize_fsq_aux: %s", e.what());
+    return VT_ERR_ARG;
+  }
 }

@@ -23,7 +23,7 @@ enum VtOpt {
   OPT_WS_PROF_MODE,        // vt_conv_profile on conv_ws2.hip: bit 0 = row slots skipped, bit 1 = LDS-DMA requests skipped (wrong results)
   OPT_CONV_SCHED_X3,       // split-bf16 arithmetic on the 8-wave tile: 0 plain loop, two-group schedule 3 with the DMA pieces of a step issued 1 in the LOAD phase / 2 between the MFMAs of the COMPUTE phase / 3 half and half
   OPT_ATTN_FLASH,          // 1: vt_flash_attention_supported answers yes where the kernel applies (0: the hosts keep the GEMM -> softmax -> GEMM operators)
-  OPT_CONV_SPLITK,         // 1: 3-tap convolutions on few pixels run split over the tap planes when the caller gives scratch (opt-in: another summation order, and which launches split depends on the batch size)
+  OPT_CONV_SPLITK,         // 1: 3-tap convolutions on few pixels PER CLIP run split over the tap planes when the caller gives scratch (another summation order; decided from one clip's geometry, never from B)
   OPT_CONV_HALF256,        // K bound (0 = off): bf16 Cout % 256 == 0 launches with the LDS-transposed epilogue and K <= the bound run 128 x 256 half tiles, two workgroups per CU
   OPT_CONV_HALF_STAGGER,   // half tiles: start offset of the second workgroup slot of every CU, shader cycles per K step (+ 6 000); 0 = none
   OPT_CONV_HALF_PLAIN,     // half tiles also for launches without a fused LayerNorm (measured slower: A/B and tests only)

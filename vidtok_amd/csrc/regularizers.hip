@@ -63,9 +63,12 @@ __device__ __forceinline__ float fsq_round(float zv, float shift, float half_l, 
   return rintf(bounded);
 }
 
+// `ncb` codebooks (FSQRegularizer num_codebooks, "b n (c d) -> b n c d", regularizers.py:227): on the NCTHW latent the d channels
+// of codebook c of clip b are contiguous -- the kernels see B = clips x codebooks "clips" of D channels -- and the reference keeps
+// the codebook axis LAST on the indices: index of (clip b, codebook c, position s) sits at [b][s][c].
 __global__ __launch_bounds__(kBlock) void fsq_quantize_kernel(const float* __restrict__ h, float* __restrict__ z,
                                                               int* __restrict__ indices, FsqConsts k, int B,
-                                                              long long S) {
+                                                              long long S, int ncb) {
   const long long n = (long long)B * S;
   for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < n; i += (long long)gridDim.x * kBlock) {
     const long long b = i / S, s = i - b * S;
@@ -78,17 +81,17 @@ __global__ __launch_bounds__(kBlock) void fsq_quantize_kernel(const float* __res
       // integer arithmetic gives the reference's value without depending on FMA contraction.
       idx += ((int)q + k.levels[d] / 2) * k.basis[d];
     }
-    indices[i] = idx;
+    indices[ncb == 1 ? i : ((b / ncb) * S + s) * ncb + (b % ncb)] = idx;
   }
 }
 
 __global__ __launch_bounds__(kBlock) void fsq_indices_to_codes_kernel(const int* __restrict__ indices,
                                                                       float* __restrict__ z, FsqConsts k, int B,
-                                                                      long long S) {
+                                                                      long long S, int ncb) {
   const long long n = (long long)B * S;
   for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < n; i += (long long)gridDim.x * kBlock) {
     const long long b = i / S, s = i - b * S;
-    const int idx = indices[i];
+    const int idx = indices[ncb == 1 ? i : ((b / ncb) * S + s) * ncb + (b % ncb)];
     for (int d = 0; d < k.D; ++d) {
       const int lv = (idx / k.basis[d]) % k.levels[d];                  // regularizers.py:186
       z[(b * k.D + d) * S + s] = ((float)lv - k.half_w[d]) / k.half_w[d];  // _scale_and_shift_inverse :170-172
@@ -335,17 +338,22 @@ extern "C" int vt_kl_sample(const float* h, const float* noise, float* z, float*
   return VT_OK;
 }
 
-extern "C" int vt_fsq_quantize(const float* h, float* z, int32_t* indices, const int32_t* levels_host, int32_t D,
-                               int32_t B, int64_t S, vt_stream stream_) {
+extern "C" int vt_fsq_quantize_cb(const float* h, float* z, int32_t* indices, const int32_t* levels_host, int32_t D,
+                                  int32_t B, int32_t ncb, int64_t S, vt_stream stream_) {
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
-  VT_CHECK_ARG(h && z && indices && B > 0 && S > 0, "vt_fsq_quantize: bad arguments");
+  VT_CHECK_ARG(h && z && indices && B > 0 && S > 0 && ncb >= 1, "vt_fsq_quantize: bad arguments");
   FsqConsts k;
   int rc = make_consts(levels_host, D, &k);
   if (rc != VT_OK) return rc;
-  hipLaunchKernelGGL(fsq_quantize_kernel, dim3(grid_for((long long)B * S)), dim3(kBlock), 0, stream, h, z, indices, k,
-                     B, (long long)S);
+  hipLaunchKernelGGL(fsq_quantize_kernel, dim3(grid_for((long long)B * ncb * S)), dim3(kBlock), 0, stream, h, z, indices, k,
+                     B * ncb, (long long)S, ncb);
   VT_CHECK_LAUNCH();
   return VT_OK;
+}
+
+extern "C" int vt_fsq_quantize(const float* h, float* z, int32_t* indices, const int32_t* levels_host, int32_t D,
+                               int32_t B, int64_t S, vt_stream stream_) {
+  return vt_fsq_quantize_cb(h, z, indices, levels_host, D, B, 1, S, stream_);
 }
 
 // y[b][o][s] = bias[o] + sum_i w[o][i] * x[b][i][s]  on NCTHW-flattened [B][C][S] fp32 tensors: nn.Linear along the
@@ -378,17 +386,22 @@ extern "C" int vt_channel_linear(const float* x, const float* w, const float* bi
   return VT_OK;
 }
 
-extern "C" int vt_fsq_indices_to_codes(const int32_t* indices, float* z, const int32_t* levels_host, int32_t D,
-                                       int32_t B, int64_t S, vt_stream stream_) {
+extern "C" int vt_fsq_indices_to_codes_cb(const int32_t* indices, float* z, const int32_t* levels_host, int32_t D,
+                                          int32_t B, int32_t ncb, int64_t S, vt_stream stream_) {
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
-  VT_CHECK_ARG(indices && z && B > 0 && S > 0, "vt_fsq_indices_to_codes: bad arguments");
+  VT_CHECK_ARG(indices && z && B > 0 && S > 0 && ncb >= 1, "vt_fsq_indices_to_codes: bad arguments");
   FsqConsts k;
   int rc = make_consts(levels_host, D, &k);
   if (rc != VT_OK) return rc;
-  hipLaunchKernelGGL(fsq_indices_to_codes_kernel, dim3(grid_for((long long)B * S)), dim3(kBlock), 0, stream, indices,
-                     z, k, B, (long long)S);
+  hipLaunchKernelGGL(fsq_indices_to_codes_kernel, dim3(grid_for((long long)B * ncb * S)), dim3(kBlock), 0, stream, indices,
+                     z, k, B * ncb, (long long)S, ncb);
   VT_CHECK_LAUNCH();
   return VT_OK;
+}
+
+extern "C" int vt_fsq_indices_to_codes(const int32_t* indices, float* z, const int32_t* levels_host, int32_t D,
+                                       int32_t B, int64_t S, vt_stream stream_) {
+  return vt_fsq_indices_to_codes_cb(indices, z, levels_host, D, B, 1, S, stream_);
 }
 
 extern "C" int64_t vt_fsq_aux_work_floats(const int32_t* levels_host, int32_t D, int32_t B, int64_t S) {

@@ -76,7 +76,7 @@ class ModelConfig(C.Structure):
         + [("n_spatial_ds", C.c_int32), ("spatial_ds", C.c_int32 * 8), ("n_tempo_ds", C.c_int32), ("tempo_ds", C.c_int32 * 8)]
         + [("n_spatial_us", C.c_int32), ("spatial_us", C.c_int32 * 8), ("n_tempo_us", C.c_int32), ("tempo_us", C.c_int32 * 8)]
         + [("time_downsample_factor", C.c_int32), ("regularizer", C.c_int32), ("n_levels", C.c_int32), ("levels", C.c_int32 * 8),
-           ("interpolation_mode", C.c_int32)]
+           ("interpolation_mode", C.c_int32), ("norm_type", C.c_int32), ("fsq_num_codebooks", C.c_int32), ("fsq_dim", C.c_int32)]
     )
 
 
@@ -139,6 +139,8 @@ SIGNATURES = {
     "vt_kl_sample": (C.c_int, [_P, _P, _P, _P, _I32, _I32, _I64, _P]),
     "vt_fsq_quantize": (C.c_int, [_P, _P, _P, C.POINTER(_I32), _I32, _I32, _I64, _P]),
     "vt_fsq_indices_to_codes": (C.c_int, [_P, _P, C.POINTER(_I32), _I32, _I32, _I64, _P]),
+    "vt_fsq_quantize_cb": (C.c_int, [_P, _P, _P, C.POINTER(_I32), _I32, _I32, _I32, _I64, _P]),
+    "vt_fsq_indices_to_codes_cb": (C.c_int, [_P, _P, C.POINTER(_I32), _I32, _I32, _I32, _I64, _P]),
     "vt_fsq_aux_work_floats": (_I64, [C.POINTER(_I32), _I32, _I32, _I64]),
     "vt_fsq_aux_stats": (C.c_int, [_P, C.POINTER(_I32), _I32, _I32, _I64, _F, _P, _P, _P]),
     "vt_fsq_aux_stats_avg": (C.c_int, [_P, C.POINTER(_I32), _I32, _I32, _I64, _F, _P, _P, _P, _P]),

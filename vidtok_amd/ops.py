@@ -546,30 +546,36 @@ def kl_sample(h, noise):
     return z, kl
 
 
-def fsq_quantize(h, levels):
+def fsq_quantize(h, levels, num_codebooks: int = 1):
+    """h [B, c*D, ...] fp32 (c = num_codebooks groups of D = len(levels) channels) -> (codes [B, c*D, ...], indices int32
+    [B, ...] or, for c > 1, [B, ..., c]: the codebook axis last, as the reference keeps it)"""
     lib = L.load()
     _chk(h, "fsq.h")
     assert h.dtype == torch.float32
-    B, D = h.shape[:2]
-    assert D == len(levels)
+    B, D, c = h.shape[0], len(levels), int(num_codebooks)
+    assert h.shape[1] == c * D
     S = h[0, 0].numel()
     z = torch.empty_like(h)
-    idx = torch.empty((B,) + tuple(h.shape[2:]), dtype=torch.int32, device=h.device)
-    L.check(lib.vt_fsq_quantize(_ptr(h), _ptr(z), _ptr(idx), _levels_arr(levels), D, B, S, _stream()),
-            "vt_fsq_quantize")
+    idx = torch.empty((B,) + tuple(h.shape[2:]) + ((c,) if c > 1 else ()), dtype=torch.int32, device=h.device)
+    L.check(lib.vt_fsq_quantize_cb(_ptr(h), _ptr(z), _ptr(idx), _levels_arr(levels), D, B, c, S, _stream()),
+            "vt_fsq_quantize_cb")
     return z, idx
 
 
-def fsq_indices_to_codes(idx, levels):
+def fsq_indices_to_codes(idx, levels, num_codebooks: int = 1):
+    """indices int32 [B, ...] (c > 1: [B, ..., c]) -> codes [B, c*D, ...]"""
     lib = L.load()
     _chk(idx, "fsq.indices")
     assert idx.dtype == torch.int32
-    B = idx.shape[0]
-    D = len(levels)
-    S = idx[0].numel()
-    z = torch.empty((B, D) + tuple(idx.shape[1:]), dtype=torch.float32, device=idx.device)
-    L.check(lib.vt_fsq_indices_to_codes(_ptr(idx), _ptr(z), _levels_arr(levels), D, B, S, _stream()),
-            "vt_fsq_indices_to_codes")
+    B, D, c = idx.shape[0], len(levels), int(num_codebooks)
+    sp = tuple(idx.shape[1:-1]) if c > 1 else tuple(idx.shape[1:])
+    assert c == 1 or idx.shape[-1] == c
+    S = 1
+    for v in sp:
+        S *= int(v)
+    z = torch.empty((B, c * D) + sp, dtype=torch.float32, device=idx.device)
+    L.check(lib.vt_fsq_indices_to_codes_cb(_ptr(idx), _ptr(z), _levels_arr(levels), D, B, c, S, _stream()),
+            "vt_fsq_indices_to_codes_cb")
     return z
 
 

@@ -140,17 +140,12 @@ class FSQRegularizer(nn.Module):
         """indices int32 [B, ...] (with keep_num_codebooks_dim: [B, ..., c]) -> codes [B, D, ...]
         (regularizers.py:180-198, image/video form)."""
         assert indices.dim() >= 3 + int(self.keep_num_codebooks_dim), "expects [B, T, H, W] (or [B, H, W]) index maps"
-        idx = indices.to(torch.int32)
-        if self.keep_num_codebooks_dim:
-            # codebook k of clip b is row b*c + k of a [B*c, ...] batch: its d code channels land at [k*d, (k+1)*d)
-            c = self.num_codebooks
-            assert idx.shape[-1] == c
-            sp = tuple(idx.shape[1:-1])
-            idx = idx.movedim(-1, 1).reshape((idx.shape[0] * c,) + sp)
-            codes = ops.fsq_indices_to_codes(idx.contiguous(), self.levels)
-            codes = codes.reshape((indices.shape[0], c * self.codebook_dim) + sp)
-        else:
-            codes = ops.fsq_indices_to_codes(idx.contiguous(), self.levels)
+        idx = indices if indices.dtype == torch.int32 else indices.to(torch.int32)
+        c = self.num_codebooks
+        if self.keep_num_codebooks_dim and c == 1:
+            idx = idx.reshape(idx.shape[:-1])          # a kept axis of one codebook: [B, ..., 1] is [B, ...] in memory
+        assert c == 1 or idx.shape[-1] == c
+        codes = ops.fsq_indices_to_codes(idx.contiguous(), self.levels, c)
         if project_out and self.has_projections:
             codes = self._linear(self.project_out, codes)
         return codes
@@ -181,15 +176,12 @@ class FSQRegularizer(nn.Module):
         h = z.float().contiguous()
         if self.has_projections:
             h = self._linear(self.project_in, h)
-        c, d = self.num_codebooks, self.codebook_dim
-        B, sp = h.shape[0], tuple(h.shape[2:])
-        # "b n (c d) -> b n c d" (regularizers.py:227): in NCTHW the d channels of codebook k of clip b are contiguous,
-        # i.e. clip b*c + k of a [B*c, d, ...] batch -- a view, the kernels see c times as many clips
-        hv = h.reshape((B * c, d) + sp)
-        codes, indices = ops.fsq_quantize(hv, self.levels)
-        codes = codes.reshape((B, c * d) + sp)
-        if self.keep_num_codebooks_dim:
-            indices = indices.reshape((B, c) + sp).movedim(1, -1).contiguous()        # [B, ..., c]
+        c = self.num_codebooks
+        # "b n (c d) -> b n c d" (regularizers.py:227): in NCTHW the d channels of codebook k of a clip are contiguous; the kernel
+        # quantises each codebook on its own and writes the indices with the codebook axis last ([B, ..., c]) for c > 1
+        codes, indices = ops.fsq_quantize(h, self.levels, c)
+        if self.keep_num_codebooks_dim and c == 1:
+            indices = indices.unsqueeze(-1)
         want_aux = self.compute_aux_loss and (self.entropy_loss_weight > 0 or self.commitment_loss_weight > 0)
         if want_aux and not self.keep_num_codebooks_dim:
             st, codebook_entropy = self._aux_stats(h, inv_temperature)
