@@ -73,6 +73,9 @@ typedef enum vt_layout { VT_NDHWC = 0, VT_NCTHW = 1 } vt_layout;
 const char* vt_last_error(void);
 /* returns a version integer; also a cheap "is the library loadable" probe */
 int vt_version(void);
+/* hipGraphLaunch of an instantiated graph (hipGraphExec_t) on `stream`, nothing else: how the Python host replays the encoder /
+ * decoder launch sequences it captured (vidtok_amd/graphs.py) -- a framework's own replay also launches bookkeeping kernels */
+int vt_graph_launch(void* graph_exec, vt_stream stream);
 /* number of bytes of dynamic LDS the biggest conv variant asks for (diagnostic) */
 int vt_conv_max_lds_bytes(void);
 
@@ -353,6 +356,17 @@ int vt_time_lerp2x_cat(const void* head, int32_t nh, const void* x, void* y, int
                        int64_t HWC, vt_stream stream);
 
 /* ------------------------------------------------------------------------------------------
+ * vt_pack_conv_weight -- a convolution parameter in the reference's layout, w fp32 [Cout][Cin][taps_in] (nn.Conv3d / Conv2d /
+ * Conv1d weight, taps = kT*kH*kW row-major), to the rows vt_conv reads: out [Cout][ldw], k = tap * cin_p + c,
+ * channels zero-padded to cin_p (the activation's stored count), the row tail zero.  out_dtype VT_F32 / VT_BF16 = plain rows
+ * (round to nearest even); VT_BF16X3 = the split-bf16 container: per 16 k [hi 16 x bf16 | lo 16 x bf16], hi = bf16(w),
+ * lo = bf16(w - hi), 4 bytes per k, ldw a multiple of 32.  mix_host (host, [taps_out][4], -1 = absent; NULL = identity): output
+ * tap j = (w[m0] + w[m1]) + (w[m2] + w[m3]) in fp32 -- the pre-summed taps of the up-samplers' parity classes (a 3-tap window
+ * over a nearest-x2 repeated input touches two inputs: [W0 + W1, W2] / [W0, W1 + W2] per axis).  One-time work per weight. */
+int vt_pack_conv_weight(const float* w, void* out, int32_t out_dtype, int32_t Cout, int32_t Cin, int32_t cin_p, int32_t taps_in,
+                        int32_t taps_out, const int32_t* mix_host, int64_t ldw, vt_stream stream);
+
+/* ------------------------------------------------------------------------------------------
  * regularizers; all tensors NCTHW fp32 as in the reference API
  * vt_kl_sample: h [B][2*zc][S] (S = T*H*W); mean,logvar = chunk(h,2,dim=1); logvar clamped to
  *   [-30,20]; z = mean + exp(0.5*logvar)*noise (noise [B][zc][S] or NULL -> mode());
@@ -391,6 +405,11 @@ int vt_fsq_aux_stats(const float* h, const int32_t* levels_host, int32_t D, int3
                      float inv_temperature, float* work, float* out3, vt_stream stream);
 int vt_fsq_aux_stats_avg(const float* h, const int32_t* levels_host, int32_t D, int32_t B, int64_t S,
                          float inv_temperature, float* work, float* out3, float* avg_out, vt_stream stream);
+/* out[0] = (stats3[0] - diversity_gamma * ce) * entropy_weight + stats3[2] * commitment_weight, ce = codebook_entropy[0] or
+ * (NULL) stats3[1]: the auxiliary loss FSQRegularizer.forward returns (regularizers.py:241,264-266), every product / sum
+ * rounded on its own like the reference's separate tensor operations */
+int vt_fsq_aux_loss(const float* stats3, const float* codebook_entropy, float diversity_gamma, float entropy_weight,
+                    float commitment_weight, float* out, vt_stream stream);
 int vt_entropy(const float* avg, int64_t J, float* out, vt_stream stream);
 
 /* ------------------------------------------------------------------------------------------

@@ -968,3 +968,39 @@ def test_conv_split_k_does_not_depend_on_the_batch(vt_opts):
         assert lib.vt_conv_work_bytes(C.byref(rec[0][0])) == 3 * x.shape[0] * 5120 * 512 * 4
     torch.cuda.synchronize()
     assert torch.equal(ys["batch"][2:3], ys["alone"])
+
+
+@pytest.mark.parametrize("mode", ["f32", "bf16", "x3"])
+def test_pack_conv_weight_on_device_equals_host_statements(mode):
+    """vt_pack_conv_weight (the device packer PackedCache uses for GPU parameters: no ATen kernel in the process) against the torch
+    statements of vidtok_amd/packing.py -- plain rows for 1-, 2- and 3-D kernels with channel padding, the pre-summed taps of the
+    up-samplers' parity classes (time: early / late; space: the four (py, px)), the split-bf16 container: SAME BITS."""
+    import functools
+
+    from vidtok_amd import packing as P
+
+    dtype = torch.bfloat16 if mode == "bf16" else torch.float32
+    g = torch.Generator().manual_seed(11)
+    cases = [((16, 3, 3, 3, 3), 8, None, None), ((24, 20, 3), 24, None, None), ((8, 12, 3, 3), 16, None, None), ((40, 8, 1, 1, 1), 8, None, None)]
+    for early in (True, False):
+        cases.append(((16, 8, 3, 3, 3), 8, functools.partial(P.time_upsample_parity_weights, early=early), functools.partial(P.time_upsample_parity_mix, early=early)))
+    for py in (0, 1):
+        for px in (0, 1):
+            cases.append(((16, 24, 3, 3), 24, functools.partial(P.space_upsample_parity_weights, py=py, px=px),
+                          functools.partial(P.space_upsample_parity_mix, py=py, px=px)))
+    for shape, cin_p, xf, mixf in cases:
+        w = torch.randn(shape, generator=g)
+        ref = P.pack_conv_weight(w if xf is None else xf(w), dtype, cin_p)
+        if mode == "x3":
+            ref = P.pack_split3(ref)
+        got = ops.pack_conv_weight(w.to(DEV), dtype, cin_p, mix=None if mixf is None else mixf(tuple(shape[2:])), split3=mode == "x3")
+        torch.cuda.synchronize()
+        assert got.dtype == ref.dtype and got.shape == ref.shape, (shape, got.shape, ref.shape)
+        assert torch.equal(got.cpu().view(torch.int16 if mode == "bf16" else torch.int32), ref.view(torch.int16 if mode == "bf16" else torch.int32)), shape
+    # a PackedCache answers GPU parameters through the device packer and host parameters through the torch statements: same bits
+    conv = torch.nn.Conv3d(8, 16, 3)
+    pc_host, pc_dev = P.PackedCache(), P.PackedCache()
+    wh, bh = pc_host.get(conv.weight, conv.bias, dtype, cin_stored=8)
+    conv = conv.to(DEV)
+    wd, bd = pc_dev.get(conv.weight, conv.bias, dtype, cin_stored=8)
+    assert wd.is_cuda and torch.equal(wd.cpu().view(torch.int16 if mode == "bf16" else torch.int32), wh.view(torch.int16 if mode == "bf16" else torch.int32)) and torch.equal(bd.cpu(), bh)

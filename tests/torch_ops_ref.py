@@ -288,6 +288,11 @@ def entropy(avg):
     return (-avg * avg.clamp(min=1e-5).log()).sum()
 
 
+def fsq_aux_loss(stats3, codebook_entropy, diversity_gamma, entropy_weight, commitment_weight):
+    ce = stats3[1] if codebook_entropy is None else codebook_entropy.reshape(())
+    return (stats3[0] - diversity_gamma * ce) * entropy_weight + stats3[2] * commitment_weight
+
+
 def fsq_aux_stats(h, levels, inv_temperature=100.0, return_avg=False):
     lv, _, _, _, half_w, basis = (t.to(h.device) for t in _fsq_consts(levels))
     codes, _ = fsq_quantize(h, levels)
@@ -361,7 +366,7 @@ def ncthw_copy_frames(src, dst, ts0, td0, n, clamp=False):
 
 
 ALL = ["conv", "gemm_nt", "layernorm_act", "softmax_rows", "ncthw_to_ndhwc", "ndhwc_to_ncthw", "time_avgpool3s2",
-       "time_lerp2x", "time_lerp2x_cat", "gather_frames", "kl_sample", "fsq_quantize", "fsq_indices_to_codes", "fsq_aux_stats", "entropy", "tanh_", "temporal_block", "temporal_block_supported", "frames_u8_to_ncthw", "ncthw_to_frames_u8", "ncthw_copy_frames",
+       "time_lerp2x", "time_lerp2x_cat", "gather_frames", "kl_sample", "fsq_quantize", "fsq_indices_to_codes", "fsq_aux_stats", "fsq_aux_loss", "entropy", "tanh_", "temporal_block", "temporal_block_supported", "frames_u8_to_ncthw", "ncthw_to_frames_u8", "ncthw_copy_frames",
        "eval_psnr_ssim", "channel_linear", "groupnorm_act"]
 
 

@@ -13,7 +13,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libvidtok_amd.so")
-SOURCES = ["conv_igemm.hip", "conv_ws128.hip", "conv_ws2.hip", "conv_narrow.hip", "tblock_ws128.hip", "attention.hip", "pointwise.hip", "groupnorm.hip", "regularizers.hip", "metrics.hip", "video_io.hip", "error.cpp", "options.cpp", "model.cpp"]
+SOURCES = ["conv_igemm.hip", "conv_ws128.hip", "conv_ws2.hip", "conv_narrow.hip", "tblock_ws128.hip", "attention.hip", "pointwise.hip", "groupnorm.hip", "regularizers.hip", "metrics.hip", "video_io.hip", "packing.hip", "error.cpp", "options.cpp", "model.cpp"]
 HEADERS = ["common.h", "conv_common.h", "options.h", os.path.join("..", "..", "include", "vidtok_amd.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 # per-file additions.  conv_ws2.hip: its row arithmetic runs beside the partner wave's MFMAs, where packed fp32

@@ -415,6 +415,29 @@ extern "C" int vt_fsq_aux_stats(const float* h, const int32_t* levels_host, int3
   return vt_fsq_aux_stats_avg(h, levels_host, D, B, S, inv_temperature, work, out3, nullptr, stream_);
 }
 
+// aux = (st[0] - gamma * codebook_entropy) * w_entropy + st[2] * w_commit: the last lines of FSQRegularizer.forward
+// (regularizers.py:241,264-266) on the three statistics of vt_fsq_aux_stats; codebook_entropy = st[1] unless the caller
+// passes the entropy of a cross-rank averaged distribution.  Each product / sum rounded on its own, as the host statement's
+// separate tensor operations are.
+__global__ void fsq_aux_loss_kernel(const float* __restrict__ st, const float* __restrict__ cb, float gamma, float w_ent,
+                                    float w_commit, float* __restrict__ out) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    const float ce = cb ? cb[0] : st[1];
+    const float ent = __fsub_rn(st[0], __fmul_rn(gamma, ce));
+    out[0] = __fadd_rn(__fmul_rn(ent, w_ent), __fmul_rn(st[2], w_commit));
+  }
+}
+
+extern "C" int vt_fsq_aux_loss(const float* stats3, const float* codebook_entropy, float diversity_gamma, float entropy_weight,
+                               float commitment_weight, float* out, vt_stream stream_) {
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  VT_CHECK_ARG(stats3 && out, "vt_fsq_aux_loss: null argument");
+  hipLaunchKernelGGL(fsq_aux_loss_kernel, dim3(1), dim3(64), 0, stream, stats3, codebook_entropy, diversity_gamma, entropy_weight,
+                     commitment_weight, out);
+  VT_CHECK_LAUNCH();
+  return VT_OK;
+}
+
 extern "C" int vt_entropy(const float* avg, int64_t J, float* out, vt_stream stream_) {
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
   VT_CHECK_ARG(avg && out && J > 0, "vt_entropy: bad arguments");

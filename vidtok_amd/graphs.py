@@ -86,7 +86,18 @@ class GraphedCall:
         return ops.ncthw_copy_frames(x, dst, frames[0], 0, frames[1] - frames[0])
 
     def _replay(self, g):
-        g.replay()
+        """hipGraphLaunch through the C-ABI (vt_graph_launch).  torch's CUDAGraph.replay() first refreshes the seed / offset of
+        every registered device generator -- two fill kernels per replay -- which the captured sequences never read (no random
+        numbers are drawn on the device: the KL noise is the reference's host stream)."""
+        ex = getattr(g, "_vt_exec", None)
+        if ex is None:
+            g.replay()
+            return
+        import ctypes as C
+
+        from . import lib as L
+
+        L.check(L.load().vt_graph_launch(C.c_void_p(ex), C.c_void_p(torch.cuda.current_stream().cuda_stream)), "vt_graph_launch")
 
     def _result(self, sy, borrow):
         return sy if borrow else sy.clone()
@@ -125,6 +136,10 @@ class GraphedCall:
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, pool=self._pool):
                 sy = self.fn(sx)
+            try:                            # the instantiated graph's handle, for vt_graph_launch (older torch: replay() of the wrapper)
+                g._vt_exec = int(g.raw_cuda_graph_exec()) or None
+            except (AttributeError, RuntimeError):
+                g._vt_exec = None
             self.entries[key] = e = (g, sx, sy, self.state_get() if stateful and self.state_get else None)
         self._touch(key)
         g, sx, sy, state = e

@@ -85,6 +85,7 @@ _P, _I32, _I64, _F = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 SIGNATURES = {
     "vt_last_error": (C.c_char_p, []),
     "vt_version": (C.c_int, []),
+    "vt_graph_launch": (C.c_int, [_P, _P]),
     "vt_conv_max_lds_bytes": (C.c_int, []),
     "vt_set_option": (C.c_int, [C.c_char_p, _I32]),
     "vt_get_option": (C.c_int, [C.c_char_p, C.POINTER(_I32)]),
@@ -135,6 +136,7 @@ SIGNATURES = {
     "vt_time_avgpool3s2": (C.c_int, [_P, _P, _P, C.c_int, _I32, _I32, _I64, _I32, _I32, _P]),
     "vt_time_lerp2x": (C.c_int, [_P, _P, C.c_int, _I32, _I32, _I64, _P]),
     "vt_time_lerp2x_cat": (C.c_int, [_P, _I32, _P, _P, C.c_int, _I32, _I32, _I32, _I64, _P]),
+    "vt_pack_conv_weight": (C.c_int, [_P, _P, _I32, _I32, _I32, _I32, _I32, _I32, C.POINTER(_I32), _I64, _P]),
     "vt_fsq_consts": (C.c_int, [C.POINTER(_I32), _I32, C.POINTER(_F)]),
     "vt_kl_sample": (C.c_int, [_P, _P, _P, _P, _I32, _I32, _I64, _P]),
     "vt_fsq_quantize": (C.c_int, [_P, _P, _P, C.POINTER(_I32), _I32, _I32, _I64, _P]),
@@ -145,6 +147,7 @@ SIGNATURES = {
     "vt_fsq_aux_stats": (C.c_int, [_P, C.POINTER(_I32), _I32, _I32, _I64, _F, _P, _P, _P]),
     "vt_fsq_aux_stats_avg": (C.c_int, [_P, C.POINTER(_I32), _I32, _I32, _I64, _F, _P, _P, _P, _P]),
     "vt_entropy": (C.c_int, [_P, _I64, _P, _P]),
+    "vt_fsq_aux_loss": (C.c_int, [_P, _P, _F, _F, _F, _P, _P]),
     "vt_groupnorm_work_bytes": (_I64, [_I32, _I32, _I32, _I32]),
     "vt_groupnorm_act": (C.c_int, [_P, C.c_int, _I64, _P, C.c_int, _I64, _P, _P, _I32, _I32, _I64, _I32, _I32, _I32,
                                    C.c_float, _I32, _P, _P]),

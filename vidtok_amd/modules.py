@@ -23,7 +23,8 @@ import torch.nn as nn
 from . import lib as L
 from . import ops
 from .ops import ConvGeom
-from .packing import PackedCache, space_upsample_parity_weights, time_upsample_parity_weights
+from .packing import (PackedCache, space_upsample_parity_mix, space_upsample_parity_weights, time_upsample_parity_mix,
+                      time_upsample_parity_weights)
 
 
 def _check_norm(norm_type):
@@ -274,7 +275,8 @@ class Upsample(nn.Module):
         # up(x)[Y][X] = x[Y>>1][X>>1]: an output pixel of parity (py, px) sees a 2x2 window of x, so the 3x3 conv over
         # the up-sampled frame is four 2x2 convs over x with pre-summed taps (4/9 of the MACs), each writing its
         # parity class of the output: rows (a-1, a) for py = 0, (a, a+1) for py = 1, likewise for columns
-        self._parity = [(py, px, PackedCache(functools.partial(space_upsample_parity_weights, py=py, px=px)),
+        self._parity = [(py, px, PackedCache(functools.partial(space_upsample_parity_weights, py=py, px=px),
+                                             mix=functools.partial(space_upsample_parity_mix, py=py, px=px)),
                          ConvGeom(kh=2, kw=2, ph=1 - py, pw=1 - px, ph_hi=py, pw_hi=px))
                         for py in (0, 1) for px in (0, 1)]
 
@@ -369,8 +371,8 @@ class TimeUpsampleResCausal2x(nn.Module):
         self.version = version
         self.is_first_chunk = True
         self.causal_cache = None
-        self._parity_packs = (PackedCache(functools.partial(time_upsample_parity_weights, early=True)),
-                              PackedCache(functools.partial(time_upsample_parity_weights, early=False)))
+        self._parity_packs = (PackedCache(functools.partial(time_upsample_parity_weights, early=True), mix=functools.partial(time_upsample_parity_mix, early=True)),
+                              PackedCache(functools.partial(time_upsample_parity_weights, early=False), mix=functools.partial(time_upsample_parity_mix, early=False)))
 
     def _interp_v11(self, x):
         n, T = self.num_temp_upsample, x.shape[1]

@@ -20,7 +20,7 @@ from . import ops
 from .modules import (SITE_CLIP, SITE_PIXEL, Downsample, Normalize, ResnetBlock, Upsample, _check_norm, _emit,
                       _level_module, _wrap, first_norm_of, plain, run_stages)
 from .ops import ConvGeom
-from .packing import PackedCache, time_upsample_parity_weights
+from .packing import PackedCache, time_upsample_parity_mix, time_upsample_parity_weights
 
 
 class _Conv3dSym:
@@ -70,9 +70,9 @@ class TimeUpsampleRes2x(nn.Module):
         self.conv = nn.Conv3d(in_channels, out_channels, 3, padding=1)
         self.mix_factor = nn.Parameter(torch.Tensor([mix_factor]))
         # centred window over up(x)[t] = x[t >> 1]:  o[2j] = W0 x[j-1] + (W1+W2) x[j],  o[2j+1] = (W0+W1) x[j] + W2 x[j+1]
-        self._parity = ((PackedCache(functools.partial(time_upsample_parity_weights, early=False)),
+        self._parity = ((PackedCache(functools.partial(time_upsample_parity_weights, early=False), mix=functools.partial(time_upsample_parity_mix, early=False)),
                          ConvGeom(kt=2, kh=3, kw=3, pt=1, pt_hi=0, ph=1, pw=1, ph_hi=1, pw_hi=1)),
-                        (PackedCache(functools.partial(time_upsample_parity_weights, early=True)),
+                        (PackedCache(functools.partial(time_upsample_parity_weights, early=True), mix=functools.partial(time_upsample_parity_mix, early=True)),
                          ConvGeom(kt=2, kh=3, kw=3, pt=0, pt_hi=1, ph=1, pw=1, ph_hi=1, pw_hi=1)))
 
     def run(self, x, dt, next_norm=None):

@@ -525,6 +525,35 @@ def gather_frames(src, idx, out=None, out_t0=0):
     return out
 
 
+def pack_conv_weight(weight, dtype, cin_stored=None, mix=None, split3=False):
+    """vt_pack_conv_weight: weight fp32 [Cout, Cin, *k] on the GPU (a reference parameter) -> packed rows [Cout, ldw] for
+    vt_conv: k = tap * cin_stored + c, in `dtype` (float32 / bfloat16) or, with split3, the int32-typed split-bf16 container.
+    mix = [[m0, m1, m2, m3], ...] per OUTPUT tap (-1 = absent): pre-summed taps of an up-sampler's parity class."""
+    lib = L.load()
+    _chk(weight, "pack.weight")
+    assert weight.dtype == torch.float32 and weight.dim() >= 3
+    cout, cin = weight.shape[:2]
+    taps_in = weight[0, 0].numel()
+    taps_out = taps_in if mix is None else len(mix)
+    cin_p = cin_stored or pad_channels(cin)
+    K = taps_out * cin_p
+    if split3:
+        assert dtype == torch.float32
+        ldw = (K + 31) // 32 * 32
+        out = torch.empty((cout, ldw), dtype=torch.int32, device=weight.device)
+        mode = L.VT_BF16X3
+    else:
+        ldw = K
+        out = torch.empty((cout, ldw), dtype=dtype, device=weight.device)
+        mode = _DT[dtype]
+    arr = None
+    if mix is not None:
+        flat = [int(v) for row in mix for v in (list(row) + [-1, -1, -1, -1])[:4]]
+        arr = (C.c_int32 * len(flat))(*flat)
+    L.check(lib.vt_pack_conv_weight(_ptr(weight), _ptr(out), mode, cout, cin, cin_p, taps_in, taps_out, arr, ldw, _stream()), "vt_pack_conv_weight")
+    return out
+
+
 def _levels_arr(levels):
     return (C.c_int32 * len(levels))(*[int(v) for v in levels])
 
@@ -621,6 +650,22 @@ def entropy(avg):
     assert avg.dtype == torch.float32
     out = torch.empty((1,), dtype=torch.float32, device=avg.device)
     L.check(lib.vt_entropy(_ptr(avg), avg.numel(), _ptr(out), _stream()), "vt_entropy")
+    return out[0]
+
+
+def fsq_aux_loss(stats3, codebook_entropy, diversity_gamma: float, entropy_weight: float, commitment_weight: float):
+    """(stats3[0] - gamma * ce) * entropy_weight + stats3[2] * commitment_weight as a fresh 0-dim fp32 tensor (vt_fsq_aux_loss);
+    ce = `codebook_entropy` (0-dim / [1] device tensor) or, None, stats3[1]"""
+    lib = L.load()
+    _chk(stats3, "fsq.stats")
+    assert stats3.dtype == torch.float32 and stats3.numel() >= 3
+    out = torch.empty((1,), dtype=torch.float32, device=stats3.device)
+    ce = None
+    if codebook_entropy is not None:
+        ce = codebook_entropy.reshape(1)
+        assert ce.dtype == torch.float32 and ce.is_cuda
+    L.check(lib.vt_fsq_aux_loss(_ptr(stats3), _ptr(ce), float(diversity_gamma), float(entropy_weight), float(commitment_weight), _ptr(out),
+                                _stream()), "vt_fsq_aux_loss")
     return out[0]
 
 

@@ -92,14 +92,47 @@ def space_upsample_parity_weights(weight: torch.Tensor, py: int, px: int):
         torch.stack([rows[..., 0] + rows[..., 1], rows[..., 2]], dim=3)               # [Co, Ci, 2, 2]
 
 
+def time_upsample_parity_mix(kdims, early: bool):
+    """the tap sums of time_upsample_parity_weights as a mix table for vt_pack_conv_weight: kdims = (3, kh, kw) of the reference
+    weight -> 2 * kh * kw output taps, each [m0, m1] (indices into the 3 * kh * kw reference taps)"""
+    kt, kh, kw = kdims
+    assert kt == 3
+    s = kh * kw
+    first = [[0 * s + i, 1 * s + i] if early else [0 * s + i] for i in range(s)]
+    second = [[2 * s + i] if early else [1 * s + i, 2 * s + i] for i in range(s)]
+    return first + second
+
+
+def space_upsample_parity_mix(kdims, py: int, px: int):
+    """the tap sums of space_upsample_parity_weights as a mix table: (3, 3) -> 4 output taps (r, c), each (w[r0][c0] + w[r1][c0]) +
+    (w[r0][c1] + w[r1][c1]) over its row set and column set -- rows first, then columns, as the host statement sums them"""
+    assert tuple(kdims) == (3, 3)
+    rows = [[0], [1, 2]] if py == 0 else [[0, 1], [2]]
+    cols = [[0], [1, 2]] if px == 0 else [[0, 1], [2]]
+    out = []
+    for R in rows:
+        for Cc in cols:
+            m = [-1, -1, -1, -1]
+            for ci, c in enumerate(Cc):
+                for ri, r in enumerate(R):
+                    m[2 * ci + ri] = r * 3 + c
+            out.append(m)
+    return out
+
+
 class PackedCache:
     """Caches the packed weight / fp32 bias of one conv-like parameter holder.  `transform` (optional) maps the
-    parameter tensor to the tensor that is packed (e.g. the parity weights of a time up-sampler)."""
+    parameter tensor to the tensor that is packed (e.g. the parity weights of a time up-sampler); `mix` is the same
+    transform as a tap-sum table (kernel dims -> [[m0..m3], ...]) for the device packer.  Parameters that live on the GPU
+    are packed there by vt_pack_conv_weight (same bits as the host statements; no foreign kernel in the process);
+    host parameters (CPU tests, tools) by the torch statements above."""
 
-    def __init__(self, transform=None, pin_native=False):
+    def __init__(self, transform=None, pin_native=False, mix=None):
         self._key = None
         self._val = None
         self._transform = transform
+        self._mix = mix
+        assert (transform is None) == (mix is None)
         self.arith = None            # set_arith(): ARITH_SPLIT3 = fp32 requests are answered with split-bf16 planes
         self.pin_native = pin_native
 
@@ -108,9 +141,17 @@ class PackedCache:
         key = (dtype, weight.device, weight._version, None if bias is None else bias._version, cin_stored,
                weight.data_ptr(), arith)
         if key != self._key:
-            w = pack_conv_weight(weight if self._transform is None else self._transform(weight), dtype, cin_stored)
-            if arith == ARITH_SPLIT3:
-                w = pack_split3(w)
+            if weight.is_cuda:
+                from . import ops
+
+                wd = weight.detach()
+                wd = wd if wd.dtype == torch.float32 and wd.is_contiguous() else wd.float().contiguous()
+                mix = None if self._mix is None else self._mix(tuple(wd.shape[2:]))
+                w = ops.pack_conv_weight(wd, dtype, cin_stored, mix=mix, split3=arith == ARITH_SPLIT3)
+            else:
+                w = pack_conv_weight(weight if self._transform is None else self._transform(weight), dtype, cin_stored)
+                if arith == ARITH_SPLIT3:
+                    w = pack_split3(w)
             b = None if bias is None else bias.detach().to(torch.float32).contiguous()
             self._key, self._val = key, (w, b)
         return self._val

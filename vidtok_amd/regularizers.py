@@ -156,14 +156,14 @@ class FSQRegularizer(nn.Module):
                                   None if lin.bias is None else lin.bias.detach().float().contiguous())
 
     def _aux_stats(self, h, inv_temperature):
-        """(stats [3], codebook entropy).  Like the reference, the batch-mean code distribution is averaged over the
+        """(stats [3], codebook entropy or None = stats[1]).  Like the reference, the batch-mean code distribution is averaged over the
         ranks whenever torch.distributed runs with world > 1 -- in eval too (maybe_distributed_mean,
         regularizers.py:49-59,240): one all_reduce (RCCL on GPUs) of prod(levels) floats, then its entropy."""
         import torch.distributed as dist
 
         if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
             st = ops.fsq_aux_stats(h, self.levels, inv_temperature)
-            return st, st[1]
+            return st, None              # the codebook entropy is st[1]
         st, avg = ops.fsq_aux_stats(h, self.levels, inv_temperature, return_avg=True)
         dist.all_reduce(avg)
         avg = avg / dist.get_world_size()
@@ -185,13 +185,20 @@ class FSQRegularizer(nn.Module):
         want_aux = self.compute_aux_loss and (self.entropy_loss_weight > 0 or self.commitment_loss_weight > 0)
         if want_aux and not self.keep_num_codebooks_dim:
             st, codebook_entropy = self._aux_stats(h, inv_temperature)
-            entropy_aux = st[0] - self.diversity_gamma * codebook_entropy
-            aux = entropy_aux * self.calculate_entropy_loss_weight(n_steps) + st[2] * self.commitment_loss_weight
+            # (st[0] - gamma * codebook_entropy) * w + st[2] * commitment_weight (regularizers.py:241,264-266), one launch
+            aux = ops.fsq_aux_loss(st, codebook_entropy, self.diversity_gamma, self.calculate_entropy_loss_weight(n_steps),
+                                   self.commitment_loss_weight)
         elif want_aux:
             # the reference cannot run this combination either: with the codebook axis kept, its implicit codebook is
             # flattened to one dimension and the distance einsum raises (regularizers.py:143-146,191-192,234)
             raise NotImplementedError("FSQ entropy / commitment loss with keep_num_codebooks_dim (num_codebooks > 1): "
                                       "the reference's forward raises for it (regularizers.py:234); set both weights to 0")
+        elif z.is_cuda:
+            # zero * w + zero * commitment_weight of the reference (regularizers.py:246,264-266): a fresh zero, from the same launch
+            z3 = self.__dict__.get("_zero3")
+            if z3 is None or z3.device != z.device:
+                z3 = self.__dict__["_zero3"] = torch.zeros(3, device=z.device)
+            aux = ops.fsq_aux_loss(z3, None, self.diversity_gamma, 0.0, 0.0)
         else:
             aux = self.zero.to(z.device) * 1.0
         if self.has_projections:
