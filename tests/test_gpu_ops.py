@@ -1004,3 +1004,39 @@ def test_pack_conv_weight_on_device_equals_host_statements(mode):
     conv = conv.to(DEV)
     wd, bd = pc_dev.get(conv.weight, conv.bias, dtype, cin_stored=8)
     assert wd.is_cuda and torch.equal(wd.cpu().view(torch.int16 if mode == "bf16" else torch.int32), wh.view(torch.int16 if mode == "bf16" else torch.int32)) and torch.equal(bd.cpu(), bh)
+
+
+# conv_in8_kernel (option conv_in8, default on): the encoder's conv_in -- CausalConv3d 3 -> 128, 3 x 3 x 3 on the 8 stored input
+# channels, bf16 -- with register-stationary weights and fragments loaded straight from memory, through the SAME MFMA sequence and
+# epilogue as the general path of the implicit-GEMM kernel: the same bits, with or without the consumer's LayerNorm, zero and
+# replicate (v1.1) time padding, several tiles per workgroup.
+IN8_CASES = [
+    ("in8_t5_16x16", (1, 5, 16, 16), 3, 128, (3, 3, 3), ConvGeom(**G333), {}),
+    ("in8_ln_keep", (2, 4, 16, 24), 3, 128, (3, 3, 3), ConvGeom(**G333), dict(ln="keep")),
+    ("in8_ln_only_nobias", (1, 3, 32, 32), 3, 128, (3, 3, 3), ConvGeom(**G333), dict(ln="only", nobias=True)),
+    ("in8_replicate_ln", (1, 5, 16, 16), 3, 128, (3, 3, 3), ConvGeom(**G333), dict(tmode="replicate", ln="keep")),
+    ("in8_many_tiles", (2, 9, 64, 64), 3, 128, (3, 3, 3), ConvGeom(**G333), dict(ln="keep")),
+    ("in8_one_frame", (1, 1, 16, 8), 3, 128, (3, 3, 3), ConvGeom(**G333), {}),
+]
+
+
+@pytest.mark.parametrize("case", IN8_CASES, ids=[c[0] for c in IN8_CASES])
+def test_conv_in8_kernel_equals_general_path(case, vt_opts):
+    outs = {}
+    for on in (1, 0):
+        vt_opts(conv_in8=on)
+        keep = []
+        plan = _check_conv(case, torch.bfloat16, keep_outputs=keep)
+        assert plan["kernel"] == ("in8" if on else "igemm"), plan
+        outs[on] = keep
+    for a, b in zip(outs[1], outs[0]):
+        assert torch.equal(a, b), f"{case[0]}: conv_in8_kernel differs from the general path"
+
+
+def test_conv_in8_kernel_is_not_taken_elsewhere(vt_opts):
+    """cache mode (a later chunk of a tiled v1.1 pass), fp32 / split-bf16, other channel counts, ragged pixel counts: the general path"""
+    assert _check_conv(("in8_cache", (1, 4, 16, 16), 3, 128, (3, 3, 3), ConvGeom(**G333), dict(tmode="cache")), torch.bfloat16)["kernel"] == "igemm"
+    assert _check_conv(("in8_f32", (1, 3, 16, 16), 3, 128, (3, 3, 3), ConvGeom(**G333), {}), torch.float32)["kernel"] == "igemm"
+    assert _check_conv(("in8_x3", (1, 3, 16, 16), 3, 128, (3, 3, 3), ConvGeom(**G333), {}), X3)["kernel"] == "igemm"
+    assert _check_conv(("in8_ragged", (1, 3, 10, 10), 3, 128, (3, 3, 3), ConvGeom(**G333), {}), torch.bfloat16)["kernel"] == "igemm"
+    assert _check_conv(("in8_cout256", (1, 3, 16, 16), 3, 256, (3, 3, 3), ConvGeom(**G333), {}), torch.bfloat16)["kernel"] == "igemm"

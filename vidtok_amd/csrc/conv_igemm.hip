@@ -184,13 +184,17 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[T
 //   LDS layout: T[pixel][32 chunks of 4 floats], chunk index XOR (pixel & 31): the 8 lanes a ds_write_b128 services
 //   together hold 8 different pixels of one chunk -> 8 different columns; a ds_read_b128 group reads 16 different
 //   chunks of one row -> 16 different bank quads.
-template <typename TOut>
-__device__ __forceinline__ void conv_epilogue_lds128(const ConvArgs& p, f32x16 (&acc)[2][2], int m_blk, int n_blk, int wm,
-                                                     int wn, int lane, int tid, char* smem, long long z) {
+// (ALLOW_RES = false: an instantiation for launches that never carry a residual -- conv_in8_kernel -- without the eight residual rows'
+// registers)
+// (NA x NB: the wave's accumulators cover channels [c_base, c_base + 32 NA) x pixel rows [prow_base, prow_base + 32 NB) of the tile:
+// 2 x 2 at (64 wn, 64 wm) for the implicit-GEMM kernel's wave grid, 1 x 4 at (32 wave, 0) for conv_in8_kernel)
+template <typename TOut, bool ALLOW_RES = true, int NA = 2, int NB = 2>
+__device__ __forceinline__ void conv_epilogue_lds128_at(const ConvArgs& p, f32x16 (&acc)[NA][NB], int m_blk, int n_blk, int c_base,
+                                                        int prow_base, int lane, int tid, char* smem, long long z) {
   TOut* __restrict__ yg = reinterpret_cast<TOut*>(p.y) + z * p.ys_z;
   const TOut* __restrict__ rg = reinterpret_cast<const TOut*>(p.res) + z * p.rs_z;
   float* T = reinterpret_cast<float*>(smem);
-  const bool has_res = p.res_mode != VT_RES_NONE;
+  const bool has_res = ALLOW_RES && p.res_mode != VT_RES_NONE;
   float alpha = 0.0f;
   if (p.res_mode == VT_RES_MIX) alpha = 1.0f / (1.0f + __expf(-p.mix_factor[0]));
   // read-back mapping: 16 lanes per pixel row, 8 consecutive channels each (two adjacent 16-B chunks of the row:
@@ -200,7 +204,7 @@ __device__ __forceinline__ void conv_epilogue_lds128(const ConvArgs& p, f32x16 (
   const int oct_j = tid & 15;
   const int row0 = tid >> 4;
   // residual first: its latency rides under the transposition
-  Oct<TOut> rq[NT];
+  Oct<TOut> rq[ALLOW_RES ? NT : 1];
   if (has_res) {
     const bool remap = p.res_tshift != 0 || p.Tr != p.To;   // uniform
     const long long HWo = (long long)p.Ho * p.Wo;
@@ -224,16 +228,16 @@ __device__ __forceinline__ void conv_epilogue_lds128(const ConvArgs& p, f32x16 (
   {
     const int h = lane >> 5;
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < NA; ++a)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        const int c = wn * 64 + 32 * a + 8 * g + 4 * h;        // first channel of the quad inside the tile
+        const int c = c_base + 32 * a + 8 * g + 4 * h;         // first channel of the quad inside the tile
         f32x4 bq;
         if (p.bias) bq = *reinterpret_cast<const f32x4*>(p.bias + n_blk + c);
         else bq[0] = bq[1] = bq[2] = bq[3] = 0.0f;
 #pragma unroll
-        for (int b = 0; b < 2; ++b) {
-          const int prow = (wm * 2 + b) * 32 + (lane & 31);
+        for (int b = 0; b < NB; ++b) {
+          const int prow = prow_base + b * 32 + (lane & 31);
           f32x4 v;
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = acc[a][b][4 * g + e] + bq[e];
@@ -262,8 +266,8 @@ __device__ __forceinline__ void conv_epilogue_lds128(const ConvArgs& p, f32x16 (
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       v[e] = e < 4 ? t0[e] : t1[e - 4];
-      if (p.res_mode == VT_RES_ADD) v[e] = rq[it].get(e) + v[e];
-      if (p.res_mode == VT_RES_MIX) v[e] = alpha * rq[it].get(e) + (1.0f - alpha) * v[e];
+      if (ALLOW_RES && p.res_mode == VT_RES_ADD) v[e] = rq[it].get(e) + v[e];
+      if (ALLOW_RES && p.res_mode == VT_RES_MIX) v[e] = alpha * rq[it].get(e) + (1.0f - alpha) * v[e];
     }
     const long long orow = out_row(p, m_blk + row);
     if (!p.ln_mode || p.ln_keep_y) Oct<TOut>::store(yg + orow * p.ldy + n_blk + 8 * oct_j, v);
@@ -288,6 +292,12 @@ __device__ __forceinline__ void conv_epilogue_lds128(const ConvArgs& p, f32x16 (
       Oct<TOut>::store(ng + orow * p.ldn + 8 * oct_j, o);
     }
   }
+}
+
+template <typename TOut>
+__device__ __forceinline__ void conv_epilogue_lds128(const ConvArgs& p, f32x16 (&acc)[2][2], int m_blk, int n_blk, int wm,
+                                                     int wn, int lane, int tid, char* smem, long long z) {
+  conv_epilogue_lds128_at<TOut, true, 2, 2>(p, acc, m_blk, n_blk, wn * 64, wm * 64, lane, tid, smem, z);
 }
 
 // LayerNorm-fusing epilogue of the 8-wave 256 x 256 tile for Cout = 256 (the second pyramid level: its conv1 -> norm2
@@ -1461,6 +1471,136 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_igemm_glds_ker
 #endif
 }
 
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, N>(f);
+  }
+}
+
+// ---- conv_in of the encoder: CausalConv3d 3 -> 128, 3 x 3 x 3 (model_3dcausal.py:568 with :162-197), bf16 ----------------------------------
+// K = 27 taps x 8 stored channels = 216: on the general path of the kernel above (Cin = 8 is below a K-step row) a 128 x 128 tile spends
+// ~20 000 cycles on four K steps whose gather addresses are worked out chunk by chunk, next to an epilogue of ~12 000 that writes y and the
+// consumer's LayerNorm -- 1.25 ms for 2.8 GB of output, 2.2 TB/s.  Here the same tile, the same MFMA sequence and the SAME epilogue
+// (conv_epilogue_lds128: the results are the general path's bit for bit) with a K loop made for this shape:
+//   * the weights (128 x 224 bf16, 56 KB) are register-stationary: a wave keeps the 28 A fragments of its 64 channels for the lifetime
+//     of the workgroup, which walks a contiguous range of tiles (persistent, XCD-aware);
+//   * a B fragment is one 16-byte load per lane -- pixel lane % 32, tap 2 j + lane / 32: the 8 stored channels of one input pixel --
+//     straight from memory through a buffer descriptor (x is 84 MB and every pixel is read 27 times: L2 / L1 traffic), padding = an
+//     out-of-range offset (hardware zero fill); the tap's displacement is a per-half constant, its validity one bit of a 27-bit
+//     mask built once per pixel and tile;
+//   * 14 k-groups of 16 = 56 MFMAs per wave and tile, the loads of group j + 4 in flight behind the MFMAs of group j; no LDS in the
+//     K loop, so the epilogue's transposition buffer is free while the NEXT tile's loads are already on their way.
+// Zero / replicate causal padding (the v1.0 models, v1.1 un-tiled and first chunks); cache mode (later chunks of a tiled pass) stays on
+// the general path.  Option conv_in8 = 0 switches it off (A/B, bit-equality test).
+struct In8Lane {            // per pixel fragment (b = 0 .. 3) of a lane
+  unsigned base;            // byte offset of the pixel's 16 bytes in x
+  unsigned mask;            // bit tap = the tap reads inside the clip (or a replicated frame)
+  unsigned c1, c2;          // replicate padding: what to add for a time tap 1 / 2 frames back so that it lands on frame 0 (0 from frame 2 on)
+};
+
+template <bool REPL>
+__global__ __launch_bounds__(256, 2) void conv_in8_kernel(const ConvArgs p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int half = lane >> 5, l32 = lane & 31;
+  const int G = gridDim.x;
+  const int slot = xcd_remap(blockIdx.x, G);
+  const int ntiles = p.M / 128;
+  const int tq = ntiles / G, tr = ntiles - tq * G;
+  const int t_begin = slot * tq + min(slot, tr);
+  const int t_end = t_begin + tq + (slot < tr ? 1 : 0);
+  if (t_begin >= t_end) return;
+
+  // ---- stationary weights: a wave owns channels [32 wave, 32 wave + 32) of all 128 pixels of a tile; A fragment j = channel
+  // 32 wave + l32, k = 16 j + 8 half .. + 8 of the packed row [Cout][216] -- 14 fragments = 56 registers, in the accumulator half
+  u32x4 wf[14];
+  {
+    const bf16_t* row = reinterpret_cast<const bf16_t*>(p.w) + (long long)(32 * wave + l32) * p.ldw + 8 * half;
+#pragma unroll
+    for (int j = 0; j < 14; ++j) {
+      if (j < 13 || half == 0) wf[j] = *reinterpret_cast<const u32x4*>(row + 16 * j);
+      else wf[j] = u32x4{0u, 0u, 0u, 0u};                        // k 216 .. 223: beyond the 27 taps
+    }
+  }
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.x), 0, p.x_bytes, 0x00020000);
+  const int HiWi = p.Hi * p.Wi;
+  const unsigned frame_bytes = (unsigned)HiWi * 16u;
+
+  auto lane_setup = [&](int m, In8Lane& q) __attribute__((always_inline)) {
+    const unsigned r1 = fast_div((unsigned)m, p.fd_wo);
+    const int wo = m - (int)r1 * p.Wo;
+    const unsigned r2 = fast_div(r1, p.fd_ho);
+    const int ho = (int)r1 - (int)r2 * p.Ho;
+    const unsigned r3 = fast_div(r2, p.fd_to);
+    const int to = (int)r2 - (int)r3 * p.To;
+    q.base = (unsigned)((((int)r3 * p.Ti + to) * p.Hi + ho) * p.Wi + wo) * 16u;
+    // tap = 9 kt + 3 kh + kw is inside iff its three one-axis tests hold: the 27-bit mask is the "outer product" of three 3-bit masks
+    unsigned hm = 0, wmk = 0, tmk = 0;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      hm |= ((unsigned)(ho + k - 1) < (unsigned)p.Hi) ? (1u << k) : 0u;
+      wmk |= ((unsigned)(wo + k - 1) < (unsigned)p.Wi) ? (1u << k) : 0u;
+      tmk |= (REPL || to + k - 2 >= 0) ? (1u << k) : 0u;
+    }
+    const unsigned hw9 = ((hm & 1u) ? wmk : 0u) | ((hm & 2u) ? (wmk << 3) : 0u) | ((hm & 4u) ? (wmk << 6) : 0u);
+    q.mask = ((tmk & 1u) ? hw9 : 0u) | ((tmk & 2u) ? (hw9 << 9) : 0u) | ((tmk & 4u) ? (hw9 << 18) : 0u);
+    q.c1 = REPL ? (unsigned)max(1 - to, 0) * frame_bytes : 0u;
+    q.c2 = REPL ? (unsigned)max(2 - to, 0) * frame_bytes : 0u;
+  };
+
+  constexpr int PF = 2;                                          // k-groups of loads in flight (4 fragments each)
+  for (int tile = t_begin; tile < t_end; ++tile) {
+    const int m_blk = tile * 128;
+    In8Lane q[4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) lane_setup(m_blk + b * 32 + l32, q[b]);
+    f32x16 acc[1][4];
+    u32x4 xf[PF + 1][4];
+    // the four fragment loads of k-group j: lane (pixel, tap 2 j + half).  The tap's displacement is one of two compile-time
+    // constants (by half); replicate padding adds the pixel's correction for a tap 1 / 2 frames back; padding = an offset beyond the
+    // descriptor (hardware zero fill); tap 27 does not exist (its weights are zero, the load is skipped into zeros as well)
+    auto issue = [&](auto jc) __attribute__((always_inline)) {
+      constexpr int j = decltype(jc)::value;
+      constexpr int tpa = 2 * j, tpb = 2 * j + 1;
+      constexpr int dta = tpa / 9 - 2, dha = (tpa % 9) / 3 - 1, dwa = tpa % 3 - 1;
+      constexpr int dtb = (tpb < 27 ? tpb : 26) / 9 - 2, dhb = ((tpb < 27 ? tpb : 26) % 9) / 3 - 1, dwb = (tpb < 27 ? tpb : 26) % 3 - 1;
+      const int da = (dta * HiWi + dha * p.Wi + dwa) * 16, db = (dtb * HiWi + dhb * p.Wi + dwb) * 16;     // scalar
+      const unsigned delta = (unsigned)(half ? db : da);
+      const unsigned bit = half ? (tpb < 27 ? (1u << tpb) : 0u) : (1u << tpa);
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        unsigned off = q[b].base + delta;
+        if (REPL) off += half ? (dtb == -2 ? q[b].c2 : (dtb == -1 ? q[b].c1 : 0u)) : (dta == -2 ? q[b].c2 : (dta == -1 ? q[b].c1 : 0u));
+        off = (q[b].mask & bit) ? off : 0xFFFF0000u;
+        xf[j % (PF + 1)][b] = __builtin_amdgcn_raw_buffer_load_b128(rx, (int)off, 0, 0);
+      }
+    };
+    static_for<0, PF>([&](auto jc) __attribute__((always_inline)) { issue(jc); });
+    static_for<0, 14>([&](auto jc) __attribute__((always_inline)) {
+      constexpr int j = decltype(jc)::value;
+      if constexpr (j + PF < 14) issue(std::integral_constant<int, j + PF>{});
+      // every accumulator takes its 16-k groups in K order, as in the general path (the sum of an output is the same chain).  The
+      // MFMA as inline asm with weights AND accumulators pinned to the accumulator half of the register file ("a": 56 + 64
+      // registers there; fragments, offsets and the epilogue's rows in the architectural half): left to the allocator they end up
+      // next to each other and spill
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        if constexpr (j == 0) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=a"(acc[0][b]) : "a"(wf[j]), "v"(xf[j % (PF + 1)][b]));
+        else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc[0][b]) : "a"(wf[j]), "v"(xf[j % (PF + 1)][b]));
+      }
+      __builtin_amdgcn_sched_barrier(0);                         // keep the address work of later groups out of this one (registers)
+    });
+    asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");              // last MFMA -> first VALU reader of its accumulator
+    conv_epilogue_lds128_at<bf16_t, false, 1, 4>(p, acc, m_blk, 0, 32 * wave, 0, lane, tid, smem, 0);
+  }
+#endif
+}
+
 // Test / A-B switches of the option table (options.h; vt_set_option, seeded once from VT_<NAME> -- no launch path reads the environment):
 //   conv_buf = 0      gather through 64-bit pointers (global_load_lds) instead of buffer descriptors
 //   conv_tinner = 0   plain pixel order for temporal convs
@@ -1487,6 +1627,40 @@ inline int device_cus() {
     if (dev_ok) cus[dev].store(n, std::memory_order_release);
   }
   return n;
+}
+
+inline bool in8_eligible(const ConvArgs& a, int nbatch, int dtype, int out_dtype, bool ln_fused, int ln_mode_asked) {
+  if (vt_opt(OPT_CONV_IN8) == 0 || !conv_buf() || nbatch != 1 || a.prof != nullptr) return false;
+  if (dtype != VT_BF16 || out_dtype != VT_BF16 || a.Cin != 8 || a.Cout != 128 || a.ldw != 216) return false;
+  if (a.KT != 3 || a.KH != 3 || a.KW != 3 || a.st != 1 || a.sh != 1 || a.sw != 1 || a.pt != 2 || a.ph != 1 || a.pw != 1) return false;
+  if (a.To != a.Ti || a.Ho != a.Hi || a.Wo != a.Wi || a.ups_t || a.ups_s || a.tmode == VT_TPAD_CACHE) return false;
+  if (a.out_layout != VT_NDHWC || a.res_mode != VT_RES_NONE || a.yt_mul != 1 || a.ys_mul == 2 || a.M % 128 != 0) return false;
+  if (ln_mode_asked != 0 && !ln_fused) return false;                                            // the LayerNorm belongs to the epilogue or to nobody
+  if (a.ldy % 8 != 0 || (a.ln_mode != 0 && a.ldn % 8 != 0) || vt_opt(OPT_CONV_LDSEPI) == 0) return false;   // conv_epilogue_lds128's rows
+  const unsigned long long xb = (unsigned long long)a.B * a.Ti * a.Hi * a.Wi * 8 * 2;
+  return xb < 0xFFFF0000ull;
+}
+
+int launch_in8(const ConvArgs& a_in, hipStream_t stream) {
+  ConvArgs a = a_in;
+  a.x_bytes = (unsigned)((unsigned long long)a.B * a.Ti * a.Hi * a.Wi * 8 * 2);
+  a.lds_epi = 1;
+  const int tiles = a.M / 128;
+  const int grid = std::min(tiles, 2 * device_cus());
+  constexpr int LDS = 128 * 128 * 4;                               // the epilogue's transposition buffer
+  const void* kern = a.tmode == VT_TPAD_REPLICATE ? reinterpret_cast<const void*>(&conv_in8_kernel<true>) : reinterpret_cast<const void*>(&conv_in8_kernel<false>);
+  static std::atomic<bool> attr_done[2][kMaxDevices];
+  int dev = 0;
+  VT_CHECK_HIP(hipGetDevice(&dev));
+  const bool dev_ok = dev >= 0 && dev < kMaxDevices;
+  const int ki = a.tmode == VT_TPAD_REPLICATE ? 1 : 0;
+  if (!dev_ok || !attr_done[ki][dev].load(std::memory_order_acquire)) {
+    VT_CHECK_HIP(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+    if (dev_ok) attr_done[ki][dev].store(true, std::memory_order_release);
+  }
+  void* kargs[] = {&a};
+  VT_CHECK_HIP(hipLaunchKernel(kern, dim3((unsigned)grid), dim3(256), kargs, LDS, stream));
+  return VT_OK;
 }
 
 template <typename MT, typename TOut, int WAVES_M, int WAVES_N, int TM, int TN, bool FAST, int LN256 = 0, int STAGES = 2, int ROWB = kRowBytes>
@@ -1964,6 +2138,12 @@ extern "C" int vt_conv_plan(const vt_conv_desc* d, int32_t* out8) {
     out8[6] = ws2 ? 3 : 1;
     return VT_OK;
   }
+  if (in8_eligible(a, nbatch, d->dtype, d->out_dtype, ln_fused, d->ln_mode)) {   // conv_in8_kernel: the 128 x 128 tile, persistent, register-stationary weights
+    out8[0] = 128; out8[1] = 128; out8[2] = 4;
+    out8[3] = std::min(a.M / 128, 2 * device_cus());
+    out8[4] = ln_fused ? 1 : 0; out8[5] = 1; out8[6] = 4; out8[7] = 1;
+    return VT_OK;
+  }
   static const int dims[4][3] = {{256, 32, 4}, {256, 64, 4}, {256, 256, 8}, {128, 128, 4}};
   const int k = (int)select_tile(a, nbatch);
   out8[0] = dims[k][0]; out8[1] = dims[k][1]; out8[2] = dims[k][2];
@@ -2023,6 +2203,7 @@ extern "C" int vt_conv(const vt_conv_desc* d, vt_stream stream_) {
   if (rc != VT_OK) return rc;
   if (use_ws) return vt_opt(OPT_CONV_WS) == 2 ? vt_ws2_launch(&a, stream_) : vt_ws128_launch(&a, stream_);
   if (narrow_eligible(a, nbatch, d->dtype, d->out_dtype, d->ln_mode)) return vt_conv_narrow_launch(&a, stream_, d->dtype == VT_BF16X3 ? 1 : 0);
+  if (in8_eligible(a, nbatch, d->dtype, d->out_dtype, ln_fused, d->ln_mode)) return launch_in8(a, stream);
   const long long M = a.M;
   const int planes = d->work != nullptr ? splitk_planes(d, a, nbatch, ln_fused, use_ws) : 0;
   if (planes > 0 && d->work_bytes >= (int64_t)planes * M * a.Cout * 4 && (reinterpret_cast<uintptr_t>(d->work) & 15) == 0)

@@ -31,12 +31,12 @@ def _conv_launch(lib, d, what, keep=()):
 
 
 def conv_plan(d):
-    """vt_conv_plan(d) -> dict(tile=(BM, BN), waves, workgroups, ln_fused, launches, kernel="igemm" | "ws128" | "ws2" | "narrow",
+    """vt_conv_plan(d) -> dict(tile=(BM, BN), waves, workgroups, ln_fused, launches, kernel="igemm" | "ws128" | "ws2" | "narrow" | "in8",
     lds_epilogue, deep_ring, half_tile)"""
     out = (C.c_int32 * 8)()
     L.check(L.load().vt_conv_plan(C.byref(d), out), "vt_conv_plan")
     return dict(tile=(out[0], out[1]), waves=out[2], workgroups=out[3], ln_fused=bool(out[4]), launches=out[5],
-                kernel={1: "ws128", 2: "narrow", 3: "ws2"}.get(out[6], "igemm"), lds_epilogue=out[7] in (1, 3), deep_ring=out[7] == 2, half_tile=out[7] == 3)
+                kernel={1: "ws128", 2: "narrow", 3: "ws2", 4: "in8"}.get(out[6], "igemm"), lds_epilogue=out[7] in (1, 3), deep_ring=out[7] == 2, half_tile=out[7] == 3)
 
 
 def replay_convs(record, conv_kernel_only=True):
