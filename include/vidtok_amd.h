@@ -109,9 +109,10 @@ int vt_conv_max_lds_bytes(void);
  *   conv_tskip (1)      causal zero padding in time (tmode VT_TPAD_ZERO): a tile that lies inside one output frame starts its K walk
  *                       behind the tap planes that read only the zero frames in front of the clip (frames 0 / 1 of a 3-tap convolution
  *                       run a third / two thirds of the K steps); the skipped products are exact zeros: same bits as the full walk
- *   conv_in8 (1)        conv_in8_kernel for the encoder's conv_in (bf16, 3 x 3 x 3, 8 stored input channels -> 128, zero / replicate time
- *                       padding): register-stationary weights, fragments loaded straight from memory, the 128 x 128 tile's LDS epilogue;
- *                       0 = the general path of the implicit-GEMM kernel (the same bits)
+ *   conv_in8 (0)        1: conv_in8_kernel for the encoder's conv_in (bf16, 3 x 3 x 3, 8 stored input channels -> 128, zero / replicate time
+ *                       padding): register-stationary weights, fragments loaded straight from memory, the 128 x 128 tile's LDS epilogue.
+ *                       The same bits as the general path of the implicit-GEMM kernel and measured 14 % slower (its direct loads cannot
+ *                       cover the L2 latency with twelve in flight per wave): off, kept as the A/B
  *   conv_half256 (0)    K bound (0 = off; measured slower than the 8-wave tile on every layer of the benchmark): bf16 Cout % 256 == 0 launches whose epilogue goes through the LDS and whose K is at most
  *                       the bound run as 128 x 256 half tiles on 4 waves, two workgroups per CU (one in its K loop while the other
  *                       is in its epilogue); results equal the 8-wave tile's bit for bit

@@ -1006,7 +1006,7 @@ def test_pack_conv_weight_on_device_equals_host_statements(mode):
     assert wd.is_cuda and torch.equal(wd.cpu().view(torch.int16 if mode == "bf16" else torch.int32), wh.view(torch.int16 if mode == "bf16" else torch.int32)) and torch.equal(bd.cpu(), bh)
 
 
-# conv_in8_kernel (option conv_in8, default on): the encoder's conv_in -- CausalConv3d 3 -> 128, 3 x 3 x 3 on the 8 stored input
+# conv_in8_kernel (option conv_in8; default OFF: measured 14 % slower than the general path): the encoder's conv_in -- CausalConv3d 3 -> 128, 3 x 3 x 3 on the 8 stored input
 # channels, bf16 -- with register-stationary weights and fragments loaded straight from memory, through the SAME MFMA sequence and
 # epilogue as the general path of the implicit-GEMM kernel: the same bits, with or without the consumer's LayerNorm, zero and
 # replicate (v1.1) time padding, several tiles per workgroup.
@@ -1035,6 +1035,7 @@ def test_conv_in8_kernel_equals_general_path(case, vt_opts):
 
 def test_conv_in8_kernel_is_not_taken_elsewhere(vt_opts):
     """cache mode (a later chunk of a tiled v1.1 pass), fp32 / split-bf16, other channel counts, ragged pixel counts: the general path"""
+    vt_opts(conv_in8=1)
     assert _check_conv(("in8_cache", (1, 4, 16, 16), 3, 128, (3, 3, 3), ConvGeom(**G333), dict(tmode="cache")), torch.bfloat16)["kernel"] == "igemm"
     assert _check_conv(("in8_f32", (1, 3, 16, 16), 3, 128, (3, 3, 3), ConvGeom(**G333), {}), torch.float32)["kernel"] == "igemm"
     assert _check_conv(("in8_x3", (1, 3, 16, 16), 3, 128, (3, 3, 3), ConvGeom(**G333), {}), X3)["kernel"] == "igemm"

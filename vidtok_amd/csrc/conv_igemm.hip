@@ -828,6 +828,12 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_igemm_glds_ker
       koff = q_step * BK + chunk * VEC;
       s_a = (unsigned)q_cc * (unsigned)ROWB;
       s_b = (unsigned)q_step * (unsigned)ROWB;
+      if constexpr (PROF) {
+        // measurement (ws_prof_mode bit 6): every K step reads the FIRST 128 bytes of its weight rows -- live, non-zero data (the matrix
+        // pipe's power draw stays what it is) that sits in the L2 after the first step: what the launch would take if the weight slab cost
+        // no traffic beyond the L2 (an upper bound for any slab-sharing scheme; wrong results)
+        if (p.prof_mode & 64) s_b = 0u;
+      }
       ++q_step;
       if (++q_cc == cpb) {
         q_cc = 0;
