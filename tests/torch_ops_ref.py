@@ -44,7 +44,9 @@ def _conv_rows(x, w, bias, geom, cout, tmode, cache):
 
 def conv(x, w, bias, geom, *, cout, out_dtype=None, tmode=L.VT_TPAD_ZERO, cache=None, res=None,
          res_mode=L.VT_RES_NONE, res_tshift=0, mix_factor=None, out_layout=L.VT_NDHWC, t_trim=0, ldy=None,
-         ln=None, ln_keep_y=True, out=None, ln_out=None, out_t=None, out_s=None):
+         ln=None, ln_keep_y=True, out=None, ln_out=None, out_t=None, out_s=None, ln_optional=False):
+    if ln_optional:                # "emit this LayerNorm if the launch's epilogue can": the host statement answers no (option conv_tup_ln off)
+        ln, ln_out = None, None
     if out_s is not None:          # this launch fills pixels (2ho+py, 2wo+px) of a preallocated tensor
         yv = conv(x, w, bias, geom, cout=cout, out_dtype=out_dtype, tmode=tmode, cache=cache, res=res, res_mode=res_mode,
                   res_tshift=res_tshift, mix_factor=mix_factor, ldy=out.shape[4])

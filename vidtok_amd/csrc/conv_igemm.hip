@@ -2101,7 +2101,10 @@ int conv_prepare(const vt_conv_desc* d, ConvArgs& a, bool& ln_fused, int& nbatch
   // ... or inside the 8-wave 256 x 256 tile's epilogue for Cout = 256 (conv_epilogue_lds256): full tiles, plain rows
   if (d->ln_mode != 0 && !ln_fused && d->Cout == 256 && M % 256 == 0 && (d->dtype == VT_BF16X3 ? VT_F32 : d->dtype) == d->out_dtype && nbatch == 1 &&
       d->Cin % (kRowBytes / (d->dtype == VT_BF16 ? 2 : 4)) == 0 && (d->ldy & 3) == 0 && (d->ldn & 3) == 0 &&
-      (d->res_mode == VT_RES_NONE || (d->res_mode == VT_RES_ADD && (d->ldr & 3) == 0 && d->Tr == d->To && d->res_tshift == 0)) &&
+      (d->res_mode == VT_RES_NONE || (d->res_mode == VT_RES_ADD && (d->ldr & 3) == 0 && d->Tr == d->To && d->res_tshift == 0) ||
+       // alpha-mix + LayerNorm (the consumer's norm behind a time up-sampler's parity launches): the bf16 v1 epilogue only (option conv_tup_ln)
+       (d->res_mode == VT_RES_MIX && (d->ldr & 7) == 0 && (d->ldy & 7) == 0 && (d->ldn & 7) == 0 && d->Tr == d->To && d->res_tshift == 0 && bf16_io &&
+        vt_opt(OPT_CONV_LN256_V) != 0 && vt_opt(OPT_CONV_TUP_LN) != 0)) &&
       vt_opt(OPT_CONV_FUSE_LN256) != 0 && select_tile(a, nbatch) == TILE_256x256)
     ln_fused = true;
   if (ln_fused) {

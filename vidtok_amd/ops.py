@@ -109,7 +109,7 @@ class ConvGeom:
 
 def conv(x, w, bias, geom: ConvGeom, *, cout: int, out_dtype=None, tmode=L.VT_TPAD_ZERO, cache=None,
          res=None, res_mode=L.VT_RES_NONE, res_tshift=0, mix_factor=None, out_layout=L.VT_NDHWC,
-         t_trim=0, ldy=None, ln=None, ln_keep_y=True, out=None, ln_out=None, out_t=None, out_s=None):
+         t_trim=0, ldy=None, ln=None, ln_keep_y=True, out=None, ln_out=None, out_t=None, out_s=None, ln_optional=False):
     """y = conv(x) (+bias) (+res | alpha-mix); x [B,Ti,Hi,Wi,Cin], w packed [cout, ldw].
     ln = (gamma, beta, eps, silu) additionally returns n = [SiLU](LayerNorm(y)): (y, n), or just n with
     ln_keep_y=False (y is then scratch: the fused kernel never writes it).
@@ -186,6 +186,13 @@ def conv(x, w, bias, geom: ConvGeom, *, cout: int, out_dtype=None, tmode=L.VT_TP
             n = (torch.zeros if ldy != cout else torch.empty)(y.shape, dtype=out_dtype, device=x.device)
         d.ln_gamma, d.ln_beta, d.ln_out = gamma.data_ptr(), beta.data_ptr(), n.data_ptr()
         d.ln_mode, d.ln_keep_y, d.ldn, d.ln_eps = (2 if silu else 1), int(bool(ln_keep_y)), ldy, float(eps)
+        if ln_optional and not conv_plan(d)["ln_fused"]:
+            # the LayerNorm of an interleaved output exists only inside an epilogue; this launch's epilogue does not take it
+            # (shape, arithmetic, option conv_tup_ln): run without, the caller's consumer normalises y itself
+            assert ln_keep_y
+            d.ln_gamma = d.ln_beta = d.ln_out = None
+            d.ln_mode = 0
+            ln, n = None, None
     work = None
     if x.dtype == torch.bfloat16 and (geom.kt == 3 or geom.kh == 3):      # split-K over tap planes (small-M launches): the library says how much scratch
         nb = lib.vt_conv_work_bytes(C.byref(d))
