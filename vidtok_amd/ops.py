@@ -186,7 +186,13 @@ def conv(x, w, bias, geom: ConvGeom, *, cout: int, out_dtype=None, tmode=L.VT_TP
             n = (torch.zeros if ldy != cout else torch.empty)(y.shape, dtype=out_dtype, device=x.device)
         d.ln_gamma, d.ln_beta, d.ln_out = gamma.data_ptr(), beta.data_ptr(), n.data_ptr()
         d.ln_mode, d.ln_keep_y, d.ldn, d.ln_eps = (2 if silu else 1), int(bool(ln_keep_y)), ldy, float(eps)
-        if ln_optional and not conv_plan(d)["ln_fused"]:
+        fused = True
+        if ln_optional:
+            try:
+                fused = conv_plan(d)["ln_fused"]
+            except L.VtError:        # "LayerNorm of an interleaved output is only available fused": this launch cannot take it
+                fused = False
+        if not fused:
             # the LayerNorm of an interleaved output exists only inside an epilogue; this launch's epilogue does not take it
             # (shape, arithmetic, option conv_tup_ln): run without, the caller's consumer normalises y itself
             assert ln_keep_y
