@@ -113,9 +113,9 @@ int vt_conv_max_lds_bytes(void);
  *                       padding): register-stationary weights, fragments loaded straight from memory, the 128 x 128 tile's LDS epilogue.
  *                       The same bits as the general path of the implicit-GEMM kernel and measured 14 % slower (its direct loads cannot
  *                       cover the L2 latency with twelve in flight per wave): off, kept as the A/B
- *   conv_tup_ln (0)     1: the LayerNorm the consumer of a v1.0 time up-sampler starts with is emitted by the up-sampler's two parity launches
+ *   conv_tup_ln (1)     the LayerNorm the consumer of a v1.0 time up-sampler starts with is emitted by the up-sampler's two parity launches
  *                       (alpha-mix + interleaved output frames + LayerNorm together in the bf16 LDS epilogue of the 8-wave tile) instead of
- *                       running as its own pass; hosts ask vt_conv_plan whether a launch fuses it
+ *                       running as its own pass (- 0.2 ... 0.3 ms of the benchmark step); hosts ask vt_conv_plan whether a launch fuses it; 0 = the separate pass
  *   conv_half256 (0)    K bound (0 = off; measured slower than the 8-wave tile on every layer of the benchmark): bf16 Cout % 256 == 0 launches whose epilogue goes through the LDS and whose K is at most
  *                       the bound run as 128 x 256 half tiles on 4 waves, two workgroups per CU (one in its K loop while the other
  *                       is in its epilogue); results equal the 8-wave tile's bit for bit

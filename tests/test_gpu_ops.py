@@ -1041,3 +1041,38 @@ def test_conv_in8_kernel_is_not_taken_elsewhere(vt_opts):
     assert _check_conv(("in8_x3", (1, 3, 16, 16), 3, 128, (3, 3, 3), ConvGeom(**G333), {}), X3)["kernel"] == "igemm"
     assert _check_conv(("in8_ragged", (1, 3, 10, 10), 3, 128, (3, 3, 3), ConvGeom(**G333), {}), torch.bfloat16)["kernel"] == "igemm"
     assert _check_conv(("in8_cout256", (1, 3, 16, 16), 3, 256, (3, 3, 3), ConvGeom(**G333), {}), torch.bfloat16)["kernel"] == "igemm"
+
+
+@pytest.mark.parametrize("silu", [True, False], ids=["ln_silu", "ln"])
+@pytest.mark.parametrize("shape", [(1, 3, 32, 32), (2, 2, 16, 32)], ids=["12_tiles", "4_tiles"])
+def test_conv_interleaved_mix_with_layernorm(shape, silu, vt_opts):
+    """option conv_tup_ln: the two parity launches of a v1.0 time up-sampler (k = 2 in time, alpha-mix against x, output frames
+    interleaved) also emit the consumer's LayerNorm(+SiLU) from the 8-wave tile's bf16 LDS epilogue -- against the host statement
+    (convolution, mix, LayerNorm of the unrounded rows); with the option off vt_conv_plan refuses and ops.conv runs without."""
+    B, T, H, W = shape
+    cin = cout = 256
+    dtype = torch.bfloat16
+    vt_opts(conv_tile=256)
+    x = _act(B, T, H, W, cin, dtype, 1)
+    g = torch.Generator().manual_seed(2)
+    geom = ConvGeom(kt=2, kh=3, kw=3, pt=1, ph=1, pw=1, ph_hi=1, pw_hi=1)
+    bias = _rand((cout,), torch.float32, 3, 0.1)
+    mf = torch.tensor([0.2], device=DEV)
+    gam, bet = _rand((cout,), torch.float32, 6, 0.5) + 1.0, _rand((cout,), torch.float32, 7, 0.2)
+    y = torch.full((B, 2 * T, H, W, cout), float("nan"), dtype=dtype, device=DEV)
+    n = torch.full_like(y, float("nan"))
+    yr, nr = torch.zeros((B, 2 * T, H, W, cout), dtype=dtype), torch.zeros((B, 2 * T, H, W, cout), dtype=dtype)
+    for par in (0, 1):
+        wt = torch.randn((cout, cin, 2, 3, 3), generator=g) / math.sqrt(cin * 18)
+        w = pack_conv_weight(wt, dtype, cin_stored=x.shape[-1]).to(DEV)
+        kw = dict(res=x, res_mode=L.VT_RES_MIX, mix_factor=mf)
+        r = ops.conv(x, w, bias, geom, cout=cout, out=y, out_t=(2, par), ln=(gam, bet, 1e-6, silu), ln_out=n, ln_optional=True, **kw)
+        assert isinstance(r, tuple), "the 8-wave tile's epilogue takes alpha-mix + interleave + LayerNorm together"
+        R.conv(x.cpu(), w.cpu(), bias.cpu(), geom, cout=cout, out=yr, out_t=(2, par), ln=(gam.cpu(), bet.cpu(), 1e-6, silu), ln_out=nr, **_cpu(kw))
+    torch.cuda.synchronize()
+    assert torch.isfinite(y.float()).all() and torch.isfinite(n.float()).all()
+    assert rel_err(y, yr) < TOL[dtype] and rel_err(n, nr) < 2 * TOL[dtype], (rel_err(y, yr), rel_err(n, nr))
+    vt_opts(conv_tup_ln=0)
+    w = pack_conv_weight(torch.randn((cout, cin, 2, 3, 3), generator=g) / math.sqrt(cin * 18), dtype, cin_stored=x.shape[-1]).to(DEV)
+    r = ops.conv(x, w, bias, geom, cout=cout, out=y, out_t=(2, 0), ln=(gam, bet, 1e-6, silu), ln_out=n, ln_optional=True, res=x, res_mode=L.VT_RES_MIX, mix_factor=mf)
+    assert not isinstance(r, tuple)

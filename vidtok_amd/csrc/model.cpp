@@ -377,6 +377,8 @@ struct ConvOpts {
   NormRef ln;                      // emit this norm of the result
   bool keep_y = true;
   Tens* out = nullptr;             // preallocated interleaved output (parity classes)
+  Tens* ln_out = nullptr;          // ... and its normalised twin (the emitted LayerNorm of an interleaved output)
+  bool ln_optional = false;        // emit `ln` only if this launch's epilogue takes it (vt_conv_plan), else run without (ops.conv ln_optional)
   int yt_mul = 1, yt_off = 0, ys = 0, ys_oh = 0, ys_ow = 0;
   float* ncthw = nullptr;          // write fp32 NCTHW here instead
   int t_trim = 0;
@@ -423,24 +425,37 @@ Act conv(Ctx& c, const Tens& x, const void* w, int ldw, const float* bias, const
   if (o.ys) { d.ys_mul = 2; d.ys_oh = o.ys_oh; d.ys_ow = o.ys_ow; }
   const bool ln_after = o.ln.norm && o.ln.norm->group;      // GroupNorm of the result: its own pass behind the convolution (GroupNorm32.after)
   if (o.ln.norm && !ln_after) {
-    r.n = c.alloc(x.B, To, Ho, Wo, ldy, c.m->dt, cout);
+    r.n = o.ln_out ? *o.ln_out : c.alloc(x.B, To, Ho, Wo, ldy, c.m->dt, cout);
     d.ln_gamma = c.m->f32(o.ln.norm->wkey(), c.dry);
     d.ln_beta = c.m->f32(o.ln.norm->bkey(), c.dry);
     d.ln_out = r.n.p;
     d.ln_mode = o.ln.silu ? 2 : 1; d.ln_keep_y = o.keep_y ? 1 : 0; d.ldn = ldy; d.ln_eps = o.ln.norm->eps;
     r.norm = o.ln.norm; r.silu = o.ln.silu;
   }
-  // split-K over the time taps (small-M launches): the library says how much scratch; it comes from the stage's arena.  (A dry run
-  // has no pointers to validate: it asks with stand-ins, the decision depends on the geometry only.)
+  // (a dry run has no pointers to validate: the library is asked with stand-ins, its decisions depend on the geometry only)
+  auto standins = [&](vt_conv_desc& q) {
+    if (!c.dry) return;
+    q.x = q.w = q.y = (void*)16;
+    if (q.res_mode != VT_RES_NONE) q.res = (void*)16;
+    if (q.res_mode == VT_RES_MIX) q.mix_factor = (const float*)16;
+    if (q.tmode == VT_TPAD_CACHE) q.cache = (void*)16;
+    if (q.ln_mode != 0) { q.ln_gamma = q.ln_beta = (const float*)16; q.ln_out = (void*)16; }
+  };
+  // the LayerNorm of an interleaved output exists only inside an epilogue: where this launch's does not take it, run without and let
+  // the consumer normalise y itself (vidtok_amd/ops.py::conv ln_optional; option conv_tup_ln)
+  if (o.ln_optional && d.ln_mode != 0) {
+    vt_conv_desc q = d;
+    standins(q);
+    int32_t plan[8];
+    if (!(vt_conv_plan(&q, plan) == VT_OK && plan[4] == 1)) {
+      d.ln_gamma = d.ln_beta = nullptr; d.ln_out = nullptr; d.ln_mode = 0;
+      r.n = Tens(); r.norm = nullptr;
+    }
+  }
+  // split-K over the time taps (small-M launches): the library says how much scratch; it comes from the stage's arena.
   {
     vt_conv_desc q = d;
-    if (c.dry) {
-      q.x = q.w = q.y = (void*)16;
-      if (q.res_mode != VT_RES_NONE) q.res = (void*)16;
-      if (q.res_mode == VT_RES_MIX) q.mix_factor = (const float*)16;
-      if (q.tmode == VT_TPAD_CACHE) q.cache = (void*)16;
-      if (q.ln_mode != 0) { q.ln_gamma = q.ln_beta = (const float*)16; q.ln_out = (void*)16; }
-    }
+    standins(q);
     const int64_t wb = (x.dt == VT_BF16 && (g.kt == 3 || g.kh == 3)) ? vt_conv_work_bytes(&q) : 0;
     if (wb > 0) {
       d.work = c.cur->alloc((size_t)wb, c.dry);
@@ -865,6 +880,10 @@ struct TimeUp : Stage {            // TimeUpsampleResCausal2x: v1.0 nearest as t
     const Tens& xp = x.y;
     Act r;
     r.y = c.alloc(xp.B, 2 * xp.T, xp.H, xp.W, pad8(ch), c.m->dt, ch);
+    // the consumer's LayerNorm from the two launches' epilogues where they can take it (TimeUpsampleResCausal2x.run of the Python host)
+    bool emit_ln = next.norm != nullptr;
+    Tens nbuf;
+    if (emit_ln) nbuf = c.alloc(xp.B, 2 * xp.T, xp.H, xp.W, pad8(ch), c.m->dt, ch);
     Geom g;
     g.kt = 2; g.kh = 3; g.kw = 3; g.pt = 1; g.ph = 1; g.pw = 1; g.ph_hi = 1; g.pw_hi = 1;
     const float* mf = c.m->f32(key + ".mix_factor", c.dry);
@@ -873,14 +892,17 @@ struct TimeUp : Stage {            // TimeUpsampleResCausal2x: v1.0 nearest as t
     for (int par = 0; par < 2; ++par) {
       ConvOpts o;
       o.out = &r.y; o.yt_mul = 2; o.yt_off = par;
+      if (emit_ln) { o.ln = next; o.ln_out = &nbuf; o.ln_optional = true; }
       o.res = &xp; o.res_mode = VT_RES_MIX; o.mix = mf;
       // causal (window ends at the output frame):  o[2j] = (W0+W1) x[j-1] + W2 x[j],  o[2j+1] = W0 x[j-1] + (W1+W2) x[j]
       // centred (TimeUpsampleRes2x, model_3dnoncausal.py:93-115):  o[2j] = W0 x[j-1] + (W1+W2) x[j],  o[2j+1] = (W0+W1) x[j] + W2 x[j+1]
       const int early = nc ? par : (par == 0 ? 1 : 0);
       Geom gp = g;
       if (nc) gp = centred(g, par == 0 ? 1 : 0);
-      conv(c, xp, c.m->conv_w(ck + ".weight", xp.ld, c.dry, xf_time_parity, early, 0), 18 * xp.ld, c.m->f32(ck + ".bias", c.dry), gp, ch, o);
+      const Act a = conv(c, xp, c.m->conv_w(ck + ".weight", xp.ld, c.dry, xf_time_parity, early, 0), 18 * xp.ld, c.m->f32(ck + ".bias", c.dry), gp, ch, o);
+      if (emit_ln && !a.has_n()) emit_ln = false;
     }
+    if (emit_ln) { r.n = nbuf; r.norm = next.norm; r.silu = next.silu; }
     return r;
   }
 };

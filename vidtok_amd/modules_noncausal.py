@@ -17,7 +17,7 @@ import torch.nn as nn
 
 from . import lib as L
 from . import ops
-from .modules import (SITE_CLIP, SITE_PIXEL, Downsample, Normalize, ResnetBlock, Upsample, _check_norm, _emit,
+from .modules import (SITE_CLIP, SITE_PIXEL, Downsample, Normalize, Normed, ResnetBlock, Upsample, _check_norm, _emit,
                       _level_module, _wrap, first_norm_of, plain, run_stages)
 from .ops import ConvGeom
 from .packing import PackedCache, time_upsample_parity_mix, time_upsample_parity_weights
@@ -81,11 +81,16 @@ class TimeUpsampleRes2x(nn.Module):
         cout = self.conv.out_channels
         ld = ops.pad_channels(cout)
         y = (torch.empty if ld == cout else torch.zeros)((B, 2 * T, H, W, ld), dtype=dt, device=x.device)
+        # the consumer's LayerNorm from the two launches' epilogues where they can take it (modules.TimeUpsampleResCausal2x.run)
+        emit = dict(_emit(next_norm))
+        n = torch.empty_like(y) if emit else None
         for par, (pack, g) in enumerate(self._parity):      # two k=2 convs with pre-summed taps: 2/3 of the MACs
             w, b = pack.get(self.conv.weight, self.conv.bias, dt, cin_stored=C)
-            ops.conv(x, w, b, g, cout=cout, res=x, res_mode=L.VT_RES_MIX, mix_factor=self.mix_factor.detach(),
-                     out=y, out_t=(2, par))
-        return y
+            r = ops.conv(x, w, b, g, cout=cout, res=x, res_mode=L.VT_RES_MIX, mix_factor=self.mix_factor.detach(),
+                         out=y, out_t=(2, par), **(dict(emit, ln_out=n, ln_optional=True) if emit else {}))
+            if emit and not isinstance(r, tuple):
+                emit, n = {}, None
+        return y if n is None else Normed(y, n, next_norm[0], next_norm[1])
 
 
 class _ResnetSym(nn.Module):
