@@ -533,26 +533,26 @@ def main():
     # the same K steps with the OTHER noise source (host stream vs device philox), so the line shows what the reference's
     # host-side noise protocol costs per step (per rank: it is the host cost SURVEY.md section 8e names as the 8-GPU risk)
     other_noise = "device" if args.noise == "host" else "host"
-    model.regularization.noise_source = other_noise
-    for _ in range(2):
-        run()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        run()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    elapsed_other = reduce_metrics(time.perf_counter() - t0, {}, device=dev)["elapsed_s"]
-    model.regularization.noise_source = args.noise
-    noise_rec = {"timed": args.noise, f"ms_per_step_{args.noise}": round(elapsed / args.steps * 1e3, 3),
-                 f"ms_per_step_{other_noise}": round(elapsed_other / args.steps * 1e3, 3),
-                 "host_over_device": round((elapsed if args.noise == "host" else elapsed_other) / (elapsed_other if args.noise == "host" else elapsed), 4),
-                 "host_threads_per_rank": torch.get_num_threads(),
+    noise_rec = {"timed": args.noise, f"ms_per_step_{args.noise}": round(elapsed / args.steps * 1e3, 3), "host_threads_per_rank": torch.get_num_threads(),
                  "note": "host = one torch.randn(shape) of the CPU generator per step (the reference's stream, distributions.py:16-18), pinned "
                          "double buffer + async upload; device = ATen philox kernel"}
+    if not args.no_extras:       # (--no-extras, the profiled form of the command, launches nothing but the timed step's kernels)
+        model.regularization.noise_source = other_noise
+        for _ in range(2):
+            run()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            run()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        elapsed_other = reduce_metrics(time.perf_counter() - t0, {}, device=dev)["elapsed_s"]
+        model.regularization.noise_source = args.noise
+        noise_rec[f"ms_per_step_{other_noise}"] = round(elapsed_other / args.steps * 1e3, 3)
+        noise_rec["host_over_device"] = round((elapsed if args.noise == "host" else elapsed_other) / (elapsed_other if args.noise == "host" else elapsed), 4)
 
     z, dec, log = out
     ok = bool(torch.isfinite(dec.cpu()).all()) and dec.shape == x.shape      # checked on the host: no foreign kernel in the profiled process
@@ -573,12 +573,27 @@ def main():
             g2 = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g2):
                 fn(records)
-            g2.replay()
+            try:                 # hipGraphLaunch and nothing else (vt_graph_launch), as the engine replays its graphs: torch's replay() also
+                ex = int(g2.raw_cuda_graph_exec()) or None    # launches two generator-state fill kernels
+            except (AttributeError, RuntimeError):
+                ex = None
+
+            def replay():
+                if ex is None:
+                    g2.replay()
+                else:
+                    import ctypes as C
+
+                    from vidtok_amd import lib as L
+
+                    L.check(L.load().vt_graph_launch(C.c_void_p(ex), C.c_void_p(torch.cuda.current_stream().cuda_stream)), "vt_graph_launch")
+
+            replay()
             torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for _ in range(reps):
-                g2.replay()
+                replay()
             e1.record()
             torch.cuda.synchronize()
             return e0.elapsed_time(e1) / reps
