@@ -1012,11 +1012,13 @@ def test_pack_conv_weight_on_device_equals_host_statements(mode):
 # replicate (v1.1) time padding, several tiles per workgroup.
 IN8_CASES = [
     ("in8_t5_16x16", (1, 5, 16, 16), 3, 128, (3, 3, 3), ConvGeom(**G333), {}),
-    ("in8_ln_keep", (2, 4, 16, 24), 3, 128, (3, 3, 3), ConvGeom(**G333), dict(ln="keep")),
+    ("in8_ln_keep", (2, 4, 16, 32), 3, 128, (3, 3, 3), ConvGeom(**G333), dict(ln="keep")),
     ("in8_ln_only_nobias", (1, 3, 32, 32), 3, 128, (3, 3, 3), ConvGeom(**G333), dict(ln="only", nobias=True)),
     ("in8_replicate_ln", (1, 5, 16, 16), 3, 128, (3, 3, 3), ConvGeom(**G333), dict(tmode="replicate", ln="keep")),
     ("in8_many_tiles", (2, 9, 64, 64), 3, 128, (3, 3, 3), ConvGeom(**G333), dict(ln="keep")),
     ("in8_one_frame", (1, 1, 16, 8), 3, 128, (3, 3, 3), ConvGeom(**G333), {}),
+    ("in8_row_segments_256", (1, 3, 8, 256), 3, 128, (3, 3, 3), ConvGeom(**G333), dict(ln="keep")),        # Wo % 128 == 0: a tile = half a row
+    ("in8_replicate_rows_64", (2, 3, 64, 64), 3, 128, (3, 3, 3), ConvGeom(**G333), dict(tmode="replicate", ln="only")),
 ]
 
 
@@ -1040,6 +1042,7 @@ def test_conv_in8_kernel_is_not_taken_elsewhere(vt_opts):
     assert _check_conv(("in8_f32", (1, 3, 16, 16), 3, 128, (3, 3, 3), ConvGeom(**G333), {}), torch.float32)["kernel"] == "igemm"
     assert _check_conv(("in8_x3", (1, 3, 16, 16), 3, 128, (3, 3, 3), ConvGeom(**G333), {}), X3)["kernel"] == "igemm"
     assert _check_conv(("in8_ragged", (1, 3, 10, 10), 3, 128, (3, 3, 3), ConvGeom(**G333), {}), torch.bfloat16)["kernel"] == "igemm"
+    assert _check_conv(("in8_w24", (1, 2, 16, 24), 3, 128, (3, 3, 3), ConvGeom(**G333), {}), torch.bfloat16)["kernel"] == "igemm"      # 24 does not divide 128
     assert _check_conv(("in8_cout256", (1, 3, 16, 16), 3, 256, (3, 3, 3), ConvGeom(**G333), {}), torch.bfloat16)["kernel"] == "igemm"
 
 

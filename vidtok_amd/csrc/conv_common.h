@@ -68,6 +68,7 @@ struct ConvArgs {
   unsigned x_bytes, w_bytes;   // BUF path: descriptor extents (0 = tensors too large, use pointers)
   unsigned c_bytes;            // BUF path in cache mode: extent of the cache tensor [B][ncache][Hi][Wi][Cin]
   long long xs_z, ws_z, ys_z, rs_z;
+  int in8_rt, in8_ct, in8_ctl2, in8_segs;   // conv_in8_kernel: tile = in8_rt rows x in8_ct (= 2^in8_ctl2) columns; 64-pixel segments per patch row
   int tskip;                   // 1: zero-padded time taps in front of the clip are skipped per tile (tile inside one output frame, tmode ZERO; launch_variant)
   int ksplit;                  // split-K: blockIdx.z = tap plane, the walk covers that plane only; 1: planes = kt, 2: planes = kh (KT = 1)
   unsigned plane_bytes;        //      bytes of one tap plane in a weight row (KH * KW * Cin, or KW * Cin, elements)
