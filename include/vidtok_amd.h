@@ -109,10 +109,10 @@ int vt_conv_max_lds_bytes(void);
  *   conv_tskip (1)      causal zero padding in time (tmode VT_TPAD_ZERO): a tile that lies inside one output frame starts its K walk
  *                       behind the tap planes that read only the zero frames in front of the clip (frames 0 / 1 of a 3-tap convolution
  *                       run a third / two thirds of the K steps); the skipped products are exact zeros: same bits as the full walk
- *   conv_in8 (0)        1: conv_in8_kernel for the encoder's conv_in (bf16, 3 x 3 x 3, 8 stored input channels -> 128, zero / replicate time
- *                       padding): register-stationary weights, fragments loaded straight from memory, the 128 x 128 tile's LDS epilogue.
- *                       The same bits as the general path of the implicit-GEMM kernel and measured 14 % slower (its direct loads cannot
- *                       cover the L2 latency with twelve in flight per wave): off, kept as the A/B
+ *   conv_in8 (1)        conv_in8_kernel for the encoder's conv_in (bf16, 3 x 3 x 3, 8 stored input channels -> 128, zero / replicate time
+ *                       padding, frames whose width divides or is a multiple of 128): the tile's halo patch arrives by LDS-DMA once, a
+ *                       fragment is one ds_read, the weights are register-stationary, the epilogue transposes through a 64-row buffer.
+ *                       The same bits as the general path of the implicit-GEMM kernel (0), 16 % faster on the launch
  *   conv_tup_ln (1)     the LayerNorm the consumer of a v1.0 time up-sampler starts with is emitted by the up-sampler's two parity launches
  *                       (alpha-mix + interleaved output frames + LayerNorm together in the bf16 LDS epilogue of the 8-wave tile) instead of
  *                       running as its own pass (- 0.2 ... 0.3 ms of the benchmark step); hosts ask vt_conv_plan whether a launch fuses it; 0 = the separate pass

@@ -1006,9 +1006,9 @@ def test_pack_conv_weight_on_device_equals_host_statements(mode):
     assert wd.is_cuda and torch.equal(wd.cpu().view(torch.int16 if mode == "bf16" else torch.int32), wh.view(torch.int16 if mode == "bf16" else torch.int32)) and torch.equal(bd.cpu(), bh)
 
 
-# conv_in8_kernel (option conv_in8; default OFF: measured 14 % slower than the general path): the encoder's conv_in -- CausalConv3d 3 -> 128, 3 x 3 x 3 on the 8 stored input
-# channels, bf16 -- with register-stationary weights and fragments loaded straight from memory, through the SAME MFMA sequence and
-# epilogue as the general path of the implicit-GEMM kernel: the same bits, with or without the consumer's LayerNorm, zero and
+# conv_in8_kernel (option conv_in8, default on): the encoder's conv_in -- CausalConv3d 3 -> 128, 3 x 3 x 3 on the 8 stored input
+# channels, bf16 -- with register-stationary weights and fragments read from a halo patch in the LDS, through the SAME MFMA
+# sequence and row arithmetic as the general path of the implicit-GEMM kernel: the same bits, with or without the consumer's LayerNorm, zero and
 # replicate (v1.1) time padding, several tiles per workgroup.
 IN8_CASES = [
     ("in8_t5_16x16", (1, 5, 16, 16), 3, 128, (3, 3, 3), ConvGeom(**G333), {}),

@@ -184,10 +184,10 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[T
 //   LDS layout: T[pixel][32 chunks of 4 floats], chunk index XOR (pixel & 31): the 8 lanes a ds_write_b128 services
 //   together hold 8 different pixels of one chunk -> 8 different columns; a ds_read_b128 group reads 16 different
 //   chunks of one row -> 16 different bank quads.
-// (ALLOW_RES = false: an instantiation for launches that never carry a residual -- conv_in8_kernel -- without the eight residual rows'
-// registers)
-// (NA x NB: the wave's accumulators cover channels [c_base, c_base + 32 NA) x pixel rows [prow_base, prow_base + 32 NB) of the tile:
-// 2 x 2 at (64 wn, 64 wm) for the implicit-GEMM kernel's wave grid, 1 x 4 at (32 wave, 0) for conv_in8_kernel)
+// (ALLOW_RES = false: an instantiation for launches that never carry a residual, without the eight residual rows' registers.
+// NA x NB: the wave's accumulators cover channels [c_base, c_base + 32 NA) x pixel rows [prow_base, prow_base + 32 NB) of the tile:
+// 2 x 2 at (64 wn, 64 wm) for the implicit-GEMM kernel's wave grid.  conv_in8_kernel's 1 x 4 grid has its own two-pass copy of this
+// row phase, conv_epilogue_in8, on a 64-row buffer.)
 template <typename TOut, bool ALLOW_RES = true, int NA = 2, int NB = 2>
 __device__ __forceinline__ void conv_epilogue_lds128_at(const ConvArgs& p, f32x16 (&acc)[NA][NB], int m_blk, int n_blk, int c_base,
                                                         int prow_base, int lane, int tid, char* smem, long long z) {
