@@ -17,9 +17,12 @@ Launch: `python bench.py --gpus N` spawns its N ranks itself (re-executes under 
 --gpus N` it reads RANK / LOCAL_RANK / WORLD_SIZE from the environment.
 
   value       real frames/s over the whole job = N*B*17*K / max-over-ranks(time of K steps)
-  roofline    the MFMA kernels (conv_igemm_glds_kernel, conv3x3_ws2_kernel, conv3d_narrow_kernel, tblock_pair_kernel: all
-              convolutions + the attention GEMMs = every MFMA FLOP of the path): algorithmic FLOPs of one step (1.0345 TFLOP per padded 256x256 frame, SURVEY.md
-              section 8d) / that kernel's time in one step.  The kernel time is measured live: the conv
+  noise       the timed step draws its KL noise from the reference's host stream (one torch.randn of the CPU generator per step, pinned double
+              buffer, async upload: the parity graph); the same K steps with ATen's device philox are timed next to it (host_over_device)
+  roofline    achieved / frac: algorithmic FLOPs of one step (1.0345 TFLOP per padded 256x256 frame) / ms_per_step -- the
+              WHOLE step the line reports -- against the dense MFMA peak of the dtype; *_kernel_only: the same FLOPs / the time of the MFMA kernels alone
+              (conv_igemm_glds_kernel, conv3x3_ws2_kernel, conv_in8_kernel, conv3d_narrow_kernel, tblock_pair_kernel, flash_attn_kernel: all convolutions +
+              the attention = every MFMA FLOP of the path); *_executed: the MACs the launches really execute.  The kernel time is measured live: the conv
               launches of one step (same descriptors, same tensors) are replayed back to back from a
               hipGraph that contains nothing else, bracketed by HIP events on the launch stream -- no
               per-launch event overhead, so it is <= ms_per_step by construction; the rocprofv3
@@ -79,7 +82,7 @@ def randomize_weights(model, seed=0):
                 p.copy_(torch.randn(p.shape, generator=g) / math.sqrt(p[0].numel()))
 
 
-def cpu_baseline(config=None, clip=None, seed=77, world=1):
+def cpu_baseline(config=None, clip=None, seed=77):
     """Time the CPU oracle (a port: the reference is Python under /root/reference, which does not exist on the GPU box and
     may not be copied into the repo) on ONE unscaled 17x256x256 clip of the bench workload -- about 30 s of CPU work.
     The thread count is the best of a sweep over 8 / 16 / 32 / 64 / 128 threads (capped by the host) on a 17x64x64 probe,
@@ -232,7 +235,7 @@ def other_config_measurements(dev, x):
 
 
 
-MFMA_KERNELS = ("conv_igemm", "conv3x3_ws2", "conv3x3_ws128", "conv3d_narrow", "tblock_pair", "flash_attn")
+MFMA_KERNELS = ("conv_igemm", "conv3x3_ws2", "conv3x3_ws128", "conv3d_narrow", "conv_in8", "tblock_pair", "flash_attn")
 
 
 def measure_traffic(dtype, batch, config, timeout_s=200, table=None):
@@ -643,7 +646,7 @@ def main():
         # *_kernel_only: the same FLOPs over the HIP-event time of the MFMA-kernel launches alone; *_executed: the MACs the
         # launches really execute (parity-class up-samplers do 4/9 resp. 2/3 of the reference's) over the step time.
         step_ms = elapsed / args.steps * 1e3
-        roof = {"bound": "mfma", "kernel": "conv_igemm_glds_kernel + conv3x3_ws2_kernel + conv3d_narrow_kernel + tblock_pair_kernel + flash_attn_kernel",
+        roof = {"bound": "mfma", "kernel": "conv_igemm_glds_kernel + conv3x3_ws2_kernel + conv_in8_kernel + conv3d_narrow_kernel + tblock_pair_kernel + flash_attn_kernel",
                 "achieved": round(flops / (step_ms * 1e-3) / 1e12, 2), "peak": peak,
                 "unit": "TFLOP/s", "frac": round(flops / (step_ms * 1e-3) / 1e12 / peak, 4), "traffic": None, "traffic_source": "not measured",
                 "basis": "algorithmic TFLOP per step / ms_per_step (whole step); *_kernel_only = / HIP-event time of the MFMA launches alone",
@@ -701,7 +704,7 @@ def main():
             roof["traffic"] = tb
             roof["traffic_source"] = src + ("" if args.traffic == "profile" else f"; {roof['traffic_source']}")
 
-    cpu, ref = (None, None) if args.no_cpu_baseline else cpu_baseline(config, clip0, world=world)
+    cpu, ref = (None, None) if args.no_cpu_baseline else cpu_baseline(config, clip0)
     parity_mode = mode_table = None
     if modes is not None:
         # every arithmetic mode on the bench workload: frames/s, and the distance of its output for clip 0 from the CPU

@@ -7,7 +7,7 @@ import sys
 from collections import defaultdict
 
 
-FAMILIES = ("conv_igemm", "conv3x3_ws2", "conv3x3_ws128", "conv3d_narrow", "tblock_pair", "flash_attn", "layernorm_act")
+FAMILIES = ("conv_igemm", "conv3x3_ws2", "conv3x3_ws128", "conv3d_narrow", "conv_in8", "tblock_pair", "flash_attn", "layernorm_act")
 
 
 def main(root):

@@ -11,7 +11,7 @@ import os
 import sys
 
 
-FAMILIES = ("conv_igemm", "conv3x3_ws2", "conv3x3_ws128", "conv3d_narrow", "tblock_pair")   # the MFMA kernels of the path (bench.py roofline.kernel)
+FAMILIES = ("conv_igemm", "conv3x3_ws2", "conv3x3_ws128", "conv3d_narrow", "conv_in8", "tblock_pair", "flash_attn")   # the MFMA kernels of the path (bench.py roofline.kernel)
 
 
 def collect(path, counter):
@@ -27,7 +27,7 @@ def main(root, out=None):
     fetch, write = collect(root, "FETCH_SIZE"), collect(root, "WRITE_SIZE")
     n = min(len(fetch), len(write))
     res = {
-        "kernel": "conv_igemm_glds_kernel + conv3x3_ws2_kernel + conv3d_narrow_kernel + tblock_pair_kernel", "launches_sampled": n,
+        "kernel": "conv_igemm_glds_kernel + conv3x3_ws2_kernel + conv_in8_kernel + conv3d_narrow_kernel + tblock_pair_kernel + flash_attn_kernel", "launches_sampled": n,
         "fetch_kib_reported_per_launch": sum(fetch) / max(1, len(fetch)),
         "write_kib_per_launch": sum(write) / max(1, len(write)),
         "fetch_correction": 2.0,

@@ -334,3 +334,47 @@ def test_graph_cache_bookkeeping_and_engine_copies():
         assert other._genc.fn.__self__ is other and other._gdec.fn.__self__ is other
         assert other._genc.state_get.__self__ is other and other._genc.fn.__func__ is type(model)._encoder_fn
         assert torch.equal(other.state_dict()["encoder.conv_in.conv.weight"], model.state_dict()["encoder.conv_in.conv.weight"])
+
+
+def test_autocast_region_switches_the_arithmetic_mode():
+    """AutoencodingEngine._sync_autocast (host logic only, no launch): the caller's torch.autocast region selects the kernels --
+    autocast(bfloat16) = bf16 whatever set_compute_dtype chose, the chosen mode (incl. an encoder tail) returns when the region ends,
+    autocast(float16) raises unless a policy maps it, "ignore" keeps the chosen mode, graphs are dropped on every switch."""
+    model, cfg, sd = build_model("vidtok_kl_causal_488_4chn", seed=3)
+    x = torch.zeros(1, 3, 5, 16, 16)
+    assert model.arith == "fp32"
+    model._sync_autocast(x)
+    assert model.arith == "fp32" and model.encoder.compute_dtype == torch.float32
+    with torch.autocast("cpu", dtype=torch.bfloat16):
+        model._sync_autocast(x)
+        assert model.arith == "bf16" and model.encoder.compute_dtype == model.decoder.compute_dtype == torch.bfloat16
+        model._sync_autocast(x)                                    # idempotent inside the region
+        assert model.arith == "bf16"
+    model._sync_autocast(x)
+    assert model.arith == "fp32" and model.encoder.compute_dtype == torch.float32
+    model.set_compute_dtype("bf16x3", encoder_tail=None)
+    with torch.autocast("cpu", dtype=torch.bfloat16):
+        model._sync_autocast(x)
+        assert model.arith == "bf16"
+    model._sync_autocast(x)
+    assert model.arith == "bf16x3" and model.encoder.compute_dtype == torch.float32
+    model.set_compute_dtype(torch.bfloat16, encoder_tail=torch.float32, tail_level=2)
+    with torch.autocast("cpu", dtype=torch.bfloat16):
+        model._sync_autocast(x)                                    # bf16 asked, but the chosen mode has an fp32 tail: plain bf16 for the region
+        assert model.arith == "bf16" and model.encoder.tail_dtype is None
+    model._sync_autocast(x)
+    assert model.encoder.tail_dtype == torch.float32 and model.encoder.tail_level == 2
+    model.set_compute_dtype(torch.float32)
+    with torch.autocast("cpu", dtype=torch.float16):
+        with pytest.raises(NotImplementedError, match="float16"):
+            model._sync_autocast(x)
+        model.set_autocast_policy(float16="ignore")
+        model._sync_autocast(x)
+        assert model.arith == "fp32"
+        model.set_autocast_policy(float16="bf16x3")
+        model._sync_autocast(x)
+        assert model.arith == "bf16x3"
+    model._sync_autocast(x)
+    assert model.arith == "fp32"
+    with pytest.raises(AssertionError):
+        model.set_autocast_policy(float16="fp8")
