@@ -215,15 +215,15 @@ int vt_conv(const vt_conv_desc* d, vt_stream stream);
  * pass: M = 4 096 pixels x N = 512 x K = 13 824 = 128 tiles of 128 x 128 with 216 K steps each on 256 CUs) is latency-bound: one tile per
  * CU walking a long K.  Given scratch, vt_conv runs it as three launches-in-one (grid.z = tap plane: each workgroup walks the KH x KW x Cin
  * -- or KW x Cin -- of ONE plane into an fp32 partial) and a reduction that owns bias / residual / rounding: 3 x the workgroups, a third of the steps.
- * vt_conv_work_bytes(d) = the scratch vt_conv(d) would use (0: this call does not split; decided from the descriptor and option
- * conv_splitk, ignoring d->work); with d->work = NULL or d->work_bytes too small the call runs unsplit.  The fp32 sum of an output
+ * vt_conv_work_bytes(d) = the scratch vt_conv(d) would use (0: this call does not split; decided from ONE clip's geometry in the
+ * descriptor -- never from B -- and option conv_splitk, ignoring d->work); with d->work = NULL or d->work_bytes too small the call runs unsplit.  The fp32 sum of an output
  * is then taken in another order (per tap, then over the taps): results differ from the unsplit launch by fp32 rounding. */
 int64_t vt_conv_work_bytes(const vt_conv_desc* d);
 /* What vt_conv(d) would do, without launching (no GPU needed): out8 = {pixel tile, channel tile, waves per
  * workgroup, workgroups (tiles for the persistent kernel), 1 if LayerNorm comes from the conv epilogue, kernel
  * launches of the call, kernel (0 = tile-per-workgroup implicit GEMM; weight-stationary persistent 3x3 for
  * Cin = Cout = 128 bf16: 1 = conv_ws128.hip, 8 x 16-pixel tiles on 4 waves, 3 = conv_ws2.hip, 4 x 16-pixel tiles on 8 waves; 2 = the
- * narrow-output kernel), 1 if the 8-wave tile's epilogue goes through the LDS (coalesced rows; always with a fused LayerNorm,
+ * narrow-output kernel; 4 = conv_in8_kernel, the encoder's conv_in from an LDS halo patch), 1 if the 8-wave tile's epilogue goes through the LDS (coalesced rows; always with a fused LayerNorm,
  * without one for bf16 full tiles), 2 if the 128 x 128 tile runs on its 4-slot ring (option conv_deep: launches with no
  * more tiles than the device has CUs), 3 if such an LDS-epilogue launch runs as 128 x 256 half tiles on 4 waves, two workgroups
  * per CU (option conv_half256)}.  Validates `d` exactly like vt_conv.  Test / measurement aid: which kernel and

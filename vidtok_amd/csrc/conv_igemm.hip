@@ -2192,7 +2192,7 @@ int conv_prepare(const vt_conv_desc* d, ConvArgs& a, bool& ln_fused, int& nbatch
 // What vt_conv(d) will do, without launching: out[0..1] = pixel x channel tile, out[2] = waves per workgroup,
 // out[3] = workgroups (tiles for the persistent kernel), out[4] = 1 when LayerNorm is produced by the conv kernel's
 // epilogue (0: second launch of vt_layernorm_act, or no LayerNorm requested), out[5] = kernel launches the call
-// performs, out[6] = kernel: 0 = conv_igemm_glds_kernel, 1 = conv3x3_ws128_kernel (weight-stationary), 2 = conv3d_narrow_kernel, 3 = conv3x3_ws2_kernel, out[7] = epilogue / ring form (see the header).  Lets tests assert which
+// performs, out[6] = kernel: 0 = conv_igemm_glds_kernel, 1 = conv3x3_ws128_kernel (weight-stationary), 2 = conv3d_narrow_kernel, 3 = conv3x3_ws2_kernel, 4 = conv_in8_kernel, out[7] = epilogue / ring form (see the header).  Lets tests assert which
 // instantiation a parity case exercises and lets bench.py separate conv kernel time from LayerNorm passes.
 extern "C" int vt_conv_plan(const vt_conv_desc* d, int32_t* out8) {
   VT_CHECK_ARG(out8 != nullptr, "vt_conv_plan: null output");
