@@ -378,3 +378,64 @@ def test_autocast_region_switches_the_arithmetic_mode():
     assert model.arith == "fp32"
     with pytest.raises(AssertionError):
         model.set_autocast_policy(float16="fp8")
+
+
+def test_parity_mix_tables_equal_the_tap_sum_statements():
+    """The tap-sum tables vt_pack_conv_weight gets for the up-samplers' parity classes (packing.{time,space}_upsample_parity_mix) against
+    the torch statements they replace on the GPU ({time,space}_upsample_parity_weights + pack_conv_weight): the kernel's contract --
+    out tap j = (w[m0] + w[m1]) + (w[m2] + w[m3]), absent terms left out, channels padded -- evaluated on the host gives the same bits."""
+    from vidtok_amd import packing as P
+
+    def by_table(w, cin_p, mix):
+        cout, cin = w.shape[:2]
+        wf = w.reshape(cout, cin, -1)
+        out = torch.zeros(cout, len(mix), cin_p)
+        for j, m in enumerate(mix):
+            m = (list(m) + [-1] * 4)[:4]
+            a = wf[:, :, m[0]].clone()
+            if m[1] >= 0:
+                a = a + wf[:, :, m[1]]
+            if m[2] >= 0:
+                b = wf[:, :, m[2]].clone()
+                if m[3] >= 0:
+                    b = b + wf[:, :, m[3]]
+                a = a + b
+            out[:, j, :cin] = a
+        return out.reshape(cout, -1)
+
+    g = torch.Generator().manual_seed(1)
+    for early in (True, False):
+        w = torch.randn(16, 5, 3, 3, 3, generator=g)
+        mix = P.time_upsample_parity_mix((3, 3, 3), early)
+        assert len(mix) == 18 and torch.equal(P.pack_conv_weight(P.time_upsample_parity_weights(w, early), torch.float32, 8), by_table(w, 8, mix))
+    for py in (0, 1):
+        for px in (0, 1):
+            w = torch.randn(8, 24, 3, 3, generator=g)
+            mix = P.space_upsample_parity_mix((3, 3), py, px)
+            assert len(mix) == 4 and torch.equal(P.pack_conv_weight(P.space_upsample_parity_weights(w, py, px), torch.float32, 24), by_table(w, 24, mix))
+
+
+def test_fsq_mismatch_report_names_the_boundary_cases():
+    """tests/util.py::fsq_mismatch_report (SURVEY.md section 8d: "count of mismatches and their distance to a rounding boundary"): a latent
+    nudged across a rounding boundary flips exactly that digit, and the report names token, channel, both bounded values and their
+    distances to the boundary in fp32 ulps."""
+    from oracle.vidtok_oracle import fsq_regularize
+    from util import fsq_mismatch_report
+
+    levels = [8, 8, 8, 5, 5, 5]
+    h = torch.randn(2, 6, 3, 8, 8, generator=torch.Generator().manual_seed(0)) * 0.3
+    # put channel 4 of one token right below the boundary 0.5 of an odd level (bounded = tanh(h) * half_l), then push it across
+    half_l = (5 - 1) * (1 + 1e-3) / 2
+    h[1, 4, 2, 3, 5] = float(torch.atanh(torch.tensor(0.5 / half_l))) - 2e-6
+    h2 = h.clone()
+    h2[1, 4, 2, 3, 5] += 4e-6
+    _, l0 = fsq_regularize(h, levels, with_aux=False)
+    _, l1 = fsq_regularize(h2, levels, with_aux=False)
+    rep = fsq_mismatch_report(levels, h2, h, l1["indices"], l0["indices"])
+    assert rep["tokens"] == 2 * 3 * 8 * 8 and rep["mismatches"] == 1 and len(rep["detail"]) == 1
+    d = rep["detail"][0]
+    assert d["token"] == [1, 2, 3, 5] and d["channel"] == 4 and d["digit"] == d["digit_ref"] + 1
+    assert d["bounded_ref"] < 0.5 < d["bounded"] and 0 < d["ref_to_boundary_ulps"] < 200 and 0 < d["ours_to_boundary_ulps"] < 200
+    assert 100 < d["h_diff_ulps"] < 170                              # 4e-6 at |h| = 0.255: ulp 3e-8
+    same = fsq_mismatch_report(levels, h, h, l0["indices"], l0["indices"])
+    assert same["mismatches"] == 0 and same["detail"] == []
