@@ -18,8 +18,14 @@
  *     the two ends by vt_ncthw_to_ndhwc / the NCTHW epilogue of vt_conv;
  *   - `dtype` selects the arithmetic: VT_F32 = fp32 storage + fp32-input MFMA
  *     (v_mfma_f32_32x32x2_f32, bit-wise an fmaf chain), VT_BF16 = bf16 storage + bf16 MFMA
- *     (v_mfma_f32_32x32x16_bf16) with fp32 accumulation.  Statistics, softmax, the regularizers
- *     and all epilogue arithmetic are fp32 in both modes.  vt_conv additionally takes
+ *     (v_mfma_f32_32x32x16_bf16) with fp32 accumulation, VT_F16 = fp16 storage + fp16 MFMA
+ *     (v_mfma_f32_32x32x16_f16, the same rate) with fp32 accumulation: what the reference's
+ *     README computes in under torch.autocast(device_type="cuda", dtype=torch.float16)
+ *     (README.md:336-340,375-385; scripts/inference_*.py --precision autocast).  Results beyond
+ *     fp16's range (|v| > 65 504) become +-inf when a tensor is stored, as they do in the
+ *     reference's fp16 convolutions.  Every operator that takes VT_BF16 takes VT_F16.
+ *     Statistics, softmax, the regularizers and all epilogue arithmetic are fp32 in every mode.
+ *     vt_conv additionally takes
  *     VT_BF16X3 ("split-bf16"): fp32 storage (x, cache, y, res, ln_out exactly as for VT_F32,
  *     out_dtype = VT_F32) with the products taken on the bf16 matrix cores from bf16 hi / lo
  *     planes of both operands (x_hi w_hi + x_hi w_lo + x_lo w_hi, fp32 accumulation: ~2^-17
@@ -51,7 +57,7 @@ typedef enum vt_status {
   VT_ERR_UNSUPPORTED = -3
 } vt_status;
 
-typedef enum vt_dtype { VT_F32 = 0, VT_BF16 = 1, VT_I32 = 2, VT_BF16X3 = 3 /* vt_conv arithmetic only, see below */ } vt_dtype;
+typedef enum vt_dtype { VT_F32 = 0, VT_BF16 = 1, VT_I32 = 2, VT_BF16X3 = 3 /* vt_conv arithmetic only, see above */, VT_F16 = 4 } vt_dtype;
 
 /* time-axis treatment of taps that fall before the first frame of the input */
 typedef enum vt_tmode {
@@ -82,26 +88,20 @@ int vt_conv_max_lds_bytes(void);
 /* ------------------------------------------------------------------------------------------
  * Process-wide tuning / test switches.  Which kernel a call runs is a function of its descriptor and of this
  * table only -- no launch path reads the environment.  The table is filled once, on first use, from the
- * environment (variable VT_<NAME>, e.g. VT_CONV_SCHED=0, so shell A/B runs work) and changes afterwards only
+ * environment (variable VT_<NAME>, e.g. VT_CONV_WS=0, so shell A/B runs work) and changes afterwards only
  * through vt_set_option; vt_reset_options() re-reads the environment defaults.  Every option selects between
  * implementations of the SAME operator contract (the parity tests run both sides of each switch), so none of them
  * is part of the reference's interface.  Names (default):
  *   conv_buf (1)        gather through buffer descriptors; 0 = 64-bit pointers (always used for > 4 GiB tensors, and in cache mode when a tile spans frames)
  *   conv_tinner (1)     temporal convolutions walk their tiles frames-innermost (L2 reuse of the kt taps)
  *   conv_ldsepi (1)     128 x 128 tile: epilogue transposed through the LDS (whole-line stores, carries the fused LayerNorm)
- *   conv_sched (2)      K-step schedule of the 8-wave 256 x 256 tile: 0 plain loop, 1 schedule 1, 2 two-group ping-pong (bf16)
- *   conv_ws (2)         weight-stationary persistent kernel for bf16 3x3 128 -> 128 convolutions: 0 off, 1 conv_ws128.hip,
- *                       2 conv_ws2.hip (two waves per SIMD splitting K)
+ *   conv_ws (2)         weight-stationary persistent kernel (conv_ws2.hip: two waves per SIMD splitting K) for the 3x3 128 -> 128
+ *                       convolutions in a 16-bit type; 0 = off (the tile-per-workgroup kernel)
  *   conv_narrow (1)     conv3d_narrow_kernel for Cout <= 4 (the decoder's conv_out)
  *   conv_tile (0)       128 / 256: force that tile wherever it is legal; 0 = choose by size
  *   conv_tile_min (128) fewest 256 x 256 tiles for which the 8-wave tile is chosen
  *   conv_fuse_ln (1), conv_fuse_ln256 (1)   LayerNorm of the result inside the epilogue for Cout = 128 / 256
- *   conv_ln256_v (1)    form of the Cout = 256 LayerNorm epilogue (0: round-2 form)
  *   conv_deep (1)       128 x 128 tile on a 4-slot ring (three K steps of DMA in flight) for launches with no more tiles than CUs
- *   conv_sched_x3 (3)   K-step schedule of the 8-wave tile under VT_BF16X3 (64-byte rows, 4-slot ring): 0 plain loop, 1 / 2 / 3 two
- *                       wave groups alternating LOAD and COMPUTE phases with the DMA pieces of a step issued in the LOAD phase /
- *                       between the MFMAs of the COMPUTE phase / half and half, 4 = "stream": one barrier per step, all eight waves
- *                       in phase, reads / split / addresses / DMA pieces in the shadows of the step's 24 MFMAs
  *   conv_splitk (1)     split-K over the tap planes for launches with few pixels PER CLIP when the caller provides scratch
  *                       (vt_conv_work_bytes).  A split launch sums in another order than a whole one, so the decision is a function
  *                       of one clip's geometry (To, Ho, Wo, Cout, K) and never of B: a clip's bits do not depend on its batch.
@@ -116,14 +116,11 @@ int vt_conv_max_lds_bytes(void);
  *   conv_tup_ln (1)     the LayerNorm the consumer of a v1.0 time up-sampler starts with is emitted by the up-sampler's two parity launches
  *                       (alpha-mix + interleaved output frames + LayerNorm together in the bf16 LDS epilogue of the 8-wave tile) instead of
  *                       running as its own pass (- 0.2 ... 0.3 ms of the benchmark step); hosts ask vt_conv_plan whether a launch fuses it; 0 = the separate pass
- *   conv_half256 (0)    K bound (0 = off; measured slower than the 8-wave tile on every layer of the benchmark): bf16 Cout % 256 == 0 launches whose epilogue goes through the LDS and whose K is at most
- *                       the bound run as 128 x 256 half tiles on 4 waves, two workgroups per CU (one in its K loop while the other
- *                       is in its epilogue); results equal the 8-wave tile's bit for bit
- *   conv_half_plain (0) half tiles also for launches without a fused LayerNorm (their epilogue is stores, nothing to overlap: slower)
- *   conv_half_stagger (900) half tiles: the second workgroup slot of every CU starts late by this many shader cycles per K step
- *                       (+ 6 000), so that the two workgroups of a CU run in anti-phase; 0 = start together
  *   attn_flash (1)      the attention block as one vt_flash_attention launch where it applies; 0: GEMM -> softmax -> GEMM operators
- *   ws_acc (0), tblock_prof_mode (0), ws_prof_mode (0)   measurement aids
+ *   tblock_prof_mode (0), ws_prof_mode (0)   measurement aids
+ * (Rounds 1-5 also kept the superseded forms selectable -- K-step schedules 0 / 1 / 3 / 4, the first LayerNorm epilogue of the 8-wave
+ * tile, the first-generation weight-stationary kernel, 128 x 256 half tiles: their measurements are in DESIGN.md section 6, the code is
+ * in the history.)
  *   tblock_fused (1)   0: vt_temporal_block_supported answers no (blocks stay on the unfused operators)
  * Returns VT_ERR_ARG for an unknown name.
  * ---------------------------------------------------------------------------------------- */
@@ -261,7 +258,7 @@ typedef struct vt_tblock_desc {
   const float* norm1_gamma; const float* norm1_beta;   /* [C] fp32                              */
   const float* norm2_gamma; const float* norm2_beta;
   const float* next_gamma; const float* next_beta;     /* used when ln_next_mode != 0           */
-  int32_t dtype;                 /* VT_BF16                                                    */
+  int32_t dtype;                 /* VT_BF16 or VT_F16                                          */
   int32_t C, ld;
   int32_t B, T;
   int64_t HW;
@@ -365,7 +362,7 @@ int vt_time_lerp2x_cat(const void* head, int32_t nh, const void* x, void* y, int
 /* ------------------------------------------------------------------------------------------
  * vt_pack_conv_weight -- a convolution parameter in the reference's layout, w fp32 [Cout][Cin][taps_in] (nn.Conv3d / Conv2d /
  * Conv1d weight, taps = kT*kH*kW row-major), to the rows vt_conv reads: out [Cout][ldw], k = tap * cin_p + c,
- * channels zero-padded to cin_p (the activation's stored count), the row tail zero.  out_dtype VT_F32 / VT_BF16 = plain rows
+ * channels zero-padded to cin_p (the activation's stored count), the row tail zero.  out_dtype VT_F32 / VT_BF16 / VT_F16 = plain rows
  * (round to nearest even); VT_BF16X3 = the split-bf16 container: per 16 k [hi 16 x bf16 | lo 16 x bf16], hi = bf16(w),
  * lo = bf16(w - hi), 4 bytes per k, ldw a multiple of 32.  mix_host (host, [taps_out][4], -1 = absent; NULL = identity): output
  * tap j = (w[m0] + w[m1]) + (w[m2] + w[m3]) in fp32 -- the pre-summed taps of the up-samplers' parity classes (a 3-tap window
@@ -424,7 +421,7 @@ int vt_entropy(const float* avg, int64_t J, float* out, vt_stream stream);
  * (reference vidtok/models/autoencoder.py:197-229: encode = encoder -> regularization, decode = decoder, forward = both;
  * the module tree of vidtok/modules/model_3dcausal.py:502-885 with `norm_type: layernorm`, `resamp_with_conv: true`).
  * Same stage graph, descriptors and fusion decisions as the Python host (vidtok_amd/modules.py), hence the same bits.
- *   vt_create(cfg, VT_BF16 | VT_F32 | VT_BF16X3, &h)   the fields of cfg are the constructor arguments of the reference's YAML;
+ *   vt_create(cfg, VT_BF16 | VT_F16 | VT_F32 | VT_BF16X3, &h)   the fields of cfg are the constructor arguments of the reference's YAML;
  *                                            VT_BF16X3 = fp32 storage with every convolution in split-bf16 arithmetic
  *   vt_load_weight(h, key, data, shape, n)   key = the reference state_dict key ("encoder.down.0.block.0.conv1.weight",
  *                                            ...), data = fp32 on the HOST in the reference's parameter layout; weights

@@ -16,11 +16,19 @@ def pytest_configure(config):
     torch.set_num_threads(max(1, min(32, os.cpu_count() or 1)))
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
     config.addinivalue_line("markers", "reference: needs /root/reference (build container only)")
+    config.addinivalue_line("markers", "variants: exhaustive cross products of GPU cases (every case x arithmetic x gather form); run with "
+                                       "-m \"gpu and variants\" -- left out of a plain -m gpu run, which covers every shipped path")
 
 
 def pytest_collection_modifyitems(config, items):
     from oracle.refload import reference_available
 
+    # the `variants` tier runs only when the -m expression names it (a plain `-m gpu` must stay inside the driver's time limit)
+    if "variants" not in (config.getoption("-m") or ""):
+        keep = [it for it in items if "variants" not in it.keywords]
+        if len(keep) != len(items):
+            config.hook.pytest_deselected(items=[it for it in items if "variants" in it.keywords])
+            items[:] = keep
     if reference_available():
         return
     skip = pytest.mark.skip(reason="/root/reference not present (GPU box): replayed from tests/golden instead")

@@ -150,14 +150,10 @@ def test_conv_plan_tile_selection(built_lib, monkeypatch):
 
     L.load().vt_reset_options()
     big = ops.conv_plan(desc((1280, 1024), 256, 256))            # the 256-channel level of the benchmark (B=4: 20 frames), K = 2 304
-    assert big["tile"] == (256, 256) and big["waves"] == 8 and big["workgroups"] == 5120 and not big["half_tile"] and big["lds_epilogue"]
-    with L.options(conv_half256=2304, conv_half_plain=1):       # option conv_half256 = K bound: 128 x 256 half tiles, two workgroups per CU
-        big = ops.conv_plan(desc((1280, 1024), 256, 256))
-        assert big["tile"] == (128, 256) and big["waves"] == 4 and big["workgroups"] == 10240 and big["half_tile"] and big["lds_epilogue"]
-        long_k = ops.conv_plan(desc((1280, 1024), 512, 256, ldw=9 * 512))                 # K = 4 608: the 8-wave tile
-        assert long_k["tile"] == (256, 256) and not long_k["half_tile"]
-        assert not ops.conv_plan(desc((128, 128), 256, 256))["half_tile"]                 # 128 half tiles: not two per CU
-        assert not ops.conv_plan(desc((1280, 1024), 256, 256, dtype=L.VT_F32, out_dtype=L.VT_F32))["half_tile"]
+    assert big["tile"] == (256, 256) and big["waves"] == 8 and big["workgroups"] == 5120 and big["lds_epilogue"]
+    f16 = ops.conv_plan(desc((1280, 1024), 256, 256, dtype=L.VT_F16, out_dtype=L.VT_F16))      # fp16: every decision of bf16
+    assert f16 == big
+    assert not ops.conv_plan(desc((1280, 1024), 256, 256, dtype=L.VT_F32, out_dtype=L.VT_F32))["lds_epilogue"]   # plain fp32 rows: the vector epilogue
     small = ops.conv_plan(desc((64, 64), 256, 256))
     assert small["tile"] == (128, 128) and small["deep_ring"] and not small["lds_epilogue"]      # 64 tiles <= CUs: 4-slot ring
     with L.options(conv_deep=0):
@@ -181,9 +177,7 @@ def test_conv_plan_tile_selection(built_lib, monkeypatch):
     # the weight-stationary persistent kernel: bf16, 3x3, Cin = Cout = 128, frames tiling by 8 x 16
     p = ops.conv_plan(desc((256, 256), 128, 128))
     assert p["kernel"] == "ws2" and p["tile"] == (64, 128) and p["waves"] == 8 and p["workgroups"] == 64 * 16      # conv_ws2.hip: 4 x 16-pixel tiles
-    with L.options(conv_ws=1):
-        p = ops.conv_plan(desc((256, 256), 128, 128))
-        assert p["kernel"] == "ws128" and p["tile"] == (128, 128) and p["waves"] == 4 and p["workgroups"] == 32 * 16  # conv_ws128.hip: 8 x 16
+    assert ops.conv_plan(desc((256, 256), 128, 128, dtype=L.VT_F16, out_dtype=L.VT_F16)) == p
     assert ops.conv_plan(desc((256, 256), 128, 128, **dict(ln, ldn=128)))["ln_fused"]
     assert ops.conv_plan(desc((256, 250), 128, 128))["kernel"] == "igemm"
     assert ops.conv_plan(desc((256, 256), 128, 128, dtype=L.VT_F32, out_dtype=L.VT_F32))["kernel"] == "igemm"
@@ -210,7 +204,8 @@ def test_conv_plan_tile_selection(built_lib, monkeypatch):
     assert lib.vt_conv_work_bytes(C.byref(deep)) == 3 * 4096 * 512 * 4 and ops.conv_plan(deep)["launches"] == 2     # the three rows of the 3 x 3 + the reduction
     assert lib.vt_conv_work_bytes(C.byref(desc((64, 64), 512, 512, B=8))) == 8 * 3 * 4096 * 512 * 4                # a batch of such clips splits too
     assert lib.vt_conv_work_bytes(C.byref(desc((256, 256), 512, 512))) == 0                                        # 65 536 pixels per clip: enough tiles
-    assert lib.vt_conv_work_bytes(C.byref(desc((64, 64), 512, 512, dtype=L.VT_F32, out_dtype=L.VT_F32))) == 0      # bf16 only
+    assert lib.vt_conv_work_bytes(C.byref(desc((64, 64), 512, 512, dtype=L.VT_F32, out_dtype=L.VT_F32))) == 0      # the 16-bit types only
+    assert lib.vt_conv_work_bytes(C.byref(desc((64, 64), 512, 512, work=4096, dtype=L.VT_F16, out_dtype=L.VT_F16))) == 3 * 4096 * 512 * 4
     assert lib.vt_conv_work_bytes(C.byref(desc((64, 64), 128, 512, ldw=9 * 128))) == 0                              # K = 1 152: too short to pay
     with L.options(conv_splitk=0):
         assert lib.vt_conv_work_bytes(C.byref(deep)) == 0 and ops.conv_plan(deep)["launches"] == 1
@@ -232,17 +227,17 @@ def test_options_table(built_lib, monkeypatch):
     with pytest.raises(L.VtError):
         L.get_option("no_such_option")
     built_lib.vt_reset_options()
-    assert L.get_option("conv_sched") == 2 and L.get_option("conv_tile_min") == 128
-    with L.options(conv_sched=0, conv_tile_min=7):
-        assert L.get_option("conv_sched") == 0 and L.get_option("conv_tile_min") == 7
-        monkeypatch.setenv("VT_CONV_SCHED", "1")          # the environment is not consulted after start-up ...
-        assert L.get_option("conv_sched") == 0
-    assert L.get_option("conv_sched") == 2
+    assert L.get_option("conv_ws") == 2 and L.get_option("conv_tile_min") == 128
+    with L.options(conv_ws=0, conv_tile_min=7):
+        assert L.get_option("conv_ws") == 0 and L.get_option("conv_tile_min") == 7
+        monkeypatch.setenv("VT_CONV_WS", "1")          # the environment is not consulted after start-up ...
+        assert L.get_option("conv_ws") == 0
+    assert L.get_option("conv_ws") == 2
     built_lib.vt_reset_options()                           # ... except by an explicit reset
-    assert L.get_option("conv_sched") == 1
-    monkeypatch.delenv("VT_CONV_SCHED")
+    assert L.get_option("conv_ws") == 1
+    monkeypatch.delenv("VT_CONV_WS")
     built_lib.vt_reset_options()
-    assert L.get_option("conv_sched") == 2
+    assert L.get_option("conv_ws") == 2
 
 
 def test_bench_committed_traffic_fallback(tmp_path, monkeypatch):

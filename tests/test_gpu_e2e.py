@@ -24,6 +24,13 @@ DEV = "cuda"
 # accuracy in a kernel turns these red.  test_bf16_vs_autocast_oracle additionally pins the bf16 path to the
 # oracle run under torch.autocast(bfloat16) on the same GPU (the reference's own bf16 mode).
 BF16_RECON, BF16_Z, BF16_CODE_RATE = 5e-2, 2e-2, 0.9
+# fp16 gates (round 6: the reference's README precision, torch.autocast(dtype=torch.float16)): 11 significant bits against bf16's 8 --
+# the oracle under autocast(float16) sits at z 1.6e-3 / reconstruction 3.2e-3 from the fp32 oracle on a 17x64x64 clip (host run)
+F16 = torch.float16
+H16 = (torch.bfloat16, F16)
+RECON = {torch.bfloat16: BF16_RECON, F16: 1e-2}
+ZTOL = {torch.bfloat16: BF16_Z, F16: 5e-3}
+CODE_RATE = {torch.bfloat16: BF16_CODE_RATE, F16: 0.98}
 # A code flip is a coin toss at a rounding boundary, so an absolute rate gate on the 320 tokens of a 17x64x64 clip is noise
 # (288..297 of 320 across summation orders): the bf16 FSQ cases of test_matches_cpu_oracle run 17x128x128 clips (1 280 / 768
 # tokens) and are gated RELATIVE to the reference's own bf16 mode on the same clip -- the oracle under torch.autocast(bfloat16)
@@ -32,9 +39,9 @@ BF16_RECON, BF16_Z, BF16_CODE_RATE = 5e-2, 2e-2, 0.9
 BF16_CODE_RATE_VS_AUTOCAST = 0.03
 
 
-def _autocast_oracle_codes(ora, x):
-    """FSQ codes of the oracle run the way the reference runs bf16: encoder under torch.autocast(bfloat16), regulariser in fp32"""
-    with torch.autocast("cpu", dtype=torch.bfloat16):
+def _autocast_oracle_codes(ora, x, dtype=torch.bfloat16):
+    """FSQ codes of the oracle run the way the reference runs bf16 / fp16: encoder under torch.autocast(dtype), regulariser in fp32"""
+    with torch.autocast("cpu", dtype=dtype):
         h = ora.pre_quant(x)
     return ora.regularize(h.float())[1]["indices"]
 
@@ -77,6 +84,11 @@ def _decode_err_on_oracle_codes(model, log2, dec2):
     ("vidtok_kl_causal_488_4chn", (2, 3, 17, 64, 64), torch.bfloat16, BF16_RECON),
     ("vidtok_fsq_causal_488_32768", (1, 3, 17, 128, 128), torch.bfloat16, BF16_RECON),     # 1 280 tokens: the code-rate gates need draws
     ("vidtok_kl_causal_488_16chn", (1, 3, 9, 40, 24), torch.bfloat16, BF16_RECON),
+    ("vidtok_kl_causal_488_4chn", (2, 3, 17, 64, 64), F16, RECON[F16]),
+    ("vidtok_fsq_causal_488_32768", (1, 3, 17, 128, 128), F16, RECON[F16]),
+    ("vidtok_kl_causal_488_16chn", (1, 3, 9, 40, 24), F16, RECON[F16]),
+    ("vidtok_kl_noncausal_488_4chn", (1, 3, 16, 64, 64), F16, RECON[F16]),
+    ("vidtok_v1_1/vidtok_fsq_causal_888_32768_v1_1", (1, 3, 17, 128, 128), F16, RECON[F16]),
     ("vidtok_kl_noncausal_488_4chn", (2, 3, 16, 64, 64), torch.float32, 1e-3),
     ("vidtok_kl_noncausal_488_4chn", (1, 3, 16, 64, 64), torch.bfloat16, BF16_RECON),
     ("vidtok_fsq_noncausal_41616_262144", (1, 3, 8, 64, 64), torch.float32, 1e-3),
@@ -122,7 +134,7 @@ def test_matches_cpu_oracle(name, shape, dtype, tol):
     ez, ed = rel_err(z, z2), rel_err(dec, dec2)
     print(f"{name} {shape} {dtype}: z rel {ez:.3e} dec rel {ed:.3e}")
     assert dec.shape == dec2.shape
-    if "indices" in log2 and dtype == torch.bfloat16:
+    if "indices" in log2 and dtype in H16:
         # a bf16 latent next to a rounding boundary flips a code (the reference's own bf16 mode agrees with its fp32
         # mode on ~94 % of the codes, SURVEY.md finding 5), and one flipped code moves the max-norm of the
         # reconstruction by more than any kernel error: the decoder is therefore gated on the ORACLE's codes
@@ -131,18 +143,18 @@ def test_matches_cpu_oracle(name, shape, dtype, tol):
         assert ed_codes < tol
     else:
         assert ed < tol
-    if "indices" not in log2 or dtype != torch.bfloat16:
+    if "indices" not in log2 or dtype not in H16:
         # (bf16 FSQ latents are code values: compared through the match rate below)
-        assert ez < (tol if dtype != torch.bfloat16 else BF16_Z)
+        assert ez < (tol if dtype not in H16 else ZTOL[dtype])
     if "indices" in log2:
         rate = (log["indices"].cpu() == log2["indices"]).float().mean().item()
         print(f"{name} {dtype}: FSQ code match rate {rate:.5f} over {log2['indices'].numel()} tokens")
         # fp32 kernels: every code (measured everywhere; north_star: bit-exact); split-bf16: these clips measure 1.0 too, the
         # gate leaves room for one boundary case per thousand tokens
-        if dtype == torch.bfloat16:
-            r_auto = (_autocast_oracle_codes(ora, x) == log2["indices"]).float().mean().item()
-            print(f"{name} {dtype}: the oracle under autocast(bfloat16) on the same clip: {r_auto:.5f}")
-            assert rate >= r_auto - BF16_CODE_RATE_VS_AUTOCAST and rate >= BF16_CODE_RATE - 0.02
+        if dtype in H16:
+            r_auto = (_autocast_oracle_codes(ora, x, dtype) == log2["indices"]).float().mean().item()
+            print(f"{name} {dtype}: the oracle under autocast({dtype}) on the same clip: {r_auto:.5f}")
+            assert rate >= r_auto - BF16_CODE_RATE_VS_AUTOCAST and rate >= CODE_RATE[dtype] - 0.02
         else:
             assert rate == 1.0 if dtype == torch.float32 else rate >= 0.999
         # the quantiser itself is exact: feeding the oracle's own pre-quantisation h gives its codes
@@ -235,7 +247,7 @@ def test_v11_long_video_tiled_matches_oracle():
     assert dec.shape == x.shape and rel_err(z, z2) < 1e-3 and rel_err(dec, dec2) < 1e-3
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, X3], ids=["f32", "bf16", "bf16x3"])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, X3, F16], ids=["f32", "bf16", "bf16x3", "f16"])
 def test_full_size_properties(dtype):
     """BASELINE.json size (17x256x256): properties that need no oracle."""
     model, cfg, sd = build_model("vidtok_fsq_causal_488_32768", seed=23, device=DEV, dtype=dtype)
@@ -303,7 +315,7 @@ FULL = [("vidtok_kl_causal_488_4chn", (2, 3, 17, 256, 256)), ("vidtok_fsq_causal
         ("vidtok_kl_causal_488_16chn", (2, 3, 17, 256, 256))]
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, X3], ids=["f32", "bf16", "bf16x3"])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, X3, F16], ids=["f32", "bf16", "bf16x3", "f16"])
 @pytest.mark.parametrize("name,shape", FULL, ids=["kl_4chn_B2", "fsq_B1", "kl_16chn_B2"])
 def test_full_size_matches_cpu_oracle(name, shape, dtype):
     cfg, sd, x, (z2, dec2, log2) = _oracle_full(name, shape, 33)
@@ -313,14 +325,14 @@ def test_full_size_matches_cpu_oracle(name, shape, dtype):
     ez, ed = rel_err(z, z2), rel_err(dec, dec2)
     print(f"FULL {name} {shape} {dtype}: z rel {ez:.3e} dec rel {ed:.3e}")
     assert dec.shape == dec2.shape
-    if dtype != torch.bfloat16:
+    if dtype not in H16:
         assert ez < 1e-3 and ed < 1e-3
     elif "indices" in log2:
         ed_codes = _decode_err_on_oracle_codes(model, log2, dec2)   # see test_matches_cpu_oracle: gate on equal codes
         print(f"FULL {name} {dtype}: dec rel on the oracle's codes {ed_codes:.3e}")
-        assert ed_codes < BF16_RECON
+        assert ed_codes < RECON[dtype]
     else:
-        assert ed < BF16_RECON and ez < BF16_Z
+        assert ed < RECON[dtype] and ez < ZTOL[dtype]
     if "indices" in log2:
         n_bad = int((log["indices"].cpu() != log2["indices"]).sum())
         print(f"FULL {name} {dtype}: {n_bad} of {log2['indices'].numel()} FSQ codes differ")
@@ -329,7 +341,7 @@ def test_full_size_matches_cpu_oracle(name, shape, dtype):
         elif dtype == X3:
             assert n_bad <= 5                      # split-bf16: >= 99.9 % of the 5 120 codes (measured: 0 differ)
         else:
-            assert n_bad <= (1 - BF16_CODE_RATE) * log2["indices"].numel()
+            assert n_bad <= (1 - CODE_RATE[dtype]) * log2["indices"].numel()
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, X3], ids=["f32", "bf16", "bf16x3"])
@@ -349,7 +361,7 @@ def test_full_size_v11_tiled_matches_cpu_oracle(dtype):
     assert (ez < 1e-3 and ed < 1e-3) if dtype != torch.bfloat16 else (ez < BF16_Z and ed < BF16_RECON)
 
 
-@pytest.mark.parametrize("dtype", [torch.bfloat16, X3, torch.float32], ids=["bf16", "bf16x3", "f32"])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, X3, torch.float32, F16], ids=["bf16", "bf16x3", "f32", "f16"])
 def test_configs4_long_video_tiled_matches_cpu_oracle(dtype):
     """BASELINE.json configs[4] AT ITS STATED LENGTH: vidtok_kl_causal_488_16chn_v1_1, one clip of 129x256x256, t_chunk_enc = 16
     temporal tiling with decoder look-ahead, against the CPU oracle running the same tiled protocol (one ~4-minute host run,
@@ -363,47 +375,48 @@ def test_configs4_long_video_tiled_matches_cpu_oracle(dtype):
     ez, ed = rel_err(z, z2), rel_err(dec, dec2)
     print(f"configs[4] tiled T=129 256x256 {dtype}: z rel {ez:.3e} dec rel {ed:.3e}")
     assert dec.shape == x.shape and z.shape == (1, 16, 33, 32, 32)
-    assert (ez < 1e-3 and ed < 1e-3) if dtype != torch.bfloat16 else (ez < BF16_Z and ed < BF16_RECON)
+    assert (ez < 1e-3 and ed < 1e-3) if dtype not in H16 else (ez < ZTOL[dtype] and ed < RECON[dtype])
 
 
 @pytest.mark.parametrize("name,shape", [("vidtok_kl_causal_488_4chn", (1, 3, 17, 128, 128)),
                                         ("vidtok_fsq_causal_488_32768", (1, 3, 17, 64, 64)),
                                         ("vidtok_kl_causal_488_4chn", (1, 3, 17, 256, 256))], ids=["kl_128", "fsq_64", "kl_256_benchmarked_size"])
-def test_bf16_vs_autocast_oracle(name, shape):
-    """bf16 kernels vs the reference's own bf16 mode -- the oracle's functional torch graph run
-    under torch.autocast(bfloat16), regulariser in fp32 like the reference's autocast(enabled=False) block.  The
+@pytest.mark.parametrize("adt", H16, ids=["bf16", "f16"])
+def test_16bit_vs_autocast_oracle(name, shape, adt):
+    """the bf16 / fp16 kernels vs the reference's own bf16 / fp16 mode (fp16 is the dtype of its README snippets)
+    -- the oracle's functional torch graph run under torch.autocast(that dtype), regulariser in fp32 like the reference's autocast(enabled=False) block.  The
     autocast run is on the host (torch's CPU bf16 kernels): on this stack MIOpen's bf16 conv3d search takes minutes per
     layer shape (measured: the GPU variant of this test did not finish in 15 min).  Both are compared with the fp32
     CPU oracle: the HIP bf16 path must not be further from fp32 than 2x the autocast run is."""
-    model, cfg, sd = build_model(name, seed=35, device=DEV, dtype=torch.bfloat16)
+    model, cfg, sd = build_model(name, seed=35, device=DEV, dtype=adt)
     ora = build_oracle(cfg, sd)
     ora.sample = False
     if hasattr(model.regularization, "sample"):
         model.regularization.sample = False
     x = torch.rand(shape, generator=torch.Generator().manual_seed(42)) * 2 - 1
     z0, dec0, log0 = ora(x)                                        # fp32 CPU oracle
-    with torch.autocast("cpu", dtype=torch.bfloat16):
+    with torch.autocast("cpu", dtype=adt):
         h = ora.pre_quant(x)
     za, loga = ora.regularize(h.float())
-    with torch.autocast("cpu", dtype=torch.bfloat16):
+    with torch.autocast("cpu", dtype=adt):
         deca = ora.decode(za).float()
     z, dec, log = model(x.to(DEV))
     if "indices" in log0:
         r_ours = (log["indices"].cpu() == log0["indices"]).float().mean().item()
         r_auto = (loga["indices"] == log0["indices"]).float().mean().item()
-        print(f"bf16 {name}: FSQ code match vs fp32 oracle: HIP {r_ours:.4f}, autocast oracle {r_auto:.4f}")
-        assert r_ours >= BF16_CODE_RATE and r_ours >= r_auto - 0.03
+        print(f"{adt} {name}: FSQ code match vs fp32 oracle: HIP {r_ours:.4f}, autocast oracle {r_auto:.4f}")
+        assert r_ours >= CODE_RATE[adt] and r_ours >= r_auto - 0.03
         # decoders on equal codes (the fp32 oracle's)
-        with torch.autocast("cpu", dtype=torch.bfloat16):
+        with torch.autocast("cpu", dtype=adt):
             deca = ora.decode(z0).float()
         dec = model.decode(log0["indices"].to(DEV), decode_from_indices=True)[:, :, -dec0.shape[2]:]
     else:
         ez_ours, ez_auto = rel_err(z, z0), rel_err(za, z0)
-        print(f"bf16 {name}: z vs fp32 oracle: HIP {ez_ours:.3e}, autocast oracle {ez_auto:.3e}")
-        assert ez_ours < BF16_Z and ez_ours < 2.0 * ez_auto + 2e-3
+        print(f"{adt} {name}: z vs fp32 oracle: HIP {ez_ours:.3e}, autocast oracle {ez_auto:.3e}")
+        assert ez_ours < ZTOL[adt] and ez_ours < 2.0 * ez_auto + (2e-3 if adt == torch.bfloat16 else 3e-4)
     e_ours, e_auto, e_cross = rel_err(dec, dec0), rel_err(deca, dec0), rel_err(dec, deca)
-    print(f"bf16 {name}: recon vs fp32 oracle: HIP {e_ours:.3e}, autocast oracle {e_auto:.3e}; HIP vs autocast {e_cross:.3e}")
-    assert e_ours < BF16_RECON and e_ours < 2.0 * e_auto + 5e-3 and e_cross < 2.0 * BF16_RECON
+    print(f"{adt} {name}: recon vs fp32 oracle: HIP {e_ours:.3e}, autocast oracle {e_auto:.3e}; HIP vs autocast {e_cross:.3e}")
+    assert e_ours < RECON[adt] and e_ours < 2.0 * e_auto + (5e-3 if adt == torch.bfloat16 else 8e-4) and e_cross < 2.0 * RECON[adt]
 
 
 @pytest.mark.parametrize("name,shape,dtype", [("vidtok_fsq_causal_488_32768", (2, 3, 9, 64, 64), torch.bfloat16),
@@ -547,7 +560,7 @@ def test_encoder_tail_precision():
 
 
 # ---- the model handle of the C-ABI (vt_create / vt_load_weight / vt_encode / vt_regularize_* / vt_decode) -------------------
-@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32, X3], ids=["bf16", "f32", "bf16x3"])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32, X3, F16], ids=["bf16", "f32", "bf16x3", "f16"])
 @pytest.mark.parametrize("name,shape", [("vidtok_kl_causal_488_4chn", (2, 3, 9, 64, 64)), ("vidtok_kl_causal_488_4chn", (1, 3, 17, 256, 256)),
                                         ("vidtok_fsq_causal_488_32768", (1, 3, 17, 128, 128)), ("vidtok_kl_causal_41616_4chn", (1, 3, 9, 128, 128)),
                                         ("vidtok_v1_1/vidtok_kl_causal_488_4chn_v1_1", (2, 3, 18, 64, 64)),      # front pad 2, trilinear
@@ -612,7 +625,7 @@ def _handle_vs_engine(model, cfg, sd, shape, dtype):
             model._empty_causal_cached(part)
         model._set_first_chunk(True)
         model._set_fused_temporal()
-    L.check(lib.vt_create(C.byref(mc), {torch.bfloat16: L.VT_BF16, torch.float32: L.VT_F32, X3: L.VT_BF16X3}[dtype], C.byref(h)), "vt_create")
+    L.check(lib.vt_create(C.byref(mc), {torch.bfloat16: L.VT_BF16, torch.float32: L.VT_F32, X3: L.VT_BF16X3, F16: L.VT_F16}[dtype], C.byref(h)), "vt_create")
     try:
         names = [lib.vt_weight_name(h, i).decode() for i in range(lib.vt_weight_count(h))]
         assert set(names) == {k for k in sd if not k.startswith("regularization") or ".project_" in k}, \
@@ -680,7 +693,7 @@ def _make_handle(L, lib, cfg, sd, dtype):
     mc = handle_config(L, prm["encoder_config"]["params"], prm["regularizer_config"]["target"], prm["regularizer_config"].get("params", {}),
                         prm["encoder_config"]["target"])
     h = C.c_void_p()
-    L.check(lib.vt_create(C.byref(mc), {torch.bfloat16: L.VT_BF16, torch.float32: L.VT_F32, X3: L.VT_BF16X3}[dtype], C.byref(h)), "vt_create")
+    L.check(lib.vt_create(C.byref(mc), {torch.bfloat16: L.VT_BF16, torch.float32: L.VT_F32, X3: L.VT_BF16X3, F16: L.VT_F16}[dtype], C.byref(h)), "vt_create")
     for i in range(lib.vt_weight_count(h)):
         k = lib.vt_weight_name(h, i).decode()
         t = sd[k].detach().float().contiguous().cpu()
@@ -697,7 +710,8 @@ def _make_handle(L, lib, cfg, sd, dtype):
     ("vidtok_v1_1/vidtok_kl_causal_288_8chn_v1_1", (1, 3, 21, 64, 64), 8, True, torch.bfloat16),         # f = 2
     ("vidtok_v1_1/vidtok_kl_causal_488_4chn_v1_1:nearest", (1, 3, 25, 64, 64), 8, True, torch.bfloat16),
     ("vidtok_v1_1/vidtok_kl_causal_488_16chn_v1_1", (1, 3, 129, 256, 256), 16, True, torch.bfloat16),    # BASELINE configs[4] itself
-], ids=["kl16_t41", "kl16_t41_f32_b2", "kl16_t37_x3_no_overlap", "fsq888_t33", "kl288_t21", "kl488_nearest_t25", "configs4_129x256x256"])
+    ("vidtok_v1_1/vidtok_kl_causal_488_16chn_v1_1", (1, 3, 41, 64, 64), 16, True, F16),
+], ids=["kl16_t41", "kl16_t41_f32_b2", "kl16_t37_x3_no_overlap", "fsq888_t33", "kl288_t21", "kl488_nearest_t25", "configs4_129x256x256", "kl16_t41_f16"])
 def test_model_handle_tiled_matches_engine(name, shape, tc, overlap, dtype):
     """The v1.1 temporal tiling driven from C++ (vt_tile_encode / vt_tile_decode: chunk schedule, per-module causal caches owned
     by the handle, look-ahead decode with the doubling cache offsets) against the Python engine's tiled pass: same bits.
@@ -777,26 +791,34 @@ def test_model_handle_tiling_refused_for_v10():
 
 def test_autocast_region_selects_the_kernels():
     """The reference's README runs `model(x)` under torch.autocast (README.md:336-340,375-385).  The engine follows the caller's
-    context: autocast(bfloat16) = the bf16 kernels for that call (bit-identical to set_compute_dtype(bfloat16)), the chosen
-    mode returns afterwards; autocast(float16) raises (no fp16 arithmetic here, and another precision is never run silently)
-    unless set_autocast_policy maps it."""
+    context: autocast(bfloat16) / autocast(float16) = the bf16 / fp16 kernels for that call (bit-identical to
+    set_compute_dtype(that dtype)), the chosen mode returns afterwards; set_autocast_policy can map a region elsewhere; captured
+    graphs of both modes survive the switching (no recapture on every transition)."""
     name, shape = "vidtok_kl_causal_488_4chn", (1, 3, 9, 64, 64)
     model, cfg, sd = build_model(name, seed=31, device=DEV, dtype=torch.float32)
     model.regularization.sample = False
     x = (torch.rand(shape, generator=torch.Generator().manual_seed(3)) * 2 - 1).to(DEV)
     z32, dec32, _ = model(x)
-    with torch.no_grad(), torch.autocast(device_type="cuda", dtype=torch.bfloat16):
-        za, deca, _ = model(x)
-        assert model.arith == "bf16"
-        zb = model.encode(x)                                   # every entry point reads the context
-        assert torch.equal(zb, za)
-    z32b, dec32b, _ = model(x)                                 # the region ended: fp32 kernels again, same bits as before
-    assert model.arith == "fp32" and torch.equal(dec32b, dec32) and torch.equal(z32b, z32)
-    model.set_compute_dtype(torch.bfloat16)
-    z16, dec16, _ = model(x)
-    assert torch.equal(deca, dec16) and torch.equal(za, z16)
-    assert not torch.equal(dec16, dec32) and rel_err(dec16, dec32) < BF16_RECON
-    model.set_compute_dtype(torch.float32)
+    outs = {}
+    for adt, arith in ((torch.bfloat16, "bf16"), (torch.float16, "fp16")):
+        with torch.no_grad(), torch.autocast(device_type="cuda", dtype=adt):
+            za, deca, _ = model(x)
+            assert model.arith == arith
+            zb = model.encode(x)                                   # every entry point reads the context
+            assert torch.equal(zb, za)
+        z32b, dec32b, _ = model(x)                                 # the region ended: fp32 kernels again, same bits as before
+        assert model.arith == "fp32" and torch.equal(dec32b, dec32) and torch.equal(z32b, z32)
+        model.set_compute_dtype(adt)
+        z16, dec16, _ = model(x)
+        assert torch.equal(deca, dec16) and torch.equal(za, z16)
+        assert not torch.equal(dec16, dec32) and rel_err(dec16, dec32) < RECON[adt]
+        outs[arith] = dec16
+        model.set_compute_dtype(torch.float32)
+    assert not torch.equal(outs["bf16"], outs["fp16"])              # two arithmetics did run
+    with torch.autocast(device_type="cuda"):                       # scripts/inference_*.py --precision autocast: torch's default dtype = float16
+        model(x)
+        assert model.arith == "fp16"
+    model.set_autocast_policy(float16="error")
     with torch.autocast(device_type="cuda", dtype=torch.float16):
         with pytest.raises(NotImplementedError, match="float16"):
             model(x)
@@ -805,3 +827,47 @@ def test_autocast_region_selects_the_kernels():
         _, decx, _ = model(x)
         assert model.arith == "bf16x3"
     assert rel_err(decx, dec32) < 1e-3 and model(x) is not None and model.arith == "fp32"
+    # graphs: a caller alternating plain and autocast calls replays both captured sets
+    model.set_autocast_policy(float16="fp16").enable_graphs()
+    seen = []
+    for rnd in range(4):
+        _, d_plain, _ = model(x)
+        with torch.autocast(device_type="cuda", dtype=torch.float16):
+            _, d_auto, _ = model(x)
+        seen.append((d_plain, d_auto))
+        assert torch.equal(d_plain, dec32) and torch.equal(d_auto, outs["fp16"]), rnd
+    assert sum(1 for e in model._gdec.entries.values() if isinstance(e, tuple)) == 2      # one captured graph per mode, neither dropped
+    # an fp32 encoder tail chosen with the mode stays in force inside the region
+    model.enable_graphs(False).set_compute_dtype(torch.bfloat16, encoder_tail=torch.float32)
+    with torch.autocast(device_type="cuda", dtype=torch.float16):
+        model(x)
+        assert model.arith == "fp16" and model.encoder.tail_dtype == torch.float32
+
+
+def test_reference_readme_snippet_runs_unmodified():
+    """The "Easy Usage" snippet of the reference (README.md:324-341) with only the config's `target:` lines naming this package (the
+    shipped configs/*.yaml): load_model_from_config, .to('cuda').eval(), a random (1, 3, 17, 256, 256) clip, `model(x_input)` under
+    torch.autocast(device_type='cuda', dtype=torch.float16) -- and the timing loop of README.md:375-385.  The result is gated against
+    the fp32 kernels' on the same clip."""
+    import vidtok_amd
+    from util import config_path, seeded_state_dict
+
+    cfg_path = config_path("vidtok_kl_causal_488_4chn")
+    model = vidtok_amd.load_model_from_config(vidtok_amd.load_config(cfg_path), verbose=False)
+    model.load_state_dict(seeded_state_dict({k: v.shape for k, v in model.state_dict().items()}, 77))
+    model.to('cuda').eval()
+    num_frames = 17 if model.is_causal else 16
+    torch.manual_seed(0)
+    x_input = (torch.rand(1, 3, num_frames, 256, 256) * 2 - 1).to('cuda')
+    with torch.no_grad(), torch.autocast(device_type='cuda', dtype=torch.float16):
+        _, x_recon, _ = model(x_input)
+    assert x_input.shape == x_recon.shape and x_recon.dtype == torch.float32 and torch.isfinite(x_recon).all()
+    with torch.no_grad(), torch.autocast(device_type='cuda', dtype=torch.float16):
+        for i in range(3):
+            _, x_recon, _ = model(x_input)
+    torch.cuda.synchronize()
+    model.regularization.sample = False
+    with torch.no_grad(), torch.autocast(device_type='cuda', dtype=torch.float16):
+        _, r16, _ = model(x_input)
+    _, r32, _ = model(x_input)                                  # outside the region: the construction default, fp32 kernels
+    assert model.arith == "fp32" and rel_err(r16, r32) < RECON[F16]

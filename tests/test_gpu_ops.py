@@ -1,6 +1,10 @@
 """`-m gpu`: every HIP operator of libvidtok_amd.so against the plain PyTorch fp32 statement of its
 contract (tests/torch_ops_ref.py) on the same seeded inputs.  fp32 arithmetic must agree to fp32
-round-off (fmaf-chain MFMA), bf16 to bf16 round-off of the output; integer results bit-exactly."""
+round-off (fmaf-chain MFMA), bf16 / fp16 to that type's round-off of the output; integer results bit-exactly.
+
+Tiers: `-m gpu` runs the shipped paths (every kernel and every selectable option on both sides, at least once per
+arithmetic); `-m "gpu and variants"` adds the exhaustive cross products (every case x every arithmetic x every gather
+form) that earlier rounds ran by default -- the full matrix is for a changed kernel, not for every round."""
 import math
 
 import pytest
@@ -18,10 +22,21 @@ DEV = "cuda"
 # "x3" = vt_conv's split-bf16 arithmetic (VT_BF16X3): fp32 tensors, weights as bf16 hi / lo planes, three bf16 MFMAs per
 # product -- checked against the same fp32 statement as the fp32 kernels (measured 2e-6 .. 6e-6 of the output's max norm)
 X3 = "x3"
-TOL = {torch.float32: 2e-5, torch.bfloat16: 1.2e-2, X3: 4e-5}
+TOL = {torch.float32: 2e-5, torch.bfloat16: 1.2e-2, torch.float16: 1.5e-3, X3: 4e-5}
 DTYPES = [torch.float32, torch.bfloat16]
 DTYPES3 = DTYPES + [X3]
 IDS3 = ["f32", "bf16", "x3"]
+F16 = torch.float16
+DTYPES4 = DTYPES3 + [F16]          # every arithmetic of vt_conv
+IDS4 = IDS3 + ["f16"]
+H16 = [torch.bfloat16, F16]        # the 16-bit storage types: one kernel source, two instantiations
+H16_IDS = ["bf16", "f16"]
+variants = pytest.mark.variants    # exhaustive cross products: `-m "gpu and variants"`
+
+
+def _tier(values, ids, main):
+    """pytest params of `values`: those in `main` run with `-m gpu`, the others only with `-m "gpu and variants"`"""
+    return [pytest.param(v, id=i, marks=() if v in main else (variants,)) for v, i in zip(values, ids)]
 
 
 def _rand(shape, dtype, seed, scale=1.0):
@@ -99,7 +114,7 @@ CONV_CASES = [
 ]
 
 
-@pytest.mark.parametrize("dtype", DTYPES3, ids=IDS3)
+@pytest.mark.parametrize("dtype", DTYPES4, ids=IDS4)
 @pytest.mark.parametrize("case", CONV_CASES, ids=[c[0] for c in CONV_CASES])
 def test_conv(case, dtype):
     _check_conv(case, dtype)
@@ -124,10 +139,10 @@ CONV_CASES_LARGE = [
 ]
 
 
-@pytest.mark.parametrize("dtype", DTYPES3, ids=IDS3)
+@pytest.mark.parametrize("dtype", DTYPES4, ids=IDS4)
 @pytest.mark.parametrize("case", BIG256, ids=[c[0] for c in BIG256])
 def test_conv_forced_256_tile(case, dtype, vt_opts):
-    vt_opts(conv_tile=256, conv_half256=0)
+    vt_opts(conv_tile=256)
     plan = _check_conv(case, dtype)
     assert plan["tile"] == (256, 256)
     (B, T, H, W), cout = case[1], case[3]
@@ -135,7 +150,7 @@ def test_conv_forced_256_tile(case, dtype, vt_opts):
         assert plan["ln_fused"] and plan["launches"] == 1       # conv_epilogue_lds256
 
 
-@pytest.mark.parametrize("dtype", DTYPES3, ids=IDS3)
+@pytest.mark.parametrize("dtype", DTYPES4, ids=IDS4)
 @pytest.mark.parametrize("case", CONV_CASES_LARGE, ids=[c[0] for c in CONV_CASES_LARGE])
 def test_conv_large(case, dtype):
     plan = _check_conv(case, dtype)
@@ -145,7 +160,7 @@ def test_conv_large(case, dtype):
         assert plan["ln_fused"]
 
 
-# The weight-stationary persistent kernel (conv_ws128.hip) takes bf16 3x3 / Cin = Cout = 128 / frames tiling by 8 x 16:
+# The weight-stationary persistent kernel (conv_ws2.hip) takes 16-bit 3x3 / Cin = Cout = 128 / frames tiling by 8 x 16:
 # single-tile frames (every halo side out of range at once), tile rows / columns with one border, many tiles per
 # workgroup (double-buffered patch pipeline), + residual, LayerNorm fused with and without keeping y.  Each case also
 # runs with option conv_ws = 0 so the tile-per-workgroup kernel keeps its coverage of the same shapes.
@@ -162,12 +177,13 @@ WS_CASES = [
 ]
 
 
-@pytest.mark.parametrize("ws", ["1", "2", "0"], ids=["ws128", "ws2", "igemm"])
+@pytest.mark.parametrize("dtype", H16, ids=H16_IDS)
+@pytest.mark.parametrize("ws", ["2", "0"], ids=["ws2", "igemm"])
 @pytest.mark.parametrize("case", WS_CASES, ids=[c[0] for c in WS_CASES])
-def test_conv_weight_stationary(case, ws, vt_opts):
+def test_conv_weight_stationary(case, ws, dtype, vt_opts):
     vt_opts(conv_ws=ws)
-    plan = _check_conv(case, torch.bfloat16)
-    assert plan["kernel"] == {"0": "igemm", "1": "ws128", "2": "ws2"}[ws]
+    plan = _check_conv(case, dtype)
+    assert plan["kernel"] == {"0": "igemm", "2": "ws2"}[ws]
     if "ln" in case[6]:
         assert plan["ln_fused"]
 
@@ -189,8 +205,8 @@ NARROW_CASES = [   # conv3d_narrow_kernel: bf16 -> fp32 NCTHW, Cin 128, Cout <= 
 ]
 
 
-@pytest.mark.parametrize("dtype", [torch.bfloat16, X3], ids=["bf16", "x3"])
-@pytest.mark.parametrize("nw", ["1", "0"], ids=["narrow", "igemm"])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, X3, F16], ids=["bf16", "x3", "f16"])
+@pytest.mark.parametrize("nw", _tier(["1", "0"], ["narrow", "igemm"], main=["1"]))
 @pytest.mark.parametrize("case", NARROW_CASES, ids=[c[0] for c in NARROW_CASES])
 def test_conv_narrow_output(case, nw, dtype, vt_opts):
     """bf16, and the split-bf16 form (fp32 x, weight planes): two passes of the same kernel, hi plane -> y, lo plane onto y"""
@@ -225,11 +241,12 @@ TBLOCK_CASES = [  # (B, T, H, W), tmode, next norm (None | silu flag), keep_y
 ]
 
 
+@pytest.mark.parametrize("dt", H16, ids=H16_IDS)
 @pytest.mark.parametrize("shape,tmode,nxt,keep", TBLOCK_CASES, ids=[f"{c[0]}-{c[1]}-{c[2]}-{c[3]}" for c in TBLOCK_CASES])
-def test_temporal_block_fused(shape, tmode, nxt, keep):
+def test_temporal_block_fused(shape, tmode, nxt, keep, dt):
     """vt_temporal_block (one launch) vs the unfused operator sequence it replaces, stated in torch on the host"""
     B, T, H, W = shape
-    dt, C_ = torch.bfloat16, 128
+    C_ = 128
     x = _act(B, T, H, W, C_, dt, 1)
     g = torch.Generator().manual_seed(2)
     ws = [pack_conv_weight(torch.randn((C_, C_, 3), generator=g) / math.sqrt(3 * C_), dt, cin_stored=C_).to(DEV) for _ in range(2)]
@@ -257,15 +274,16 @@ def test_temporal_block_fused(shape, tmode, nxt, keep):
     assert not ops.temporal_block_supported(x, L.VT_TPAD_CACHE)          # cache mode without caches
 
 
+@pytest.mark.parametrize("dt", H16, ids=H16_IDS)
 @pytest.mark.parametrize("shape,off,cuts", [((2, 14, 16, 16), 0, (5, 9)), ((1, 26, 64, 64), 4, (9, 17)), ((3, 12, 24, 48), 2, (6,))],
                          ids=["two_cuts", "lookahead_4_256_columns", "lookahead_2_uneven_split"])
-def test_temporal_block_chunked(shape, off, cuts):
+def test_temporal_block_chunked(shape, off, cuts, dt):
     """v1.1 tiling through the fused launch (VERDICT r2 #5a): a clip run as chunks -- first chunk with replicate padding,
     later ones from the chunk state the launch itself keeps (caches of BOTH convolutions' inputs, rewritten in place,
     `cache_offset` look-ahead frames recomputed by the next chunk: reference model_3dcausal_v1_1.py:159-178) -- must give
     the bits of the same clip run in one launch: the ring rows a chunk restores are the ring rows the previous one had."""
     B, T, H, W = shape
-    dt, C_ = torch.bfloat16, 128
+    C_ = 128
     x = _act(B, T, H, W, C_, dt, 1)
     g = torch.Generator().manual_seed(2)
     ws = [pack_conv_weight(torch.randn((C_, C_, 3), generator=g) / math.sqrt(3 * C_), dt, cin_stored=C_).to(DEV) for _ in range(2)]
@@ -292,11 +310,12 @@ def test_temporal_block_chunked(shape, off, cuts):
     assert not ops.temporal_block_supported(x[:, :off + 2].contiguous(), L.VT_TPAD_CACHE, None, caches, off)
 
 
-def test_weight_stationary_kernels_are_split_independent():
+@pytest.mark.parametrize("dt", H16, ids=H16_IDS)
+def test_weight_stationary_kernels_are_split_independent(dt):
     """A pixel's bits must not depend on which workgroup / code path computed it: run-to-run equality and
     batch slice == batch of one for the persistent kernels (their row phases exist in a sliced and a plain version);
     the 3x3 kernel without LayerNorm is moreover bit-identical to the tile-per-workgroup kernel (same fp32 sums)."""
-    dt, C_ = torch.bfloat16, 128
+    C_ = 128
     B, T, H, W = 2, 5, 128, 128
     x, res = _act(B, T, H, W, C_, dt, 1), _act(B, T, H, W, C_, dt, 2)
     g = torch.Generator().manual_seed(3)
@@ -305,21 +324,15 @@ def test_weight_stationary_kernels_are_split_independent():
     ln = (_rand((C_,), torch.float32, 5, 0.3) + 1.0, _rand((C_,), torch.float32, 6, 0.2), 1e-6, True)
     tup = lambda o: o if isinstance(o, tuple) else (o,)
     for kw in ({}, dict(res=res, res_mode=L.VT_RES_ADD), dict(res=res, res_mode=L.VT_RES_ADD, ln=ln), dict(ln=ln, ln_keep_y=False)):
-        gens = {}
-        for gen in (1, 2):                               # both generations of the weight-stationary kernel
-            with L.options(conv_ws=gen):
-                a = tup(ops.conv(x, w, bias, ConvGeom(**G3), cout=C_, **kw))
-                b = tup(ops.conv(x, w, bias, ConvGeom(**G3), cout=C_, **kw))
-                kw1 = dict(kw, res=res[1:2].contiguous()) if "res" in kw else kw
-                one = tup(ops.conv(x[1:2].contiguous(), w, bias, ConvGeom(**G3), cout=C_, **kw1))
-            assert all(torch.equal(u, v) for u, v in zip(a, b)) and all(torch.equal(u[1:2], v) for u, v in zip(a, one)), (gen, kw.keys())
-            gens[gen] = a
-        # same fp32 chains and the same row arithmetic in both generations
-        assert all(torch.equal(u, v) for u, v in zip(gens[1], gens[2])), kw.keys()
+        a = tup(ops.conv(x, w, bias, ConvGeom(**G3), cout=C_, **kw))
+        b = tup(ops.conv(x, w, bias, ConvGeom(**G3), cout=C_, **kw))
+        kw1 = dict(kw, res=res[1:2].contiguous()) if "res" in kw else kw
+        one = tup(ops.conv(x[1:2].contiguous(), w, bias, ConvGeom(**G3), cout=C_, **kw1))
+        assert all(torch.equal(u, v) for u, v in zip(a, b)) and all(torch.equal(u[1:2], v) for u, v in zip(a, one)), kw.keys()
         if "ln" not in kw:
             with L.options(conv_ws=0):
                 ig = tup(ops.conv(x, w, bias, ConvGeom(**G3), cout=C_, **kw))
-            assert torch.equal(gens[1][0], ig[0])
+            assert torch.equal(a[0], ig[0])
     ws = [pack_conv_weight(torch.randn((C_, C_, 3), generator=g) / math.sqrt(3 * C_), dt, cin_stored=C_).to(DEV) for _ in range(2)]
     bs = [_rand((C_,), torch.float32, 7 + i, 0.1) for i in range(2)]
     nm = (ln[0], ln[1])
@@ -344,7 +357,7 @@ POINTER_CASES = [c for c in CONV_CASES if c[0] in ("conv2d_3x3_256_128_res", "co
 
 
 @pytest.mark.parametrize("tile", ["", "256"])
-@pytest.mark.parametrize("dtype", DTYPES3, ids=IDS3)
+@pytest.mark.parametrize("dtype", _tier(DTYPES4, IDS4, main=[torch.bfloat16]))
 @pytest.mark.parametrize("case", POINTER_CASES, ids=[c[0] for c in POINTER_CASES])
 def test_conv_pointer_gather(case, dtype, tile, vt_opts):
     """conv_buf = 0: the 64-bit pointer form of the gather (what tensors >= 4 GiB and v1.1 cache mode use)"""
@@ -357,35 +370,8 @@ def test_conv_pointer_gather(case, dtype, tile, vt_opts):
     assert not tile or plan["tile"] == (256, 256)
 
 
-# Every switch that selects between two implementations of one contract is exercised on both sides:
-# the K-step schedules of the 8-wave tile (conv_sched 0 plain / 1 schedule 1 / 2 two-group ping-pong), the Cout = 256
-# LayerNorm epilogue (fused or conv + vt_layernorm_act; both of its forms), the 128 x 128 tile with and without the
-# LDS-transposed epilogue (without it LayerNorm cannot be fused either).
 SCHED_CASES = [c for c in BIG256 if c[0] in ("nin_1x1_128_256", "nin_1x1_64_256_one_kstep", "temporal_k3_512", "conv3d_333_256", "v11_cache_1d", "nc_conv1d_sym_512",
                                              "conv3d_333_tinner_256", "conv2d_ln256_only", "conv2d_ln256_res_keep", "temporal_ln256_only")]
-
-
-@pytest.mark.parametrize("sched", [0, 1, 2])
-@pytest.mark.parametrize("case", SCHED_CASES + CONV_CASES_LARGE, ids=[c[0] for c in SCHED_CASES + CONV_CASES_LARGE])
-def test_conv_8wave_schedules(case, sched, vt_opts):
-    vt_opts(conv_sched=sched, conv_half256=0)
-    if case in SCHED_CASES:
-        vt_opts(conv_tile=256)
-    plan = _check_conv(case, torch.bfloat16)
-    small = (64, 128) if plan["kernel"] == "ws2" else (128, 128)        # (the Cin = Cout = 128 3 x 3 case runs on conv_ws2.hip)
-    assert plan["tile"] == ((256, 256) if case[3] % 256 == 0 else small)
-
-
-@pytest.mark.parametrize("sched", [0, 1, 2, 3, 4], ids=["plain_loop", "two_groups_dma_in_load", "two_groups_dma_in_compute", "two_groups_dma_split", "stream"])
-@pytest.mark.parametrize("case", SCHED_CASES + CONV_CASES_LARGE, ids=[c[0] for c in SCHED_CASES + CONV_CASES_LARGE])
-def test_conv_8wave_schedules_split_bf16(case, sched, vt_opts):
-    """split-bf16 arithmetic on the 8-wave tile (64-byte rows, 4-slot ring): schedule 3 (LOAD / COMPUTE phases, two wave
-    groups one barrier apart) and the plain K loop of the same instantiation"""
-    vt_opts(conv_sched_x3=sched)
-    if case in SCHED_CASES:
-        vt_opts(conv_tile=256)
-    plan = _check_conv(case, X3)
-    assert plan["tile"] == ((256, 256) if case[3] % 256 == 0 else (128, 128))
 
 
 # Cache mode (v1.1 chunks after the first) gathers through buffer descriptors when a tile lies inside one output frame
@@ -403,13 +389,11 @@ CACHE_BUF_CASES = [
 ]
 
 
-@pytest.mark.parametrize("dtype", DTYPES3, ids=IDS3)
-@pytest.mark.parametrize("gather", ["descriptors", "descriptors_plain_loop", "pointers"])
+@pytest.mark.parametrize("dtype", _tier(DTYPES4, IDS4, main=[torch.bfloat16, X3]))
+@pytest.mark.parametrize("gather", ["descriptors", "pointers"])
 @pytest.mark.parametrize("case", CACHE_BUF_CASES, ids=[c[0] for c in CACHE_BUF_CASES])
 def test_conv_cache_mode_gather_forms(case, gather, dtype, vt_opts):
-    vt_opts(conv_buf=(0 if gather == "pointers" else 1), conv_sched=(0 if gather == "descriptors_plain_loop" else 2))
-    if gather == "descriptors_plain_loop":
-        vt_opts(conv_sched_x3=0)
+    vt_opts(conv_buf=(0 if gather == "pointers" else 1))
     if case[3] % 256 == 0:
         vt_opts(conv_tile=256)
     plan = _check_conv(case, dtype)
@@ -432,13 +416,13 @@ DEEP_CASES = [
 ]
 
 
-@pytest.mark.parametrize("dtype", DTYPES3, ids=IDS3)
-@pytest.mark.parametrize("ring", ["deep", "deep_pointers", "two_slots"])
+@pytest.mark.parametrize("dtype", _tier(DTYPES4, IDS4, main=[torch.bfloat16]))
+@pytest.mark.parametrize("ring", _tier(["deep", "deep_pointers", "two_slots"], ["deep", "deep_pointers", "two_slots"], main=["deep", "two_slots"]))
 @pytest.mark.parametrize("case", DEEP_CASES, ids=[c[0] for c in DEEP_CASES])
 def test_conv_128_tile_rings(case, ring, dtype, vt_opts):
     vt_opts(conv_tile=128, conv_ws=0, conv_deep=(0 if ring == "two_slots" else 1), conv_buf=(0 if ring == "deep_pointers" else 1))
     plan = _check_conv(case, dtype)
-    steps = math.prod(case[4]) * case[2] // (64 if dtype == torch.bfloat16 else 32)
+    steps = math.prod(case[4]) * case[2] // (64 if dtype in H16 else 32)
     assert plan["tile"] == (128, 128) and plan["deep_ring"] == (ring != "two_slots" and steps >= 8), (plan, steps)
 
 
@@ -456,11 +440,12 @@ SPLITK_CASES = [
 ]
 
 
+@pytest.mark.parametrize("dtype", H16, ids=H16_IDS)
 @pytest.mark.parametrize("split", [1, 0], ids=["split", "whole"])
 @pytest.mark.parametrize("case", SPLITK_CASES, ids=[c[0] for c in SPLITK_CASES])
-def test_conv_split_k(case, split, vt_opts):
+def test_conv_split_k(case, split, dtype, vt_opts):
     vt_opts(conv_splitk=split)
-    plan = _check_conv(case, torch.bfloat16)
+    plan = _check_conv(case, dtype)
     extra = 1 if "ln" in case[6] else 0                      # Cout = 512: the LayerNorm is its own launch either way
     assert plan["launches"] == (2 if split else 1) + extra, plan
 
@@ -496,9 +481,9 @@ def test_conv_split_k_needs_scratch_and_small_m(vt_opts):
 @pytest.mark.parametrize("coalesced", [True, False], ids=["lds_epilogue", "vector_epilogue"])
 @pytest.mark.parametrize("case", [c for c in CONV_CASES_LARGE if c[3] % 256 == 0], ids=[c[0] for c in CONV_CASES_LARGE if c[3] % 256 == 0])
 def test_conv_8wave_plain_epilogues(case, coalesced, vt_opts):
-    """8-wave tile without LayerNorm: the LDS-transposed epilogue (bf16 full tiles; + residual / alpha-mix / interleaved
-    output frames) and the MFMA-layout vector epilogue it replaces, both against the reference"""
-    vt_opts(conv_ln256_v=(1 if coalesced else 0), conv_half256=0)
+    """8-wave tile without LayerNorm: the LDS-transposed epilogue (16-bit full tiles; + residual / alpha-mix / interleaved
+    output frames) and the MFMA-layout vector epilogue it replaces (option conv_ldsepi = 0), both against the reference"""
+    vt_opts(conv_ldsepi=(1 if coalesced else 0), conv_fuse_ln256=(1 if coalesced else 0))
     plan = _check_conv(case, torch.bfloat16)
     if plan["tile"] == (256, 256) and not plan["ln_fused"]:
         name, (B, T, H, W), cin, cout, kdims, geom, ex = case
@@ -511,63 +496,42 @@ LN256_CASES = [c for c in CONV_CASES if c[0] in ("conv2d_ln256_only", "conv2d_ln
               [c for c in CONV_CASES_LARGE if c[0] in ("L_conv2d_256_256_ln", "L_temporal_k3_256_ln_only")]
 
 
-@pytest.mark.parametrize("dtype", DTYPES3, ids=IDS3)
-@pytest.mark.parametrize("mode", ["unfused", "fused_v0", "fused_v1"])
+@pytest.mark.parametrize("dtype", DTYPES4, ids=IDS4)
+@pytest.mark.parametrize("mode", ["unfused", "fused"])
 @pytest.mark.parametrize("case", LN256_CASES, ids=[c[0] for c in LN256_CASES])
 def test_conv_ln256_variants(case, mode, dtype, vt_opts):
-    vt_opts(conv_tile=256, conv_fuse_ln256=(mode != "unfused"), conv_ln256_v=(1 if mode == "fused_v1" else 0), conv_half256=0)
+    vt_opts(conv_tile=256, conv_fuse_ln256=(mode != "unfused"))
     plan = _check_conv(case, dtype)
     assert plan["tile"] == (256, 256) and plan["ln_fused"] == (mode != "unfused") and plan["launches"] == (2 if mode == "unfused" else 1)
-
-
-# Half tiles (option conv_half256 = K bound): the bf16 launches of the 8-wave tile whose epilogue goes through the LDS -- with or
-# without a fused LayerNorm, residual added or alpha-mixed, interleaved output frames, cache-mode gather, frames-innermost tile
-# order, Cout = 512 (two channel tiles) -- run as 128 x 256 tiles on 4 waves, two workgroups per CU.  Same K order and the same
-# epilogue arithmetic per element: the results must equal the 8-wave tile's bit for bit.
-HALF_CASES = [c for c in CONV_CASES_LARGE if c[3] % 256 == 0]
-
-
-@pytest.mark.parametrize("sched", [0, 2], ids=["plain_loop", "schedule_1_two_stages_in_flight"])
-@pytest.mark.parametrize("case", HALF_CASES, ids=[c[0] for c in HALF_CASES])
-def test_conv_half_tile(case, sched, vt_opts):
-    vt_opts(conv_half256=1 << 20, conv_half_plain=1, conv_sched=sched)
-    half = []
-    plan = _check_conv(case, torch.bfloat16, keep_outputs=half)
-    assert plan["half_tile"] and plan["tile"] == (128, 256) and plan["waves"] == 4 and plan["lds_epilogue"] and plan["launches"] == 1, plan
-    vt_opts(conv_half256=0)
-    full = []
-    plan8 = _check_conv(case, torch.bfloat16, keep_outputs=full)
-    assert not plan8["half_tile"] and plan8["tile"] == (256, 256) and plan8["waves"] == 8 and plan8["workgroups"] * 2 == plan["workgroups"]
-    assert len(half) == len(full) and all(torch.equal(a, b) for a, b in zip(half, full))
-
-
-def test_conv_half_tile_bounds(vt_opts):
-    """the K bound, and not on launches too small to give both workgroup slots of every CU a tile / other arithmetic / ragged M"""
-    case = next(c for c in CONV_CASES_LARGE if c[0] == "L_conv2d_3x3_256_256")           # K = 2 304, 98 304 pixels
-    assert not _check_conv(case, torch.bfloat16)["half_tile"]                            # off by default (measured slower, DESIGN section 6)
-    vt_opts(conv_half256=2304)
-    assert not _check_conv(case, torch.bfloat16)["half_tile"]                            # no LayerNorm in this launch: conv_half_plain
-    vt_opts(conv_half_plain=1)
-    assert _check_conv(case, torch.bfloat16)["half_tile"]
-    vt_opts(conv_half256=2303)
-    assert not _check_conv(case, torch.bfloat16)["half_tile"]
-    vt_opts(conv_half256=1 << 20)
-    assert not _check_conv(case, torch.float32)["half_tile"] and not _check_conv(case, X3)["half_tile"]
-    small = next(c for c in BIG256 if c[0] == "conv2d_ln256_only")
-    vt_opts(conv_tile=256)
-    assert not _check_conv(small, torch.bfloat16)["half_tile"]
 
 
 LDSEPI_CASES = [c for c in CONV_CASES if c[0] in ("conv2d_3x3_128_128", "conv2d_3x3_256_128_res", "temporal_k3_tinner", "conv2d_ln_fused",
                                                   "conv2d_ln_fused_res_keep", "temporal_ln_fused")]
 
 
-@pytest.mark.parametrize("dtype", DTYPES3, ids=IDS3)
+@pytest.mark.parametrize("dtype", _tier(DTYPES4, IDS4, main=[torch.float32, torch.bfloat16]))
 @pytest.mark.parametrize("case", LDSEPI_CASES, ids=[c[0] for c in LDSEPI_CASES])
 def test_conv_without_lds_epilogue(case, dtype, vt_opts):
     vt_opts(conv_ldsepi=0, conv_ws=0)
     plan = _check_conv(case, dtype)
     assert plan["tile"] == (128, 128) and not plan["ln_fused"]
+
+
+# The host reference of a (case, arithmetic) does not depend on the options a test sets: the parametrisations that replay a case under
+# several options (gather forms, rings, split / whole, fused / unfused) share one evaluation of the torch statement -- the CPU
+# convolutions of the large cases are most of this file's run time.  A few most recent entries only (their outputs reach 100 MB).
+_REF_CACHE = {}
+
+
+def _ref_cached(key, fn):
+    if key in _REF_CACHE:
+        _REF_CACHE[key] = _REF_CACHE.pop(key)
+        return _REF_CACHE[key]
+    val = fn()
+    _REF_CACHE[key] = val
+    while len(_REF_CACHE) > 8:
+        _REF_CACHE.pop(next(iter(_REF_CACHE)))
+    return val
 
 
 def _check_conv(case, dtype, keep_outputs=None):
@@ -605,8 +569,8 @@ def _check_conv(case, dtype, keep_outputs=None):
         out = ops.conv(x, w, bias, geom, cout=cout, ln=(gam, bet, 1e-6, True), ln_keep_y=keep, **kw)
         rec, ops.CONV_RECORD = ops.CONV_RECORD, None
         torch.cuda.synchronize()
-        ref = R.conv(x.cpu(), w_rows.cpu(), None if bias is None else bias.cpu(), geom, cout=cout, ln=(gam.cpu(), bet.cpu(), 1e-6, True),
-                     ln_keep_y=keep, **_cpu(kw))
+        ref = _ref_cached((name, str(mode)), lambda: R.conv(x.cpu(), w_rows.cpu(), None if bias is None else bias.cpu(), geom, cout=cout,
+                                                            ln=(gam.cpu(), bet.cpu(), 1e-6, True), ln_keep_y=keep, **_cpu(kw)))
         outs, refs = (out if keep else (out,)), (ref if keep else (ref,))
         if keep_outputs is not None:
             keep_outputs.extend(outs)
@@ -620,7 +584,7 @@ def _check_conv(case, dtype, keep_outputs=None):
     y = ops.conv(x, w, bias, geom, cout=cout, **kw)
     rec, ops.CONV_RECORD = ops.CONV_RECORD, None
     torch.cuda.synchronize()
-    yr = R.conv(x.cpu(), w_rows.cpu(), None if bias is None else bias.cpu(), geom, cout=cout, **_cpu(kw))   # reference on the host
+    yr = _ref_cached((name, str(mode)), lambda: R.conv(x.cpu(), w_rows.cpu(), None if bias is None else bias.cpu(), geom, cout=cout, **_cpu(kw)))   # reference on the host
     assert y.shape == yr.shape and y.dtype == yr.dtype
     assert torch.isfinite(y.float()).all()
     if keep_outputs is not None:
@@ -631,7 +595,7 @@ def _check_conv(case, dtype, keep_outputs=None):
     return ops.conv_plan(rec[0][0])
 
 
-@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+@pytest.mark.parametrize("dtype", DTYPES + [F16], ids=["f32", "bf16", "f16"])
 @pytest.mark.parametrize("cout,hw", [(128, (16, 16)), (256, (8, 8)), (512, (5, 7))])
 def test_conv_output_frame_interleave(cout, hw, dtype):
     """yt_mul / yt_off: two k=2 launches fill the even / odd frames of one output (the parity convs of a time
@@ -655,7 +619,7 @@ def test_conv_output_frame_interleave(cout, hw, dtype):
     assert torch.isfinite(y.float()).all() and rel_err(y, yr) < TOL[dtype]
 
 
-@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+@pytest.mark.parametrize("dtype", DTYPES + [F16], ids=["f32", "bf16", "f16"])
 @pytest.mark.parametrize("cout,hw", [(128, (8, 16)), (256, (8, 8)), (512, (5, 7))])
 def test_conv_output_pixel_interleave(cout, hw, dtype):
     """ys_mul = 2: four 2x2 launches fill the parity classes of a 2H x 2W output (spatial up-sampler)"""
@@ -679,7 +643,7 @@ def test_conv_output_pixel_interleave(cout, hw, dtype):
     assert torch.isfinite(y.float()).all() and rel_err(y, yr) < 1.5 * TOL[dtype]
 
 
-@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+@pytest.mark.parametrize("dtype", DTYPES + [F16], ids=["f32", "bf16", "f16"])
 @pytest.mark.parametrize("Z,M,N,K,bcast,use_bias", [(3, 80, 48, 128, False, False), (2, 512, 64, 512, True, True),
                                                       (5, 16, 16, 16, False, False), (2, 100, 512, 104, False, True),
                                                       (2, 1024, 1024, 512, False, False)])
@@ -696,12 +660,12 @@ def test_gemm_nt(Z, M, N, K, bcast, use_bias, dtype):
 
 @pytest.mark.parametrize("Z,S,ld,use_bias", [(2, 64, 64, True), (3, 256, 256, False), (2, 1024, 1024, True), (1, 4096, 4096, True), (2, 128, 136, True)],
                          ids=["one_q_tile", "s256", "s1024_benchmark_size", "s4096_512x512_input", "padded_vT"])
-def test_flash_attention(Z, S, ld, use_bias):
+@pytest.mark.parametrize("dt", H16, ids=H16_IDS)
+def test_flash_attention(Z, S, ld, use_bias, dt):
     """vt_flash_attention (one launch, online softmax, nothing S x S in memory) against the fp32 statement of the attention and against
     the operator sequence it replaces (batched GEMM -> row softmax -> batched GEMM) on the same tensors: S = 1 024 is the attention of
     a 256 x 256 input, S = 4 096 of a 512 x 512 one"""
     C_ = 512
-    dt = torch.bfloat16
     q, k = _rand((Z, S, C_), dt, 1), _rand((Z, S, C_), dt, 2)
     v = _rand((Z, S, C_), dt, 3)
     vT = torch.zeros((Z, C_, ld), dtype=dt, device=DEV)
@@ -737,7 +701,8 @@ def test_flash_attention_declines_other_shapes(vt_opts):
 
 @pytest.mark.parametrize("C", [32, 64, 128, 256, 512, 1024])
 @pytest.mark.parametrize("din,dout", [(torch.float32, torch.float32), (torch.bfloat16, torch.bfloat16),
-                                      (torch.float32, torch.bfloat16), (torch.bfloat16, torch.float32)])
+                                      (torch.float32, torch.bfloat16), (torch.bfloat16, torch.float32),
+                                      (F16, F16), (torch.float32, F16), (F16, torch.float32)])
 @pytest.mark.parametrize("silu", [True, False])
 def test_layernorm_act(C, din, dout, silu):
     x = _rand((3, 7, 11, C), din, 1, 2.0) + 0.5
@@ -749,7 +714,7 @@ def test_layernorm_act(C, din, dout, silu):
 
 
 @pytest.mark.parametrize("cols", [16, 100, 1024])
-@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+@pytest.mark.parametrize("dtype", DTYPES + [F16], ids=["f32", "bf16", "f16"])
 def test_softmax_rows(cols, dtype):
     s = _rand((5, 33, cols), torch.float32, 1, 8.0)
     p = ops.softmax_rows(s, 0.0442, dtype)
@@ -758,7 +723,7 @@ def test_softmax_rows(cols, dtype):
     assert (p.float().sum(-1) - 1).abs().max() < (1e-5 if dtype == torch.float32 else 2e-2)
 
 
-@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+@pytest.mark.parametrize("dtype", DTYPES + [F16], ids=["f32", "bf16", "f16"])
 def test_layout_roundtrip(dtype):
     x = _rand((2, 3, 5, 6, 7), torch.float32, 1)
     y = ops.ncthw_to_ndhwc(x, dtype, tpad=3)
@@ -770,7 +735,7 @@ def test_layout_roundtrip(dtype):
     assert torch.equal(ops.ndhwc_to_ncthw(ops.ncthw_to_ndhwc(z, dtype), 16), z.to(dtype).float())
 
 
-@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+@pytest.mark.parametrize("dtype", DTYPES + [F16], ids=["f32", "bf16", "f16"])
 @pytest.mark.parametrize("tmode", [L.VT_TPAD_ZERO, L.VT_TPAD_REPLICATE, L.VT_TPAD_CACHE, L.VT_TPAD_ZERO_BACK])
 @pytest.mark.parametrize("Ti", [6, 9], ids=["T6", "T9odd"])
 def test_time_avgpool(dtype, tmode, Ti):
@@ -783,7 +748,7 @@ def test_time_avgpool(dtype, tmode, Ti):
     assert y.shape == (2, Ti // 2, 4, 4, 128) and rel_err(y, yr) < (1e-6 if dtype == torch.float32 else 8e-3)
 
 
-@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+@pytest.mark.parametrize("dtype", DTYPES + [F16], ids=["f32", "bf16", "f16"])
 @pytest.mark.parametrize("Ti", [1, 2, 5])
 def test_time_lerp2x(dtype, Ti):
     x = _act(2, Ti, 4, 4, 128, dtype, 1)
@@ -795,7 +760,7 @@ def test_time_lerp2x(dtype, Ti):
     assert torch.equal(out[:, 2:2 + 2 * Ti], y) and float(out[:, :2].float().abs().max()) == 0
 
 
-@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+@pytest.mark.parametrize("dtype", DTYPES + [F16], ids=["f32", "bf16", "f16"])
 @pytest.mark.parametrize("nh,T,skip", [(1, 4, 2), (2, 5, 4), (4, 8, 8), (2, 1, 0), (1, 3, 7)])
 def test_time_lerp2x_cat(dtype, nh, T, skip):
     """interpolation of [head | x] without assembling it, minus the first `skip` frames (v1.1 chunks after the first:
@@ -883,8 +848,8 @@ def test_fsq_aux_avg_and_entropy():
     assert torch.allclose(ops.entropy(avg).cpu(), R.entropy(avgr), rtol=2e-4)
 
 
-@pytest.mark.parametrize("din,dout", [(torch.float32, torch.float32), (torch.bfloat16, torch.bfloat16)],
-                         ids=["f32", "bf16"])
+@pytest.mark.parametrize("din,dout", [(torch.float32, torch.float32), (torch.bfloat16, torch.bfloat16), (F16, F16)],
+                         ids=["f32", "bf16", "f16"])
 @pytest.mark.parametrize("scope", [L.VT_GN_FRAME, L.VT_GN_PIXEL, L.VT_GN_CLIP, ops.GN_POS], ids=["frame", "pixel", "clip", "pos"])
 @pytest.mark.parametrize("C", [128, 512])
 def test_groupnorm_act(C, scope, din, dout):
@@ -932,7 +897,7 @@ TSKIP_CASES = [
 
 
 @pytest.mark.parametrize("tile", [0, 256], ids=["auto_tile", "tile256"])
-@pytest.mark.parametrize("dtype", DTYPES3, ids=IDS3)
+@pytest.mark.parametrize("dtype", _tier(DTYPES4, IDS4, main=[torch.float32, torch.bfloat16, X3]))
 @pytest.mark.parametrize("case", TSKIP_CASES, ids=[c[0] for c in TSKIP_CASES])
 def test_conv_time_tap_skip_is_bit_exact(case, dtype, tile, vt_opts):
     if tile == 256 and case[3] % 256 != 0:
@@ -970,7 +935,7 @@ def test_conv_split_k_does_not_depend_on_the_batch(vt_opts):
     assert torch.equal(ys["batch"][2:3], ys["alone"])
 
 
-@pytest.mark.parametrize("mode", ["f32", "bf16", "x3"])
+@pytest.mark.parametrize("mode", ["f32", "bf16", "x3", "f16"])
 def test_pack_conv_weight_on_device_equals_host_statements(mode):
     """vt_pack_conv_weight (the device packer PackedCache uses for GPU parameters: no ATen kernel in the process) against the torch
     statements of vidtok_amd/packing.py -- plain rows for 1-, 2- and 3-D kernels with channel padding, the pre-summed taps of the
@@ -979,7 +944,8 @@ def test_pack_conv_weight_on_device_equals_host_statements(mode):
 
     from vidtok_amd import packing as P
 
-    dtype = torch.bfloat16 if mode == "bf16" else torch.float32
+    dtype = {"bf16": torch.bfloat16, "f16": F16}.get(mode, torch.float32)
+    bits = torch.int16 if mode in ("bf16", "f16") else torch.int32
     g = torch.Generator().manual_seed(11)
     cases = [((16, 3, 3, 3, 3), 8, None, None), ((24, 20, 3), 24, None, None), ((8, 12, 3, 3), 16, None, None), ((40, 8, 1, 1, 1), 8, None, None)]
     for early in (True, False):
@@ -996,14 +962,14 @@ def test_pack_conv_weight_on_device_equals_host_statements(mode):
         got = ops.pack_conv_weight(w.to(DEV), dtype, cin_p, mix=None if mixf is None else mixf(tuple(shape[2:])), split3=mode == "x3")
         torch.cuda.synchronize()
         assert got.dtype == ref.dtype and got.shape == ref.shape, (shape, got.shape, ref.shape)
-        assert torch.equal(got.cpu().view(torch.int16 if mode == "bf16" else torch.int32), ref.view(torch.int16 if mode == "bf16" else torch.int32)), shape
+        assert torch.equal(got.cpu().view(bits), ref.view(bits)), shape
     # a PackedCache answers GPU parameters through the device packer and host parameters through the torch statements: same bits
     conv = torch.nn.Conv3d(8, 16, 3)
     pc_host, pc_dev = P.PackedCache(), P.PackedCache()
     wh, bh = pc_host.get(conv.weight, conv.bias, dtype, cin_stored=8)
     conv = conv.to(DEV)
     wd, bd = pc_dev.get(conv.weight, conv.bias, dtype, cin_stored=8)
-    assert wd.is_cuda and torch.equal(wd.cpu().view(torch.int16 if mode == "bf16" else torch.int32), wh.view(torch.int16 if mode == "bf16" else torch.int32)) and torch.equal(bd.cpu(), bh)
+    assert wd.is_cuda and torch.equal(wd.cpu().view(bits), wh.view(bits)) and torch.equal(bd.cpu(), bh)
 
 
 # conv_in8_kernel (option conv_in8, default on): the encoder's conv_in -- CausalConv3d 3 -> 128, 3 x 3 x 3 on the 8 stored input
@@ -1022,13 +988,14 @@ IN8_CASES = [
 ]
 
 
+@pytest.mark.parametrize("dt", H16, ids=H16_IDS)
 @pytest.mark.parametrize("case", IN8_CASES, ids=[c[0] for c in IN8_CASES])
-def test_conv_in8_kernel_equals_general_path(case, vt_opts):
+def test_conv_in8_kernel_equals_general_path(case, dt, vt_opts):
     outs = {}
     for on in (1, 0):
         vt_opts(conv_in8=on)
         keep = []
-        plan = _check_conv(case, torch.bfloat16, keep_outputs=keep)
+        plan = _check_conv(case, dt, keep_outputs=keep)
         assert plan["kernel"] == ("in8" if on else "igemm"), plan
         outs[on] = keep
     for a, b in zip(outs[1], outs[0]):

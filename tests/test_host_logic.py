@@ -338,8 +338,9 @@ def test_graph_cache_bookkeeping_and_engine_copies():
 
 def test_autocast_region_switches_the_arithmetic_mode():
     """AutoencodingEngine._sync_autocast (host logic only, no launch): the caller's torch.autocast region selects the kernels --
-    autocast(bfloat16) = bf16 whatever set_compute_dtype chose, the chosen mode (incl. an encoder tail) returns when the region ends,
-    autocast(float16) raises unless a policy maps it, "ignore" keeps the chosen mode, graphs are dropped on every switch."""
+    autocast(bfloat16) / autocast(float16) = the bf16 / fp16 kernels whatever set_compute_dtype chose, the chosen mode returns when
+    the region ends (an fp32 encoder tail chosen with it stays in force inside the region), a policy can map a region elsewhere or
+    refuse it, "ignore" keeps the chosen mode; captured graphs are kept across the switches (their keys carry the mode)."""
     model, cfg, sd = build_model("vidtok_kl_causal_488_4chn", seed=3)
     x = torch.zeros(1, 3, 5, 16, 16)
     assert model.arith == "fp32"
@@ -360,11 +361,23 @@ def test_autocast_region_switches_the_arithmetic_mode():
     assert model.arith == "bf16x3" and model.encoder.compute_dtype == torch.float32
     model.set_compute_dtype(torch.bfloat16, encoder_tail=torch.float32, tail_level=2)
     with torch.autocast("cpu", dtype=torch.bfloat16):
-        model._sync_autocast(x)                                    # bf16 asked, but the chosen mode has an fp32 tail: plain bf16 for the region
-        assert model.arith == "bf16" and model.encoder.tail_dtype is None
+        model._sync_autocast(x)                                    # bf16 asked and chosen: nothing to switch, the fp32 tail stays
+        assert model.arith == "bf16" and model.encoder.tail_dtype == torch.float32
+    with torch.autocast("cpu", dtype=torch.float16):
+        model._sync_autocast(x)                                    # fp16 for the region, the tail chosen with the mode stays in force
+        assert model.arith == "fp16" and model.encoder.compute_dtype == torch.float16
+        assert model.encoder.tail_dtype == torch.float32 and model.encoder.tail_level == 2
     model._sync_autocast(x)
-    assert model.encoder.tail_dtype == torch.float32 and model.encoder.tail_level == 2
+    assert model.arith == "bf16" and model.encoder.tail_dtype == torch.float32 and model.encoder.tail_level == 2
     model.set_compute_dtype(torch.float32)
+    model._genc.entries["kept"] = "warm"
+    with torch.autocast("cpu", dtype=torch.float16):
+        model._sync_autocast(x)                                    # the README's region: the fp16 kernels
+        assert model.arith == "fp16" and model.decoder.compute_dtype == torch.float16
+        assert "kept" in model._genc.entries                       # a mode switch does not drop captured graphs
+    model._sync_autocast(x)
+    assert model.arith == "fp32" and "kept" in model._genc.entries
+    model.set_autocast_policy(float16="error")
     with torch.autocast("cpu", dtype=torch.float16):
         with pytest.raises(NotImplementedError, match="float16"):
             model._sync_autocast(x)

@@ -13,8 +13,8 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libvidtok_amd.so")
-SOURCES = ["conv_igemm.hip", "conv_ws128.hip", "conv_ws2.hip", "conv_narrow.hip", "tblock_ws128.hip", "attention.hip", "pointwise.hip", "groupnorm.hip", "regularizers.hip", "metrics.hip", "video_io.hip", "packing.hip", "error.cpp", "options.cpp", "model.cpp"]
-HEADERS = ["common.h", "conv_common.h", "options.h", os.path.join("..", "..", "include", "vidtok_amd.h")]
+SOURCES = ["conv_igemm_bf16.hip", "conv_igemm_f16.hip", "conv_igemm_f32.hip", "conv_igemm_x3.hip", "conv_igemm.hip", "conv_in8.hip", "conv_ws2.hip", "conv_narrow.hip", "tblock_ws128.hip", "attention.hip", "pointwise.hip", "groupnorm.hip", "regularizers.hip", "metrics.hip", "video_io.hip", "packing.hip", "error.cpp", "options.cpp", "model.cpp"]
+HEADERS = ["common.h", "conv_common.h", "conv_select.h", "conv_igemm_kernel.h", "options.h", os.path.join("..", "..", "include", "vidtok_amd.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 # per-file additions.  conv_ws2.hip: its row arithmetic runs beside the partner wave's MFMAs, where packed fp32
 # (v_pk_*_f32, what the SLP vectoriser makes of eight parallel scalar chains) stalls the matrix pipe

@@ -33,16 +33,17 @@ constexpr int FA_VTILE = FA_D * FA_BK * 2;        // 32 768 B: [512 dims][64 B]
 constexpr int FA_STAGE = FA_KTILE + FA_VTILE;
 constexpr int FA_LDS = 2 * FA_STAGE;              // 131 072 B
 
-struct FlashArgs {
-  const bf16_t* q;      // [Z][S][512]
-  const bf16_t* k;      // [Z][S][512]
-  const bf16_t* vt;     // [Z][512][ldv]: V^T, keys contiguous
+struct FlashArgs {     // (uint16_t: elements of the launch's 16-bit storage type, bf16 or fp16)
+  const uint16_t* q;    // [Z][S][512]
+  const uint16_t* k;    // [Z][S][512]
+  const uint16_t* vt;   // [Z][512][ldv]: V^T, keys contiguous
   const float* bias_v;  // [512] or null
-  bf16_t* o;            // [Z][S][512]
+  uint16_t* o;          // [Z][S][512]
   int S, ldv;
   float scale_log2e;    // scale * log2(e): exp(scale * s - m) = exp2(scale_log2e * s - m')
 };
 
+template <typename H>
 __global__ __launch_bounds__(256, 1) void flash_attn_kernel(const FlashArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -52,9 +53,9 @@ __global__ __launch_bounds__(256, 1) void flash_attn_kernel(const FlashArgs p) {
   const int z = blockIdx.y, q0 = blockIdx.x * FA_BQ + wave * 16;
   const int S = p.S;
   const int n = lane & 15, g = lane >> 4;            // my query row (column of the products), my contraction group
-  const bf16_t* qz = p.q + (long long)z * S * FA_D;
-  const bf16_t* kz = p.k + (long long)z * S * FA_D;
-  const bf16_t* vz = p.vt + (long long)z * FA_D * p.ldv;
+  const uint16_t* qz = p.q + (long long)z * S * FA_D;
+  const uint16_t* kz = p.k + (long long)z * S * FA_D;
+  const uint16_t* vz = p.vt + (long long)z * FA_D * p.ldv;
 
   // ---- Q: B fragments of the first product, k-step ks = dims 32 ks + 8 g .. + 8 of row q0 + n
   u32x4 qf[16];
@@ -64,8 +65,8 @@ __global__ __launch_bounds__(256, 1) void flash_attn_kernel(const FlashArgs p) {
   // ---- tile DMA.  K tile: row r (key) = 1 024 B = 64 slots of 16 B, logical chunk c at slot c ^ (r % 16); instruction i of wave w
   // fills row 8 w + i (lane = slot).  V^T tile: row d (dimension) = 64 B = 4 slots, logical chunk c at slot c ^ ((d / 4) % 4);
   // instruction j of wave w fills rows 16 (8 w + j) .. + 15 (lane / 4 = row, lane % 4 = slot).
-  const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(kz), 0, (unsigned)S * FA_D * 2u, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(vz), 0, (unsigned)FA_D * (unsigned)p.ldv * 2u, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(kz), 0, (unsigned)S * FA_D * 2u, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(vz), 0, (unsigned)FA_D * (unsigned)p.ldv * 2u, 0x00020000);
   auto issue_tile = [&](int t, int stg) {
     char* kd = smem + stg * FA_STAGE;
     char* vd = kd + FA_KTILE;
@@ -105,8 +106,8 @@ __global__ __launch_bounds__(256, 1) void flash_attn_kernel(const FlashArgs p) {
       const int slot = ((4 * ks + g) ^ n) * 16;       // (row % 16 = n for both tiles)
       const u32x4 a0 = *reinterpret_cast<const u32x4*>(kt + n * 1024 + slot);
       const u32x4 a1 = *reinterpret_cast<const u32x4*>(kt + (16 + n) * 1024 + slot);
-      s0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a0), __builtin_bit_cast(bf16x8, qf[ks]), s0, 0, 0, 0);
-      s1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a1), __builtin_bit_cast(bf16x8, qf[ks]), s1, 0, 0, 0);
+      s0 = h16<H>::mfma16(a0, qf[ks], s0);
+      s1 = h16<H>::mfma16(a1, qf[ks], s1);
     }
     // ---- online softmax of my query row over the 32 keys of the tile (my 8 values + the other three lane groups')
     float v[8];
@@ -134,10 +135,10 @@ __global__ __launch_bounds__(256, 1) void flash_attn_kernel(const FlashArgs p) {
     m_run = m_new;
     // P^T as the B fragment of the second product: contraction slot (g, e) = key 16 (e / 4) + 4 g + e % 4
     u32x4 pf;
-    pf[0] = pack_bf16x2(pv[0], pv[1]);
-    pf[1] = pack_bf16x2(pv[2], pv[3]);
-    pf[2] = pack_bf16x2(pv[4], pv[5]);
-    pf[3] = pack_bf16x2(pv[6], pv[7]);
+    pf[0] = h16<H>::pack(pv[0], pv[1]);
+    pf[1] = h16<H>::pack(pv[2], pv[3]);
+    pf[2] = h16<H>::pack(pv[4], pv[5]);
+    pf[3] = h16<H>::pack(pv[6], pv[7]);
     // ---- O^T = alpha O^T + V^T P^T: 32 tiles of 16 dims; A fragment of dims row d = 16 mt + n: keys 4 g .. + 3 (logical chunk g / 2,
     // half g % 2) and 16 + 4 g .. + 3 (logical chunk 2 + g / 2)
     // (once the running maxima have settled alpha is exactly 1 for every row of the wave: the 128 multiplications are skipped --
@@ -156,12 +157,12 @@ __global__ __launch_bounds__(256, 1) void flash_attn_kernel(const FlashArgs p) {
       const u32x2 lo = *reinterpret_cast<const u32x2*>(row + (((g >> 1) ^ sw) * 16));
       const u32x2 hi = *reinterpret_cast<const u32x2*>(row + (((2 + (g >> 1)) ^ sw) * 16));
       const u32x4 a = u32x4{lo[0], lo[1], hi[0], hi[1]};
-      acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, pf), acc[mt], 0, 0, 0);
+      acc[mt] = h16<H>::mfma16(a, pf, acc[mt]);
     }
   }
   // ---- O[q][dims] = O^T / l + bias_v: a lane owns 4 consecutive dims of its row per tile (8-byte stores)
   const float inv = 1.0f / l_run;
-  bf16_t* orow = p.o + ((long long)z * S + q0 + n) * FA_D;
+  H* orow = reinterpret_cast<H*>(p.o) + ((long long)z * S + q0 + n) * FA_D;
 #pragma unroll
   for (int mt = 0; mt < 32; ++mt) {
     const int d0 = 16 * mt + 4 * g;
@@ -170,7 +171,7 @@ __global__ __launch_bounds__(256, 1) void flash_attn_kernel(const FlashArgs p) {
     float o[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) o[i] = acc[mt][i] * inv + b[i];
-    store_quad<bf16_t>(orow + d0, o);
+    store_quad<H>(orow + d0, o);
   }
 #endif
 }
@@ -178,7 +179,7 @@ __global__ __launch_bounds__(256, 1) void flash_attn_kernel(const FlashArgs p) {
 }  // namespace
 
 extern "C" int vt_flash_attention_supported(int32_t dtype, int32_t S, int32_t C, int32_t ldv) {
-  return vt_opt(OPT_ATTN_FLASH) != 0 && dtype == VT_BF16 && C == FA_D && S > 0 && S % FA_BQ == 0 && ldv >= S && ldv % 8 == 0 &&
+  return vt_opt(OPT_ATTN_FLASH) != 0 && vt_is_h16(dtype) && C == FA_D && S > 0 && S % FA_BQ == 0 && ldv >= S && ldv % 8 == 0 &&
          (long long)S * FA_D * 2 < 0xFFFF0000ll && (long long)FA_D * ldv * 2 < 0xFFFF0000ll;
 }
 
@@ -187,23 +188,24 @@ extern "C" int vt_flash_attention(const void* q, const void* k, const void* vt, 
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
   VT_CHECK_ARG(q && k && vt && o && Z > 0, "vt_flash_attention: null tensor or empty batch");
   VT_CHECK_ARG(vt_opt(OPT_ATTN_FLASH) != 0, "vt_flash_attention: switched off (option attn_flash = 0)");
-  VT_CHECK_ARG(vt_flash_attention_supported(dtype, S, C, ldv), "vt_flash_attention: bf16, C = 512, S %% 64 == 0, ldv >= S and %% 8 == 0 only (got dtype %d S %d C %d ldv %d)",
+  VT_CHECK_ARG(vt_flash_attention_supported(dtype, S, C, ldv), "vt_flash_attention: bf16 / fp16, C = 512, S %% 64 == 0, ldv >= S and %% 8 == 0 only (got dtype %d S %d C %d ldv %d)",
                dtype, S, C, ldv);
   const uintptr_t al = reinterpret_cast<uintptr_t>(q) | reinterpret_cast<uintptr_t>(k) | reinterpret_cast<uintptr_t>(vt) | reinterpret_cast<uintptr_t>(o) |
                        reinterpret_cast<uintptr_t>(bias_v);
   VT_CHECK_ARG((al & 15) == 0, "vt_flash_attention: tensors must be 16-byte aligned");
   FlashArgs a;
-  a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.vt = (const bf16_t*)vt; a.bias_v = bias_v; a.o = (bf16_t*)o;
+  a.q = (const uint16_t*)q; a.k = (const uint16_t*)k; a.vt = (const uint16_t*)vt; a.bias_v = bias_v; a.o = (uint16_t*)o;
   a.S = S; a.ldv = ldv;
   a.scale_log2e = scale * 1.4426950408889634f;
-  const void* kern = reinterpret_cast<const void*>(&flash_attn_kernel);
-  static std::atomic<bool> attr_done[kMaxDevices];
+  const void* kern = dtype == VT_F16 ? reinterpret_cast<const void*>(&flash_attn_kernel<f16_t>) : reinterpret_cast<const void*>(&flash_attn_kernel<bf16_t>);
+  const int ki = dtype == VT_F16 ? 1 : 0;
+  static std::atomic<bool> attr_done[2][kMaxDevices];
   int dev = 0;
   VT_CHECK_HIP(hipGetDevice(&dev));
   const bool dev_ok = dev >= 0 && dev < kMaxDevices;
-  if (!dev_ok || !attr_done[dev].load(std::memory_order_acquire)) {
+  if (!dev_ok || !attr_done[ki][dev].load(std::memory_order_acquire)) {
     VT_CHECK_HIP(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, FA_LDS));
-    if (dev_ok) attr_done[dev].store(true, std::memory_order_release);
+    if (dev_ok) attr_done[ki][dev].store(true, std::memory_order_release);
   }
   // the frame index rides in grid.y (65 535 at most): more frames than that go out as slices of the batch
   for (int z0 = 0; z0 < Z; z0 += 65535) {

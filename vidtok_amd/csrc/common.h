@@ -8,7 +8,9 @@
 #include "../../include/vidtok_amd.h"
 
 typedef __bf16 bf16_t;
+typedef _Float16 f16_t;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
@@ -60,6 +62,72 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
   return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
 }
 
+// The two 16-bit storage types (vt_dtype VT_BF16 / VT_F16): one word = two values (the lower address in bits 0..15), fp32 <-> storage
+// conversions (round to nearest even both ways; fp16 results beyond 65 504 become +-inf, as the reference's autocast(float16) convolutions
+// do), and the matrix instruction that takes the type -- v_mfma_f32_*_bf16 / _f16 run at the same rate on gfx950.  Kernels written for
+// "a 16-bit type" take one of them as a template parameter and say h16<H>::...
+template <typename H>
+struct h16;
+template <>
+struct h16<bf16_t> {
+  typedef bf16x8 vec8;
+  static __device__ __forceinline__ float lo(uint32_t w) { return __uint_as_float(w << 16); }
+  static __device__ __forceinline__ float hi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
+  static __device__ __forceinline__ uint32_t pack(float a, float b) { return pack_bf16x2(a, b); }
+  static __device__ __forceinline__ f32x16 mfma32(const u32x4& a, const u32x4& b, const f32x16& c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ f32x4 mfma16(const u32x4& a, const u32x4& b, const f32x4& c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+  }
+};
+template <>
+struct h16<f16_t> {
+  typedef f16x8 vec8;
+  typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+  typedef float f32x2_t __attribute__((ext_vector_type(2)));
+  static __device__ __forceinline__ float lo(uint32_t w) { return (float)__builtin_bit_cast(f16x2_t, w)[0]; }   // v_cvt_f32_f16
+  static __device__ __forceinline__ float hi(uint32_t w) { return (float)__builtin_bit_cast(f16x2_t, w)[1]; }   // ... src0_sel:WORD_1
+  static __device__ __forceinline__ uint32_t pack(float a, float b) {                                          // one v_cvt_pk_f16_f32
+    const f32x2_t v = {a, b};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, f16x2_t));
+  }
+  static __device__ __forceinline__ f32x16 mfma32(const u32x4& a, const u32x4& b, const f32x16& c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ f32x4 mfma16(const u32x4& a, const u32x4& b, const f32x4& c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  }
+};
+template <typename T>
+struct is_h16 {
+  [[maybe_unused]] static constexpr bool value = false;
+};
+template <>
+struct is_h16<bf16_t> {
+  [[maybe_unused]] static constexpr bool value = true;
+};
+template <>
+struct is_h16<f16_t> {
+  [[maybe_unused]] static constexpr bool value = true;
+};
+// vt_dtype code of a storage type
+template <typename T>
+struct dtype_code;
+template <>
+struct dtype_code<float> {
+  [[maybe_unused]] static constexpr int value = VT_F32;
+};
+template <>
+struct dtype_code<bf16_t> {
+  [[maybe_unused]] static constexpr int value = VT_BF16;
+};
+template <>
+struct dtype_code<f16_t> {
+  [[maybe_unused]] static constexpr int value = VT_F16;
+};
+inline bool vt_is_h16(int dtype) { return dtype == VT_BF16 || dtype == VT_F16; }
+
 template <typename T>
 __device__ __forceinline__ float to_f32(T v);
 template <>
@@ -68,8 +136,12 @@ template <>
 __device__ __forceinline__ float to_f32<bf16_t>(bf16_t v) {
   return bf16_bits_to_f32((uint32_t)__builtin_bit_cast(uint16_t, v));
 }
+template <>
+__device__ __forceinline__ float to_f32<f16_t>(f16_t v) { return (float)v; }
 template <typename T>
 __device__ __forceinline__ T from_f32(float v);
+template <>
+__device__ __forceinline__ f16_t from_f32<f16_t>(float v) { return (f16_t)v; }
 template <>
 __device__ __forceinline__ float from_f32<float>(float v) { return v; }
 template <>

@@ -74,8 +74,6 @@ struct ConvArgs {
   unsigned plane_bytes;        //      bytes of one tap plane in a weight row (KH * KW * Cin, or KW * Cin, elements)
   unsigned long long* prof;    // PROF instantiation only (vt_conv_profile): cycle stamps of workgroup 0
   int prof_mode;               // PROF instantiation of conv_ws2.hip only: option ws_prof_mode
-  int stagger_cycles;          // half tiles (option conv_half256): the second workgroup slot of every CU starts this many shader cycles late
-  int stagger_cus;             //      = CUs of the device: workgroups [cus, 2 cus) of the launch are taken to be those second slots
 };
 
 // Split-bf16 arithmetic (vt_dtype VT_BF16X3, "bf16x3"): fp32 STORAGE on both sides of the convolution, bf16 MATRIX cores
@@ -137,6 +135,10 @@ __device__ __forceinline__ void mma_step<bf16_t>(const u32x4& wfrag, const u32x4
                                                 __builtin_bit_cast(bf16x8, xfrag), acc, 0, 0, 0);
 }
 template <>
+__device__ __forceinline__ void mma_step<f16_t>(const u32x4& wfrag, const u32x4& xfrag, f32x16& acc) {
+  acc = h16<f16_t>::mfma32(wfrag, xfrag, acc);
+}
+template <>
 __device__ __forceinline__ void mma_step<float>(const u32x4& wfrag, const u32x4& xfrag, f32x16& acc) {
 #pragma unroll
   for (int e = 0; e < 4; ++e)
@@ -160,14 +162,18 @@ struct Quad<float> {
   f32x4 v;
   __device__ __forceinline__ float get(int e) const { return v[e]; }
 };
-template <>
-struct Quad<bf16_t> {
+template <typename H>
+struct Quad16 {     // a 16-bit storage type: two words
   u32x2 v;
   __device__ __forceinline__ float get(int e) const {
     const uint32_t w = v[e >> 1];
-    return bf16_bits_to_f32((e & 1) ? (w >> 16) : (w & 0xffffu));
+    return (e & 1) ? h16<H>::hi(w) : h16<H>::lo(w);
   }
 };
+template <>
+struct Quad<bf16_t> : Quad16<bf16_t> {};
+template <>
+struct Quad<f16_t> : Quad16<f16_t> {};
 template <typename TOut>
 __device__ __forceinline__ void store_quad(TOut* p, const float (&v)[4]);
 template <>
@@ -179,8 +185,15 @@ __device__ __forceinline__ void store_quad<float>(float* p, const float (&v)[4])
 template <>
 __device__ __forceinline__ void store_quad<bf16_t>(bf16_t* p, const float (&v)[4]) {
   u32x2 t;
-  t[0] = f32_to_bf16_bits(v[0]) | (f32_to_bf16_bits(v[1]) << 16);
-  t[1] = f32_to_bf16_bits(v[2]) | (f32_to_bf16_bits(v[3]) << 16);
+  t[0] = h16<bf16_t>::pack(v[0], v[1]);
+  t[1] = h16<bf16_t>::pack(v[2], v[3]);
+  *reinterpret_cast<u32x2*>(p) = t;
+}
+template <>
+__device__ __forceinline__ void store_quad<f16_t>(f16_t* p, const float (&v)[4]) {
+  u32x2 t;
+  t[0] = h16<f16_t>::pack(v[0], v[1]);
+  t[1] = h16<f16_t>::pack(v[2], v[3]);
   *reinterpret_cast<u32x2*>(p) = t;
 }
 
@@ -203,21 +216,25 @@ struct Oct<float> {
     *reinterpret_cast<f32x4*>(p + 4) = b;
   }
 };
-template <>
-struct Oct<bf16_t> {
+template <typename H>
+struct Oct16 {      // a 16-bit storage type: one 16-byte access
   u32x4 w;
-  __device__ __forceinline__ void load(const bf16_t* p) { w = *reinterpret_cast<const u32x4*>(p); }
+  __device__ __forceinline__ void load(const H* p) { w = *reinterpret_cast<const u32x4*>(p); }
   __device__ __forceinline__ float get(int e) const {
     const uint32_t t = w[e >> 1];
-    return bf16_bits_to_f32((e & 1) ? (t >> 16) : (t & 0xffffu));
+    return (e & 1) ? h16<H>::hi(t) : h16<H>::lo(t);
   }
-  static __device__ __forceinline__ void store(bf16_t* p, const float (&v)[8]) {
+  static __device__ __forceinline__ void store(H* p, const float (&v)[8]) {
     u32x4 t;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) t[e] = f32_to_bf16_bits(v[2 * e]) | (f32_to_bf16_bits(v[2 * e + 1]) << 16);
+    for (int e = 0; e < 4; ++e) t[e] = h16<H>::pack(v[2 * e], v[2 * e + 1]);
     *reinterpret_cast<u32x4*>(p) = t;
   }
 };
+template <>
+struct Oct<bf16_t> : Oct16<bf16_t> {};
+template <>
+struct Oct<f16_t> : Oct16<f16_t> {};
 
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {

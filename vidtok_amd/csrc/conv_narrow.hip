@@ -25,7 +25,7 @@
 #include <atomic>
 #include <type_traits>
 
-#include "conv_common.h"
+#include "conv_select.h"
 
 namespace {
 
@@ -66,7 +66,8 @@ __device__ __forceinline__ void nw_static_for(F&& f) {
 // TWO passes over x, each with 36 stationary fragments like the bf16 kernel (both planes at once would be 288 registers of
 // weights): pass 1 keeps the hi plane and takes W_hi x_lo + W_hi x_hi (+ bias) -> y, pass 2 keeps the lo plane and adds
 // W_lo x_hi to y.  The activations are split in registers behind their fragment read (split3_x, conv_common.h).
-template <int MODE>
+// HT: the 16-bit type of the tensors (MODE 0: bf16_t / f16_t; the split planes of MODE 1 / 2 are bf16)
+template <int MODE, typename HT = bf16_t>
 __global__ __launch_bounds__(256, 1) void conv3d_narrow_kernel(const NarrowArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr int NW_ROWB = NwCfg<MODE>::ROWB, NW_RING = NwCfg<MODE>::RING, NW_DEPTH = NwCfg<MODE>::DEPTH, NDMA = NwCfg<MODE>::NDMA;
@@ -96,7 +97,7 @@ __global__ __launch_bounds__(256, 1) void conv3d_narrow_kernel(const NarrowArgs 
     const int m = lane & 15, co = m >> 2, kw = m & 3;
     const bool ok = co < p.Cout && kw < 3;
     if constexpr (MODE == 0) {
-      const bf16_t* row = reinterpret_cast<const bf16_t*>(p.w) + (long long)(ok ? co : 0) * p.ldw + (ok ? kw : 0) * 128 + (lane >> 4) * 8;
+      const HT* row = reinterpret_cast<const HT*>(p.w) + (long long)(ok ? co : 0) * p.ldw + (ok ? kw : 0) * 128 + (lane >> 4) * 8;
 #pragma unroll
       for (int f = 0; f < 36; ++f) {                 // f = (kt*3 + kh)*4 + ks
         u32x4 v = *reinterpret_cast<const u32x4*>(row + (f >> 2) * 3 * 128 + (f & 3) * 32);
@@ -215,10 +216,8 @@ __global__ __launch_bounds__(256, 1) void conv3d_narrow_kernel(const NarrowArgs 
             constexpr int orow = r - kh;              // input row h0 - 1 + r is tap kh of output row h0 + r - kh
             if constexpr (orow >= 0 && orow < NW_TH) {
               if constexpr (MODE == 1)                // small term first: W_hi x_lo
-                acc[s][orow] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[(kt * 3 + kh) * 4 + ks]),
-                                                                       __builtin_bit_cast(bf16x8, xlo), acc[s][orow], 0, 0, 0);
-              acc[s][orow] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[(kt * 3 + kh) * 4 + ks]),
-                                                                     __builtin_bit_cast(bf16x8, xhi), acc[s][orow], 0, 0, 0);
+                acc[s][orow] = h16<HT>::mfma16(wf[(kt * 3 + kh) * 4 + ks], xlo, acc[s][orow]);
+              acc[s][orow] = h16<HT>::mfma16(wf[(kt * 3 + kh) * 4 + ks], xhi, acc[s][orow]);
             }
           });
         });
@@ -284,13 +283,14 @@ extern "C" __attribute__((visibility("hidden"))) void vt_conv_narrow_plan(const 
 }
 
 // conv_igemm.hip's dispatcher hands over launches that qualify; `args` is its ConvArgs
-extern "C" __attribute__((visibility("hidden"))) int vt_conv_narrow_launch(const void* args, void* stream_, int x3) {
+// mode: 0 bf16, 1 fp16, 2 split-bf16 (fp32 x, two passes)
+extern "C" __attribute__((visibility("hidden"))) int vt_conv_narrow_launch(const void* args, void* stream_, int mode) {
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
   NarrowArgs n;
   const long long grid = narrow_geometry(*reinterpret_cast<const ConvArgs*>(args), n);
   VT_CHECK_ARG(grid > 0 && grid < (1ll << 31), "vt_conv (narrow): grid");
-  const void* kerns[3] = {reinterpret_cast<const void*>(&conv3d_narrow_kernel<0>), reinterpret_cast<const void*>(&conv3d_narrow_kernel<1>),
-                          reinterpret_cast<const void*>(&conv3d_narrow_kernel<2>)};
+  const void* kerns[4] = {reinterpret_cast<const void*>(&conv3d_narrow_kernel<0>), reinterpret_cast<const void*>(&conv3d_narrow_kernel<1>),
+                          reinterpret_cast<const void*>(&conv3d_narrow_kernel<2>), reinterpret_cast<const void*>(&conv3d_narrow_kernel<0, f16_t>)};
   static std::atomic<bool> attr_done[kMaxDevices];
   int dev = 0;
   VT_CHECK_HIP(hipGetDevice(&dev));
@@ -300,8 +300,8 @@ extern "C" __attribute__((visibility("hidden"))) int vt_conv_narrow_launch(const
     if (dev_ok) attr_done[dev].store(true, std::memory_order_release);
   }
   void* kargs[] = {&n};
-  if (!x3) {
-    VT_CHECK_HIP(hipLaunchKernel(kerns[0], dim3((unsigned)grid), dim3(256), kargs, NW_LDS, stream));
+  if (mode != 2) {
+    VT_CHECK_HIP(hipLaunchKernel(kerns[mode == 1 ? 3 : 0], dim3((unsigned)grid), dim3(256), kargs, NW_LDS, stream));
     return VT_OK;
   }
   // split-bf16: two passes over x (hi weight plane -> y, lo weight plane onto y), stream-ordered

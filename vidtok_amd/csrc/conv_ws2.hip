@@ -39,7 +39,7 @@
 #include <atomic>
 #include <type_traits>
 
-#include "conv_common.h"
+#include "conv_select.h"
 
 namespace {
 
@@ -73,18 +73,29 @@ __device__ __forceinline__ void w2_static_for(F&& f) {
 // half with the accumulators, the fragment ring and the row phase.  (With all 36 constrained to "a" the allocator kept
 // 128 / 128 and spilled 10-13 registers into the LayerNorm instantiations.)
 [[maybe_unused]] constexpr int W2_WA = 32;
-template <bool FIRST, bool W_IN_AGPR>
+template <typename H, bool FIRST, bool W_IN_AGPR>
 __device__ __forceinline__ void w2_mfma(const u32x4& w, const u32x4& x, f32x16& acc) {
-  if constexpr (FIRST) {
-    if constexpr (W_IN_AGPR) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=v"(acc) : "a"(w), "v"(x));
-    else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=v"(acc) : "v"(w), "v"(x));
+  if constexpr (std::is_same<H, bf16_t>::value) {
+    if constexpr (FIRST) {
+      if constexpr (W_IN_AGPR) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=v"(acc) : "a"(w), "v"(x));
+      else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=v"(acc) : "v"(w), "v"(x));
+    } else {
+      if constexpr (W_IN_AGPR) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "a"(w), "v"(x));
+      else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(w), "v"(x));
+    }
   } else {
-    if constexpr (W_IN_AGPR) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "a"(w), "v"(x));
-    else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(w), "v"(x));
+    if constexpr (FIRST) {
+      if constexpr (W_IN_AGPR) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=v"(acc) : "a"(w), "v"(x));
+      else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=v"(acc) : "v"(w), "v"(x));
+    } else {
+      if constexpr (W_IN_AGPR) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc) : "a"(w), "v"(x));
+      else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(w), "v"(x));
+    }
   }
 }
 
-template <int LN, bool KEEP, bool PROF = false>
+// H = the 16-bit storage type (bf16_t / f16_t: common.h)
+template <typename H, int LN, bool KEEP, bool PROF = false>
 __global__ __launch_bounds__(512, 1) void conv3x3_ws2_kernel(const ConvArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -94,9 +105,9 @@ __global__ __launch_bounds__(512, 1) void conv3x3_ws2_kernel(const ConvArgs p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int cw = wave & 3;                                             // channel group: output channels [32 cw, +32)
   const int grp = wave >> 2;                                           // K half and ping-pong group
-  const int H = p.Ho, W = p.Wo;
+  const int FH = p.Ho, W = p.Wo;
   const int tiles_w = W / W2_TW;
-  const int tiles_pf = tiles_w * (H / W2_TH);
+  const int tiles_pf = tiles_w * (FH / W2_TH);
   const int ntiles = tiles_pf * p.B * p.To;
   const int G = gridDim.x;
   const int slot = xcd_remap(blockIdx.x, G);
@@ -106,17 +117,17 @@ __global__ __launch_bounds__(512, 1) void conv3x3_ws2_kernel(const ConvArgs p) {
   if (t_begin >= t_end) return;
   const int U = t_end - t_begin;                                       // tiles of this workgroup
 
-  const bf16_t* __restrict__ xg = reinterpret_cast<const bf16_t*>(p.x);
-  bf16_t* __restrict__ yg = reinterpret_cast<bf16_t*>(p.y);
-  const bf16_t* __restrict__ rg = reinterpret_cast<const bf16_t*>(p.res);
-  bf16_t* __restrict__ ng = reinterpret_cast<bf16_t*>(p.ln_out);
+  const H* __restrict__ xg = reinterpret_cast<const H*>(p.x);
+  H* __restrict__ yg = reinterpret_cast<H*>(p.y);
+  const H* __restrict__ rg = reinterpret_cast<const H*>(p.res);
+  H* __restrict__ ng = reinterpret_cast<H*>(p.ln_out);
   constexpr unsigned kOob = 0xFFFF0000u;
   const bool has_res = p.res_mode == VT_RES_ADD;                        // uniform
 
   // ---- stationary weights: K groups [36 grp, 36 grp + 36) of the 72 (group g = tap * 8 + 16-channel chunk) -------------
   u32x4 wreg[36];
   {
-    const bf16_t* row = reinterpret_cast<const bf16_t*>(p.w) + (long long)(cw * 32 + (lane & 31)) * p.ldw + (lane >> 5) * 8 + grp * (36 * 16);
+    const H* row = reinterpret_cast<const H*>(p.w) + (long long)(cw * 32 + (lane & 31)) * p.ldw + (lane >> 5) * 8 + grp * (36 * 16);
 #pragma unroll
     for (int c = 0; c < 36; ++c) wreg[c] = *reinterpret_cast<const u32x4*>(row + c * 16);
   }
@@ -155,7 +166,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_ws2_kernel(const ConvArgs p) {
     if (c.w0 == W) {
       c.w0 = 0;
       c.h0 += W2_TH;
-      if (c.h0 == H) {
+      if (c.h0 == FH) {
         c.h0 = 0;
         c.f += 1;
       }
@@ -169,7 +180,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_ws2_kernel(const ConvArgs p) {
   // bits 4.. = byte offset relative to the tile origin, bit 0 / 1 = left / right halo column, bit 2 = never fetched: pad
   // bytes, image tail); a request then costs five instructions instead of the ~100 of the divide-by-272 arithmetic (first
   // measurement of this file: 5 000 cycles of request code per tile).
-  const unsigned frame_bytes = (unsigned)H * (unsigned)W * 256u;
+  const unsigned frame_bytes = (unsigned)FH * (unsigned)W * 256u;
   unsigned pgeo[W2_PSLOTS], rgeo[W2_RSLOTS];
 #pragma unroll
   for (int q = 0; q < W2_PSLOTS; ++q) {
@@ -193,7 +204,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_ws2_kernel(const ConvArgs p) {
     }
     if (want_patch) {
       const int f = pt.f, h0 = pt.h0, w0 = pt.w0;
-      const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(xg) + (long long)f * H * W * 128, 0, frame_bytes, 0x00020000);
+      const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<H*>(xg) + (long long)f * FH * W * 128, 0, frame_bytes, 0x00020000);
       const unsigned tmask = (w0 == 0 ? 1u : 0u) | (w0 + W2_TW == W ? 2u : 0u) | 4u;
       const unsigned toff = (unsigned)((h0 * W + w0) * 256);
       w2_static_for<0, W2_PSLOTS>([&](auto qc) {
@@ -206,7 +217,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_ws2_kernel(const ConvArgs p) {
     }
     if (want_res) {
       const int f = rt.f, h0 = rt.h0, w0 = rt.w0;
-      const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(rg) + (long long)f * H * W * 128, 0, frame_bytes, 0x00020000);
+      const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<H*>(rg) + (long long)f * FH * W * 128, 0, frame_bytes, 0x00020000);
       const unsigned toff = (unsigned)((h0 * W + w0) * 256);
       w2_static_for<0, W2_RSLOTS>([&](auto qc) {
         constexpr int q = decltype(qc)::value;
@@ -262,8 +273,8 @@ __global__ __launch_bounds__(512, 1) void conv3x3_ws2_kernel(const ConvArgs p) {
     const int oct_j = tg & 15, row_l = tg >> 4;
     const int tile_pix = tc.h0 * W + tc.w0;
     __amdgpu_buffer_rsrc_t yrs, nrs;
-    if constexpr (KEEP) yrs = __builtin_amdgcn_make_buffer_rsrc(yg + (long long)tc.f * H * W * 128, 0, frame_bytes, 0x00020000);
-    if constexpr (LN != 0) nrs = __builtin_amdgcn_make_buffer_rsrc(ng + (long long)tc.f * H * W * 128, 0, frame_bytes, 0x00020000);
+    if constexpr (KEEP) yrs = __builtin_amdgcn_make_buffer_rsrc(yg + (long long)tc.f * FH * W * 128, 0, frame_bytes, 0x00020000);
+    if constexpr (LN != 0) nrs = __builtin_amdgcn_make_buffer_rsrc(ng + (long long)tc.f * FH * W * 128, 0, frame_bytes, 0x00020000);
     const float* pl = prm + 4 * oct_j;                         // gamma of channels [8 oct_j, +4) and, 64 floats on, [8 oct_j + 4, +4); beta + 128, bias + 256
     f32x4 g0, g1, b0, b1;
     if constexpr (LN != 0) {
@@ -295,7 +306,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_ws2_kernel(const ConvArgs p) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         const uint32_t w2 = rw[e >> 1];
-        const float r = __uint_as_float((e & 1) ? (w2 & 0xffff0000u) : (w2 << 16));
+        const float r = (e & 1) ? h16<H>::hi(w2) : h16<H>::lo(w2);
         rv[e] = __fadd_rn(r, __fadd_rn(e < 4 ? t0[e] : t1[e - 4], e < 4 ? o0[e] : o1[e - 4]));
         pinf(rv[e]);
         s = __fadd_rn(s, rv[e]);
@@ -304,7 +315,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_ws2_kernel(const ConvArgs p) {
       if constexpr (KEEP) {
         u32x4 w4;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) w4[e] = pack_bf16x2(rv[2 * e], rv[2 * e + 1]);
+        for (int e = 0; e < 4; ++e) w4[e] = h16<H>::pack(rv[2 * e], rv[2 * e + 1]);
         __builtin_amdgcn_raw_buffer_store_b128(w4, yrs, (tile_pix + pix) * 256 + oct_j * 16, 0, 0);
       }
       if constexpr (LN != 0) {
@@ -327,7 +338,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_ws2_kernel(const ConvArgs p) {
           pinf(rv[e]);
         }
 #pragma unroll
-        for (int e = 0; e < 4; ++e) w4[e] = pack_bf16x2(rv[2 * e], rv[2 * e + 1]);
+        for (int e = 0; e < 4; ++e) w4[e] = h16<H>::pack(rv[2 * e], rv[2 * e + 1]);
         __builtin_amdgcn_raw_buffer_store_b128(w4, nrs, (tile_pix + pix) * 256 + oct_j * 16, 0, 0);
       }
     }
@@ -380,7 +391,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_ws2_kernel(const ConvArgs p) {
     __builtin_amdgcn_s_setprio(1);
     w2_static_for<0, 72>([&](auto mc) {
       constexpr int m = decltype(mc)::value;
-      w2_mfma<(KH == 0 && m < 2), ((m >> 1) < W2_WA)>(wreg[m >> 1], xf[m % (W2_FD + 1)], acc[m & 1]);
+      w2_mfma<H, (KH == 0 && m < 2), ((m >> 1) < W2_WA)>(wreg[m >> 1], xf[m % (W2_FD + 1)], acc[m & 1]);
       if constexpr (m + W2_FD < 72) xf[(m + W2_FD) % (W2_FD + 1)] = *frag_addr(m + W2_FD);
       __builtin_amdgcn_sched_barrier(0);
     });
@@ -460,20 +471,26 @@ __global__ __launch_bounds__(512, 1) void conv3x3_ws2_kernel(const ConvArgs p) {
 
 }  // namespace
 
-// conv_igemm.hip's dispatcher hands over launches that qualify (ws128_eligible there) when option conv_ws = 2
-extern "C" __attribute__((visibility("hidden"))) int vt_ws2_launch(const void* args, void* stream_) {
+// conv_igemm.hip's dispatcher hands over launches that qualify (ws_eligible, conv_select.h); dtype = VT_BF16 / VT_F16
+extern "C" __attribute__((visibility("hidden"))) int vt_ws2_launch(const void* args, int dtype, void* stream_) {
   const ConvArgs& a = *reinterpret_cast<const ConvArgs*>(args);
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
   const bool keep = a.ln_mode == 0 || a.ln_keep_y != 0;
   int vi = a.ln_mode == 0 ? 0 : (a.ln_mode == 1 ? (keep ? 1 : 2) : (keep ? 3 : 4));
-  static const void* const kerns[7] = {
-      reinterpret_cast<const void*>(&conv3x3_ws2_kernel<0, true>), reinterpret_cast<const void*>(&conv3x3_ws2_kernel<1, true>),
-      reinterpret_cast<const void*>(&conv3x3_ws2_kernel<1, false>), reinterpret_cast<const void*>(&conv3x3_ws2_kernel<2, true>),
-      reinterpret_cast<const void*>(&conv3x3_ws2_kernel<2, false>), reinterpret_cast<const void*>(&conv3x3_ws2_kernel<0, true, true>),
-      reinterpret_cast<const void*>(&conv3x3_ws2_kernel<2, true, true>)};
-  if (a.prof != nullptr) {           // vt_conv_profile: the plain and the LayerNorm+SiLU (y kept) instantiations carry stamps [8 waves][16]
-    VT_CHECK_ARG(vi == 0 || vi == 3, "vt_conv_profile (weight-stationary kernel): ln_mode 0, or 2 with ln_keep_y");
+  constexpr int NK = 12;
+  static const void* const kerns[NK] = {
+      reinterpret_cast<const void*>(&conv3x3_ws2_kernel<bf16_t, 0, true>), reinterpret_cast<const void*>(&conv3x3_ws2_kernel<bf16_t, 1, true>),
+      reinterpret_cast<const void*>(&conv3x3_ws2_kernel<bf16_t, 1, false>), reinterpret_cast<const void*>(&conv3x3_ws2_kernel<bf16_t, 2, true>),
+      reinterpret_cast<const void*>(&conv3x3_ws2_kernel<bf16_t, 2, false>), reinterpret_cast<const void*>(&conv3x3_ws2_kernel<bf16_t, 0, true, true>),
+      reinterpret_cast<const void*>(&conv3x3_ws2_kernel<bf16_t, 2, true, true>),
+      reinterpret_cast<const void*>(&conv3x3_ws2_kernel<f16_t, 0, true>), reinterpret_cast<const void*>(&conv3x3_ws2_kernel<f16_t, 1, true>),
+      reinterpret_cast<const void*>(&conv3x3_ws2_kernel<f16_t, 1, false>), reinterpret_cast<const void*>(&conv3x3_ws2_kernel<f16_t, 2, true>),
+      reinterpret_cast<const void*>(&conv3x3_ws2_kernel<f16_t, 2, false>)};
+  if (a.prof != nullptr) {           // vt_conv_profile: the plain and the LayerNorm+SiLU (y kept) bf16 instantiations carry stamps [8 waves][16]
+    VT_CHECK_ARG(dtype == VT_BF16 && (vi == 0 || vi == 3), "vt_conv_profile (weight-stationary kernel): bf16, ln_mode 0, or 2 with ln_keep_y");
     vi = vi == 0 ? 5 : 6;
+  } else if (dtype == VT_F16) {
+    vi += 7;
   }
   static std::atomic<int> cus[kMaxDevices];         // 0 = not set up on that device yet; else its CU count
   int dev = 0;
@@ -481,12 +498,12 @@ extern "C" __attribute__((visibility("hidden"))) int vt_ws2_launch(const void* a
   const bool dev_ok = dev >= 0 && dev < kMaxDevices;
   int ncu = dev_ok ? cus[dev].load(std::memory_order_acquire) : 0;
   if (ncu == 0) {
-    for (int k = 0; k < 7; ++k) VT_CHECK_HIP(hipFuncSetAttribute(kerns[k], hipFuncAttributeMaxDynamicSharedMemorySize, W2_LDS));
+    for (int k = 0; k < NK; ++k) VT_CHECK_HIP(hipFuncSetAttribute(kerns[k], hipFuncAttributeMaxDynamicSharedMemorySize, W2_LDS));
     VT_CHECK_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
     if (ncu <= 0) ncu = 256;
     if (dev_ok) cus[dev].store(ncu, std::memory_order_release);
   }
-  const int ntiles = (a.Wo / W2_TW) * (a.Ho / W2_TH) * a.B * a.To;   // 4 x 16-pixel tiles (ws128_eligible guarantees Ho % 8 == 0, Wo % 16 == 0)
+  const int ntiles = (a.Wo / W2_TW) * (a.Ho / W2_TH) * a.B * a.To;   // 4 x 16-pixel tiles (ws_eligible guarantees Ho % 8 == 0, Wo % 16 == 0)
   const int grid = ntiles < ncu ? ntiles : ncu;     // one persistent workgroup per CU (nearly all of its LDS)
   ConvArgs args_copy = a;
   void* kargs[] = {&args_copy};

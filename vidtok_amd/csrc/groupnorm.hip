@@ -191,6 +191,12 @@ extern "C" int vt_groupnorm_act(const void* x, int in_dtype, int64_t ldx, void* 
     return launch_groupnorm<float, bf16_t>(x, ldx, y, ldy, gamma, beta, B, T, HW, C, groups, scope, eps, silu, w, stream);
   if (in_dtype == VT_BF16 && out_dtype == VT_F32)
     return launch_groupnorm<bf16_t, float>(x, ldx, y, ldy, gamma, beta, B, T, HW, C, groups, scope, eps, silu, w, stream);
+  if (in_dtype == VT_F16 && out_dtype == VT_F16)
+    return launch_groupnorm<f16_t, f16_t>(x, ldx, y, ldy, gamma, beta, B, T, HW, C, groups, scope, eps, silu, w, stream);
+  if (in_dtype == VT_F32 && out_dtype == VT_F16)
+    return launch_groupnorm<float, f16_t>(x, ldx, y, ldy, gamma, beta, B, T, HW, C, groups, scope, eps, silu, w, stream);
+  if (in_dtype == VT_F16 && out_dtype == VT_F32)
+    return launch_groupnorm<f16_t, float>(x, ldx, y, ldy, gamma, beta, B, T, HW, C, groups, scope, eps, silu, w, stream);
   vt_set_error("vt_groupnorm_act: dtype combination %d -> %d", in_dtype, out_dtype);
   return VT_ERR_ARG;
 }

@@ -162,7 +162,7 @@ struct Model {
     }
     return (char*)st.buf->p;
   }
-  int dt;                          // storage type of the activations (VT_BF16 | VT_F32)
+  int dt;                          // storage type of the activations (VT_BF16 | VT_F16 | VT_F32)
   bool x3 = false;                 // VT_BF16X3: fp32 storage, convolutions on split-bf16 weight planes (three bf16 MFMAs per product)
   bool v11() const { return cfg.version == 1; }
   bool noncausal() const { return cfg.version == 2; }          // Encoder3D / Decoder3D of model_3dnoncausal.py: centred temporal windows
@@ -268,7 +268,14 @@ struct Model {
     }
     if (dt == VT_F32) return upload(ckey, w.data(), w.size() * 4);
     std::vector<uint16_t> h(w.size());
-    for (size_t i = 0; i < w.size(); ++i) h[i] = bf16_rne(w[i]);
+    if (dt == VT_F16) {
+      for (size_t i = 0; i < w.size(); ++i) {          // round to nearest even (the compiler's float -> _Float16 conversion)
+        const _Float16 f = (_Float16)w[i];
+        memcpy(&h[i], &f, 2);
+      }
+    } else {
+      for (size_t i = 0; i < w.size(); ++i) h[i] = bf16_rne(w[i]);
+    }
     return upload(ckey, h.data(), h.size() * 2);
   }
 };
@@ -456,7 +463,7 @@ Act conv(Ctx& c, const Tens& x, const void* w, int ldw, const float* bias, const
   {
     vt_conv_desc q = d;
     standins(q);
-    const int64_t wb = (x.dt == VT_BF16 && (g.kt == 3 || g.kh == 3)) ? vt_conv_work_bytes(&q) : 0;
+    const int64_t wb = ((x.dt == VT_BF16 || x.dt == VT_F16) && (g.kt == 3 || g.kh == 3)) ? vt_conv_work_bytes(&q) : 0;
     if (wb > 0) {
       d.work = c.cur->alloc((size_t)wb, c.dry);
       d.work_bytes = wb;
@@ -614,7 +621,7 @@ struct TBlock : Stage {            // ResnetCausalBlock1D, model_3dcausal.py:427
   // stand at the same point of the chunk schedule and, past the first chunk, both caches must be there
   bool fusable(const Ctx& c) const {
     if (c.m->noncausal()) return false;                // the fused launch is the causal block
-    if (!(c.m->dt == VT_BF16 && ch == 128 && n1.eps == n2.eps) || n1.group) return false;
+    if (!((c.m->dt == VT_BF16 || c.m->dt == VT_F16) && ch == 128 && n1.eps == n2.eps) || n1.group) return false;
     if (!c.m->tiled) return true;
     if (s1.offset != s2.offset) return false;
     return c.m->first_chunk || c.dry || (s1.frames >= 2 && s2.frames >= 2);
@@ -1266,7 +1273,8 @@ struct vt_model {
 extern "C" int vt_create(const vt_model_config* cfg, int32_t compute_dtype, vt_model** out) {
   try {
     M_CHECK(cfg != nullptr && out != nullptr, "vt_create: null argument");
-    M_CHECK(compute_dtype == VT_BF16 || compute_dtype == VT_F32 || compute_dtype == VT_BF16X3, "vt_create: compute dtype must be VT_BF16, VT_F32 or VT_BF16X3");
+    M_CHECK(compute_dtype == VT_BF16 || compute_dtype == VT_F16 || compute_dtype == VT_F32 || compute_dtype == VT_BF16X3,
+            "vt_create: compute dtype must be VT_BF16, VT_F16, VT_F32 or VT_BF16X3");
     M_CHECK(cfg->version >= 0 && cfg->version <= 2, "vt_create: version 0 (v1.0 causal), 1 (v1.1 causal) or 2 (non-causal Encoder3D / Decoder3D)");
     M_CHECK(cfg->interpolation_mode == 0 || (cfg->interpolation_mode == 1 && cfg->version == 1), "vt_create: interpolation_mode 0 (nearest) or, for v1.1, 1 (trilinear)");
     M_CHECK(cfg->num_resolutions >= 1 && cfg->num_resolutions <= 8 && cfg->num_res_blocks >= 1 && cfg->ch > 0, "vt_create: bad level / block counts");

@@ -18,11 +18,11 @@ struct OptDef {
 };
 // order = enum VtOpt
 const OptDef kDefs[OPT_COUNT] = {
-    {"conv_buf", 1},        {"conv_tinner", 1},     {"conv_ldsepi", 1},      {"conv_sched", 2},   {"conv_ws", 2},
+    {"conv_buf", 1},        {"conv_tinner", 1},     {"conv_ldsepi", 1},      {"conv_ws", 2},
     {"conv_narrow", 1},     {"conv_tile", 0},       {"conv_tile_min", 128},  {"conv_fuse_ln", 1}, {"conv_fuse_ln256", 1},
-    {"conv_ln256_v", 1},    {"ws_acc", 0},          {"tblock_fused", 1},     {"tblock_prof_mode", 0},
-    {"conv_deep", 1},       {"ws_prof_mode", 0},    {"conv_sched_x3", 3},   {"attn_flash", 1},      {"conv_splitk", 1},
-    {"conv_half256", 0},  {"conv_half_stagger", 900}, {"conv_half_plain", 0},     {"conv_tskip", 1},     {"conv_in8", 1},     {"conv_tup_ln", 1},
+    {"tblock_fused", 1},    {"tblock_prof_mode", 0},
+    {"conv_deep", 1},       {"ws_prof_mode", 0},    {"attn_flash", 1},      {"conv_splitk", 1},
+    {"conv_tskip", 1},      {"conv_in8", 1},        {"conv_tup_ln", 1},
 };
 std::atomic<int> g_val[OPT_COUNT];
 std::once_flag g_once;

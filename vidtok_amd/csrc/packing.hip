@@ -18,7 +18,7 @@ struct PackArgs {
   void* out;
   int Cout, Cin, cin_p, taps_in, taps_out;
   long long ldw;          // k-values per packed row (>= taps_out * cin_p; the tail is zero)
-  int mode;               // VT_F32, VT_BF16, VT_BF16X3
+  int mode;               // VT_F32, VT_BF16, VT_F16, VT_BF16X3
   int mix[kMaxTaps][4];   // source taps of output tap j, -1 = absent
 };
 
@@ -45,6 +45,8 @@ __global__ __launch_bounds__(256) void pack_conv_weight_kernel(const PackArgs p)
       reinterpret_cast<float*>(p.out)[i] = v;
     } else if (p.mode == VT_BF16) {
       reinterpret_cast<uint16_t*>(p.out)[i] = (uint16_t)f32_to_bf16_bits(v);
+    } else if (p.mode == VT_F16) {
+      reinterpret_cast<f16_t*>(p.out)[i] = (f16_t)v;
     } else {   // split-bf16 planes: per group of 16 k, [hi x 16 | lo x 16] (packing.py::pack_split3)
       const uint32_t hi = f32_to_bf16_bits(v);
       const uint32_t lo = f32_to_bf16_bits(__fsub_rn(v, bf16_bits_to_f32(hi)));
@@ -62,7 +64,7 @@ extern "C" int vt_pack_conv_weight(const float* w, void* out, int32_t out_dtype,
                                    int32_t taps_out, const int32_t* mix_host, int64_t ldw, vt_stream stream_) {
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
   VT_CHECK_ARG(w && out && Cout > 0 && Cin > 0 && cin_p >= Cin && taps_in > 0 && taps_out > 0, "vt_pack_conv_weight: bad arguments");
-  VT_CHECK_ARG(out_dtype == VT_F32 || out_dtype == VT_BF16 || out_dtype == VT_BF16X3, "vt_pack_conv_weight: out_dtype %d", out_dtype);
+  VT_CHECK_ARG(out_dtype == VT_F32 || out_dtype == VT_BF16 || out_dtype == VT_F16 || out_dtype == VT_BF16X3, "vt_pack_conv_weight: out_dtype %d", out_dtype);
   VT_CHECK_ARG(taps_out <= kMaxTaps && (mix_host != nullptr || taps_out == taps_in), "vt_pack_conv_weight: at most %d taps; without a mix table taps_out = taps_in", kMaxTaps);
   VT_CHECK_ARG(ldw >= (int64_t)taps_out * cin_p && (out_dtype != VT_BF16X3 || ldw % 32 == 0), "vt_pack_conv_weight: ldw %lld (split-bf16 rows: a multiple of 32)", (long long)ldw);
   PackArgs p;

@@ -28,8 +28,21 @@ __device__ __forceinline__ void load4<bf16_t>(const bf16_t* p, float (&v)[4]) {
   v[2] = bf16_bits_to_f32(t[1] & 0xffffu);
   v[3] = bf16_bits_to_f32(t[1] >> 16);
 }
+template <>
+__device__ __forceinline__ void load4<f16_t>(const f16_t* p, float (&v)[4]) {
+  const u32x2 t = *reinterpret_cast<const u32x2*>(p);
+  v[0] = h16<f16_t>::lo(t[0]); v[1] = h16<f16_t>::hi(t[0]);
+  v[2] = h16<f16_t>::lo(t[1]); v[3] = h16<f16_t>::hi(t[1]);
+}
 template <typename T>
 __device__ __forceinline__ void store4(T* p, const float (&v)[4]);
+template <>
+__device__ __forceinline__ void store4<f16_t>(f16_t* p, const float (&v)[4]) {
+  u32x2 t;
+  t[0] = h16<f16_t>::pack(v[0], v[1]);
+  t[1] = h16<f16_t>::pack(v[2], v[3]);
+  *reinterpret_cast<u32x2*>(p) = t;
+}
 template <>
 __device__ __forceinline__ void store4<float>(float* p, const float (&v)[4]) {
   f32x4 t;
@@ -66,8 +79,24 @@ __device__ __forceinline__ void load8<bf16_t>(const bf16_t* p, float (&v)[8]) {
     v[2 * e + 1] = bf16_bits_to_f32(t[e] >> 16);
   }
 }
+template <>
+__device__ __forceinline__ void load8<f16_t>(const f16_t* p, float (&v)[8]) {
+  const u32x4 t = *reinterpret_cast<const u32x4*>(p);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    v[2 * e] = h16<f16_t>::lo(t[e]);
+    v[2 * e + 1] = h16<f16_t>::hi(t[e]);
+  }
+}
 template <typename T>
 __device__ __forceinline__ void store8(T* p, const float (&v)[8]);
+template <>
+__device__ __forceinline__ void store8<f16_t>(f16_t* p, const float (&v)[8]) {
+  u32x4 t;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) t[e] = h16<f16_t>::pack(v[2 * e], v[2 * e + 1]);
+  *reinterpret_cast<u32x4*>(p) = t;
+}
 template <>
 __device__ __forceinline__ void store8<float>(float* p, const float (&v)[8]) {
   f32x4 a, b;
@@ -351,6 +380,12 @@ extern "C" int vt_layernorm_act(const void* x, int in_dtype, int64_t ldx, void* 
     return launch_layernorm<float, bf16_t>(x, ldx, y, ldy, gamma, beta, M, C, eps, silu, stream);
   if (in_dtype == VT_BF16 && out_dtype == VT_F32)
     return launch_layernorm<bf16_t, float>(x, ldx, y, ldy, gamma, beta, M, C, eps, silu, stream);
+  if (in_dtype == VT_F16 && out_dtype == VT_F16)
+    return launch_layernorm<f16_t, f16_t>(x, ldx, y, ldy, gamma, beta, M, C, eps, silu, stream);
+  if (in_dtype == VT_F32 && out_dtype == VT_F16)
+    return launch_layernorm<float, f16_t>(x, ldx, y, ldy, gamma, beta, M, C, eps, silu, stream);
+  if (in_dtype == VT_F16 && out_dtype == VT_F32)
+    return launch_layernorm<f16_t, float>(x, ldx, y, ldy, gamma, beta, M, C, eps, silu, stream);
   vt_set_error("vt_layernorm_act: dtype combination %d -> %d", in_dtype, out_dtype);
   return VT_ERR_ARG;
 }
@@ -384,6 +419,9 @@ extern "C" int vt_softmax_rows(const float* s, void* p, int out_dtype, int64_t r
   else if (out_dtype == VT_BF16)
     hipLaunchKernelGGL(softmax_rows_kernel<bf16_t>, dim3((unsigned)blocks), dim3(kBlock), 0, stream, s, (bf16_t*)p,
                        (long long)rows, cols, (long long)ldp, scale);
+  else if (out_dtype == VT_F16)
+    hipLaunchKernelGGL(softmax_rows_kernel<f16_t>, dim3((unsigned)blocks), dim3(kBlock), 0, stream, s, (f16_t*)p,
+                       (long long)rows, cols, (long long)ldp, scale);
   else
     VT_CHECK_ARG(false, "vt_softmax_rows: out_dtype %d", out_dtype);
   VT_CHECK_LAUNCH();
@@ -402,6 +440,9 @@ extern "C" int vt_ncthw_to_ndhwc(const float* x, void* y, int out_dtype, int32_t
   else if (out_dtype == VT_BF16)
     hipLaunchKernelGGL(ncthw_to_ndhwc_kernel<bf16_t>, dim3(grid_for(npix)), dim3(kBlock), 0, stream, x, (bf16_t*)y, B,
                        C, T, H, W, ldy, tpad);
+  else if (out_dtype == VT_F16)
+    hipLaunchKernelGGL(ncthw_to_ndhwc_kernel<f16_t>, dim3(grid_for(npix)), dim3(kBlock), 0, stream, x, (f16_t*)y, B,
+                       C, T, H, W, ldy, tpad);
   else
     VT_CHECK_ARG(false, "vt_ncthw_to_ndhwc: out_dtype %d", out_dtype);
   VT_CHECK_LAUNCH();
@@ -419,6 +460,9 @@ extern "C" int vt_ndhwc_to_ncthw(const void* x, int in_dtype, float* y, int32_t 
                        C, T, H, W, ldx, ttrim);
   else if (in_dtype == VT_BF16)
     hipLaunchKernelGGL(ndhwc_to_ncthw_kernel<bf16_t>, dim3(grid_for(n)), dim3(kBlock), 0, stream, (const bf16_t*)x, y,
+                       B, C, T, H, W, ldx, ttrim);
+  else if (in_dtype == VT_F16)
+    hipLaunchKernelGGL(ndhwc_to_ncthw_kernel<f16_t>, dim3(grid_for(n)), dim3(kBlock), 0, stream, (const f16_t*)x, y,
                        B, C, T, H, W, ldx, ttrim);
   else
     VT_CHECK_ARG(false, "vt_ndhwc_to_ncthw: in_dtype %d", in_dtype);
@@ -442,6 +486,9 @@ extern "C" int vt_time_avgpool3s2(const void* x, const void* cache, void* y, int
   else if (dtype == VT_BF16)
     hipLaunchKernelGGL(time_avgpool3s2_kernel<bf16_t>, dim3(grid_for(n)), dim3(kBlock), 0, stream, (const bf16_t*)x,
                        (const bf16_t*)cache, (bf16_t*)y, B, Ti, F4, tmode);
+  else if (dtype == VT_F16)
+    hipLaunchKernelGGL(time_avgpool3s2_kernel<f16_t>, dim3(grid_for(n)), dim3(kBlock), 0, stream, (const f16_t*)x,
+                       (const f16_t*)cache, (f16_t*)y, B, Ti, F4, tmode);
   else
     VT_CHECK_ARG(false, "vt_time_avgpool3s2: dtype %d", dtype);
   VT_CHECK_LAUNCH();
@@ -461,6 +508,9 @@ extern "C" int vt_time_lerp2x_cat(const void* head, int32_t nh, const void* x, v
   else if (dtype == VT_BF16)
     hipLaunchKernelGGL(time_lerp2x_kernel<bf16_t>, dim3(grid_for(n)), dim3(kBlock), 0, stream, (const bf16_t*)head, nh, (const bf16_t*)x,
                        (bf16_t*)y, B, Tx, skip, F4);
+  else if (dtype == VT_F16)
+    hipLaunchKernelGGL(time_lerp2x_kernel<f16_t>, dim3(grid_for(n)), dim3(kBlock), 0, stream, (const f16_t*)head, nh, (const f16_t*)x,
+                       (f16_t*)y, B, Tx, skip, F4);
   else
     VT_CHECK_ARG(false, "vt_time_lerp2x: dtype %d", dtype);
   VT_CHECK_LAUNCH();

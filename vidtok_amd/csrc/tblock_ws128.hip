@@ -35,12 +35,14 @@ namespace {
 [[maybe_unused]] constexpr int TB_RING = 3 * TB_SLOT;            // 52 224
 [[maybe_unused]] constexpr int TB_T = TB_PIX * 128 * 4;          // 32 768
 
+// (tensor pointers as uint16_t*: elements of the launch's 16-bit storage type, bf16 or fp16 -- the kernel's template parameter)
+typedef uint16_t tb_h;
 struct TBlockArgs {
-  const bf16_t* x;
-  bf16_t* y;
-  bf16_t* n_out;
-  const bf16_t* w1;
-  const bf16_t* w2;
+  const tb_h* x;
+  tb_h* y;
+  tb_h* n_out;
+  const tb_h* w1;
+  const tb_h* w2;
   const float* b1;
   const float* b2;
   const float* g1; const float* be1;
@@ -48,8 +50,8 @@ struct TBlockArgs {
   const float* gn; const float* ben;
   int B, T, HW;
   int replicate;      // frames before the clip: 0 zeros, 1 the first frame repeated, 2 the two cached frames (cache1 / cache2)
-  bf16_t* cache1;     // [B][2][HW][128]: conv1's input (SiLU(LN1(x))) at frames -2, -1; rewritten in place with frames
-  bf16_t* cache2;     //   T - cache_off - 2, T - cache_off - 1 of this clip (NULL: no chunk state kept); conv2's input likewise
+  tb_h* cache1;       // [B][2][HW][128]: conv1's input (SiLU(LN1(x))) at frames -2, -1; rewritten in place with frames
+  tb_h* cache2;       //   T - cache_off - 2, T - cache_off - 1 of this clip (NULL: no chunk state kept); conv2's input likewise
   int cache_off;
   int keep_y;         // write y (0 only with ln_next != 0: the consumer needs just the normalised tensor)
   int ln_next;        // 0 none, 1 LayerNorm, 2 LayerNorm + SiLU
@@ -74,9 +76,9 @@ __device__ __forceinline__ void tb_static_for(F&& f) {
 // last steps and straight-line middle steps are separate instantiations of the same source).
 #pragma clang fp contract(off)
 typedef float f32x2 __attribute__((ext_vector_type(2)));
-typedef __bf16 tb_bf16x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ uint32_t tb_pack2(f32x2 v) {              // round-to-nearest-even, one v_cvt_pk_bf16_f32
-  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, tb_bf16x2));
+template <typename H>
+__device__ __forceinline__ uint32_t tb_pack2(f32x2 v) {              // round-to-nearest-even, one v_cvt_pk_bf16_f32 / v_cvt_pk_f16_f32
+  return h16<H>::pack(v[0], v[1]);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -90,17 +92,19 @@ __device__ __forceinline__ uint32_t tb_pack2(f32x2 v) {              // round-to
 [[maybe_unused]] constexpr int T3_OFF_T1 = 2 * TB_RING;
 [[maybe_unused]] constexpr int T3_OFF_T2 = 2 * TB_RING + TB_PIX * T3_T1P;
 [[maybe_unused]] constexpr int T3_LDS = T3_OFF_T2 + TB_T;                 // 153 600
+template <typename H>
 __device__ __forceinline__ void t3_unpack8(const u32x4& w, float (&v)[8]) {
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
-    v[2 * q] = __uint_as_float(w[q] << 16);
-    v[2 * q + 1] = __uint_as_float(w[q] & 0xffff0000u);
+    v[2 * q] = h16<H>::lo(w[q]);
+    v[2 * q + 1] = h16<H>::hi(w[q]);
   }
 }
+template <typename H>
 __device__ __forceinline__ u32x4 t3_pack8(const float (&o)[8]) {
   u32x4 w;
 #pragma unroll
-  for (int q = 0; q < 4; ++q) w[q] = tb_pack2(f32x2{o[2 * q], o[2 * q + 1]});
+  for (int q = 0; q < 4; ++q) w[q] = tb_pack2<H>(f32x2{o[2 * q], o[2 * q + 1]});
   return w;
 }
 
@@ -129,10 +133,15 @@ __device__ __forceinline__ u32x4 t3_pack8(const float (&o)[8]) {
 [[maybe_unused]] constexpr int T4_LDS = T4_OFF_PRM + 8 * 128 * 4;         // 157 696
 [[maybe_unused]] constexpr int T4_FD = 3;                                 // fragment prefetch distance of a GEMM, in MFMAs
 
-template <bool FIRST>
+template <typename H, bool FIRST>
 __device__ __forceinline__ void t4_mfma(const u32x4& w, const u32x4& x, f32x16& acc) {
-  if constexpr (FIRST) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=v"(acc) : "a"(w), "v"(x));
-  else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "a"(w), "v"(x));
+  if constexpr (std::is_same<H, bf16_t>::value) {
+    if constexpr (FIRST) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=v"(acc) : "a"(w), "v"(x));
+    else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "a"(w), "v"(x));
+  } else {
+    if constexpr (FIRST) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=v"(acc) : "a"(w), "v"(x));
+    else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc) : "a"(w), "v"(x));
+  }
 }
 // LayerNorm(+SiLU) of a row slice, even and odd channels summed separately and then together (the order of the packed-fp32
 // form this row phase once had; kept so that results did not move when the arrangement changed)
@@ -193,7 +202,8 @@ __device__ __forceinline__ void t4_row_norm(float (&v)[8], const float (&g)[8], 
 // CACHE: the instantiation that keeps v1.1 chunk state (cache1 / cache2).  Separate because its loads and stores are
 // conditional (a column starts, a kept frame goes by), and with conditional memory operations in the step body the
 // compiler no longer counts what is in flight -- it waits for everything.
-template <int LNN, bool KEEP, bool CACHE, bool PROF = false>
+// H = the 16-bit storage type (bf16_t / f16_t)
+template <typename H, int LNN, bool KEEP, bool CACHE, bool PROF = false>
 __global__ __launch_bounds__(512, 1) void tblock_pair_kernel(const TBlockArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -255,8 +265,8 @@ __global__ __launch_bounds__(512, 1) void tblock_pair_kernel(const TBlockArgs p)
       }
     }
   };
-  auto frame_rsrc = [&](const bf16_t* base, const Cur& c) __attribute__((always_inline)) {
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(base) + ((long long)c.b * p.T + c.t) * p.HW * 128, 0, frame_bytes, 0x00020000);
+  auto frame_rsrc = [&](const tb_h* base, const Cur& c) __attribute__((always_inline)) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<tb_h*>(base) + ((long long)c.b * p.T + c.t) * p.HW * 128, 0, frame_bytes, 0x00020000);
   };
 
   // PROF: stamps of workgroup 0, steps [8, 12): [step][wave][8] in the LDS behind the parameters, copied out at the end
@@ -280,7 +290,7 @@ __global__ __launch_bounds__(512, 1) void tblock_pair_kernel(const TBlockArgs p)
   // ---- stationary weights of my convolution
   u32x4 wreg[24];
   {
-    const bf16_t* wsrc = grp == 0 ? p.w1 : p.w2;
+    const tb_h* wsrc = grp == 0 ? p.w1 : p.w2;
     const long long roff = (long long)(cw * 32 + (lane & 31)) * 384 + (lane >> 5) * 8;
 #pragma unroll
     for (int g = 0; g < 24; ++g) wreg[g] = *reinterpret_cast<const u32x4*>(wsrc + roff + g * 16);
@@ -317,7 +327,7 @@ __global__ __launch_bounds__(512, 1) void tblock_pair_kernel(const TBlockArgs p)
     __builtin_amdgcn_s_setprio(1);
     tb_static_for<M0, 48>([&](auto mc) __attribute__((always_inline)) {
       constexpr int m = decltype(mc)::value;
-      t4_mfma<(m < M0 + 2)>(wreg[m >> 1], xf[m % (T4_FD + 1)], acc[m & 1]);
+      t4_mfma<H, (m < M0 + 2)>(wreg[m >> 1], xf[m % (T4_FD + 1)], acc[m & 1]);
       if constexpr (m + T4_FD < 48) xf[(m + T4_FD) % (T4_FD + 1)] = *faddr(m + T4_FD);
       __builtin_amdgcn_sched_barrier(0);
     });
@@ -341,8 +351,8 @@ __global__ __launch_bounds__(512, 1) void tblock_pair_kernel(const TBlockArgs p)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         u32x2 w;
-        w[0] = tb_pack2(f32x2{acc[j][4 * g], acc[j][4 * g + 1]});
-        w[1] = tb_pack2(f32x2{acc[j][4 * g + 2], acc[j][4 * g + 3]});
+        w[0] = tb_pack2<H>(f32x2{acc[j][4 * g], acc[j][4 * g + 1]});
+        w[1] = tb_pack2<H>(f32x2{acc[j][4 * g + 2], acc[j][4 * g + 3]});
         *reinterpret_cast<u32x2*>(smem + base + j * (32 * T3_T1P) + (((4 * cw + g) ^ (l31 & 15)) << 4)) = w;
       }
   };
@@ -391,7 +401,7 @@ __global__ __launch_bounds__(512, 1) void tblock_pair_kernel(const TBlockArgs p)
   };
   // L1 of units [U0, U1): LayerNorm1 + SiLU of x rows -> ring1 slot s3
   // chunk state: the row of frame c.t that a convolution's cache keeps (slot j = t - (T - cache_off - 2) in {0, 1})
-  auto cache_put = [&](bf16_t* cache, const Cur& c, int oct_j, int row, const u32x4& w) __attribute__((always_inline)) {
+  auto cache_put = [&](tb_h* cache, const Cur& c, int oct_j, int row, const u32x4& w) __attribute__((always_inline)) {
     if constexpr (!CACHE) return;
     const int j = c.t - (p.T - p.cache_off - 2);
     if (cache != nullptr && (j == 0 || j == 1)) {                    // uniform
@@ -401,14 +411,14 @@ __global__ __launch_bounds__(512, 1) void tblock_pair_kernel(const TBlockArgs p)
   };
   // ... and the other direction: the cached frames -2, -1 of the column at cursor c into ring slots sl2, sl1 (a group's 256
   // threads move 2 x 64 rows of 256 B; once per column)
-  auto cache_get = [&](const bf16_t* cache, int roff, const Cur& c, int sl2, int sl1) __attribute__((always_inline)) {
+  auto cache_get = [&](const tb_h* cache, int roff, const Cur& c, int sl2, int sl1) __attribute__((always_inline)) {
     if constexpr (!CACHE) return;
     int oct_j, row0;
     unit_geom(oct_j, row0);
     u32x4 w[2][4];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(cache) + ((long long)c.b * 2 + j) * p.HW * 128, 0, frame_bytes, 0x00020000);
+      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<tb_h*>(cache) + ((long long)c.b * 2 + j) * p.HW * 128, 0, frame_bytes, 0x00020000);
 #pragma unroll
       for (int it = 0; it < 4; ++it) w[j][it] = __builtin_amdgcn_raw_buffer_load_b128(rs, (c.pt * TB_PIX + row0 + 16 * it) * 256 + oct_j * 16, 0, 0);
     }
@@ -429,9 +439,9 @@ __global__ __launch_bounds__(512, 1) void tblock_pair_kernel(const TBlockArgs p)
 #pragma unroll
     for (int it = U0; it < U1; ++it) {
       float v[8], o[8];
-      t3_unpack8(xr[it], v);
+      t3_unpack8<H>(xr[it], v);
       t4_row_norm_pairs<true>(v, g, b, p.eps, o);
-      const u32x4 w = t3_pack8(o);
+      const u32x4 w = t3_pack8<H>(o);
       *reinterpret_cast<u32x4*>(smem + wo + it * (16 * TB_ROWP)) = w;
       cache_put(p.cache1, c, oct_j, row0 + 16 * it, w);
     }
@@ -516,11 +526,11 @@ __global__ __launch_bounds__(512, 1) void tblock_pair_kernel(const TBlockArgs p)
 #pragma unroll
     for (int it = U0; it < U1; ++it) {
       float v[8], o[8];
-      t3_unpack8(tw[it], v);
+      t3_unpack8<H>(tw[it], v);
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] = v[e] + bo1[e];
       t4_row_norm<true>(v, g, b, p.eps, o);
-      const u32x4 w = t3_pack8(o);
+      const u32x4 w = t3_pack8<H>(o);
       *reinterpret_cast<u32x4*>(smem + wo + it * (16 * TB_ROWP)) = w;
       cache_put(p.cache2, c, oct_j, row0 + 16 * it, w);
     }
@@ -543,14 +553,14 @@ __global__ __launch_bounds__(512, 1) void tblock_pair_kernel(const TBlockArgs p)
     const f32x4 t0 = *reinterpret_cast<const f32x4*>(smem + to);
     const f32x4 t1 = *reinterpret_cast<const f32x4*>(smem + (to ^ 16));
     float v[8], xv[8];
-    t3_unpack8(xrow, xv);
+    t3_unpack8<H>(xrow, xv);
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] = xv[e] + ((e < 4 ? t0[e] : t1[e - 4]) + bo2[e]);
-    if constexpr (KEEP) out_store(t3_pack8(v), frame_rsrc(p.y, c), vo);
+    if constexpr (KEEP) out_store(t3_pack8<H>(v), frame_rsrc(p.y, c), vo);
     if constexpr (LNN != 0) {
       float o[8];
       t4_row_norm<(LNN == 2)>(v, gn, bn, p.eps, o);
-      out_store(t3_pack8(o), frame_rsrc(p.n_out, c), vo);
+      out_store(t3_pack8<H>(o), frame_rsrc(p.n_out, c), vo);
     }
   };
   using I0 = std::integral_constant<int, 0>;
@@ -662,7 +672,7 @@ extern "C" int vt_tblock_desc_size(void) { return (int)sizeof(vt_tblock_desc); }
 
 extern "C" int vt_temporal_block_supported(const vt_tblock_desc* d) {
   if (!d) return 0;
-  if (d->dtype != VT_BF16 || d->C != 128 || d->ld != 128) return 0;
+  if (!vt_is_h16(d->dtype) || d->C != 128 || d->ld != 128) return 0;
   if (d->B <= 0 || d->T <= 0 || d->HW <= 0 || d->HW % TB_PIX != 0) return 0;
   if (d->tmode != VT_TPAD_ZERO && d->tmode != VT_TPAD_REPLICATE && d->tmode != VT_TPAD_CACHE) return 0;
   if (d->tmode == VT_TPAD_CACHE && (d->cache1 == nullptr || d->cache2 == nullptr)) return 0;
@@ -679,7 +689,7 @@ int tblock_launch(const vt_tblock_desc* d, vt_stream stream_, unsigned long long
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
   VT_CHECK_ARG(d != nullptr, "vt_temporal_block: null descriptor");
   VT_CHECK_ARG(vt_temporal_block_supported(d),
-               "vt_temporal_block: only bf16, C = ld = 128, HW %% 64 == 0; cache mode needs both caches, kept chunk state "
+               "vt_temporal_block: only bf16 / fp16, C = ld = 128, HW %% 64 == 0; cache mode needs both caches, kept chunk state "
                "T - cache_offset >= 3 (got dtype %d C %d ld %d HW %lld T %d tmode %d cache_offset %d)", d->dtype, d->C, d->ld,
                (long long)d->HW, d->T, d->tmode, d->cache_offset);
   VT_CHECK_ARG(d->x && d->w1 && d->w2 && d->norm1_gamma && d->norm1_beta && d->norm2_gamma && d->norm2_beta,
@@ -691,13 +701,13 @@ int tblock_launch(const vt_tblock_desc* d, vt_stream stream_, unsigned long long
                        reinterpret_cast<uintptr_t>(d->w1) | reinterpret_cast<uintptr_t>(d->w2);
   VT_CHECK_ARG((al & 15) == 0, "vt_temporal_block: tensors must be 16-byte aligned");
   TBlockArgs a;
-  a.x = (const bf16_t*)d->x; a.y = (bf16_t*)d->y; a.n_out = (bf16_t*)d->n_out;
-  a.w1 = (const bf16_t*)d->w1; a.w2 = (const bf16_t*)d->w2; a.b1 = d->b1; a.b2 = d->b2;
+  a.x = (const tb_h*)d->x; a.y = (tb_h*)d->y; a.n_out = (tb_h*)d->n_out;
+  a.w1 = (const tb_h*)d->w1; a.w2 = (const tb_h*)d->w2; a.b1 = d->b1; a.b2 = d->b2;
   a.g1 = d->norm1_gamma; a.be1 = d->norm1_beta; a.g2 = d->norm2_gamma; a.be2 = d->norm2_beta;
   a.gn = d->next_gamma; a.ben = d->next_beta;
   a.B = d->B; a.T = d->T; a.HW = (int)d->HW;
   a.replicate = d->tmode == VT_TPAD_REPLICATE ? 1 : (d->tmode == VT_TPAD_CACHE ? 2 : 0);
-  a.cache1 = (bf16_t*)d->cache1; a.cache2 = (bf16_t*)d->cache2; a.cache_off = d->cache_offset;
+  a.cache1 = (tb_h*)d->cache1; a.cache2 = (tb_h*)d->cache2; a.cache_off = d->cache_offset;
   VT_CHECK_ARG(((reinterpret_cast<uintptr_t>(d->cache1) | reinterpret_cast<uintptr_t>(d->cache2)) & 15) == 0, "vt_temporal_block: caches must be 16-byte aligned");
   a.keep_y = d->keep_y ? 1 : 0;
   a.ln_next = d->ln_next_mode;
@@ -706,23 +716,26 @@ int tblock_launch(const vt_tblock_desc* d, vt_stream stream_, unsigned long long
   a.prof_mode = prof ? vt_opt(OPT_TBLOCK_PROF_MODE) : 0;
   VT_CHECK_ARG((long long)d->HW * 256 < (1ll << 31), "vt_temporal_block: frames of at most 2^23 pixels");
   // one instantiation per output shape: next norm none / LayerNorm / LayerNorm+SiLU, y kept or not
-  static const void* const kerns2[11] = {
-      reinterpret_cast<const void*>(&tblock_pair_kernel<0, true, false>), reinterpret_cast<const void*>(&tblock_pair_kernel<1, true, false>),
-      reinterpret_cast<const void*>(&tblock_pair_kernel<1, false, false>), reinterpret_cast<const void*>(&tblock_pair_kernel<2, true, false>),
-      reinterpret_cast<const void*>(&tblock_pair_kernel<2, false, false>), reinterpret_cast<const void*>(&tblock_pair_kernel<2, true, false, true>),
-      reinterpret_cast<const void*>(&tblock_pair_kernel<0, true, true>), reinterpret_cast<const void*>(&tblock_pair_kernel<1, true, true>),
-      reinterpret_cast<const void*>(&tblock_pair_kernel<1, false, true>), reinterpret_cast<const void*>(&tblock_pair_kernel<2, true, true>),
-      reinterpret_cast<const void*>(&tblock_pair_kernel<2, false, true>)};
+#define VT_TB_KERNS(H)                                                                                                              \
+  reinterpret_cast<const void*>(&tblock_pair_kernel<H, 0, true, false>), reinterpret_cast<const void*>(&tblock_pair_kernel<H, 1, true, false>),      \
+      reinterpret_cast<const void*>(&tblock_pair_kernel<H, 1, false, false>), reinterpret_cast<const void*>(&tblock_pair_kernel<H, 2, true, false>), \
+      reinterpret_cast<const void*>(&tblock_pair_kernel<H, 2, false, false>), reinterpret_cast<const void*>(&tblock_pair_kernel<H, 0, true, true>),  \
+      reinterpret_cast<const void*>(&tblock_pair_kernel<H, 1, true, true>), reinterpret_cast<const void*>(&tblock_pair_kernel<H, 1, false, true>),   \
+      reinterpret_cast<const void*>(&tblock_pair_kernel<H, 2, true, true>), reinterpret_cast<const void*>(&tblock_pair_kernel<H, 2, false, true>)
+  constexpr int NK = 21;             // [bf16: 5 output shapes x {plain, chunk state}] [fp16: the same] [bf16 with stamps]
+  static const void* const kerns2[NK] = {VT_TB_KERNS(bf16_t), VT_TB_KERNS(f16_t), reinterpret_cast<const void*>(&tblock_pair_kernel<bf16_t, 2, true, false, true>)};
+#undef VT_TB_KERNS
   const bool cached = a.replicate == 2 || a.cache1 != nullptr || a.cache2 != nullptr;
   int ki = a.ln_next == 0 ? 0 : (a.ln_next == 1 ? (a.keep_y ? 1 : 2) : (a.keep_y ? 3 : 4));
   int lds = T4_LDS;
   const unsigned threads = 512;
-  if (prof != nullptr) {                      // measurement aid: stamps [wave 0..7][step][8] of the LayerNorm+SiLU, y kept instantiation
-    VT_CHECK_ARG(a.ln_next == 2 && a.keep_y && !cached, "vt_temporal_block_profile: ln_next_mode 2 and keep_y only, no chunk state");
-    ki = 5;
+  if (cached) ki += 5;
+  if (d->dtype == VT_F16) ki += 10;
+  if (prof != nullptr) {                      // measurement aid: stamps [wave 0..7][step][8] of the bf16 LayerNorm+SiLU, y kept instantiation
+    VT_CHECK_ARG(d->dtype == VT_BF16 && a.ln_next == 2 && a.keep_y && !cached, "vt_temporal_block_profile: bf16, ln_next_mode 2 and keep_y only, no chunk state");
+    ki = 20;
     lds += 2048;
   }
-  if (cached) ki += 6;
   const void* kern = kerns2[ki];
   // per device, once: the dynamic-LDS attribute of every instantiation and the CU count (not a per-launch runtime call)
   static std::atomic<int> cus[kMaxDevices];
@@ -730,8 +743,8 @@ int tblock_launch(const vt_tblock_desc* d, vt_stream stream_, unsigned long long
   VT_CHECK_HIP(hipGetDevice(&dev));
   int ncu = (dev >= 0 && dev < kMaxDevices) ? cus[dev].load(std::memory_order_acquire) : 0;
   if (ncu == 0) {
-    for (int k = 0; k < 11; ++k)
-      VT_CHECK_HIP(hipFuncSetAttribute(kerns2[k], hipFuncAttributeMaxDynamicSharedMemorySize, k == 5 ? T4_LDS + 2048 : T4_LDS));
+    for (int k = 0; k < NK; ++k)
+      VT_CHECK_HIP(hipFuncSetAttribute(kerns2[k], hipFuncAttributeMaxDynamicSharedMemorySize, k == 20 ? T4_LDS + 2048 : T4_LDS));
     VT_CHECK_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
     if (ncu <= 0) ncu = 256;
     if (dev >= 0 && dev < kMaxDevices) cus[dev].store(ncu, std::memory_order_release);

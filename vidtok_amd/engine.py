@@ -30,7 +30,7 @@ def _print0(msg):
 
 class AutoencodingEngine(nn.Module):
     version = "v1_0"
-    arith = "fp32"          # set_compute_dtype(): "fp32" | "bf16" | "bf16x3"
+    arith = "fp32"          # set_compute_dtype(): "fp32" | "bf16" | "fp16" | "bf16x3"
 
     def __init__(self, *args, encoder_config: Dict, decoder_config: Dict, loss_config: Dict = None,
                  regularizer_config: Dict, optimizer_config: Union[Dict, None] = None, lr_g_factor: float = 1.0,
@@ -66,26 +66,33 @@ class AutoencodingEngine(nn.Module):
 
     # ---- numeric mode ---------------------------------------------------------------------------
     def set_compute_dtype(self, dtype, encoder_tail: Optional[torch.dtype] = None, tail_level: Optional[int] = None):
-        """torch.float32: fp32 storage + fp32-input MFMA (parity mode); torch.bfloat16: bf16 storage +
-        bf16 MFMA with fp32 accumulation (throughput mode, the reference's autocast analogue); "bf16x3": fp32 storage,
+        """torch.float32: fp32 storage + fp32-input MFMA (parity mode); torch.bfloat16 / torch.float16: 16-bit storage +
+        bf16 / fp16 MFMA with fp32 accumulation (throughput modes: what the reference computes in under torch.autocast with
+        that dtype; fp16 values beyond 65 504 become inf, as in the reference's fp16 convolutions); "bf16x3": fp32 storage,
         every convolution on the bf16 matrix cores from bf16 hi / lo planes of both operands (vt_conv VT_BF16X3: three
         MFMAs per product, ~2^-17 relative per product) -- the fast mode that stays inside the reference's fp32 tolerance;
-        `self.arith` says which ("fp32" | "bf16" | "bf16x3").
+        `self.arith` says which ("fp32" | "bf16" | "fp16" | "bf16x3").
         `encoder_tail` (causal encoders): the encoder levels from `tail_level` on (default: the last level), its mid section
         and conv_out run in that type instead -- the small deep layers, whose rounding decides most of the FSQ code flips
         of a bf16 pass, in fp32 while the wide levels stay on the bf16 kernels."""
         self._chosen = (dtype, encoder_tail, tail_level)         # what to return to when an autocast region ends
         self._autocast_active = None
         self._apply_compute_dtype(dtype, encoder_tail, tail_level)
+        self.invalidate_graphs()
         return self
 
+    _ARITH_NAME = {torch.float32: "fp32", torch.bfloat16: "bf16", torch.float16: "fp16"}
+
     def _apply_compute_dtype(self, dtype, encoder_tail=None, tail_level=None):
+        """switch the arithmetic mode.  Captured graphs stay: their keys carry (dtype, arith, tail), the packed weights of every
+        mode a module has run in stay cached (packing.PackedCache), the v1.1 chunk-cache buffers are kept per dtype -- a caller
+        that alternates autocast and plain calls replays both sets"""
         split3 = dtype == packing.ARITH_SPLIT3
         if split3:
             dtype = torch.float32
-        assert dtype in (torch.float32, torch.bfloat16) and encoder_tail in (None, torch.float32, torch.bfloat16)
+        assert dtype in self._ARITH_NAME and encoder_tail in (None,) + tuple(self._ARITH_NAME)
         packing.set_arith(self, packing.ARITH_SPLIT3 if split3 else None)
-        self.arith = packing.ARITH_SPLIT3 if split3 else ("fp32" if dtype == torch.float32 else "bf16")
+        self.arith = packing.ARITH_SPLIT3 if split3 else self._ARITH_NAME[dtype]
         self.encoder.compute_dtype = dtype
         self.decoder.compute_dtype = dtype
         if hasattr(self.encoder, "tail_dtype"):
@@ -95,29 +102,27 @@ class AutoencodingEngine(nn.Module):
             assert encoder_tail is None or 0 <= self.encoder.tail_level <= n
         else:
             assert encoder_tail is None, "encoder_tail: causal encoders only"
-        self.invalidate_graphs()
 
     # ---- the caller's torch.autocast region (reference README.md:336-340,375-385: `with torch.autocast(device_type="cuda",
     # dtype=...): model(x)`) ---------------------------------------------------------------------------------------------
     # The reference has no precision switch of its own: the ambient autocast context decides what its convolutions and
     # matmuls compute in.  Here the kernels are chosen by `set_compute_dtype`, so the engine reads the context at every
-    # entry point: autocast(bfloat16) -> the bf16 kernels for this call (whatever was set; the chosen mode returns when
-    # the region ends), autocast(float16) -> per `autocast_policy["float16"]`: "error" (default: there are no fp16
-    # kernels, and running another precision silently is not what the caller asked for), or "bf16" / "bf16x3" to map it.
-    autocast_policy = {"bfloat16": "bf16", "float16": "error"}
+    # entry point: autocast(bfloat16) -> the bf16 kernels for this call, autocast(float16) -- the dtype of the README's
+    # snippets and of `--precision autocast` in scripts/inference_*.py -- -> the fp16 kernels (whatever was set; the chosen
+    # mode, and an fp32 `encoder_tail` chosen with it, return / stay).  `autocast_policy` can map a region elsewhere.
+    autocast_policy = {"bfloat16": "bf16", "float16": "fp16"}
 
     def set_autocast_policy(self, **kw):
-        """e.g. set_autocast_policy(float16="bf16"): run autocast(float16) regions on the bf16 kernels (fp32 accumulation,
-        8 significant bits of storage instead of fp16's 11); "bf16x3" = the split-bf16 mode (inside fp32 tolerance); "error";
-        "ignore" = keep the mode chosen by set_compute_dtype"""
+        """e.g. set_autocast_policy(float16="bf16x3"): run autocast(float16) regions in the split-bf16 mode (inside fp32
+        tolerance); "bf16" / "fp16" = those kernels; "ignore" = keep the mode chosen by set_compute_dtype; "error" = raise"""
         pol = dict(self.autocast_policy)
         for k, v in kw.items():
-            assert k in ("bfloat16", "float16") and v in ("bf16", "bf16x3", "error", "ignore"), (k, v)
+            assert k in ("bfloat16", "float16") and v in ("bf16", "fp16", "bf16x3", "error", "ignore"), (k, v)
             pol[k] = v
         self.autocast_policy = pol
         return self
 
-    _MODE_DTYPE = {"bf16": torch.bfloat16, "bf16x3": packing.ARITH_SPLIT3}
+    _MODE_DTYPE = {"bf16": torch.bfloat16, "fp16": torch.float16, "bf16x3": packing.ARITH_SPLIT3}
 
     def _sync_autocast(self, x):
         """make the arithmetic mode follow the caller's autocast context (device of `x`)"""
@@ -133,20 +138,21 @@ class AutoencodingEngine(nn.Module):
             pol = self.autocast_policy.get({torch.bfloat16: "bfloat16", torch.float16: "float16"}.get(adt, ""), "error")
             if pol == "error":
                 raise NotImplementedError(
-                    f"vidtok_amd: called under torch.autocast(dtype={adt}); the MI355X kernels compute in bf16 (autocast(bfloat16) "
-                    f"selects them), split-bf16 or fp32 -- there is no {adt} arithmetic.  Use torch.autocast(dtype=torch.bfloat16), "
-                    f"or model.set_autocast_policy(float16='bf16' | 'bf16x3' | 'ignore') to choose what such a region runs")
+                    f"vidtok_amd: called under torch.autocast(dtype={adt}): no kernels for that dtype (bfloat16 and float16 regions "
+                    f"select the bf16 / fp16 kernels), or the policy for it is 'error' (model.set_autocast_policy)")
             if pol != "ignore":
                 want = self._MODE_DTYPE[pol]
         active = getattr(self, "_autocast_active", None)
         if want is not None:
-            name = "bf16" if want == torch.bfloat16 else want
-            if active is None and self.arith == name and getattr(self.encoder, "tail_dtype", None) is None:
+            name = self._ARITH_NAME.get(want, want)
+            if active is None and self.arith == name:
                 return                                          # already the mode the region asks for: nothing to switch, nothing to restore
             if active != want:
                 if getattr(self, "_chosen", None) is None:      # never set: the construction default
                     self._chosen = (self.encoder.compute_dtype, None, None)
-                self._apply_compute_dtype(want)
+                # an encoder tail chosen with the mode (fp32 deep levels for FSQ code stability) stays in force inside the region
+                _, tail, level = self._chosen
+                self._apply_compute_dtype(want, tail, level)
                 self._autocast_active = want
         elif active is not None:
             self._autocast_active = None

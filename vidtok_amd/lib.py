@@ -15,7 +15,7 @@ import torch  # noqa: F401  (load order matters)
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libvidtok_amd.so")
 
-VT_F32, VT_BF16, VT_I32, VT_BF16X3 = 0, 1, 2, 3
+VT_F32, VT_BF16, VT_I32, VT_BF16X3, VT_F16 = 0, 1, 2, 3, 4
 VT_TPAD_ZERO, VT_TPAD_REPLICATE, VT_TPAD_CACHE, VT_TPAD_ZERO_BACK = 0, 1, 2, 3
 VT_GN_FRAME, VT_GN_PIXEL, VT_GN_CLIP = 0, 1, 2
 VT_RES_NONE, VT_RES_ADD, VT_RES_MIX = 0, 1, 2

@@ -520,7 +520,7 @@ class ResnetCausalBlock1D(nn.Module):
 
     def _fusable(self, dt):
         """may run as ONE launch (ops.temporal_block): LayerNorm variant, C -> C, bf16"""
-        if not _FUSE_TBLOCK or dt != torch.bfloat16 or self.in_channels != self.out_channels:
+        if not _FUSE_TBLOCK or dt not in ops.H16 or self.in_channels != self.out_channels:
             return False
         if not (self.norm1.fusable and self.norm2.fusable) or self.norm1.norm.eps != self.norm2.norm.eps:
             return False

@@ -4,7 +4,7 @@ PyTorch is plumbing here: tensors provide device memory and the current HIP stre
 arithmetic operation of the path is one of the HIP kernels in vidtok_amd/csrc.  All wrappers
 raise if the tensors are not on a GPU -- there is no CPU implementation in the product.
 
-Activation tensors are NDHWC: shape [B, T, H, W, C], contiguous, float32 or bfloat16.
+Activation tensors are NDHWC: shape [B, T, H, W, C], contiguous, float32, bfloat16 or float16.
 """
 import ctypes as C
 from dataclasses import dataclass
@@ -14,7 +14,8 @@ import torch
 
 from . import lib as L
 
-_DT = {torch.float32: L.VT_F32, torch.bfloat16: L.VT_BF16}
+_DT = {torch.float32: L.VT_F32, torch.bfloat16: L.VT_BF16, torch.float16: L.VT_F16}
+H16 = (torch.bfloat16, torch.float16)      # the 16-bit storage types: every kernel written for one takes the other
 CH_ALIGN = 8  # channel padding granule: 16 B of bf16 (and a multiple of the 4-float fp32 granule)
 
 
@@ -31,12 +32,12 @@ def _conv_launch(lib, d, what, keep=()):
 
 
 def conv_plan(d):
-    """vt_conv_plan(d) -> dict(tile=(BM, BN), waves, workgroups, ln_fused, launches, kernel="igemm" | "ws128" | "ws2" | "narrow" | "in8",
-    lds_epilogue, deep_ring, half_tile)"""
+    """vt_conv_plan(d) -> dict(tile=(BM, BN), waves, workgroups, ln_fused, launches, kernel="igemm" | "ws2" | "narrow" | "in8",
+    lds_epilogue, deep_ring)"""
     out = (C.c_int32 * 8)()
     L.check(L.load().vt_conv_plan(C.byref(d), out), "vt_conv_plan")
     return dict(tile=(out[0], out[1]), waves=out[2], workgroups=out[3], ln_fused=bool(out[4]), launches=out[5],
-                kernel={1: "ws128", 2: "narrow", 3: "ws2", 4: "in8"}.get(out[6], "igemm"), lds_epilogue=out[7] in (1, 3), deep_ring=out[7] == 2, half_tile=out[7] == 3)
+                kernel={2: "narrow", 3: "ws2", 4: "in8"}.get(out[6], "igemm"), lds_epilogue=out[7] == 1, deep_ring=out[7] == 2)
 
 
 def replay_convs(record, conv_kernel_only=True):
@@ -200,7 +201,7 @@ def conv(x, w, bias, geom: ConvGeom, *, cout: int, out_dtype=None, tmode=L.VT_TP
             d.ln_mode = 0
             ln, n = None, None
     work = None
-    if x.dtype == torch.bfloat16 and (geom.kt == 3 or geom.kh == 3):      # split-K over tap planes (small-M launches): the library says how much scratch
+    if x.dtype in H16 and (geom.kt == 3 or geom.kh == 3):      # split-K over tap planes (small-M launches): the library says how much scratch
         nb = lib.vt_conv_work_bytes(C.byref(d))
         if nb > 0:
             work = torch.empty((nb,), dtype=torch.uint8, device=x.device)
@@ -362,7 +363,7 @@ def launch_bytes(d):
         es = 2
         px = d.B * d.T * d.HW
         return px * d.ld * es * (1 + (1 if d.keep_y else 0) + (1 if d.ln_next_mode else 0)) + 2 * d.C * 3 * d.C * es
-    es = 2 if d.dtype == L.VT_BF16 else 4
+    es = 2 if d.dtype in (L.VT_BF16, L.VT_F16) else 4
     eo = 4 if d.out_dtype == L.VT_F32 else 2
     nb = max(1, d.nbatch)
     M = d.B * d.To * d.Ho * d.Wo * nb
@@ -540,7 +541,7 @@ def gather_frames(src, idx, out=None, out_t0=0):
 
 def pack_conv_weight(weight, dtype, cin_stored=None, mix=None, split3=False):
     """vt_pack_conv_weight: weight fp32 [Cout, Cin, *k] on the GPU (a reference parameter) -> packed rows [Cout, ldw] for
-    vt_conv: k = tap * cin_stored + c, in `dtype` (float32 / bfloat16) or, with split3, the int32-typed split-bf16 container.
+    vt_conv: k = tap * cin_stored + c, in `dtype` (float32 / bfloat16 / float16) or, with split3, the int32-typed split-bf16 container.
     mix = [[m0, m1, m2, m3], ...] per OUTPUT tap (-1 = absent): pre-summed taps of an up-sampler's parity class."""
     lib = L.load()
     _chk(weight, "pack.weight")

@@ -128,9 +128,8 @@ class PackedCache:
     host parameters (CPU tests, tools) by the torch statements above."""
 
     def __init__(self, transform=None, pin_native=False, mix=None):
-        self._key = None
-        self._val = None
-        self._transform = transform
+        self._entries = {}           # (dtype, arith, cin_stored) -> (validity key, (w, b)): the packed rows of every mode the module has run
+        self._transform = transform  # in stay alive, so a graph captured in one mode still replays after a detour through another
         self._mix = mix
         assert (transform is None) == (mix is None)
         self.arith = None            # set_arith(): ARITH_SPLIT3 = fp32 requests are answered with split-bf16 planes
@@ -140,7 +139,9 @@ class PackedCache:
         arith = self.arith if dtype == torch.float32 else None
         key = (dtype, weight.device, weight._version, None if bias is None else bias._version, cin_stored,
                weight.data_ptr(), arith)
-        if key != self._key:
+        slot = (dtype, arith, cin_stored)
+        ent = self._entries.get(slot)
+        if ent is None or ent[0] != key:
             if weight.is_cuda:
                 from . import ops
 
@@ -153,5 +154,5 @@ class PackedCache:
                 if arith == ARITH_SPLIT3:
                     w = pack_split3(w)
             b = None if bias is None else bias.detach().to(torch.float32).contiguous()
-            self._key, self._val = key, (w, b)
-        return self._val
+            ent = self._entries[slot] = (key, (w, b))
+        return ent[1]
