@@ -58,7 +58,7 @@ sys.path.insert(0, ROOT)
 FLOP_PER_PADDED_FRAME_256 = 1.0345e12     # SURVEY.md section 8(d), conv + attention MACs x 2
 # MI355X_MICROARCH.md: dense MFMA peaks.  bf16x3 (split-bf16: fp32 storage, three bf16 MFMAs per product) is priced per
 # ALGORITHMIC FLOP like the others: a third of the bf16 peak
-PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3, "bf16x3": 2500.0 / 3}
+PEAK_TFLOPS = {"bf16": 2500.0, "fp16": 2500.0, "fp32": 157.3, "bf16x3": 2500.0 / 3}
 PEAK_HBM_GBS = 8000.0                           # MI355X_MICROARCH.md: HBM3E 8 TB/s (6.3 TB/s achievable by a copy)
 T_REAL, T_PADDED, RES = 17, 20, 256
 CONFIG_1GPU = "vidtok_kl_causal_488_4chn"       # BASELINE.json configs[1]
@@ -80,6 +80,12 @@ def randomize_weights(model, seed=0):
                 p.copy_(0.05 * torch.randn(p.shape, generator=g))
             else:
                 p.copy_(torch.randn(p.shape, generator=g) / math.sqrt(p[0].numel()))
+
+
+# seconds of the UNMODIFIED reference's forward / seconds of the oracle port's, same 17x256x256 clip, same threads: measured where the reference can
+# be imported (scripts/cpu_port_vs_reference.py in the build container, 8 vCPUs) -- the reference is that much slower than the port timed here
+REFERENCE_OVER_PORT = {"ratio": 1.14, "measured_on": "build container, 8 vCPU, 8 torch threads, fp32, vidtok_kl_causal_488_4chn 17x256x256",
+                       "source": "profiles/r05_cpu_port_vs_reference.txt (re-measured per round by scripts/cpu_port_vs_reference.py)"}
 
 
 def cpu_baseline(config=None, clip=None, seed=77):
@@ -117,15 +123,31 @@ def cpu_baseline(config=None, clip=None, seed=77):
             best_t, threads = t, nt
         if t > 3.0 * best_t or t > 10.0:
             break                 # past the knee: more threads only get slower
-    torch.set_num_threads(threads)
     if clip is None:
         clip = torch.rand(1, 3, T_REAL, RES, RES) * 2 - 1
-    torch.manual_seed(seed)          # the KL noise stream: the engine's host-noise pass of the same clip draws the same numbers
-    t0 = time.perf_counter()
-    z, dec, _ = ora(clip)
-    t = time.perf_counter() - t0
+    # the probe's winner AND its faster neighbour in the sweep run the real 17x256x256 clip (the knee of a 64x64 probe need
+    # not be the knee of the 256x256 clip); `value` is the faster of the two
+    order = sorted(int(k) for k in sweep)
+    i = order.index(threads)
+    cands = [threads] + [n for n in (order[i + 1] if i + 1 < len(order) else None, order[i - 1] if i > 0 else None) if n is not None][:1]
+    full, best = {}, None
+    for nt in cands:
+        torch.set_num_threads(nt)
+        torch.manual_seed(seed)      # the KL noise stream: the engine's host-noise pass of the same clip draws the same numbers
+        t0 = time.perf_counter()
+        z, dec, _ = ora(clip)
+        t = time.perf_counter() - t0
+        full[str(nt)] = round(t, 2)
+        if best is None or t < best[0]:
+            best = (t, nt, z, dec)
+    t, threads, z, dec = best
+    torch.set_num_threads(threads)
     return {"value": round(T_REAL / t, 4), "unit": "frames/s", "cores": threads, "kind": "port",
-            "thread_sweep": {"probe": "17x64x64 clip, seconds per forward by torch thread count", **sweep},
+            "thread_sweep": {"probe": "17x64x64 clip, seconds per forward by torch thread count", **sweep,
+                             "full_clip": {"what": f"17x{RES}x{RES} clip, seconds per forward: the probe's winner and its neighbour", **full}},
+            # the unmodified reference (importable only in the build container: /root/reference does not exist on the GPU box) against this
+            # port on the same clip at the same thread count: scripts/cpu_port_vs_reference.py, profiles/r06_cpu_port_vs_reference.txt
+            "reference_over_port": REFERENCE_OVER_PORT,
             "sample": f"oracle/vidtok_oracle.py forward, fp32, 1 unscaled clip 17x{RES}x{RES} in {t:.2f}s on {threads} of "
                       f"{cores} host threads, the best of the sweep ({config})"}, (z, dec)
 
@@ -147,7 +169,7 @@ def time_steps(fn, steps, warmup=3):
     return (time.perf_counter() - t0) / steps, out
 
 
-MODES = {"bf16": torch.bfloat16, "fp32": torch.float32, "bf16x3": "bf16x3"}
+MODES = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": torch.float32, "bf16x3": "bf16x3"}
 
 
 def mode_measurements(model, x, main_mode, seed=77):
@@ -404,8 +426,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--dtype", choices=["bf16", "fp32", "bf16x3"], default="bf16",
-                    help="bf16: bf16 storage + MFMA (throughput mode); fp32: fp32 storage + fp32 MFMA; bf16x3: fp32 storage, every "
+    ap.add_argument("--dtype", choices=["bf16", "fp16", "fp32", "bf16x3"], default="bf16",
+                    help="bf16 / fp16: 16-bit storage + MFMA (throughput modes; fp16 = the reference README's autocast dtype); fp32: fp32 storage + fp32 MFMA; bf16x3: fp32 storage, every "
                          "convolution as three bf16 MFMAs per product (the fast mode inside the reference's fp32 tolerance)")
     ap.add_argument("--batch", type=int, default=4, help="clips per GPU")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
@@ -451,8 +473,8 @@ def main():
         if world > 1:
             dist.init_process_group("gloo", rank=rank, world_size=world)
         a, b = shard_range(4 * world, world, rank)
-        red = reduce_metrics(1.0 + rank, {"clips": float(b - a)})
-        rec = {"selftest": "spawn", "n_gpus": red["world"], "clips": red["clips"], "elapsed_s": red["elapsed_s"]}
+        red = reduce_metrics(1.0 + rank, {"clips": float(b - a), "ranks": 1.0})
+        rec = {"selftest": "spawn", "n_gpus": red["world"], "ranks_seen": int(round(red["ranks"])), "clips": red["clips"], "elapsed_s": red["elapsed_s"]}
         if args.selftest_steps > 0:
             host_s = selftest_host_loop(args.selftest_steps, args.batch, world)
             if world > 1:
@@ -479,7 +501,7 @@ def main():
     import vidtok_amd
     from vidtok_amd import ops
 
-    dtype = {"bf16": torch.bfloat16, "fp32": torch.float32, "bf16x3": "bf16x3"}[args.dtype]
+    dtype = MODES[args.dtype]
     config = args.config or (CONFIG_1GPU if world == 1 else CONFIG_NGPU)
     model = vidtok_amd.load_model_from_config(os.path.join(ROOT, "configs", config + ".yaml"), verbose=False)
     randomize_weights(model, 0)
@@ -531,7 +553,8 @@ def main():
     elapsed = time.perf_counter() - t0
     from vidtok_amd.sharding import reduce_metrics
 
-    red = reduce_metrics(elapsed, {"frames": float(B * T_REAL * args.steps)}, device=dev)  # one tiny RCCL all_reduce
+    # one tiny RCCL all_reduce; "ranks": every rank contributes 1 -- the sum is the number of ranks the collective really reached
+    red = reduce_metrics(elapsed, {"frames": float(B * T_REAL * args.steps), "ranks": 1.0}, device=dev)
     elapsed, total_frames = red["elapsed_s"], red["frames"]
     # the same K steps with the OTHER noise source (host stream vs device philox), so the line shows what the reference's
     # host-side noise protocol costs per step (per rank: it is the host cost SURVEY.md section 8e names as the 8-GPU risk)
@@ -727,11 +750,12 @@ def main():
     value = total_frames / elapsed
     line = {
         "metric": f"encode+decode frames/sec, {config} 17x256x256", "value": round(value, 2),
-        "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "unit": "frames/s", "n_gpus": world, "ranks_seen": int(round(red["ranks"])), "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": args.dtype, "data": "synthetic uniform[-1,1] clips, random-init weights (temporal convs un-zeroed)",
         "config": {"workload": f"{config} forward (encode+KL+decode), {args.dtype}, B={B} clips/GPU, 17x256x256",
-                   "global_batch": world * B, "parallelism": f"dp{world} (batch-sharded, no data-path collective)",
+                   "global_batch": world * B, "parallelism": f"dp{world} (batch-sharded, no data-path collective; ranks_seen = the world size the RCCL "
+                                                              f"metrics all_reduce counted)",
                    "launch": "hipGraph replay (engine graph cache)" if graph is not None else "eager"},
         "output_finite": ok, "noise": noise_rec, "roofline": roof, "cpu_baseline": cpu,
     }

@@ -20,7 +20,7 @@ from vidtok_amd.ops import ConvGeom  # noqa: E402
 # barrier / stage end; schedule 2 (two-group ping-pong): the eight phase boundaries of a step.  NB: a stamp is an s_memtime plus
 # its lgkmcnt(0) -- it drains the fragment reads in flight, so the stamped kernel is slower than the shipped one (K = 13 824
 # layers: ~2 400 cycles per step by the launch time against ~3 100 here); the PROPORTIONS are what to read
-SCHED = int(os.environ.get("VT_CONV_SCHED", "2"))
+SCHED = 2            # the two-group ping-pong (bf16) / schedule 5 (split-bf16): the shipped schedules; the others are in the history
 X3 = os.environ.get("MODE", "bf16") == "bf16x3"      # split-bf16 arithmetic: fp32 tensors, schedule 3 (K steps of 16)
 if X3:
     NAMES = ["LOAD: 12 ds_read + set-up + 4 pieces + x split", "waits + barrier", "COMPUTE: 24 MFMAs", "barrier"]

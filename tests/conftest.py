@@ -23,6 +23,11 @@ def pytest_configure(config):
 def pytest_collection_modifyitems(config, items):
     from oracle.refload import reference_available
 
+    # a hung kernel (or a pathological host path) costs one test, not the whole GPU call: 15 minutes per GPU test at most (pytest-timeout;
+    # the 129 x 256 x 256 oracle run of configs[4] takes ~4 of them)
+    for it in items:
+        if "gpu" in it.keywords and it.get_closest_marker("timeout") is None:
+            it.add_marker(pytest.mark.timeout(900))
     # the `variants` tier runs only when the -m expression names it (a plain `-m gpu` must stay inside the driver's time limit)
     if "variants" not in (config.getoption("-m") or ""):
         keep = [it for it in items if "variants" not in it.keywords]

@@ -15,7 +15,7 @@ import torch
 from safetensors.torch import load_file
 
 from golden_cases import CASES, apply_tiling, make_input
-from util import GOLDEN_DIR, build_model, build_oracle, handle_config, rel_err
+from util import GOLDEN_DIR, build_model, build_oracle, cpu_autocast_usable, handle_config, rel_err
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
@@ -152,9 +152,11 @@ def test_matches_cpu_oracle(name, shape, dtype, tol):
         # fp32 kernels: every code (measured everywhere; north_star: bit-exact); split-bf16: these clips measure 1.0 too, the
         # gate leaves room for one boundary case per thousand tokens
         if dtype in H16:
-            r_auto = (_autocast_oracle_codes(ora, x, dtype) == log2["indices"]).float().mean().item()
-            print(f"{name} {dtype}: the oracle under autocast({dtype}) on the same clip: {r_auto:.5f}")
-            assert rate >= r_auto - BF16_CODE_RATE_VS_AUTOCAST and rate >= CODE_RATE[dtype] - 0.02
+            assert rate >= CODE_RATE[dtype] - 0.02
+            if cpu_autocast_usable(dtype):        # (a host whose torch has no vectorised fp16 convolution skips the relative gate, not the absolute one)
+                r_auto = (_autocast_oracle_codes(ora, x, dtype) == log2["indices"]).float().mean().item()
+                print(f"{name} {dtype}: the oracle under autocast({dtype}) on the same clip: {r_auto:.5f}")
+                assert rate >= r_auto - BF16_CODE_RATE_VS_AUTOCAST
         else:
             assert rate == 1.0 if dtype == torch.float32 else rate >= 0.999
         # the quantiser itself is exact: feeding the oracle's own pre-quantisation h gives its codes
@@ -388,6 +390,8 @@ def test_16bit_vs_autocast_oracle(name, shape, adt):
     autocast run is on the host (torch's CPU bf16 kernels): on this stack MIOpen's bf16 conv3d search takes minutes per
     layer shape (measured: the GPU variant of this test did not finish in 15 min).  Both are compared with the fp32
     CPU oracle: the HIP bf16 path must not be further from fp32 than 2x the autocast run is."""
+    if not cpu_autocast_usable(adt):
+        pytest.skip(f"torch's CPU convolutions under autocast({adt}) are not usable on this host (scalar fall-back)")
     model, cfg, sd = build_model(name, seed=35, device=DEV, dtype=adt)
     ora = build_oracle(cfg, sd)
     ora.sample = False

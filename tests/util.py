@@ -127,3 +127,32 @@ def fsq_mismatch_report(levels, h, h_ref, idx, idx_ref, limit=16):
                                   "ours_to_boundary_ulps": round(float(abs(bo - edge) / ulp_b), 2),
                                   "h_diff_ulps": round(float(abs(float(hv[c]) - float(hr[c])) / ulp_h), 2)})
     return out
+
+
+_FP16_PROBE = {}
+
+
+def cpu_autocast_usable(dtype, factor=6.0):
+    """Can the oracle be run under torch.autocast("cpu", dtype) in reasonable time on THIS host?  torch's CPU convolutions in float16 fall
+    back to a scalar path on hosts without fp16 vector support (the first GPU-box run of round 6 sat in one such call for the rest of its
+    45 minutes): a 3x3x3 convolution 64 -> 64 on a 3 x 32 x 32 block is timed in fp32 and under autocast(dtype), once per session; callers skip
+    the autocast comparison (not the kernel checks against the fp32 oracle) when the autocast form is more than `factor` times slower."""
+    import time
+
+    if dtype not in _FP16_PROBE:
+        x, w = torch.randn(1, 64, 3, 32, 32), torch.randn(64, 64, 3, 3, 3)
+
+        def run(ctx):
+            with ctx:
+                torch.nn.functional.conv3d(x[:, :, :1, :8, :8], w, padding=1)        # warm-up (dispatch, thread pool)
+                t0 = time.perf_counter()
+                torch.nn.functional.conv3d(x, w, padding=1)
+                return time.perf_counter() - t0
+
+        import contextlib
+
+        t32 = run(contextlib.nullcontext())
+        t16 = run(torch.autocast("cpu", dtype=dtype))
+        _FP16_PROBE[dtype] = t16 < max(0.25, factor * t32)
+        print(f"[cpu_autocast_usable] conv3d 3x3x3 64->64 on 3x32x32: fp32 {t32:.3f} s, autocast({dtype}) {t16:.3f} s -> usable {_FP16_PROBE[dtype]}")
+    return _FP16_PROBE[dtype]

@@ -690,6 +690,15 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void conv_igemm_glds_ker
             const unsigned delta = (unsigned)(q_kh * p.Wi + q_kw) * pix_bytes;
 #pragma unroll
             for (int i = 0; i < A_VECS; ++i) a_off[i] = ((a_mask[i] & tm) == tm) ? a_tb[i] + delta : kOob;
+            if constexpr (PROF) {
+              // measurement (ws_prof_mode bit 7): every activation piece is gathered from the first 128 KiB of x -- live, non-zero data
+              // (the matrix pipe's power draw stays what it is) that sits in every XCD's L2 after the first tiles: what the launch would
+              // take if the activation gather cost no traffic beyond the L2 (the control the zero-fill probe lacks; wrong results)
+              if (p.prof_mode & 128) {
+#pragma unroll
+                for (int i = 0; i < A_VECS; ++i) a_off[i] = a_off[i] == kOob ? kOob : (a_off[i] & 0x1FFF0u);
+              }
+            }
           } else {
             const unsigned delta = (unsigned)((q_kh >> 1) * p.Wi + (q_kw >> 1)) * pix_bytes;
             const unsigned dh = (q_kh & 1) ? (unsigned)p.Wi * pix_bytes : 0u;

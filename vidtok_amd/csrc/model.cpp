@@ -386,6 +386,7 @@ struct ConvOpts {
   Tens* out = nullptr;             // preallocated interleaved output (parity classes)
   Tens* ln_out = nullptr;          // ... and its normalised twin (the emitted LayerNorm of an interleaved output)
   bool ln_optional = false;        // emit `ln` only if this launch's epilogue takes it (vt_conv_plan), else run without (ops.conv ln_optional)
+  bool plan_only = false;          // with ln_optional: launch nothing, only answer (Act::has_n) whether the epilogue would take the LayerNorm
   int yt_mul = 1, yt_off = 0, ys = 0, ys_oh = 0, ys_ow = 0;
   float* ncthw = nullptr;          // write fp32 NCTHW here instead
   int t_trim = 0;
@@ -454,11 +455,13 @@ Act conv(Ctx& c, const Tens& x, const void* w, int ldw, const float* bias, const
     vt_conv_desc q = d;
     standins(q);
     int32_t plan[8];
+    if (q.ln_out == nullptr) q.ln_out = (void*)16;             // (plan_only: the twin tensor is not allocated yet)
     if (!(vt_conv_plan(&q, plan) == VT_OK && plan[4] == 1)) {
       d.ln_gamma = d.ln_beta = nullptr; d.ln_out = nullptr; d.ln_mode = 0;
       r.n = Tens(); r.norm = nullptr;
     }
   }
+  if (o.plan_only) return r;
   // split-K over the time taps (small-M launches): the library says how much scratch; it comes from the stage's arena.
   {
     vt_conv_desc q = d;
@@ -890,12 +893,24 @@ struct TimeUp : Stage {            // TimeUpsampleResCausal2x: v1.0 nearest as t
     // the consumer's LayerNorm from the two launches' epilogues where they can take it (TimeUpsampleResCausal2x.run of the Python host)
     bool emit_ln = next.norm != nullptr;
     Tens nbuf;
-    if (emit_ln) nbuf = c.alloc(xp.B, 2 * xp.T, xp.H, xp.W, pad8(ch), c.m->dt, ch);
     Geom g;
     g.kt = 2; g.kh = 3; g.kw = 3; g.pt = 1; g.ph = 1; g.pw = 1; g.ph_hi = 1; g.pw_hi = 1;
     const float* mf = c.m->f32(key + ".mix_factor", c.dry);
     const bool nc = c.m->noncausal();
     const std::string ck = key + ".conv" + c.m->cv();
+    if (emit_ln) {
+      // ask before allocating the twin (a launch that refuses -- the 512-channel up-sampler always does -- left a full-size
+      // buffer in the arena's peak): the decision depends on the geometry only, the same for both parity launches
+      ConvOpts o;
+      Tens probe = r.y;
+      probe.p = nullptr;
+      o.out = &r.y; o.yt_mul = 2; o.yt_off = 0; o.ln = next; o.ln_out = &probe; o.ln_optional = true; o.plan_only = true;
+      o.res = &xp; o.res_mode = VT_RES_MIX; o.mix = mf;
+      Geom gp = g;
+      if (nc) gp = centred(g, 1);
+      emit_ln = conv(c, xp, c.m->conv_w(ck + ".weight", xp.ld, c.dry, xf_time_parity, nc ? 0 : 1, 0), 18 * xp.ld, c.m->f32(ck + ".bias", c.dry), gp, ch, o).has_n();
+      if (emit_ln) nbuf = c.alloc(xp.B, 2 * xp.T, xp.H, xp.W, pad8(ch), c.m->dt, ch);
+    }
     for (int par = 0; par < 2; ++par) {
       ConvOpts o;
       o.out = &r.y; o.yt_mul = 2; o.yt_off = par;

@@ -419,13 +419,19 @@ class TimeUpsampleResCausal2x(nn.Module):
             # the consumer's LayerNorm from the two launches' epilogues where they can take it (vt_conv_plan decides: bf16, Cout = 256
             # on the 8-wave tile, option conv_tup_ln), else the consumer runs its own pass
             emit = dict(_emit(next_norm))
-            n = torch.empty_like(y) if emit else None
+            n = None
+
+            def alloc_n():           # the LayerNorm twin, allocated by ops.conv only once vt_conv_plan says the launch emits it (pad lanes as y's)
+                return (torch.empty if ld == self.conv.chan_out else torch.zeros)(y.shape, dtype=dt, device=x.device)
+
             for par, pack in enumerate(self._parity_packs):
                 w, b = pack.get(self.conv.conv.weight, self.conv.conv.bias, dt, cin_stored=C)
                 r = ops.conv(x, w, b, g, cout=self.conv.chan_out, tmode=L.VT_TPAD_ZERO, res=x, res_mode=L.VT_RES_MIX,
-                             mix_factor=mf, out=y, out_t=(2, par), **(dict(emit, ln_out=n, ln_optional=True) if emit else {}))
+                             mix_factor=mf, out=y, out_t=(2, par), **(dict(emit, ln_out=(alloc_n if n is None else n), ln_optional=True) if emit else {}))
                 if emit and not isinstance(r, tuple):
                     emit, n = {}, None
+                elif emit:
+                    n = r[1]
             return y if n is None else Normed(y, n, next_norm[0], next_norm[1])
         xi = self._interp_v11(x)
         return _wrap(self.conv.run(xi, dt, res=xi, res_mode=L.VT_RES_MIX, mix_factor=mf, **_emit(next_norm)), next_norm)

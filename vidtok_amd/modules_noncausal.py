@@ -83,13 +83,19 @@ class TimeUpsampleRes2x(nn.Module):
         y = (torch.empty if ld == cout else torch.zeros)((B, 2 * T, H, W, ld), dtype=dt, device=x.device)
         # the consumer's LayerNorm from the two launches' epilogues where they can take it (modules.TimeUpsampleResCausal2x.run)
         emit = dict(_emit(next_norm))
-        n = torch.empty_like(y) if emit else None
+        n = None
+
+        def alloc_n():               # allocated by ops.conv only once vt_conv_plan says the launch emits the LayerNorm (pad lanes as y's)
+            return (torch.empty if ld == cout else torch.zeros)(y.shape, dtype=dt, device=x.device)
+
         for par, (pack, g) in enumerate(self._parity):      # two k=2 convs with pre-summed taps: 2/3 of the MACs
             w, b = pack.get(self.conv.weight, self.conv.bias, dt, cin_stored=C)
             r = ops.conv(x, w, b, g, cout=cout, res=x, res_mode=L.VT_RES_MIX, mix_factor=self.mix_factor.detach(),
-                         out=y, out_t=(2, par), **(dict(emit, ln_out=n, ln_optional=True) if emit else {}))
+                         out=y, out_t=(2, par), **(dict(emit, ln_out=(alloc_n if n is None else n), ln_optional=True) if emit else {}))
             if emit and not isinstance(r, tuple):
                 emit, n = {}, None
+            elif emit:
+                n = r[1]
         return y if n is None else Normed(y, n, next_norm[0], next_norm[1])
 
 

@@ -37,7 +37,7 @@ def conv_plan(d):
     out = (C.c_int32 * 8)()
     L.check(L.load().vt_conv_plan(C.byref(d), out), "vt_conv_plan")
     return dict(tile=(out[0], out[1]), waves=out[2], workgroups=out[3], ln_fused=bool(out[4]), launches=out[5],
-                kernel={2: "narrow", 3: "ws2", 4: "in8"}.get(out[6], "igemm"), lds_epilogue=out[7] == 1, deep_ring=out[7] == 2)
+                kernel={2: "narrow", 3: "ws2", 4: "in8", 5: "tr256"}.get(out[6], "igemm"), lds_epilogue=out[7] == 1, deep_ring=out[7] == 2)
 
 
 def replay_convs(record, conv_kernel_only=True):
@@ -180,20 +180,24 @@ def conv(x, w, bias, geom: ConvGeom, *, cout: int, out_dtype=None, tmode=L.VT_TP
         gamma, beta, eps, silu = ln
         assert out_layout == L.VT_NDHWC and gamma.dtype == torch.float32 and beta.dtype == torch.float32
         assert gamma.numel() >= cout and beta.numel() >= cout and gamma.is_cuda and beta.is_cuda
-        if ln_out is not None:
-            assert ln_out.shape == y.shape and ln_out.dtype == out_dtype and ln_out.is_contiguous()
-            n = ln_out
-        else:
-            n = (torch.zeros if ldy != cout else torch.empty)(y.shape, dtype=out_dtype, device=x.device)
-        d.ln_gamma, d.ln_beta, d.ln_out = gamma.data_ptr(), beta.data_ptr(), n.data_ptr()
+        d.ln_gamma, d.ln_beta, d.ln_out = gamma.data_ptr(), beta.data_ptr(), y.data_ptr()      # (ln_out: a placeholder until the plan is known)
         d.ln_mode, d.ln_keep_y, d.ldn, d.ln_eps = (2 if silu else 1), int(bool(ln_keep_y)), ldy, float(eps)
         fused = True
-        if ln_optional:
+        if ln_optional:              # ask before allocating the twin tensor (a launch that refuses left a full-size buffer behind)
             try:
                 fused = conv_plan(d)["ln_fused"]
             except L.VtError:        # "LayerNorm of an interleaved output is only available fused": this launch cannot take it
                 fused = False
-        if not fused:
+        if fused:
+            if callable(ln_out):     # the caller's allocator, run only now that the launch is known to emit the LayerNorm
+                ln_out = ln_out()
+            if ln_out is not None:
+                assert ln_out.shape == y.shape and ln_out.dtype == out_dtype and ln_out.is_contiguous()
+                n = ln_out
+            else:                    # pad lanes defined like y's (they meet zero weights in the consumer)
+                n = (torch.zeros if ldy != cout else torch.empty)(y.shape, dtype=out_dtype, device=x.device)
+            d.ln_out = n.data_ptr()
+        else:
             # the LayerNorm of an interleaved output exists only inside an epilogue; this launch's epilogue does not take it
             # (shape, arithmetic, option conv_tup_ln): run without, the caller's consumer normalises y itself
             assert ln_keep_y
