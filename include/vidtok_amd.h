@@ -116,9 +116,6 @@ int vt_conv_max_lds_bytes(void);
  *   conv_tup_ln (1)     the LayerNorm the consumer of a v1.0 time up-sampler starts with is emitted by the up-sampler's two parity launches
  *                       (alpha-mix + interleaved output frames + LayerNorm together in the bf16 LDS epilogue of the 8-wave tile) instead of
  *                       running as its own pass (- 0.2 ... 0.3 ms of the benchmark step); hosts ask vt_conv_plan whether a launch fuses it; 0 = the separate pass
- *   conv_tr256 (0)      conv_tr256.hip for the 16-bit Cout % 256 == 0 launches the 8-wave tile would take with its LDS epilogue: a persistent
- *                       workgroup of four MATRIX waves (128 x 256 tile, fragment reads and MFMAs only, one barrier per K step) and four LOADER
- *                       waves (every LDS-DMA request and all gather arithmetic); same results as the 8-wave tile
  *   attn_flash (1)      the attention block as one vt_flash_attention launch where it applies; 0: GEMM -> softmax -> GEMM operators
  *   tblock_prof_mode (0), ws_prof_mode (0)   measurement aids
  * (Rounds 1-5 also kept the superseded forms selectable -- K-step schedules 0 / 1 / 3 / 4, the first LayerNorm epilogue of the 8-wave

@@ -505,55 +505,6 @@ def test_conv_ln256_variants(case, mode, dtype, vt_opts):
     assert plan["tile"] == (256, 256) and plan["ln_fused"] == (mode != "unfused") and plan["launches"] == (2 if mode == "unfused" else 1)
 
 
-# conv_tr256.hip (option conv_tr256): the loader-fed 128 x 256 tile -- four matrix waves that only read fragments and issue MFMAs, four
-# loader waves that own every LDS-DMA request -- on the launches the 8-wave tile takes with its LDS-transposed epilogue.  Same K order, same
-# epilogue arithmetic: the results must equal the 8-wave tile's bit for bit; every padding / cache / residual / LayerNorm / interleave mode,
-# Cout = 512 (two channel tiles), the frames-innermost tile order, zero-padded time taps skipped (a tile's own step count).
-TR256_CASES = [c for c in CONV_CASES_LARGE if c[3] % 256 == 0] + [
-    ("tr_3d_256_zero_tskip", (2, 5, 32, 32), 256, 256, (3, 3, 3), ConvGeom(**G333), dict(res="add", ln="keep")),
-    ("tr_1d_256_ln_only", (1, 6, 32, 32), 256, 256, (3,), ConvGeom(kt=3, pt=2), dict(ln="only")),
-    ("tr_1d_512_replicate", (2, 4, 16, 16), 512, 512, (3,), ConvGeom(kt=3, pt=2), dict(tmode="replicate", res="add")),
-    ("tr_3d_cache_256", (2, 5, 32, 32), 256, 256, (3, 3, 3), ConvGeom(**G333), dict(tmode="cache", res="add")),
-    ("tr_s2_mix_256", (1, 6, 32, 32), 256, 256, (3, 3, 3), ConvGeom(kt=3, kh=3, kw=3, st=2, pt=1, ph=1, pw=1, ph_hi=1, pw_hi=1), dict(res="mix")),
-    ("tr_ups_fold_256", (1, 2, 16, 16), 256, 256, (3, 3), ConvGeom(ups_s=1, **G3), {}),
-    ("tr_1x1_512_256", (1, 2, 32, 32), 512, 256, (1, 1), ConvGeom(), dict(res="add")),
-    ("tr_nobias_plain", (1, 2, 16, 32), 128, 256, (3, 3), ConvGeom(**G3), dict(nobias=True)),
-]
-
-
-@pytest.mark.parametrize("mode", [1, 2], ids=["serial_epilogue", "overlapped_rows"])
-@pytest.mark.parametrize("dtype", H16, ids=H16_IDS)
-@pytest.mark.parametrize("case", TR256_CASES, ids=[c[0] for c in TR256_CASES])
-def test_conv_tr256(case, dtype, mode, vt_opts):
-    """mode 1: the rows behind the K loop, the 8-wave tile's epilogue arithmetic (bit-equal to it); mode 2: the rows of a tile worked on
-    during the next tile's K loop from a 16-bit row buffer (LayerNorm of the ROUNDED result where y is kept: the two-launch arithmetic)"""
-    vt_opts(conv_tile=256, conv_tr256=mode)
-    mine = []
-    plan = _check_conv(case, dtype, keep_outputs=mine)
-    assert plan["kernel"] == "tr256" and plan["tile"] == (128, 256) and plan["waves"] == 8 and plan["launches"] == 1, plan
-    again = []
-    _check_conv(case, dtype, keep_outputs=again)          # persistent workgroups, hand-overs by barriers only: run-to-run identical
-    assert all(torch.equal(a, b) for a, b in zip(mine, again))
-    vt_opts(conv_tr256=0)
-    ref = []
-    plan8 = _check_conv(case, dtype, keep_outputs=ref)
-    assert plan8["kernel"] == "igemm" and plan8["tile"] == (256, 256)
-    (B, T, H, W), geom = case[1], case[5]
-    To, Ho, Wo = geom.out_dims(T, H, W)
-    if mode == 1 and (B * To * Ho * Wo) % 256 == 0:   # the 8-wave tile's LDS epilogue needs full 256-pixel tiles: only then is the arithmetic the same
-        assert len(mine) == len(ref) and all(torch.equal(a, b) for a, b in zip(mine, ref)), case[0]
-
-
-def test_conv_tr256_is_not_taken_elsewhere(vt_opts):
-    vt_opts(conv_tile=256, conv_tr256=1)
-    assert _check_conv(("tr_f32", (1, 2, 16, 16), 256, 256, (3, 3), ConvGeom(**G3), {}), torch.float32)["kernel"] == "igemm"
-    assert _check_conv(("tr_ragged_m", (1, 3, 10, 10), 256, 256, (3, 3), ConvGeom(**G3), {}), torch.bfloat16)["kernel"] == "igemm"          # M % 128
-    assert _check_conv(("tr_cin_32", (1, 2, 16, 16), 32, 256, (3, 3), ConvGeom(**G3), {}), torch.bfloat16)["kernel"] == "igemm"              # Cin % 64
-    assert _check_conv(("tr_cout_128", (1, 2, 16, 16), 256, 128, (3, 3), ConvGeom(**G3), {}), torch.bfloat16)["kernel"] != "tr256"
-    assert _check_conv(("tr_ncthw", (1, 3, 16, 16), 256, 256, (3, 3, 3), ConvGeom(**G333), dict(ncthw=0)), torch.bfloat16)["kernel"] == "igemm"
-    assert _check_conv(("tr_mix_up", (1, 3, 16, 16), 256, 256, (3, 3, 3), ConvGeom(ups_t=1, **G333), dict(res="mix_up")), torch.bfloat16)["kernel"] == "igemm"   # residual at half rate
-
-
 LDSEPI_CASES = [c for c in CONV_CASES if c[0] in ("conv2d_3x3_128_128", "conv2d_3x3_256_128_res", "temporal_k3_tinner", "conv2d_ln_fused",
                                                   "conv2d_ln_fused_res_keep", "temporal_ln_fused")]
 

@@ -13,7 +13,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libvidtok_amd.so")
-SOURCES = ["conv_igemm_bf16.hip", "conv_igemm_f16.hip", "conv_igemm_f32.hip", "conv_igemm_x3.hip", "conv_igemm.hip", "conv_in8.hip", "conv_tr256.hip", "conv_ws2.hip", "conv_narrow.hip", "tblock_ws128.hip", "attention.hip", "pointwise.hip", "groupnorm.hip", "regularizers.hip", "metrics.hip", "video_io.hip", "packing.hip", "error.cpp", "options.cpp", "model.cpp"]
+SOURCES = ["conv_igemm_bf16.hip", "conv_igemm_f16.hip", "conv_igemm_f32.hip", "conv_igemm_x3.hip", "conv_igemm.hip", "conv_in8.hip", "conv_ws2.hip", "conv_narrow.hip", "tblock_ws128.hip", "attention.hip", "pointwise.hip", "groupnorm.hip", "regularizers.hip", "metrics.hip", "video_io.hip", "packing.hip", "error.cpp", "options.cpp", "model.cpp"]
 HEADERS = ["common.h", "conv_common.h", "conv_select.h", "conv_igemm_kernel.h", "options.h", os.path.join("..", "..", "include", "vidtok_amd.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 # per-file additions.  conv_ws2.hip: its row arithmetic runs beside the partner wave's MFMAs, where packed fp32
@@ -21,7 +21,7 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-u
 # (profiles/r02_mfma_issue_microbench.txt) -- so no SLP there, and the instruction scheduler stays free to interleave
 # the chains (the asm pins that used to keep the elements apart also kept every chain in program order: 63 s_nop of
 # hazard padding in a 540-instruction row slot)
-EXTRA_FLAGS = {"conv_ws2.hip": ["-fno-slp-vectorize"], "tblock_ws128.hip": ["-fno-slp-vectorize"], "conv_tr256.hip": ["-fno-slp-vectorize"]}
+EXTRA_FLAGS = {"conv_ws2.hip": ["-fno-slp-vectorize"], "tblock_ws128.hip": ["-fno-slp-vectorize"]}
 
 
 def _hipcc():

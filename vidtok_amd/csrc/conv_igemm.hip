@@ -246,11 +246,6 @@ extern "C" int vt_conv_plan(const vt_conv_desc* d, int32_t* out8) {
   out8[5] = (d->ln_mode != 0 && !ln_fused) ? 2 : 1;
   const bool split_k = d->work != nullptr && splitk_planes(d, a, nbatch, ln_fused, use_ws) > 0;
   if (split_k) out8[5] += 1;                                                                      // partial launch + reduction
-  if (!split_k && tr256_eligible(a, nbatch, d->dtype, d->out_dtype)) {                            // conv_tr256.hip: persistent, 128 x 256 tiles, 4 matrix + 4 loader waves
-    const long long tiles = (long long)(a.M / 128) * (a.Cout / 256);
-    out8[0] = 128; out8[1] = 256; out8[2] = 8; out8[3] = (int32_t)std::min<long long>(tiles, device_cus()); out8[6] = 5; out8[7] = 1;
-    return VT_OK;
-  }
   // epilogue through the LDS (rows of 16-byte accesses) instead of the MFMA-layout vector epilogue
   if (k == TILE_256x256) {
     const bool h16_io = vt_is_h16(d->dtype) && d->out_dtype == d->dtype;
@@ -303,7 +298,6 @@ extern "C" int vt_conv(const vt_conv_desc* d, vt_stream stream_) {
   const int planes = d->work != nullptr ? splitk_planes(d, a, nbatch, ln_fused, use_ws) : 0;
   if (planes > 0 && d->work_bytes >= (int64_t)planes * M * a.Cout * 4 && (reinterpret_cast<uintptr_t>(d->work) & 15) == 0)
     rc = launch_splitk(d, a, planes, stream);
-  else if (tr256_eligible(a, nbatch, d->dtype, d->out_dtype)) rc = vt_conv_tr256_launch(&a, d->dtype, stream_);
   else if (d->dtype == VT_F32) rc = vt_igemm_dispatch_f32(&a, nbatch, stream_);
   else if (d->dtype == VT_BF16X3) rc = vt_igemm_dispatch_x3(&a, nbatch, stream_);
   else if (d->dtype == VT_F16) rc = vt_igemm_dispatch_f16(&a, nbatch, d->out_dtype == VT_F32 ? 1 : 0, stream_);

@@ -121,21 +121,6 @@ inline bool lds256_plain_eligible(const ConvArgs& a, int nbatch, bool h16_io) {
          (a.ldy & 7) == 0 && (a.res_mode == VT_RES_NONE || ((a.ldr & 7) == 0 && a.Tr == a.To && a.res_tshift == 0));
 }
 
-// Loader-fed 128 x 256 tile (conv_tr256.hip; option conv_tr256): the launches the 8-wave tile would take with its LDS-transposed epilogue
-// -- a 16-bit type, full tiles, plain NDHWC rows, tap-walk form on descriptors, a residual / mix operand indexed like the output
-inline bool tr256_eligible(const ConvArgs& a, int nbatch, int dtype, int out_dtype) {
-  if (vt_opt(OPT_CONV_TR256) == 0 || !conv_buf() || vt_opt(OPT_CONV_LDSEPI) == 0 || nbatch != 1 || a.prof != nullptr || a.ksplit) return false;
-  if (!vt_is_h16(dtype) || out_dtype != dtype || a.Cout % 256 != 0 || a.M % 128 != 0 || a.Cin % 64 != 0) return false;
-  if (a.out_layout != VT_NDHWC || (a.ldy & 7) != 0 || a.KH > 8 || a.KW > 8) return false;
-  if (a.res_mode != VT_RES_NONE && ((a.ldr & 7) != 0 || a.Tr != a.To || a.res_tshift != 0)) return false;
-  if (a.ln_mode != 0 && (a.Cout != 256 || (a.ldn & 7) != 0)) return false;
-  if (a.tmode == VT_TPAD_CACHE && (((long long)a.Ho * a.Wo) % 128 != 0 || a.ups_t != 0)) return false;
-  const unsigned long long xb = (unsigned long long)a.B * a.Ti * a.Hi * a.Wi * a.Cin * 2, wb = (unsigned long long)a.Cout * a.ldw * 2;
-  const unsigned long long cb = a.tmode == VT_TPAD_CACHE ? (unsigned long long)a.B * a.ncache * a.Hi * a.Wi * a.Cin * 2 : 0ull;
-  if (xb >= 0xFFFF0000ull || wb >= 0xFFFF0000ull || cb >= 0xFFFF0000ull) return false;
-  return select_tile(a, nbatch) == TILE_256x256;
-}
-
 }  // namespace
 
 // the per-type translation units (conv_igemm_*.hip): tile selection + launch of the implicit-GEMM kernel; `args` = ConvArgs
@@ -145,6 +130,5 @@ extern "C" int vt_igemm_dispatch_bf16(const void* args, int nbatch, int out_f32,
 extern "C" int vt_igemm_dispatch_f16(const void* args, int nbatch, int out_f32, void* stream);        // fp16 -> fp16 | fp32
 extern "C" int vt_ws2_launch(const void* conv_args, int dtype, void* stream);                         // conv_ws2.hip
 extern "C" int vt_conv_in8_launch(const void* conv_args, int dtype, void* stream);                    // conv_in8.hip
-extern "C" int vt_conv_tr256_launch(const void* conv_args, int dtype, void* stream);                  // conv_tr256.hip
 extern "C" int vt_conv_narrow_launch(const void* conv_args, void* stream, int mode);                  // conv_narrow.hip (mode: 0 bf16, 1 fp16, 2 split-bf16: fp32 x, two passes)
 extern "C" void vt_conv_narrow_plan(const void* conv_args, int32_t* plan4);

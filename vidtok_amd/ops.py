@@ -37,7 +37,7 @@ def conv_plan(d):
     out = (C.c_int32 * 8)()
     L.check(L.load().vt_conv_plan(C.byref(d), out), "vt_conv_plan")
     return dict(tile=(out[0], out[1]), waves=out[2], workgroups=out[3], ln_fused=bool(out[4]), launches=out[5],
-                kernel={2: "narrow", 3: "ws2", 4: "in8", 5: "tr256"}.get(out[6], "igemm"), lds_epilogue=out[7] == 1, deep_ring=out[7] == 2)
+                kernel={2: "narrow", 3: "ws2", 4: "in8"}.get(out[6], "igemm"), lds_epilogue=out[7] == 1, deep_ring=out[7] == 2)
 
 
 def replay_convs(record, conv_kernel_only=True):
