@@ -632,9 +632,24 @@ def main():
             rows = [(lab, len(rs), time_replay(rs)) for lab, rs in groups.items()]
             print("[bench] conv launches of one step by (pixels, Cout, K=taps*Cin), each group replayed alone:", file=sys.stderr)
             tot = sum(ms for _, _, ms in rows)
+            def served_by(rs):          # which kernel / tile / epilogue the dispatcher gives the group's launches (vt_conv_plan)
+                kinds = []
+                for d, _k, _l in rs:
+                    if isinstance(d, tuple):
+                        k = "flash_attn"
+                    elif not hasattr(d, "ln_mode"):
+                        k = "tblock_pair (fused temporal block)"
+                    else:
+                        pl = ops.conv_plan(d)
+                        k = f"{pl['kernel']} {pl['tile'][0]}x{pl['tile'][1]}" + (" +LN" if pl["ln_fused"] else "") + \
+                            (" lds-epilogue" if pl["lds_epilogue"] else "") + (" deep-ring" if pl["deep_ring"] else "") + \
+                            (f" x{pl['launches']} launches" if pl["launches"] > 1 else "")
+                    if k not in kinds:
+                        kinds.append(k)
+                return " | ".join(kinds)
             for (M, N, K), n, ms in sorted(rows, key=lambda r: -r[2]):
                 print(f"[bench]   M={M:8d} N={N:4d} K={K:6d}  x{n:3d}  {ms:8.3f} ms  {2.0 * M * N * K * n / ms / 1e9:8.1f} TFLOP/s"
-                      f"  {100 * ms / tot:5.1f}%", file=sys.stderr)
+                      f"  {100 * ms / tot:5.1f}%   {served_by(groups[(M, N, K)])}", file=sys.stderr)
         # HBM-shaped kernel classes (SURVEY.md section 8d asks for both roofs): LayerNorm passes and the MFMA-kernel
         # launches whose FLOP per byte is below the ridge, each class replayed alone; algorithmic bytes = every operand
         # and result moved once (vidtok_amd/ops.py::launch_class)

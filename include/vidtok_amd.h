@@ -115,7 +115,8 @@ int vt_conv_max_lds_bytes(void);
  *                       The same bits as the general path of the implicit-GEMM kernel (0), 16 % faster on the launch
  *   conv_tup_ln (1)     the LayerNorm the consumer of a v1.0 time up-sampler starts with is emitted by the up-sampler's two parity launches
  *                       (alpha-mix + interleaved output frames + LayerNorm together in the bf16 LDS epilogue of the 8-wave tile) instead of
- *                       running as its own pass (- 0.2 ... 0.3 ms of the benchmark step); hosts ask vt_conv_plan whether a launch fuses it; 0 = the separate pass
+ *                       running as its own pass (- 0.2 ... 0.3 ms of the benchmark step); hosts ask vt_conv_plan whether a launch fuses it; 0 = the separate pass.
+ *                       (Gates the Cout = 256 epilogue only: the Cout = 128 LayerNorm epilogue takes an alpha-mix / interleaved output under conv_fuse_ln alone.)
  *   attn_flash (1)      the attention block as one vt_flash_attention launch where it applies; 0: GEMM -> softmax -> GEMM operators
  *   tblock_prof_mode (0), ws_prof_mode (0)   measurement aids
  * (Rounds 1-5 also kept the superseded forms selectable -- K-step schedules 0 / 1 / 3 / 4, the first LayerNorm epilogue of the 8-wave

@@ -1,0 +1,17 @@
+#!/bin/bash
+# round 6, seventh GPU call: fused temporal block with counted waits in the middle loop (one register set, explicit vmcnt(0) in front of it)
+export TMPDIR=/tmp
+mkdir -p gpurun_out
+O=gpurun_out
+timeout 600 python -m pytest tests/test_gpu_ops.py -q -m gpu --timeout 600 -k "temporal_block or weight_stationary or tblock" > $O/r6g_ops.log 2>&1; echo "ops rc=$?"; tail -5 $O/r6g_ops.log | cut -c1-250
+for rep in 1 2; do
+for lib in ab_libs/libvidtok_amd_base.so vidtok_amd/libvidtok_amd.so; do
+  VIDTOK_AMD_LIB=$PWD/$lib timeout 120 python scripts/c128_time.py bf16 2>&1 | grep -v amdgpu.ids
+done
+done | tee $O/r06_c128_variants2.txt
+timeout 120 python scripts/c128_time.py f16 2>&1 | grep -v amdgpu.ids | tee -a $O/r06_c128_variants2.txt
+for lib in ab_libs/libvidtok_amd_base.so vidtok_amd/libvidtok_amd.so ab_libs/libvidtok_amd_base.so vidtok_amd/libvidtok_amd.so; do
+  VIDTOK_AMD_LIB=$PWD/$lib timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --traffic none --no-extras 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$lib', d['value'], d['ms_per_step'])"
+done 2>&1 | tee $O/r06_step_variants2.txt
+timeout 200 python scripts/tblock_profile.py > $O/r06_tblock_pair_phase_cycles.txt 2>&1; grep "per launch" $O/r06_tblock_pair_phase_cycles.txt
+timeout 200 python scripts/ws2_profile.py > $O/r06_ws2_iteration_cycles.txt 2>&1; head -12 $O/r06_ws2_iteration_cycles.txt | cut -c1-250

@@ -19,6 +19,9 @@ from util import GOLDEN_DIR, build_model, build_oracle, cpu_autocast_usable, han
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
+# tiers: `-m gpu` keeps one oracle case per shipped path and BASELINE size; `-m "gpu and variants"` adds the long host runs (the 129-frame
+# configs[4] clip: a 5-minute CPU oracle pass; the configs[3] shard; the 256 x 256 autocast oracle) -- run once per round, not by every call
+variants = pytest.mark.variants
 # bf16 gates: a small multiple of what the bf16 kernels measure against the fp32 oracle (recon 1.5e-2..2.2e-2, z 6e-3,
 # FSQ codes 93-94 % -- the reference's own fp32 vs bf16-autocast agreement, SURVEY.md finding 5): a 2-3x loss of
 # accuracy in a kernel turns these red.  test_bf16_vs_autocast_oracle additionally pins the bf16 path to the
@@ -44,6 +47,9 @@ def _autocast_oracle_codes(ora, x, dtype=torch.bfloat16):
     with torch.autocast("cpu", dtype=dtype):
         h = ora.pre_quant(x)
     return ora.regularize(h.float())[1]["indices"]
+
+
+_ORACLE_RUNS = {}      # session cache of CPU oracle passes (test infrastructure): see _oracle_full and test_matches_cpu_oracle
 
 
 # split-bf16 mode ("bf16x3": fp32 storage, every convolution as three bf16 MFMAs per product, vt_conv VT_BF16X3): the fast
@@ -124,13 +130,18 @@ def _decode_err_on_oracle_codes(model, log2, dec2):
 ])
 def test_matches_cpu_oracle(name, shape, dtype, tol):
     model, cfg, sd = build_model(name, seed=21, device=DEV, dtype=dtype)
-    ora = build_oracle(cfg, sd)
     g = torch.Generator().manual_seed(9)
     x = torch.rand(shape, generator=g) * 2 - 1
     torch.manual_seed(4)
     z, dec, log = model(x.to(DEV))
-    torch.manual_seed(4)
-    z2, dec2, log2 = ora(x)
+    key = ("small", name, shape)                    # the oracle's pass of a (config, clip) is shared by the arithmetic modes that run it
+    if key not in _ORACLE_RUNS:
+        ora = build_oracle(cfg, sd)
+        torch.manual_seed(4)
+        _ORACLE_RUNS[key] = (ora, ora(x))
+        for k in [k for k in _ORACLE_RUNS if k[0] == "small" and k != key][:-3]:      # a few recent ones only
+            del _ORACLE_RUNS[k]
+    ora, (z2, dec2, log2) = _ORACLE_RUNS[key]
     ez, ed = rel_err(z, z2), rel_err(dec, dec2)
     print(f"{name} {shape} {dtype}: z rel {ez:.3e} dec rel {ed:.3e}")
     assert dec.shape == dec2.shape
@@ -296,9 +307,6 @@ def test_v11_full_size_long_video_tiling_property():
 # tile order over 20 frames, cache-mode gathers on 256x256 frames -- are compared with the CPU oracle itself.
 # The oracle needs ~30 s per 17x256x256 clip, so each (config, shape) result is computed once per session.
 # --------------------------------------------------------------------------------------------------
-_ORACLE_RUNS = {}
-
-
 def _oracle_full(name, shape, seed, tiling=None):
     key = (name, shape, seed, tiling)
     if key not in _ORACLE_RUNS:
@@ -313,12 +321,13 @@ def _oracle_full(name, shape, seed, tiling=None):
 
 
 # kl_16chn B=2: the per-GPU shard of BASELINE.json configs[3] (the N > 1 bench workload) -- VERDICT r2 weak #2
-FULL = [("vidtok_kl_causal_488_4chn", (2, 3, 17, 256, 256)), ("vidtok_fsq_causal_488_32768", (1, 3, 17, 256, 256)),
-        ("vidtok_kl_causal_488_16chn", (2, 3, 17, 256, 256))]
+FULL = [pytest.param("vidtok_kl_causal_488_4chn", (1, 3, 17, 256, 256), id="kl_4chn_B1"), pytest.param("vidtok_fsq_causal_488_32768", (1, 3, 17, 256, 256), id="fsq_B1"),
+        pytest.param("vidtok_kl_causal_488_4chn", (2, 3, 17, 256, 256), id="kl_4chn_B2", marks=variants),
+        pytest.param("vidtok_kl_causal_488_16chn", (2, 3, 17, 256, 256), id="kl_16chn_B2", marks=variants)]
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, X3, F16], ids=["f32", "bf16", "bf16x3", "f16"])
-@pytest.mark.parametrize("name,shape", FULL, ids=["kl_4chn_B2", "fsq_B1", "kl_16chn_B2"])
+@pytest.mark.parametrize("name,shape", FULL)
 def test_full_size_matches_cpu_oracle(name, shape, dtype):
     cfg, sd, x, (z2, dec2, log2) = _oracle_full(name, shape, 33)
     model, _, _ = build_model(name, seed=33, device=DEV, dtype=dtype)
@@ -346,23 +355,26 @@ def test_full_size_matches_cpu_oracle(name, shape, dtype):
             assert n_bad <= (1 - CODE_RATE[dtype]) * log2["indices"].numel()
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, X3], ids=["f32", "bf16", "bf16x3"])
-def test_full_size_v11_tiled_matches_cpu_oracle(dtype):
-    """BASELINE.json configs[4] geometry (256x256 frames, t_chunk_enc=16, decoder look-ahead) on a 33-frame clip:
-    cache-mode (pointer form) gathers, chunk caches and the trilinear up-sampler at full frame size vs the oracle --
-    in fp32 and in bf16, the dtype BASELINE.json names for this configuration."""
+@pytest.mark.parametrize("T", [17, pytest.param(33, marks=variants)], ids=["t17", "t33"])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, X3, F16], ids=["f32", "bf16", "bf16x3", "f16"])
+def test_full_size_v11_tiled_matches_cpu_oracle(dtype, T):
+    """BASELINE.json configs[4] geometry (256x256 frames, t_chunk_enc=16, decoder look-ahead) on a 17-frame clip (the single-frame first
+    chunk + one 16-frame cache-mode chunk; 33 frames = two such chunks in the variants tier): cache-mode gathers, chunk caches and the
+    trilinear up-sampler at full frame size vs the oracle -- in fp32, split-bf16, and in bf16 (the dtype BASELINE.json names for this
+    configuration) and fp16."""
     name = "vidtok_v1_1/vidtok_kl_causal_488_16chn_v1_1"
-    cfg, sd, x, (z2, dec2, log2) = _oracle_full(name, (1, 3, 33, 256, 256), 34, tiling=(16, True))
+    cfg, sd, x, (z2, dec2, log2) = _oracle_full(name, (1, 3, T, 256, 256), 34, tiling=(16, True))
     model, _, _ = build_model(name, seed=34, device=DEV, dtype=dtype)
     model.use_tiling, model.t_chunk_enc, model.t_chunk_dec, model.use_overlap = True, 16, 4, True
     torch.manual_seed(8)
     z, dec, log = model(x.to(DEV))
     ez, ed = rel_err(z, z2), rel_err(dec, dec2)
-    print(f"FULL v1.1 tiled T=33 256x256 {dtype}: z rel {ez:.3e} dec rel {ed:.3e}")
+    print(f"FULL v1.1 tiled T={T} 256x256 {dtype}: z rel {ez:.3e} dec rel {ed:.3e}")
     assert dec.shape == x.shape
-    assert (ez < 1e-3 and ed < 1e-3) if dtype != torch.bfloat16 else (ez < BF16_Z and ed < BF16_RECON)
+    assert (ez < 1e-3 and ed < 1e-3) if dtype not in H16 else (ez < ZTOL[dtype] and ed < RECON[dtype])
 
 
+@variants
 @pytest.mark.parametrize("dtype", [torch.bfloat16, X3, torch.float32, F16], ids=["bf16", "bf16x3", "f32", "f16"])
 def test_configs4_long_video_tiled_matches_cpu_oracle(dtype):
     """BASELINE.json configs[4] AT ITS STATED LENGTH: vidtok_kl_causal_488_16chn_v1_1, one clip of 129x256x256, t_chunk_enc = 16
@@ -380,9 +392,9 @@ def test_configs4_long_video_tiled_matches_cpu_oracle(dtype):
     assert (ez < 1e-3 and ed < 1e-3) if dtype not in H16 else (ez < ZTOL[dtype] and ed < RECON[dtype])
 
 
-@pytest.mark.parametrize("name,shape", [("vidtok_kl_causal_488_4chn", (1, 3, 17, 128, 128)),
-                                        ("vidtok_fsq_causal_488_32768", (1, 3, 17, 64, 64)),
-                                        ("vidtok_kl_causal_488_4chn", (1, 3, 17, 256, 256))], ids=["kl_128", "fsq_64", "kl_256_benchmarked_size"])
+@pytest.mark.parametrize("name,shape", [pytest.param("vidtok_kl_causal_488_4chn", (1, 3, 17, 128, 128), id="kl_128"),
+                                        pytest.param("vidtok_fsq_causal_488_32768", (1, 3, 17, 64, 64), id="fsq_64"),
+                                        pytest.param("vidtok_kl_causal_488_4chn", (1, 3, 17, 256, 256), id="kl_256_benchmarked_size", marks=variants)])
 @pytest.mark.parametrize("adt", H16, ids=["bf16", "f16"])
 def test_16bit_vs_autocast_oracle(name, shape, adt):
     """the bf16 / fp16 kernels vs the reference's own bf16 / fp16 mode (fp16 is the dtype of its README snippets)

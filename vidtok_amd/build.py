@@ -24,6 +24,42 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-u
 EXTRA_FLAGS = {"conv_ws2.hip": ["-fno-slp-vectorize"], "tblock_ws128.hip": ["-fno-slp-vectorize"]}
 
 
+# objects whose kernels keep operands in hand-assigned registers around inline-asm MFMAs (weights in the accumulator half, results read behind
+# explicit wait states): a register spill there is not a slow-down but a wrong result (round 6: the fp16 fused temporal block with 16 spilled
+# registers computed garbage) -- the build refuses it.  Instantiations with cycle stamps (measurement aids, last template argument true) may spill.
+NO_SPILL = {"tblock_ws128.hip": "tblock_pair_kernel", "conv_ws2.hip": "conv3x3_ws2_kernel"}
+LLVM_BIN = "/opt/rocm/lib/llvm/bin"
+
+
+def kernel_resources(obj):
+    """[(mangled name, vgpr, agpr, spilled vgprs, scratch bytes)] of the gfx950 code object inside a compiled .o"""
+    import re
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        fat, dev = os.path.join(d, "fat.bin"), os.path.join(d, "dev.o")
+        subprocess.check_call([f"{LLVM_BIN}/llvm-objcopy", "--dump-section", f".hip_fatbin={fat}", obj])
+        subprocess.check_call([f"{LLVM_BIN}/clang-offload-bundler", "--unbundle", "--type=o", f"--input={fat}",
+                               "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", f"--output={dev}"])
+        notes = subprocess.check_output([f"{LLVM_BIN}/llvm-readelf", "--notes", dev], text=True)
+    out = []
+    for blk in notes.split("- .agpr_count:")[1:]:
+        g = lambda k: re.search(r"\." + k + r":\s+(\S+)", blk).group(1)  # noqa: E731
+        out.append((g("name"), int(g("vgpr_count")), int(blk.split()[0]), int(g("vgpr_spill_count")), int(g("private_segment_fixed_size"))))
+    return out
+
+
+def check_no_spill(objdir):
+    bad = []
+    for src, kern in NO_SPILL.items():
+        obj = os.path.join(objdir, os.path.splitext(src)[0] + ".o")
+        for name, _v, _a, spill, scratch in kernel_resources(obj):
+            measured = name.endswith("Lb1EEEvNS_10TBlockArgsE") or name.endswith("Lb1EEEvNS_8ConvArgsE")      # PROF = true
+            if kern in name and not measured and (spill or scratch):
+                bad.append(f"{name}: {spill} spilled registers, {scratch} B scratch")
+    if bad:
+        raise RuntimeError("register spills in hand-scheduled kernels (wrong results, not only slow):\n  " + "\n  ".join(bad))
+
+
 def _hipcc():
     for c in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
         if c and os.path.exists(c):
@@ -80,6 +116,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
                 f.write(odig)
     if failed:
         raise RuntimeError(f"hipcc failed on {', '.join(failed)}")
+    check_no_spill(objdir)
     cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", LIB]
     if verbose:
         print("[vidtok_amd.build]", " ".join(cmd), flush=True)

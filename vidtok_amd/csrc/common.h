@@ -171,6 +171,52 @@ __device__ __forceinline__ float group_sum_dpp(float v) {
 // x * sigmoid(x) with the hardware reciprocal (1 ulp) instead of an IEEE division sequence
 __device__ __forceinline__ float silu_fast(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 
+// ---- LayerNorm(+SiLU) row arithmetic of the 16-bit kernels (bf16 / fp16 storage), "diet" form (round 6) --------------------------------------
+// Every fused LayerNorm site is VALU time (scripts/valu_rate_bench.hip): the two-pass form costs 9.5 plain instructions + 2 transcendentals an
+// element (unpack, sum, centre, square-sum, scale, affine, exp argument, exp2, + 1, rcp, multiply, half a pack).  This form costs 7.5 + 2:
+//   * both moments in ONE pass (var = E[x^2] - mean^2 in fp32 over 128 / 256 values, clamped at 0): the two lane reductions are independent
+//     (their DPP wait states fill each other) and the centring disappears into
+//   * t = x rstd + (-mean rstd): one fma instead of a subtraction and a multiplication;
+//   * SiLU with -log2(e) folded into the affine the CALLER passes (g' = -log2e g, b' = -log2e b, see ln_fold): a = t g' + b' = -log2e u, and
+//     u sigmoid(u) = u / (1 + 2^a) = a / (-log2e (1 + 2^a)) = a * rcp(fma(2^a, -log2e, -log2e)): no separate exponent argument.
+// The fp32-storage kernels (fp32 and split-bf16 modes, held to 1e-3 of the oracle with FSQ codes bit-exact) keep the two-pass form.
+// Nothing here depends on FMA contraction (fused operations are spelled out, the rest are single operations).
+[[maybe_unused]] constexpr float kNegLog2e = -1.4426950408889634f;
+// the affine a site hands to ln_row8: scaled for the SiLU form, as is for a plain LayerNorm
+__device__ __forceinline__ float ln_fold(float v, bool silu) { return silu ? v * kNegLog2e : v; }
+// statistics of a row held as 8 values a lane on G lanes (C = 8 G channels): returns rstd, *nm = -mean rstd
+template <int G>
+__device__ __forceinline__ float ln_row_stats(float s, float q, float eps, float* nm) {
+  constexpr float kInvC = 1.0f / (8.0f * G);
+  const float mean = group_sum_dpp<G>(s) * kInvC;
+  const float ex2 = group_sum_dpp<G>(q) * kInvC;
+  const float var = fmaxf(__builtin_fmaf(-mean, mean, ex2), 0.0f);
+  const float rstd = __builtin_amdgcn_rsqf(var + eps);
+  *nm = -mean * rstd;
+  return rstd;
+}
+__device__ __forceinline__ float ln_tail(float t, float g, float b, bool silu) {
+  float a = __builtin_fmaf(t, g, b);
+  if (silu) {
+    const float den = __builtin_fmaf(__builtin_amdgcn_exp2f(a), kNegLog2e, kNegLog2e);
+    a = a * __builtin_amdgcn_rcpf(den);
+  }
+  return a;
+}
+template <int G, bool SILU>
+__device__ __forceinline__ void ln_row8(const float (&v)[8], const float (&g)[8], const float (&b)[8], float eps, float (&o)[8]) {
+  float s = v[0], q = v[0] * v[0];
+#pragma unroll
+  for (int e = 1; e < 8; ++e) {
+    s = s + v[e];
+    q = __builtin_fmaf(v[e], v[e], q);
+  }
+  float nm;
+  const float rstd = ln_row_stats<G>(s, q, eps, &nm);
+#pragma unroll
+  for (int e = 0; e < 8; ++e) o[e] = ln_tail(__builtin_fmaf(v[e], rstd, nm), g[e], b[e], SILU);
+}
+
 __device__ __forceinline__ float wave_sum(float v, int width) {
   for (int o = width >> 1; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   return v;

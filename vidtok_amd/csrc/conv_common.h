@@ -228,7 +228,11 @@ struct Oct16 {      // a 16-bit storage type: one 16-byte access
     u32x4 t;
 #pragma unroll
     for (int e = 0; e < 4; ++e) t[e] = h16<H>::pack(v[2 * e], v[2 * e + 1]);
+#ifdef VT_OCT_NT                                                       // A/B aid: streaming (nt) stores of the epilogue rows
+    __builtin_nontemporal_store(t, reinterpret_cast<u32x4*>(p));
+#else
     *reinterpret_cast<u32x4*>(p) = t;
+#endif
   }
 };
 template <>

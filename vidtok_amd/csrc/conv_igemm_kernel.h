@@ -252,8 +252,8 @@ __device__ __forceinline__ void conv_epilogue_lds128_at(const ConvArgs& p, f32x1
   if (p.ln_mode) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      lg[e] = p.ln_gamma[8 * oct_j + e];
-      lb[e] = p.ln_beta[8 * oct_j + e];
+      lg[e] = ln_fold(p.ln_gamma[8 * oct_j + e], sizeof(TOut) == 2 && p.ln_mode == 2);     // 16-bit storage + SiLU: the affine carries -log2(e)
+      lb[e] = ln_fold(p.ln_beta[8 * oct_j + e], sizeof(TOut) == 2 && p.ln_mode == 2);
     }
   }
 #pragma unroll
@@ -271,23 +271,28 @@ __device__ __forceinline__ void conv_epilogue_lds128_at(const ConvArgs& p, f32x1
     }
     const long long orow = out_row(p, m_blk + row);
     if (!p.ln_mode || p.ln_keep_y) Oct<TOut>::store(yg + orow * p.ldy + n_blk + 8 * oct_j, v);
-    if (p.ln_mode) {   // uniform; same two-pass statistics as layernorm_act_kernel, taken before the rounding to TOut
-      float s = 0.f;
-#pragma unroll
-      for (int e = 0; e < 8; ++e) s += v[e];
-      const float mean = group_sum_dpp<16>(s) * (1.0f / 128.0f);
-      float q = 0.f;
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        v[e] -= mean;
-        q += v[e] * v[e];
-      }
-      const float rstd = __builtin_amdgcn_rsqf(group_sum_dpp<16>(q) * (1.0f / 128.0f) + p.ln_eps);
+    if (p.ln_mode) {   // uniform; statistics of the fp32 row, taken before the rounding to TOut
       float o[8];
+      if constexpr (sizeof(TOut) == 2) {   // 16-bit storage: the one-pass form every fused LayerNorm site of these modes shares (ln_row8, common.h; lg / lb folded above)
+        if (p.ln_mode == 2) ln_row8<16, true>(v, lg, lb, p.ln_eps, o);
+        else ln_row8<16, false>(v, lg, lb, p.ln_eps, o);
+      } else {                              // fp32 storage (fp32 / split-bf16 modes): two-pass statistics like layernorm_act_kernel
+        float s = 0.f;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const float u = v[e] * rstd * lg[e] + lb[e];
-        o[e] = (p.ln_mode == 2) ? silu_fast(u) : u;
+        for (int e = 0; e < 8; ++e) s += v[e];
+        const float mean = group_sum_dpp<16>(s) * (1.0f / 128.0f);
+        float q = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          v[e] -= mean;
+          q += v[e] * v[e];
+        }
+        const float rstd = __builtin_amdgcn_rsqf(group_sum_dpp<16>(q) * (1.0f / 128.0f) + p.ln_eps);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float u = v[e] * rstd * lg[e] + lb[e];
+          o[e] = (p.ln_mode == 2) ? silu_fast(u) : u;
+        }
       }
       Oct<TOut>::store(ng + orow * p.ldn + 8 * oct_j, o);
     }
@@ -335,6 +340,13 @@ __device__ __forceinline__ void conv_epilogue_lds256(const ConvArgs& p, f32x16 (
     const f32x4 b0 = *reinterpret_cast<const f32x4*>(p.ln_beta + 8 * j), b1 = *reinterpret_cast<const f32x4*>(p.ln_beta + 8 * j + 4);
     lg[0] = f32x2{g0[0], g0[1]}; lg[1] = f32x2{g0[2], g0[3]}; lg[2] = f32x2{g1[0], g1[1]}; lg[3] = f32x2{g1[2], g1[3]};
     lb[0] = f32x2{b0[0], b0[1]}; lb[1] = f32x2{b0[2], b0[3]}; lb[2] = f32x2{b1[0], b1[1]}; lb[3] = f32x2{b1[2], b1[3]};
+    if (sizeof(TOut) == 2 && p.ln_mode == 2) {            // 16-bit storage + SiLU: the affine carries -log2(e) (ln_row8, common.h)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        lg[q] = lg[q] * kNegLog2e;
+        lb[q] = lb[q] * kNegLog2e;
+      }
+    }
   }
   const int h = lane >> 5;
   auto half = [&](auto pz_c) {
@@ -386,26 +398,48 @@ __device__ __forceinline__ void conv_epilogue_lds256(const ConvArgs& p, f32x16 (
         Oct<TOut>::store(yg + orow * p.ldy + n_blk + 8 * j, yv);
       }
       if (!has_ln) continue;
-      const f32x2 s = (v[0] + v[1]) + (v[2] + v[3]);
-      const float mean = group_sum_dpp<32>(s[0] + s[1]) * (1.0f / 256.0f);
-      f32x2 d[4], qq = {0.f, 0.f};
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        d[q] = v[q] - mean;
-        qq = __builtin_elementwise_fma(d[q], d[q], qq);
-      }
-      const float rstd = __builtin_amdgcn_rsqf(__builtin_fmaf(group_sum_dpp<32>(qq[0] + qq[1]), 1.0f / 256.0f, p.ln_eps));
       float o[8];
+      if constexpr (sizeof(TOut) == 2) {
+        // 16-bit storage: the one-pass form of ln_row8 (common.h) on channel pairs -- both moments together, t = x rstd - mean rstd, and
+        // for SiLU a = t g' + b' with -log2(e) folded into lg / lb above: u sigmoid(u) = a * rcp(fma(2^a, -log2e, -log2e))
+        const f32x2 s = (v[0] + v[1]) + (v[2] + v[3]);
+        f32x2 qq = v[0] * v[0];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        f32x2 u = __builtin_elementwise_fma(d[q] * rstd, lg[q], lb[q]);
-        if (p.ln_mode == 2) {                            // u * sigmoid(u), the arithmetic of silu_fast on a pair
-          const f32x2 t = u * -1.4426950408889634f;
-          const f32x2 e = f32x2{__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])} + 1.0f;
-          u = u * f32x2{__builtin_amdgcn_rcpf(e[0]), __builtin_amdgcn_rcpf(e[1])};
+        for (int q = 1; q < 4; ++q) qq = __builtin_elementwise_fma(v[q], v[q], qq);
+        float nm;
+        const float rstd = ln_row_stats<32>(s[0] + s[1], qq[0] + qq[1], p.ln_eps, &nm);
+        const f32x2 rstd2 = {rstd, rstd}, nm2 = {nm, nm}, c2 = {kNegLog2e, kNegLog2e};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          f32x2 u = __builtin_elementwise_fma(__builtin_elementwise_fma(v[q], rstd2, nm2), lg[q], lb[q]);
+          if (p.ln_mode == 2) {
+            const f32x2 den = __builtin_elementwise_fma(f32x2{__builtin_amdgcn_exp2f(u[0]), __builtin_amdgcn_exp2f(u[1])}, c2, c2);
+            u = u * f32x2{__builtin_amdgcn_rcpf(den[0]), __builtin_amdgcn_rcpf(den[1])};
+          }
+          o[2 * q] = u[0];
+          o[2 * q + 1] = u[1];
         }
-        o[2 * q] = u[0];
-        o[2 * q + 1] = u[1];
+      } else {
+        const f32x2 s = (v[0] + v[1]) + (v[2] + v[3]);
+        const float mean = group_sum_dpp<32>(s[0] + s[1]) * (1.0f / 256.0f);
+        f32x2 d[4], qq = {0.f, 0.f};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          d[q] = v[q] - mean;
+          qq = __builtin_elementwise_fma(d[q], d[q], qq);
+        }
+        const float rstd = __builtin_amdgcn_rsqf(__builtin_fmaf(group_sum_dpp<32>(qq[0] + qq[1]), 1.0f / 256.0f, p.ln_eps));
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          f32x2 u = __builtin_elementwise_fma(d[q] * rstd, lg[q], lb[q]);
+          if (p.ln_mode == 2) {                            // u * sigmoid(u), the arithmetic of silu_fast on a pair
+            const f32x2 t = u * -1.4426950408889634f;
+            const f32x2 e = f32x2{__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])} + 1.0f;
+            u = u * f32x2{__builtin_amdgcn_rcpf(e[0]), __builtin_amdgcn_rcpf(e[1])};
+          }
+          o[2 * q] = u[0];
+          o[2 * q + 1] = u[1];
+        }
       }
       Oct<TOut>::store(ng + orow * p.ldn + 8 * j, o);
     }

@@ -46,8 +46,8 @@ __device__ __forceinline__ void conv_epilogue_in8(const ConvArgs& p, f32x16 (&ac
   if (p.ln_mode) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      lg[e] = p.ln_gamma[8 * oct_j + e];
-      lb[e] = p.ln_beta[8 * oct_j + e];
+      lg[e] = ln_fold(p.ln_gamma[8 * oct_j + e], sizeof(TOut) == 2 && p.ln_mode == 2);     // 16-bit storage + SiLU: the affine carries -log2(e)
+      lb[e] = ln_fold(p.ln_beta[8 * oct_j + e], sizeof(TOut) == 2 && p.ln_mode == 2);
     }
   }
   static_for<0, 2>([&](auto pc) __attribute__((always_inline)) {
@@ -83,23 +83,28 @@ __device__ __forceinline__ void conv_epilogue_in8(const ConvArgs& p, f32x16 (&ac
       for (int e = 0; e < 8; ++e) v[e] = e < 4 ? t0[e] : t1[e - 4];
       const long long orow = out_row(p, m_blk + 64 * pass + row);
       if (!p.ln_mode || p.ln_keep_y) Oct<TOut>::store(yg + orow * p.ldy + 8 * oct_j, v);
-      if (p.ln_mode) {   // uniform; same two-pass statistics as layernorm_act_kernel, taken before the rounding to TOut
-        float s = 0.f;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) s += v[e];
-        const float mean = group_sum_dpp<16>(s) * (1.0f / 128.0f);
-        float q = 0.f;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          v[e] -= mean;
-          q += v[e] * v[e];
-        }
-        const float rstd = __builtin_amdgcn_rsqf(group_sum_dpp<16>(q) * (1.0f / 128.0f) + p.ln_eps);
+      if (p.ln_mode) {   // uniform; statistics of the fp32 row, taken before the rounding to TOut
         float o[8];
+        if constexpr (sizeof(TOut) == 2) {   // 16-bit storage: the one-pass form every fused LayerNorm site of these modes shares (ln_row8, common.h; lg / lb folded above)
+          if (p.ln_mode == 2) ln_row8<16, true>(v, lg, lb, p.ln_eps, o);
+          else ln_row8<16, false>(v, lg, lb, p.ln_eps, o);
+        } else {                              // fp32 storage (fp32 / split-bf16 modes): two-pass statistics like layernorm_act_kernel
+          float s = 0.f;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const float u = v[e] * rstd * lg[e] + lb[e];
-          o[e] = (p.ln_mode == 2) ? silu_fast(u) : u;
+          for (int e = 0; e < 8; ++e) s += v[e];
+          const float mean = group_sum_dpp<16>(s) * (1.0f / 128.0f);
+          float q = 0.f;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            v[e] -= mean;
+            q += v[e] * v[e];
+          }
+          const float rstd = __builtin_amdgcn_rsqf(group_sum_dpp<16>(q) * (1.0f / 128.0f) + p.ln_eps);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float u = v[e] * rstd * lg[e] + lb[e];
+            o[e] = (p.ln_mode == 2) ? silu_fast(u) : u;
+          }
         }
         Oct<TOut>::store(ng + orow * p.ldn + 8 * oct_j, o);
       }

@@ -41,6 +41,10 @@
 
 #include "conv_select.h"
 
+#ifndef VT_STORE_AUX
+#define VT_STORE_AUX 2      // cache policy bits of the y / n stores (A/B aid; 2 = nt)
+#endif
+
 namespace {
 
 [[maybe_unused]] constexpr int W2_TH = 4, W2_TW = 16;
@@ -136,8 +140,8 @@ __global__ __launch_bounds__(512, 1) void conv3x3_ws2_kernel(const ConvArgs p) {
   float* prm = reinterpret_cast<float*>(smem + W2_OFF_PRM);
   if (tid < 384) {
     float v = 0.0f;
-    if (tid < 128) v = LN != 0 ? p.ln_gamma[tid] : 1.0f;
-    else if (tid < 256) v = LN != 0 ? p.ln_beta[tid - 128] : 0.0f;
+    if (tid < 128) v = LN != 0 ? ln_fold(p.ln_gamma[tid], LN == 2) : 1.0f;             // LayerNorm + SiLU: the affine carries -log2(e) (ln_row8, common.h)
+    else if (tid < 256) v = LN != 0 ? ln_fold(p.ln_beta[tid - 128], LN == 2) : 0.0f;
     else v = p.bias ? p.bias[tid - 256] : 0.0f;
     // channel c = 8 oct + 4 half + e of an array at [half][oct][e]: the 16 lanes of a row read 256 contiguous bytes (in channel
     // order lanes oct and oct + 8 of a ds_read_b128 group share their banks: every parameter read 2-way conflicted)
@@ -255,7 +259,6 @@ __global__ __launch_bounds__(512, 1) void conv3x3_ws2_kernel(const ConvArgs p) {
   // Row arithmetic in explicit-rounding intrinsics, the operation order of conv_ws128.hip (bias joined the tile before the
   // transposition there); every intermediate is pinned so the vectoriser cannot pair the elements -- packed fp32 does not
   // run beside the other wave's MFMAs (scripts/mfma_issue_bench.hip).
-  auto pinf = [](float&) {};
   // y / n go out through buffer descriptors rebased to the tile's frame (as the DMA requests come in): the per-lane byte
   // offset is tile-invariant and 32-bit, the tile's own offset is one more addition -- no 64-bit address arithmetic per
   // store (rows of y and n are 128 channels wide: ws128_eligible).  The tile offset does NOT ride in the instruction's
@@ -302,44 +305,28 @@ __global__ __launch_bounds__(512, 1) void conv3x3_ws2_kernel(const ConvArgs p) {
       if (has_res) rw = *reinterpret_cast<const u32x4*>(smem + rbase + (16 * prow + col) * W2_ROWP);
       else rw[0] = rw[1] = rw[2] = rw[3] = 0u;
       const int pix = prow * W + col;                          // relative to the tile's first pixel
-      float rv[8], s = 0.f;
+      float rv[8];
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         const uint32_t w2 = rw[e >> 1];
         const float r = (e & 1) ? h16<H>::hi(w2) : h16<H>::lo(w2);
         rv[e] = __fadd_rn(r, __fadd_rn(e < 4 ? t0[e] : t1[e - 4], e < 4 ? o0[e] : o1[e - 4]));
-        pinf(rv[e]);
-        s = __fadd_rn(s, rv[e]);
-        pinf(s);
       }
       if constexpr (KEEP) {
         u32x4 w4;
 #pragma unroll
         for (int e = 0; e < 4; ++e) w4[e] = h16<H>::pack(rv[2 * e], rv[2 * e + 1]);
-        __builtin_amdgcn_raw_buffer_store_b128(w4, yrs, (tile_pix + pix) * 256 + oct_j * 16, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(w4, yrs, (tile_pix + pix) * 256 + oct_j * 16, 0, VT_STORE_AUX);
       }
-      if constexpr (LN != 0) {
-        const float mean = group_sum_dpp<16>(s) * (1.0f / 128.0f);
-        float q = 0.f;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          rv[e] = __fsub_rn(rv[e], mean);
-          pinf(rv[e]);
-          q = __fmaf_rn(rv[e], rv[e], q);
-          pinf(q);
-        }
-        const float rstd = __builtin_amdgcn_rsqf(__fmaf_rn(group_sum_dpp<16>(q), 1.0f / 128.0f, p.ln_eps));
+      if constexpr (LN != 0) {                                 // the row arithmetic every 16-bit LayerNorm site shares (round 6: one-pass moments)
+        const float gg[8] = {g0[0], g0[1], g0[2], g0[3], g1[0], g1[1], g1[2], g1[3]};
+        const float bb[8] = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+        float ov[8];
+        ln_row8<16, LN == 2>(rv, gg, bb, p.ln_eps, ov);
         u32x4 w4;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          float a = __fmaf_rn(__fmul_rn(rv[e], rstd), e < 4 ? g0[e] : g1[e - 4], e < 4 ? b0[e] : b1[e - 4]);
-          pinf(a);
-          rv[e] = (LN == 2) ? silu_fast(a) : a;
-          pinf(rv[e]);
-        }
-#pragma unroll
-        for (int e = 0; e < 4; ++e) w4[e] = h16<H>::pack(rv[2 * e], rv[2 * e + 1]);
-        __builtin_amdgcn_raw_buffer_store_b128(w4, nrs, (tile_pix + pix) * 256 + oct_j * 16, 0, 0);
+        for (int e = 0; e < 4; ++e) w4[e] = h16<H>::pack(ov[2 * e], ov[2 * e + 1]);
+        __builtin_amdgcn_raw_buffer_store_b128(w4, nrs, (tile_pix + pix) * 256 + oct_j * 16, 0, VT_STORE_AUX);
       }
     }
   };

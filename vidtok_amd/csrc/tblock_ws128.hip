@@ -27,6 +27,10 @@
 
 #include "conv_common.h"
 
+#ifndef VT_STORE_AUX
+#define VT_STORE_AUX 2      // cache policy bits of the y / n stores (A/B aid; 2 = nt)
+#endif
+
 namespace {
 
 [[maybe_unused]] constexpr int TB_PIX = 64;                      // pixels per column step
@@ -131,7 +135,10 @@ __device__ __forceinline__ u32x4 t3_pack8(const float (&o)[8]) {
 // ---------------------------------------------------------------------------------------------------------------------
 [[maybe_unused]] constexpr int T4_OFF_PRM = T3_LDS;                       // g1 | be1 | g2 | be2 | gn | ben | b1 | b2, 128 fp32 each
 [[maybe_unused]] constexpr int T4_LDS = T4_OFF_PRM + 8 * 128 * 4;         // 157 696
-[[maybe_unused]] constexpr int T4_FD = 3;                                 // fragment prefetch distance of a GEMM, in MFMAs
+#ifndef VT_T4_FD
+#define VT_T4_FD 6
+#endif
+[[maybe_unused]] constexpr int T4_FD = VT_T4_FD;                          // fragment prefetch distance of a GEMM, in MFMAs
 
 template <typename H, bool FIRST>
 __device__ __forceinline__ void t4_mfma(const u32x4& w, const u32x4& x, f32x16& acc) {
@@ -143,60 +150,11 @@ __device__ __forceinline__ void t4_mfma(const u32x4& w, const u32x4& x, f32x16& 
     else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc) : "a"(w), "v"(x));
   }
 }
-// LayerNorm(+SiLU) of a row slice, even and odd channels summed separately and then together (the order of the packed-fp32
-// form this row phase once had; kept so that results did not move when the arrangement changed)
-template <bool SILU>
-__device__ __forceinline__ void t4_row_norm_pairs(float (&v)[8], const float (&g)[8], const float (&b)[8], float eps, float (&o)[8]) {
-  float s0 = v[0], s1 = v[1];
-#pragma unroll
-  for (int q = 1; q < 4; ++q) {
-    s0 = s0 + v[2 * q];
-    s1 = s1 + v[2 * q + 1];
-  }
-  const float mean = group_sum_dpp<16>(s0 + s1) * (1.0f / 128.0f);
-  float d[8], q0 = 0.f, q1 = 0.f;
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    d[2 * q] = v[2 * q] - mean;
-    d[2 * q + 1] = v[2 * q + 1] - mean;
-    q0 = __builtin_fmaf(d[2 * q], d[2 * q], q0);
-    q1 = __builtin_fmaf(d[2 * q + 1], d[2 * q + 1], q1);
-  }
-  const float rstd = __builtin_amdgcn_rsqf(__builtin_fmaf(group_sum_dpp<16>(q0 + q1), 1.0f / 128.0f, eps));
-#pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    float u = __builtin_fmaf(d[e] * rstd, g[e], b[e]);
-    if constexpr (SILU) {
-      const float ex = __builtin_amdgcn_exp2f(u * -1.4426950408889634f);
-      u = u * __builtin_amdgcn_rcpf(ex + 1.0f);
-    }
-    o[e] = u;
-  }
-}
-// the same with the channels summed in order (no pins between the elements: this file is compiled without the SLP
-// vectoriser, see build.py)
+// LayerNorm(+SiLU) of a row slice: ln_row8 of common.h (round 6: one-pass moments, centring + scaling as one fma, -log2(e) folded into the
+// affines in the LDS; 7.5 plain + 2 transcendental instructions an element against 9.5 + 2 of the two-pass form this kernel had until round 5)
 template <bool SILU>
 __device__ __forceinline__ void t4_row_norm(float (&v)[8], const float (&g)[8], const float (&b)[8], float eps, float (&o)[8]) {
-  float s = 0.f;
-#pragma unroll
-  for (int e = 0; e < 8; ++e) s = s + v[e];
-  const float mean = group_sum_dpp<16>(s) * (1.0f / 128.0f);
-  float q = 0.f, d[8];
-#pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    d[e] = v[e] - mean;
-    q = __builtin_fmaf(d[e], d[e], q);
-  }
-  const float rstd = __builtin_amdgcn_rsqf(__builtin_fmaf(group_sum_dpp<16>(q), 1.0f / 128.0f, eps));
-#pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    float u = __builtin_fmaf(d[e] * rstd, g[e], b[e]);
-    if constexpr (SILU) {
-      const float ex = __builtin_amdgcn_exp2f(u * -1.4426950408889634f);
-      u = u * __builtin_amdgcn_rcpf(ex + 1.0f);
-    }
-    o[e] = u;
-  }
+  ln_row8<16, SILU>(v, g, b, eps, o);
 }
 
 // CACHE: the instantiation that keeps v1.1 chunk state (cache1 / cache2).  Separate because its loads and stores are
@@ -219,6 +177,12 @@ __global__ __launch_bounds__(512, 1) void tblock_pair_kernel(const TBlockArgs p)
   const int c_begin = slot_id * cq + min(slot_id, cr);
   const int c_end = c_begin + cq + (slot_id < cr ? 1 : 0);
   if (c_begin >= c_end) return;
+#ifdef VT_TB_STAGGER                                                  // A/B aid: every other workgroup starts half a step late (do the CUs' store bursts collide?)
+  if (blockIdx.x & 8) {
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    while ((long long)(__builtin_amdgcn_s_memtime() - t0) < VT_TB_STAGGER) __builtin_amdgcn_s_sleep(32);
+  }
+#endif
   const int n = (c_end - c_begin) * p.T;                             // virtual steps of this workgroup
   constexpr int R1 = 0, R2 = TB_RING;                                // ring offsets in the LDS
   const unsigned frame_bytes = (unsigned)p.HW * 256u;
@@ -232,10 +196,10 @@ __global__ __launch_bounds__(512, 1) void tblock_pair_kernel(const TBlockArgs p)
     // the same banks -- every parameter read 2-way conflicted, 23 % of the kernel's LDS cycles (profiles/r03_bench_bf16_sq_pmc.txt)
     const int pc = ((c >> 2) & 1) * 64 + (c >> 3) * 4 + (c & 3);
     const float* src0 = a == 0 ? p.g1 : (a == 1 ? p.be1 : (a == 2 ? p.g2 : p.be2));
-    prm[a * 128 + pc] = src0[c];
+    prm[a * 128 + pc] = ln_fold(src0[c], true);                      // norm1 / norm2 are followed by SiLU: the affines carry -log2(e) (ln_row8)
     float v;
-    if (a == 0) v = LNN ? p.gn[c] : 1.0f;
-    else if (a == 1) v = LNN ? p.ben[c] : 0.0f;
+    if (a == 0) v = LNN ? ln_fold(p.gn[c], LNN == 2) : 1.0f;
+    else if (a == 1) v = LNN ? ln_fold(p.ben[c], LNN == 2) : 0.0f;
     else if (a == 2) v = p.b1 ? p.b1[c] : 0.0f;
     else v = p.b2 ? p.b2[c] : 0.0f;
     prm[(a + 4) * 128 + pc] = v;
@@ -440,10 +404,11 @@ __global__ __launch_bounds__(512, 1) void tblock_pair_kernel(const TBlockArgs p)
     for (int it = U0; it < U1; ++it) {
       float v[8], o[8];
       t3_unpack8<H>(xr[it], v);
-      t4_row_norm_pairs<true>(v, g, b, p.eps, o);
+      t4_row_norm<true>(v, g, b, p.eps, o);
       const u32x4 w = t3_pack8<H>(o);
       *reinterpret_cast<u32x4*>(smem + wo + it * (16 * TB_ROWP)) = w;
       cache_put(p.cache1, c, oct_j, row0 + 16 * it, w);
+      __builtin_amdgcn_sched_barrier(0);                                // one row at a time: interleaved rows double the live registers (fp16 spilled)
     }
   };
 
@@ -451,48 +416,46 @@ __global__ __launch_bounds__(512, 1) void tblock_pair_kernel(const TBlockArgs p)
     if constexpr (PROF) {
       if (p.prof_mode & 16) return;                                  // measurement: no stores at all
     }
-    __builtin_amdgcn_raw_buffer_store_b128(w, rs, vo, 0, 0);
+    __builtin_amdgcn_raw_buffer_store_b128(w, rs, vo, 0, VT_STORE_AUX);
   };
   // ---- prologue: L1(0) -> ring1 slot 0; x(1) rows for the L1 units of phase B_0
+  // x rows in registers: ONE set (round 6).  A row unit's input -- the x rows of step k + 1 for an L1 unit, those of step k - 2 as the
+  // residual of an O unit -- is requested a full step ahead, and the request goes out right BEHIND the unit that consumed the register's
+  // previous contents, into the same registers.  Until round 5 the requests of a phase went out together at its top, in front of the phase's
+  // stores, into a second register set (two sets, two bodies): 40 of the 128 architectural registers in group 0 held x rows, the allocator
+  // sat at 254 / 256 with values parked in the accumulator half, and a fragment ring deeper than three MFMAs did not fit (the fp16
+  // instantiations spilled outright).  A request behind stores returns only when they have retired (~5 000 cycles) -- its consumer is
+  // a whole step (> 8 000 cycles) away.
   struct XSet {
     u32x4 xn[4], xr[4];
   };
-  XSet sa, sb;
+  XSet xs;
   Cur c_p2 = cur_at(0);          // cursors of virtual steps k + 2, k + 1, k, k - 1, k - 2 (valid where those steps exist)
   Cur c_p1 = c_p2, c_0 = c_p2, c_m1 = c_p2, c_m2 = c_p2;
   __syncthreads();               // parameters are in the LDS
   if (grp == 0) {
-    load_rows(std::integral_constant<int, 0>{}, std::integral_constant<int, 3>{}, sa.xn, c_0);
-    ln1_units(std::integral_constant<int, 0>{}, std::integral_constant<int, 3>{}, sa.xn, 0, c_0);
+    load_rows(std::integral_constant<int, 0>{}, std::integral_constant<int, 3>{}, xs.xn, c_0);
+    ln1_units(std::integral_constant<int, 0>{}, std::integral_constant<int, 3>{}, xs.xn, 0, c_0);
   } else {
-    load_rows(std::integral_constant<int, 3>{}, std::integral_constant<int, 4>{}, sa.xn, c_0);
-    ln1_units(std::integral_constant<int, 3>{}, std::integral_constant<int, 4>{}, sa.xn, 0, c_0);
+    load_rows(std::integral_constant<int, 3>{}, std::integral_constant<int, 4>{}, xs.xn, c_0);
+    ln1_units(std::integral_constant<int, 3>{}, std::integral_constant<int, 4>{}, xs.xn, 0, c_0);
     if (CACHE && p.replicate == 2) cache_get(p.cache1, R1, c_0, 1, 2);         // frames -2, -1 of the first column: slots (-2) % 3, (-1) % 3
   }
   cur_step(c_p1);
   c_p2 = c_p1;
   cur_step(c_p2);
   if (1 < n) {
-    if (grp == 0) load_rows(std::integral_constant<int, 0>{}, std::integral_constant<int, 3>{}, sa.xn, c_p1);
-    else load_rows(std::integral_constant<int, 3>{}, std::integral_constant<int, 4>{}, sa.xn, c_p1);
+    if (grp == 0) load_rows(std::integral_constant<int, 0>{}, std::integral_constant<int, 3>{}, xs.xn, c_p1);
+    else load_rows(std::integral_constant<int, 3>{}, std::integral_constant<int, 4>{}, xs.xn, c_p1);
   }
-  // every register of both sets is defined before the loop (guarded steps skip loads, not uses); a group touches only
+  // every register of the set is defined before the loop (guarded steps skip loads, not uses); a group touches only
   // its own units: group 0 xn[0..2] and xr[0..1], group 1 xn[3] and xr[2..3]
   if (grp == 0) {
 #pragma unroll
-    for (int it = 0; it < 3; ++it) sb.xn[it] = sa.xn[it];
-#pragma unroll
-    for (int it = 0; it < 2; ++it) {
-      sa.xr[it] = sa.xn[0];
-      sb.xr[it] = sa.xn[0];
-    }
+    for (int it = 0; it < 2; ++it) xs.xr[it] = xs.xn[0];
   } else {
-    sb.xn[3] = sa.xn[3];
 #pragma unroll
-    for (int it = 2; it < 4; ++it) {
-      sa.xr[it] = sa.xn[3];
-      sb.xr[it] = sa.xn[3];
-    }
+    for (int it = 2; it < 4; ++it) xs.xr[it] = xs.xn[3];
   }
   int s3 = 0;                    // k % 3
   auto advance = [&]() __attribute__((always_inline)) {
@@ -520,11 +483,11 @@ __global__ __launch_bounds__(512, 1) void tblock_pair_kernel(const TBlockArgs p)
     ld_prm(3, oct_j, b);
     const int ro = T3_OFF_T1 + row0 * T3_T1P + ((oct_j ^ row0) << 4);    // rows row0 + 16 it: swizzle key row % 16 = row0
     const int wo = R2 + sl * TB_SLOT + row0 * TB_ROWP + oct_j * 16;
-    u32x4 tw[4];
-#pragma unroll
-    for (int it = U0; it < U1; ++it) tw[it] = *reinterpret_cast<const u32x4*>(smem + ro + it * (16 * T3_T1P));
+    u32x4 tw[4];                                                       // the row after the one being worked on is in flight, not all of them
+    tw[U0] = *reinterpret_cast<const u32x4*>(smem + ro + U0 * (16 * T3_T1P));
 #pragma unroll
     for (int it = U0; it < U1; ++it) {
+      if (it + 1 < U1) tw[it + 1] = *reinterpret_cast<const u32x4*>(smem + ro + (it + 1) * (16 * T3_T1P));
       float v[8], o[8];
       t3_unpack8<H>(tw[it], v);
 #pragma unroll
@@ -533,6 +496,7 @@ __global__ __launch_bounds__(512, 1) void tblock_pair_kernel(const TBlockArgs p)
       const u32x4 w = t3_pack8<H>(o);
       *reinterpret_cast<u32x4*>(smem + wo + it * (16 * TB_ROWP)) = w;
       cache_put(p.cache2, c, oct_j, row0 + 16 * it, w);
+      __builtin_amdgcn_sched_barrier(0);
     }
   };
   // O of unit IT of the step at cursor c: rows of T2 + b2 + x -> y, LayerNorm_next -> n
@@ -562,6 +526,7 @@ __global__ __launch_bounds__(512, 1) void tblock_pair_kernel(const TBlockArgs p)
       t4_row_norm<(LNN == 2)>(v, gn, bn, p.eps, o);
       out_store(t3_pack8<H>(o), frame_rsrc(p.n_out, c), vo);
     }
+    __builtin_amdgcn_sched_barrier(0);                                  // a unit at a time (see ln1_units)
   };
   using I0 = std::integral_constant<int, 0>;
   using I1 = std::integral_constant<int, 1>;
@@ -578,7 +543,7 @@ __global__ __launch_bounds__(512, 1) void tblock_pair_kernel(const TBlockArgs p)
   // 2 500 cycles on top of 2 900 of arithmetic (profiles/r03_tblock_pair_phase_cycles.txt).
   if (grp == 0) {
     // ======================================================= group 0 =======================================================
-    auto body = [&](auto guard_c, int k, XSet& cur, XSet& nxt) __attribute__((always_inline)) {
+    auto body = [&](auto guard_c, int k) __attribute__((always_inline)) {
       constexpr bool GUARD = decltype(guard_c)::value;
       kcur = k;
       stamp(0);
@@ -591,36 +556,41 @@ __global__ __launch_bounds__(512, 1) void tblock_pair_kernel(const TBlockArgs p)
       if (CACHE && p.replicate == 2 && k >= 1 && k - 1 < n && c_m1.t == 0) cache_get(p.cache2, R2, c_m1, s3, slot_back(2));
       stamp(2);
       __syncthreads();
-      // ---- phase B_k: requests for B_{k+1} in front of this phase's stores, T1 <- conv1(k), my units of O(k-2) and L1(k+1)
-      if (!GUARD || k + 2 < n) load_rows(I0{}, I3{}, nxt.xn, c_p2);
-      if (!GUARD || (k >= 1 && k - 1 < n)) load_rows(I0{}, I2{}, nxt.xr, c_m1);
-      __builtin_amdgcn_sched_barrier(0);
+      // ---- phase B_k: T1 <- conv1(k), my units of O(k-2) and L1(k+1); behind each unit the request for its successor of step k+1
       if (!GUARD || k < n) acc_to_T1();
       stamp(3);
       const bool do_o = (!GUARD || (k >= 2 && k - 2 < n)) && !(PROF && (p.prof_mode & 2));
       const bool do_l1 = (!GUARD || k + 1 < n) && !(PROF && (p.prof_mode & 2));
-      if (do_o) o_unit(I0{}, cur.xr[0], c_m2);
-      if (do_l1) ln1_units(I0{}, I1{}, cur.xn, slot_back(2), c_p1);   // (k + 1) % 3 = (k - 2) % 3
-      if (do_o) o_unit(I1{}, cur.xr[1], c_m2);
+      const bool ld_r = !GUARD || (k >= 1 && k - 1 < n);                 // residual rows of step k-1, for O(k-1) in phase B_{k+1}
+      const bool ld_n = !GUARD || k + 2 < n;                             // x rows of step k+2, for L1(k+2) in phase B_{k+1}
+      if (do_o) o_unit(I0{}, xs.xr[0], c_m2);
+      if (ld_r) load_rows(I0{}, I1{}, xs.xr, c_m1);
+      if (do_l1) ln1_units(I0{}, I1{}, xs.xn, slot_back(2), c_p1);       // (k + 1) % 3 = (k - 2) % 3
+      if (ld_n) load_rows(I0{}, I1{}, xs.xn, c_p2);
+      if (do_o) o_unit(I1{}, xs.xr[1], c_m2);
+      if (ld_r) load_rows(I1{}, I2{}, xs.xr, c_m1);
       stamp(4);
-      if (do_l1) ln1_units(I1{}, I3{}, cur.xn, slot_back(2), c_p1);
+      if (do_l1) ln1_units(I1{}, I3{}, xs.xn, slot_back(2), c_p1);
+      if (ld_n) load_rows(I1{}, I3{}, xs.xn, c_p2);
       stamp(5);
       __syncthreads();
       stamp(6);
       advance();
     };
-    for (int k = 0; k < n + 2; k += 2) {
-      if (k >= 2 && k + 3 < n) {
-        body(std::false_type{}, k, sa, sb);
-        body(std::false_type{}, k + 1, sb, sa);
-      } else {
-        body(std::true_type{}, k, sa, sb);
-        if (k + 1 < n + 2) body(std::true_type{}, k + 1, sb, sa);
-      }
-    }
+    // three loops, not one with a branch: the registers with requests in flight cross only the back edge of the middle loop, whose body has
+    // no guarded twin to merge with (with both bodies in one loop the allocator moved the x rows at the loop header -- behind a vmcnt(0))
+    int k = 0;
+    for (; k < 2 && k < n + 2; ++k) body(std::true_type{}, k);
+    // a REAL vmcnt(0) (the builtin): the compiler's wait-count bookkeeping enters the middle loop with nothing pending, so the waits it
+    // places in front of the units count only what the loop itself issued behind the request (vmcnt(4..7): stores stay in flight).  With
+    // the guarded steps' unknown state merged in at the loop header, every unit waited for vmcnt(0) -- i.e. for the previous step's STORES
+    // to be acknowledged by the memory, ~1 500 cycles a unit (profiles/r06_tblock_pair_phase_cycles.txt, "no stores")
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    for (; k + 2 < n; ++k) body(std::false_type{}, k);              // straight-line middle steps
+    for (; k < n + 2; ++k) body(std::true_type{}, k);
   } else {
     // ======================================================= group 1 =======================================================
-    auto body = [&](auto guard_c, int k, XSet& cur, XSet& nxt) __attribute__((always_inline)) {
+    auto body = [&](auto guard_c, int k) __attribute__((always_inline)) {
       constexpr bool GUARD = decltype(guard_c)::value;
       kcur = k;
       stamp(0);
@@ -630,18 +600,20 @@ __global__ __launch_bounds__(512, 1) void tblock_pair_kernel(const TBlockArgs p)
       if ((!GUARD || (k >= 1 && k - 1 < n)) && !(PROF && (p.prof_mode & 2))) l2_units(I0{}, I3{}, slot_back(1), c_m1);
       stamp(2);
       __syncthreads();
-      // ---- phase B_k: requests for B_{k+1}; G2(k-1); my units of O(k-2) and L1(k+1)
-      if (!GUARD || k + 2 < n) load_rows(I3{}, I4{}, nxt.xn, c_p2);
-      if (!GUARD || (k >= 1 && k - 1 < n)) load_rows(I2{}, I4{}, nxt.xr, c_m1);
-      __builtin_amdgcn_sched_barrier(0);
+      // ---- phase B_k: G2(k-1); my units of O(k-2) and L1(k+1), each followed by the request for its successor of step k+1
       if ((!GUARD || (k >= 1 && k - 1 < n)) && !(PROF && (p.prof_mode & 1))) run_gemm(R2, slot_back(1), c_m1.t);
       stamp(3);
       const bool do_o = (!GUARD || (k >= 2 && k - 2 < n)) && !(PROF && (p.prof_mode & 2));
       const bool do_l1 = (!GUARD || k + 1 < n) && !(PROF && (p.prof_mode & 2));
-      if (do_o) o_unit(I2{}, cur.xr[2], c_m2);
+      const bool ld_r = !GUARD || (k >= 1 && k - 1 < n);
+      const bool ld_n = !GUARD || k + 2 < n;
+      if (do_o) o_unit(I2{}, xs.xr[2], c_m2);
+      if (ld_r) load_rows(I2{}, I3{}, xs.xr, c_m1);
       stamp(4);
-      if (do_l1) ln1_units(I3{}, I4{}, cur.xn, slot_back(2), c_p1);
-      if (do_o) o_unit(I3{}, cur.xr[3], c_m2);
+      if (do_l1) ln1_units(I3{}, I4{}, xs.xn, slot_back(2), c_p1);
+      if (ld_n) load_rows(I3{}, I4{}, xs.xn, c_p2);
+      if (do_o) o_unit(I3{}, xs.xr[3], c_m2);
+      if (ld_r) load_rows(I3{}, I4{}, xs.xr, c_m1);
       // step k+1 opens a column: conv1's cached frames -2, -1 go into ring1 slots (k-1) % 3, k % 3 -- read for the last time
       // by G1(k) in phase A_k, needed by G1(k+1) in phase A_{k+1}
       if (CACHE && p.replicate == 2 && k + 1 < n && c_p1.t == 0) cache_get(p.cache1, R1, c_p1, slot_back(1), s3);
@@ -650,15 +622,17 @@ __global__ __launch_bounds__(512, 1) void tblock_pair_kernel(const TBlockArgs p)
       stamp(6);
       advance();
     };
-    for (int k = 0; k < n + 2; k += 2) {
-      if (k >= 2 && k + 3 < n) {
-        body(std::false_type{}, k, sa, sb);
-        body(std::false_type{}, k + 1, sb, sa);
-      } else {
-        body(std::true_type{}, k, sa, sb);
-        if (k + 1 < n + 2) body(std::true_type{}, k + 1, sb, sa);
-      }
-    }
+    // three loops, not one with a branch: the registers with requests in flight cross only the back edge of the middle loop, whose body has
+    // no guarded twin to merge with (with both bodies in one loop the allocator moved the x rows at the loop header -- behind a vmcnt(0))
+    int k = 0;
+    for (; k < 2 && k < n + 2; ++k) body(std::true_type{}, k);
+    // a REAL vmcnt(0) (the builtin): the compiler's wait-count bookkeeping enters the middle loop with nothing pending, so the waits it
+    // places in front of the units count only what the loop itself issued behind the request (vmcnt(4..7): stores stay in flight).  With
+    // the guarded steps' unknown state merged in at the loop header, every unit waited for vmcnt(0) -- i.e. for the previous step's STORES
+    // to be acknowledged by the memory, ~1 500 cycles a unit (profiles/r06_tblock_pair_phase_cycles.txt, "no stores")
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    for (; k + 2 < n; ++k) body(std::false_type{}, k);              // straight-line middle steps
+    for (; k < n + 2; ++k) body(std::true_type{}, k);
   }
   dump();
 #endif
