@@ -1046,3 +1046,29 @@ def test_conv_interleaved_mix_with_layernorm(shape, silu, vt_opts):
     w = pack_conv_weight(torch.randn((cout, cin, 2, 3, 3), generator=g) / math.sqrt(cin * 18), dtype, cin_stored=x.shape[-1]).to(DEV)
     r = ops.conv(x, w, bias, geom, cout=cout, out=y, out_t=(2, 0), ln=(gam, bet, 1e-6, silu), ln_out=n, ln_optional=True, res=x, res_mode=L.VT_RES_MIX, mix_factor=mf)
     assert not isinstance(r, tuple)
+
+
+@pytest.mark.parametrize("dt", H16, ids=H16_IDS)
+@pytest.mark.parametrize("cout,tile", [(128, 0), (256, 256)], ids=["lds128_epilogue", "lds256_epilogue"])
+def test_conv_streaming_stores_same_bits(cout, tile, dt, vt_opts):
+    """option conv_nt_mb: outputs at least that large leave the LDS epilogues as streaming (nt) stores -- a cache policy, not arithmetic:
+    y and the fused LayerNorm are the bits of the plain stores (threshold 1 MiB vs off, on a tensor of 2 / 4 MiB)."""
+    B, T, H, W = 1, 2, 64, 64
+    cin = cout
+    if tile:
+        vt_opts(conv_tile=tile)
+    x = _act(B, T, H, W, cin, dt, 1)
+    res = _act(B, T, H, W, cout, dt, 4)
+    g = torch.Generator().manual_seed(2)
+    geom = ConvGeom(kh=3, kw=3, ph=1, pw=1, ph_hi=1, pw_hi=1)
+    w = pack_conv_weight(torch.randn((cout, cin, 3, 3), generator=g) / math.sqrt(cin * 9), dt, cin_stored=cin).to(DEV)
+    bias = _rand((cout,), torch.float32, 3, 0.1)
+    ln = (_rand((cout,), torch.float32, 6, 0.5) + 1.0, _rand((cout,), torch.float32, 7, 0.2), 1e-6, True)
+    outs = []
+    for mb in (0, 1):
+        vt_opts(conv_nt_mb=mb, conv_ws=0)
+        y, n = ops.conv(x, w, bias, geom, cout=cout, res=res, res_mode=L.VT_RES_ADD, ln=ln, ln_keep_y=True)
+        torch.cuda.synchronize()
+        outs.append((y.clone(), n.clone()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    assert torch.isfinite(outs[1][1].float()).all()

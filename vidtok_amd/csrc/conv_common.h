@@ -72,6 +72,7 @@ struct ConvArgs {
   int tskip;                   // 1: zero-padded time taps in front of the clip are skipped per tile (tile inside one output frame, tmode ZERO; launch_variant)
   int ksplit;                  // split-K: blockIdx.z = tap plane, the walk covers that plane only; 1: planes = kt, 2: planes = kh (KT = 1)
   unsigned plane_bytes;        //      bytes of one tap plane in a weight row (KH * KW * Cin, or KW * Cin, elements)
+  int nt_store;                // 1: the LDS epilogues write y / LayerNorm(y) with streaming (nt) stores (16-bit outputs of at least kNtStoreBytes)
   unsigned long long* prof;    // PROF instantiation only (vt_conv_profile): cycle stamps of workgroup 0
   int prof_mode;               // PROF instantiation of conv_ws2.hip only: option ws_prof_mode
 };
@@ -208,7 +209,7 @@ struct Oct<float> {
     hi = *reinterpret_cast<const f32x4*>(p + 4);
   }
   __device__ __forceinline__ float get(int e) const { return e < 4 ? lo[e] : hi[e - 4]; }
-  static __device__ __forceinline__ void store(float* p, const float (&v)[8]) {
+  static __device__ __forceinline__ void store(float* p, const float (&v)[8], bool = false) {
     f32x4 a, b;
 #pragma unroll
     for (int e = 0; e < 4; ++e) { a[e] = v[e]; b[e] = v[4 + e]; }
@@ -224,15 +225,14 @@ struct Oct16 {      // a 16-bit storage type: one 16-byte access
     const uint32_t t = w[e >> 1];
     return (e & 1) ? h16<H>::hi(t) : h16<H>::lo(t);
   }
-  static __device__ __forceinline__ void store(H* p, const float (&v)[8]) {
+  // nt: streaming store (the launcher sets ConvArgs::nt_store for outputs far larger than the caches: the rows do not displace the weights and
+  // halo rows the next tiles read again -- whole step 72.95 -> 72.43 ms, profiles/r06_nt_stores_ab.txt)
+  static __device__ __forceinline__ void store(H* p, const float (&v)[8], bool nt = false) {
     u32x4 t;
 #pragma unroll
     for (int e = 0; e < 4; ++e) t[e] = h16<H>::pack(v[2 * e], v[2 * e + 1]);
-#ifdef VT_OCT_NT                                                       // A/B aid: streaming (nt) stores of the epilogue rows
-    __builtin_nontemporal_store(t, reinterpret_cast<u32x4*>(p));
-#else
-    *reinterpret_cast<u32x4*>(p) = t;
-#endif
+    if (nt) __builtin_nontemporal_store(t, reinterpret_cast<u32x4*>(p));
+    else *reinterpret_cast<u32x4*>(p) = t;
   }
 };
 template <>

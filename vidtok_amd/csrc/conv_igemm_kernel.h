@@ -270,7 +270,7 @@ __device__ __forceinline__ void conv_epilogue_lds128_at(const ConvArgs& p, f32x1
       if (ALLOW_RES && p.res_mode == VT_RES_MIX) v[e] = alpha * rq[it].get(e) + (1.0f - alpha) * v[e];
     }
     const long long orow = out_row(p, m_blk + row);
-    if (!p.ln_mode || p.ln_keep_y) Oct<TOut>::store(yg + orow * p.ldy + n_blk + 8 * oct_j, v);
+    if (!p.ln_mode || p.ln_keep_y) Oct<TOut>::store(yg + orow * p.ldy + n_blk + 8 * oct_j, v, p.nt_store != 0);
     if (p.ln_mode) {   // uniform; statistics of the fp32 row, taken before the rounding to TOut
       float o[8];
       if constexpr (sizeof(TOut) == 2) {   // 16-bit storage: the one-pass form every fused LayerNorm site of these modes shares (ln_row8, common.h; lg / lb folded above)
@@ -294,7 +294,7 @@ __device__ __forceinline__ void conv_epilogue_lds128_at(const ConvArgs& p, f32x1
           o[e] = (p.ln_mode == 2) ? silu_fast(u) : u;
         }
       }
-      Oct<TOut>::store(ng + orow * p.ldn + 8 * oct_j, o);
+      Oct<TOut>::store(ng + orow * p.ldn + 8 * oct_j, o, p.nt_store != 0);
     }
   }
 }
@@ -395,7 +395,7 @@ __device__ __forceinline__ void conv_epilogue_lds256(const ConvArgs& p, f32x16 (
       }
       if (p.ln_keep_y || !has_ln) {
         const float yv[8] = {v[0][0], v[0][1], v[1][0], v[1][1], v[2][0], v[2][1], v[3][0], v[3][1]};
-        Oct<TOut>::store(yg + orow * p.ldy + n_blk + 8 * j, yv);
+        Oct<TOut>::store(yg + orow * p.ldy + n_blk + 8 * j, yv, p.nt_store != 0);
       }
       if (!has_ln) continue;
       float o[8];
@@ -441,7 +441,7 @@ __device__ __forceinline__ void conv_epilogue_lds256(const ConvArgs& p, f32x16 (
           o[2 * q + 1] = u[1];
         }
       }
-      Oct<TOut>::store(ng + orow * p.ldn + 8 * j, o);
+      Oct<TOut>::store(ng + orow * p.ldn + 8 * j, o, p.nt_store != 0);
     }
   };
   half(std::integral_constant<int, 0>{});

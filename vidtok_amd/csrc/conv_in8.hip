@@ -82,7 +82,7 @@ __device__ __forceinline__ void conv_epilogue_in8(const ConvArgs& p, f32x16 (&ac
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] = e < 4 ? t0[e] : t1[e - 4];
       const long long orow = out_row(p, m_blk + 64 * pass + row);
-      if (!p.ln_mode || p.ln_keep_y) Oct<TOut>::store(yg + orow * p.ldy + 8 * oct_j, v);
+      if (!p.ln_mode || p.ln_keep_y) Oct<TOut>::store(yg + orow * p.ldy + 8 * oct_j, v, p.nt_store != 0);
       if (p.ln_mode) {   // uniform; statistics of the fp32 row, taken before the rounding to TOut
         float o[8];
         if constexpr (sizeof(TOut) == 2) {   // 16-bit storage: the one-pass form every fused LayerNorm site of these modes shares (ln_row8, common.h; lg / lb folded above)
@@ -106,7 +106,7 @@ __device__ __forceinline__ void conv_epilogue_in8(const ConvArgs& p, f32x16 (&ac
             o[e] = (p.ln_mode == 2) ? silu_fast(u) : u;
           }
         }
-        Oct<TOut>::store(ng + orow * p.ldn + 8 * oct_j, o);
+        Oct<TOut>::store(ng + orow * p.ldn + 8 * oct_j, o, p.nt_store != 0);
       }
     }
   });

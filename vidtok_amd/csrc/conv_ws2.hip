@@ -60,6 +60,16 @@ namespace {
 [[maybe_unused]] constexpr int W2_OFF_R = W2_OFF_T + 2 * W2_TBUF;
 [[maybe_unused]] constexpr int W2_OFF_PRM = W2_OFF_R + 2 * W2_RBUF;    // 159 744: LayerNorm gamma | beta | bias, 3 x 128 fp32
 [[maybe_unused]] constexpr int W2_LDS = W2_OFF_PRM + 3 * 128 * 4;      // 161 280
+#ifndef VT_W2_HEAD_PRIO
+#define VT_W2_HEAD_PRIO 0
+#endif
+// MFMAs of group 0's phase that run in front of the end-of-iteration barrier (even, 2 .. 70): what fits beside group 1's phase without
+// lengthening it -- the window in which group 1 hands over its sums, less what group 0's own rows take (profiles/r06_ws2_split_phase.txt)
+#ifdef VT_W2_HEAD
+template <int LN, bool KEEP> [[maybe_unused]] constexpr int w2_head = VT_W2_HEAD;
+#else
+template <int LN, bool KEEP> [[maybe_unused]] constexpr int w2_head = LN == 0 ? 24 : (KEEP ? 8 : 16);
+#endif
 [[maybe_unused]] constexpr int W2_FD = 6;                               // fragment prefetch distance of an MFMA phase, in MFMAs
 [[maybe_unused]] constexpr int W2_PSLOTS = 8, W2_RSLOTS = 5;           // DMA pieces per wave of group 1: patch pieces w + 4 q (< 29), residual pieces w + 4 q (< 17)
 
@@ -345,45 +355,50 @@ __global__ __launch_bounds__(512, 1) void conv3x3_ws2_kernel(const ConvArgs p) {
     return W2_OFF_T + par * W2_TBUF + l31 * 512 + (((cw * 8 + (l >> 5)) ^ l31) << 4);
   };
   auto t_slot = [&](int tb, int jj, int g) -> float* { return reinterpret_cast<float*>(smem + ((tb ^ (g << 5)) + jj * (32 * 512))); };
-  auto mfma_phase = [&](auto kh_c, int u) {
-    constexpr int KH = decltype(kh_c)::value;
-    const int tb = t_base(u & 1);
-    if constexpr (KH == 1) {                                   // continue the sum of K-half 0
-#pragma unroll
-      for (int jj = 0; jj < 2; ++jj)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const f32x4 v = *reinterpret_cast<const f32x4*>(t_slot(tb, jj, g));
-#pragma unroll
-          for (int e = 0; e < 4; ++e) acc[jj][4 * g + e] = v[e];
-        }
-    }
+  // Group 0's phase is split across the end-of-iteration barrier (round 6): MFMAs [0, w2_head) of M0(u+1) run at the tail of group 0's row
+  // half of iteration u -- beside group 1's M1(u), the matrix pipe shared -- and MFMAs [w2_head, 72) + the hand-over of the sums in the first
+  // half of iteration u+1, beside group 1's rows.  Before, the two groups' MFMA phases were strictly serial (each 2 440 cycles of MFMAs inside
+  // ~3 600 of fragments-in / sums-out / barrier: the matrix pipe idled a third of every iteration while group 0 waited ~2 800 cycles at the
+  // barrier, profiles/r04_ws2_iteration_cycles.txt).  The fragment ring and the accumulators stay in registers across the barrier; group 1
+  // awaits its patch requests at the end of its row half, so that the mid barrier publishes patch(u+1) for the head.  An output's fp32 chain
+  // is unchanged (K groups in order): the same bits.
+  u32x4 xf[W2_FD + 1];
+  auto frag_base = [&](int u) -> const char* {
     int f_rsel, f_col, lo = lane;
     asm volatile("" : "+v"(lo));
     subtile_pixel(lo & 31, f_rsel, f_col);
     const int frag_off = (f_rsel * W2_PW + f_col) * W2_ROWP + (lo >> 5) * 16;
-    const char* pb = smem + (u & 1) * W2_PATCH + frag_off;
-    auto frag_addr = [&](int m) -> const u32x4* {              // MFMA m = 2 g + jj of the phase
-      const int gg = 36 * KH + (m >> 1), jj = m & 1;
-      const int tap = gg >> 3, c = gg & 7;
-      const int kh = tap / 3, kw = tap - 3 * kh;
-      return reinterpret_cast<const u32x4*>(pb + ((2 * jj + kh) * W2_PW + kw) * W2_ROWP + c * 32);
-    };
-    // fragment ring: a read is requested W2_FD MFMAs (~200 cycles) ahead of its use -- three ahead (~100 cycles) left every
-    // MFMA waiting for the LDS: 51 cycles per MFMA instead of ~36 (profiles/r03_ws2_iteration_cycles.txt, first measurement)
-    u32x4 xf[W2_FD + 1];
+    return smem + (u & 1) * W2_PATCH + frag_off;
+  };
+  auto frag_ptr = [&](auto kh_c, const char* pb, int m) -> const u32x4* {     // MFMA m = 2 g + jj of the phase
+    constexpr int KH = decltype(kh_c)::value;
+    const int gg = 36 * KH + (m >> 1), jj = m & 1;
+    const int tap = gg >> 3, c = gg & 7;
+    const int kh = tap / 3, kw = tap - 3 * kh;
+    return reinterpret_cast<const u32x4*>(pb + ((2 * jj + kh) * W2_PW + kw) * W2_ROWP + c * 32);
+  };
+  // MFMAs [M0, M1) of the phase of K-half KH on tile u; the ring holds the fragments of [M0, M0 + W2_FD) on entry when M0 > 0
+  auto mfma_run = [&](auto kh_c, auto m0_c, auto m1_c, auto prio_c, int u) {
+    constexpr int KH = decltype(kh_c)::value, M0 = decltype(m0_c)::value, M1 = decltype(m1_c)::value, PRIO = decltype(prio_c)::value;
+    const char* pb = frag_base(u);
+    if constexpr (M0 == 0) {
+      // fragment ring: a read is requested W2_FD MFMAs (~200 cycles) ahead of its use -- three ahead (~100 cycles) left every
+      // MFMA waiting for the LDS: 51 cycles per MFMA instead of ~36 (profiles/r03_ws2_iteration_cycles.txt, first measurement)
 #pragma unroll
-    for (int m = 0; m < W2_FD; ++m) xf[m] = *frag_addr(m);
-    stamp(5);
-    __builtin_amdgcn_s_setprio(1);
-    w2_static_for<0, 72>([&](auto mc) {
+      for (int m = 0; m < W2_FD; ++m) xf[m] = *frag_ptr(kh_c, pb, m);
+      stamp(5);
+    }
+    __builtin_amdgcn_s_setprio(PRIO);
+    w2_static_for<M0, M1>([&](auto mc) {
       constexpr int m = decltype(mc)::value;
       w2_mfma<H, (KH == 0 && m < 2), ((m >> 1) < W2_WA)>(wreg[m >> 1], xf[m % (W2_FD + 1)], acc[m & 1]);
-      if constexpr (m + W2_FD < 72) xf[(m + W2_FD) % (W2_FD + 1)] = *frag_addr(m + W2_FD);
+      if constexpr (m + W2_FD < 72) xf[(m + W2_FD) % (W2_FD + 1)] = *frag_ptr(kh_c, pb, m + W2_FD);
       __builtin_amdgcn_sched_barrier(0);
     });
     __builtin_amdgcn_s_setprio(0);
-    stamp(6);
+  };
+  auto sums_out = [&](int u) {
+    const int tb = t_base(u & 1);
     asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");         // last MFMA -> first reader of its accumulator
 #pragma unroll
     for (int jj = 0; jj < 2; ++jj)
@@ -394,6 +409,33 @@ __global__ __launch_bounds__(512, 1) void conv3x3_ws2_kernel(const ConvArgs p) {
         for (int e = 0; e < 4; ++e) v[e] = acc[jj][4 * g + e];
         *reinterpret_cast<f32x4*>(t_slot(tb, jj, g)) = v;
       }
+  };
+  using W2K0 = std::integral_constant<int, 0>;
+  using W2K1 = std::integral_constant<int, 1>;
+  using W2M0 = std::integral_constant<int, 0>;
+  using W2MH = std::integral_constant<int, w2_head<LN, KEEP>>;
+  using W2ME = std::integral_constant<int, 72>;
+  // issue priorities: the head runs beside group 1's whole phase and must not delay it (that phase and group 1's rows are the iteration's
+  // critical chain) -- it takes the matrix pipe while group 1 restores / hands over its sums and otherwise what is left
+  auto m0_head = [&](int u) { mfma_run(W2K0{}, W2M0{}, W2MH{}, std::integral_constant<int, VT_W2_HEAD_PRIO>{}, u); };
+  auto m0_tail = [&](int u) {
+    mfma_run(W2K0{}, W2MH{}, W2ME{}, std::integral_constant<int, 1>{}, u);
+    stamp(6);
+    sums_out(u);
+  };
+  auto m1_phase = [&](int u) {
+    const int tb = t_base(u & 1);
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj)                               // continue the sum of K-half 0
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(t_slot(tb, jj, g));
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[jj][4 * g + e] = v[e];
+      }
+    mfma_run(W2K1{}, W2M0{}, W2ME{}, std::integral_constant<int, 2>{}, u);
+    stamp(6);
+    sums_out(u);
   };
   auto publish = [&]() {                                       // my LDS writes are retired, then the barrier hands the buffers over
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -409,31 +451,25 @@ __global__ __launch_bounds__(512, 1) void conv3x3_ws2_kernel(const ConvArgs p) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   publish();
   constexpr int NS = 2 * ((KEEP ? 1 : 0) + (LN != 0 ? 1 : 0));  // stores of a row slot
-  // iteration u: M phases of tile u, rows of tile u-1; group 1 requests patch(u+1), group 0 the residual rows of tile u
-  for (int u = 0; u <= U; ++u) {
-    if constexpr (PROF) prof_u = (blockIdx.x == 0 && (u == 8 || u == 9)) ? u - 8 : -1;
-    stamp(0);
-    // ---- first half: group 0 M0(u) | group 1: requests, rows [0,32) of tile u-1
-    if (grp == 0) {
-      if (u < U) mfma_phase(std::integral_constant<int, 0>{}, u);
-    } else {
-      // patch(u+1) goes where patch(u-1) was (read for the last time in iteration u-1); needed in iteration u+1, awaited
-      // at the end of my MFMA phase below
-      if (u < U) issue_dma(c_next, (u + 1) & 1, c_next, 0, u + 1 < U, false);
-      __builtin_amdgcn_sched_barrier(0);                       // the counted waits below rely on "requests, then stores" in issue order
-      if (u >= 1) row_slot(c_prev, (u - 1) & 1, 0);
-    }
-    stamp(1);
-    publish();
-    stamp(2);
-    // ---- second half: group 1 M1(u) | group 0 rows [32,64) of tile u-1
-    if (grp == 1) {
-      if (u < U) mfma_phase(std::integral_constant<int, 1>{}, u);
-      stamp(7);
-      // my requests of this iteration have landed once only the stores I issued behind them are outstanding
-      if (u >= 1) wait_vmcnt<NS>();
-      else wait_vmcnt<0>();
-    } else {
+  // iteration u: M phases of tile u (group 0's head ran in iteration u-1), rows of tile u-1; group 1 requests patch(u+1), group 0 the
+  // residual rows of tile u.  One loop per group (the same two barriers an iteration in both): in a common loop the accumulators and the
+  // fragment ring that group 0 carries across the back edge were live in group 1's row half as well, and 40 registers spilled.
+  auto advance = [&]() {
+    c_prev = c_cur;
+    c_cur = c_next;
+    cur_step(c_next);
+  };
+  if (grp == 0) {
+    m0_head(0);
+    for (int u = 0; u <= U; ++u) {
+      if constexpr (PROF) prof_u = (blockIdx.x == 0 && (u == 8 || u == 9)) ? u - 8 : -1;
+      stamp(0);
+      // ---- first half: the rest of M0(u), sums -> LDS   (group 1: requests, rows [0,32) of tile u-1)
+      if (u < U) m0_tail(u);
+      stamp(1);
+      publish();
+      stamp(2);
+      // ---- second half: rows [32,64) of tile u-1, head of M0(u+1)   (group 1: M1(u))
       // the residual rows of tile u go where those of tile u-2 were (read for the last time in iteration u-1); needed in
       // iteration u+1.  Requested ahead of my rows and stores, awaited behind them with the stores left outstanding.  (The
       // rows of the first tile came with the prologue.)
@@ -444,13 +480,36 @@ __global__ __launch_bounds__(512, 1) void conv3x3_ws2_kernel(const ConvArgs p) {
         __builtin_amdgcn_sched_barrier(0);
         wait_vmcnt<NS>();
       }
+      if (u + 1 < U) m0_head(u + 1);
+      stamp(3);
+      publish();
+      stamp(4);
+      advance();
     }
-    stamp(3);
-    publish();
-    stamp(4);
-    c_prev = c_cur;
-    c_cur = c_next;
-    cur_step(c_next);
+  } else {
+    for (int u = 0; u <= U; ++u) {
+      if constexpr (PROF) prof_u = (blockIdx.x == 0 && (u == 8 || u == 9)) ? u - 8 : -1;
+      stamp(0);
+      // ---- first half: requests, rows [0,32) of tile u-1   (group 0: the rest of M0(u))
+      // patch(u+1) goes where patch(u-1) was (read for the last time in iteration u-1); group 0 starts on it in the second half, so the
+      // requests are awaited HERE, behind my rows: they have landed once only the stores I issued behind them are outstanding
+      if (u < U) issue_dma(c_next, (u + 1) & 1, c_next, 0, u + 1 < U, false);
+      __builtin_amdgcn_sched_barrier(0);                       // the counted waits below rely on "requests, then stores" in issue order
+      if (u >= 1) row_slot(c_prev, (u - 1) & 1, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (u >= 1) wait_vmcnt<NS>();
+      else wait_vmcnt<0>();
+      stamp(1);
+      publish();
+      stamp(2);
+      // ---- second half: M1(u)   (group 0: rows [32,64) of tile u-1, head of M0(u+1))
+      if (u < U) m1_phase(u);
+      stamp(7);
+      stamp(3);
+      publish();
+      stamp(4);
+      advance();
+    }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif

@@ -22,7 +22,7 @@ const OptDef kDefs[OPT_COUNT] = {
     {"conv_narrow", 1},     {"conv_tile", 0},       {"conv_tile_min", 128},  {"conv_fuse_ln", 1}, {"conv_fuse_ln256", 1},
     {"tblock_fused", 1},    {"tblock_prof_mode", 0},
     {"conv_deep", 1},       {"ws_prof_mode", 0},    {"attn_flash", 1},      {"conv_splitk", 1},
-    {"conv_tskip", 1},      {"conv_in8", 1},        {"conv_tup_ln", 1},
+    {"conv_tskip", 1},      {"conv_in8", 1},        {"conv_tup_ln", 1},     {"conv_nt_mb", 64},
 };
 std::atomic<int> g_val[OPT_COUNT];
 std::once_flag g_once;
