@@ -41,9 +41,10 @@ def main():
             for wv in range(8):
                 for it in range(2):
                     t = [int(s[wv, 8 * it + k]) for k in range(8)]
-                    if wv < 4:     # group 0: stamps 0 [first fragments] 5 [72 MFMAs] 6 [T writes] 1 [barrier] 2 [requests + rows] 3 [barrier] 4
-                        seg = [("first fragments", t[5] - t[0]), ("72 MFMAs", t[6] - t[5]), ("partial sums -> LDS", t[1] - t[6]), ("barrier", t[2] - t[1]),
-                               ("requests + rows [32,64) + wait", t[3] - t[2]), ("barrier", t[4] - t[3])]
+                    if wv < 4:     # group 0 (split phase, round 6): stamps 0 [tail MFMAs] 6 [P writes] 1 [barrier] 2 [requests + rows + head's fragments] 5 [head MFMAs] 3 [barrier] 4
+                        seg = [("tail MFMAs", t[6] - t[0]), ("partial sums -> LDS", t[1] - t[6]), ("barrier", t[2] - t[1]),
+                               ("requests + rows [32,64) + wait + first fragments of the next tile", t[5] - t[2]), ("head MFMAs (beside group 1's phase)", t[3] - t[5]),
+                               ("barrier", t[4] - t[3])]
                     else:          # group 1: 0 [requests + rows] 1 [barrier] 2 [partial sums + fragments] 5 [72 MFMAs] 6 [T writes] 7 [wait] 3 [barrier] 4
                         seg = [("requests + rows [0,32)", t[1] - t[0]), ("barrier", t[2] - t[1]), ("partial sums <- LDS + first fragments", t[5] - t[2]),
                                ("72 MFMAs", t[6] - t[5]), ("sums -> LDS", t[7] - t[6]), ("wait for my requests", t[3] - t[7]), ("barrier", t[4] - t[3])]

@@ -15,9 +15,11 @@
 //     M1(u): group 1 (kh = 1): accumulators <- P(u), 72 MFMAs over K-half 1     -> T(u), in place over P(u)
 //     R(u):  rows of T(u) + bias + residual -> y, LayerNorm(+SiLU) -> n; rows [0,32) by group 1, rows [32,64) by group 0
 // and the two groups alternate, one barrier per half-step, so that a SIMD always has one wave in an MFMA phase and one in
-// a row slot (plain-fp32 VALU work of a wave overlaps the other wave's MFMAs):
-//     iteration u, first half:    group 0: M0(u)                 |  group 1: request patch(u+1), R(u-1) rows [0,32)
-//     iteration u, second half:   group 1: M1(u)                 |  group 0: request residual(u), R(u-1) rows [32,64)
+// a row slot (plain-fp32 VALU work of a wave overlaps the other wave's MFMAs).  Since round 6 group 0's phase straddles the
+// end-of-iteration barrier: its first w2_head MFMAs ("head", issue priority 0) run beside group 1's phase, in the window in which
+// group 1 hands over its sums; the rest ("tail") and the hand-over of P beside group 1's rows:
+//     iteration u, first half:    group 0: tail of M0(u), P(u) -> LDS           |  group 1: request patch(u+1), R(u-1) rows [0,32), await the patch
+//     iteration u, second half:   group 1: M1(u) (priority 2)                   |  group 0: request residual(u), R(u-1) rows [32,64), head of M0(u+1)
 // The fp32 sum of an output element is the same chain as in the first generation (K groups 0..35 from zero, then 36..71
 // on top) and the row arithmetic is the same, so results are bit-identical to conv_ws128.hip (and, without LayerNorm,
 // to the tile-per-workgroup kernel).
@@ -41,9 +43,7 @@
 
 #include "conv_select.h"
 
-#ifndef VT_STORE_AUX
-#define VT_STORE_AUX 2      // cache policy bits of the y / n stores (A/B aid; 2 = nt)
-#endif
+#define VT_STORE_AUX 2      // cache policy bits of the y / n stores: nt (streaming; - 0.6 ... - 2.7 % per launch, profiles/r06_c128_kernel_variants.txt)
 
 namespace {
 
@@ -60,16 +60,9 @@ namespace {
 [[maybe_unused]] constexpr int W2_OFF_R = W2_OFF_T + 2 * W2_TBUF;
 [[maybe_unused]] constexpr int W2_OFF_PRM = W2_OFF_R + 2 * W2_RBUF;    // 159 744: LayerNorm gamma | beta | bias, 3 x 128 fp32
 [[maybe_unused]] constexpr int W2_LDS = W2_OFF_PRM + 3 * 128 * 4;      // 161 280
-#ifndef VT_W2_HEAD_PRIO
-#define VT_W2_HEAD_PRIO 0
-#endif
 // MFMAs of group 0's phase that run in front of the end-of-iteration barrier (even, 2 .. 70): what fits beside group 1's phase without
 // lengthening it -- the window in which group 1 hands over its sums, less what group 0's own rows take (profiles/r06_ws2_split_phase.txt)
-#ifdef VT_W2_HEAD
-template <int LN, bool KEEP> [[maybe_unused]] constexpr int w2_head = VT_W2_HEAD;
-#else
 template <int LN, bool KEEP> [[maybe_unused]] constexpr int w2_head = LN == 0 ? 24 : (KEEP ? 8 : 16);
-#endif
 [[maybe_unused]] constexpr int W2_FD = 6;                               // fragment prefetch distance of an MFMA phase, in MFMAs
 [[maybe_unused]] constexpr int W2_PSLOTS = 8, W2_RSLOTS = 5;           // DMA pieces per wave of group 1: patch pieces w + 4 q (< 29), residual pieces w + 4 q (< 17)
 
@@ -417,7 +410,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_ws2_kernel(const ConvArgs p) {
   using W2ME = std::integral_constant<int, 72>;
   // issue priorities: the head runs beside group 1's whole phase and must not delay it (that phase and group 1's rows are the iteration's
   // critical chain) -- it takes the matrix pipe while group 1 restores / hands over its sums and otherwise what is left
-  auto m0_head = [&](int u) { mfma_run(W2K0{}, W2M0{}, W2MH{}, std::integral_constant<int, VT_W2_HEAD_PRIO>{}, u); };
+  auto m0_head = [&](int u) { mfma_run(W2K0{}, W2M0{}, W2MH{}, std::integral_constant<int, 0>{}, u); };
   auto m0_tail = [&](int u) {
     mfma_run(W2K0{}, W2MH{}, W2ME{}, std::integral_constant<int, 1>{}, u);
     stamp(6);

@@ -27,9 +27,9 @@
 
 #include "conv_common.h"
 
-#ifndef VT_STORE_AUX
-#define VT_STORE_AUX 2      // cache policy bits of the y / n stores (A/B aid; 2 = nt)
-#endif
+// cache policy bits of the y / n stores: nt (streaming).  The rows are read next by another launch, long after they have left every cache;
+// stored plainly they displace x rows the O units read again two steps later (1.62 -> 1.58 ms per launch, profiles/r06_c128_kernel_variants.txt)
+#define VT_STORE_AUX 2
 
 namespace {
 
@@ -123,10 +123,11 @@ __device__ __forceinline__ u32x4 t3_pack8(const float (&o)[8]) {
 //     phase A_k:   group 0: G1(k)                                  | group 1: T2 <- acc2(k-2), L2(k-1) (4 row units)
 //     phase B_k:   group 0: T1 <- acc1(k), O(k-2) (4 units), L1(k+1) unit 0 | group 1: G2(k-1), L1(k+1) units 1-3
 // (row unit = 16 pixel rows x 128 channels on a group's 256 threads).  Buffers and their hand-over are those of the
-// two-role kernel: written in one phase, read in a later one, one barrier per phase.  Group 1 never stores to memory,
-// so its loads (x rows of its L1 units, requested a step ahead) never queue behind stores; group 0 requests its x rows
-// (O's residual, its L1 unit) at the top of phase B in front of that phase's stores, into the register set the phase
-// does not use -- the same two-set, two-body arrangement as above.
+// two-role kernel: written in one phase, read in a later one, one barrier per phase.  The x rows a unit needs (an L1 unit: the rows of
+// step k + 1; an O unit: those of step k - 2, its residual) are requested a whole step ahead into ONE register set, each request right behind
+// the unit that consumed the register's previous contents (round 6; rounds 3-5 kept two sets and two loop bodies and requested at the top of
+// phase B: 40 registers of x rows in group 0, the allocator at 254 / 256).  The middle steps run in a loop of their own that is entered behind
+// a real vmcnt(0), so the compiler's counted waits in front of the units leave the step's stores in flight (see the loops below).
 // The LayerNorm affines and the biases live in the LDS (4 KiB; a unit reads what it needs: two ds_read_b128 an array),
 // all addressing is 32-bit through buffer descriptors rebased to the frame, the (column, frame) of a virtual step is
 // carried by additions.  Row arithmetic: plain fp32, element order of the two-role kernel (L1 sums the even and the odd
@@ -135,10 +136,7 @@ __device__ __forceinline__ u32x4 t3_pack8(const float (&o)[8]) {
 // ---------------------------------------------------------------------------------------------------------------------
 [[maybe_unused]] constexpr int T4_OFF_PRM = T3_LDS;                       // g1 | be1 | g2 | be2 | gn | ben | b1 | b2, 128 fp32 each
 [[maybe_unused]] constexpr int T4_LDS = T4_OFF_PRM + 8 * 128 * 4;         // 157 696
-#ifndef VT_T4_FD
-#define VT_T4_FD 6
-#endif
-[[maybe_unused]] constexpr int T4_FD = VT_T4_FD;                          // fragment prefetch distance of a GEMM, in MFMAs
+[[maybe_unused]] constexpr int T4_FD = 6;                                 // fragment prefetch distance of a GEMM, in MFMAs
 
 template <typename H, bool FIRST>
 __device__ __forceinline__ void t4_mfma(const u32x4& w, const u32x4& x, f32x16& acc) {
@@ -177,12 +175,10 @@ __global__ __launch_bounds__(512, 1) void tblock_pair_kernel(const TBlockArgs p)
   const int c_begin = slot_id * cq + min(slot_id, cr);
   const int c_end = c_begin + cq + (slot_id < cr ? 1 : 0);
   if (c_begin >= c_end) return;
-#ifdef VT_TB_STAGGER                                                  // A/B aid: every other workgroup starts half a step late (do the CUs' store bursts collide?)
-  if (blockIdx.x & 8) {
-    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
-    while ((long long)(__builtin_amdgcn_s_memtime() - t0) < VT_TB_STAGGER) __builtin_amdgcn_s_sleep(32);
-  }
-#endif
+  // Issue priority: group 1 is the step's critical path in both phases (T2 + three L2 units beside G1; G2 + two O units beside group 0's
+  // rows -- group 0 waits ~600 + ~1 700 cycles a step at the two barriers, profiles/r06_tblock_pair_phase_cycles.txt), so its instructions
+  // win the arbitration throughout (2, its GEMM 3); group 0 stays at 0, its GEMM included.  1.64 -> 1.61 ms per launch.
+  if (grp == 1) __builtin_amdgcn_s_setprio(2);
   const int n = (c_end - c_begin) * p.T;                             // virtual steps of this workgroup
   constexpr int R1 = 0, R2 = TB_RING;                                // ring offsets in the LDS
   const unsigned frame_bytes = (unsigned)p.HW * 256u;
@@ -288,14 +284,14 @@ __global__ __launch_bounds__(512, 1) void tblock_pair_kernel(const TBlockArgs p)
     u32x4 xf[T4_FD + 1];
 #pragma unroll
     for (int m = M0; m < M0 + T4_FD; ++m) xf[m % (T4_FD + 1)] = *faddr(m);
-    __builtin_amdgcn_s_setprio(1);
+    if (grp == 1) __builtin_amdgcn_s_setprio(3);
     tb_static_for<M0, 48>([&](auto mc) __attribute__((always_inline)) {
       constexpr int m = decltype(mc)::value;
       t4_mfma<H, (m < M0 + 2)>(wreg[m >> 1], xf[m % (T4_FD + 1)], acc[m & 1]);
       if constexpr (m + T4_FD < 48) xf[(m + T4_FD) % (T4_FD + 1)] = *faddr(m + T4_FD);
       __builtin_amdgcn_sched_barrier(0);
     });
-    __builtin_amdgcn_s_setprio(0);
+    if (grp == 1) __builtin_amdgcn_s_setprio(2);
     asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");             // last MFMA -> first VALU reader of its accumulator
   };
   auto run_gemm = [&](int roff, int s3, int t) __attribute__((always_inline)) {
@@ -433,20 +429,22 @@ __global__ __launch_bounds__(512, 1) void tblock_pair_kernel(const TBlockArgs p)
   Cur c_p2 = cur_at(0);          // cursors of virtual steps k + 2, k + 1, k, k - 1, k - 2 (valid where those steps exist)
   Cur c_p1 = c_p2, c_0 = c_p2, c_m1 = c_p2, c_m2 = c_p2;
   __syncthreads();               // parameters are in the LDS
+  constexpr int L1G0 = 3;                                            // L1 units [0, L1G0) belong to group 0, the rest to group 1 (4 : 0 measured the same)
+  using IL = std::integral_constant<int, L1G0>;
   if (grp == 0) {
-    load_rows(std::integral_constant<int, 0>{}, std::integral_constant<int, 3>{}, xs.xn, c_0);
-    ln1_units(std::integral_constant<int, 0>{}, std::integral_constant<int, 3>{}, xs.xn, 0, c_0);
+    load_rows(std::integral_constant<int, 0>{}, IL{}, xs.xn, c_0);
+    ln1_units(std::integral_constant<int, 0>{}, IL{}, xs.xn, 0, c_0);
   } else {
-    load_rows(std::integral_constant<int, 3>{}, std::integral_constant<int, 4>{}, xs.xn, c_0);
-    ln1_units(std::integral_constant<int, 3>{}, std::integral_constant<int, 4>{}, xs.xn, 0, c_0);
+    load_rows(IL{}, std::integral_constant<int, 4>{}, xs.xn, c_0);
+    ln1_units(IL{}, std::integral_constant<int, 4>{}, xs.xn, 0, c_0);
     if (CACHE && p.replicate == 2) cache_get(p.cache1, R1, c_0, 1, 2);         // frames -2, -1 of the first column: slots (-2) % 3, (-1) % 3
   }
   cur_step(c_p1);
   c_p2 = c_p1;
   cur_step(c_p2);
   if (1 < n) {
-    if (grp == 0) load_rows(std::integral_constant<int, 0>{}, std::integral_constant<int, 3>{}, xs.xn, c_p1);
-    else load_rows(std::integral_constant<int, 3>{}, std::integral_constant<int, 4>{}, xs.xn, c_p1);
+    if (grp == 0) load_rows(std::integral_constant<int, 0>{}, IL{}, xs.xn, c_p1);
+    else load_rows(IL{}, std::integral_constant<int, 4>{}, xs.xn, c_p1);
   }
   // every register of the set is defined before the loop (guarded steps skip loads, not uses); a group touches only
   // its own units: group 0 xn[0..2] and xr[0..1], group 1 xn[3] and xr[2..3]
@@ -570,8 +568,8 @@ __global__ __launch_bounds__(512, 1) void tblock_pair_kernel(const TBlockArgs p)
       if (do_o) o_unit(I1{}, xs.xr[1], c_m2);
       if (ld_r) load_rows(I1{}, I2{}, xs.xr, c_m1);
       stamp(4);
-      if (do_l1) ln1_units(I1{}, I3{}, xs.xn, slot_back(2), c_p1);
-      if (ld_n) load_rows(I1{}, I3{}, xs.xn, c_p2);
+      if (do_l1) ln1_units(I1{}, IL{}, xs.xn, slot_back(2), c_p1);
+      if (ld_n) load_rows(I1{}, IL{}, xs.xn, c_p2);
       stamp(5);
       __syncthreads();
       stamp(6);
@@ -610,8 +608,8 @@ __global__ __launch_bounds__(512, 1) void tblock_pair_kernel(const TBlockArgs p)
       if (do_o) o_unit(I2{}, xs.xr[2], c_m2);
       if (ld_r) load_rows(I2{}, I3{}, xs.xr, c_m1);
       stamp(4);
-      if (do_l1) ln1_units(I3{}, I4{}, xs.xn, slot_back(2), c_p1);
-      if (ld_n) load_rows(I3{}, I4{}, xs.xn, c_p2);
+      if (do_l1) ln1_units(IL{}, I4{}, xs.xn, slot_back(2), c_p1);
+      if (ld_n) load_rows(IL{}, I4{}, xs.xn, c_p2);
       if (do_o) o_unit(I3{}, xs.xr[3], c_m2);
       if (ld_r) load_rows(I3{}, I4{}, xs.xr, c_m1);
       // step k+1 opens a column: conv1's cached frames -2, -1 go into ring1 slots (k-1) % 3, k % 3 -- read for the last time
