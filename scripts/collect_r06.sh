@@ -12,11 +12,7 @@ timeout 300 python bench.py --steps 10 --warmup 3 --breakdown --no-cpu-baseline 
 timeout 400 python bench.py --dtype fp32 --steps 10 --warmup 3 --breakdown --no-cpu-baseline --traffic none --no-extras > $O/${P}_bench_fp32.json 2> $O/${P}_bench_fp32_conv_breakdown.txt; echo "fp32 rc=$?"; cut -c1-200 $O/${P}_bench_fp32.json
 timeout 600 python bench.py --dtype bf16x3 --steps 10 --warmup 3 --breakdown --no-cpu-baseline --no-extras > $O/${P}_bench_bf16x3.json 2> $O/${P}_bench_bf16x3_conv_breakdown.txt; echo "bf16x3 rc=$?"; cut -c1-200 $O/${P}_bench_bf16x3.json
 timeout 400 python bench.py --dtype fp16 --steps 20 --warmup 5 --breakdown --no-cpu-baseline --no-extras > $O/${P}_bench_fp16.json 2> $O/${P}_bench_fp16_conv_breakdown.txt; echo "fp16 rc=$?"; cut -c1-200 $O/${P}_bench_fp16.json
-# the activation side of the traffic question -- times, then the same process under the profiler for the shader clock of every arm
-timeout 300 python scripts/activation_restream_ab.py 10 > $O/${P}_activation_restream_ab.txt 2>&1; echo "restream A/B rc=$?"; cat $O/${P}_activation_restream_ab.txt
-(cd /tmp && timeout 400 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE --output-format csv -d $R/$O/${P}_ab_clock -o p -- python $R/scripts/activation_restream_ab.py 10 > $R/$O/${P}_ab_clock.log 2>&1); echo "restream clock rc=$?"
-python scripts/ab_clock_summary.py $O/${P}_ab_clock 10 >> $O/${P}_activation_restream_ab.txt 2>&1; tail -20 $O/${P}_activation_restream_ab.txt
-rm -rf $O/${P}_ab_clock/*/*.db
+# (the activation restream A/B of VERDICT r5 #4: scripts/r6_gpu_c.sh -> profiles/r06_activation_restream_ab.txt)
 (cd /tmp && timeout 400 rocprofv3 --kernel-trace --stats -d $R/$O/${P}_prof -o bench -- python $R/bench.py --steps 3 --warmup 3 --no-cpu-baseline --traffic none --no-extras > $R/$O/${P}_prof.log 2>&1); echo "rocprof rc=$?"
 DB=$(find $O/${P}_prof -name "*.db" | head -1); rm -f $O/${P}_bench_bf16_kernel_stats.md; python scripts/rocprof_summary.py "$DB" $O/${P}_bench_bf16_kernel_stats.md; head -30 $O/${P}_bench_bf16_kernel_stats.md | cut -c1-170
 rm -rf $O/${P}_prof
@@ -33,5 +29,7 @@ done
 cd $R
 python scripts/pmc_summary.py $O/${P}_sq > $O/${P}_bench_bf16_sq_pmc.txt 2>&1; head -30 $O/${P}_bench_bf16_sq_pmc.txt
 timeout 200 python scripts/tblock_profile.py > $O/${P}_tblock_pair_phase_cycles.txt 2>&1; grep "per launch" $O/${P}_tblock_pair_phase_cycles.txt
+timeout 200 python scripts/ws2_profile.py > $O/${P}_ws2_iteration_cycles.txt 2>&1; head -4 $O/${P}_ws2_iteration_cycles.txt | cut -c1-200
+timeout 120 python scripts/c128_time.py bf16 > $O/${P}_c128_time.txt 2>&1; timeout 120 python scripts/c128_time.py f16 >> $O/${P}_c128_time.txt 2>&1; cat $O/${P}_c128_time.txt
 timeout 900 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | grep -v amdgpu.ids > $O/${P}_smoke.log; tail -14 $O/${P}_smoke.log
 rm -rf $O/${P}_pmc_traffic/*/*.db $O/${P}_sq/*/*.db
