@@ -194,7 +194,7 @@ def mode_measurements(model, x, main_mode, seed=77):
 
 def other_config_measurements(dev, x):
     """rank 0, N = 1: the BASELINE.json configurations that are not the bench line -- configs[2] (vidtok_fsq_causal_488_32768,
-    B=4 17x256x256: frames/s in bf16 and bf16x3, FSQ integer codes of those modes against the fp32 kernels', which
+    B=4 17x256x256: frames/s in bf16, fp16 and bf16x3, FSQ integer codes of those modes against the fp32 kernels', which
     reproduce the CPU oracle's codes exactly in the GPU tests and in smoke()) and configs[4] (vidtok_kl_causal_488_16chn_v1_1,
     one clip of 129x256x256, t_chunk_enc = 16 tiling with decoder look-ahead, bf16; chunks replayed from the graph cache)."""
     import vidtok_amd
@@ -223,7 +223,7 @@ def other_config_measurements(dev, x):
     from util import fsq_mismatch_report       # checker (test infrastructure): which codes differ and how close to a rounding boundary
 
     levels = m.regularization.levels
-    for mode in ("fp32", "bf16x3", "bf16"):
+    for mode in ("fp32", "bf16x3", "bf16", "fp16"):
         m.set_compute_dtype(MODES[mode])
         m.enable_graphs(False)
         hs[mode] = m._run_encoder(x)            # the pre-quantisation latent

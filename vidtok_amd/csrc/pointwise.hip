@@ -306,32 +306,40 @@ __global__ __launch_bounds__(kBlock) void time_avgpool3s2_kernel(const T* __rest
 // The sequence that is interpolated is [h (nh frames) | x (Tx frames)] per clip -- nh = 0: x alone -- and the first `skip`
 // of its 2 (nh + Tx) output frames are not produced (v1.1 chunks after the first: h = the cached frames of the previous
 // chunk, whose part of the output the previous chunk already delivered; model_3dcausal_v1_1.py:327-341).
+// One output frame per blockIdx.y (round 6): the source frames and weights are scalar work done once per workgroup, a thread moves 16 bytes of
+// the 16-bit types (two quads through the same load4 / store4 arithmetic, so the bits are those of the element-indexed first version, whose 64-bit
+// divisions per quad held it at 0.6 TB/s: 330 us for the 8 frames of a 256 x 256 x 128 chunk, 13 ms of a four-pass tiled run, profiles/r05_tiled_kernel_stats.md)
 template <typename T>
 __global__ __launch_bounds__(kBlock) void time_lerp2x_kernel(const T* __restrict__ h, int nh, const T* __restrict__ x, T* __restrict__ y,
                                                              int B, int Tx, int skip, long long F4) {
+  constexpr int Q = sizeof(T) == 2 ? 2 : 1;                // quads per thread and iteration
   const int Ti = nh + Tx;
   const int To = 2 * Ti - skip;
-  const long long n = (long long)B * To * F4;
-  for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < n; i += (long long)gridDim.x * kBlock) {
-    const long long f = i % F4;
-    long long r = i / F4;
-    const int j = (int)(r % To) + skip;
-    const int b = (int)(r / To);
-    // align_corners=False source coordinate, scale 1/2:  src = (j + 0.5) * 0.5 - 0.5, clamped at 0
-    float src = ((float)j + 0.5f) * 0.5f - 0.5f;
-    if (src < 0.f) src = 0.f;
-    const int t0 = (int)src;
-    const int t1 = t0 + (t0 < Ti - 1 ? 1 : 0);
-    const float l1 = src - (float)t0;
-    const float l0 = 1.0f - l1;
-    float a[4], c[4], o[4];
-    const T* p0 = t0 < nh ? h + ((long long)b * nh + t0) * F4 * 4 : x + ((long long)b * Tx + (t0 - nh)) * F4 * 4;
-    const T* p1 = t1 < nh ? h + ((long long)b * nh + t1) * F4 * 4 : x + ((long long)b * Tx + (t1 - nh)) * F4 * 4;
-    load4<T>(p0 + f * 4, a);
-    load4<T>(p1 + f * 4, c);
+  const int r = blockIdx.y;                                // output frame (b, j - skip)
+  const int b = r / To;
+  const int j = r - b * To + skip;
+  // align_corners=False source coordinate, scale 1/2:  src = (j + 0.5) * 0.5 - 0.5, clamped at 0
+  float src = ((float)j + 0.5f) * 0.5f - 0.5f;
+  if (src < 0.f) src = 0.f;
+  const int t0 = (int)src;
+  const int t1 = t0 + (t0 < Ti - 1 ? 1 : 0);
+  const float l1 = src - (float)t0;
+  const float l0 = 1.0f - l1;
+  const T* p0 = t0 < nh ? h + ((long long)b * nh + t0) * F4 * 4 : x + ((long long)b * Tx + (t0 - nh)) * F4 * 4;
+  const T* p1 = t1 < nh ? h + ((long long)b * nh + t1) * F4 * 4 : x + ((long long)b * Tx + (t1 - nh)) * F4 * 4;
+  T* yo = y + (long long)r * F4 * 4;
+  for (long long f = ((long long)blockIdx.x * kBlock + threadIdx.x) * Q; f < F4; f += (long long)gridDim.x * kBlock * Q) {
 #pragma unroll
-    for (int e = 0; e < 4; ++e) o[e] = l0 * a[e] + l1 * c[e];
-    store4<T>(y + i * 4, o);
+    for (int q = 0; q < Q; ++q) {
+      if (f + q < F4) {
+        float a[4], c[4], o[4];
+        load4<T>(p0 + (f + q) * 4, a);
+        load4<T>(p1 + (f + q) * 4, c);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = l0 * a[e] + l1 * c[e];
+        store4<T>(yo + (f + q) * 4, o);
+      }
+    }
   }
 }
 
@@ -501,16 +509,18 @@ extern "C" int vt_time_lerp2x_cat(const void* head, int32_t nh, const void* x, v
   VT_CHECK_ARG(x && y && B > 0 && Tx > 0 && HWC > 0 && HWC % 4 == 0, "vt_time_lerp2x: bad dims");
   VT_CHECK_ARG(nh >= 0 && (nh == 0 || head != nullptr) && skip >= 0 && skip < 2 * (nh + Tx), "vt_time_lerp2x_cat: head frames %d, skip %d of %d", nh, skip, 2 * (nh + Tx));
   const long long F4 = HWC / 4;
-  const long long n = (long long)B * (2 * (nh + Tx) - skip) * F4;
+  const int To = 2 * (nh + Tx) - skip;
+  VT_CHECK_ARG((long long)B * To <= 65535, "vt_time_lerp2x: B * output frames = %lld > 65 535", (long long)B * To);
+  const long long per = (long long)kBlock * (dtype == VT_F32 ? 1 : 2);                  // quads a workgroup moves per sweep of a frame
+  long long gx = (F4 + per - 1) / per;
+  if (gx > 1024) gx = 1024;
+  const dim3 grid((unsigned)gx, (unsigned)(B * To));
   if (dtype == VT_F32)
-    hipLaunchKernelGGL(time_lerp2x_kernel<float>, dim3(grid_for(n)), dim3(kBlock), 0, stream, (const float*)head, nh, (const float*)x,
-                       (float*)y, B, Tx, skip, F4);
+    hipLaunchKernelGGL(time_lerp2x_kernel<float>, grid, dim3(kBlock), 0, stream, (const float*)head, nh, (const float*)x, (float*)y, B, Tx, skip, F4);
   else if (dtype == VT_BF16)
-    hipLaunchKernelGGL(time_lerp2x_kernel<bf16_t>, dim3(grid_for(n)), dim3(kBlock), 0, stream, (const bf16_t*)head, nh, (const bf16_t*)x,
-                       (bf16_t*)y, B, Tx, skip, F4);
+    hipLaunchKernelGGL(time_lerp2x_kernel<bf16_t>, grid, dim3(kBlock), 0, stream, (const bf16_t*)head, nh, (const bf16_t*)x, (bf16_t*)y, B, Tx, skip, F4);
   else if (dtype == VT_F16)
-    hipLaunchKernelGGL(time_lerp2x_kernel<f16_t>, dim3(grid_for(n)), dim3(kBlock), 0, stream, (const f16_t*)head, nh, (const f16_t*)x,
-                       (f16_t*)y, B, Tx, skip, F4);
+    hipLaunchKernelGGL(time_lerp2x_kernel<f16_t>, grid, dim3(kBlock), 0, stream, (const f16_t*)head, nh, (const f16_t*)x, (f16_t*)y, B, Tx, skip, F4);
   else
     VT_CHECK_ARG(false, "vt_time_lerp2x: dtype %d", dtype);
   VT_CHECK_LAUNCH();
