@@ -75,6 +75,11 @@ class DiagonalGaussianRegularizer(nn.Module):
             if self.noise_source == "host":
                 noise = self._host_noise(shape, z.device)
             else:
+                # device random numbers must never end up inside a captured launch sequence: the engine replays its graphs through
+                # vt_graph_launch, which does not refresh a device generator's philox offset -- every replay would reuse the same noise
+                if z.is_cuda and torch.cuda.is_current_stream_capturing():
+                    raise RuntimeError("DiagonalGaussianRegularizer(noise_source='device') inside a hipGraph capture: the replay path "
+                                       "(vt_graph_launch) does not advance the device generator; regularize outside the captured region")
                 noise = torch.randn(shape, device=z.device, dtype=torch.float32)
         zs, kl = ops.kl_sample(z.contiguous(), noise)
         return zs, {"kl_loss": kl}
