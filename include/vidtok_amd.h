@@ -117,7 +117,7 @@ int vt_conv_max_lds_bytes(void);
  *                       (alpha-mix + interleaved output frames + LayerNorm together in the bf16 LDS epilogue of the 8-wave tile) instead of
  *                       running as its own pass (- 0.2 ... 0.3 ms of the benchmark step); hosts ask vt_conv_plan whether a launch fuses it; 0 = the separate pass.
  *                       (Gates the Cout = 256 epilogue only: the Cout = 128 LayerNorm epilogue takes an alpha-mix / interleaved output under conv_fuse_ln alone.)
- *   conv_nt_mb (64)     16-bit outputs (y and the fused LayerNorm) of at least this many MiB are written by the LDS epilogues with streaming (nt)
+ *   conv_nt_mb (64)     outputs (y and the fused LayerNorm) of at least this many MiB are written by the LDS epilogues with streaming (nt)
  *                       stores: rows nobody reads before they have left every cache do not displace the weight slabs and halo rows the next tiles
  *                       read again (whole benchmark step - 0.7 %; the fused temporal block and conv3x3_ws2 always store this way); 0 = plain stores
  *   attn_flash (1)      the attention block as one vt_flash_attention launch where it applies; 0: GEMM -> softmax -> GEMM operators

@@ -1048,7 +1048,7 @@ def test_conv_interleaved_mix_with_layernorm(shape, silu, vt_opts):
     assert not isinstance(r, tuple)
 
 
-@pytest.mark.parametrize("dt", H16, ids=H16_IDS)
+@pytest.mark.parametrize("dt", list(H16) + [torch.float32], ids=list(H16_IDS) + ["f32"])
 @pytest.mark.parametrize("cout,tile", [(128, 0), (256, 256)], ids=["lds128_epilogue", "lds256_epilogue"])
 def test_conv_streaming_stores_same_bits(cout, tile, dt, vt_opts):
     """option conv_nt_mb: outputs at least that large leave the LDS epilogues as streaming (nt) stores -- a cache policy, not arithmetic:

@@ -72,7 +72,7 @@ struct ConvArgs {
   int tskip;                   // 1: zero-padded time taps in front of the clip are skipped per tile (tile inside one output frame, tmode ZERO; launch_variant)
   int ksplit;                  // split-K: blockIdx.z = tap plane, the walk covers that plane only; 1: planes = kt, 2: planes = kh (KT = 1)
   unsigned plane_bytes;        //      bytes of one tap plane in a weight row (KH * KW * Cin, or KW * Cin, elements)
-  int nt_store;                // 1: the LDS epilogues write y / LayerNorm(y) with streaming (nt) stores (16-bit outputs of at least kNtStoreBytes)
+  int nt_store;                // 1: the LDS epilogues write y / LayerNorm(y) with streaming (nt) stores (outputs of at least conv_nt_mb MiB)
   unsigned long long* prof;    // PROF instantiation only (vt_conv_profile): cycle stamps of workgroup 0
   int prof_mode;               // PROF instantiation of conv_ws2.hip only: option ws_prof_mode
 };
@@ -209,12 +209,17 @@ struct Oct<float> {
     hi = *reinterpret_cast<const f32x4*>(p + 4);
   }
   __device__ __forceinline__ float get(int e) const { return e < 4 ? lo[e] : hi[e - 4]; }
-  static __device__ __forceinline__ void store(float* p, const float (&v)[8], bool = false) {
+  static __device__ __forceinline__ void store(float* p, const float (&v)[8], bool nt = false) {
     f32x4 a, b;
 #pragma unroll
     for (int e = 0; e < 4; ++e) { a[e] = v[e]; b[e] = v[4 + e]; }
-    *reinterpret_cast<f32x4*>(p) = a;
-    *reinterpret_cast<f32x4*>(p + 4) = b;
+    if (nt) {
+      __builtin_nontemporal_store(a, reinterpret_cast<f32x4*>(p));
+      __builtin_nontemporal_store(b, reinterpret_cast<f32x4*>(p + 4));
+    } else {
+      *reinterpret_cast<f32x4*>(p) = a;
+      *reinterpret_cast<f32x4*>(p + 4) = b;
+    }
   }
 };
 template <typename H>

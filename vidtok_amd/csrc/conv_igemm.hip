@@ -168,8 +168,8 @@ int conv_prepare(const vt_conv_desc* d, ConvArgs& a, bool& ln_fused, int& nbatch
   a.res_mode = d->res_mode; a.res_tshift = d->res_tshift;
   a.Tr = d->res_mode != VT_RES_NONE ? d->Tr : d->To;
   a.ldr = d->ldr;
-  // streaming (nt) stores of the LDS epilogues' rows for 16-bit outputs far larger than the caches (option conv_nt_mb, MiB; 0 = never)
-  a.nt_store = (vt_opt(OPT_CONV_NT_MB) > 0 && vt_is_h16(d->out_dtype) && M * d->Cout * 2 >= ((long long)vt_opt(OPT_CONV_NT_MB) << 20)) ? 1 : 0;
+  // streaming (nt) stores of the LDS epilogues' rows for outputs far larger than the caches (option conv_nt_mb, MiB; 0 = never)
+  a.nt_store = (vt_opt(OPT_CONV_NT_MB) > 0 && M * d->Cout * (vt_is_h16(d->out_dtype) ? 2 : 4) >= ((long long)vt_opt(OPT_CONV_NT_MB) << 20)) ? 1 : 0;
   a.out_layout = d->out_layout; a.t_trim = d->t_trim;
   a.M = (int)M; a.ntaps = d->KT * d->KH * d->KW; a.K = a.ntaps * d->Cin;
   a.ys_mul = ys_mul; a.ys_oh = d->ys_oh; a.ys_ow = d->ys_ow;

@@ -23,7 +23,7 @@ enum VtOpt {
   OPT_CONV_TSKIP,          // 1: a tile whose leading time taps read only the zero frames in front of the clip (causal padding, tmode ZERO) starts its K walk behind them
   OPT_CONV_IN8,            // 1: conv_in8_kernel for the encoder's conv_in (bf16, 3 x 3 x 3, 8 stored input channels -> 128: halo patch by LDS-DMA, register-stationary weights); 0: the general path of the implicit-GEMM kernel (the same bits)
   OPT_CONV_TUP_LN,         // 1: the consumer's LayerNorm behind a v1.0 time up-sampler is emitted by its two parity launches (alpha-mix + interleaved frames + LayerNorm in the bf16 LDS epilogue of the 8-wave tile) instead of a separate pass
-  OPT_CONV_NT_MB,          // > 0: 16-bit outputs of at least this many MiB leave the LDS epilogues as streaming (nt) stores; 0 = plain stores everywhere
+  OPT_CONV_NT_MB,          // > 0: outputs of at least this many MiB leave the LDS epilogues as streaming (nt) stores; 0 = plain stores everywhere
   OPT_COUNT
 };
 
