@@ -201,6 +201,14 @@ __device__ __forceinline__ void store_quad<f16_t>(f16_t* p, const float (&v)[4])
 // 8 consecutive channels of one pixel row as stored (16 B bf16 / 32 B fp32)
 template <typename TOut>
 struct Oct;
+// A 16-byte streaming store.  Inline assembly on purpose: written as `if (nt) __builtin_nontemporal_store(..) else plain store` the two
+// stores to one address are merged by the optimiser into ONE plain store -- the hint vanishes (round 6: the first build of option
+// conv_nt_mb compiled to 688 global_store_dwordx4 and not one "nt"; measured, it did nothing).  The compiler's wait-count bookkeeping
+// does not see the store; nothing ever waits on it, and unseen stores can only make a counted wait for a later load stricter.
+__device__ __forceinline__ void store16_nt(void* p, const u32x4& v) {
+  asm volatile("global_store_dwordx4 %0, %1, off nt" ::"v"(p), "v"(v) : "memory");
+}
+
 template <>
 struct Oct<float> {
   f32x4 lo, hi;
@@ -214,8 +222,8 @@ struct Oct<float> {
 #pragma unroll
     for (int e = 0; e < 4; ++e) { a[e] = v[e]; b[e] = v[4 + e]; }
     if (nt) {
-      __builtin_nontemporal_store(a, reinterpret_cast<f32x4*>(p));
-      __builtin_nontemporal_store(b, reinterpret_cast<f32x4*>(p + 4));
+      store16_nt(p, __builtin_bit_cast(u32x4, a));
+      store16_nt(p + 4, __builtin_bit_cast(u32x4, b));
     } else {
       *reinterpret_cast<f32x4*>(p) = a;
       *reinterpret_cast<f32x4*>(p + 4) = b;
@@ -231,12 +239,12 @@ struct Oct16 {      // a 16-bit storage type: one 16-byte access
     return (e & 1) ? h16<H>::hi(t) : h16<H>::lo(t);
   }
   // nt: streaming store (the launcher sets ConvArgs::nt_store for outputs far larger than the caches: the rows do not displace the weights and
-  // halo rows the next tiles read again -- whole step 72.95 -> 72.43 ms, profiles/r06_nt_stores_ab.txt)
+  // halo rows the next tiles read again -- whole step + 0.6 ... 0.75 %, profiles/r06_nt_stores_ab.txt)
   static __device__ __forceinline__ void store(H* p, const float (&v)[8], bool nt = false) {
     u32x4 t;
 #pragma unroll
     for (int e = 0; e < 4; ++e) t[e] = h16<H>::pack(v[2 * e], v[2 * e + 1]);
-    if (nt) __builtin_nontemporal_store(t, reinterpret_cast<u32x4*>(p));
+    if (nt) store16_nt(p, t);
     else *reinterpret_cast<u32x4*>(p) = t;
   }
 };
