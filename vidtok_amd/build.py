@@ -49,6 +49,9 @@ def kernel_resources(obj):
 
 
 def check_no_spill(objdir):
+    if not all(os.path.exists(os.path.join(LLVM_BIN, t)) for t in ("llvm-objcopy", "clang-offload-bundler", "llvm-readelf")):
+        print("[vidtok_amd.build] spill check skipped: LLVM binutils not found under", LLVM_BIN, flush=True)
+        return
     bad = []
     for src, kern in NO_SPILL.items():
         obj = os.path.join(objdir, os.path.splitext(src)[0] + ".o")
